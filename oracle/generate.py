@@ -1,0 +1,157 @@
+"""Restatement of the generation loops the reference drives through transformers' GenerationMixin
+(TEST INFRASTRUCTURE; see oracle/__init__.py).  TF5:gen = transformers/generation/utils.py @ 5.15.0.
+
+The oracle always steps WITHOUT a KV cache through the full-sequence forward (under
+transformers 5.15 this is bit-identical to the 4.41-era cached `generate`).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import token_ops
+
+
+def prepare_decoder_input_ids(prompt_ids, batch_size, bos_token_id):
+    """TF5:gen:850-907: no prompt -> [[BOS]]; prompt whose rows ALL do not start with BOS -> BOS is prepended."""
+    start = torch.full((batch_size, 1), bos_token_id, dtype=torch.long)
+    if prompt_ids is None:
+        return start
+    prompt_ids = torch.as_tensor(prompt_ids, dtype=torch.long)
+    if bool((prompt_ids[:, 0] != bos_token_id).all()):
+        return torch.cat([start, prompt_ids], dim=-1)
+    return prompt_ids
+
+
+def step_inputs(kind, input_ids, special_token_ids, mask_token_id=None, bos_token_id=1):
+    """What prepare_inputs_for_generation hands to forward() when there is no cache.
+    kind 'single'/'multi': modelling_single.py:217-249;  'longitudinal': modelling_longitudinal.py:251-295."""
+    ids = input_ids
+    if kind == "longitudinal":
+        if bool(torch.all(ids[:, 0] == bos_token_id)):                       # :270-271
+            ids = ids[:, 1:]
+        mask = (ids != mask_token_id).int()                                  # :274
+        pos = torch.from_numpy(token_ops.position_ids_from_mask(mask.numpy()))
+        tt = torch.from_numpy(token_ops.token_ids_to_token_type_ids(ids.numpy(), special_token_ids, [0, 1, 0, 1]))
+        return ids, mask, tt, pos
+    tt = torch.from_numpy(token_ops.token_ids_to_token_type_ids(ids.numpy(), special_token_ids))
+    return ids, torch.ones_like(ids), tt, None
+
+
+def top_k_filter(scores, top_k):
+    """TopKLogitsWarper (TF5 logits_process.py): entries below the k-th largest become -inf (ties at the k-th kept)."""
+    top_k = min(top_k, scores.shape[-1])
+    kth = torch.topk(scores, top_k)[0][..., -1, None]
+    return scores.masked_fill(scores < kth, float("-inf"))
+
+
+def greedy(logits_fn, kind, batch_size, special_token_ids, bos_token_id, eos_token_id, pad_token_id, max_length,
+           prompt_ids=None, mask_token_id=None, max_new_tokens=None, forced_tokens=None, return_margins=False):
+    """TF5:gen:2783-2973 with do_sample=False. `logits_fn(ids, attn_mask, token_type_ids, position_ids) -> [B,T,V]`.
+    `forced_tokens` [B,steps] (optional) teacher-forces the continuation while still recording each step's argmax
+    and top-1/top-2 margin -- used for margin-gated parity of reduced-precision paths."""
+    ids = prepare_decoder_input_ids(prompt_ids, batch_size, bos_token_id)
+    if max_new_tokens is not None:
+        max_length = ids.shape[1] + max_new_tokens
+    unfinished = torch.ones(batch_size, dtype=torch.long)
+    argmaxes, margins = [], []
+    step = 0
+    while True:
+        fed, am, tt, pos = step_inputs(kind, ids, special_token_ids, mask_token_id, bos_token_id)
+        logits = logits_fn(fed, am, tt, pos)[:, -1].float()
+        nxt = torch.argmax(logits, dim=-1)
+        if return_margins:
+            top2 = torch.topk(logits, 2, dim=-1)[0]
+            margins.append((top2[:, 0] - top2[:, 1]).numpy())
+        argmaxes.append(nxt.numpy().copy())
+        if forced_tokens is not None:
+            nxt = torch.as_tensor(forced_tokens[:, step], dtype=torch.long)
+        if eos_token_id is not None:
+            nxt = nxt * unfinished + pad_token_id * (1 - unfinished)        # :2932-2933
+        ids = torch.cat([ids, nxt[:, None]], dim=-1)
+        if eos_token_id is not None:
+            unfinished = unfinished & (nxt != eos_token_id).long()
+        step += 1
+        if ids.shape[1] >= max_length or unfinished.max() == 0:
+            break
+        if forced_tokens is not None and step >= forced_tokens.shape[1]:
+            break
+    if return_margins:
+        return ids, np.stack(argmaxes, 1), np.stack(margins, 1)
+    return ids
+
+
+def beam_search(logits_fn, kind, batch_size, num_beams, special_token_ids, bos_token_id, eos_token_id, pad_token_id,
+                max_length, prompt_ids=None, mask_token_id=None, length_penalty=1.0):
+    """TF5:gen:3208-3560 with do_sample=False, early_stopping=False, num_return_sequences=1, one EOS id."""
+    ids = prepare_decoder_input_ids(prompt_ids, batch_size, bos_token_id)
+    ids = ids.repeat_interleave(num_beams, dim=0)                              # _expand_inputs_for_generation
+    cur_len = prompt_len = ids.shape[1]
+    keep = 2 * num_beams
+    top_mask = torch.cat([torch.ones(num_beams, dtype=torch.bool), torch.zeros(keep - num_beams, dtype=torch.bool)])
+    running = torch.full((batch_size, num_beams, max_length), pad_token_id, dtype=torch.long)
+    running[:, :, :cur_len] = ids.view(batch_size, num_beams, cur_len)
+    sequences = running.clone()
+    running_scores = torch.zeros(batch_size, num_beams)
+    running_scores[:, 1:] = -1e9
+    beam_scores = torch.full((batch_size, num_beams), -1e9)
+    finished = torch.zeros(batch_size, num_beams, dtype=torch.bool)
+    unsat = torch.ones(batch_size, 1, dtype=torch.bool)
+
+    def gather(t, idx):
+        while idx.dim() < t.dim():
+            idx = idx.unsqueeze(-1)
+        return torch.gather(t, 1, idx.expand(-1, -1, *t.shape[2:]))
+
+    while True:
+        flat = running[:, :, :cur_len].reshape(batch_size * num_beams, cur_len)
+        fed, am, tt, pos = step_inputs(kind, flat, special_token_ids, mask_token_id, bos_token_id)
+        logits = logits_fn(fed, am, tt, pos)[:, -1].float()
+        vocab = logits.shape[-1]
+        logp = F.log_softmax(logits, dim=-1).view(batch_size, num_beams, vocab) + running_scores[:, :, None]
+        topk_lp, topk_idx = torch.topk(logp.view(batch_size, num_beams * vocab), k=keep)
+        beam_of = topk_idx // vocab
+        topk_seq = gather(running, beam_of)
+        topk_seq[:, :, cur_len] = topk_idx % vocab
+        hits = (topk_seq[:, :, cur_len] == eos_token_id) | torch.tensor(cur_len + 1 >= max_length)
+        # next running beams (:3144-3162)
+        run_lp = topk_lp + hits.float() * -1.0e9
+        nxt = torch.topk(run_lp, k=num_beams)[1]
+        running, running_scores = gather(topk_seq, nxt), gather(run_lp, nxt)
+        # finished beams (:3164-3204)
+        just = hits & top_mask[None, :]
+        fin_lp = topk_lp / ((cur_len + 1 - prompt_len) ** length_penalty)
+        fin_lp = fin_lp + (~unsat).float() * -1.0e9
+        fin_lp = fin_lp + (~just).float() * -1.0e9
+        m_seq = torch.cat((sequences, topk_seq), dim=1)
+        m_sc = torch.cat((beam_scores, fin_lp), dim=1)
+        m_fin = torch.cat((finished, just), dim=1)
+        best = torch.topk(m_sc, k=num_beams)[1]
+        sequences, beam_scores, finished = gather(m_seq, best), gather(m_sc, best), gather(m_fin, best)
+        cur_len += 1
+        # early-stop heuristic (:3008-3052) with early_stopping=False
+        best_run = running_scores[:, :1] / ((cur_len - prompt_len) ** length_penalty)
+        worst_fin = torch.where(finished, beam_scores.min(dim=1, keepdim=True)[0], torch.tensor(-1.0e9))
+        unsat = unsat & torch.any(best_run > worst_fin, dim=-1, keepdim=True)
+        if not (bool(unsat.any()) and not bool(hits.all())):
+            break
+    out = sequences[:, 0, :]
+    # trim to the longest generated hypothesis, as HF does through beam_indices (:3515-3519)
+    lens = torch.full((batch_size,), prompt_len, dtype=torch.long)
+    for b in range(batch_size):
+        row = out[b, prompt_len:]
+        eos = (row == eos_token_id).nonzero()
+        lens[b] = prompt_len + (int(eos[0]) + 1 if len(eos) else row.shape[0])
+    return out[:, : int(lens.max())], beam_scores[:, 0]
+
+
+def reinforce_loss(logits, sampled_token_ids, reward, pad_token_id):
+    """reference modules/lightning_modules/longitudinal/scst/gt_prompt.py:211-246. logits [B,V,T] (processed scores)."""
+    loss = F.nll_loss(F.log_softmax(logits, dim=1), sampled_token_ids, ignore_index=pad_token_id, reduction="none")
+    return (loss.sum(dim=-1) * reward).mean()
+
+
+def tf_cross_entropy(logits, label_ids, pad_token_id):
+    """reference modules/lightning_modules/single.py:467-469."""
+    return F.cross_entropy(logits.permute(0, 2, 1), label_ids, ignore_index=pad_token_id)

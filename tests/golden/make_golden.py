@@ -1,0 +1,520 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING THE REFERENCE (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Reads /root/reference (never written to, never copied): the reference's own model classes are instantiated with
+random-init weights produced by cxrmate_amd.weights.init_* (seeded, CPU) and executed in fp32 on CPU.
+Harness pieces that are NOT reference code (documented in SURVEY.md appendix A):
+  * a ~40-line stand-in for the `peft` package (not installed) so modelling_longitudinal.py can be imported,
+  * the two-function adapter that restores transformers-4.41 generate semantics under transformers 5.15.0.
+Outputs are inputs + expected outputs only (npz/json); no reference text is stored.
+"""
+import json
+import os
+import re
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+warnings.filterwarnings("ignore")
+os.environ.setdefault("TRANSFORMERS_OFFLINE", "1")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# ------------------------------------------------------------------------------------------------ peft stand-in
+def install_peft_stub():
+    peft = types.ModuleType("peft")
+
+    class LoraConfig:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    class TaskType:
+        pass
+
+    class LoraLinear(torch.nn.Module):
+        def __init__(self, base, r, alpha, p):
+            super().__init__()
+            self.base_layer = base
+            self.lora_A = torch.nn.ModuleDict({"default": torch.nn.Linear(base.in_features, r, bias=False)})
+            self.lora_B = torch.nn.ModuleDict({"default": torch.nn.Linear(r, base.out_features, bias=False)})
+            self.lora_dropout = torch.nn.ModuleDict({"default": torch.nn.Dropout(p)})
+            torch.nn.init.zeros_(self.lora_B["default"].weight)
+            self.scaling = alpha / r
+
+        def forward(self, x):
+            return self.base_layer(x) + self.lora_B["default"](self.lora_A["default"](self.lora_dropout["default"](x))) * self.scaling
+
+    class _Base(torch.nn.Module):
+        def __init__(self, model):
+            super().__init__()
+            self.model = model
+
+        def forward(self, *a, **k):
+            return self.model(*a, **k)
+
+    class PeftModel(torch.nn.Module):
+        def __init__(self, model, cfg):
+            super().__init__()
+            for p in model.parameters():
+                p.requires_grad = False
+            for name, mod in list(model.named_modules()):
+                if isinstance(mod, torch.nn.Linear) and re.fullmatch(cfg.target_modules, name):
+                    parent = model.get_submodule(name.rsplit(".", 1)[0])
+                    setattr(parent, name.rsplit(".", 1)[1], LoraLinear(mod, cfg.r, cfg.lora_alpha, cfg.lora_dropout))
+            self.base_model = _Base(model)
+
+        def forward(self, *a, **k):
+            return self.base_model(*a, **k)
+
+        def __getattr__(self, name):
+            try:
+                return super().__getattr__(name)
+            except AttributeError:
+                return getattr(self.base_model.model, name)
+
+        def print_trainable_parameters(self):
+            t = sum(p.numel() for p in self.parameters() if p.requires_grad)
+            a = sum(p.numel() for p in self.parameters())
+            print(f"trainable params: {t} || all params: {a}")
+
+    peft.LoraConfig, peft.TaskType = LoraConfig, TaskType
+    peft.get_peft_config = lambda *a, **k: None
+    peft.get_peft_model = lambda model, cfg: PeftModel(model, cfg)
+    sys.modules["peft"] = peft
+
+
+install_peft_stub()
+import transformers  # noqa: E402
+from modules.transformers.single_model.modelling_single import (  # noqa: E402
+    CvtWithProjectionHeadConfig, SingleCXREncoderDecoderModel)
+from modules.transformers.multi_model.modelling_multi import MultiCXREncoderDecoderModel  # noqa: E402
+from modules.transformers.longitudinal_model.modelling_longitudinal import (  # noqa: E402
+    LongitudinalPromptMultiCXREncoderDecoderModel)
+
+from cxrmate_amd import weights  # noqa: E402
+from cxrmate_amd.config import tiny_config, BertConfig as MyBertConfig  # noqa: E402
+
+BOS, EOS, SEP, PAD, PMT, PMT_SEP, NPF, NPI = 1, 2, 3, 4, 8, 9, 10, 11
+
+
+# ------------------------------------------------------------------------------------------------ generate adapter
+def install_generate_adapter(model, ref_cls, longitudinal):
+    dec = model.decoder.base_model.model if longitudinal else model.decoder
+
+    def legacy(input_ids, past_key_values=None, attention_mask=None, use_cache=True, **kw):
+        if attention_mask is None:
+            attention_mask = input_ids.new_ones(input_ids.shape)
+        if past_key_values is not None:
+            n = past_key_values.get_seq_length()
+            input_ids = input_ids[:, (n if input_ids.shape[1] > n else input_ids.shape[1] - 1):]
+        return dict(input_ids=input_ids, attention_mask=attention_mask, past_key_values=past_key_values, use_cache=use_cache)
+
+    dec.prepare_inputs_for_generation = legacy
+    if longitudinal:
+        def adapted(self, input_ids, special_token_ids, mask_token_id, past_key_values=None, attention_mask=None,
+                    use_cache=None, encoder_outputs=None, **kw):
+            empty = past_key_values is not None and past_key_values.get_seq_length() == 0
+            out = ref_cls.prepare_inputs_for_generation(self, input_ids, special_token_ids, mask_token_id,
+                                                        past_key_values=None if empty else past_key_values,
+                                                        attention_mask=attention_mask, use_cache=use_cache,
+                                                        encoder_outputs=encoder_outputs, **kw)
+            if empty:
+                out["past_key_values"] = past_key_values
+            return out
+    else:
+        def adapted(self, input_ids, special_token_ids, past_key_values=None, attention_mask=None, use_cache=None,
+                    encoder_outputs=None, **kw):
+            empty = past_key_values is not None and past_key_values.get_seq_length() == 0
+            out = ref_cls.prepare_inputs_for_generation(self, input_ids, special_token_ids,
+                                                        past_key_values=None if empty else past_key_values,
+                                                        attention_mask=attention_mask, use_cache=use_cache,
+                                                        encoder_outputs=encoder_outputs, **kw)
+            if empty:
+                out["past_key_values"] = past_key_values
+            return out
+    model.prepare_inputs_for_generation = types.MethodType(adapted, model)
+
+
+def build(ref_cls, cfg, seed, perturb, longitudinal=False):
+    dec = transformers.BertConfig(vocab_size=cfg.decoder.vocab_size, num_hidden_layers=cfg.decoder.num_hidden_layers,
+                                  type_vocab_size=2)
+    dec.is_decoder = True
+    dec.add_cross_attention = True
+    enc = CvtWithProjectionHeadConfig(projection_size=dec.hidden_size, depth=list(cfg.encoder.depth))
+    hf = transformers.VisionEncoderDecoderConfig.from_encoder_decoder_configs(enc, dec)
+    model = ref_cls(config=hf)
+    sd = weights.init_encoder_decoder(cfg, seed=seed, perturb=perturb)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("lora_dropout" in m or "position_ids" in m or "token_type_ids" in m for m in missing), missing
+    model.eval()
+    install_generate_adapter(model, ref_cls, longitudinal)
+    return model, sd
+
+
+def sample(t, n=4096):
+    """Deterministic strided subsample so fixtures stay small."""
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].to(torch.float32).numpy()
+
+
+def stats(t):
+    t = t.detach().float()
+    return np.array([t.mean().item(), t.std().item(), t.abs().max().item(), t.norm().item()], dtype=np.float64)
+
+
+# ------------------------------------------------------------------------------------------------ fixtures
+def fixture_encoder():
+    cfg = tiny_config(vocab_size=1000, decoder_layers=1, depth=(1, 2, 3), image_size=384)
+    model, _ = build(MultiCXREncoderDecoderModel, cfg, seed=11, perturb=0.05)
+    g = torch.Generator().manual_seed(101)
+    x = torch.randn(2, 2, 3, 384, 384, generator=g)
+    x[1, 1] = 0.0                                    # ragged study: zero-padded image (quirk Q3)
+    with torch.no_grad():
+        cvt_out = model.encoder.cvt(x.view(-1, 3, 384, 384), output_hidden_states=True, return_dict=True)
+        out = model.encoder(x)
+    d = {"seed": 11, "perturb": 0.05, "pixel_seed": 101, "depth": np.array(cfg.encoder.depth)}
+    for i, h in enumerate(cvt_out.hidden_states):
+        d[f"stage{i}_sample"] = sample(h)
+        d[f"stage{i}_stats"] = stats(h)
+        d[f"stage{i}_shape"] = np.array(h.shape)
+    d["last_hidden_state_sample"] = sample(out.last_hidden_state, 16384)
+    d["last_hidden_state_stats"] = stats(out.last_hidden_state)
+    d["last_hidden_state_shape"] = np.array(out.last_hidden_state.shape)
+    d["attention_mask"] = out.attention_mask.numpy()
+    np.savez_compressed(os.path.join(OUT, "encoder_multi.npz"), **d)
+    print("encoder_multi", d["last_hidden_state_stats"])
+
+
+def rand_report_ids(g, b, t, vocab, sep_at, lengths):
+    ids = torch.randint(12, vocab, (b, t), generator=g)
+    ids[:, 0] = BOS
+    for r in range(b):
+        ids[r, sep_at[r]] = SEP
+        ids[r, lengths[r] - 1] = EOS
+        ids[r, lengths[r]:] = PAD
+    return ids
+
+
+def fixture_tf_single():
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, depth=(1, 2, 3), image_size=96)
+    model, _ = build(SingleCXREncoderDecoderModel, cfg, seed=12, perturb=0.05)
+    g = torch.Generator().manual_seed(102)
+    x = torch.randn(3, 3, 96, 96, generator=g)
+    full = rand_report_ids(g, 3, 25, 1000, [7, 11, 5], [25, 18, 12])
+    attn = (full != PAD).long()
+    inp, lab, am = full[:, :-1], full[:, 1:].clone(), attn[:, 1:]
+    tt = model.token_ids_to_token_type_ids(inp, [SEP])
+    for p in model.parameters():
+        p.requires_grad_(True)
+    out = model(pixel_values=x, decoder_input_ids=inp, decoder_attention_mask=am, decoder_token_type_ids=tt, return_dict=True)
+    loss = torch.nn.functional.cross_entropy(out.logits.permute(0, 2, 1), lab, ignore_index=PAD)
+    loss.backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    pick = ["decoder.bert.embeddings.word_embeddings.weight", "decoder.bert.encoder.layer.1.crossattention.self.key.weight",
+            "decoder.bert.encoder.layer.0.attention.self.query.weight", "decoder.bert.encoder.layer.0.output.LayerNorm.weight",
+            "decoder.cls.predictions.transform.dense.bias", "decoder.cls.predictions.bias",
+            "decoder.bert.embeddings.position_embeddings.weight",
+            "encoder.projection_head.projection.weight", "encoder.projection_head.layer_norm.bias",
+            "encoder.cvt.encoder.stages.2.layers.2.output.dense.weight", "encoder.cvt.encoder.stages.2.cls_token",
+            "encoder.cvt.encoder.stages.2.layers.0.attention.attention.convolution_projection_key.convolution_projection.convolution.weight",
+            "encoder.cvt.encoder.stages.2.layers.0.attention.attention.convolution_projection_query.convolution_projection.normalization.weight",
+            "encoder.cvt.encoder.stages.1.layers.0.attention.attention.projection_value.weight",
+            "encoder.cvt.encoder.stages.1.embedding.convolution_embeddings.projection.weight",
+            "encoder.cvt.encoder.stages.0.layers.0.intermediate.dense.weight",
+            "encoder.cvt.encoder.stages.0.layers.0.layernorm_before.weight",
+            "encoder.cvt.encoder.stages.0.embedding.convolution_embeddings.projection.weight",
+            "encoder.cvt.encoder.stages.0.embedding.convolution_embeddings.normalization.bias"]
+    d = {"seed": 12, "perturb": 0.05, "pixel_seed": 102, "full_ids": full.numpy(), "token_type_ids": tt.numpy(),
+         "logits_sample": sample(out.logits, 16384), "logits_stats": stats(out.logits), "loss": np.array(loss.item()),
+         "logits_argmax": out.logits.argmax(-1).numpy(), "grad_names": np.array(pick)}
+    top2 = torch.topk(out.logits.detach(), 2, dim=-1)[0]
+    d["logits_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
+    for i, n in enumerate(pick):
+        d[f"grad{i}_sample"] = sample(grads[n], 2048)
+        d[f"grad{i}_stats"] = stats(grads[n])
+    d["grad_total_norm"] = np.array(torch.sqrt(sum((v.double() ** 2).sum() for v in grads.values())).item())
+    np.savez_compressed(os.path.join(OUT, "tf_single.npz"), **d)
+    print("tf_single loss", loss.item(), "gradnorm", d["grad_total_norm"])
+
+
+def make_prompt(g, b, vocab, lens):
+    t = max(lens)
+    ids = torch.full((b, t), PAD, dtype=torch.long)
+    for r in range(b):
+        n = lens[r]
+        if n == 5:
+            ids[r, :5] = torch.tensor([PMT, NPF, PMT_SEP, NPI, BOS])
+        else:
+            body = torch.randint(12, vocab, (n,), generator=g)
+            body[0], body[n // 2], body[n - 1] = PMT, PMT_SEP, BOS
+            ids[r, :n] = body
+    return ids
+
+
+def fixture_tf_longitudinal():
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, depth=(1, 2, 3), image_size=96, lora_r=8)
+    model, _ = build(LongitudinalPromptMultiCXREncoderDecoderModel, cfg, seed=13, perturb=0.05, longitudinal=True)
+    g = torch.Generator().manual_seed(103)
+    x = torch.randn(2, 2, 3, 96, 96, generator=g)
+    x[0, 1] = 0.0
+    prompt = make_prompt(g, 2, 1000, [9, 5])
+    full = rand_report_ids(g, 2, 14, 1000, [4, 6], [14, 10])
+    rep_attn = (full != PAD).long()
+    inp = torch.cat([prompt, full[:, :-1]], dim=1)
+    am = torch.cat([(prompt != PAD).long(), rep_attn[:, 1:]], dim=1)
+    lab = full[:, 1:].clone()
+    pos = torch.nn.functional.relu(torch.cumsum(am, dim=1) - 1)
+    tt = model.token_ids_to_token_type_ids(inp, [PMT_SEP, BOS, SEP], [0, 1, 0, 1])
+    for p in model.decoder.parameters():
+        p.requires_grad_(True)                              # SCST unfreezes the whole decoder (scst/gt_prompt.py:38-40)
+    out = model(pixel_values=x, decoder_input_ids=inp, decoder_attention_mask=am, decoder_token_type_ids=tt,
+                decoder_position_ids=pos, return_dict=True)
+    logits = out.logits[:, prompt.shape[1]:]
+    loss = torch.nn.functional.cross_entropy(logits.permute(0, 2, 1), lab, ignore_index=PAD)
+    loss.backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    pick = ["decoder.base_model.model.bert.encoder.layer.0.attention.self.query.lora_A.default.weight",
+            "decoder.base_model.model.bert.encoder.layer.1.attention.self.key.lora_B.default.weight",
+            "decoder.base_model.model.bert.encoder.layer.0.attention.self.query.base_layer.weight",
+            "decoder.base_model.model.bert.encoder.layer.1.attention.self.value.weight",
+            "decoder.base_model.model.bert.embeddings.token_type_embeddings.weight"]
+    d = {"seed": 13, "perturb": 0.05, "pixel_seed": 103, "prompt_ids": prompt.numpy(), "full_ids": full.numpy(),
+         "token_type_ids": tt.numpy(), "position_ids": pos.numpy(), "attention_mask": am.numpy(),
+         "logits_sample": sample(out.logits, 16384), "logits_stats": stats(out.logits), "loss": np.array(loss.item()),
+         "enc_mask": model.encoder(x).attention_mask.numpy(), "grad_names": np.array(pick)}
+    for i, n in enumerate(pick):
+        d[f"grad{i}_sample"] = sample(grads[n], 2048)
+        d[f"grad{i}_stats"] = stats(grads[n])
+    np.savez_compressed(os.path.join(OUT, "tf_longitudinal.npz"), **d)
+    print("tf_longitudinal loss", loss.item())
+
+
+def nocache_greedy(model, kind, x_or_eo, steps, prompt=None, special=None, forced=None):
+    """Argmax loop through the reference's own forward()/helpers without a cache."""
+    eo = x_or_eo
+    b = eo.last_hidden_state.shape[0]
+    ids = torch.full((b, 1), BOS) if prompt is None else prompt.clone()
+    unfinished = torch.ones(b, dtype=torch.long)
+    margins, argm = [], []
+    for s in range(steps):
+        kw = {}
+        if kind == "longitudinal":
+            am = (ids != PAD).int()
+            kw = dict(decoder_attention_mask=am, decoder_position_ids=torch.nn.functional.relu(torch.cumsum(am, 1) - 1),
+                      decoder_token_type_ids=model.token_ids_to_token_type_ids(ids, special, [0, 1, 0, 1]))
+        else:
+            kw = dict(decoder_token_type_ids=model.token_ids_to_token_type_ids(ids, special))
+        with torch.no_grad():
+            lg = model(encoder_outputs=eo, decoder_input_ids=ids, use_cache=False, return_dict=True, **kw).logits[:, -1]
+        t2 = torch.topk(lg, 2, dim=-1)[0]
+        margins.append((t2[:, 0] - t2[:, 1]).numpy())
+        nxt = lg.argmax(-1)
+        argm.append(nxt.numpy().copy())
+        if forced is not None:
+            nxt = forced[:, s]
+        nxt = nxt * unfinished + PAD * (1 - unfinished)
+        ids = torch.cat([ids, nxt[:, None]], 1)
+        unfinished = unfinished & (nxt != EOS).long()
+        if unfinished.max() == 0:
+            break
+    return ids, np.stack(argm, 1), np.stack(margins, 1)
+
+
+def fixture_generate():
+    # ---- multi model: greedy (cache vs no-cache must agree) and beam-4
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, depth=(1, 2, 3), image_size=96)
+    model, _ = build(MultiCXREncoderDecoderModel, cfg, seed=14, perturb=0.05)
+    g = torch.Generator().manual_seed(104)
+    x = torch.randn(3, 2, 3, 96, 96, generator=g)
+    x[1, 1] = 0.0
+    with torch.no_grad():
+        eo = model.encoder(x)
+        steps = 20
+        seq_nc, argm, margins = nocache_greedy(model, "multi", eo, steps, special=[SEP])
+        seq_gen = model.generate(pixel_values=x, special_token_ids=[SEP], max_length=steps + 1, bos_token_id=BOS,
+                                 eos_token_id=EOS, pad_token_id=PAD, num_beams=1, return_dict_in_generate=True,
+                                 use_cache=True, do_sample=False)["sequences"]
+        assert torch.equal(seq_nc, seq_gen), (seq_nc, seq_gen)
+        beam = model.generate(pixel_values=x, special_token_ids=[SEP], max_length=steps + 1, bos_token_id=BOS,
+                              eos_token_id=EOS, pad_token_id=PAD, num_beams=4, return_dict_in_generate=True,
+                              use_cache=True, do_sample=False, output_scores=True)
+        # force an early EOS for one row by biasing the EOS logit, to exercise EOS->PAD fill + beam finalisation
+        eos_bias = 0.0
+        while True:
+            eos_bias += 0.02
+            model.decoder.cls.predictions.bias.data[EOS] += 0.02
+            seq_eos = model.generate(pixel_values=x, special_token_ids=[SEP], max_length=steps + 1, bos_token_id=BOS,
+                                     eos_token_id=EOS, pad_token_id=PAD, num_beams=1, return_dict_in_generate=True,
+                                     use_cache=True, do_sample=False)["sequences"]
+            first = torch.where((seq_eos == EOS).any(1), (seq_eos == EOS).int().argmax(1), torch.tensor(-1))
+            if (first >= 0).any() and len(set(first.tolist())) > 1:
+                break
+            assert eos_bias < 20, "no ragged EOS found"
+        beam_eos = model.generate(pixel_values=x, special_token_ids=[SEP], max_length=steps + 1, bos_token_id=BOS,
+                                  eos_token_id=EOS, pad_token_id=PAD, num_beams=4, return_dict_in_generate=True,
+                                  use_cache=True, do_sample=False, output_scores=True)
+    np.savez_compressed(os.path.join(OUT, "generate_multi.npz"), seed=14, perturb=0.05, pixel_seed=104,
+                        greedy=seq_gen.numpy(), greedy_argmax=argm, greedy_margin=margins,
+                        beam4=beam["sequences"].numpy(), beam4_scores=beam["sequences_scores"].numpy(),
+                        eos_bias=eos_bias, greedy_eos=seq_eos.numpy(), beam4_eos=beam_eos["sequences"].numpy(),
+                        beam4_eos_scores=beam_eos["sequences_scores"].numpy())
+    print("generate_multi greedy", seq_gen[0, :8].tolist(), "min margin", margins.min(), "eos", seq_eos.tolist())
+
+    # ---- longitudinal: prompted greedy (ragged prompts with interior PADs) + top-k sampling scores + REINFORCE
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, depth=(1, 2, 3), image_size=96, lora_r=8)
+    model, _ = build(LongitudinalPromptMultiCXREncoderDecoderModel, cfg, seed=15, perturb=0.05, longitudinal=True)
+    g = torch.Generator().manual_seed(105)
+    x = torch.randn(2, 2, 3, 96, 96, generator=g)
+    x[0, 1] = 0.0
+    prompt = make_prompt(g, 2, 1000, [8, 5])
+    new = 12
+    with torch.no_grad():
+        eo = model.encoder(x)
+        seq_nc, argm, margins = nocache_greedy(model, "longitudinal", eo, new, prompt=prompt, special=[PMT_SEP, BOS, SEP])
+        base = model.generate(encoder_outputs=eo, decoder_input_ids=prompt, special_token_ids=[PMT_SEP, BOS, SEP],
+                              max_length=new + 1 + prompt.shape[1], bos_token_id=BOS, eos_token_id=EOS, pad_token_id=PAD,
+                              mask_token_id=PAD, num_beams=1, return_dict_in_generate=True, use_cache=True,
+                              do_sample=False)["sequences"]
+        assert torch.all(base[:, 0] == BOS)
+        assert torch.equal(base[:, 1:], seq_nc), (base, seq_nc)
+        # sampling path of SCST (scst/gt_prompt.py:162-180): special_token_ids=[bos, sep] (quirk Q5)
+        torch.manual_seed(7)
+        smp = model.generate(input_ids=prompt, special_token_ids=[BOS, SEP], encoder_outputs=eo, bos_token_id=BOS,
+                             eos_token_id=EOS, pad_token_id=PAD, mask_token_id=PAD, return_dict_in_generate=True,
+                             do_sample=True, num_beams=1, use_cache=True, output_scores=True, top_p=1.0, top_k=50,
+                             temperature=1.0, max_new_tokens=new)
+        seqs = smp["sequences"]
+        if torch.all(seqs[:, 0] == BOS):
+            seqs = seqs[:, 1:]
+        scores = torch.stack(smp["scores"], dim=-1)                       # [B, V, T]
+        sampled = seqs[:, prompt.shape[1]:]
+        reward = torch.tensor([0.37, -0.21])
+        nll = torch.nn.functional.nll_loss(torch.log_softmax(scores, dim=1), sampled, ignore_index=PAD, reduction="none")
+        loss = (nll.sum(-1) * reward).mean()
+        finite = torch.isfinite(scores)
+    np.savez_compressed(os.path.join(OUT, "generate_longitudinal.npz"), seed=15, perturb=0.05, pixel_seed=105,
+                        prompt_ids=prompt.numpy(), greedy=seq_nc.numpy(), greedy_argmax=argm, greedy_margin=margins,
+                        sampled_sequences=seqs.numpy(), scores_finite_count=finite.sum(1).numpy(),
+                        scores_finite_mask=np.packbits(finite.numpy(), axis=1), scores_shape=np.array(scores.shape),
+                        scores_at_sampled=torch.gather(scores, 1, sampled[:, None, :])[:, 0].numpy(),
+                        nll=nll.numpy(), reward=reward.numpy(), reinforce_loss=np.array(loss.item()))
+    print("generate_longitudinal greedy", seq_nc.tolist(), "loss", loss.item())
+
+
+def fixture_token_ops():
+    """Integer known answers straight from the reference helper functions."""
+    cfg = tiny_config(vocab_size=64, decoder_layers=1, depth=(1, 2, 3), image_size=96)
+    model, _ = build(SingleCXREncoderDecoderModel, cfg, seed=1, perturb=0.0)
+    cfgl = tiny_config(vocab_size=64, decoder_layers=1, depth=(1, 2, 3), image_size=96, lora_r=8)
+    modell, _ = build(LongitudinalPromptMultiCXREncoderDecoderModel, cfgl, seed=1, perturb=0.0, longitudinal=True)
+    g = torch.Generator().manual_seed(106)
+    cases = []
+    for n in range(60):
+        b, t = int(torch.randint(1, 5, (1,), generator=g)), int(torch.randint(2, 18, (1,), generator=g))
+        ids = torch.randint(0, 12, (b, t), generator=g)          # dense in special ids -> many boundary cases
+        for special, sections in (([SEP], None), ([PMT_SEP, BOS, SEP], [0, 1, 0, 1]), ([BOS, SEP], [0, 1, 0, 1])):
+            mdl = model if sections is None else modell
+            tt = mdl.token_ids_to_token_type_ids(ids, special, sections)
+            ttp = mdl.token_ids_to_token_type_ids_past(ids, special, sections)
+            cases.append({"ids": ids.tolist(), "special": special, "sections": sections,
+                          "token_type_ids": tt.tolist(), "token_type_ids_past": ttp.tolist()})
+    # documented known answers
+    doc = []
+    for ids, special, sections in (([[1, 50, 51, 3, 60, 61, 2]], [3], None), ([[1, 50, 51, 60, 61, 2, 3]], [3], None),
+                                   ([[8, 50, 9, 60, 1, 70, 71, 3, 80, 2, 4]], [9, 1, 3], [0, 1, 0, 1]),
+                                   ([[8, 50, 9, 60, 1, 70, 71, 3, 80, 2, 4]], [1, 3], [0, 1, 0, 1])):
+        t = torch.tensor(ids)
+        mdl = model if sections is None else modell
+        doc.append({"ids": ids, "special": special, "sections": sections,
+                    "token_type_ids": mdl.token_ids_to_token_type_ids(t, special, sections).tolist(),
+                    "token_type_ids_past": mdl.token_ids_to_token_type_ids_past(t, special, sections).tolist()})
+
+    # tokenizer-dependent helpers on a synthetic byte-level BPE tokenizer with the reference id layout
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, trainers
+    tok = Tokenizer(models.BPE(unk_token="[UNK]"))
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tok.decoder = decoders.ByteLevel()
+    specials = ["[UNK]", "[BOS]", "[EOS]", "[SEP]", "[PAD]", "[MASK]", "[RSV6]", "[RSV7]", "[PMT]", "[PMT-SEP]", "[NPF]", "[NPI]"]
+    corpus = ["The lungs are clear.", "No acute cardiopulmonary process.", "Heart size is normal.",
+              "There is no pleural effusion or pneumothorax.", "Mild cardiomegaly is stable.", "Normal.",
+              "Interval improvement of the right lower lobe opacity.", "No focal consolidation is seen."] * 20
+    tok.train_from_iterator(corpus, trainers.BpeTrainer(vocab_size=400, special_tokens=specials,
+                                                        initial_alphabet=pre_tokenizers.ByteLevel.alphabet()))
+    tok.save(os.path.join(OUT, "tokenizer.json"))
+    fast = transformers.PreTrainedTokenizerFast(tokenizer_file=os.path.join(OUT, "tokenizer.json"), unk_token="[UNK]",
+                                                pad_token="[PAD]", bos_token="[BOS]", cls_token="[BOS]", sep_token="[SEP]",
+                                                eos_token="[EOS]", mask_token="[MASK]",
+                                                extra_special_tokens=["[PMT]", "[PMT-SEP]", "[NPF]", "[NPI]"])
+    assert [fast.bos_token_id, fast.eos_token_id, fast.sep_token_id, fast.pad_token_id] == [BOS, EOS, SEP, PAD]
+    findings = ["The lungs are clear. Heart size is normal.", "No focal consolidation is seen.", "Mild cardiomegaly is stable."]
+    impression = ["No acute cardiopulmonary process.", "Normal.", "Interval improvement of the right lower lobe opacity."]
+    helper = []
+    for max_len in (64, 12, 6):
+        tf = modell.tokenize_report_teacher_forcing(findings, impression, fast, max_len)
+        helper.append({"fn": "tokenize_report_teacher_forcing", "max_len": max_len,
+                       **{k: v.tolist() for k, v in tf.items()}})
+    prev_f = [None, "The lungs are clear.", "There is no pleural effusion or pneumothorax."]
+    prev_i = [None, "No acute cardiopulmonary process.", None]
+    for max_len in (32, 8):
+        for add_bos in (True, False):
+            pr = modell.tokenize_prompt(prev_f, prev_i, fast, max_len, add_bos_token_id=add_bos)
+            helper.append({"fn": "tokenize_prompt", "max_len": max_len, "add_bos_token_id": add_bos,
+                           "input_ids": pr["input_ids"].tolist(), "attention_mask": pr["attention_mask"].tolist()})
+    enc = lambda s: fast(s, add_special_tokens=False)["input_ids"]
+    seqs = [[PMT, NPF, PMT_SEP, NPI, BOS] + enc("The lungs are clear.") + [SEP] + enc("Normal.") + [EOS, PAD, PAD],
+            [PMT, NPF, PMT_SEP, NPI, BOS] + enc("Heart size is normal.") + enc(" Mild cardiomegaly is stable.")]
+    width = max(len(s) for s in seqs)
+    seqs = [s + [PAD] * (width - len(s)) for s in seqs]
+    sp = modell.split_and_decode_sections(torch.tensor(seqs), [BOS, SEP, EOS], fast)
+    helper.append({"fn": "split_and_decode_sections", "token_ids": seqs, "special": [BOS, SEP, EOS],
+                   "sections": [list(s) for s in sp]})
+    sp2 = model.split_and_decode_sections(torch.tensor([s[4:] for s in seqs]), [SEP, EOS], fast)
+    helper.append({"fn": "split_and_decode_sections", "token_ids": [s[4:] for s in seqs], "special": [SEP, EOS],
+                   "sections": [list(s) for s in sp2]})
+    json.dump({"random": cases, "documented": doc, "helpers": helper, "findings": findings, "impression": impression,
+               "previous_findings": prev_f, "previous_impression": prev_i},
+              open(os.path.join(OUT, "token_ops.json"), "w"))
+    print("token_ops", len(cases), "random cases;", len(helper), "helper cases")
+
+
+def fixture_reward_trunk():
+    """Pins the bidirectional BERT trunk of the CXR-BERT stand-in against transformers.BertModel (the projection head
+    itself is an assumption -- parity unpinned)."""
+    cfg = MyBertConfig(vocab_size=600, num_hidden_layers=2, is_decoder=False, add_cross_attention=False, cls_projection_size=128)
+    sd = weights.init_reward(cfg, seed=16, perturb=0.05)
+    hf = transformers.BertModel(transformers.BertConfig(vocab_size=600, num_hidden_layers=2), add_pooling_layer=False)
+    trunk = {k[len("bert."):]: v for k, v in sd.items() if k.startswith("bert.")}
+    missing, unexpected = hf.load_state_dict(trunk, strict=False)
+    assert not unexpected and all("position_ids" in m or "token_type_ids" in m for m in missing), (missing, unexpected)
+    hf.eval()
+    g = torch.Generator().manual_seed(107)
+    ids = torch.randint(5, 600, (3, 17), generator=g)
+    am = torch.ones(3, 17, dtype=torch.long)
+    am[1, 11:] = 0
+    am[2, 5:] = 0
+    with torch.no_grad():
+        h = hf(input_ids=ids, attention_mask=am).last_hidden_state
+    np.savez_compressed(os.path.join(OUT, "reward_trunk.npz"), seed=16, perturb=0.05, ids=ids.numpy(), attention_mask=am.numpy(),
+                        cls_state=h[:, 0].numpy(), hidden_stats=stats(h))
+    print("reward_trunk", stats(h))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["token_ops", "encoder", "tf_single", "tf_longitudinal", "generate", "reward_trunk"]
+    meta = {"transformers": transformers.__version__, "torch": torch.__version__,
+            "adapter": "SURVEY.md A.3 (D1 legacy decoder.prepare_inputs_for_generation + D2 empty-cache prefill)",
+            "reference": "/root/reference (aehrc/cxrmate @ 2025-02-22)", "mode": "eval(), fp32, CPU"}
+    json.dump(meta, open(os.path.join(OUT, "META.json"), "w"), indent=1)
+    for w in which:
+        globals()["fixture_" + w]()

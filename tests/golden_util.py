@@ -1,0 +1,100 @@
+"""Shared helpers for tests that replay the golden fixtures (inputs are regenerated from the recorded seeds)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from cxrmate_amd import weights
+from cxrmate_amd.config import BertConfig, tiny_config
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BOS, EOS, SEP, PAD, PMT, PMT_SEP, NPF, NPI = 1, 2, 3, 4, 8, 9, 10, 11
+
+
+def load(name):
+    if name.endswith(".json"):
+        return json.load(open(os.path.join(GOLDEN, name)))
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def sample(t, n=4096):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].to(torch.float32).cpu().numpy()
+
+
+def stats(t):
+    t = t.detach().float().cpu()
+    return np.array([t.mean().item(), t.std().item(), t.abs().max().item(), t.norm().item()], dtype=np.float64)
+
+
+def rel_rms(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).mean()) / (np.sqrt((b ** 2).mean()) + 1e-30))
+
+
+def cosine(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+
+
+def encoder_case():
+    g = load("encoder_multi.npz")
+    cfg = tiny_config(vocab_size=1000, decoder_layers=1, depth=tuple(int(i) for i in g["depth"]), image_size=384)
+    sd = weights.init_encoder_decoder(cfg, seed=int(g["seed"]), perturb=float(g["perturb"]))
+    gen = torch.Generator().manual_seed(int(g["pixel_seed"]))
+    x = torch.randn(2, 2, 3, 384, 384, generator=gen)
+    x[1, 1] = 0.0
+    return g, cfg, sd, x
+
+
+def tf_single_case():
+    g = load("tf_single.npz")
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, image_size=96)
+    sd = weights.init_encoder_decoder(cfg, seed=int(g["seed"]), perturb=float(g["perturb"]))
+    gen = torch.Generator().manual_seed(int(g["pixel_seed"]))
+    x = torch.randn(3, 3, 96, 96, generator=gen)
+    full = torch.from_numpy(g["full_ids"])
+    attn = (full != PAD).long()
+    return g, cfg, sd, x, full[:, :-1], full[:, 1:].clone(), attn[:, 1:], torch.from_numpy(g["token_type_ids"])
+
+
+def tf_longitudinal_case():
+    g = load("tf_longitudinal.npz")
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, image_size=96, lora_r=8)
+    sd = weights.init_encoder_decoder(cfg, seed=int(g["seed"]), perturb=float(g["perturb"]))
+    gen = torch.Generator().manual_seed(int(g["pixel_seed"]))
+    x = torch.randn(2, 2, 3, 96, 96, generator=gen)
+    x[0, 1] = 0.0
+    prompt, full = torch.from_numpy(g["prompt_ids"]), torch.from_numpy(g["full_ids"])
+    inp = torch.cat([prompt, full[:, :-1]], dim=1)
+    return (g, cfg, sd, x, prompt, inp, full[:, 1:].clone(), torch.from_numpy(g["attention_mask"]),
+            torch.from_numpy(g["token_type_ids"]), torch.from_numpy(g["position_ids"]))
+
+
+def generate_multi_case():
+    g = load("generate_multi.npz")
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, image_size=96)
+    sd = weights.init_encoder_decoder(cfg, seed=int(g["seed"]), perturb=float(g["perturb"]))
+    gen = torch.Generator().manual_seed(int(g["pixel_seed"]))
+    x = torch.randn(3, 2, 3, 96, 96, generator=gen)
+    x[1, 1] = 0.0
+    return g, cfg, sd, x
+
+
+def generate_longitudinal_case():
+    g = load("generate_longitudinal.npz")
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, image_size=96, lora_r=8)
+    sd = weights.init_encoder_decoder(cfg, seed=int(g["seed"]), perturb=float(g["perturb"]))
+    gen = torch.Generator().manual_seed(int(g["pixel_seed"]))
+    x = torch.randn(2, 2, 3, 96, 96, generator=gen)
+    x[0, 1] = 0.0
+    return g, cfg, sd, x, torch.from_numpy(g["prompt_ids"])
+
+
+def reward_trunk_case():
+    g = load("reward_trunk.npz")
+    cfg = BertConfig(vocab_size=600, num_hidden_layers=2, is_decoder=False, add_cross_attention=False, cls_projection_size=128)
+    sd = weights.init_reward(cfg, seed=int(g["seed"]), perturb=float(g["perturb"]))
+    return g, cfg, sd, torch.from_numpy(g["ids"]), torch.from_numpy(g["attention_mask"])

@@ -1,0 +1,163 @@
+"""CPU: the oracle (oracle/) must reproduce what the REFERENCE produced for the same seeded inputs
+(fixtures written by tests/golden/make_golden.py, which imports /root/reference in the build container)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import bert as obert
+from oracle import cvt as ocvt
+from oracle import generate as ogen
+from oracle import token_ops
+
+FP32_TOL = 2e-4   # oracle and reference are both fp32 on CPU; only summation order differs
+
+
+def test_token_type_ids_random_and_documented():
+    g = gu.load("token_ops.json")
+    for case in g["random"] + g["documented"]:
+        tt = token_ops.token_ids_to_token_type_ids(case["ids"], case["special"], case["sections"])
+        ttp = token_ops.token_ids_to_token_type_ids_past(case["ids"], case["special"], case["sections"])
+        assert tt.tolist() == case["token_type_ids"], case
+        assert ttp.tolist() == case["token_type_ids_past"], case
+
+
+def test_documented_quirks():
+    # SURVEY.md Q4 / Q5 / A.5
+    assert token_ops.token_ids_to_token_type_ids([[1, 50, 51, 3, 60, 61, 2]], [3]).tolist() == [[0, 0, 0, 0, 1, 1, 1]]
+    assert token_ops.token_ids_to_token_type_ids([[1, 50, 51, 60, 61, 2, 3]], [3]).tolist() == [[0] * 7]
+    ids = [[8, 50, 9, 60, 1, 70, 71, 3, 80, 2, 4]]
+    assert token_ops.token_ids_to_token_type_ids(ids, [9, 1, 3], [0, 1, 0, 1]).tolist() == [[0, 0, 0, 1, 1, 0, 0, 0, 1, 1, 1]]
+    assert token_ops.token_ids_to_token_type_ids(ids, [1, 3], [0, 1, 0, 1]).tolist() == [[0, 0, 0, 0, 0, 1, 1, 1, 0, 0, 0]]
+    assert token_ops.token_ids_to_token_type_ids_past([[1, 50, 3, 60]], [3]).tolist() == [[1]]
+    assert token_ops.token_ids_to_token_type_ids_past([[1, 50, 60, 3]], [3]).tolist() == [[0]]
+    assert token_ops.position_ids_from_mask([[1, 1, 0, 0, 1, 1]]).tolist() == [[0, 1, 1, 1, 2, 3]]
+    assert token_ops.position_ids_from_mask([[0, 0, 1]]).tolist() == [[0, 0, 0]]
+
+
+def test_encoder_matches_reference():
+    g, cfg, sd, x = gu.encoder_case()
+    with torch.no_grad():
+        h, mask, stages = ocvt.encoder_forward(x, sd, cfg.encoder, return_stages=True)
+    assert list(h.shape) == g["last_hidden_state_shape"].tolist()
+    assert np.array_equal(mask.numpy(), g["attention_mask"])
+    for i, s in enumerate(stages):
+        assert list(s.shape) == g[f"stage{i}_shape"].tolist()
+        assert gu.rel_rms(gu.sample(s), g[f"stage{i}_sample"]) < FP32_TOL, i
+    assert gu.rel_rms(gu.sample(h, 16384), g["last_hidden_state_sample"]) < FP32_TOL
+    np.testing.assert_allclose(gu.stats(h), g["last_hidden_state_stats"], rtol=1e-4)
+
+
+def _tf_single_logits(sd, cfg, x, inp, am, tt):
+    h, _ = ocvt.encoder_forward(x, sd, cfg.encoder)
+    return obert.decoder_forward(inp, sd, cfg.decoder, h, None, am, tt, None)
+
+
+def test_tf_single_logits_loss_grads():
+    g, cfg, sd, x, inp, lab, am, tt = gu.tf_single_case()
+    assert np.array_equal(token_ops.token_ids_to_token_type_ids(inp.numpy(), [gu.SEP]), g["token_type_ids"])
+    names = [str(n) for n in g["grad_names"]]
+    leaves = {n: sd[n].clone().requires_grad_(True) for n in names}
+    sd2 = dict(sd)
+    sd2.update(leaves)
+    logits = _tf_single_logits(sd2, cfg, x, inp, am, tt)
+    loss = ogen.tf_cross_entropy(logits, lab, gu.PAD)
+    assert gu.rel_rms(gu.sample(logits, 16384), g["logits_sample"]) < FP32_TOL
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    # argmax agrees wherever the reference margin is not numerically degenerate
+    safe = g["logits_margin"] > 1e-3
+    assert np.array_equal(logits.argmax(-1).numpy()[safe], g["logits_argmax"][safe])
+    loss.backward()
+    for i, n in enumerate(names):
+        gr = leaves[n].grad
+        if n.endswith("word_embeddings.weight"):
+            pass  # tied with the LM projection: both contributions flow into the same leaf here as in the reference
+        assert gu.rel_rms(gu.sample(gr, 2048), g[f"grad{i}_sample"]) < 2e-3, n
+        np.testing.assert_allclose(gu.stats(gr)[3], g[f"grad{i}_stats"][3], rtol=2e-3, err_msg=n)
+
+
+def test_tf_longitudinal_lora_prompt():
+    g, cfg, sd, x, prompt, inp, lab, am, tt, pos = gu.tf_longitudinal_case()
+    assert np.array_equal(token_ops.token_ids_to_token_type_ids(inp.numpy(), [gu.PMT_SEP, gu.BOS, gu.SEP], [0, 1, 0, 1]), g["token_type_ids"])
+    assert np.array_equal(token_ops.position_ids_from_mask(am.numpy()), g["position_ids"])
+    names = [str(n) for n in g["grad_names"]]
+    leaves = {n: sd[n].clone().requires_grad_(True) for n in names}
+    sd2 = dict(sd)
+    sd2.update(leaves)
+    h, emask = ocvt.encoder_forward(x, sd2, cfg.encoder)
+    assert np.array_equal(emask.numpy(), g["enc_mask"])
+    logits = obert.decoder_forward(inp, sd2, cfg.decoder, h, emask, am, tt, pos)
+    assert gu.rel_rms(gu.sample(logits, 16384), g["logits_sample"]) < FP32_TOL
+    loss = ogen.tf_cross_entropy(logits[:, prompt.shape[1]:], lab, gu.PAD)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    loss.backward()
+    for i, n in enumerate(names):
+        assert gu.rel_rms(gu.sample(leaves[n].grad, 2048), g[f"grad{i}_sample"]) < 2e-3, n
+
+
+def test_greedy_and_beam_multi():
+    g, cfg, sd, x = gu.generate_multi_case()
+    with torch.no_grad():
+        h, emask = ocvt.encoder_forward(x, sd, cfg.encoder)
+
+        def fn(ids, am, tt, pos, h=h, emask=emask, sd=sd):
+            hh = h if ids.shape[0] == h.shape[0] else h.repeat_interleave(ids.shape[0] // h.shape[0], 0)
+            mm = emask if ids.shape[0] == h.shape[0] else emask.repeat_interleave(ids.shape[0] // h.shape[0], 0)
+            return obert.decoder_forward(ids, sd, cfg.decoder, hh, mm, None, tt, pos)
+
+        max_len = g["greedy"].shape[1]
+        seq, argm, margin = ogen.greedy(fn, "multi", 3, [gu.SEP], gu.BOS, gu.EOS, gu.PAD, max_len, return_margins=True)
+        assert np.array_equal(seq.numpy(), g["greedy"])
+        np.testing.assert_allclose(margin, g["greedy_margin"], atol=2e-4)
+        beam, score = ogen.beam_search(fn, "multi", 3, 4, [gu.SEP], gu.BOS, gu.EOS, gu.PAD, max_len)
+        assert np.array_equal(beam.numpy(), g["beam4"])
+        np.testing.assert_allclose(score.numpy(), g["beam4_scores"], atol=1e-4)
+        # EOS-biased variant: EOS -> PAD fill and beam finalisation
+        sd_e = dict(sd)
+        sd_e["decoder.cls.predictions.bias"] = sd["decoder.cls.predictions.bias"].clone()
+        sd_e["decoder.cls.predictions.bias"][gu.EOS] += float(g["eos_bias"])
+        fn_e = lambda *a: fn(*a, sd=sd_e)
+        seq = ogen.greedy(fn_e, "multi", 3, [gu.SEP], gu.BOS, gu.EOS, gu.PAD, max_len)
+        assert np.array_equal(seq.numpy(), g["greedy_eos"])
+        beam, score = ogen.beam_search(fn_e, "multi", 3, 4, [gu.SEP], gu.BOS, gu.EOS, gu.PAD, max_len)
+        assert np.array_equal(beam.numpy(), g["beam4_eos"]), (beam, g["beam4_eos"])
+        np.testing.assert_allclose(score.numpy(), g["beam4_eos_scores"], atol=1e-4)
+
+
+def test_prompted_greedy_scores_and_reinforce():
+    g, cfg, sd, x, prompt = gu.generate_longitudinal_case()
+    with torch.no_grad():
+        h, emask = ocvt.encoder_forward(x, sd, cfg.encoder)
+        fn = lambda ids, am, tt, pos: obert.decoder_forward(ids, sd, cfg.decoder, h, emask, am, tt, pos)
+        new = g["greedy"].shape[1] - prompt.shape[1]
+        seq = ogen.greedy(fn, "longitudinal", 2, [gu.PMT_SEP, gu.BOS, gu.SEP], gu.BOS, gu.EOS, gu.PAD, None,
+                          prompt_ids=prompt, mask_token_id=gu.PAD, max_new_tokens=new)
+        assert bool(torch.all(seq[:, 0] == gu.BOS))           # HF prepends BOS; callers strip it
+        assert np.array_equal(token_ops.strip_prepended_bos(seq.numpy()), g["greedy"])
+        # processed scores of the sampling path for the reference's sampled ids (teacher-forced, quirk Q5 special ids)
+        seqs = torch.from_numpy(g["sampled_sequences"])
+        fed, am, tt, pos = ogen.step_inputs("longitudinal", seqs, [gu.BOS, gu.SEP], gu.PAD, gu.BOS)
+        logits = fn(fed, am, tt, pos)
+        p = prompt.shape[1]
+        scores = ogen.top_k_filter(logits[:, p - 1:-1].float(), 50).permute(0, 2, 1)      # [B,V,T]
+        assert list(scores.shape) == g["scores_shape"].tolist()
+        finite = torch.isfinite(scores)
+        assert np.array_equal(finite.sum(1).numpy(), g["scores_finite_count"])
+        assert np.array_equal(np.packbits(finite.numpy(), axis=1), g["scores_finite_mask"])
+        sampled = seqs[:, p:]
+        np.testing.assert_allclose(torch.gather(scores, 1, sampled[:, None, :])[:, 0].numpy(), g["scores_at_sampled"], atol=2e-4)
+        loss = ogen.reinforce_loss(scores, sampled, torch.from_numpy(g["reward"]), gu.PAD)
+        assert abs(loss.item() - float(g["reinforce_loss"])) < 2e-4
+
+
+def test_reward_trunk_matches_transformers_bert():
+    g, cfg, sd, ids, am = gu.reward_trunk_case()
+    with torch.no_grad():
+        h = obert.embeddings(ids, None, None, sd, "bert.embeddings.", cfg.layer_norm_eps)
+        mask = torch.zeros(ids.shape[0], 1, 1, ids.shape[1]).masked_fill(~am.bool().view(ids.shape[0], 1, 1, -1), obert.NEG)
+        h = obert.bert_layers(h, sd, "bert.", cfg, mask)
+        np.testing.assert_allclose(h[:, 0].numpy(), g["cls_state"], atol=2e-4)
+        cos = obert.reward_cosine(ids, am, ids.flip(0), am.flip(0), sd, cfg)
+        assert cos.shape == (3,) and bool((cos.abs() <= 1.0 + 1e-6).all())
+        same = obert.reward_cosine(ids, am, ids, am, sd, cfg)
+        np.testing.assert_allclose(same.numpy(), 1.0, atol=1e-5)
