@@ -1,0 +1,311 @@
+// Backward of the fused attention (head_dim 64, bf16, fp32 accumulate): dQ, dK, dV with P recomputed from (Q, K, LSE).
+// Two deterministic kernels (no atomics):
+//   dkdv: workgroup = 128 keys (32 per wave, key on the MFMA lane) sweeping 64-query tiles; S and dP accumulators are
+//         already the B operands of dV^T += dO^T.P and dK^T += Q^T.dS (accumulator-as-operand); dK/dV never leave registers.
+//   dq  : workgroup = 128 queries (32 per wave, query on the lane) sweeping 64-key tiles; dQ^T += K^T.dS^T.
+// Tiles that are consumed both row-wise (ds_read_b128) and column-wise (ds_read_b64_tr_b16) are kept as two LDS images
+// (144-B rows / 192-B rows) so both read patterns are bank-conflict free.
+#include "common.h"
+
+struct AttnBwdArgs {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* V; const bf16_t* dO;
+    const float* LSE; const float* delta;
+    bf16_t* dQ; bf16_t* dK; bf16_t* dV;
+    const unsigned char* kpm;
+    long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, kpm_bs;
+    long dq_bs, dq_rs, dk_bs, dk_rs;         // dQ has Q's logical shape, dK/dV have K's (contiguous outputs)
+    int B, H, Tq, Tk;
+    float scale, scale_log2e;
+    int causal, causal_shift;
+};
+
+constexpr int RS = 72;     // row-image stride (bf16 elements)
+constexpr int TS = 96;     // transposed-read image stride
+
+__device__ __forceinline__ bf16x8_t trp(const bf16_t* p0, const bf16_t* p1) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+    s16x8_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& x, int s) {
+    s16x8_t pv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pv[j] = (short)f2bf(x[8 * s + j]);
+    return __builtin_bit_cast(bf16x8_t, pv);
+}
+
+// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, long o_bs, long o_rs,
+                                                         float* __restrict__ delta, int B, int H, int Tq) {
+    const long total = (long)B * H * Tq * 8;             // 8 lanes per (b,h,q): 8 elements each
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f;
+    long bhq = idx >> 3;
+    if (idx < total) {
+        const int c = (int)(idx & 7);
+        const int q = (int)(bhq % Tq), h = (int)((bhq / Tq) % H), b = (int)(bhq / ((long)Tq * H));
+        const long off = (long)b * o_bs + (long)q * o_rs + h * 64 + c * 8;
+        float x[8], y[8];
+        unpack8(*reinterpret_cast<const uint4*>(O + off), x);
+        unpack8(*reinterpret_cast<const uint4*>(dO + off), y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += x[j] * y[j];
+    }
+    s = group_sum<8>(s);
+    if (idx < total && (idx & 7) == 0) delta[bhq] = s;   // delta laid out [B,H,Tq]: bhq = (b*H + h)*Tq + q
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t Qr[64 * RS];
+    __shared__ __attribute__((aligned(16))) bf16_t Qt[64 * TS];
+    __shared__ __attribute__((aligned(16))) bf16_t Dr[64 * RS];
+    __shared__ __attribute__((aligned(16))) bf16_t Dt[64 * TS];
+    __shared__ float Ls[64];
+    __shared__ float Es[64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int kb0 = blockIdx.x * 128;
+    const int kl = lane & 31, hh = lane >> 5;
+    const int key = kb0 + wave * 32 + kl;
+    const int keyc = key < a.Tk ? key : a.Tk - 1;
+    int code = 0;
+    if (key < a.Tk) code = (a.kpm == nullptr || a.kpm[(long)b * a.kpm_bs + key]) ? 2 : 1;
+
+    bf16x8_t kf[4], vf[4];
+    {
+        const bf16_t* kp = a.K + (long)b * a.k_bs + (long)keyc * a.k_rs + head * 64 + hh * 8;
+        const bf16_t* vp = a.V + (long)b * a.v_bs + (long)keyc * a.v_rs + head * 64 + hh * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { kf[s] = *reinterpret_cast<const bf16x8_t*>(kp + s * 16); vf[s] = *reinterpret_cast<const bf16x8_t*>(vp + s * 16); }
+    }
+
+    const int ntiles = (a.Tq + 63) >> 6;
+    int tile0 = 0;
+    if (a.causal) { const int first = kb0 - a.causal_shift; tile0 = first > 0 ? (first >> 6) : 0; }
+
+    const bf16_t* qbase = a.Q + (long)b * a.q_bs + head * 64;
+    const bf16_t* dbase = a.dO + (long)b * a.o_bs + head * 64;
+    const float* lbase = a.LSE + ((long)b * a.H + head) * a.Tq;
+    const float* ebase = a.delta + ((long)b * a.H + head) * a.Tq;
+    const int srow0 = tid >> 3, srow1 = (256 + tid) >> 3, sc = tid & 7;
+    uint4 q0, q1, d0, d1;
+    float lsev = 0.f;
+#define BWD_GLOAD_Q(tile)                                                                                   \
+    do {                                                                                                    \
+        int r0_ = (tile) * 64 + srow0; r0_ = r0_ < a.Tq ? r0_ : a.Tq - 1;                                   \
+        int r1_ = (tile) * 64 + srow1; r1_ = r1_ < a.Tq ? r1_ : a.Tq - 1;                                   \
+        q0 = *reinterpret_cast<const uint4*>(qbase + (long)r0_ * a.q_rs + sc * 8);                          \
+        q1 = *reinterpret_cast<const uint4*>(qbase + (long)r1_ * a.q_rs + sc * 8);                          \
+        d0 = *reinterpret_cast<const uint4*>(dbase + (long)r0_ * a.o_rs + sc * 8);                          \
+        d1 = *reinterpret_cast<const uint4*>(dbase + (long)r1_ * a.o_rs + sc * 8);                          \
+        if (tid < 128) {                                                                                    \
+            const int qq_ = (tile) * 64 + (tid & 63);                                                       \
+            if (tid < 64) lsev = qq_ < a.Tq ? lbase[qq_] * 1.4426950408889634f : INFINITY;                  \
+            else          lsev = qq_ < a.Tq ? ebase[qq_] : 0.f;                                             \
+        }                                                                                                   \
+    } while (0)
+
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+
+    if (tile0 < ntiles) BWD_GLOAD_Q(tile0);
+    for (int tile = tile0; tile < ntiles; ++tile) {
+        __syncthreads();
+        *reinterpret_cast<uint4*>(Qr + srow0 * RS + sc * 8) = q0; *reinterpret_cast<uint4*>(Qr + srow1 * RS + sc * 8) = q1;
+        *reinterpret_cast<uint4*>(Qt + srow0 * TS + sc * 8) = q0; *reinterpret_cast<uint4*>(Qt + srow1 * TS + sc * 8) = q1;
+        *reinterpret_cast<uint4*>(Dr + srow0 * RS + sc * 8) = d0; *reinterpret_cast<uint4*>(Dr + srow1 * RS + sc * 8) = d1;
+        *reinterpret_cast<uint4*>(Dt + srow0 * TS + sc * 8) = d0; *reinterpret_cast<uint4*>(Dt + srow1 * TS + sc * 8) = d1;
+        if (tid < 64) Ls[tid] = lsev; else if (tid < 128) Es[tid - 64] = lsev;
+        __syncthreads();
+        if (tile + 1 < ntiles) BWD_GLOAD_Q(tile + 1);
+
+        const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            f32x16_t S, dP;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(Qr + (qs * 32 + kl) * RS + s * 16 + hh * 8);
+                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(Dr + (qs * 32 + kl) * RS + s * 16 + hh * 8);
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[s], dP, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = qs * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                bool ok = code == 2;
+                if (a.causal) ok = ok && (key <= tile * 64 + ql + a.causal_shift);
+                const float p = ok ? exp2f(S[r] * a.scale_log2e - Ls[ql]) : 0.f;
+                S[r] = p;
+                dP[r] = p * (dP[r] - Es[ql]) * a.scale;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8_t pf = pack_frag(S, s2), dsf = pack_frag(dP, s2);
+                const int qb = qs * 32 + s2 * 16 + 4 * hh + (li >> 2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int col = dt * 32 + 16 * (g & 1) + 4 * (li & 3);
+                    const bf16x8_t dot = trp(Dt + qb * TS + col, Dt + (qb + 8) * TS + col);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pf, dv[dt], 0, 0, 0);
+                    const bf16x8_t qt = trp(Qt + qb * TS + col, Qt + (qb + 8) * TS + col);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dsf, dk[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+#undef BWD_GLOAD_Q
+    if (key < a.Tk) {
+        bf16_t* kp = a.dK + (long)b * a.dk_bs + (long)key * a.dk_rs + head * 64;
+        bf16_t* vp = a.dV + (long)b * a.dk_bs + (long)key * a.dk_rs + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                uint2 pk;
+                pk.x = pack2bf(dk[dt][4 * rg], dk[dt][4 * rg + 1]); pk.y = pack2bf(dk[dt][4 * rg + 2], dk[dt][4 * rg + 3]);
+                *reinterpret_cast<uint2*>(kp + dt * 32 + 8 * rg + 4 * hh) = pk;
+                pk.x = pack2bf(dv[dt][4 * rg], dv[dt][4 * rg + 1]); pk.y = pack2bf(dv[dt][4 * rg + 2], dv[dt][4 * rg + 3]);
+                *reinterpret_cast<uint2*>(vp + dt * 32 + 8 * rg + 4 * hh) = pk;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t Kr[64 * RS];
+    __shared__ __attribute__((aligned(16))) bf16_t Kt[64 * TS];
+    __shared__ __attribute__((aligned(16))) bf16_t Vr[64 * RS];
+    __shared__ unsigned char Ms[64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int qb0 = blockIdx.x * 128;
+    const int ql = lane & 31, hh = lane >> 5;
+    const int qrow = qb0 + wave * 32 + ql;
+    const int qc = qrow < a.Tq ? qrow : a.Tq - 1;
+
+    bf16x8_t qf[4], dof[4];
+    {
+        const bf16_t* qp = a.Q + (long)b * a.q_bs + (long)qc * a.q_rs + head * 64 + hh * 8;
+        const bf16_t* dp = a.dO + (long)b * a.o_bs + (long)qc * a.o_rs + head * 64 + hh * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + s * 16); dof[s] = *reinterpret_cast<const bf16x8_t*>(dp + s * 16); }
+    }
+    const float lse2 = a.LSE[((long)b * a.H + head) * a.Tq + qc] * 1.4426950408889634f;
+    const float dl = a.delta[((long)b * a.H + head) * a.Tq + qc];
+
+    int ntiles = (a.Tk + 63) >> 6;
+    if (a.causal) {
+        const int last = qb0 + 127 + a.causal_shift;
+        const int lim = last < 0 ? 0 : (last >> 6) + 1;
+        ntiles = lim < ntiles ? lim : ntiles;
+    }
+    const bf16_t* kbase = a.K + (long)b * a.k_bs + head * 64;
+    const bf16_t* vbase = a.V + (long)b * a.v_bs + head * 64;
+    const int srow0 = tid >> 3, srow1 = (256 + tid) >> 3, sc = tid & 7;
+    uint4 k0, k1, v0, v1;
+#define BWD_GLOAD_KV(tile)                                                                           \
+    do {                                                                                             \
+        int r0_ = (tile) * 64 + srow0; r0_ = r0_ < a.Tk ? r0_ : a.Tk - 1;                            \
+        int r1_ = (tile) * 64 + srow1; r1_ = r1_ < a.Tk ? r1_ : a.Tk - 1;                            \
+        k0 = *reinterpret_cast<const uint4*>(kbase + (long)r0_ * a.k_rs + sc * 8);                   \
+        k1 = *reinterpret_cast<const uint4*>(kbase + (long)r1_ * a.k_rs + sc * 8);                   \
+        v0 = *reinterpret_cast<const uint4*>(vbase + (long)r0_ * a.v_rs + sc * 8);                   \
+        v1 = *reinterpret_cast<const uint4*>(vbase + (long)r1_ * a.v_rs + sc * 8);                   \
+    } while (0)
+
+    f32x16_t dq[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
+
+    if (ntiles > 0) BWD_GLOAD_KV(0);
+    for (int tile = 0; tile < ntiles; ++tile) {
+        __syncthreads();
+        *reinterpret_cast<uint4*>(Kr + srow0 * RS + sc * 8) = k0; *reinterpret_cast<uint4*>(Kr + srow1 * RS + sc * 8) = k1;
+        *reinterpret_cast<uint4*>(Kt + srow0 * TS + sc * 8) = k0; *reinterpret_cast<uint4*>(Kt + srow1 * TS + sc * 8) = k1;
+        *reinterpret_cast<uint4*>(Vr + srow0 * RS + sc * 8) = v0; *reinterpret_cast<uint4*>(Vr + srow1 * RS + sc * 8) = v1;
+        if (tid < 64) {
+            const int kk = tile * 64 + tid;
+            unsigned char code = 0;
+            if (kk < a.Tk) code = (a.kpm == nullptr || a.kpm[(long)b * a.kpm_bs + kk]) ? 2 : 1;
+            Ms[tid] = code;
+        }
+        __syncthreads();
+        if (tile + 1 < ntiles) BWD_GLOAD_KV(tile + 1);
+
+        const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16_t S, dP;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8_t ka = *reinterpret_cast<const bf16x8_t*>(Kr + (kt * 32 + ql) * RS + s * 16 + hh * 8);
+                const bf16x8_t va = *reinterpret_cast<const bf16x8_t*>(Vr + (kt * 32 + ql) * RS + s * 16 + hh * 8);
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[s], dP, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kloc = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                bool ok = Ms[kloc] == 2;
+                if (a.causal) ok = ok && (tile * 64 + kloc <= qrow + a.causal_shift);
+                const float p = ok ? exp2f(S[r] * a.scale_log2e - lse2) : 0.f;
+                dP[r] = p * (dP[r] - dl) * a.scale;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8_t dsf = pack_frag(dP, s2);
+                const int kb = kt * 32 + s2 * 16 + 4 * hh + (li >> 2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int col = dt * 32 + 16 * (g & 1) + 4 * (li & 3);
+                    const bf16x8_t ktf = trp(Kt + kb * TS + col, Kt + (kb + 8) * TS + col);
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+#undef BWD_GLOAD_KV
+    if (qrow < a.Tq) {
+        bf16_t* qp = a.dQ + (long)b * a.dq_bs + (long)qrow * a.dq_rs + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                uint2 pk;
+                pk.x = pack2bf(dq[dt][4 * rg], dq[dt][4 * rg + 1]); pk.y = pack2bf(dq[dt][4 * rg + 2], dq[dt][4 * rg + 3]);
+                *reinterpret_cast<uint2*>(qp + dt * 32 + 8 * rg + 4 * hh) = pk;
+            }
+    }
+}
+
+// dQ [B,Tq,H*64], dK/dV [B,Tk,H*64] are written contiguously.
+extern "C" int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* delta,
+                                 void* dQ, void* dK, void* dV, const void* kpm, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
+                                 long o_bs, long o_rs, long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal, int causal_shift,
+                                 hipStream_t stream) {
+    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || !LSE || !delta) return CXR_ERR_ARG;
+    if ((q_rs % 8) || (k_rs % 8) || (v_rs % 8) || (o_rs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 8)) return CXR_ERR_ARG;
+    AttnBwdArgs a;
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.dO = (const bf16_t*)dO; a.LSE = LSE; a.delta = delta;
+    a.dQ = (bf16_t*)dQ; a.dK = (bf16_t*)dK; a.dV = (bf16_t*)dV; a.kpm = (const unsigned char*)kpm;
+    a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_rs = o_rs; a.kpm_bs = kpm_bs;
+    a.dq_rs = (long)H * 64; a.dq_bs = (long)Tq * H * 64; a.dk_rs = (long)H * 64; a.dk_bs = (long)Tk * H * 64;
+    a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
+    a.causal = causal; a.causal_shift = causal_shift;
+    const long nd = (long)B * H * Tq * 8;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(nd, 256)), dim3(256), 0, stream, (const bf16_t*)O, (const bf16_t*)dO, o_bs, o_rs, delta, B, H, Tq);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(cdiv(Tk, 128), H, B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(Tq, 128), H, B), dim3(256), 0, stream, a);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}

@@ -1,0 +1,360 @@
+// Convolutional pieces of the CvT encoder, all on token-major (NHWC) bf16 activations:
+//   * im2col for the three patch-embedding convs (7x7 s4 p2 on NCHW fp32 pixels; 3x3 s2 p1 on tokens) -> MFMA GEMM
+//   * col2im (gather form, no atomics) for the embedding convs' input gradient
+//   * depthwise 3x3 conv + folded BatchNorm producing q (stride 1) or k AND v (stride 2, one read of the input)
+//   * its backward (input gradient + per-channel tap/shift gradient sums)
+// These are HBM-bound: channel-contiguous 16-byte accesses, taps re-read through L1/L2.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------- stage-1 im2col
+// pixels [Bn, Cin, H, W] fp32 NCHW  ->  col [Bn*Ho*Wo, Kpad] bf16, k = c*KS*KS + ky*KS + kx (= weight.view(Cout,-1)), zero padded
+__global__ __launch_bounds__(256) void im2col_nchw_kernel(const float* __restrict__ px, bf16_t* __restrict__ col, int Bn, int Cin, int H, int W,
+                                                          int KS, int stride, int pad, int Ho, int Wo, int Kreal, int Kpad) {
+    const int chunks = Kpad / 8;
+    const long total = (long)Bn * Ho * Wo * chunks;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ch = (int)(idx % chunks);
+        const long pix = idx / chunks;
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ch * 8 + j;
+            float v = 0.f;
+            if (k < Kreal) {
+                const int c = k / (KS * KS), rem = k % (KS * KS), ky = rem / KS, kx = rem % KS;
+                const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = px[(((long)b * Cin + c) * H + iy) * W + ix];
+            }
+            o[j] = v;
+        }
+        *reinterpret_cast<uint4*>(col + pix * Kpad + ch * 8) = pack8(o);
+    }
+}
+
+// tokens [Bn, tok_rs rows..] bf16, spatial token (y,x) at row y*W+x  ->  col [Bn*Ho*Wo, 9*Cin], k = (ky*3+kx)*Cin + c
+__global__ __launch_bounds__(256) void im2col_tok_kernel(const bf16_t* __restrict__ x, long x_bs, long x_rs, bf16_t* __restrict__ col,
+                                                         int Bn, int Cin, int H, int W, int stride, int pad, int Ho, int Wo) {
+    const int cch = Cin / 8, chunks = 9 * cch;
+    const long total = (long)Bn * Ho * Wo * chunks;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ch = (int)(idx % chunks);
+        const long pix = idx / chunks;
+        const int tap = ch / cch, c8 = (ch % cch) * 8, ky = tap / 3, kx = tap % 3;
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
+        const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const uint4*>(x + (long)b * x_bs + ((long)iy * W + ix) * x_rs + c8);
+        *reinterpret_cast<uint4*>(col + pix * (long)(9 * Cin) + tap * Cin + c8) = v;
+    }
+}
+
+// gather-form col2im: dx[b,(iy,ix),c] = sum over taps/out positions covering (iy,ix) of dcol[b,(oy,ox), tap, c]
+__global__ __launch_bounds__(256) void col2im_tok_kernel(const bf16_t* __restrict__ dcol, bf16_t* __restrict__ dx, long dx_bs, long dx_rs,
+                                                         int Bn, int Cin, int H, int W, int stride, int pad, int Ho, int Wo) {
+    const int cch = Cin / 8;
+    const long total = (long)Bn * H * W * cch;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % cch) * 8;
+        const long pix = idx / cch;
+        const int ix = (int)(pix % W), iy = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + pad - ky;
+            if (ty < 0 || (ty % stride) || ty / stride >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix + pad - kx;
+                if (tx < 0 || (tx % stride) || tx / stride >= Wo) continue;
+                const long opix = ((long)b * Ho + ty / stride) * Wo + tx / stride;
+                float f[8];
+                unpack8(*reinterpret_cast<const uint4*>(dcol + opix * (long)(9 * Cin) + (ky * 3 + kx) * Cin + c8), f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += f[j];
+            }
+        }
+        *reinterpret_cast<uint4*>(dx + (long)b * dx_bs + ((long)iy * W + ix) * dx_rs + c8) = pack8(acc);
+    }
+}
+
+extern "C" int cxr_im2col_nchw_f32(const float* px, void* col, int Bn, int Cin, int H, int W, int KS, int stride, int pad,
+                                   int Ho, int Wo, int Kpad, hipStream_t stream) {
+    if (Bn <= 0 || (Kpad % 8) || Kpad < Cin * KS * KS) return CXR_ERR_ARG;
+    const long total = (long)Bn * Ho * Wo * (Kpad / 8);
+    const int grid = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+    hipLaunchKernelGGL(im2col_nchw_kernel, dim3(grid), dim3(256), 0, stream, px, (bf16_t*)col, Bn, Cin, H, W, KS, stride, pad, Ho, Wo,
+                       Cin * KS * KS, Kpad);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+extern "C" int cxr_im2col_tok_bf16(const void* x, long x_bs, long x_rs, void* col, int Bn, int Cin, int H, int W, int stride, int pad,
+                                   int Ho, int Wo, hipStream_t stream) {
+    if (Bn <= 0 || (Cin % 8) || (x_rs % 8) || (x_bs % 8)) return CXR_ERR_ARG;
+    const long total = (long)Bn * Ho * Wo * 9 * (Cin / 8);
+    const int grid = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+    hipLaunchKernelGGL(im2col_tok_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, (bf16_t*)col, Bn, Cin, H, W,
+                       stride, pad, Ho, Wo);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+extern "C" int cxr_col2im_tok_bf16(const void* dcol, void* dx, long dx_bs, long dx_rs, int Bn, int Cin, int H, int W, int stride, int pad,
+                                   int Ho, int Wo, hipStream_t stream) {
+    if (Bn <= 0 || (Cin % 8) || (dx_rs % 8) || (dx_bs % 8)) return CXR_ERR_ARG;
+    const long total = (long)Bn * H * W * (Cin / 8);
+    const int grid = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+    hipLaunchKernelGGL(col2im_tok_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dcol, (bf16_t*)dx, dx_bs, dx_rs, Bn, Cin, H, W,
+                       stride, pad, Ho, Wo);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- depthwise 3x3 + BN
+// Folded parameters per projection: wf[9][C] = conv_w[c][tap] * bn_scale[c], sh[C] = bn_bias - mean*bn_scale  (fp32)
+// (eval-mode BatchNorm, TF5 modeling_cvt.py:93-110; the batch-statistics variant feeds batch mean/var through the same fold)
+__global__ void bn_fold_kernel(const float* __restrict__ w /*[C,9]*/, const float* __restrict__ g, const float* __restrict__ b,
+                               const float* __restrict__ mean, const float* __restrict__ var, float eps, float* __restrict__ wf,
+                               float* __restrict__ sh, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s = g[c] * rsqrtf(var[c] + eps);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wf[t * C + c] = w[c * 9 + t] * s;
+    sh[c] = b[c] - mean[c] * s;
+}
+
+extern "C" int cxr_bn_fold(const float* w, const float* g, const float* b, const float* mean, const float* var, float eps, float* wf,
+                           float* sh, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 128)), dim3(128), 0, stream, w, g, b, mean, var, eps, wf, sh, C);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// param gradients from the tap sums: G[9][C] = sum dy*x_tap, S[C] = sum dy
+//   dw[c][t] = s*G[t][c];  dgamma = r*(sum_t w[c][t]*G[t][c] - mean*S);  dbeta = S      (s = gamma*r, r = rsqrt(var+eps))
+__global__ void bn_fold_bwd_kernel(const float* __restrict__ w, const float* __restrict__ g, const float* __restrict__ mean,
+                                   const float* __restrict__ var, float eps, const float* __restrict__ G, const float* __restrict__ S,
+                                   float* __restrict__ dw, float* __restrict__ dg, float* __restrict__ db, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float r = rsqrtf(var[c] + eps), s = g[c] * r;
+    float dot = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { dw[c * 9 + t] += s * G[t * C + c]; dot += w[c * 9 + t] * G[t * C + c]; }
+    dg[c] += r * (dot - mean[c] * S[c]);
+    db[c] += S[c];
+}
+
+extern "C" int cxr_bn_fold_bwd(const float* w, const float* g, const float* mean, const float* var, float eps, const float* G,
+                               const float* S, float* dw, float* dg, float* db, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3(cdiv(C, 128)), dim3(128), 0, stream, w, g, mean, var, eps, G, S, dw, dg, db, C);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// x: [Bn, x_rs-strided rows], spatial token (y,x) at row `tok0 + y*W + x`; outputs y0 (and y1 when NOUT==2) at row `tok0 + oy*Wo + ox`.
+// When tok0 == 1 the class-token row 0 is copied through unchanged (TF5 modeling_cvt.py:195-198).
+template <int NOUT>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16_t* __restrict__ x, long x_bs, long x_rs, const float* __restrict__ wf0,
+                                                         const float* __restrict__ sh0, const float* __restrict__ wf1,
+                                                         const float* __restrict__ sh1, bf16_t* __restrict__ y0, bf16_t* __restrict__ y1,
+                                                         long y_bs, long y_rs, int Bn, int C, int H, int W, int stride, int Ho, int Wo, int tok0) {
+    const int cch = C / 8;
+    const long total = (long)Bn * (Ho * Wo + tok0) * cch;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % cch) * 8;
+        const long t = idx / cch;
+        const int tok = (int)(t % (Ho * Wo + tok0)), b = (int)(t / (Ho * Wo + tok0));
+        const bf16_t* xb = x + (long)b * x_bs;
+        if (tok < tok0) {                                                   // class token passthrough
+            const uint4 v = *reinterpret_cast<const uint4*>(xb + c8);
+            *reinterpret_cast<uint4*>(y0 + (long)b * y_bs + c8) = v;
+            if (NOUT == 2) *reinterpret_cast<uint4*>(y1 + (long)b * y_bs + c8) = v;
+            continue;
+        }
+        const int p = tok - tok0, oy = p / Wo, ox = p % Wo;
+        float a0[8], a1[8];
+        {
+            const float4 s0 = *reinterpret_cast<const float4*>(sh0 + c8), s1 = *reinterpret_cast<const float4*>(sh0 + c8 + 4);
+            a0[0] = s0.x; a0[1] = s0.y; a0[2] = s0.z; a0[3] = s0.w; a0[4] = s1.x; a0[5] = s1.y; a0[6] = s1.z; a0[7] = s1.w;
+            if (NOUT == 2) {
+                const float4 t0 = *reinterpret_cast<const float4*>(sh1 + c8), t1 = *reinterpret_cast<const float4*>(sh1 + c8 + 4);
+                a1[0] = t0.x; a1[1] = t0.y; a1[2] = t0.z; a1[3] = t0.w; a1[4] = t1.x; a1[5] = t1.y; a1[6] = t1.z; a1[7] = t1.w;
+            }
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * stride - 1 + ky;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * stride - 1 + kx;
+                if (ix < 0 || ix >= W) continue;
+                float f[8];
+                unpack8(*reinterpret_cast<const uint4*>(xb + (long)(tok0 + iy * W + ix) * x_rs + c8), f);
+                const float* w0 = wf0 + (ky * 3 + kx) * C + c8;
+                const float4 u0 = *reinterpret_cast<const float4*>(w0), u1 = *reinterpret_cast<const float4*>(w0 + 4);
+                a0[0] += f[0] * u0.x; a0[1] += f[1] * u0.y; a0[2] += f[2] * u0.z; a0[3] += f[3] * u0.w;
+                a0[4] += f[4] * u1.x; a0[5] += f[5] * u1.y; a0[6] += f[6] * u1.z; a0[7] += f[7] * u1.w;
+                if (NOUT == 2) {
+                    const float* w1 = wf1 + (ky * 3 + kx) * C + c8;
+                    const float4 q0 = *reinterpret_cast<const float4*>(w1), q1 = *reinterpret_cast<const float4*>(w1 + 4);
+                    a1[0] += f[0] * q0.x; a1[1] += f[1] * q0.y; a1[2] += f[2] * q0.z; a1[3] += f[3] * q0.w;
+                    a1[4] += f[4] * q1.x; a1[5] += f[5] * q1.y; a1[6] += f[6] * q1.z; a1[7] += f[7] * q1.w;
+                }
+            }
+        }
+        *reinterpret_cast<uint4*>(y0 + (long)b * y_bs + (long)tok * y_rs + c8) = pack8(a0);
+        if (NOUT == 2) *reinterpret_cast<uint4*>(y1 + (long)b * y_bs + (long)tok * y_rs + c8) = pack8(a1);
+    }
+}
+
+extern "C" int cxr_dwconv_bn_fwd_bf16(const void* x, long x_bs, long x_rs, const float* wf0, const float* sh0, const float* wf1,
+                                      const float* sh1, void* y0, void* y1, long y_bs, long y_rs, int Bn, int C, int H, int W, int stride,
+                                      int tok0, hipStream_t stream) {
+    if (Bn <= 0 || (C % 8) || (x_rs % 8) || (y_rs % 8) || (x_bs % 8) || (y_bs % 8) || (stride != 1 && stride != 2)) return CXR_ERR_ARG;
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const long total = (long)Bn * (Ho * Wo + tok0) * (C / 8);
+    const int grid = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
+    if (y1) hipLaunchKernelGGL((dwconv_fwd_kernel<2>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, wf0, sh0, wf1, sh1,
+                               (bf16_t*)y0, (bf16_t*)y1, y_bs, y_rs, Bn, C, H, W, stride, Ho, Wo, tok0);
+    else    hipLaunchKernelGGL((dwconv_fwd_kernel<1>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, wf0, sh0, wf0, sh0,
+                               (bf16_t*)y0, (bf16_t*)nullptr, y_bs, y_rs, Bn, C, H, W, stride, Ho, Wo, tok0);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// Backward, input gradient (gather form): dx[b,(iy,ix),c] (+)= sum_taps wf[tap][c] * dy[b,(oy,ox),c]; class row: dx[0] (+)= dy[0].
+// Up to three projections (q stride 1; k, v stride 2) are folded into one pass so dx is written once.
+struct DwBwdProj { const bf16_t* dy; const float* wf; long bs, rs; int stride, Ho, Wo; };
+__global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(DwBwdProj p0, DwBwdProj p1, DwBwdProj p2, int nproj, bf16_t* __restrict__ dx,
+                                                            long dx_bs, long dx_rs, int Bn, int C, int H, int W, int tok0) {
+    const int cch = C / 8;
+    const long total = (long)Bn * (H * W + tok0) * cch;
+    const DwBwdProj pr[3] = {p0, p1, p2};
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % cch) * 8;
+        const long t = idx / cch;
+        const int tok = (int)(t % (H * W + tok0)), b = (int)(t / (H * W + tok0));
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (tok < tok0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (q >= nproj) break;
+                float f[8];
+                unpack8(*reinterpret_cast<const uint4*>(pr[q].dy + (long)b * pr[q].bs + c8), f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += f[j];
+            }
+        } else {
+            const int p = tok - tok0, iy = p / W, ix = p % W;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (q >= nproj) break;
+                const int st = pr[q].stride;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int ty = iy + 1 - ky;
+                    if (ty < 0 || (ty % st) || ty / st >= pr[q].Ho) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int tx = ix + 1 - kx;
+                        if (tx < 0 || (tx % st) || tx / st >= pr[q].Wo) continue;
+                        float f[8];
+                        unpack8(*reinterpret_cast<const uint4*>(pr[q].dy + (long)b * pr[q].bs +
+                                                                (long)(tok0 + (ty / st) * pr[q].Wo + tx / st) * pr[q].rs + c8), f);
+                        const float* w = pr[q].wf + (ky * 3 + kx) * C + c8;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] += f[j] * w[j];
+                    }
+                }
+            }
+        }
+        *reinterpret_cast<uint4*>(dx + (long)b * dx_bs + (long)tok * dx_rs + c8) = pack8(acc);
+    }
+}
+
+extern "C" int cxr_dwconv_bn_bwd_dx_bf16(const void* dy0, const float* wf0, long bs0, long rs0, int stride0,
+                                         const void* dy1, const float* wf1, long bs1, long rs1, int stride1,
+                                         const void* dy2, const float* wf2, long bs2, long rs2, int stride2,
+                                         int nproj, void* dx, long dx_bs, long dx_rs, int Bn, int C, int H, int W, int tok0,
+                                         hipStream_t stream) {
+    if (Bn <= 0 || (C % 8) || nproj < 1 || nproj > 3) return CXR_ERR_ARG;
+    auto mk = [&](const void* dy, const float* wf, long bs, long rs, int st) {
+        DwBwdProj p; p.dy = (const bf16_t*)dy; p.wf = wf; p.bs = bs; p.rs = rs; p.stride = st > 0 ? st : 1;
+        p.Ho = (H + 2 - 3) / p.stride + 1; p.Wo = (W + 2 - 3) / p.stride + 1; return p;
+    };
+    const long total = (long)Bn * (H * W + tok0) * (C / 8);
+    const int grid = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
+    hipLaunchKernelGGL(dwconv_bwd_dx_kernel, dim3(grid), dim3(256), 0, stream, mk(dy0, wf0, bs0, rs0, stride0), mk(dy1, wf1, bs1, rs1, stride1),
+                       mk(dy2, wf2, bs2, rs2, stride2), nproj, (bf16_t*)dx, dx_bs, dx_rs, Bn, C, H, W, tok0);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// Backward, tap sums: G[tap][c] += sum_{b,oy,ox} dy[b,(oy,ox),c] * x[b,(iy,ix),c],  S[c] += sum dy.   (fp32 atomics, per-block pre-reduced)
+__global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const bf16_t* __restrict__ x, long x_bs, long x_rs, const bf16_t* __restrict__ dy,
+                                                           long dy_bs, long dy_rs, float* __restrict__ G, float* __restrict__ S,
+                                                           int Bn, int C, int H, int W, int stride, int Ho, int Wo, int tok0, int pix_per_block) {
+    // block = (C/8 channel chunks) x (256/(C/8) pixel lanes); each thread keeps 10x8 partial sums
+    const int cch = C / 8;
+    const int cl = threadIdx.x % cch, pl = threadIdx.x / cch, npl = 256 / cch;
+    const int c8 = cl * 8;
+    float g[10][8];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[t][j] = 0.f;
+    const long npix = (long)Bn * Ho * Wo;
+    const long beg = (long)blockIdx.x * pix_per_block, end = beg + pix_per_block < npix ? beg + pix_per_block : npix;
+    if (pl < npl) {
+        for (long pix = beg + pl; pix < end; pix += npl) {
+            const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
+            float d[8];
+            unpack8(*reinterpret_cast<const uint4*>(dy + (long)b * dy_bs + (long)(tok0 + oy * Wo + ox) * dy_rs + c8), d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[9][j] += d[j];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy * stride - 1 + ky;
+                if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox * stride - 1 + kx;
+                    if (ix < 0 || ix >= W) continue;
+                    float f[8];
+                    unpack8(*reinterpret_cast<const uint4*>(x + (long)b * x_bs + (long)(tok0 + iy * W + ix) * x_rs + c8), f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[ky * 3 + kx][j] += d[j] * f[j];
+                }
+            }
+        }
+    }
+    __shared__ float red[10 * 384];
+    for (int i = threadIdx.x; i < 10 * C; i += 256) red[i] = 0.f;
+    __syncthreads();
+    if (pl < npl) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(&red[t * C + c8 + j], g[t][j]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * C; i += 256) atomicAdd(G + i, red[i]);
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(S + i, red[9 * C + i]);
+}
+
+extern "C" int cxr_dwconv_bn_bwd_w_bf16(const void* x, long x_bs, long x_rs, const void* dy, long dy_bs, long dy_rs, float* G, float* S,
+                                        int Bn, int C, int H, int W, int stride, int tok0, hipStream_t stream) {
+    if (Bn <= 0 || (C % 8) || C > 384 || (256 % (C / 8) != 0 && C / 8 > 256)) return CXR_ERR_ARG;
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const long npix = (long)Bn * Ho * Wo;
+    int ppb = (int)cdiv(npix, 1024);
+    if (ppb < 32) ppb = 32;
+    hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3(cdiv(npix, ppb)), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, (const bf16_t*)dy, dy_bs,
+                       dy_rs, G, S, Bn, C, H, W, stride, Ho, Wo, tok0, ppb);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}

@@ -1,0 +1,281 @@
+// bf16 MFMA GEMM for every dense contraction on the CXRMate hot path.
+//
+//   C[M,N] = epilogue( alpha * A[M,K] . W[N,K]^T )          ("NT": both operands K-contiguous = nn.Linear layout)
+//
+// gfx950 design: 128x128 block tile, 4 waves (2x2), each wave 64x64 as 4x4 v_mfma_f32_16x16x32_bf16 tiles;
+// operands staged HBM->LDS with 16-byte LDS-DMA (global_load_lds_dwordx4) into a double-buffered, XOR-swizzled
+// image (swizzle applied on the per-lane SOURCE address; ds_read_b128 fragment reads are bank-conflict free);
+// the MFMA is issued as D^T = W.A^T so that each lane owns 4 CONSECUTIVE output columns -> 8/16-byte epilogue
+// accesses for bias / residual / store. 1-D grid with an XCD-aware (bijective) tile remap so the 8 private L2s
+// each see a contiguous run of N-tiles sharing one A panel.
+#include "common.h"
+
+struct GemmArgs {
+    const bf16_t* A; long lda;
+    const bf16_t* W; long ldw;
+    void* C; long ldc;
+    const float* bias;            // [N] or null
+    const bf16_t* residual; long ldr;   // [M,N] or null, added after the activation
+    bf16_t* aux; long ldaux;      // act==1 && aux: pre-activation is stored here; act==2: pre-activation is read from here
+    int M, N, K;
+    float alpha;
+    int act;                      // 0 none, 1 GELU(erf), 2 multiply by GELU'(aux)  (backward of 1)
+    int out_f32;                  // 0: C is bf16, 1: C is f32
+    int accumulate;               // out_f32 only: C += result
+};
+
+template <int BK> struct Swz;
+template <> struct Swz<32> { static __device__ __forceinline__ int f(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; } };
+template <> struct Swz<64> { static __device__ __forceinline__ int f(int row) { return (row >> 1) & 7; } };
+
+template <int BK, bool GLDS>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
+    constexpr int BM = 128, BN = 128;
+    constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
+    constexpr int SLOTS = BM * CPR;             // 16-byte slots per operand tile
+    constexpr int PASSES = SLOTS / 256;
+    constexpr int TILE_BYTES = SLOTS * 16;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * TILE_BYTES];   // [buf][A|W]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    int swz;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = swz / tiles_n, tn = swz % tiles_n;
+
+    // per-thread staging sources (row clamp keeps every load in bounds; out-of-range rows are never stored)
+    const bf16_t* srcA[PASSES];
+    const bf16_t* srcW[PASSES];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int s = p * 256 + tid;
+        const int row = s / CPR, cp = s % CPR;
+        const int c = cp ^ Swz<BK>::f(row);
+        int ra = tm * BM + row; ra = ra < g.M ? ra : g.M - 1;
+        int rw = tn * BN + row; rw = rw < g.N ? rw : g.N - 1;
+        srcA[p] = g.A + (long)ra * g.lda + c * 8;
+        srcW[p] = g.W + (long)rw * g.ldw + c * 8;
+    }
+
+    auto stage = [&](int buf, int kt) {
+        unsigned char* la = lds + (buf * 2 + 0) * TILE_BYTES;
+        unsigned char* lw = lds + (buf * 2 + 1) * TILE_BYTES;
+        const long k0 = (long)kt * BK;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            if constexpr (GLDS) {
+                const int wbase = (p * 256 + wave * 64) * 16;      // wave-uniform; hardware adds lane*16
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[p] + k0),
+                                                 (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[p] + k0),
+                                                 (__attribute__((address_space(3))) void*)(lw + wbase), 16, 0, 0);
+            } else {
+                const uint4 va = *reinterpret_cast<const uint4*>(srcA[p] + k0);
+                const uint4 vw = *reinterpret_cast<const uint4*>(srcW[p] + k0);
+                *reinterpret_cast<uint4*>(la + (p * 256 + tid) * 16) = va;
+                *reinterpret_cast<uint4*>(lw + (p * 256 + tid) * 16) = vw;
+            }
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nk = g.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const unsigned char* la = lds + ((kt & 1) * 2 + 0) * TILE_BYTES;
+        const unsigned char* lw = lds + ((kt & 1) * 2 + 1) * TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8_t fa[4], fw[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ra = wm * 64 + t * 16 + fr;
+                const int rw = wn * 64 + t * 16 + fr;
+                const int c = kk * 4 + fq;
+                fa[t] = *reinterpret_cast<const bf16x8_t*>(la + (ra * CPR + (c ^ Swz<BK>::f(ra))) * 16);
+                fw[t] = *reinterpret_cast<const bf16x8_t*>(lw + (rw * CPR + (c ^ Swz<BK>::f(rw))) * 16);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+
+    // epilogue: lane owns C[m][n0..n0+3], m = .. + (lane&15), n0 = .. + (lane>>4)*4
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = tm * BM + wm * 64 + mt * 16 + fr;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n0 = tn * BN + wn * 64 + nt * 16 + fq * 4;
+            if (n0 >= g.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[nt][mt][r] * g.alpha;
+            if (g.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(g.bias + n0);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (g.act == 1) {
+                if (g.aux) {
+                    uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(g.aux + (long)m * g.ldaux + n0) = pk;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            } else if (g.act == 2) {
+                const uint2 pk = *reinterpret_cast<const uint2*>(g.aux + (long)m * g.ldaux + n0);
+                v[0] *= gelu_grad_f(__uint_as_float(pk.x << 16)); v[1] *= gelu_grad_f(__uint_as_float(pk.x & 0xffff0000u));
+                v[2] *= gelu_grad_f(__uint_as_float(pk.y << 16)); v[3] *= gelu_grad_f(__uint_as_float(pk.y & 0xffff0000u));
+            }
+            if (g.residual) {
+                const uint2 pk = *reinterpret_cast<const uint2*>(g.residual + (long)m * g.ldr + n0);
+                v[0] += __uint_as_float(pk.x << 16); v[1] += __uint_as_float(pk.x & 0xffff0000u);
+                v[2] += __uint_as_float(pk.y << 16); v[3] += __uint_as_float(pk.y & 0xffff0000u);
+            }
+            if (g.out_f32) {
+                float* c = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n0;
+                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                if (g.accumulate) {
+                    const float4 old = *reinterpret_cast<const float4*>(c);
+                    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                }
+                *reinterpret_cast<float4*>(c) = o;
+            } else {
+                uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n0) = pk;
+            }
+        }
+    }
+}
+
+static int g_gemm_regstage = 0;     // debugging aid: 1 = stage through registers instead of LDS-DMA
+
+extern "C" int cxr_gemm_set_regstage(int on) { g_gemm_regstage = on; return CXR_OK; }
+
+extern "C" int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc,
+                                const float* bias, const void* residual, long ldr, void* aux, long ldaux,
+                                int M, int N, int K, float alpha, int act, int out_f32, int accumulate,
+                                hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return CXR_ERR_ARG;
+    if ((K % 32) || (N % 4) || (lda % 8) || (ldw % 8) || (ldc % 4)) return CXR_ERR_ARG;
+    if (residual && (ldr % 4)) return CXR_ERR_ARG;
+    if (act == 2 && !aux) return CXR_ERR_ARG;
+    if (aux && (ldaux % 4)) return CXR_ERR_ARG;
+    if (accumulate && !out_f32) return CXR_ERR_ARG;
+    GemmArgs g;
+    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = C; g.ldc = ldc;
+    g.bias = bias; g.residual = (const bf16_t*)residual; g.ldr = ldr; g.aux = (bf16_t*)aux; g.ldaux = ldaux;
+    g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.act = act; g.out_f32 = out_f32; g.accumulate = accumulate;
+    const int grid = cdiv(M, 128) * cdiv(N, 128);
+    const bool bk64 = (K % 64) == 0;
+    if (g_gemm_regstage) {
+        if (bk64) hipLaunchKernelGGL((gemm_nt_kernel<64, false>), dim3(grid), dim3(256), 0, stream, g);
+        else      hipLaunchKernelGGL((gemm_nt_kernel<32, false>), dim3(grid), dim3(256), 0, stream, g);
+    } else {
+        if (bk64) hipLaunchKernelGGL((gemm_nt_kernel<64, true>), dim3(grid), dim3(256), 0, stream, g);
+        else      hipLaunchKernelGGL((gemm_nt_kernel<32, true>), dim3(grid), dim3(256), 0, stream, g);
+    }
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 2-D transpose of a bf16 matrix (used by the backward pass to present dY^T / X^T / W^T as K-contiguous operands).
+// in [R, C] (ld_in) -> out [C, R] (ld_out). 64x64 tile through LDS, 16-byte global accesses on both sides.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, long ld_in,
+                                                             bf16_t* __restrict__ out, long ld_out, int R, int C) {
+    __shared__ bf16_t tile[64][64 + 2];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int s = p * 256 + tid;            // 512 chunks of 8 elements
+        const int r = s >> 3, c8 = (s & 7) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + r < R && c0 + c8 < C) v = *reinterpret_cast<const uint4*>(in + (long)(r0 + r) * ld_in + c0 + c8);
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[r][c8 + j] = e[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int s = p * 256 + tid;
+        const int c = s >> 3, r8 = (s & 7) * 8;   // output row = input column
+        if (c0 + c < C && r0 + r8 < R) {
+            bf16_t e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = tile[r8 + j][c];
+            if (r0 + r8 + 8 <= R) {
+                *reinterpret_cast<uint4*>(out + (long)(c0 + c) * ld_out + r0 + r8) = *reinterpret_cast<const uint4*>(e);
+            } else {
+                for (int j = 0; j < 8 && r0 + r8 + j < R; ++j) out[(long)(c0 + c) * ld_out + r0 + r8 + j] = e[j];
+            }
+        }
+    }
+}
+
+extern "C" int cxr_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int C, hipStream_t stream) {
+    if (R <= 0 || C <= 0 || (C % 8) || (ld_in % 8) || (ld_out % 8)) return CXR_ERR_ARG;
+    dim3 grid(cdiv(C, 64), cdiv(R, 64));
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, R, C);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// column sums of a bf16 matrix into f32 (bias gradients): out[c] (+)= sum_r in[r][c]
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ in, long ld, float* __restrict__ out,
+                                                          int R, int C, int rows_per_block) {
+    // block handles 32 column-chunks(8 wide) x rows_per_block rows; 256 threads = 32 chunk-lanes x 8 row-lanes
+    __shared__ float red[8][256 + 8];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c8 = (blockIdx.x * 32 + cl) * 8;
+    const int rbeg = blockIdx.y * rows_per_block, rend = min(R, rbeg + rows_per_block);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c8 < C) {
+        for (int r = rbeg + rl; r < rend; r += 8) {
+            const uint4 v = *reinterpret_cast<const uint4*>(in + (long)r * ld + c8);
+            float f[8]; unpack8(v, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += f[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rl][cl * 8 + j] = acc[j];
+    __syncthreads();
+    const int col = threadIdx.x;                 // 256 columns per block
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += red[r][col];
+    const int c = blockIdx.x * 256 + col;
+    if (c < C) atomicAdd(out + c, s);
+}
+
+extern "C" int cxr_colsum_bf16(const void* in, long ld, float* out, int R, int C, hipStream_t stream) {
+    if (R <= 0 || C <= 0 || (C % 8) || (ld % 8)) return CXR_ERR_ARG;
+    const int rows_per_block = 512;
+    dim3 grid(cdiv(C, 256), cdiv(R, rows_per_block));
+    hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)in, ld, out, R, C, rows_per_block);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}

@@ -1,0 +1,273 @@
+// Vocabulary-row kernels: cross-entropy & REINFORCE loss + logits gradient, exact top-k threshold,
+// greedy argmax (lowest index wins ties, like torch.argmax), and top-k multinomial sampling. One 256-thread block per logits row
+// (V = 30000 fp32 = 120 KB: first pass from HBM, later passes from L2).
+#include "common.h"
+
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = group_max<64>(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = group_sum<64>(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// row_loss[r] = logsumexp_kept(logits[r]) - logits[r][label]   (0 for ignored rows)
+// dlogits[r][v] = row_w[r] * (softmax_kept - onehot)            (0 for ignored rows and for filtered entries)
+// "kept" = entries >= thr[r] when thr != null (top-k filtered distribution of the SCST sampler, reference scst/gt_prompt.py:189,230-235)
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ labels,
+                                                         long ignore_index, const float* __restrict__ thr, const float* __restrict__ row_w,
+                                                         float* __restrict__ row_loss, bf16_t* __restrict__ dlogits, long lddl, int V) {
+    __shared__ float sh[4];
+    const long r = blockIdx.x;
+    const float* x = logits + r * ld;
+    const long label = labels[r];
+    const bool ignored = label == ignore_index;
+    if (ignored) {
+        if (row_loss && threadIdx.x == 0) row_loss[r] = 0.f;
+        if (dlogits) for (int v = threadIdx.x * 8; v < V; v += 2048) {
+            if (v + 8 <= V) *reinterpret_cast<uint4*>(dlogits + r * lddl + v) = make_uint4(0, 0, 0, 0);
+            else for (int j = v; j < V; ++j) dlogits[r * lddl + j] = 0;
+        }
+        return;
+    }
+    const float t = thr ? thr[r] : -INFINITY;
+    float mx = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += 256) { const float a = x[v]; if (a >= t) mx = fmaxf(mx, a); }
+    mx = block_max(mx, sh);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) { const float a = x[v]; if (a >= t) s += __expf(a - mx); }
+    s = block_sum(s, sh);
+    const float lse = mx + __logf(s);
+    if (row_loss && threadIdx.x == 0) row_loss[r] = lse - x[label];
+    if (dlogits) {
+        const float w = row_w[r], inv = 1.0f / s;
+        for (int v = threadIdx.x * 8; v < V; v += 2048) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int vv = v + j;
+                float gv = 0.f;
+                if (vv < V) { const float a = x[vv]; if (a >= t) gv = __expf(a - mx) * inv; if (vv == label) gv -= 1.0f; }
+                o[j] = gv * w;
+            }
+            if (v + 8 <= V) *reinterpret_cast<uint4*>(dlogits + r * lddl + v) = pack8(o);
+            else for (int j = 0; v + j < V; ++j) dlogits[r * lddl + v + j] = f2bf(o[j]);
+        }
+    }
+}
+
+extern "C" int cxr_softmax_ce(const float* logits, long ld, const long* labels, long ignore_index, const float* thr, const float* row_w,
+                              float* row_loss, void* dlogits, long lddl, long R, int V, hipStream_t stream) {
+    if (R <= 0 || V <= 0 || (dlogits && (!row_w || (lddl % 8)))) return CXR_ERR_ARG;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, labels, ignore_index, thr, row_w, row_loss,
+                       (bf16_t*)dlogits, lddl, V);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// Row weights + scalar loss.
+//   mode 0 (teacher forcing, reference single.py:467-469): w[r] = 1/count(labels != ignore);  loss = sum row_loss / count
+//   mode 1 (REINFORCE, reference scst/gt_prompt.py:238-244): w[r] = reward[r / T] / B;          loss = mean_b(reward_b * sum_t row_loss)
+__global__ __launch_bounds__(256) void ce_weights_kernel(const long* __restrict__ labels, long R, long ignore_index, int mode,
+                                                         const float* __restrict__ reward, int T, float* __restrict__ row_w) {
+    __shared__ float sh[4];
+    float cnt = 0.f;
+    if (mode == 0) {
+        for (long r = threadIdx.x; r < R; r += 256) cnt += labels[r] != ignore_index;
+        cnt = block_sum(cnt, sh);
+    }
+    const int B = (int)(R / (T > 0 ? T : 1));
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < R; r += (long)gridDim.x * 256) {
+        const bool ig = labels[r] == ignore_index;
+        row_w[r] = ig ? 0.f : (mode == 0 ? 1.0f / fmaxf(cnt, 1.0f) : reward[r / T] / (float)B);
+    }
+}
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict__ row_loss, const float* __restrict__ row_w, long R,
+                                                        float* __restrict__ loss) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (long r = threadIdx.x; r < R; r += 256) s += row_loss[r] * row_w[r];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) *loss = s;
+}
+extern "C" int cxr_ce_weights(const long* labels, long R, long ignore_index, int mode, const float* reward, int T, float* row_w,
+                              hipStream_t stream) {
+    if (R <= 0 || (mode == 1 && (!reward || T <= 0))) return CXR_ERR_ARG;
+    hipLaunchKernelGGL(ce_weights_kernel, dim3(cdiv(R, 256) < 64 ? cdiv(R, 256) : 64), dim3(256), 0, stream, labels, R, ignore_index, mode,
+                       reward, T, row_w);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+extern "C" int cxr_ce_reduce(const float* row_loss, const float* row_w, long R, float* loss, hipStream_t stream) {
+    if (R <= 0) return CXR_ERR_ARG;
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, stream, row_loss, row_w, R, loss);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- exact k-th largest (TopKLogitsWarper threshold)
+__device__ __forceinline__ unsigned f2ord(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+
+// radix select, 4 passes of 8 bits over the order-preserving integer image of the floats; returns the k-th largest value of x[0..V)
+__device__ float kth_largest(const float* __restrict__ x, int V, int k, unsigned* hist /*[256]*/, unsigned* bcast /*[2]*/) {
+    unsigned prefix = 0u, mask = 0u;
+    int remaining = k;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        __syncthreads();
+        hist[threadIdx.x] = 0u;
+        __syncthreads();
+        for (int v = threadIdx.x; v < V; v += 256) {
+            const unsigned o = f2ord(x[v]);
+            if ((o & mask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int acc = 0, d = 255;
+            for (; d > 0; --d) { if (acc + (int)hist[d] >= remaining) break; acc += hist[d]; }
+            bcast[0] = (unsigned)d; bcast[1] = (unsigned)acc;
+        }
+        __syncthreads();
+        prefix |= bcast[0] << shift;
+        mask |= 255u << shift;
+        remaining -= (int)bcast[1];
+    }
+    return ord2f(prefix);
+}
+
+__global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __restrict__ logits, long ld, int V, int k, float* __restrict__ thr) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned bc[2];
+    const float t = kth_largest(logits + (long)blockIdx.x * ld, V, k < V ? k : V, hist, bc);
+    if (threadIdx.x == 0) thr[blockIdx.x] = t;
+}
+extern "C" int cxr_topk_threshold(const float* logits, long ld, long R, int V, int k, float* thr, hipStream_t stream) {
+    if (R <= 0 || V <= 0 || k <= 0) return CXR_ERR_ARG;
+    hipLaunchKernelGGL(topk_threshold_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, V, k, thr);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- next-token selection (K14)
+// mode 0: argmax (first maximal index).  mode 1: temperature -> top-k -> softmax -> inverse-CDF draw with the caller's uniform u[r]
+// (index order = torch.multinomial's category order). Finished rows (unfinished[r]==0) emit pad (TF5 generation/utils.py:2932-2933),
+// and a row that emits eos clears its unfinished flag.
+__global__ __launch_bounds__(256) void select_token_kernel(const float* __restrict__ logits, long ld, int V, int mode, float temperature, int top_k,
+                                                           const float* __restrict__ u, long* __restrict__ next, int* __restrict__ unfinished,
+                                                           long eos, long pad, float* __restrict__ margin) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned bc[2];
+    __shared__ float shf[4];
+    __shared__ int shi[4];
+    __shared__ float wsum[4];
+    const long r = blockIdx.x;
+    const float* x = logits + r * ld;
+    long tok;
+    if (mode == 0) {
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int v = threadIdx.x; v < V; v += 256) { const float a = x[v]; if (a > best) { best = a; bi = v; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if ((threadIdx.x & 63) == 0) { shf[threadIdx.x >> 6] = best; shi[threadIdx.x >> 6] = bi; }
+        __syncthreads();
+        best = shf[0]; bi = shi[0];
+        for (int w = 1; w < 4; ++w) if (shf[w] > best || (shf[w] == best && shi[w] < bi)) { best = shf[w]; bi = shi[w]; }
+        tok = bi;
+        if (margin) {                                   // top-1 / top-2 gap (parity gating of reduced-precision decode)
+            float second = -INFINITY;
+            for (int v = threadIdx.x; v < V; v += 256) { const float a = x[v]; if (v != bi) second = fmaxf(second, a); }
+            second = block_max(second, wsum);
+            if (threadIdx.x == 0) margin[r] = best - second;
+        }
+    } else {
+        const float invt = 1.0f / temperature;
+        float t = -INFINITY;
+        if (top_k > 0 && top_k < V) t = kth_largest(x, V, top_k, hist, bc);
+        float mx = -INFINITY;
+        for (int v = threadIdx.x; v < V; v += 256) { const float a = x[v]; if (a >= t) mx = fmaxf(mx, a * invt); }
+        mx = block_max(mx, shf);
+        // contiguous slice per thread so that the prefix order is the vocabulary order
+        const int per = (V + 255) / 256, beg = threadIdx.x * per, end = min(V, beg + per);
+        float mine = 0.f;
+        for (int v = beg; v < end; ++v) { const float a = x[v]; if (a >= t) mine += __expf(a * invt - mx); }
+        // block-wide exclusive scan of `mine`
+        float incl = mine;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const float y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        float woff = 0.f;
+        for (int w = 0; w < wv; ++w) woff += wsum[w];
+        const float total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        const float target = u[r] * total;
+        const float excl = woff + incl - mine;
+        if (threadIdx.x == 0) shi[0] = -1;
+        __syncthreads();
+        if (mine > 0.f && target >= excl && target < excl + mine) {
+            float c = excl; int pick = -1;
+            for (int v = beg; v < end; ++v) { const float a = x[v]; if (a >= t) { c += __expf(a * invt - mx); pick = v; if (target < c) break; } }
+            shi[0] = pick;
+        }
+        __syncthreads();
+        const int pick0 = shi[0];
+        __syncthreads();
+        if (pick0 < 0) {                                // numerical edge (u ~ 1): take the last kept entry
+            int last = -1;
+            for (int v = threadIdx.x; v < V; v += 256) if (x[v] >= t) last = max(last, v);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+            if (lane == 0) atomicMax(&shi[0], last);
+            __syncthreads();
+        }
+        tok = shi[0];
+    }
+    if (threadIdx.x == 0) {
+        if (unfinished) {
+            const int uf = unfinished[r];
+            if (!uf) tok = pad;
+            else if (tok == eos) unfinished[r] = 0;
+        }
+        next[r] = tok;
+    }
+}
+
+extern "C" int cxr_select_token(const float* logits, long ld, long R, int V, int mode, float temperature, int top_k, const float* u, long* next,
+                                int* unfinished, long eos, long pad, float* margin, hipStream_t stream) {
+    if (R <= 0 || V <= 0 || (mode == 1 && (!u || temperature <= 0.f))) return CXR_ERR_ARG;
+    hipLaunchKernelGGL(select_token_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, V, mode, temperature, top_k, u, next, unfinished,
+                       eos, pad, margin);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// log_softmax over the vocabulary, in place on fp32 rows (beam search scoring, TF5 generation/utils.py:3380)
+__global__ __launch_bounds__(256) void log_softmax_kernel(float* __restrict__ x, long ld, int V, const float* __restrict__ add_row) {
+    __shared__ float sh[4];
+    float* row = x + (long)blockIdx.x * ld;
+    float mx = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, row[v]);
+    mx = block_max(mx, sh);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) s += __expf(row[v] - mx);
+    s = block_sum(s, sh);
+    const float off = mx + __logf(s) - (add_row ? add_row[blockIdx.x] : 0.f);
+    for (int v = threadIdx.x; v < V; v += 256) row[v] = row[v] - off;
+}
+extern "C" int cxr_log_softmax_rows(float* x, long ld, long R, int V, const float* add_row, hipStream_t stream) {
+    if (R <= 0 || V <= 0) return CXR_ERR_ARG;
+    hipLaunchKernelGGL(log_softmax_kernel, dim3((unsigned)R), dim3(256), 0, stream, x, ld, V, add_row);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}

@@ -1,0 +1,353 @@
+"""Thin tensor-level wrappers over the C ABI (include/cxrmate_hip.h). torch is used for device memory and streams only:
+every function here allocates outputs with torch.empty/zeros and hands raw device pointers to libcxrmate_hip.so."""
+from __future__ import annotations
+
+import torch
+
+from ._lib import LIB, CxrError
+
+BF16 = torch.bfloat16
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise CxrError("cxrmate_amd kernels need CUDA(HIP) tensors; there is no CPU path")
+    return t.data_ptr()
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype=None):
+    assert t.is_contiguous() or t.stride(-1) == 1, "innermost dimension must be contiguous"
+    if dtype is not None:
+        assert t.dtype == dtype, (t.dtype, dtype)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM family
+def gemm_nt(a, w, bias=None, residual=None, act=0, aux=None, out=None, out_f32=False, accumulate=False, alpha=1.0):
+    """out[M,N] = epi(alpha * a[M,K] @ w[N,K]^T). a, w bf16 2-D (row stride arbitrary, unit column stride)."""
+    _chk(a, BF16); _chk(w, BF16)
+    M, K = a.shape
+    N, K2 = w.shape
+    assert K == K2, (a.shape, w.shape)
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else BF16)
+    assert out.shape == (M, N) and out.dtype == (torch.float32 if out_f32 else BF16)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+    if residual is not None:
+        _chk(residual, BF16); assert residual.shape == (M, N)
+    if aux is not None:
+        _chk(aux, BF16); assert aux.shape == (M, N)
+    LIB.call("cxr_gemm_nt_bf16", _p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias), _p(residual),
+             residual.stride(0) if residual is not None else 0, _p(aux), aux.stride(0) if aux is not None else 0,
+             M, N, K, float(alpha), int(act), int(out_f32), int(accumulate), _s())
+    return out
+
+
+def transpose(x, pad_cols_to=1, out=None):
+    """x [R,C] bf16 -> [C, R(padded)] (padding columns are zero)."""
+    _chk(x, BF16)
+    R, C = x.shape
+    Rp = ((R + pad_cols_to - 1) // pad_cols_to) * pad_cols_to
+    if out is None:
+        out = (torch.zeros if Rp != R else torch.empty)((C, Rp), device=x.device, dtype=BF16)
+    LIB.call("cxr_transpose_bf16", _p(x), x.stride(0), _p(out), out.stride(0), R, C, _s())
+    return out
+
+
+def colsum_into(x, out):
+    """out[c] += sum_r x[r,c]  (fp32)."""
+    _chk(x, BF16)
+    LIB.call("cxr_colsum_bf16", _p(x), x.stride(0), _p(out), x.shape[0], x.shape[1], _s())
+
+
+def linear_bwd_weight(dy, x, dw, db=None):
+    """dw[N,K] += dy[M,N]^T @ x[M,K]; db[N] += colsum(dy). Both operands are re-presented K(=M)-contiguous via transposes."""
+    dyt = transpose(dy, 64)
+    xt = transpose(x, 64)
+    gemm_nt(dyt, xt, out=dw, out_f32=True, accumulate=True)
+    if db is not None:
+        colsum_into(dy, db)
+
+
+def linear_bwd_input(dy, w_t, **kw):
+    """dx[M,K] = dy[M,N] @ w[N,K]   given w_t = w^T [K,N] (bf16)."""
+    return gemm_nt(dy, w_t, **kw)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attention(q, k, v, heads, scale, kpm=None, causal=False, causal_shift=None, need_lse=False, out=None):
+    """q [B,Tq,H*64], k/v [B,Tk,H*64] bf16 (last dim contiguous; batch/row strides free). -> out [B,Tq,H*64], lse [B,H,Tq] | None"""
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    assert D == heads * 64 and k.shape[2] == D and v.shape[2] == D
+    for t in (q, k, v):
+        assert t.dtype == BF16 and t.stride(2) == 1
+    if out is None:
+        out = torch.empty((B, Tq, D), device=q.device, dtype=BF16)
+    lse = torch.empty((B, heads, Tq), device=q.device, dtype=torch.float32) if need_lse else None
+    if kpm is not None:
+        assert kpm.dtype == torch.uint8 and kpm.shape == (B, Tk) and kpm.stride(1) == 1
+    if causal_shift is None:
+        causal_shift = Tk - Tq
+    LIB.call("cxr_attn_fwd_bf16", _p(q), _p(k), _p(v), _p(out), _p(lse), _p(kpm), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+             v.stride(0), v.stride(1), out.stride(0), out.stride(1), kpm.stride(0) if kpm is not None else 0, B, heads, Tq, Tk,
+             float(scale), int(causal), int(causal_shift), _s())
+    return out, lse
+
+
+def attention_bwd(q, k, v, o, do, lse, heads, scale, kpm=None, causal=False, causal_shift=None):
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    dq = torch.empty((B, Tq, D), device=q.device, dtype=BF16)
+    dk = torch.empty((B, Tk, D), device=q.device, dtype=BF16)
+    dv = torch.empty((B, Tk, D), device=q.device, dtype=BF16)
+    delta = torch.empty((B, heads, Tq), device=q.device, dtype=torch.float32)
+    for t in (q, k, v, o, do):
+        assert t.dtype == BF16 and t.stride(2) == 1
+    assert o.stride() == do.stride() or True
+    if causal_shift is None:
+        causal_shift = Tk - Tq
+    do = do if do.stride() == o.stride() else do.contiguous()
+    LIB.call("cxr_attn_bwd_bf16", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(kpm),
+             q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), o.stride(0), o.stride(1),
+             kpm.stride(0) if kpm is not None else 0, B, heads, Tq, Tk, float(scale), int(causal), int(causal_shift), _s())
+    return dq, dk, dv
+
+
+# ------------------------------------------------------------------------------------------------ normalisation
+def layernorm(x, gamma, beta, eps, need_stats=False, out=None):
+    """x [rows, C] bf16 (row stride free) -> y, stats[rows,2] | None"""
+    _chk(x, BF16)
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty((rows, C), device=x.device, dtype=BF16)
+    stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32) if need_stats else None
+    LIB.call("cxr_layernorm_fwd_bf16", _p(x), x.stride(0), _p(gamma), _p(beta), _p(out), out.stride(0), _p(stats), rows, C, float(eps), _s())
+    return out, stats
+
+
+def layernorm_bwd(x, dy, gamma, stats, dgamma, dbeta, add=None, out=None):
+    _chk(x, BF16); _chk(dy, BF16)
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty((rows, C), device=x.device, dtype=BF16)
+    LIB.call("cxr_layernorm_bwd_bf16", _p(x), x.stride(0), _p(dy), dy.stride(0), _p(gamma), _p(stats), _p(add),
+             add.stride(0) if add is not None else 0, _p(out), out.stride(0), _p(dgamma), _p(dbeta), rows, C, _s())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ convolutional pieces
+def im2col_pixels(px, ks, stride, pad, kpad):
+    Bn, Cin, H, W = px.shape
+    assert px.dtype == torch.float32 and px.is_contiguous()
+    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    col = torch.empty((Bn * Ho * Wo, kpad), device=px.device, dtype=BF16)
+    LIB.call("cxr_im2col_nchw_f32", _p(px), _p(col), Bn, Cin, H, W, ks, stride, pad, Ho, Wo, kpad, _s())
+    return col, Ho, Wo
+
+
+def im2col_tokens(x, H, W, stride, pad):
+    """x [Bn, H*W, C] bf16 (batch/row strides free) -> col [Bn*Ho*Wo, 9*C]"""
+    Bn, L, C = x.shape
+    assert L == H * W and x.stride(2) == 1
+    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    col = torch.empty((Bn * Ho * Wo, 9 * C), device=x.device, dtype=BF16)
+    LIB.call("cxr_im2col_tok_bf16", _p(x), x.stride(0), x.stride(1), _p(col), Bn, C, H, W, stride, pad, Ho, Wo, _s())
+    return col, Ho, Wo
+
+
+def col2im_tokens(dcol, Bn, C, H, W, stride, pad):
+    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    dx = torch.empty((Bn, H * W, C), device=dcol.device, dtype=BF16)
+    LIB.call("cxr_col2im_tok_bf16", _p(dcol), _p(dx), dx.stride(0), dx.stride(1), Bn, C, H, W, stride, pad, Ho, Wo, _s())
+    return dx
+
+
+def bn_fold(w, g, b, mean, var, eps):
+    """w [C,1,3,3] fp32 etc -> wf [9,C], sh [C] fp32"""
+    C = w.shape[0]
+    wf = torch.empty((9, C), device=w.device, dtype=torch.float32)
+    sh = torch.empty((C,), device=w.device, dtype=torch.float32)
+    LIB.call("cxr_bn_fold", _p(w), _p(g), _p(b), _p(mean), _p(var), float(eps), _p(wf), _p(sh), C, _s())
+    return wf, sh
+
+
+def bn_fold_bwd(w, g, mean, var, eps, G, S, dw, dg, db):
+    LIB.call("cxr_bn_fold_bwd", _p(w), _p(g), _p(mean), _p(var), float(eps), _p(G), _p(S), _p(dw), _p(dg), _p(db), w.shape[0], _s())
+
+
+def dwconv_bn(x, H, W, stride, tok0, fold0, fold1=None):
+    """x [Bn, tok0+H*W, C] -> y0 (and y1) [Bn, tok0+Ho*Wo, C]"""
+    Bn, L, C = x.shape
+    assert L == tok0 + H * W and x.dtype == BF16 and x.stride(2) == 1
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y0 = torch.empty((Bn, tok0 + Ho * Wo, C), device=x.device, dtype=BF16)
+    y1 = torch.empty_like(y0) if fold1 is not None else None
+    LIB.call("cxr_dwconv_bn_fwd_bf16", _p(x), x.stride(0), x.stride(1), _p(fold0[0]), _p(fold0[1]),
+             _p(fold1[0]) if fold1 is not None else None, _p(fold1[1]) if fold1 is not None else None, _p(y0), _p(y1),
+             y0.stride(0), y0.stride(1), Bn, C, H, W, stride, tok0, _s())
+    return y0, y1
+
+
+def dwconv_bn_bwd_dx(projs, Bn, C, H, W, tok0):
+    """projs: list of (dy [Bn, tok0+Ho*Wo, C], wf [9,C], stride) -> dx [Bn, tok0+H*W, C]"""
+    dx = torch.empty((Bn, tok0 + H * W, C), device=projs[0][0].device, dtype=BF16)
+    args = []
+    for i in range(3):
+        if i < len(projs):
+            dy, wf, st = projs[i]
+            args += [_p(dy), _p(wf), dy.stride(0), dy.stride(1), st]
+        else:
+            args += [None, None, 0, 0, 1]
+    LIB.call("cxr_dwconv_bn_bwd_dx_bf16", *args, len(projs), _p(dx), dx.stride(0), dx.stride(1), Bn, C, H, W, tok0, _s())
+    return dx
+
+
+def dwconv_bn_bwd_w(x, dy, H, W, stride, tok0):
+    Bn, _, C = x.shape
+    G = torch.zeros((9, C), device=x.device, dtype=torch.float32)
+    S = torch.zeros((C,), device=x.device, dtype=torch.float32)
+    LIB.call("cxr_dwconv_bn_bwd_w_bf16", _p(x), x.stride(0), x.stride(1), _p(dy), dy.stride(0), dy.stride(1), _p(G), _p(S), Bn, C, H, W,
+             stride, tok0, _s())
+    return G, S
+
+
+# ------------------------------------------------------------------------------------------------ embeddings / integer ops
+def bert_embed(ids, tt, pid, word, typ, posw, gamma, beta, eps, T, pos_offset=0, need_sum=False):
+    R = ids.numel()
+    C = word.shape[1]
+    out = torch.empty((R, C), device=ids.device, dtype=BF16)
+    ssum = torch.empty((R, C), device=ids.device, dtype=BF16) if need_sum else None
+    stats = torch.empty((R, 2), device=ids.device, dtype=torch.float32) if need_sum else None
+    LIB.call("cxr_bert_embed_fwd", _p(ids), _p(tt), _p(pid), _p(word), _p(typ), _p(posw), _p(gamma), _p(beta), float(eps), _p(ssum), _p(out),
+             _p(stats), R, T, pos_offset, C, _s())
+    return out, ssum, stats
+
+
+def bert_embed_bwd(dsum, ids, tt, pid, dword, dtype_, dpos, T, pos_offset, padding_idx):
+    LIB.call("cxr_bert_embed_bwd", _p(dsum), _p(ids), _p(tt), _p(pid), _p(dword), _p(dtype_), _p(dpos), ids.numel(), T, pos_offset,
+             int(padding_idx), dsum.shape[1], _s())
+
+
+def token_type_ids(ids, special, sections, past=False):
+    """Device version of token_ids_to_token_type_ids[_past]; ids int64 [B,T]."""
+    assert ids.dtype == torch.int64 and ids.stride(1) == 1
+    B, T = ids.shape
+    sp = torch.tensor(list(special), dtype=torch.int64, device=ids.device)
+    sections = sections if sections is not None else list(range(len(special) + 1))
+    se = torch.tensor(list(sections), dtype=torch.int64, device=ids.device)
+    out = torch.empty((B, 1 if past else T), dtype=torch.int64, device=ids.device)
+    LIB.call("cxr_token_type_ids", _p(ids), ids.stride(0), B, T, _p(sp), _p(se), len(special), _p(out), out.stride(0), int(past), _s())
+    return out
+
+
+def mask_position_ids(ids, mask_token_id):
+    assert ids.dtype == torch.int64 and ids.stride(1) == 1
+    B, T = ids.shape
+    mask = torch.empty((B, T), dtype=torch.uint8, device=ids.device)
+    pos = torch.empty((B, T), dtype=torch.int64, device=ids.device)
+    LIB.call("cxr_mask_position_ids", _p(ids), ids.stride(0), B, T, int(mask_token_id), _p(mask), mask.stride(0), _p(pos), pos.stride(0), _s())
+    return mask, pos
+
+
+def image_mask(pixel_values, tokens):
+    """pixel_values [B,N,3,H,W] fp32 -> uint8 [B, N*tokens]"""
+    B, N = pixel_values.shape[:2]
+    assert pixel_values.dtype == torch.float32 and pixel_values.is_contiguous()
+    out = torch.empty((B, N * tokens), dtype=torch.uint8, device=pixel_values.device)
+    LIB.call("cxr_image_mask", _p(pixel_values), pixel_values.stride(1), B * N, tokens, _p(out), _s())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ losses / selection
+def ce_weights(labels, ignore_index, mode=0, reward=None, T=0):
+    R = labels.numel()
+    w = torch.empty((R,), dtype=torch.float32, device=labels.device)
+    LIB.call("cxr_ce_weights", _p(labels), R, int(ignore_index), mode, _p(reward), T, _p(w), _s())
+    return w
+
+
+def softmax_ce(logits, labels, ignore_index, row_w, thr=None, need_grad=True):
+    """logits fp32 [R,V]; -> loss scalar tensor (fp32, [1]), row_loss [R], dlogits bf16 [R,V] | None"""
+    R, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    row_loss = torch.empty((R,), dtype=torch.float32, device=logits.device)
+    dl = torch.empty((R, V), dtype=BF16, device=logits.device) if need_grad else None
+    LIB.call("cxr_softmax_ce", _p(logits), logits.stride(0), _p(labels), int(ignore_index), _p(thr), _p(row_w), _p(row_loss), _p(dl),
+             dl.stride(0) if dl is not None else 0, R, V, _s())
+    loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    LIB.call("cxr_ce_reduce", _p(row_loss), _p(row_w), R, _p(loss), _s())
+    return loss, row_loss, dl
+
+
+def topk_threshold(logits, k):
+    R, V = logits.shape
+    thr = torch.empty((R,), dtype=torch.float32, device=logits.device)
+    LIB.call("cxr_topk_threshold", _p(logits), logits.stride(0), R, V, int(k), _p(thr), _s())
+    return thr
+
+
+def select_token(logits, mode=0, temperature=1.0, top_k=0, u=None, unfinished=None, eos=-1, pad=0, need_margin=False):
+    R, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    nxt = torch.empty((R,), dtype=torch.int64, device=logits.device)
+    margin = torch.empty((R,), dtype=torch.float32, device=logits.device) if need_margin else None
+    LIB.call("cxr_select_token", _p(logits), logits.stride(0), R, V, mode, float(temperature), int(top_k), _p(u), _p(nxt), _p(unfinished),
+             int(eos), int(pad), _p(margin), _s())
+    return nxt, margin
+
+
+def log_softmax_rows_(x, add_row=None):
+    LIB.call("cxr_log_softmax_rows", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(add_row), _s())
+    return x
+
+
+# ------------------------------------------------------------------------------------------------ optimiser / plumbing
+def adamw_step(p, g, m, v, p16, lr, b1, b2, eps, wd, step, gscale=1.0):
+    LIB.call("cxr_adamw_step", _p(p), _p(g), _p(m), _p(v), _p(p16), p.numel(), float(lr), float(b1), float(b2), float(eps), float(wd),
+             int(step), float(gscale), _s())
+
+
+def cast_to_bf16(src, dst=None):
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=BF16, device=src.device)
+    LIB.call("cxr_cast_f32_to_bf16", _p(src), _p(dst), src.numel(), _s())
+    return dst
+
+
+def cast_to_f32(src, dst=None):
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    LIB.call("cxr_cast_bf16_to_f32", _p(src), _p(dst), src.numel(), _s())
+    return dst
+
+
+def add(a, b, out=None):
+    rows, C = a.shape
+    if out is None:
+        out = torch.empty((rows, C), dtype=BF16, device=a.device)
+    LIB.call("cxr_add_bf16", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), rows, C, _s())
+    return out
+
+
+def copy_rows(src, dst):
+    """src, dst [B, rows, C] bf16 views (arbitrary batch/row strides)."""
+    B, rows, C = src.shape
+    assert dst.shape == src.shape and src.stride(2) == 1 and dst.stride(2) == 1
+    LIB.call("cxr_copy_rows_bf16", _p(src), src.stride(0), src.stride(1), _p(dst), dst.stride(0), dst.stride(1), B, rows, C, _s())
+    return dst
+
+
+def bcast_row(row_f32, dst):
+    """dst [B, L, C] bf16: dst[:, 0, :] = row"""
+    LIB.call("cxr_bcast_row_f32_bf16", _p(row_f32), _p(dst), dst.stride(0), dst.shape[0], dst.shape[2], _s())
+
+
+def sum_row0_into(src, out_f32):
+    LIB.call("cxr_sum_row0_bf16_f32", _p(src), src.stride(0), _p(out_f32), src.shape[0], src.shape[2], _s())

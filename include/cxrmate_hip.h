@@ -1,0 +1,113 @@
+/* cxrmate_hip.h -- C ABI of libcxrmate_hip.so: hand-written gfx950 (MI355X) kernels for the CXRMate hot path.
+ *
+ * The reference (aehrc/cxrmate) has no native boundary of its own: its model layer is a Python object API
+ * (modules/transformers/{single,multi,longitudinal}_model/modelling_*.py, tools/rewards/cxrbert.py) and all arithmetic runs
+ * inside third-party `transformers` / torch ops. This header is the FFI a maintainer would bind (ctypes stub in INTEGRATION.md)
+ * to run that arithmetic on MI355X; each entry point names the reference / third-party code whose math it replaces.
+ *   TF5:cvt  = transformers/models/cvt/modeling_cvt.py    (5.15.0)      TF5:bert = transformers/models/bert/modeling_bert.py
+ *   TF5:gen  = transformers/generation/utils.py                          REF:     = file under /root/reference
+ *
+ * Conventions: every pointer is a DEVICE pointer owned by the caller (no allocation, no ownership transfer, no host sync);
+ * activations are bf16 (raw uint16 bits) row-major "token-major" [rows, channels] with explicit leading dimensions in ELEMENTS;
+ * parameters arrive as bf16 shadows (GEMM operands) or fp32 (norm scales, biases); accumulation is fp32; `stream` is a
+ * hipStream_t; return 0 on success, <0 on error (-1 bad argument, -2 launch failure). Re-entrant per stream.
+ */
+#ifndef CXRMATE_HIP_H
+#define CXRMATE_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+/* ---- dense contractions ------------------------------------------------------------------------------------------------
+ * C[M,N] = epi(alpha * A[M,K] . W[N,K]^T): every nn.Linear of CvT (TF5:cvt:171-173,224,274-293), the projection head
+ * (REF:modules/transformers/single_model/modelling_single.py:25-40), BERT q/k/v/o/FFN/LM head (TF5:bert:164-203,289-351,466-496),
+ * the patch-embedding convs after im2col (TF5:cvt:77-90) and all their backward products (via cxr_transpose_bf16).
+ * epi: +bias[N] (fp32) -> act (0 none | 1 GELU(erf), pre-activation optionally stored to aux | 2 multiply by GELU'(aux)) -> +residual[M,N]
+ * -> store bf16 or fp32 (optionally accumulating). Requires K%32==0, N%4==0, lda/ldw%8==0. */
+int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias, const void* residual, long ldr,
+                     void* aux, long ldaux, int M, int N, int K, float alpha, int act, int out_f32, int accumulate, hipStream_t stream);
+int cxr_gemm_set_regstage(int on);   /* debug: 1 = stage operands through registers instead of LDS-DMA */
+int cxr_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int C, hipStream_t stream);
+int cxr_colsum_bf16(const void* in, long ld, float* out, int R, int C, hipStream_t stream);   /* out[c] += sum_r in[r][c] (bias grads) */
+
+/* ---- attention -----------------------------------------------------------------------------------------------------------
+ * O = softmax(scale * Q K^T + mask) V, head_dim 64, flash-style. CvT: einsum/softmax/einsum with scale = embed_dim^-0.5
+ * (TF5:cvt:152,205-209, quirk Q1); BERT eager_attention_forward (TF5:bert:111-136) with causal and/or key-padding mask
+ * (kpm[B,Tk] bytes, 1 = attend). Element (b,t,h,d) of X lives at X + b*x_bs + t*x_rs + h*64 + d. LSE[B,H,Tq] (natural log) optional. */
+int cxr_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, float* LSE, const void* kpm, long q_bs, long q_rs, long k_bs,
+                      long k_rs, long v_bs, long v_rs, long o_bs, long o_rs, long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal,
+                      int causal_shift, hipStream_t stream);
+/* backward: dQ,dK,dV (contiguous [B,T,H*64]) from dO with P recomputed from (Q,K,LSE); delta[B,H,Tq] = rowsum(dO*O) is scratch */
+int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* delta, void* dQ,
+                      void* dK, void* dV, const void* kpm, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
+                      long o_rs, long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal, int causal_shift, hipStream_t stream);
+
+/* ---- LayerNorm (TF5:cvt:79,363-364; REF:modelling_single.py:29; TF5:bert:103,292,350,478) ------------------------------- */
+int cxr_layernorm_fwd_bf16(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* stats, long rows, int C,
+                           float eps, hipStream_t stream);           /* stats[rows][2] = (mean, rstd), optional */
+int cxr_layernorm_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, const float* gamma, const float* stats, const void* add,
+                           long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, long rows, int C, hipStream_t stream);
+
+/* ---- CvT convolutional pieces ---------------------------------------------------------------------------------------------
+ * patch-embedding Conv2d (TF5:cvt:77-90) = im2col + cxr_gemm_nt_bf16; depthwise 3x3 + BatchNorm2d projections of q/k/v
+ * (TF5:cvt:93-110,157-169) on token-major activations with the class token passed through (TF5:cvt:195-198). */
+int cxr_im2col_nchw_f32(const float* px, void* col, int Bn, int Cin, int H, int W, int KS, int stride, int pad, int Ho, int Wo, int Kpad,
+                        hipStream_t stream);
+int cxr_im2col_tok_bf16(const void* x, long x_bs, long x_rs, void* col, int Bn, int Cin, int H, int W, int stride, int pad, int Ho, int Wo,
+                        hipStream_t stream);
+int cxr_col2im_tok_bf16(const void* dcol, void* dx, long dx_bs, long dx_rs, int Bn, int Cin, int H, int W, int stride, int pad, int Ho, int Wo,
+                        hipStream_t stream);
+int cxr_bn_fold(const float* w, const float* g, const float* b, const float* mean, const float* var, float eps, float* wf, float* sh, int C,
+                hipStream_t stream);
+int cxr_bn_fold_bwd(const float* w, const float* g, const float* mean, const float* var, float eps, const float* G, const float* S, float* dw,
+                    float* dg, float* db, int C, hipStream_t stream);
+int cxr_dwconv_bn_fwd_bf16(const void* x, long x_bs, long x_rs, const float* wf0, const float* sh0, const float* wf1, const float* sh1, void* y0,
+                           void* y1, long y_bs, long y_rs, int Bn, int C, int H, int W, int stride, int tok0, hipStream_t stream);
+int cxr_dwconv_bn_bwd_dx_bf16(const void* dy0, const float* wf0, long bs0, long rs0, int stride0, const void* dy1, const float* wf1, long bs1,
+                              long rs1, int stride1, const void* dy2, const float* wf2, long bs2, long rs2, int stride2, int nproj, void* dx,
+                              long dx_bs, long dx_rs, int Bn, int C, int H, int W, int tok0, hipStream_t stream);
+int cxr_dwconv_bn_bwd_w_bf16(const void* x, long x_bs, long x_rs, const void* dy, long dy_bs, long dy_rs, float* G, float* S, int Bn, int C,
+                             int H, int W, int stride, int tok0, hipStream_t stream);
+
+/* ---- BERT embeddings (TF5:bert:70-108) ------------------------------------------------------------------------------------ */
+int cxr_bert_embed_fwd(const long* ids, const long* tt, const long* pid, const void* word, const void* type, const void* posw,
+                       const float* gamma, const float* beta, float eps, void* sum_out, void* out, float* stats, long R, int T, int pos_offset,
+                       int C, hipStream_t stream);
+int cxr_bert_embed_bwd(const void* dsum, const long* ids, const long* tt, const long* pid, float* dword, float* dtype, float* dpos, long R,
+                       int T, int pos_offset, long padding_idx, int C, hipStream_t stream);
+
+/* ---- token indexing, bit-exact (REF:modules/transformers/longitudinal_model/modelling_longitudinal.py:297-364,274-277;
+ *      REF:modules/transformers/multi_model/modelling_multi.py:80) ---------------------------------------------------------- */
+int cxr_token_type_ids(const long* ids, long ld, int B, int T, const long* special, const long* sections, int nspecial, long* out, long ldo,
+                       int past, hipStream_t stream);
+int cxr_mask_position_ids(const long* ids, long ld, int B, int T, long mask_token_id, void* mask, long ldm, long* pos, long ldp,
+                          hipStream_t stream);
+int cxr_image_mask(const float* px, long img_stride, int BN, int tokens, void* out, hipStream_t stream);
+
+/* ---- losses and token selection (REF:modules/lightning_modules/single.py:467-469;
+ *      REF:modules/lightning_modules/longitudinal/scst/gt_prompt.py:211-246; TF5:gen:2894-2937; TopKLogitsWarper) ------------ */
+int cxr_softmax_ce(const float* logits, long ld, const long* labels, long ignore_index, const float* thr, const float* row_w, float* row_loss,
+                   void* dlogits, long lddl, long R, int V, hipStream_t stream);
+int cxr_ce_weights(const long* labels, long R, long ignore_index, int mode, const float* reward, int T, float* row_w, hipStream_t stream);
+int cxr_ce_reduce(const float* row_loss, const float* row_w, long R, float* loss, hipStream_t stream);
+int cxr_topk_threshold(const float* logits, long ld, long R, int V, int k, float* thr, hipStream_t stream);
+int cxr_select_token(const float* logits, long ld, long R, int V, int mode, float temperature, int top_k, const float* u, long* next,
+                     int* unfinished, long eos, long pad, float* margin, hipStream_t stream);
+int cxr_log_softmax_rows(float* x, long ld, long R, int V, const float* add_row, hipStream_t stream);
+
+/* ---- optimiser and plumbing (REF:modules/lightning_modules/single.py:426-431 torch.optim.AdamW defaults) ------------------ */
+int cxr_adamw_step(float* p, const float* g, float* m, float* v, void* p16, long n, float lr, float b1, float b2, float eps, float wd, int step,
+                   float gscale, hipStream_t stream);
+int cxr_cast_f32_to_bf16(const float* in, void* out, long n, hipStream_t stream);
+int cxr_cast_bf16_to_f32(const void* in, float* out, long n, hipStream_t stream);
+int cxr_add_bf16(const void* a, long lda, const void* b, long ldb, void* out, long ldo, long rows, int C, hipStream_t stream);
+int cxr_copy_rows_bf16(const void* in, long in_bs, long in_rs, void* out, long out_bs, long out_rs, int B, int rows, int C, hipStream_t stream);
+int cxr_bcast_row_f32_bf16(const float* row, void* out, long out_bs, int B, int C, hipStream_t stream);
+int cxr_sum_row0_bf16_f32(const void* in, long in_bs, float* out, int B, int C, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,416 @@
+"""GPU: each HIP kernel (called through the C ABI) against an fp32 torch reference of the same op on the same
+bf16-rounded inputs. Tolerances are those of bf16 storage with fp32 accumulation; integer kernels are bit-exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cxrmate_amd import ops as _ops
+    from cxrmate_amd._lib import LIB
+    LIB.load()
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + int(np.prod(shape)) % 9973)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def close(a, b, rtol=2e-2, atol=2e-2, what=""):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    denom = b.abs().max().item() + 1e-12
+    rel_rms = (err.pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-12)).item()
+    assert torch.isfinite(a).all(), f"{what}: non-finite output"
+    assert rel_rms < rtol and err.max().item() < atol * max(1.0, denom), \
+        f"{what}: rel_rms {rel_rms:.3e} max_err {err.max().item():.3e} (ref absmax {denom:.3e})"
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 192, 192), (577, 384, 1536), (1000, 30000 // 8 * 4, 768), (64, 64, 32),
+                                   (9216, 64, 192), (17, 768, 3072), (256, 128, 96)])
+@pytest.mark.parametrize("regstage", [0, 1])
+def test_gemm_plain(ops, M, N, K, regstage):
+    from cxrmate_amd._lib import LIB
+    LIB.call("cxr_gemm_set_regstage", regstage)
+    try:
+        a, w = dev(rnd(M, K).to(BF)), dev(rnd(N, K, seed=1).to(BF))
+        out = ops.gemm_nt(a, w)
+        ref = a.float() @ w.float().t()
+        close(out, ref, rtol=1e-2, atol=1e-2, what=f"gemm {M}x{N}x{K} regstage={regstage}")
+    finally:
+        LIB.call("cxr_gemm_set_regstage", 0)
+
+
+def test_gemm_asymmetric_identity(ops):
+    # A = I with an asymmetric W catches transposed / permuted fragment layouts exactly (integers are exact in bf16)
+    K = 128
+    a = torch.eye(K).to(BF).cuda()
+    w = (torch.arange(192 * K).reshape(192, K) % 251 - 125).float().to(BF).cuda()
+    out = ops.gemm_nt(a, w, out_f32=True)
+    assert torch.equal(out.cpu(), w.float().t().cpu())
+
+
+def test_gemm_epilogues(ops):
+    M, N, K = 333, 256, 192
+    a, w = dev(rnd(M, K).to(BF)), dev(rnd(N, K, seed=1, scale=0.1).to(BF))
+    bias, res = dev(rnd(N, seed=2)), dev(rnd(M, N, seed=3).to(BF))
+    base = a.float() @ w.float().t() + bias
+    close(ops.gemm_nt(a, w, bias=bias), base, what="bias")
+    aux = torch.empty(M, N, dtype=BF, device="cuda")
+    out = ops.gemm_nt(a, w, bias=bias, act=1, aux=aux, residual=res)
+    close(aux, base, what="preact")
+    close(out, torch.nn.functional.gelu(base) + res.float(), what="gelu+res")
+    # act=2: multiply by GELU'(aux)
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    out2 = ops.gemm_nt(a, w, act=2, aux=aux)
+    close(out2, (a.float() @ w.float().t()) * x.grad, what="gelu'")
+    # fp32 out with accumulate and alpha, row-strided operands
+    big = dev(rnd(M, 2 * K, seed=5).to(BF))
+    av = big[:, K:]
+    acc = dev(rnd(M, N, seed=6))
+    ref = acc + 0.5 * (av.float() @ w.float().t())
+    ops.gemm_nt(av, w, out=acc, out_f32=True, accumulate=True, alpha=0.5)
+    close(acc, ref, what="accumulate")
+
+
+def test_transpose_colsum_weightgrad(ops):
+    x = dev(rnd(577, 384).to(BF))
+    t = ops.transpose(x, 64)
+    assert t.shape == (384, 640)
+    assert torch.equal(t[:, :577].cpu(), x.t().cpu()) and bool((t[:, 577:] == 0).all())
+    out = torch.zeros(384, device="cuda")
+    ops.colsum_into(x, out)
+    close(out, x.float().sum(0), rtol=1e-3, atol=1e-3, what="colsum")
+    dy = dev(rnd(577, 192, seed=3).to(BF))
+    dw = torch.zeros(192, 384, device="cuda")
+    db = torch.zeros(192, device="cuda")
+    ops.linear_bwd_weight(dy, x, dw, db)
+    close(dw, dy.float().t() @ x.float(), what="dW")
+    close(db, dy.float().sum(0), rtol=1e-3, atol=1e-3, what="db")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def ref_attention(q, k, v, heads, scale, kpm=None, causal=False, shift=0):
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    qh = q.float().view(B, Tq, heads, 64).transpose(1, 2)
+    kh = k.float().view(B, Tk, heads, 64).transpose(1, 2)
+    vh = v.float().view(B, Tk, heads, 64).transpose(1, 2)
+    s = qh @ kh.transpose(2, 3) * scale
+    neg = torch.finfo(torch.float32).min
+    if kpm is not None:
+        s = s.masked_fill(~kpm.bool().view(B, 1, 1, Tk), neg)
+    if causal:
+        i = torch.arange(Tq, device=q.device).view(Tq, 1)
+        j = torch.arange(Tk, device=q.device).view(1, Tk)
+        s = s.masked_fill((j > i + shift).view(1, 1, Tq, Tk), neg)
+    p = torch.softmax(s, -1)
+    lse = torch.logsumexp(s, -1)
+    return (p @ vh).transpose(1, 2).reshape(B, Tq, D), lse
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,causal,masked", [(2, 1, 200, 77, False, False), (1, 3, 577, 145, False, False),
+                                                     (2, 12, 40, 40, True, True), (2, 12, 256, 256, True, False),
+                                                     (3, 12, 33, 1152, False, True), (2, 1, 1000, 2304, False, False),
+                                                     (2, 12, 1, 130, True, True)])
+def test_attention_fwd(ops, B, H, Tq, Tk, causal, masked):
+    D = H * 64
+    q, k, v = dev(rnd(B, Tq, D).to(BF)), dev(rnd(B, Tk, D, seed=1).to(BF)), dev(rnd(B, Tk, D, seed=2).to(BF))
+    kpm = None
+    if masked:
+        kpm = torch.ones(B, Tk, dtype=torch.uint8)
+        kpm[0, Tk // 2:] = 0
+        kpm[-1, 3:7] = 0
+        kpm = kpm.cuda()
+    scale = 0.125 if H > 1 else 64 ** -0.5
+    out, lse = ops.attention(q, k, v, H, scale, kpm=kpm, causal=causal, need_lse=True)
+    ref, ref_lse = ref_attention(q, k, v, H, scale, kpm, causal, Tk - Tq)
+    close(out, ref, rtol=2e-2, atol=2e-2, what="attn out")
+    close(lse, ref_lse, rtol=1e-3, atol=1e-3, what="lse")
+
+
+def test_attention_exact_integers(ops):
+    # one-hot keys/queries: softmax is (almost) a hard selection, V integers -> catches any key/lane permutation in P.V
+    B, H, T = 1, 1, 128
+    q = torch.zeros(B, T, 64)
+    k = torch.zeros(B, T, 64)
+    for t in range(T):
+        q[0, t, t % 64] = 30.0
+        k[0, t, (t * 7) % 64] = 30.0 if t < 64 else 0.0      # key t<64 is selected by queries with t%64 == (7t)%64
+    v = (torch.arange(T * 64).reshape(1, T, 64) % 127).float()
+    q, k, v = q.to(BF).cuda(), k.to(BF).cuda(), v.to(BF).cuda()
+    out, _ = ops.attention(q, k, v, 1, 1.0)
+    ref, _ = ref_attention(q, k, v, 1, 1.0)
+    close(out, ref, rtol=1e-2, atol=1e-2, what="attn onehot")
+
+
+def test_attention_strided_views(ops):
+    # q/k/v as column slices of one packed [B,T,3D] buffer and a class-token offset view
+    B, T, H = 2, 145, 6
+    D = H * 64
+    packed = dev(rnd(B, T + 1, 3 * D).to(BF))
+    q, k, v = packed[:, 1:, :D], packed[:, 1:, D:2 * D], packed[:, 1:, 2 * D:]
+    out, _ = ops.attention(q, k, v, H, 384 ** -0.5)
+    ref, _ = ref_attention(q, k, v, H, 384 ** -0.5)
+    close(out, ref, what="attn strided")
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,causal,masked", [(2, 1, 200, 77, False, False), (1, 3, 577, 145, False, False),
+                                                     (2, 12, 40, 40, True, True), (2, 12, 256, 256, True, False),
+                                                     (2, 12, 70, 1152, False, True)])
+def test_attention_bwd(ops, B, H, Tq, Tk, causal, masked):
+    D = H * 64
+    q, k, v = dev(rnd(B, Tq, D).to(BF)), dev(rnd(B, Tk, D, seed=1).to(BF)), dev(rnd(B, Tk, D, seed=2).to(BF))
+    do = dev(rnd(B, Tq, D, seed=3).to(BF))
+    kpm = None
+    if masked:
+        kpm = torch.ones(B, Tk, dtype=torch.uint8)
+        kpm[0, Tk // 2:] = 0
+        kpm[-1, 3:7] = 0
+        kpm = kpm.cuda()
+    scale = 0.125 if H > 1 else 64 ** -0.5
+    out, lse = ops.attention(q, k, v, H, scale, kpm=kpm, causal=causal, need_lse=True)
+    dq, dk, dv = ops.attention_bwd(q, k, v, out, do, lse, H, scale, kpm=kpm, causal=causal)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref, _ = ref_attention(qr, kr, vr, H, scale, kpm, causal, Tk - Tq)
+    ref.backward(do.float())
+    close(dq, qr.grad, rtol=3e-2, atol=3e-2, what="dq")
+    close(dk, kr.grad, rtol=3e-2, atol=3e-2, what="dk")
+    close(dv, vr.grad, rtol=3e-2, atol=3e-2, what="dv")
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("C", [64, 128, 192, 384, 768])
+def test_layernorm_fwd_bwd(ops, C):
+    rows = 1000 + C // 64
+    x = dev((rnd(rows, C) * 2 + 0.5).to(BF))
+    g, b = dev(1 + 0.1 * rnd(C, seed=1)), dev(0.1 * rnd(C, seed=2))
+    y, stats = ops.layernorm(x, g, b, 1e-5, need_stats=True)
+    xr = x.float().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-5)
+    close(y, ref, what=f"ln fwd C={C}")
+    dy = dev(rnd(rows, C, seed=3).to(BF))
+    add = dev(rnd(rows, C, seed=4).to(BF))
+    ref.backward(dy.float())
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx = ops.layernorm_bwd(x, dy, g, stats, dg, db, add=add)
+    close(dx, xr.grad + add.float(), what=f"ln dx C={C}")
+    close(dg, gr.grad, rtol=1e-2, atol=1e-2, what="ln dgamma")
+    close(db, br.grad, rtol=1e-2, atol=1e-2, what="ln dbeta")
+
+
+# ------------------------------------------------------------------------------------------------ conv pieces
+def test_im2col_pixels_matches_conv(ops):
+    px = dev(rnd(2, 3, 96, 96))
+    w = dev(rnd(64, 3, 7, 7, seed=1, scale=0.1))
+    col, Ho, Wo = ops.im2col_pixels(px, 7, 4, 2, 192)
+    wp = torch.zeros(64, 192, device="cuda")
+    wp[:, :147] = w.view(64, -1)
+    out = ops.gemm_nt(col, wp.to(BF))
+    ref = torch.nn.functional.conv2d(px, w.to(BF).float(), stride=4, padding=2)
+    ref = ref.flatten(2).transpose(1, 2).reshape(-1, 64)
+    close(out, ref, what="patch conv 7x7")
+
+
+def test_im2col_tokens_and_col2im(ops):
+    Bn, C, H, W = 2, 64, 24, 24
+    x = dev(rnd(Bn, H * W, C).to(BF))
+    w = dev(rnd(192, C, 3, 3, seed=1, scale=0.1))
+    col, Ho, Wo = ops.im2col_tokens(x, H, W, 2, 1)
+    wp = w.permute(0, 2, 3, 1).reshape(192, 9 * C).contiguous().to(BF)
+    out = ops.gemm_nt(col, wp)
+    xi = x.float().transpose(1, 2).reshape(Bn, C, H, W).requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xi, w.to(BF).float(), stride=2, padding=1)
+    close(out, ref.flatten(2).transpose(1, 2).reshape(-1, 192), what="conv 3x3 s2")
+    # col2im == conv input gradient
+    dy = dev(rnd(Bn * Ho * Wo, 192, seed=2).to(BF))
+    dcol = ops.gemm_nt(dy, ops.transpose(wp))
+    dx = ops.col2im_tokens(dcol, Bn, C, H, W, 2, 1)
+    ref.backward(dy.float().view(Bn, Ho * Wo, 192).transpose(1, 2).reshape(Bn, 192, Ho, Wo))
+    close(dx, xi.grad.flatten(2).transpose(1, 2), what="col2im")
+
+
+@pytest.mark.parametrize("C,H,tok0", [(64, 24, 0), (192, 12, 0), (384, 6, 1)])
+def test_dwconv_bn_fwd_bwd(ops, C, H, tok0):
+    Bn, W = 3, H
+    x = dev(rnd(Bn, tok0 + H * W, C).to(BF))
+    par = {}
+    for name, seed in (("q", 1), ("k", 2), ("v", 3)):
+        par[name] = dict(w=dev(rnd(C, 1, 3, 3, seed=seed, scale=0.3)), g=dev(1 + 0.1 * rnd(C, seed=seed + 10)), b=dev(0.1 * rnd(C, seed=seed + 20)),
+                         mean=dev(0.1 * rnd(C, seed=seed + 30)), var=dev(1 + 0.1 * rnd(C, seed=seed + 40).abs()))
+    fold = {n: ops.bn_fold(p["w"], p["g"], p["b"], p["mean"], p["var"], 1e-5) for n, p in par.items()}
+    yq, _ = ops.dwconv_bn(x, H, W, 1, tok0, fold["q"])
+    yk, yv = ops.dwconv_bn(x, H, W, 2, tok0, fold["k"], fold["v"])
+    xs = x[:, tok0:].float().transpose(1, 2).reshape(Bn, C, H, W).requires_grad_(True)
+    leaves = {n: {k: v.clone().requires_grad_(k in ("w", "g", "b")) for k, v in p.items()} for n, p in par.items()}
+
+    def ref(n, stride):
+        p = leaves[n]
+        y = torch.nn.functional.conv2d(xs, p["w"], None, stride=stride, padding=1, groups=C)
+        y = torch.nn.functional.batch_norm(y, p["mean"], p["var"], p["g"], p["b"], False, 0.0, 1e-5)
+        return y.flatten(2).transpose(1, 2)
+
+    refs = {"q": ref("q", 1), "k": ref("k", 2), "v": ref("v", 2)}
+    for n, y in (("q", yq), ("k", yk), ("v", yv)):
+        close(y[:, tok0:], refs[n], what=f"dwconv {n}")
+        if tok0:
+            assert torch.equal(y[:, 0], x[:, 0])
+    dys = {n: dev(rnd(*y.shape, seed=7 + i).to(BF)) for i, (n, y) in enumerate((("q", yq), ("k", yk), ("v", yv)))}
+    sum(((refs[n] * dys[n][:, tok0:].float()).sum() for n in refs)).backward()
+    dx = ops.dwconv_bn_bwd_dx([(dys["q"], fold["q"][0], 1), (dys["k"], fold["k"][0], 2), (dys["v"], fold["v"][0], 2)], Bn, C, H, W, tok0)
+    close(dx[:, tok0:], xs.grad.flatten(2).transpose(1, 2), what="dwconv dx")
+    if tok0:
+        close(dx[:, 0], sum(d[:, 0].float() for d in dys.values()), what="dwconv dx cls")
+    for n, stride in (("q", 1), ("k", 2), ("v", 2)):
+        G, S = ops.dwconv_bn_bwd_w(x, dys[n], H, W, stride, tok0)
+        p = par[n]
+        dw, dg, db = torch.zeros(C, 9, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        ops.bn_fold_bwd(p["w"], p["g"], p["mean"], p["var"], 1e-5, G, S, dw, dg, db)
+        close(dw.view(C, 1, 3, 3), leaves[n]["w"].grad, what=f"dwconv dW {n}")
+        close(dg, leaves[n]["g"].grad, what=f"bn dgamma {n}")
+        close(db, leaves[n]["b"].grad, what=f"bn dbeta {n}")
+
+
+# ------------------------------------------------------------------------------------------------ embeddings / integer ops
+def test_bert_embed_fwd_bwd(ops):
+    V, T, B, C = 500, 20, 3, 768
+    word, typ, pos = dev(rnd(V, C).to(BF)), dev(rnd(2, C, seed=1).to(BF)), dev(rnd(64, C, seed=2).to(BF))
+    g, b = dev(1 + 0.1 * rnd(C, seed=3)), dev(0.1 * rnd(C, seed=4))
+    gen = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, V, (B, T), generator=gen).cuda()
+    tt = torch.randint(0, 2, (B, T), generator=gen).cuda()
+    pid = torch.randint(0, 64, (B, T), generator=gen).cuda()
+    out, ssum, stats = ops.bert_embed(ids, tt, pid, word, typ, pos, g, b, 1e-12, T, need_sum=True)
+    ref_sum = word.float()[ids] + typ.float()[tt] + pos.float()[pid]
+    ref = torch.nn.functional.layer_norm(ref_sum, (C,), g, b, 1e-12).view(-1, C)
+    close(out, ref, what="embed")
+    out2, _, _ = ops.bert_embed(ids, None, None, word, typ, pos, g, b, 1e-12, T, pos_offset=3)
+    ref2 = word.float()[ids] + typ.float()[0] + pos.float()[torch.arange(T).cuda() + 3]
+    close(out2, torch.nn.functional.layer_norm(ref2, (C,), g, b, 1e-12).view(-1, C), what="embed default ids")
+    dsum = dev(rnd(B * T, C, seed=5).to(BF))
+    dw, dt, dp = torch.zeros(V, C, device="cuda"), torch.zeros(2, C, device="cuda"), torch.zeros(64, C, device="cuda")
+    ops.bert_embed_bwd(dsum, ids, tt, pid, dw, dt, dp, T, 0, padding_idx=0)
+    rw = torch.zeros(V, C, device="cuda").index_add_(0, ids.view(-1), dsum.float())
+    rw[0] = 0
+    close(dw, rw, rtol=1e-3, atol=1e-3, what="dword")
+    close(dt, torch.zeros(2, C, device="cuda").index_add_(0, tt.view(-1), dsum.float()), rtol=1e-3, atol=1e-3, what="dtype")
+    close(dp, torch.zeros(64, C, device="cuda").index_add_(0, pid.view(-1), dsum.float()), rtol=1e-3, atol=1e-3, what="dpos")
+
+
+def test_token_ops_bit_exact(ops):
+    import golden_util as gu
+    from oracle import token_ops
+    g = gu.load("token_ops.json")
+    for case in g["random"] + g["documented"]:
+        ids = torch.tensor(case["ids"], dtype=torch.int64).cuda()
+        tt = ops.token_type_ids(ids, case["special"], case["sections"])
+        ttp = ops.token_type_ids(ids, case["special"], case["sections"], past=True)
+        assert tt.cpu().tolist() == case["token_type_ids"], case
+        assert ttp.cpu().tolist() == case["token_type_ids_past"], case
+    gen = torch.Generator().manual_seed(3)
+    for T in (1, 5, 64, 65, 200, 512):
+        ids = torch.randint(0, 6, (4, T), generator=gen)
+        mask, pos = ops.mask_position_ids(ids.cuda(), 4)
+        assert np.array_equal(mask.cpu().numpy(), (ids != 4).numpy().astype(np.uint8))
+        assert np.array_equal(pos.cpu().numpy(), token_ops.position_ids_from_mask((ids != 4).numpy()))
+    px = torch.randn(3, 2, 3, 8, 8)
+    px[1, 1] = 0
+    px[2, 0, 0, 0, 0] = 0
+    m = ops.image_mask(px.cuda(), 36)
+    assert torch.equal(m.cpu().bool(), (px[:, :, 0, 0, 0] != 0).repeat_interleave(36, dim=1))
+
+
+# ------------------------------------------------------------------------------------------------ losses / selection
+def test_softmax_ce_and_reinforce(ops):
+    R, V = 37, 30000
+    logits = dev(rnd(R, V) * 2)
+    labels = torch.randint(5, V, (R,), generator=torch.Generator().manual_seed(1))
+    labels[::5] = 4
+    labels = labels.cuda()
+    w = ops.ce_weights(labels, 4)
+    loss, row_loss, dl = ops.softmax_ce(logits, labels, 4, w)
+    lr = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, labels, ignore_index=4)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-4
+    close(dl, lr.grad, rtol=2e-2, atol=2e-2, what="dlogits")
+    # REINFORCE over top-k filtered scores: B=3, T=5
+    B, T, k = 3, 5, 50
+    logits = dev(rnd(B * T, V, seed=2) * 2)
+    thr = ops.topk_threshold(logits, k)
+    kth = torch.topk(logits, k)[0][:, -1]
+    assert torch.equal(thr, kth)
+    sampled = torch.topk(logits, k)[1][:, 7].clone()
+    sampled[4] = 4
+    reward = torch.tensor([0.3, -0.2, 0.9]).cuda()
+    w = ops.ce_weights(sampled, 4, mode=1, reward=reward, T=T)
+    loss, _, dl = ops.softmax_ce(logits, sampled, 4, w, thr=thr)
+    lr = logits.clone().requires_grad_(True)
+    scores = lr.masked_fill(lr < kth[:, None], float("-inf")).view(B, T, V).permute(0, 2, 1)
+    nll = torch.nn.functional.nll_loss(torch.log_softmax(scores, 1), sampled.view(B, T), ignore_index=4, reduction="none")
+    ref = (nll.sum(-1) * reward).mean()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-4, (loss.item(), ref.item())
+    close(dl, lr.grad, rtol=2e-2, atol=2e-2, what="reinforce dlogits")
+
+
+def test_select_token(ops):
+    R, V = 16, 30000
+    logits = dev(rnd(R, V))
+    logits[3, 100] = logits[3, 20000] = 50.0            # tie -> lowest index
+    nxt, margin = ops.select_token(logits, need_margin=True)
+    assert torch.equal(nxt, logits.argmax(-1)) and nxt[3].item() == 100
+    t2 = torch.topk(logits, 2)[0]
+    close(margin, t2[:, 0] - t2[:, 1], rtol=1e-5, atol=1e-5, what="margin")
+    unf = torch.ones(R, dtype=torch.int32).cuda()
+    unf[5] = 0
+    eos = int(nxt[7])
+    out, _ = ops.select_token(logits, unfinished=unf, eos=eos, pad=4)
+    assert out[5].item() == 4 and out[7].item() == eos and unf[7].item() == 0 and unf[6].item() == 1
+    # sampling: draws land inside the top-k set and follow the filtered distribution
+    k = 50
+    row = logits[:1].expand(4096, V).contiguous()
+    u = torch.rand(4096, generator=torch.Generator().manual_seed(5)).cuda()
+    draws, _ = ops.select_token(row, mode=1, temperature=0.7, top_k=k, u=u)
+    topv, topi = torch.topk(logits[0], k)
+    assert bool(torch.isin(draws, topi).all())
+    p = torch.softmax(topv / 0.7, -1)
+    freq = torch.stack([(draws == i).float().mean() for i in topi])
+    assert (freq - p).abs().max().item() < 0.03
+    # inverse-CDF order is the vocabulary order: u -> 0 picks the smallest kept index, u -> 1 the largest
+    lo, _ = ops.select_token(row[:1], mode=1, temperature=1.0, top_k=k, u=torch.tensor([0.0]).cuda())
+    hi, _ = ops.select_token(row[:1], mode=1, temperature=1.0, top_k=k, u=torch.tensor([0.999999]).cuda())
+    assert lo.item() == topi.min().item() and hi.item() == topi.max().item()
+
+
+def test_adamw_matches_torch(ops):
+    n = 4096 * 3
+    p = dev(rnd(n))
+    g = dev(rnd(n, seed=1))
+    ref_p = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref_p], lr=1e-3)
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    p16 = torch.empty(n, dtype=BF, device="cuda")
+    for step in range(1, 4):
+        ref_p.grad = g.clone() * step
+        opt.step()
+        ops.adamw_step(p, g * step, m, v, p16, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+    close(p, ref_p.detach(), rtol=1e-5, atol=1e-5, what="adamw")
+    assert torch.equal(p16, p.to(BF))
