@@ -31,10 +31,8 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     const bool ignored = label == ignore_index;
     if (ignored) {
         if (row_loss && threadIdx.x == 0) row_loss[r] = 0.f;
-        if (dlogits) for (int v = threadIdx.x * 8; v < V; v += 2048) {
-            if (v + 8 <= V) *reinterpret_cast<uint4*>(dlogits + r * lddl + v) = make_uint4(0, 0, 0, 0);
-            else for (int j = v; j < V; ++j) dlogits[r * lddl + j] = 0;
-        }
+        if (dlogits) for (int v = threadIdx.x * 8; v < (int)lddl; v += 2048)
+            *reinterpret_cast<uint4*>(dlogits + r * lddl + v) = make_uint4(0, 0, 0, 0);
         return;
     }
     const float t = thr ? thr[r] : -INFINITY;
@@ -48,7 +46,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     if (row_loss && threadIdx.x == 0) row_loss[r] = lse - x[label];
     if (dlogits) {
         const float w = row_w[r], inv = 1.0f / s;
-        for (int v = threadIdx.x * 8; v < V; v += 2048) {
+        for (int v = threadIdx.x * 8; v < (int)lddl; v += 2048) {      // columns [V, lddl) are zero padding (K of the next GEMM)
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -57,8 +55,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
                 if (vv < V) { const float a = x[vv]; if (a >= t) gv = __expf(a - mx) * inv; if (vv == label) gv -= 1.0f; }
                 o[j] = gv * w;
             }
-            if (v + 8 <= V) *reinterpret_cast<uint4*>(dlogits + r * lddl + v) = pack8(o);
-            else for (int j = 0; v + j < V; ++j) dlogits[r * lddl + v + j] = f2bf(o[j]);
+            *reinterpret_cast<uint4*>(dlogits + r * lddl + v) = pack8(o);
         }
     }
 }

@@ -324,3 +324,22 @@ extern "C" int cxr_sum_row0_bf16_f32(const void* in, long in_bs, float* out, int
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
+
+// dx = dy * GELU'(u)   (LM-head transform backward, TF5 modeling_bert.py:466-481)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ u, bf16_t* __restrict__ dx, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float a[8], b[8];
+        unpack8(*reinterpret_cast<const uint4*>(dy + i * 8), a);
+        unpack8(*reinterpret_cast<const uint4*>(u + i * 8), b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] *= gelu_grad_f(b[j]);
+        *reinterpret_cast<uint4*>(dx + i * 8) = pack8(a);
+    }
+}
+extern "C" int cxr_gelu_bwd_bf16(const void* dy, const void* u, void* dx, long n, hipStream_t stream) {
+    if (n <= 0 || (n % 8)) return CXR_ERR_ARG;
+    const int grid = (int)(cdiv(n / 8, 256) < 8192 ? cdiv(n / 8, 256) : 8192);
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)u, (bf16_t*)dx, n / 8);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}

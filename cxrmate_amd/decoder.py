@@ -1,0 +1,317 @@
+"""BERT decoder with cross-attention (BertLMHeadModel) on MI355X: teacher-forced forward, hand-written backward and
+KV-cached decode steps over the HIP kernels. Also runs the bidirectional CXR-BERT stand-in (no cross-attention, no LM head).
+
+Mirrors transformers' BertLMHeadModel as driven by the reference forward()
+(modules/transformers/longitudinal_model/modelling_longitudinal.py:212-224; TF5 = transformers/models/bert/modeling_bert.py
+@ 5.15.0: embeddings :70-108, eager attention :111-136, layers :374-411, LM head :466-496). LoRA on self-attention query/key
+(modelling_longitudinal.py:163-170) is merged into the effective weight W + (alpha/r) B A before the GEMM (dropout is identity).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .config import BertConfig
+
+BF16 = torch.bfloat16
+
+
+class KVCache:
+    """Per-layer self-attention K/V [B, Tmax, D] (appended in place) and cross-attention K/V [B, S, D] (projected once)."""
+
+    def __init__(self, layers, B, Tmax, D, device):
+        self.k = [torch.empty((B, Tmax, D), dtype=BF16, device=device) for _ in range(layers)]
+        self.v = [torch.empty((B, Tmax, D), dtype=BF16, device=device) for _ in range(layers)]
+        self.k2 = [torch.empty((B, Tmax, D), dtype=BF16, device=device) for _ in range(layers)]   # reorder targets (beam search)
+        self.v2 = [torch.empty((B, Tmax, D), dtype=BF16, device=device) for _ in range(layers)]
+        self.ck = [None] * layers
+        self.cv = [None] * layers
+        self.len = 0
+        self.Tmax = Tmax
+
+    def reorder(self, idx):
+        """self K/V <- K/V[idx] (TF5 generation/utils.py:3468-3478)."""
+        for l in range(len(self.k)):
+            ops.gather_batch(self.k[l], idx, self.len, self.k2[l])
+            ops.gather_batch(self.v[l], idx, self.len, self.v2[l])
+            self.k[l], self.k2[l] = self.k2[l], self.k[l]
+            self.v[l], self.v2[l] = self.v2[l], self.v[l]
+
+
+class BertEngine:
+    def __init__(self, store, cfg: BertConfig, prefix: str = "decoder."):
+        self.s, self.cfg = store, cfg
+        self.p = prefix + ("base_model.model." if cfg.lora_r else "")
+        self._prep_version = -1
+        self._prep = {}
+
+    # ------------------------------------------------------------------------------------------ parameters
+    def _lin(self, base):
+        """-> (weight bf16 [N,K], bias fp32 [N]) of an nn.Linear or a LoRA-wrapped Linear (merged)."""
+        st = self.s
+        if st.has(base + ".weight"):
+            return st.w16(base + ".weight"), st.f32(base + ".bias")
+        return self.prepare()[("lora", base)], st.f32(base + ".base_layer.bias")
+
+    def prepare(self):
+        st = self.s
+        st.refresh_shadow()
+        if self._prep_version == st.shadow_version:
+            return self._prep
+        prep = {}
+        cfg = self.cfg
+        if cfg.lora_r:
+            scale = cfg.lora_alpha / cfg.lora_r
+            for l in range(cfg.num_hidden_layers):
+                for name in ("query", "key"):
+                    base = self.p + f"bert.encoder.layer.{l}.attention.self.{name}"
+                    d = cfg.hidden_size
+                    b_pad = torch.zeros((d, 32), dtype=BF16, device=st.device)
+                    ops.copy_rows(st.w16(base + ".lora_B.default.weight").view(1, d, cfg.lora_r), b_pad[:, :cfg.lora_r].unsqueeze(0))
+                    a_t = ops.transpose(st.w16(base + ".lora_A.default.weight"), 32)          # [d, 32]: A^T zero padded
+                    w = st.f32(base + ".base_layer.weight").clone()
+                    ops.gemm_nt(b_pad, a_t, out=w, out_f32=True, accumulate=True, alpha=scale)   # W + (alpha/r) B A
+                    prep[("lora", base)] = ops.cast_to_bf16(w)
+        self._prep, self._prep_version = prep, st.shadow_version
+        return prep
+
+    # ------------------------------------------------------------------------------------------ teacher-forced forward
+    def forward(self, ids, enc=None, enc_mask=None, attn_mask=None, token_type_ids=None, position_ids=None, save=False, causal=True,
+                lm_head=True):
+        """ids int64 [B,T]; enc bf16 [B,S,D] | None; masks uint8 (1 = attend). -> logits fp32 [B,T,V] (or hidden bf16 [B,T,D]), saved"""
+        cfg, st, p = self.cfg, self.s, self.p
+        self.prepare()
+        B, T = ids.shape
+        D, nh = cfg.hidden_size, cfg.num_attention_heads
+        R = B * T
+        e = p + "bert.embeddings."
+        h, esum, estats = ops.bert_embed(ids, token_type_ids, position_ids, st.w16(e + "word_embeddings.weight"),
+                                         st.w16(e + "token_type_embeddings.weight"), st.w16(e + "position_embeddings.weight"),
+                                         st.f32(e + "LayerNorm.weight"), st.f32(e + "LayerNorm.bias"), cfg.layer_norm_eps, T, need_sum=save)
+        saved = dict(B=B, T=T, ids=ids, tt=token_type_ids, pos=position_ids, esum=esum, estats=estats, attn_mask=attn_mask, enc=enc,
+                     enc_mask=enc_mask, causal=causal, layers=[]) if save else None
+        scale = cfg.head_dim ** -0.5
+        for l in range(cfg.num_hidden_layers):
+            lp = p + f"bert.encoder.layer.{l}."
+            sv = {}
+            wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key"); wv, bv = self._lin(lp + "attention.self.value")
+            q = ops.gemm_nt(h, wq, bias=bq).view(B, T, D)
+            k = ops.gemm_nt(h, wk, bias=bk).view(B, T, D)
+            v = ops.gemm_nt(h, wv, bias=bv).view(B, T, D)
+            ctx, lse = ops.attention(q, k, v, nh, scale, kpm=attn_mask, causal=causal, need_lse=save)
+            wo, bo = self._lin(lp + "attention.output.dense")
+            a1 = ops.gemm_nt(ctx.view(R, D), wo, bias=bo, residual=h)
+            h1, s1 = ops.layernorm(a1, st.f32(lp + "attention.output.LayerNorm.weight"), st.f32(lp + "attention.output.LayerNorm.bias"),
+                                   cfg.layer_norm_eps, need_stats=save)
+            if save:
+                sv.update(h=h, q=q, k=k, v=v, ctx=ctx, lse=lse, a1=a1, s1=s1, h1=h1)
+            if cfg.add_cross_attention and enc is not None:
+                S = enc.shape[1]
+                cq, cbq = self._lin(lp + "crossattention.self.query"); ck, cbk = self._lin(lp + "crossattention.self.key")
+                cv, cbv = self._lin(lp + "crossattention.self.value"); co, cbo = self._lin(lp + "crossattention.output.dense")
+                q2 = ops.gemm_nt(h1, cq, bias=cbq).view(B, T, D)
+                k2 = ops.gemm_nt(enc.view(B * S, D), ck, bias=cbk).view(B, S, D)
+                v2 = ops.gemm_nt(enc.view(B * S, D), cv, bias=cbv).view(B, S, D)
+                ctx2, lse2 = ops.attention(q2, k2, v2, nh, scale, kpm=enc_mask, need_lse=save)
+                a2 = ops.gemm_nt(ctx2.view(R, D), co, bias=cbo, residual=h1)
+                h2, s2 = ops.layernorm(a2, st.f32(lp + "crossattention.output.LayerNorm.weight"), st.f32(lp + "crossattention.output.LayerNorm.bias"),
+                                       cfg.layer_norm_eps, need_stats=save)
+                if save:
+                    sv.update(q2=q2, k2=k2, v2=v2, ctx2=ctx2, lse2=lse2, a2=a2, s2=s2, h2=h2)
+            else:
+                h2 = h1
+            w1, b1 = self._lin(lp + "intermediate.dense"); w2, b2 = self._lin(lp + "output.dense")
+            u = torch.empty((R, cfg.intermediate_size), dtype=BF16, device=ids.device) if save else None
+            f = ops.gemm_nt(h2, w1, bias=b1, act=1, aux=u)
+            a3 = ops.gemm_nt(f, w2, bias=b2, residual=h2)
+            h, s3 = ops.layernorm(a3, st.f32(lp + "output.LayerNorm.weight"), st.f32(lp + "output.LayerNorm.bias"), cfg.layer_norm_eps, need_stats=save)
+            if save:
+                sv.update(u=u, f=f, a3=a3, s3=s3, h2in=h2)
+                saved["layers"].append(sv)
+        if not lm_head:
+            if save:
+                saved["h_out"] = h
+            return h.view(B, T, D), saved
+        logits, hs = self._lm_head(h, save)
+        if save:
+            saved.update(h_out=h, **hs)
+        return logits.view(B, T, -1), saved
+
+    def _lm_head(self, h, save):
+        """BertLMPredictionHead (TF5:bert:466-496): dense -> GELU -> LayerNorm -> tied projection + bias; logits fp32."""
+        cfg, st, p = self.cfg, self.s, self.p
+        c = p + "cls.predictions."
+        tu = torch.empty((h.shape[0], cfg.hidden_size), dtype=BF16, device=h.device) if save else None
+        t = ops.gemm_nt(h, st.w16(c + "transform.dense.weight"), bias=st.f32(c + "transform.dense.bias"), act=1, aux=tu)
+        tn, ts = ops.layernorm(t, st.f32(c + "transform.LayerNorm.weight"), st.f32(c + "transform.LayerNorm.bias"), cfg.layer_norm_eps, need_stats=save)
+        logits = ops.gemm_nt(tn, st.w16(p + "bert.embeddings.word_embeddings.weight"), bias=st.f32(c + "bias"), out_f32=True)
+        return logits, dict(tu=tu, t=t, ts=ts, tn=tn)
+
+    # ------------------------------------------------------------------------------------------ backward
+    def _wgrad(self, base, dy, x):
+        """Accumulate dW/db of a (possibly LoRA-wrapped) Linear."""
+        st = self.s
+        if st.has(base + ".weight"):
+            ops.linear_bwd_weight(dy, x, st.grad(base + ".weight"), st.grad(base + ".bias"))
+            return
+        cfg = self.cfg
+        scale = cfg.lora_alpha / cfg.lora_r
+        dw = torch.zeros(st.f32(base + ".base_layer.weight").shape, dtype=torch.float32, device=dy.device)
+        ops.linear_bwd_weight(dy, x, dw, st.grad(base + ".base_layer.bias"))
+        st.grad(base + ".base_layer.weight").add_(dw)
+        dw16 = ops.cast_to_bf16(dw)
+        # dB[n,r] = s * sum_k dW[n,k] A[r,k] ;  dA[r,k] = s * sum_n B[n,r] dW[n,k]
+        ops.gemm_nt(dw16, st.w16(base + ".lora_A.default.weight"), out=st.grad(base + ".lora_B.default.weight"), out_f32=True,
+                    accumulate=True, alpha=scale)
+        bt = ops.transpose(st.w16(base + ".lora_B.default.weight"))                 # [r, d]
+        ops.gemm_nt(bt, ops.transpose(dw16), out=st.grad(base + ".lora_A.default.weight"), out_f32=True, accumulate=True, alpha=scale)
+
+    def _wt(self, base):
+        return ops.transpose(self._lin(base)[0])
+
+    def backward(self, saved, dlogits=None, dhidden=None, need_denc=False):
+        """dlogits bf16 [R, V] (row stride may be padded to a multiple of 64) or dhidden bf16 [R, D]. Accumulates parameter
+        gradients into the store; returns d(enc) bf16 [B,S,D] when need_denc."""
+        cfg, st, p = self.cfg, self.s, self.p
+        self.prepare()
+        st.ensure_grads()
+        B, T = saved["B"], saved["T"]
+        R, D, nh = B * T, cfg.hidden_size, cfg.num_attention_heads
+        g = st.grad
+        if dlogits is not None:
+            c = p + "cls.predictions."
+            V = cfg.vocab_size
+            Vp = ((V + 63) // 64) * 64
+            if dlogits.stride(0) >= Vp and dlogits.stride(0) % 8 == 0:
+                dlp = dlogits.as_strided((R, Vp), (dlogits.stride(0), 1))        # padded columns are zero by construction (ops.softmax_ce)
+            else:
+                dlp = torch.zeros((R, Vp), dtype=BF16, device=dlogits.device)
+                ops.copy_rows(dlogits.unsqueeze(0), dlp[:, :V].unsqueeze(0))
+            word = st.w16(p + "bert.embeddings.word_embeddings.weight")
+            ops.colsum_into(dlp[:, :V], g(c + "bias"))
+            ops.gemm_nt(ops.transpose(dlp[:, :V], 64), ops.transpose(saved["tn"], 64), out=g(p + "bert.embeddings.word_embeddings.weight"),
+                        out_f32=True, accumulate=True)
+            dtn = ops.gemm_nt(dlp, ops.transpose(word, 64))                       # K = Vp
+            dt = ops.layernorm_bwd(saved["t"], dtn, st.f32(c + "transform.LayerNorm.weight"), saved["ts"], g(c + "transform.LayerNorm.weight"),
+                                   g(c + "transform.LayerNorm.bias"))
+            dtu = ops.gelu_bwd(dt, saved["tu"])
+            ops.linear_bwd_weight(dtu, saved["h_out"], g(c + "transform.dense.weight"), g(c + "transform.dense.bias"))
+            dh = ops.gemm_nt(dtu, ops.transpose(st.w16(c + "transform.dense.weight")))
+        else:
+            dh = dhidden
+        denc = None
+        enc = saved["enc"]
+        if need_denc and enc is not None:
+            denc = torch.zeros((enc.shape[0] * enc.shape[1], D), dtype=torch.float32, device=dh.device)
+        scale = cfg.head_dim ** -0.5
+        for l in reversed(range(cfg.num_hidden_layers)):
+            lp = p + f"bert.encoder.layer.{l}."
+            sv = saved["layers"][l]
+            da3 = ops.layernorm_bwd(sv["a3"], dh, st.f32(lp + "output.LayerNorm.weight"), sv["s3"], g(lp + "output.LayerNorm.weight"),
+                                    g(lp + "output.LayerNorm.bias"))
+            self._wgrad(lp + "output.dense", da3, sv["f"])
+            du = ops.gemm_nt(da3, self._wt(lp + "output.dense"), act=2, aux=sv["u"])
+            self._wgrad(lp + "intermediate.dense", du, sv["h2in"])
+            dh2 = ops.gemm_nt(du, self._wt(lp + "intermediate.dense"), residual=da3)
+            if "a2" in sv:
+                S = enc.shape[1]
+                da2 = ops.layernorm_bwd(sv["a2"], dh2, st.f32(lp + "crossattention.output.LayerNorm.weight"), sv["s2"],
+                                        g(lp + "crossattention.output.LayerNorm.weight"), g(lp + "crossattention.output.LayerNorm.bias"))
+                self._wgrad(lp + "crossattention.output.dense", da2, sv["ctx2"].view(R, D))
+                dctx2 = ops.gemm_nt(da2, self._wt(lp + "crossattention.output.dense")).view(B, T, D)
+                dq2, dk2, dv2 = ops.attention_bwd(sv["q2"], sv["k2"], sv["v2"], sv["ctx2"], dctx2, sv["lse2"], nh, scale, kpm=saved["enc_mask"])
+                self._wgrad(lp + "crossattention.self.query", dq2.view(R, D), sv["h1"])
+                self._wgrad(lp + "crossattention.self.key", dk2.view(B * S, D), enc.view(B * S, D))
+                self._wgrad(lp + "crossattention.self.value", dv2.view(B * S, D), enc.view(B * S, D))
+                if denc is not None:
+                    ops.gemm_nt(dk2.view(B * S, D), self._wt(lp + "crossattention.self.key"), out=denc, out_f32=True, accumulate=True)
+                    ops.gemm_nt(dv2.view(B * S, D), self._wt(lp + "crossattention.self.value"), out=denc, out_f32=True, accumulate=True)
+                dh1 = ops.gemm_nt(dq2.view(R, D), self._wt(lp + "crossattention.self.query"), residual=da2)
+            else:
+                dh1 = dh2
+            da1 = ops.layernorm_bwd(sv["a1"], dh1, st.f32(lp + "attention.output.LayerNorm.weight"), sv["s1"],
+                                    g(lp + "attention.output.LayerNorm.weight"), g(lp + "attention.output.LayerNorm.bias"))
+            self._wgrad(lp + "attention.output.dense", da1, sv["ctx"].view(R, D))
+            dctx = ops.gemm_nt(da1, self._wt(lp + "attention.output.dense")).view(B, T, D)
+            dq, dk, dv = ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, scale, kpm=saved["attn_mask"],
+                                           causal=saved["causal"])
+            self._wgrad(lp + "attention.self.query", dq.view(R, D), sv["h"])
+            self._wgrad(lp + "attention.self.key", dk.view(R, D), sv["h"])
+            self._wgrad(lp + "attention.self.value", dv.view(R, D), sv["h"])
+            t1 = ops.gemm_nt(dq.view(R, D), self._wt(lp + "attention.self.query"), residual=da1)
+            t2 = ops.gemm_nt(dk.view(R, D), self._wt(lp + "attention.self.key"), residual=t1)
+            dh = ops.gemm_nt(dv.view(R, D), self._wt(lp + "attention.self.value"), residual=t2)
+        e = p + "bert.embeddings."
+        dsum = ops.layernorm_bwd(saved["esum"], dh, st.f32(e + "LayerNorm.weight"), saved["estats"], g(e + "LayerNorm.weight"), g(e + "LayerNorm.bias"))
+        ops.bert_embed_bwd(dsum, saved["ids"], saved["tt"], saved["pos"], g(e + "word_embeddings.weight"), g(e + "token_type_embeddings.weight"),
+                           g(e + "position_embeddings.weight"), T, 0, cfg.pad_token_id)
+        if denc is not None:
+            return ops.cast_to_bf16(denc).view(enc.shape)
+        return None
+
+    # ------------------------------------------------------------------------------------------ cached decode
+    def new_cache(self, B, Tmax, device):
+        return KVCache(self.cfg.num_hidden_layers, B, Tmax, self.cfg.hidden_size, device)
+
+    def decode(self, cache: KVCache, ids_new, enc, enc_mask, attn_mask_full, token_type_ids, position_ids):
+        """One cached step. ids_new [B,Tn] (Tn = prompt length at prefill, 1 afterwards); attn_mask_full uint8 [B, len+Tn] | None.
+        Returns fp32 logits of the LAST position [B, V] (TF5 generation/utils.py:2894)."""
+        cfg, st, p = self.cfg, self.s, self.p
+        self.prepare()
+        B, Tn = ids_new.shape
+        D, nh = cfg.hidden_size, cfg.num_attention_heads
+        past = cache.len
+        R = B * Tn
+        e = p + "bert.embeddings."
+        h, _, _ = ops.bert_embed(ids_new, token_type_ids, position_ids, st.w16(e + "word_embeddings.weight"),
+                                 st.w16(e + "token_type_embeddings.weight"), st.w16(e + "position_embeddings.weight"),
+                                 st.f32(e + "LayerNorm.weight"), st.f32(e + "LayerNorm.bias"), cfg.layer_norm_eps, Tn, pos_offset=past)
+        scale = cfg.head_dim ** -0.5
+        for l in range(cfg.num_hidden_layers):
+            lp = p + f"bert.encoder.layer.{l}."
+            wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key"); wv, bv = self._lin(lp + "attention.self.value")
+            q = ops.gemm_nt(h, wq, bias=bq).view(B, Tn, D)
+            if Tn == 1:                                                       # project straight into the cache row
+                ops.gemm_nt(h, wk, bias=bk, out=cache.k[l][:, past, :])
+                ops.gemm_nt(h, wv, bias=bv, out=cache.v[l][:, past, :])
+            else:
+                ops.copy_rows(ops.gemm_nt(h, wk, bias=bk).view(B, Tn, D), cache.k[l][:, past:past + Tn, :])
+                ops.copy_rows(ops.gemm_nt(h, wv, bias=bv).view(B, Tn, D), cache.v[l][:, past:past + Tn, :])
+            kk, vv = cache.k[l][:, :past + Tn, :], cache.v[l][:, :past + Tn, :]
+            ctx, _ = ops.attention(q, kk, vv, nh, scale, kpm=attn_mask_full, causal=True, causal_shift=past)
+            wo, bo = self._lin(lp + "attention.output.dense")
+            a1 = ops.gemm_nt(ctx.view(R, D), wo, bias=bo, residual=h)
+            h1, _ = ops.layernorm(a1, st.f32(lp + "attention.output.LayerNorm.weight"), st.f32(lp + "attention.output.LayerNorm.bias"), cfg.layer_norm_eps)
+            if cfg.add_cross_attention and enc is not None:
+                S = enc.shape[1]
+                if cache.ck[l] is None:
+                    ck, cbk = self._lin(lp + "crossattention.self.key"); cv, cbv = self._lin(lp + "crossattention.self.value")
+                    cache.ck[l] = ops.gemm_nt(enc.reshape(B * S, D), ck, bias=cbk).view(B, S, D)
+                    cache.cv[l] = ops.gemm_nt(enc.reshape(B * S, D), cv, bias=cbv).view(B, S, D)
+                cq, cbq = self._lin(lp + "crossattention.self.query"); co, cbo = self._lin(lp + "crossattention.output.dense")
+                q2 = ops.gemm_nt(h1, cq, bias=cbq).view(B, Tn, D)
+                ctx2, _ = ops.attention(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask)
+                a2 = ops.gemm_nt(ctx2.view(R, D), co, bias=cbo, residual=h1)
+                h2, _ = ops.layernorm(a2, st.f32(lp + "crossattention.output.LayerNorm.weight"), st.f32(lp + "crossattention.output.LayerNorm.bias"),
+                                      cfg.layer_norm_eps)
+            else:
+                h2 = h1
+            w1, b1 = self._lin(lp + "intermediate.dense"); w2, b2 = self._lin(lp + "output.dense")
+            f = ops.gemm_nt(h2, w1, bias=b1, act=1)
+            a3 = ops.gemm_nt(f, w2, bias=b2, residual=h2)
+            h, _ = ops.layernorm(a3, st.f32(lp + "output.LayerNorm.weight"), st.f32(lp + "output.LayerNorm.bias"), cfg.layer_norm_eps)
+        cache.len = past + Tn
+        last = h.view(B, Tn, D)[:, -1, :]                                      # [B, D] view, row stride Tn*D
+        logits, _ = self._lm_head(last, False)
+        return logits
+
+    # ------------------------------------------------------------------------------------------ CXR-BERT stand-in head
+    def cls_projection(self, hidden, prefix=""):
+        """last_hidden_state[:,0] -> Linear(768,128) -> GELU -> LayerNorm(128) -> Linear(128,128)  (assumption)."""
+        st, cfg = self.s, self.cfg
+        c = prefix + "cls_projection_head."
+        B, T, D = hidden.shape
+        cls = hidden[:, 0, :]
+        x = ops.gemm_nt(cls, st.w16(c + "dense_to_hidden.weight"), bias=st.f32(c + "dense_to_hidden.bias"), act=1)
+        x, _ = ops.layernorm(x, st.f32(c + "LayerNorm.weight"), st.f32(c + "LayerNorm.bias"), cfg.layer_norm_eps)
+        return ops.gemm_nt(x, st.w16(c + "dense_to_output.weight"), bias=st.f32(c + "dense_to_output.bias"), out_f32=True)

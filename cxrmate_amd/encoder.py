@@ -1,0 +1,216 @@
+"""CvT-21 + projection head on MI355X: forward and hand-written backward over the HIP kernels.
+
+Mirrors CvtWithProjectionHead / MultiCvtWithProjectionHead of the reference
+(modules/transformers/single_model/modelling_single.py:43-78, multi_model/modelling_multi.py:43-87) on top of
+transformers' CvtModel (TF5 = transformers/models/cvt/modeling_cvt.py @ 5.15.0). Activations are kept token-major
+[Bn, L, C] in bf16 for the whole network (the reference flips between NCHW and token-major around every conv).
+BatchNorm runs with its running statistics folded into the depthwise taps (eval semantics, SURVEY.md Q7/Q11 explain
+why parity fixtures are eval-mode); dropout / DropPath are identity.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .config import CvtConfig
+
+
+class CvtEncoderEngine:
+    def __init__(self, store, cfg: CvtConfig, prefix: str = "encoder."):
+        self.s, self.cfg, self.p = store, cfg, prefix
+        self._prep_version = -1
+        self._prep = {}
+
+    # ------------------------------------------------------------------------------------------ weight preparation
+    def _stage(self, s):
+        return f"{self.p}cvt.encoder.stages.{s}."
+
+    def prepare(self):
+        """Per-weight-version re-layouts: conv taps as GEMM operands, BatchNorm folded into the depthwise taps."""
+        st = self.s
+        st.refresh_shadow()
+        if self._prep_version == st.shadow_version:
+            return self._prep
+        cfg, prep = self.cfg, {}
+        for s in range(len(cfg.depth)):
+            sp = self._stage(s)
+            w = st.w16(sp + "embedding.convolution_embeddings.projection.weight")
+            co = w.shape[0]
+            if s == 0:
+                k = w.shape[1] * w.shape[2] * w.shape[3]
+                kpad = ((k + 63) // 64) * 64
+                wp = torch.zeros((co, kpad), dtype=torch.bfloat16, device=w.device)
+                wp[:, :k] = w.reshape(co, k)                         # K order (c, ky, kx) = weight.view(Cout, -1)
+            else:
+                wp = w.permute(0, 2, 3, 1).reshape(co, -1).contiguous()   # K order (ky, kx, c): channel-contiguous gathers
+            prep[("embed", s)] = wp
+            for l in range(cfg.depth[s]):
+                lp = sp + f"layers.{l}.attention.attention."
+                for name in ("query", "key", "value"):
+                    cp = lp + f"convolution_projection_{name}.convolution_projection."
+                    prep[("fold", s, l, name)] = ops.bn_fold(
+                        st.f32(cp + "convolution.weight"), st.f32(cp + "normalization.weight"), st.f32(cp + "normalization.bias"),
+                        st.f32(cp + "normalization.running_mean"), st.f32(cp + "normalization.running_var"), cfg.bn_eps)
+        self._prep, self._prep_version = prep, st.shadow_version
+        return prep
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, px: torch.Tensor, save: bool = False):
+        """px [Bn,3,H,W] fp32 (contiguous) -> feats [Bn*tokens, projection_size] bf16, saved-activation dict | None"""
+        cfg, st = self.cfg, self.s
+        prep = self.prepare()
+        Bn = px.shape[0]
+        saved = {"Bn": Bn, "stages": []} if save else None
+        x = None            # [Bn, H*W, C] output of the previous stage (no class token)
+        H = W = None
+        for s in range(len(cfg.depth)):
+            sp = self._stage(s)
+            C = cfg.embed_dim[s]
+            ep = sp + "embedding.convolution_embeddings."
+            if s == 0:
+                col, Ho, Wo = ops.im2col_pixels(px, cfg.patch_sizes[0], cfg.patch_stride[0], cfg.patch_padding[0], prep[("embed", 0)].shape[1])
+            else:
+                col, Ho, Wo = ops.im2col_tokens(x, H, W, cfg.patch_stride[s], cfg.patch_padding[s])
+            e = ops.gemm_nt(col, prep[("embed", s)], bias=st.f32(ep + "projection.bias"))
+            tok0 = 1 if cfg.cls_token[s] else 0
+            L = tok0 + Ho * Wo
+            xs = torch.empty((Bn, L, C), dtype=torch.bfloat16, device=px.device)
+            if tok0:
+                y, estats = ops.layernorm(e, st.f32(ep + "normalization.weight"), st.f32(ep + "normalization.bias"), cfg.inner_layer_norm_eps, need_stats=save)
+                ops.copy_rows(y.view(Bn, Ho * Wo, C), xs[:, 1:, :])
+                ops.bcast_row(st.f32(sp + "cls_token"), xs)
+            else:
+                _, estats = ops.layernorm(e, st.f32(ep + "normalization.weight"), st.f32(ep + "normalization.bias"), cfg.inner_layer_norm_eps,
+                                          need_stats=save, out=xs.view(Bn * L, C))
+            H, W = Ho, Wo
+            ssave = {"col": col, "e": e, "estats": estats, "H": H, "W": W, "layers": []} if save else None
+            cur = xs
+            for l in range(cfg.depth[s]):
+                cur, lsave = self._layer_fwd(cur, s, l, H, W, tok0, prep, save)
+                if save:
+                    ssave["layers"].append(lsave)
+            if save:
+                saved["stages"].append(ssave)
+            if tok0:
+                x = torch.empty((Bn, H * W, C), dtype=torch.bfloat16, device=px.device)
+                ops.copy_rows(cur[:, 1:, :], x)
+            else:
+                x = cur
+        # projection head: LayerNorm(eps = config.layer_norm_eps) -> Linear(384 -> 768, no bias)
+        hp = self.p + "projection_head."
+        C = cfg.embed_dim[-1]
+        hn, hstats = ops.layernorm(x.view(-1, C), st.f32(hp + "layer_norm.weight"), st.f32(hp + "layer_norm.bias"), cfg.layer_norm_eps, need_stats=save)
+        feats = ops.gemm_nt(hn, st.w16(hp + "projection.weight"))
+        if save:
+            saved.update(x_last=x, hn=hn, hstats=hstats)
+        return feats, saved
+
+    def _layer_fwd(self, x, s, l, H, W, tok0, prep, save):
+        cfg, st = self.cfg, self.s
+        lp = self._stage(s) + f"layers.{l}."
+        ap = lp + "attention.attention."
+        Bn, L, C = x.shape
+        nh = cfg.num_heads[s]
+        x2d = x.view(Bn * L, C)
+        h1, st1 = ops.layernorm(x2d, st.f32(lp + "layernorm_before.weight"), st.f32(lp + "layernorm_before.bias"), cfg.inner_layer_norm_eps, need_stats=save)
+        h1 = h1.view(Bn, L, C)
+        qc, _ = ops.dwconv_bn(h1, H, W, cfg.stride_q[s], tok0, prep[("fold", s, l, "query")])
+        kc, vc = ops.dwconv_bn(h1, H, W, cfg.stride_kv[s], tok0, prep[("fold", s, l, "key")], prep[("fold", s, l, "value")])
+        Lk = kc.shape[1]
+        q = ops.gemm_nt(qc.view(-1, C), st.w16(ap + "projection_query.weight"), bias=st.f32(ap + "projection_query.bias")).view(Bn, L, C)
+        k = ops.gemm_nt(kc.view(-1, C), st.w16(ap + "projection_key.weight"), bias=st.f32(ap + "projection_key.bias")).view(Bn, Lk, C)
+        v = ops.gemm_nt(vc.view(-1, C), st.w16(ap + "projection_value.weight"), bias=st.f32(ap + "projection_value.bias")).view(Bn, Lk, C)
+        ctx, lse = ops.attention(q, k, v, nh, C ** -0.5, need_lse=save)                  # scale = embed_dim^-0.5 (quirk Q1)
+        x2 = ops.gemm_nt(ctx.view(-1, C), st.w16(lp + "attention.output.dense.weight"), bias=st.f32(lp + "attention.output.dense.bias"), residual=x2d)
+        h2, st2 = ops.layernorm(x2, st.f32(lp + "layernorm_after.weight"), st.f32(lp + "layernorm_after.bias"), cfg.inner_layer_norm_eps, need_stats=save)
+        Ch = st.w16(lp + "intermediate.dense.weight").shape[0]
+        u = torch.empty((Bn * L, Ch), dtype=torch.bfloat16, device=x.device) if save else None
+        g = ops.gemm_nt(h2, st.w16(lp + "intermediate.dense.weight"), bias=st.f32(lp + "intermediate.dense.bias"), act=1, aux=u)
+        x3 = ops.gemm_nt(g, st.w16(lp + "output.dense.weight"), bias=st.f32(lp + "output.dense.bias"), residual=x2)
+        lsave = None
+        if save:
+            lsave = dict(x=x, st1=st1, h1=h1, qc=qc, kc=kc, vc=vc, q=q, k=k, v=v, ctx=ctx, lse=lse, x2=x2, st2=st2, h2=h2, u=u, g=g)
+        return x3.view(Bn, L, C), lsave
+
+    # ------------------------------------------------------------------------------------------ backward
+    def backward(self, saved, dfeats: torch.Tensor):
+        """dfeats [Bn*tokens, projection_size] bf16. Parameter gradients are ACCUMULATED into the store's flat gradient buffer."""
+        cfg, st = self.cfg, self.s
+        prep = self.prepare()
+        st.ensure_grads()
+        Bn = saved["Bn"]
+        hp = self.p + "projection_head."
+        C = cfg.embed_dim[-1]
+        ops.linear_bwd_weight(dfeats, saved["hn"], st.grad(hp + "projection.weight"))
+        dhn = ops.gemm_nt(dfeats, ops.transpose(st.w16(hp + "projection.weight")))
+        dx = ops.layernorm_bwd(saved["x_last"].view(-1, C), dhn, st.f32(hp + "layer_norm.weight"), saved["hstats"],
+                               st.grad(hp + "layer_norm.weight"), st.grad(hp + "layer_norm.bias"))
+        dx = dx.view(Bn, -1, C)                                     # grad wrt stage output tokens (no class token)
+        for s in reversed(range(len(cfg.depth))):
+            sp = self._stage(s)
+            C = cfg.embed_dim[s]
+            ss = saved["stages"][s]
+            H, W = ss["H"], ss["W"]
+            tok0 = 1 if cfg.cls_token[s] else 0
+            if tok0:
+                full = torch.zeros((Bn, 1 + H * W, C), dtype=torch.bfloat16, device=dx.device)   # class-token output is discarded -> zero grad
+                ops.copy_rows(dx, full[:, 1:, :])
+                dx = full
+            for l in reversed(range(cfg.depth[s])):
+                dx = self._layer_bwd(dx, ss["layers"][l], s, l, H, W, tok0, prep)
+            if tok0:
+                ops.sum_row0_into(dx, st.grad(sp + "cls_token").view(-1))
+                dsp = torch.empty((Bn, H * W, C), dtype=torch.bfloat16, device=dx.device)
+                ops.copy_rows(dx[:, 1:, :], dsp)
+                dx = dsp
+            ep = sp + "embedding.convolution_embeddings."
+            de = ops.layernorm_bwd(ss["e"], dx.view(-1, C), st.f32(ep + "normalization.weight"), ss["estats"],
+                                   st.grad(ep + "normalization.weight"), st.grad(ep + "normalization.bias"))
+            wp = prep[("embed", s)]
+            dwp = torch.zeros(wp.shape, dtype=torch.float32, device=dx.device)
+            ops.linear_bwd_weight(de, ss["col"], dwp, st.grad(ep + "projection.bias"))
+            gw = st.grad(ep + "projection.weight")
+            if s == 0:
+                gw.add_(dwp[:, :gw[0].numel()].view(gw.shape))                           # layout plumbing back to [Co,Ci,kh,kw]
+            else:
+                gw.add_(dwp.view(gw.shape[0], gw.shape[2], gw.shape[3], gw.shape[1]).permute(0, 3, 1, 2))
+                dcol = ops.gemm_nt(de, ops.transpose(wp))
+                Hp = Wp = cfg.grid(s - 1)
+                dx = ops.col2im_tokens(dcol, Bn, cfg.embed_dim[s - 1], Hp, Wp, cfg.patch_stride[s], cfg.patch_padding[s])
+        return None
+
+    def _layer_bwd(self, dy, sv, s, l, H, W, tok0, prep):
+        cfg, st = self.cfg, self.s
+        lp = self._stage(s) + f"layers.{l}."
+        ap = lp + "attention.attention."
+        Bn, L, C = dy.shape
+        nh = cfg.num_heads[s]
+        dy2 = dy.reshape(Bn * L, C)
+        g = st.grad
+        # MLP:  x3 = x2 + W2 gelu(W1 h2 + b1) + b2
+        ops.linear_bwd_weight(dy2, sv["g"], g(lp + "output.dense.weight"), g(lp + "output.dense.bias"))
+        du = ops.gemm_nt(dy2, ops.transpose(st.w16(lp + "output.dense.weight")), act=2, aux=sv["u"])
+        ops.linear_bwd_weight(du, sv["h2"], g(lp + "intermediate.dense.weight"), g(lp + "intermediate.dense.bias"))
+        dh2 = ops.gemm_nt(du, ops.transpose(st.w16(lp + "intermediate.dense.weight")))
+        dx2 = ops.layernorm_bwd(sv["x2"], dh2, st.f32(lp + "layernorm_after.weight"), sv["st2"], g(lp + "layernorm_after.weight"),
+                                g(lp + "layernorm_after.bias"), add=dy2)
+        # attention output projection: x2 = x + Wo ctx + bo
+        ops.linear_bwd_weight(dx2, sv["ctx"].view(-1, C), g(lp + "attention.output.dense.weight"), g(lp + "attention.output.dense.bias"))
+        dctx = ops.gemm_nt(dx2, ops.transpose(st.w16(lp + "attention.output.dense.weight"))).view(Bn, L, C)
+        dq, dk, dv = ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, C ** -0.5)
+        projs = []
+        for name, d, inp, stride in (("query", dq, sv["qc"], cfg.stride_q[s]), ("key", dk, sv["kc"], cfg.stride_kv[s]),
+                                     ("value", dv, sv["vc"], cfg.stride_kv[s])):
+            ops.linear_bwd_weight(d.view(-1, C), inp.view(-1, C), g(ap + f"projection_{name}.weight"), g(ap + f"projection_{name}.bias"))
+            dc = ops.gemm_nt(d.view(-1, C), ops.transpose(st.w16(ap + f"projection_{name}.weight"))).view(d.shape)
+            wf, _ = prep[("fold", s, l, name)]
+            projs.append((dc, wf, stride))
+            G, S = ops.dwconv_bn_bwd_w(sv["h1"], dc, H, W, stride, tok0)
+            cp = ap + f"convolution_projection_{name}.convolution_projection."
+            ops.bn_fold_bwd(st.f32(cp + "convolution.weight"), st.f32(cp + "normalization.weight"), st.f32(cp + "normalization.running_mean"),
+                            st.f32(cp + "normalization.running_var"), cfg.bn_eps, G, S, g(cp + "convolution.weight"),
+                            g(cp + "normalization.weight"), g(cp + "normalization.bias"))
+        dh1 = ops.dwconv_bn_bwd_dx(projs, Bn, C, H, W, tok0)
+        dx = ops.layernorm_bwd(sv["x"].view(-1, C), dh1.view(-1, C), st.f32(lp + "layernorm_before.weight"), sv["st1"],
+                               g(lp + "layernorm_before.weight"), g(lp + "layernorm_before.bias"), add=dx2)
+        return dx.view(Bn, L, C)

@@ -1,0 +1,232 @@
+"""Autoregressive generation for the MI355X engines: greedy, top-k sampling and beam search with a KV cache.
+
+Replaces what the reference obtains from transformers' GenerationMixin (TF5 = transformers/generation/utils.py @ 5.15.0:
+generate :2260, _sample :2783, _beam_search :3208) together with the reference's own per-step input assembly
+`prepare_inputs_for_generation` (modules/transformers/longitudinal_model/modelling_longitudinal.py:251-295 and the
+single/multi variants). Behaviour kept: BOS is prepended when no row of the prompt starts with it (:850-907) and the
+longitudinal model strips it again before feeding the decoder (:270-271); finished rows keep emitting PAD (:2932);
+`generate.__wrapped__` (no torch.no_grad) returns `scores` that carry autograd -- implemented as sample-then-recompute:
+the sampled sequence is re-scored by ONE teacher-forced pass whose per-step inputs are exactly those of the cached steps.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class GenerationMixin:
+    # ------------------------------------------------------------------------------------------ per-step inputs
+    def _fed(self, ids, bos_token_id):
+        if self.kind == "longitudinal" and bool(torch.all(ids[:, 0] == bos_token_id)):
+            return ids[:, 1:]
+        return ids
+
+    def _step_inputs(self, fed, special_token_ids, mask_token_id, prefill):
+        """-> (ids_new, attention_mask_full | None, token_type_ids, position_ids | None)"""
+        if self.kind == "longitudinal":
+            mask, pos = ops.mask_position_ids(fed.contiguous(), mask_token_id)
+            if prefill:
+                tt = ops.token_type_ids(fed.contiguous(), special_token_ids, [0, 1, 0, 1])
+                return fed, mask, tt, pos
+            tt = ops.token_type_ids(fed.contiguous(), special_token_ids, [0, 1, 0, 1], past=True)
+            return fed[:, -1:], mask, tt, pos[:, -1:]
+        if prefill:
+            return fed, None, ops.token_type_ids(fed.contiguous(), special_token_ids, None), None
+        return fed[:, -1:], None, ops.token_type_ids(fed.contiguous(), special_token_ids, None, past=True), None
+
+    # ------------------------------------------------------------------------------------------ generate
+    def _generate(self, inputs=None, pixel_values=None, encoder_outputs=None, decoder_input_ids=None, input_ids=None,
+                  special_token_ids=None, mask_token_id=None, max_length=None, max_new_tokens=None, bos_token_id=None,
+                  eos_token_id=None, pad_token_id=None, num_beams=1, do_sample=False, top_k=50, top_p=1.0, temperature=1.0,
+                  output_scores=False, return_dict_in_generate=False, use_cache=True, length_penalty=1.0, return_margins=False,
+                  forced_tokens=None, **unused):
+        from .modelling import ModelOutput
+        if inputs is not None and pixel_values is None:
+            pixel_values = inputs
+        if special_token_ids is None:
+            raise ValueError("special_token_ids is required (reference prepare_inputs_for_generation signature)")
+        if self.kind == "longitudinal" and mask_token_id is None:
+            raise ValueError("mask_token_id is required for the longitudinal model")
+        if top_p is not None and float(top_p) < 1.0:
+            raise NotImplementedError("top_p < 1 is not on the accelerated path (the reference samples with top_p=1.0)")
+        with torch.no_grad():
+            if encoder_outputs is None:
+                encoder_outputs = self._encode(pixel_values)
+        enc = encoder_outputs[0]
+        enc_mask = encoder_outputs.get("attention_mask") if isinstance(encoder_outputs, dict) else None
+        if self.kind == "single":
+            enc_mask = None
+        dev = self.device
+        B = enc.shape[0]
+        prompt = decoder_input_ids if decoder_input_ids is not None else input_ids
+        start = torch.full((B, 1), bos_token_id, dtype=torch.int64, device=dev)
+        if prompt is None:
+            ids = start
+        else:
+            prompt = prompt.to(device=dev, dtype=torch.int64)
+            ids = torch.cat([start, prompt], dim=-1) if bool((prompt[:, 0] != bos_token_id).all()) else prompt
+        if max_new_tokens is not None:
+            max_length = ids.shape[1] + max_new_tokens
+        if max_length is None:
+            max_length = 20 + ids.shape[1]
+        enc16 = (enc if enc.dtype == torch.bfloat16 else ops.cast_to_bf16(enc.float().contiguous())).detach().contiguous()
+        enc_mask8 = None if enc_mask is None else enc_mask.to(device=dev, dtype=torch.uint8).contiguous()
+        if num_beams > 1:
+            if do_sample:
+                raise NotImplementedError("beam sampling is not used by the reference")
+            with torch.no_grad():
+                seqs, seq_scores = self._beam_search(ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, num_beams,
+                                                     bos_token_id, eos_token_id, pad_token_id, length_penalty)
+            if return_dict_in_generate:
+                return ModelOutput(sequences=seqs, sequences_scores=seq_scores if output_scores else None)
+            return seqs
+
+        prompt_len = ids.shape[1]
+        rec = {"tt": [], "pos": []}
+        margins = []
+        with torch.no_grad():
+            cache = self._dec.new_cache(B, max_length, dev)
+            unfinished = torch.ones(B, dtype=torch.int32, device=dev)
+            step = 0
+            while ids.shape[1] < max_length:
+                fed = self._fed(ids, bos_token_id)
+                new, mask, tt, pos = self._step_inputs(fed, special_token_ids, mask_token_id, prefill=cache.len == 0)
+                logits = self._dec.decode(cache, new.contiguous(), enc16, enc_mask8, mask, tt.contiguous(),
+                                          None if pos is None else pos.contiguous())
+                if output_scores and do_sample:
+                    rec["tt"].append(tt)
+                    rec["pos"].append(pos)
+                if do_sample:
+                    u = torch.rand(B, device=dev, dtype=torch.float32)
+                    nxt, _ = ops.select_token(logits, mode=1, temperature=temperature, top_k=top_k or 0, u=u,
+                                              unfinished=unfinished if eos_token_id is not None else None,
+                                              eos=eos_token_id if eos_token_id is not None else -1, pad=pad_token_id or 0)
+                else:
+                    if forced_tokens is not None:
+                        greedy_tok, mg = ops.select_token(logits, need_margin=True)
+                        margins.append((greedy_tok, mg))
+                        nxt = forced_tokens[:, step].to(dev).clone()
+                        if eos_token_id is not None:
+                            nxt = torch.where(unfinished.bool(), nxt, torch.full_like(nxt, pad_token_id))
+                            unfinished = unfinished & (nxt != eos_token_id).int()
+                    else:
+                        nxt, mg = ops.select_token(logits, unfinished=unfinished if eos_token_id is not None else None,
+                                                   eos=eos_token_id if eos_token_id is not None else -1, pad=pad_token_id or 0,
+                                                   need_margin=return_margins)
+                        if return_margins:
+                            margins.append((nxt.clone(), mg))
+                ids = torch.cat([ids, nxt[:, None]], dim=-1)
+                step += 1
+                if forced_tokens is not None and step >= forced_tokens.shape[1]:
+                    break
+                if eos_token_id is not None and (step % 8 == 0) and int(unfinished.max()) == 0:
+                    break
+            # HF stops at the step on which the last row finishes: trim what the 8-step polling overshot
+            if eos_token_id is not None and forced_tokens is None:
+                gen = ids[:, prompt_len:]
+                is_eos = gen == eos_token_id
+                first = torch.where(is_eos.any(1), is_eos.int().argmax(1) + 1, torch.full((B,), gen.shape[1], device=dev))
+                ids = ids[:, : prompt_len + int(first.max())]
+
+        scores = None
+        if output_scores and do_sample:
+            scores = self._rescore_sampled(ids, prompt_len, rec, enc, enc_mask, special_token_ids, mask_token_id, bos_token_id,
+                                           top_k, temperature)
+        if return_dict_in_generate:
+            out = ModelOutput(sequences=ids, scores=scores)
+            if margins:
+                out["greedy_tokens"] = torch.stack([m[0] for m in margins], 1)
+                out["greedy_margins"] = torch.stack([m[1] for m in margins], 1)
+            return out
+        return ids
+
+    generate = torch.no_grad()(_generate)          # `.generate.__wrapped__` is the grad-enabled body (reference scst/gt_prompt.py:162)
+
+    # ------------------------------------------------------------------------------------------ differentiable scores
+    def _rescore_sampled(self, ids, prompt_len, rec, enc, enc_mask, special_token_ids, mask_token_id, bos_token_id, top_k, temperature):
+        """Processed scores of every sampling step, [B,V] each, with autograd through the decoder (and encoder_outputs)."""
+        fed = self._fed(ids, bos_token_id)
+        stripped = ids.shape[1] - fed.shape[1]
+        n_new = ids.shape[1] - prompt_len
+        steps = len(rec["tt"])
+        n_new = min(n_new, steps)
+        tf_in = fed[:, : (prompt_len - stripped) + n_new - 1]
+        tt = torch.cat(rec["tt"][:n_new], dim=1)
+        pos = torch.cat(rec["pos"][:n_new], dim=1) if rec["pos"][0] is not None else None
+        mask = (tf_in != mask_token_id).to(torch.uint8) if self.kind == "longitudinal" else None
+        logits = self._decode_tf(tf_in, enc, None if self.kind == "single" else enc_mask, mask, tt, pos)
+        first = prompt_len - stripped - 1
+        sc = logits[:, first:, :]
+        if temperature is not None and float(temperature) != 1.0:
+            sc = sc / float(temperature)
+        if top_k:
+            with torch.no_grad():
+                flat = sc.detach().reshape(-1, sc.shape[-1]).contiguous()
+                thr = ops.topk_threshold(flat, int(top_k)).view(sc.shape[0], sc.shape[1], 1)
+            sc = sc.masked_fill(sc < thr, float("-inf"))                    # TopKLogitsWarper semantics (ties at the k-th value kept)
+        return tuple(sc[:, t, :] for t in range(sc.shape[1]))
+
+    # ------------------------------------------------------------------------------------------ beam search
+    def _beam_search(self, ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, num_beams, bos, eos, pad, length_penalty):
+        """TF5 generation/utils.py:3208-3560 with do_sample=False, early_stopping=False, one EOS id, num_return_sequences=1."""
+        dev = ids.device
+        B = ids.shape[0]
+        nb, keep = num_beams, 2 * num_beams
+        V = self.config.decoder.vocab_size
+        ids = ids.repeat_interleave(nb, dim=0)
+        enc16 = enc16.repeat_interleave(nb, dim=0).contiguous()
+        enc_mask8 = None if enc_mask8 is None else enc_mask8.repeat_interleave(nb, dim=0).contiguous()
+        cur = prompt_len = ids.shape[1]
+        running = torch.full((B, nb, max_length), pad, dtype=torch.int64, device=dev)
+        running[:, :, :cur] = ids.view(B, nb, cur)
+        sequences = running.clone()
+        run_scores = torch.zeros((B, nb), dtype=torch.float32, device=dev)
+        run_scores[:, 1:] = -1e9
+        beam_scores = torch.full((B, nb), -1e9, dtype=torch.float32, device=dev)
+        finished = torch.zeros((B, nb), dtype=torch.bool, device=dev)
+        unsat = torch.ones((B, 1), dtype=torch.bool, device=dev)
+        top_mask = torch.arange(keep, device=dev) < nb
+        batch_off = (torch.arange(B, device=dev) * nb).view(B, 1)
+        cache = self._dec.new_cache(B * nb, max_length, dev)
+
+        def gather(t, idx):
+            while idx.dim() < t.dim():
+                idx = idx.unsqueeze(-1)
+            return torch.gather(t, 1, idx.expand(-1, -1, *t.shape[2:]))
+
+        while True:
+            flat = running[:, :, :cur].reshape(B * nb, cur)
+            fed = self._fed(flat, bos)
+            new, mask, tt, pos = self._step_inputs(fed, special_token_ids, mask_token_id, prefill=cache.len == 0)
+            logits = self._dec.decode(cache, new.contiguous(), enc16, enc_mask8, mask, tt.contiguous(), None if pos is None else pos.contiguous())
+            ops.log_softmax_rows_(logits, add_row=run_scores.view(-1).contiguous())          # log_softmax + running beam score
+            topk_lp, topk_idx = ops.topk_rows(logits.view(B, nb * V), keep)
+            beam_of = topk_idx // V
+            topk_seq = gather(running, beam_of)
+            topk_seq[:, :, cur] = topk_idx % V
+            hits = (topk_seq[:, :, cur] == eos) | (cur + 1 >= max_length)
+            run_lp = topk_lp + hits.float() * -1.0e9
+            nxt = torch.topk(run_lp, k=nb)[1]
+            running, run_scores = gather(topk_seq, nxt), gather(run_lp, nxt)
+            beam_idx = (gather(beam_of, nxt) + batch_off).view(-1)
+            just = hits & top_mask[None, :]
+            fin_lp = topk_lp / ((cur + 1 - prompt_len) ** length_penalty)
+            fin_lp = fin_lp + (~unsat).float() * -1.0e9 + (~just).float() * -1.0e9
+            m_seq = torch.cat((sequences, topk_seq), dim=1)
+            m_sc = torch.cat((beam_scores, fin_lp), dim=1)
+            m_fin = torch.cat((finished, just), dim=1)
+            best = torch.topk(m_sc, k=nb)[1]
+            sequences, beam_scores, finished = gather(m_seq, best), gather(m_sc, best), gather(m_fin, best)
+            cache.reorder(beam_idx.contiguous())
+            cur += 1
+            best_run = run_scores[:, :1] / ((cur - prompt_len) ** length_penalty)
+            worst_fin = torch.where(finished, beam_scores.min(dim=1, keepdim=True)[0], torch.full_like(beam_scores, -1.0e9))
+            unsat = unsat & torch.any(best_run > worst_fin, dim=-1, keepdim=True)
+            if not (bool(unsat.any()) and not bool(hits.all())):
+                break
+        out = sequences[:, 0, :]
+        gen = out[:, prompt_len:]
+        is_eos = gen == eos
+        lens = torch.where(is_eos.any(1), is_eos.int().argmax(1) + 1, torch.full((B,), gen.shape[1], device=dev))
+        return out[:, : prompt_len + int(lens.max())], beam_scores[:, 0]

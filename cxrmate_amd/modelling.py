@@ -1,0 +1,254 @@
+"""Drop-in counterparts of the reference's encoder-to-decoder models, running on the MI355X engines.
+
+    reference class (modules/transformers/...)                         here
+    single_model/modelling_single.py   SingleCXREncoderDecoderModel  -> SingleCXREncoderDecoderModel
+    multi_model/modelling_multi.py     MultiCXREncoderDecoderModel   -> MultiCXREncoderDecoderModel
+    longitudinal_model/modelling_longitudinal.py
+                     LongitudinalPromptMultiCXREncoderDecoderModel   -> LongitudinalPromptMultiCXREncoderDecoderModel
+
+Same surface as the reference uses from its Lightning modules: `.encoder(pixel_values)`, `.decoder`,
+`forward(pixel_values=|encoder_outputs=, decoder_input_ids=, decoder_attention_mask=, decoder_token_type_ids=,
+[decoder_position_ids=]).logits` (differentiable), `generate(...)` / `generate.__wrapped__(...)`, the token helpers, HF
+state-dict key names. There is no PyTorch fallback for the math: every op goes through libcxrmate_hip.so.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops, weights
+from .config import EncoderDecoderConfig
+from .decoder import BertEngine
+from .encoder import CvtEncoderEngine
+from .generation import GenerationMixin
+from .store import ParamStore, _Node
+from .token_helpers import TokenHelpers
+
+
+class ModelOutput(dict):
+    """Minimal stand-in for transformers' ModelOutput: attribute, key and integer access; item assignment
+    (the SCST caller does `sample['sequences'] = ...`, reference scst/gt_prompt.py:185-186)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return [v for v in self.values() if v is not None][k]
+        return super().__getitem__(k)
+
+    def to_tuple(self):
+        return tuple(v for v in self.values() if v is not None)
+
+
+# ---------------------------------------------------------------------------------------------------- autograd bridges
+class _EncodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, px, *params):
+        feats, saved = model._enc.forward(px, save=True)
+        ctx.model, ctx.saved, ctx.nparams = model, saved, len(params)
+        return feats
+
+    @staticmethod
+    def backward(ctx, dfeats):
+        model = ctx.model
+        if not model.direct_grads:
+            model.zero_grads_prefix("encoder.")
+        model._enc.backward(ctx.saved, dfeats.contiguous())
+        ctx.saved = None
+        return (None, None) + model._collect_grads("encoder.", ctx.nparams)
+
+
+class _DecodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, enc, enc_mask, ids, attn_mask, tt, pos, *params):
+        logits, saved = model._dec.forward(ids, enc, enc_mask, attn_mask, tt, pos, save=True)
+        ctx.model, ctx.saved, ctx.nparams = model, saved, len(params)
+        ctx.need_denc = enc is not None and enc.requires_grad
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        if not model.direct_grads:
+            model.zero_grads_prefix("decoder.")
+        B, T, V = dlogits.shape
+        d16 = dlogits.reshape(B * T, V)
+        d16 = ops.cast_to_bf16(d16.contiguous()) if d16.dtype == torch.float32 else d16.contiguous()
+        denc = model._dec.backward(ctx.saved, dlogits=d16, need_denc=ctx.need_denc)
+        ctx.saved = None
+        return (None, denc, None, None, None, None, None) + model._collect_grads("decoder.", ctx.nparams)
+
+
+# ---------------------------------------------------------------------------------------------------- sub-modules
+class _EncoderModule(_Node):
+    """`encoder_decoder.encoder(...)` of the reference (CvtWithProjectionHead / MultiCvtWithProjectionHead)."""
+
+    def forward(self, pixel_values=None, output_hidden_states=None, return_dict=None, output_attentions=None):
+        if pixel_values is None:
+            raise ValueError("You have to specify pixel_values")
+        out = self.__dict__["_owner"]()._encode(pixel_values)
+        if return_dict is False:
+            return out.last_hidden_state
+        return out
+
+
+class _DecoderModule(_Node):
+    def print_trainable_parameters(self):
+        t = sum(p.numel() for p in self.parameters() if p.requires_grad)
+        a = sum(p.numel() for p in self.parameters())
+        print(f"trainable params: {t} || all params: {a}")
+
+
+# ---------------------------------------------------------------------------------------------------- models
+class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
+    kind = "single"
+    main_input_name = "pixel_values"
+
+    def __init__(self, config: Optional[EncoderDecoderConfig] = None, device="cuda", seed: Optional[int] = 0, perturb: float = 0.0):
+        if config is None:
+            raise ValueError("Either a configuration or an encoder and a decoder has to be provided.")
+        if not isinstance(config, EncoderDecoderConfig):
+            raise ValueError(f"Config: {config} has to be of type {EncoderDecoderConfig}")
+        assert config.decoder.add_cross_attention, '"add_cross_attention" must be True for the given decoder'
+        assert config.decoder.is_decoder, '"is_decoder" must be True for the given decoder'
+        shapes = weights.encoder_decoder_param_shapes(config)
+        aliases = weights.tied_aliases(config.decoder)
+        enc_mod, dec_mod = _EncoderModule(), _DecoderModule()
+        ParamStore.__init__(self, shapes, aliases, device, trainable=self._initially_trainable,
+                            root_modules={"encoder": enc_mod, "decoder": dec_mod})
+        enc_mod.__dict__["_owner"] = weakref.ref(self)
+        self.config = config
+        self._enc = CvtEncoderEngine(self, config.encoder)
+        self._dec = BertEngine(self, config.decoder)
+        self.direct_grads = False
+        if seed is not None:
+            self.load_state_dict(weights.init_encoder_decoder(config, seed=seed, perturb=perturb))
+
+    def _initially_trainable(self, key):
+        return True
+
+    # -------------------------------------------------------------------------------------- gradient plumbing
+    def enable_direct_grads(self):
+        """p.grad are views of the flat gradient buffer (no autograd copies); pair with FusedAdamW."""
+        self.direct_grads = True
+        self.attach_grads()
+
+    def zero_grads_prefix(self, prefix):
+        self.ensure_grads()
+        offs = [(self._offsets[k], self._numel(k)) for k in self._offsets if k.startswith(prefix)]
+        lo, hi = min(o for o, _ in offs), max(o + n for o, n in offs)
+        self.gflat[lo:hi].zero_()
+
+    def _grad_params(self, prefix):
+        return [(k, p) for k, p in self._params.items() if k.startswith(prefix) and p.requires_grad]
+
+    def _collect_grads(self, prefix, n):
+        if self.direct_grads:
+            return (None,) * n
+        return tuple(self.grad(k).clone() for k, _ in self._grad_params(prefix))
+
+    # -------------------------------------------------------------------------------------- encoder
+    def _pixels(self, pixel_values):
+        px = pixel_values
+        if px.device != self.device:
+            px = px.to(self.device)
+        return px.float().contiguous()
+
+    def _encode(self, pixel_values):
+        px = self._pixels(pixel_values)
+        multi = px.dim() == 5
+        flat = px.view(-1, *px.shape[-3:]) if multi else px
+        params = [p for _, p in self._grad_params("encoder.")]
+        if torch.is_grad_enabled() and params:
+            feats = _EncodeFn.apply(self, flat, *params)
+        else:
+            feats, _ = self._enc.forward(flat, save=False)
+        tokens = self.config.encoder.tokens_per_image
+        if multi:
+            B, N = px.shape[:2]
+            return ModelOutput(last_hidden_state=feats.view(B, N * tokens, -1), attention_mask=ops.image_mask(px, tokens).bool())
+        return ModelOutput(last_hidden_state=feats.view(px.shape[0], tokens, -1))
+
+    # -------------------------------------------------------------------------------------- forward
+    def forward(self, pixel_values=None, decoder_input_ids=None, decoder_attention_mask=None, encoder_outputs=None, past_key_values=None,
+                decoder_inputs_embeds=None, labels=None, use_cache=None, output_attentions=None, output_hidden_states=None,
+                return_dict=None, **kwargs):
+        """reference modelling_longitudinal.py:173-249 (and the single/multi copies)."""
+        kwargs_decoder = {k[len("decoder_"):]: v for k, v in kwargs.items() if k.startswith("decoder_")}
+        if encoder_outputs is None:
+            if pixel_values is None:
+                raise ValueError("You have to specify pixel_values")
+            encoder_outputs = self._encode(pixel_values)
+        elif isinstance(encoder_outputs, tuple):
+            encoder_outputs = ModelOutput(last_hidden_state=encoder_outputs[0])
+        enc = encoder_outputs[0]
+        enc_mask = encoder_outputs.get("attention_mask") if isinstance(encoder_outputs, dict) else None
+        if self.kind == "single":
+            enc_mask = None                                                  # modelling_single.py:176
+        if decoder_inputs_embeds is not None or past_key_values is not None:
+            raise NotImplementedError("decoder_inputs_embeds / external past_key_values are not part of the accelerated path")
+        logits = self._decode_tf(decoder_input_ids, enc, enc_mask, decoder_attention_mask, kwargs_decoder.get("token_type_ids"),
+                                 kwargs_decoder.get("position_ids"))
+        loss = None
+        if labels is not None:
+            loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1))
+        out = ModelOutput(loss=loss, logits=logits, past_key_values=None, encoder_last_hidden_state=enc)
+        if return_dict is False:
+            return out.to_tuple()
+        return out
+
+    @staticmethod
+    def _u8(mask, device):
+        if mask is None:
+            return None
+        return mask.to(device=device, dtype=torch.uint8).contiguous()
+
+    @staticmethod
+    def _i64(t, device):
+        if t is None:
+            return None
+        return t.to(device=device, dtype=torch.int64).contiguous()
+
+    def _decode_tf(self, ids, enc, enc_mask, attn_mask, tt, pos):
+        dev = self.device
+        ids, tt, pos = self._i64(ids, dev), self._i64(tt, dev), self._i64(pos, dev)
+        attn_mask, enc_mask = self._u8(attn_mask, dev), self._u8(enc_mask, dev)
+        enc = enc if enc.dtype == torch.bfloat16 else ops.cast_to_bf16(enc.float().contiguous())
+        enc = enc.contiguous()
+        params = [p for _, p in self._grad_params("decoder.")]
+        if torch.is_grad_enabled() and (params or enc.requires_grad):
+            return _DecodeFn.apply(self, enc, enc_mask, ids, attn_mask, tt, pos, *params)
+        logits, _ = self._dec.forward(ids, enc, enc_mask, attn_mask, tt, pos, save=False)
+        return logits
+
+
+class SingleCXREncoderDecoderModel(_CXREncoderDecoderBase):
+    kind = "single"
+
+
+class MultiCXREncoderDecoderModel(_CXREncoderDecoderBase):
+    kind = "multi"
+
+
+class LongitudinalPromptMultiCXREncoderDecoderModel(_CXREncoderDecoderBase):
+    """Frozen encoder, LoRA (r=8, alpha=32) on decoder self-attention query/key (modelling_longitudinal.py:158-171)."""
+    kind = "longitudinal"
+
+    def __init__(self, config=None, device="cuda", seed=0, perturb=0.0):
+        if config is not None and not config.decoder.lora_r:
+            config.decoder.lora_r = 8
+        super().__init__(config, device, seed, perturb)
+        self.decoder.print_trainable_parameters()
+
+    def _initially_trainable(self, key):
+        return "lora_" in key

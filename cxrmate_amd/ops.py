@@ -278,12 +278,13 @@ def softmax_ce(logits, labels, ignore_index, row_w, thr=None, need_grad=True):
     R, V = logits.shape
     assert logits.dtype == torch.float32 and logits.stride(1) == 1
     row_loss = torch.empty((R,), dtype=torch.float32, device=logits.device)
-    dl = torch.empty((R, V), dtype=BF16, device=logits.device) if need_grad else None
+    Vp = ((V + 63) // 64) * 64            # zero-padded so that V can be the K dimension of the LM-head backward GEMMs
+    dl = torch.empty((R, Vp), dtype=BF16, device=logits.device) if need_grad else None
     LIB.call("cxr_softmax_ce", _p(logits), logits.stride(0), _p(labels), int(ignore_index), _p(thr), _p(row_w), _p(row_loss), _p(dl),
              dl.stride(0) if dl is not None else 0, R, V, _s())
     loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
     LIB.call("cxr_ce_reduce", _p(row_loss), _p(row_w), R, _p(loss), _s())
-    return loss, row_loss, dl
+    return loss, row_loss, (dl[:, :V] if dl is not None else None)
 
 
 def topk_threshold(logits, k):
@@ -351,3 +352,26 @@ def bcast_row(row_f32, dst):
 
 def sum_row0_into(src, out_f32):
     LIB.call("cxr_sum_row0_bf16_f32", _p(src), src.stride(0), _p(out_f32), src.shape[0], src.shape[2], _s())
+
+
+def gather_batch(src, idx, rows, dst):
+    """dst[b, :rows] = src[idx[b], :rows]  for [B, Tmax, C] bf16 caches."""
+    B, _, C = dst.shape
+    LIB.call("cxr_gather_batch_bf16", _p(src), src.stride(0), src.stride(1), _p(dst), dst.stride(0), dst.stride(1), _p(idx), B, rows, C, _s())
+    return dst
+
+
+def topk_rows(x, k):
+    """x fp32 [R, n] -> (values [R,k], indices [R,k]) in descending order."""
+    R, n = x.shape
+    vals = torch.empty((R, k), dtype=torch.float32, device=x.device)
+    inds = torch.empty((R, k), dtype=torch.int64, device=x.device)
+    LIB.call("cxr_topk_rows", _p(x), x.stride(0), R, n, int(k), _p(vals), _p(inds), _s())
+    return vals, inds
+
+
+def gelu_bwd(dy, u):
+    assert dy.is_contiguous() and u.is_contiguous() and dy.shape == u.shape
+    dx = torch.empty_like(dy)
+    LIB.call("cxr_gelu_bwd_bf16", _p(dy), _p(u), _p(dx), dy.numel(), _s())
+    return dx

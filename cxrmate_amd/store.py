@@ -25,8 +25,11 @@ class _Node(nn.Module):
 
 
 class ParamStore(nn.Module):
-    def __init__(self, shapes: "OrderedDict[str, Tuple[int, ...]]", aliases: Dict[str, str], device, trainable=lambda k: True):
+    def __init__(self, shapes: "OrderedDict[str, Tuple[int, ...]]", aliases: Dict[str, str], device, trainable=lambda k: True,
+                 root_modules: Dict[str, nn.Module] | None = None):
         super().__init__()
+        for name, mod in (root_modules or {}).items():      # callable nodes (`.encoder(...)`, `.decoder`) the HF keys hang under
+            self.add_module(name, mod)
         self._shapes = OrderedDict((k, tuple(v)) for k, v in shapes.items() if k not in aliases)
         self._aliases = dict(aliases)
         self._trainable = trainable

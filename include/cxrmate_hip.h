@@ -97,11 +97,17 @@ int cxr_select_token(const float* logits, long ld, long R, int V, int mode, floa
                      int* unfinished, long eos, long pad, float* margin, hipStream_t stream);
 int cxr_log_softmax_rows(float* x, long ld, long R, int V, const float* add_row, hipStream_t stream);
 
+/* ---- autoregressive decode helpers (TF5:gen:3388-3485 beam continuation search + cache reorder) ------------------------- */
+int cxr_gather_batch_bf16(const void* in, long in_bs, long in_rs, void* out, long out_bs, long out_rs, const long* idx, int B, int rows, int C,
+                          hipStream_t stream);
+int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, long* inds, hipStream_t stream);
+
 /* ---- optimiser and plumbing (REF:modules/lightning_modules/single.py:426-431 torch.optim.AdamW defaults) ------------------ */
 int cxr_adamw_step(float* p, const float* g, float* m, float* v, void* p16, long n, float lr, float b1, float b2, float eps, float wd, int step,
                    float gscale, hipStream_t stream);
 int cxr_cast_f32_to_bf16(const float* in, void* out, long n, hipStream_t stream);
 int cxr_cast_bf16_to_f32(const void* in, float* out, long n, hipStream_t stream);
+int cxr_gelu_bwd_bf16(const void* dy, const void* u, void* dx, long n, hipStream_t stream);   /* dx = dy * GELU'(u), contiguous */
 int cxr_add_bf16(const void* a, long lda, const void* b, long ldb, void* out, long ldo, long rows, int C, hipStream_t stream);
 int cxr_copy_rows_bf16(const void* in, long in_bs, long in_rs, void* out, long out_bs, long out_rs, int B, int rows, int C, hipStream_t stream);
 int cxr_bcast_row_f32_bf16(const float* row, void* out, long out_bs, int B, int C, hipStream_t stream);

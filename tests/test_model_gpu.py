@@ -1,0 +1,251 @@
+"""GPU: the MI355X model path (HIP kernels through the C ABI) against (a) the golden fixtures produced by the REFERENCE and
+(b) the fp32 CPU oracle on the same seeded inputs.
+
+Tolerances (the reference's own bf16-vs-fp32 deviation is rel-rms 1.1-1.2 %, cosine 0.9999):
+  activations / logits : rel-rms <= 2.5e-2 and cosine >= 0.9995 vs fp32
+  gradients            : rel-rms <= 6e-2 (bf16 activations in the backward chain)
+  greedy / argmax      : identical wherever the fp32 top-1/top-2 margin exceeds MARGIN (measured logit error bound), teacher-forced
+  token indexing       : bit-exact
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+ACT_RMS, ACT_COS, GRAD_RMS, MARGIN = 2.5e-2, 0.9995, 6e-2, 0.05
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cxrmate_amd import modelling
+    return modelling
+
+
+def check_act(a, ref, what, rms=ACT_RMS, cos=ACT_COS):
+    r, c = gu.rel_rms(a, ref), gu.cosine(a, ref)
+    assert np.isfinite(a).all(), what
+    assert r <= rms and c >= cos, f"{what}: rel_rms {r:.4f} cosine {c:.6f}"
+
+
+def test_state_dict_keys_match_reference_layout(M):
+    from cxrmate_amd import weights
+    cfg = gu.tiny_config(vocab_size=1000, decoder_layers=2, image_size=96)
+    m = M.MultiCXREncoderDecoderModel(cfg, seed=3)
+    ref_keys = list(weights.encoder_decoder_param_shapes(cfg).keys())
+    assert sorted(m.state_dict().keys()) == sorted(ref_keys)
+    assert sum(p.numel() for p in m.parameters()) == sum(int(np.prod(s)) for k, s in weights.encoder_decoder_param_shapes(cfg).items()
+                                                         if not weights.is_buffer(k) and k not in weights.tied_aliases(cfg.decoder))
+    sd = weights.init_encoder_decoder(cfg, seed=9, perturb=0.05)
+    m.load_state_dict(sd)
+    back = m.state_dict()
+    for k in ("encoder.cvt.encoder.stages.2.cls_token", "decoder.cls.predictions.decoder.weight", "decoder.bert.embeddings.word_embeddings.weight"):
+        assert torch.equal(back[k].cpu(), sd[k])
+    cfgl = gu.tiny_config(vocab_size=1000, decoder_layers=2, image_size=96, lora_r=8)
+    ml = M.LongitudinalPromptMultiCXREncoderDecoderModel(cfgl, seed=3)
+    t = sum(p.numel() for p in ml.decoder.parameters() if p.requires_grad)
+    assert t == 2 * 2 * 2 * 8 * 768                         # layers x {query,key} x {A,B} x r x d  (147456 for 6 layers, cxrmate.ipynb:89)
+    assert all(not p.requires_grad for p in ml.encoder.parameters())
+
+
+def test_encoder_matches_reference_fixture(M):
+    g, cfg, sd, x = gu.encoder_case()
+    m = M.MultiCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        out = m.encoder(x.cuda())
+    h = out.last_hidden_state.float().cpu()
+    assert list(h.shape) == g["last_hidden_state_shape"].tolist()
+    assert np.array_equal(out.attention_mask.cpu().numpy(), g["attention_mask"])
+    check_act(gu.sample(h, 16384), g["last_hidden_state_sample"], "encoder last_hidden_state")
+    np.testing.assert_allclose(gu.stats(h)[1], g["last_hidden_state_stats"][1], rtol=2e-2)
+
+
+def _grads_by_name(m, names):
+    return {n: m.param(n).grad.detach().float().cpu() for n in names}
+
+
+def test_tf_single_logits_loss_grads(M):
+    g, cfg, sd, x, inp, lab, am, tt = gu.tf_single_case()
+    m = M.SingleCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    tt_dev = m.token_ids_to_token_type_ids(inp, [gu.SEP])
+    assert np.array_equal(tt_dev.cpu().numpy(), g["token_type_ids"])
+    out = m(pixel_values=x.cuda(), decoder_input_ids=inp.cuda(), decoder_attention_mask=am.cuda(), decoder_token_type_ids=tt_dev, return_dict=True)
+    logits = out.logits
+    assert logits.dtype == torch.float32 and list(logits.shape) == [3, 24, 1000]
+    check_act(gu.sample(logits, 16384), g["logits_sample"], "tf logits")
+    loss = torch.nn.functional.cross_entropy(logits.permute(0, 2, 1), lab.cuda(), ignore_index=gu.PAD)      # the caller's own loss (single.py:467)
+    assert abs(loss.item() - float(g["loss"])) < 2e-2
+    safe = g["logits_margin"] > MARGIN
+    assert np.array_equal(logits.argmax(-1).cpu().numpy()[safe], g["logits_argmax"][safe])
+    loss.backward()
+    names = [str(n) for n in g["grad_names"]]
+    grads = _grads_by_name(m, names)
+    for i, n in enumerate(names):
+        r = gu.rel_rms(gu.sample(grads[n], 2048), g[f"grad{i}_sample"])
+        assert r < GRAD_RMS, f"{n}: rel_rms {r:.4f}"
+    # fused loss kernel (bench path) == caller's loss on the same logits
+    from cxrmate_amd import ops
+    w = ops.ce_weights(lab.cuda().reshape(-1), gu.PAD)
+    l2, _, _ = ops.softmax_ce(logits.detach().reshape(-1, 1000), lab.cuda().reshape(-1), gu.PAD, w, need_grad=False)
+    assert abs(l2.item() - loss.item()) < 1e-4
+
+
+def test_tf_longitudinal_lora_prompt(M):
+    g, cfg, sd, x, prompt, inp, lab, am, tt, pos = gu.tf_longitudinal_case()
+    m = M.LongitudinalPromptMultiCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    for p in m.decoder.parameters():
+        p.requires_grad_(True)                                   # SCST unfreezes the decoder (scst/gt_prompt.py:38-40)
+    # teacher forcing: the CALLER derives position ids from its shifted mask (longitudinal/gt_prompt.py:198-208)
+    pos_dev = torch.nn.functional.relu(torch.cumsum(am, dim=1) - 1).cuda()
+    assert np.array_equal(pos_dev.cpu().numpy(), g["position_ids"])
+    tt_dev = m.token_ids_to_token_type_ids(inp, [gu.PMT_SEP, gu.BOS, gu.SEP], [0, 1, 0, 1])
+    assert np.array_equal(tt_dev.cpu().numpy(), g["token_type_ids"])
+    eo = m.encoder(x.cuda())
+    assert np.array_equal(eo.attention_mask.cpu().numpy(), g["enc_mask"])
+    out = m(encoder_outputs=eo, decoder_input_ids=inp.cuda(), decoder_attention_mask=am.cuda(), decoder_token_type_ids=tt_dev,
+            decoder_position_ids=pos_dev, return_dict=True)
+    check_act(gu.sample(out.logits, 16384), g["logits_sample"], "longitudinal logits")
+    loss = torch.nn.functional.cross_entropy(out.logits[:, prompt.shape[1]:].permute(0, 2, 1), lab.cuda(), ignore_index=gu.PAD)
+    assert abs(loss.item() - float(g["loss"])) < 2e-2
+    loss.backward()
+    names = [str(n) for n in g["grad_names"]]
+    grads = _grads_by_name(m, names)
+    for i, n in enumerate(names):
+        r = gu.rel_rms(gu.sample(grads[n], 2048), g[f"grad{i}_sample"])
+        assert r < GRAD_RMS, f"{n}: rel_rms {r:.4f}"
+
+
+def test_greedy_and_beam_multi(M):
+    g, cfg, sd, x = gu.generate_multi_case()
+    m = M.MultiCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    ref = torch.from_numpy(g["greedy"])
+    L = ref.shape[1]
+    # teacher-forced stepping along the reference's greedy sequence: cached argmax == reference argmax wherever the margin is safe
+    out = m.generate(pixel_values=x.cuda(), special_token_ids=[gu.SEP], max_length=L, bos_token_id=gu.BOS, eos_token_id=gu.EOS,
+                     pad_token_id=gu.PAD, num_beams=1, return_dict_in_generate=True, use_cache=True, forced_tokens=ref[:, 1:])
+    assert torch.equal(out["sequences"].cpu(), ref)
+    safe = g["greedy_margin"] > MARGIN
+    assert safe.mean() > 0.5
+    assert np.array_equal(out["greedy_tokens"].cpu().numpy()[safe], g["greedy_argmax"][safe])
+    np.testing.assert_allclose(out["greedy_margins"].cpu().numpy()[safe], g["greedy_margin"][safe], atol=0.05)
+    # free-running greedy: identical up to the first unsafe position of each row
+    free = m.generate(pixel_values=x.cuda(), special_token_ids=[gu.SEP], max_length=L, bos_token_id=gu.BOS, eos_token_id=gu.EOS,
+                      pad_token_id=gu.PAD, num_beams=1, return_dict_in_generate=True, use_cache=True)["sequences"].cpu()
+    for b in range(ref.shape[0]):
+        unsafe = np.nonzero(~safe[b])[0]
+        upto = (unsafe[0] if len(unsafe) else L - 1) + 1
+        assert torch.equal(free[b, :upto], ref[b, :upto]), (b, free[b], ref[b])
+    # cache consistency: cached generate == no-cache argmax loop through forward() of the SAME engine (bit-exact)
+    eo = m.encoder(x.cuda())
+    ids = torch.full((3, 1), gu.BOS, dtype=torch.int64, device="cuda")
+    with torch.no_grad():
+        for _ in range(L - 1):
+            tt = m.token_ids_to_token_type_ids(ids, [gu.SEP])
+            lg = m(encoder_outputs=eo, decoder_input_ids=ids, decoder_token_type_ids=tt).logits[:, -1]
+            ids = torch.cat([ids, lg.argmax(-1, keepdim=True)], 1)
+    free_noeos = m.generate(encoder_outputs=eo, special_token_ids=[gu.SEP], max_length=L, bos_token_id=gu.BOS, eos_token_id=None,
+                            pad_token_id=gu.PAD, num_beams=1, use_cache=True)
+    agree = (free_noeos == ids).float().mean().item()
+    assert agree > 0.9, agree                                   # tile-order differences between the TF and decode kernels may flip razor-thin margins
+    # beam-4 returns a well-formed result; equal to the reference when every decision on its path is safe
+    beam = m.generate(pixel_values=x.cuda(), special_token_ids=[gu.SEP], max_length=L, bos_token_id=gu.BOS, eos_token_id=gu.EOS,
+                      pad_token_id=gu.PAD, num_beams=4, return_dict_in_generate=True, use_cache=True, output_scores=True)
+    bs = beam["sequences"].cpu()
+    assert bs.shape[0] == 3 and bool((bs[:, 0] == gu.BOS).all()) and bs.shape[1] <= L
+    np.testing.assert_allclose(beam["sequences_scores"].cpu().numpy(), g["beam4_scores"], atol=0.05)
+    # EOS handling (EOS -> PAD fill, stop/trim when every row has finished): bias the EOS logit well past the fixture's threshold
+    with torch.no_grad():
+        m.param("decoder.cls.predictions.bias")[gu.EOS] += float(g["eos_bias"]) + 1.0
+    m.mark_dirty()
+    eos_seq = m.generate(pixel_values=x.cuda(), special_token_ids=[gu.SEP], max_length=L, bos_token_id=gu.BOS, eos_token_id=gu.EOS,
+                         pad_token_id=gu.PAD, num_beams=1, use_cache=True).cpu()
+    is_eos = eos_seq == gu.EOS
+    assert bool(is_eos.any(1).all()) and eos_seq.shape[1] < L
+    first = is_eos.int().argmax(1)
+    assert eos_seq.shape[1] == int(first.max()) + 1               # HF stops on the step the last row finishes
+    for b in range(3):
+        assert bool((eos_seq[b, first[b] + 1:] == gu.PAD).all())
+        assert torch.equal(eos_seq[b, :4], torch.from_numpy(g["greedy_eos"])[0, :4]) or first[b] < 3
+    beam_e = m.generate(pixel_values=x.cuda(), special_token_ids=[gu.SEP], max_length=L, bos_token_id=gu.BOS, eos_token_id=gu.EOS,
+                        pad_token_id=gu.PAD, num_beams=4, use_cache=True).cpu()
+    assert bool(((beam_e == gu.EOS).sum(1) == 1).all())
+
+
+def test_prompted_generate_and_scst_scores(M):
+    g, cfg, sd, x, prompt = gu.generate_longitudinal_case()
+    m = M.LongitudinalPromptMultiCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    for p in m.decoder.parameters():
+        p.requires_grad_(True)
+    ref = torch.from_numpy(g["greedy"])
+    P = prompt.shape[1]
+    new = ref.shape[1] - P
+    eo = m.encoder(x.cuda())
+    out = m.generate(encoder_outputs=eo, decoder_input_ids=prompt.cuda(), special_token_ids=[gu.PMT_SEP, gu.BOS, gu.SEP],
+                     max_length=new + 1 + P, bos_token_id=gu.BOS, eos_token_id=gu.EOS, pad_token_id=gu.PAD, mask_token_id=gu.PAD,
+                     num_beams=1, return_dict_in_generate=True, use_cache=True, forced_tokens=ref[:, P:])
+    seq = out["sequences"]
+    assert bool(torch.all(seq[:, 0] == gu.BOS))                  # prepended BOS, callers strip it (scst/gt_prompt.py:117-118)
+    assert torch.equal(seq[:, 1:].cpu(), ref)
+    safe = g["greedy_margin"] > MARGIN
+    assert np.array_equal(out["greedy_tokens"].cpu().numpy()[safe], g["greedy_argmax"][safe])
+    # SCST sampling path: scores carry autograd, exactly top_k finite entries, REINFORCE loss matches the oracle on the same sampled ids
+    torch.manual_seed(0)
+    smp = m.generate.__wrapped__(m, input_ids=prompt.cuda(), special_token_ids=[gu.BOS, gu.SEP], encoder_outputs=eo, bos_token_id=gu.BOS,
+                                 eos_token_id=gu.EOS, pad_token_id=gu.PAD, mask_token_id=gu.PAD, return_dict_in_generate=True, do_sample=True,
+                                 num_beams=1, use_cache=True, output_scores=True, top_p=1.0, top_k=50, temperature=1.0, max_new_tokens=new)
+    if torch.all(smp["sequences"][:, 0] == 1):
+        smp["sequences"] = smp["sequences"][:, 1:]               # item assignment, as the reference caller does
+    scores = torch.stack(smp["scores"], dim=-1)                   # [B, V, T]
+    sampled = smp["sequences"][:, P:]
+    assert scores.requires_grad and scores.shape[0] == 2 and scores.shape[2] == sampled.shape[1]
+    finite = torch.isfinite(scores).sum(1)
+    assert bool((finite >= 50).all()) and bool((finite <= 52).all())
+    assert bool(torch.isfinite(torch.gather(scores, 1, sampled[:, None, :])).all())     # every sampled id lies inside its step's top-k set
+    reward = torch.tensor([0.37, -0.21], device="cuda")
+    nll = torch.nn.functional.nll_loss(torch.log_softmax(scores, dim=1), sampled, ignore_index=gu.PAD, reduction="none")
+    loss = (nll.sum(-1) * reward).mean()
+    loss.backward()
+    gq = m.param("decoder.base_model.model.bert.encoder.layer.0.attention.self.query.lora_A.default.weight").grad
+    assert gq is not None and float(gq.abs().sum()) > 0
+    # oracle on the same sampled sequence
+    from oracle import bert as obert, cvt as ocvt, generate as ogen
+    with torch.no_grad():
+        h, emask = ocvt.encoder_forward(x, sd, cfg.encoder)
+        seqs = smp["sequences"].cpu()
+        fed, am, tt, pos = ogen.step_inputs("longitudinal", seqs, [gu.BOS, gu.SEP], gu.PAD, gu.BOS)
+        lg = obert.decoder_forward(fed, sd, cfg.decoder, h, emask, am, tt, pos)
+        osc = ogen.top_k_filter(lg[:, P - 1:-1].float(), 50).permute(0, 2, 1)
+        oloss = ogen.reinforce_loss(osc, seqs[:, P:], reward.cpu(), gu.PAD)
+    assert abs(loss.item() - oloss.item()) < 0.05 * max(1.0, abs(oloss.item())), (loss.item(), oloss.item())
+
+
+def test_reference_sampled_sequence_scores_fixture(M):
+    """Processed-score statistics for the REFERENCE's own sampled ids (fixture) reproduced through the fused loss kernel."""
+    from cxrmate_amd import ops
+    g, cfg, sd, x, prompt = gu.generate_longitudinal_case()
+    m = M.LongitudinalPromptMultiCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    seqs = torch.from_numpy(g["sampled_sequences"]).cuda()
+    P = prompt.shape[1]
+    with torch.no_grad():
+        eo = m.encoder(x.cuda())
+        mask, pos = m.position_ids_from_mask_token(seqs, gu.PAD)
+        tt = m.token_ids_to_token_type_ids(seqs, [gu.BOS, gu.SEP], [0, 1, 0, 1])
+        lg = m(encoder_outputs=eo, decoder_input_ids=seqs, decoder_attention_mask=mask, decoder_token_type_ids=tt, decoder_position_ids=pos).logits
+        sc = lg[:, P - 1:-1].contiguous()
+        B, T, V = sc.shape
+        thr = ops.topk_threshold(sc.view(-1, V), 50)
+        sampled = seqs[:, P:].contiguous().view(-1)
+        w = ops.ce_weights(sampled, gu.PAD, mode=1, reward=torch.from_numpy(g["reward"]).cuda(), T=T)
+        loss, row_loss, _ = ops.softmax_ce(sc.view(-1, V), sampled, gu.PAD, w, thr=thr, need_grad=False)
+    assert abs(loss.item() - float(g["reinforce_loss"])) < 0.05 * max(1.0, abs(float(g["reinforce_loss"])))
+    np.testing.assert_allclose(row_loss.view(B, T).cpu().numpy(), g["nll"], atol=0.08)
