@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the CXRMate hot path on MI355X (contract: README of the build driver).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one teacher-forcing optimisation step (forward, cross-entropy, backward, AdamW; BASELINE.json configs[1]:
+cxrmate-single-tf, batch 32 x 1 image 384x384, T = 256, CvT-21 + 6-layer BERT decoder, vocab 30000, bf16 MFMA with fp32
+accumulation and fp32 master weights) on synthetic data with random-init weights. Per-GPU work is fixed (weak scaling, pure data
+parallel); gradients are all-reduced over RCCL. Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work: forward FLOPs, training = 3x forward for trainable parts
+ENC_FWD_GF_PER_IMAGE = 50.04
+MFMA_BF16_PEAK_TF = 2500.0
+
+
+def dec_fwd_gf(n_images, T):
+    return 8.15 * n_images + T * (146.4 + 10.6 * n_images + 0.0184 * T) * 1e-3
+
+
+def synth_batch(B, T, vocab, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    px = torch.randn(B, 3, 384, 384, generator=g)
+    full = torch.randint(12, vocab, (B, T + 1), generator=g)
+    full[:, 0] = 1
+    full[:, T // 2] = 3
+    inp, lab = full[:, :-1].contiguous(), full[:, 1:].contiguous()
+    am = torch.ones(B, T, dtype=torch.int64)
+    return px.to(device), inp.to(device), am.to(device), lab.to(device)
+
+
+def cpu_baseline(T, vocab, budget_s=25.0):
+    """The CPU restatement of the reference path (oracle/, fp32, all host threads): TF fwd + bwd + AdamW on a bounded sample."""
+    from cxrmate_amd import weights
+    from cxrmate_amd.config import EncoderDecoderConfig
+    from oracle import bert as obert, cvt as ocvt, generate as ogen
+    cfg = EncoderDecoderConfig()
+    cfg.decoder.vocab_size = vocab
+    sd = weights.init_encoder_decoder(cfg, seed=0)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32 and not weights.is_buffer(k)
+              and k not in weights.tied_aliases(cfg.decoder)}
+    sd2 = dict(sd)
+    sd2.update(leaves)
+    opt = torch.optim.AdamW(list(leaves.values()), lr=5e-5)
+    B = 1
+    px, inp, am, lab = synth_batch(B, T, vocab, "cpu", 123)
+    tt = torch.from_numpy(__import__("oracle.token_ops", fromlist=["x"]).token_ids_to_token_type_ids(inp.numpy(), [3]))
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        h, _ = ocvt.encoder_forward(px, sd2, cfg.encoder)
+        logits = obert.decoder_forward(inp, sd2, cfg.decoder, h, None, am, tt, None)
+        loss = ogen.tf_cross_entropy(logits, lab, 4)
+        loss.backward()
+        opt.step()
+
+    step()                                  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s * 0.6 or n >= 8:
+            break
+    return {"value": n * B * T / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} TF steps (fwd+bwd+AdamW), batch {B} x 1 image 384x384, T={T}, fp32, oracle/ restatement of the reference path"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--seq-len", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from cxrmate_amd import dp
+    rank, local, world = dp.init_from_env()
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from cxrmate_amd import ops
+    from cxrmate_amd.config import EncoderDecoderConfig
+    from cxrmate_amd.modelling import SingleCXREncoderDecoderModel
+    from cxrmate_amd.training import FusedAdamW, tf_train_step
+
+    cfg = EncoderDecoderConfig()
+    B, T, V = args.batch, args.seq_len, cfg.decoder.vocab_size
+    model = SingleCXREncoderDecoderModel(cfg, device=dev, seed=0)
+    opt = FusedAdamW(model, lr=5e-5)
+    px, inp, am, lab = synth_batch(B, T, V, dev, 1000 + rank)
+    tt = model.token_ids_to_token_type_ids(inp, [3])
+
+    def step():
+        return tf_train_step(model, opt, px, inp, am, tt, lab, pad_token_id=4)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    tokens_per_s = world * B * T * args.steps / dt
+
+    # dominant kernel = gemm_nt_kernel (bf16 MFMA): live HIP-event timing of every launch in one extra step
+    ops.GEMM_PROFILE = []
+    step()
+    torch.cuda.synchronize()
+    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in prof)
+    gemm_flops = sum(f for f, _, _, _ in prof)
+    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
+    step_gf = 3.0 * (ENC_FWD_GF_PER_IMAGE + dec_fwd_gf(1, T)) * B
+
+    out = {
+        "metric": "tf_tokens_per_sec", "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic (randn 384x384 images, uniform token ids, random-init weights)",
+        "config": {"workload": "cxrmate-single-tf teacher-forcing fwd/bwd + AdamW (BASELINE.json configs[1])", "global_batch": B * world,
+                   "images_per_study": 1, "seq_len": T, "encoder": "CvT-21 @384", "decoder": "BERT 6 layers, vocab 30000",
+                   "parallelism": f"dp{world}", "mode": "eval-mode BatchNorm (running statistics), dropout p=0",
+                   "loss": float(loss.item()), "tokens_per_sec_per_gpu": tokens_per_s / world,
+                   "model_tflops_per_gpu": step_gf * 1e-3 / (ms_per_step * 1e-3)},
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<64,true> (v_mfma_f32_16x16x32_bf16)", "achieved": achieved,
+                     "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TF, "traffic": None,
+                     "launches_per_step": len(prof), "avg_launch_us": gemm_ms * 1e3 / max(1, len(prof)),
+                     "avg_launch_gflop": gemm_flops / max(1, len(prof)) * 1e-9, "gemm_share_of_step": gemm_ms / ms_per_step},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(T, V)
+        except Exception as e:                              # the baseline must never take the GPU number down with it
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

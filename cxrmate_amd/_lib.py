@@ -47,6 +47,7 @@ class _Lib:
             if not os.path.exists(LIB_PATH):
                 raise CxrError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(cxrmate_amd has no CPU / PyTorch fallback)")
+            import torch  # noqa: F401  -- torch's HIP runtime must be resident first so that the library binds to the same one
             self._dll = ctypes.CDLL(LIB_PATH)
             for name, args in self.protos.items():
                 fn = getattr(self._dll, name)
@@ -58,7 +59,12 @@ class _Lib:
         fn = getattr(self.load(), name)
         rc = fn(*args)
         if rc != 0:
-            raise CxrError(f"{name} failed with code {rc} (args: {args})")
+            detail = ""
+            if rc == -2:
+                f = self._dll.cxr_last_hip_error_string
+                f.restype = ctypes.c_char_p
+                detail = f" [hip error {self._dll.cxr_last_hip_error()}: {f().decode()}]"
+            raise CxrError(f"{name} failed with code {rc}{detail} (args: {args})")
 
 
 LIB = _Lib()

@@ -192,7 +192,7 @@ extern "C" int cxr_attn_fwd_bf16(const void* Q, const void* K, const void* V, vo
     a.kpm_bs = kpm_bs; a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk;
     a.scale_log2e = scale * 1.4426950408889634f; a.causal = causal; a.causal_shift = causal_shift;
     dim3 grid(cdiv(Tq, 128), H, B);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, stream, a);
+    CXR_LAUNCH(attn_fwd_kernel, grid, dim3(256), 0, stream, a);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

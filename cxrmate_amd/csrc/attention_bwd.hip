@@ -303,9 +303,9 @@ extern "C" int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, co
     a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
     a.causal = causal; a.causal_shift = causal_shift;
     const long nd = (long)B * H * Tq * 8;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(nd, 256)), dim3(256), 0, stream, (const bf16_t*)O, (const bf16_t*)dO, o_bs, o_rs, delta, B, H, Tq);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(cdiv(Tk, 128), H, B), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(Tq, 128), H, B), dim3(256), 0, stream, a);
+    CXR_LAUNCH(attn_delta_kernel, dim3(cdiv(nd, 256)), dim3(256), 0, stream, (const bf16_t*)O, (const bf16_t*)dO, o_bs, o_rs, delta, B, H, Tq);
+    CXR_LAUNCH(attn_bwd_dkdv_kernel, dim3(cdiv(Tk, 128), H, B), dim3(256), 0, stream, a);
+    CXR_LAUNCH(attn_bwd_dq_kernel, dim3(cdiv(Tq, 128), H, B), dim3(256), 0, stream, a);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

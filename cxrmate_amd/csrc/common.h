@@ -14,10 +14,19 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 #define CXR_ERR_ARG (-1)
 #define CXR_ERR_LAUNCH (-2)
 
+// torch (and anything else in the process) may leave a stale error in the HIP runtime's per-thread slot: clear it before launching so that
+// CXR_LAUNCH_CHECK reports only OUR launch failures.
+#define CXR_LAUNCH(...)                                      \
+    do {                                                     \
+        (void)hipGetLastError();                             \
+        hipLaunchKernelGGL(__VA_ARGS__);                     \
+    } while (0)
+
+extern "C" int g_cxr_last_hip_error;    // defined in misc.hip; exposed through cxr_last_hip_error()
 #define CXR_LAUNCH_CHECK()                                   \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \
-        if (e__ != hipSuccess) return CXR_ERR_LAUNCH;        \
+        if (e__ != hipSuccess) { g_cxr_last_hip_error = (int)e__; return CXR_ERR_LAUNCH; } \
     } while (0)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }

@@ -83,7 +83,7 @@ extern "C" int cxr_im2col_nchw_f32(const float* px, void* col, int Bn, int Cin, 
     if (Bn <= 0 || (Kpad % 8) || Kpad < Cin * KS * KS) return CXR_ERR_ARG;
     const long total = (long)Bn * Ho * Wo * (Kpad / 8);
     const int grid = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
-    hipLaunchKernelGGL(im2col_nchw_kernel, dim3(grid), dim3(256), 0, stream, px, (bf16_t*)col, Bn, Cin, H, W, KS, stride, pad, Ho, Wo,
+    CXR_LAUNCH(im2col_nchw_kernel, dim3(grid), dim3(256), 0, stream, px, (bf16_t*)col, Bn, Cin, H, W, KS, stride, pad, Ho, Wo,
                        Cin * KS * KS, Kpad);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
@@ -94,7 +94,7 @@ extern "C" int cxr_im2col_tok_bf16(const void* x, long x_bs, long x_rs, void* co
     if (Bn <= 0 || (Cin % 8) || (x_rs % 8) || (x_bs % 8)) return CXR_ERR_ARG;
     const long total = (long)Bn * Ho * Wo * 9 * (Cin / 8);
     const int grid = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
-    hipLaunchKernelGGL(im2col_tok_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, (bf16_t*)col, Bn, Cin, H, W,
+    CXR_LAUNCH(im2col_tok_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, (bf16_t*)col, Bn, Cin, H, W,
                        stride, pad, Ho, Wo);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
@@ -105,7 +105,7 @@ extern "C" int cxr_col2im_tok_bf16(const void* dcol, void* dx, long dx_bs, long 
     if (Bn <= 0 || (Cin % 8) || (dx_rs % 8) || (dx_bs % 8)) return CXR_ERR_ARG;
     const long total = (long)Bn * H * W * (Cin / 8);
     const int grid = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
-    hipLaunchKernelGGL(col2im_tok_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dcol, (bf16_t*)dx, dx_bs, dx_rs, Bn, Cin, H, W,
+    CXR_LAUNCH(col2im_tok_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dcol, (bf16_t*)dx, dx_bs, dx_rs, Bn, Cin, H, W,
                        stride, pad, Ho, Wo);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
@@ -127,7 +127,7 @@ __global__ void bn_fold_kernel(const float* __restrict__ w /*[C,9]*/, const floa
 
 extern "C" int cxr_bn_fold(const float* w, const float* g, const float* b, const float* mean, const float* var, float eps, float* wf,
                            float* sh, int C, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 128)), dim3(128), 0, stream, w, g, b, mean, var, eps, wf, sh, C);
+    CXR_LAUNCH(bn_fold_kernel, dim3(cdiv(C, 128)), dim3(128), 0, stream, w, g, b, mean, var, eps, wf, sh, C);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -149,7 +149,7 @@ __global__ void bn_fold_bwd_kernel(const float* __restrict__ w, const float* __r
 
 extern "C" int cxr_bn_fold_bwd(const float* w, const float* g, const float* mean, const float* var, float eps, const float* G,
                                const float* S, float* dw, float* dg, float* db, int C, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3(cdiv(C, 128)), dim3(128), 0, stream, w, g, mean, var, eps, G, S, dw, dg, db, C);
+    CXR_LAUNCH(bn_fold_bwd_kernel, dim3(cdiv(C, 128)), dim3(128), 0, stream, w, g, mean, var, eps, G, S, dw, dg, db, C);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -218,9 +218,9 @@ extern "C" int cxr_dwconv_bn_fwd_bf16(const void* x, long x_bs, long x_rs, const
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const long total = (long)Bn * (Ho * Wo + tok0) * (C / 8);
     const int grid = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
-    if (y1) hipLaunchKernelGGL((dwconv_fwd_kernel<2>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, wf0, sh0, wf1, sh1,
+    if (y1) CXR_LAUNCH((dwconv_fwd_kernel<2>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, wf0, sh0, wf1, sh1,
                                (bf16_t*)y0, (bf16_t*)y1, y_bs, y_rs, Bn, C, H, W, stride, Ho, Wo, tok0);
-    else    hipLaunchKernelGGL((dwconv_fwd_kernel<1>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, wf0, sh0, wf0, sh0,
+    else    CXR_LAUNCH((dwconv_fwd_kernel<1>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, wf0, sh0, wf0, sh0,
                                (bf16_t*)y0, (bf16_t*)nullptr, y_bs, y_rs, Bn, C, H, W, stride, Ho, Wo, tok0);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
@@ -288,7 +288,7 @@ extern "C" int cxr_dwconv_bn_bwd_dx_bf16(const void* dy0, const float* wf0, long
     };
     const long total = (long)Bn * (H * W + tok0) * (C / 8);
     const int grid = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
-    hipLaunchKernelGGL(dwconv_bwd_dx_kernel, dim3(grid), dim3(256), 0, stream, mk(dy0, wf0, bs0, rs0, stride0), mk(dy1, wf1, bs1, rs1, stride1),
+    CXR_LAUNCH(dwconv_bwd_dx_kernel, dim3(grid), dim3(256), 0, stream, mk(dy0, wf0, bs0, rs0, stride0), mk(dy1, wf1, bs1, rs1, stride1),
                        mk(dy2, wf2, bs2, rs2, stride2), nproj, (bf16_t*)dx, dx_bs, dx_rs, Bn, C, H, W, tok0);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
@@ -353,7 +353,7 @@ extern "C" int cxr_dwconv_bn_bwd_w_bf16(const void* x, long x_bs, long x_rs, con
     const long npix = (long)Bn * Ho * Wo;
     int ppb = (int)cdiv(npix, 1024);
     if (ppb < 32) ppb = 32;
-    hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3(cdiv(npix, ppb)), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, (const bf16_t*)dy, dy_bs,
+    CXR_LAUNCH(dwconv_bwd_w_kernel, dim3(cdiv(npix, ppb)), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, (const bf16_t*)dy, dy_bs,
                        dy_rs, G, S, Bn, C, H, W, stride, Ho, Wo, tok0, ppb);
     CXR_LAUNCH_CHECK();
     return CXR_OK;

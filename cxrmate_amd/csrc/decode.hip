@@ -20,7 +20,7 @@ extern "C" int cxr_gather_batch_bf16(const void* in, long in_bs, long in_rs, voi
     if (B <= 0 || rows <= 0 || (C % 8)) return CXR_ERR_ARG;
     const long total = (long)B * rows * (C / 8);
     const int grid = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
-    hipLaunchKernelGGL(gather_batch_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)in, in_bs, in_rs, (bf16_t*)out, out_bs, out_rs, idx,
+    CXR_LAUNCH(gather_batch_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)in, in_bs, in_rs, (bf16_t*)out, out_bs, out_rs, idx,
                        B, rows, C);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 }
 extern "C" int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, long* inds, hipStream_t stream) {
     if (R <= 0 || n <= 0 || K <= 0 || K > 16 || K > n) return CXR_ERR_ARG;
-    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)R), dim3(256), 0, stream, x, ld, n, K, vals, inds);
+    CXR_LAUNCH(topk_rows_kernel, dim3((unsigned)R), dim3(256), 0, stream, x, ld, n, K, vals, inds);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

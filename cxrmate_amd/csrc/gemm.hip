@@ -189,12 +189,156 @@ extern "C" int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw
     const int grid = cdiv(M, 128) * cdiv(N, 128);
     const bool bk64 = (K % 64) == 0;
     if (g_gemm_regstage) {
-        if (bk64) hipLaunchKernelGGL((gemm_nt_kernel<64, false>), dim3(grid), dim3(256), 0, stream, g);
-        else      hipLaunchKernelGGL((gemm_nt_kernel<32, false>), dim3(grid), dim3(256), 0, stream, g);
+        if (bk64) CXR_LAUNCH((gemm_nt_kernel<64, false>), dim3(grid), dim3(256), 0, stream, g);
+        else      CXR_LAUNCH((gemm_nt_kernel<32, false>), dim3(grid), dim3(256), 0, stream, g);
     } else {
-        if (bk64) hipLaunchKernelGGL((gemm_nt_kernel<64, true>), dim3(grid), dim3(256), 0, stream, g);
-        else      hipLaunchKernelGGL((gemm_nt_kernel<32, true>), dim3(grid), dim3(256), 0, stream, g);
+        if (bk64) CXR_LAUNCH((gemm_nt_kernel<64, true>), dim3(grid), dim3(256), 0, stream, g);
+        else      CXR_LAUNCH((gemm_nt_kernel<32, true>), dim3(grid), dim3(256), 0, stream, g);
     }
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM ("TN", split over the token dimension):
+//     C[I,J] += alpha * sum_r P[r,I] * Q[r,J]        (dW[N,K] += dY[M,N]^T . X[M,K]),   dbias[I] += sum_r P[r,I]
+// Both operands are read in their natural row-major (token-major) layout: a 32-row x 128-col tile of each is register-staged
+// into LDS (rows padded to 288 B and permuted so that ds_read_b64_tr_b16 is bank-conflict free) and the MFMA fragments
+// (8 consecutive tokens of one column) come from the hardware transposing read. The reduction dimension (tokens, 8k..295k)
+// is split across workgroups so that the small I x J outputs (64x64 .. 1536x384) still fill 256 CUs; partial products are
+// combined with fp32 atomics into the (already fp32, already accumulating) gradient buffer.
+struct GemmTnArgs {
+    const bf16_t* P; long ldp;
+    const bf16_t* Q; long ldq;
+    float* C; long ldc;
+    float* dbias;
+    int R, I, J;
+    int splits, tiles_j, rt_per_split;
+    float alpha;
+};
+
+__device__ __forceinline__ int tn_rho(int r) { return (r & 3) | (((r >> 3) & 1) << 2) | (((r >> 2) & 1) << 3) | (r & 16); }
+
+__device__ __forceinline__ bf16x8_t tn_frag(const bf16_t* tile, int colbase, int lane) {
+    constexpr int ST = 144;
+    const int g = lane >> 4, i = lane & 15;
+    const int q = i >> 2, p = i & 3;
+    const bf16_t* p0 = tile + tn_rho(8 * g + q) * ST + colbase + 4 * p;
+    const bf16_t* p1 = tile + tn_rho(8 * g + 4 + q) * ST + colbase + 4 * p;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+    s16x8_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
+    constexpr int BR = 32, ST = 144;
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * BR * ST];
+    __shared__ float bred[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    const int split = blockIdx.x % g.splits, tile = blockIdx.x / g.splits;
+    const int ti = tile / g.tiles_j, tj = tile % g.tiles_j;
+    const int nrt = (g.R + BR - 1) / BR;
+    const int rt0 = split * g.rt_per_split;
+    const int rt1 = min(nrt, rt0 + g.rt_per_split);
+
+    // staging slots: 2 chunks of 8 columns per operand per thread
+    const int srow0 = tid >> 4, srow1 = (256 + tid) >> 4, sc = tid & 15;
+    int colp = ti * 128 + sc * 8; if (colp >= g.I) colp = 0;
+    int colq = tj * 128 + sc * 8; if (colq >= g.J) colq = 0;
+    const int l0 = tn_rho(srow0) * ST + sc * 8, l1 = tn_rho(srow1) * ST + sc * 8;
+    uint4 p0, p1, q0, q1;
+#define TN_GLOAD(rt)                                                                                              \
+    do {                                                                                                          \
+        const long ra_ = (long)(rt) * BR + srow0, rb_ = (long)(rt) * BR + srow1;                                  \
+        p0 = p1 = q0 = q1 = make_uint4(0, 0, 0, 0);                                                               \
+        if (ra_ < g.R) { p0 = *reinterpret_cast<const uint4*>(g.P + ra_ * g.ldp + colp);                          \
+                         q0 = *reinterpret_cast<const uint4*>(g.Q + ra_ * g.ldq + colq); }                        \
+        if (rb_ < g.R) { p1 = *reinterpret_cast<const uint4*>(g.P + rb_ * g.ldp + colp);                          \
+                         q1 = *reinterpret_cast<const uint4*>(g.Q + rb_ * g.ldq + colq); }                        \
+    } while (0)
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool do_bias = g.dbias != nullptr && tj == 0;
+
+    if (rt0 < rt1) TN_GLOAD(rt0);
+    for (int rt = rt0; rt < rt1; ++rt) {
+        bf16_t* tp = lds + ((rt - rt0) & 1) * (2 * BR * ST);
+        bf16_t* tq = tp + BR * ST;
+        *reinterpret_cast<uint4*>(tp + l0) = p0; *reinterpret_cast<uint4*>(tp + l1) = p1;
+        *reinterpret_cast<uint4*>(tq + l0) = q0; *reinterpret_cast<uint4*>(tq + l1) = q1;
+        if (do_bias) {
+            float f[8];
+            unpack8(p0, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum[j] += f[j];
+            unpack8(p1, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum[j] += f[j];
+        }
+        __syncthreads();                                   // tile visible; the other buffer was fully consumed one iteration ago
+        if (rt + 1 < rt1) TN_GLOAD(rt + 1);
+        bf16x8_t fa[4], fb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            fa[t] = tn_frag(tp, wi * 64 + t * 16, lane);
+            fb[t] = tn_frag(tq, wj * 64 + t * 16, lane);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it], fb[jt], acc[it][jt], 0, 0, 0);
+    }
+#undef TN_GLOAD
+    // epilogue: D[i][j], lane owns column j = ..+(lane&15), rows i = ..+(lane>>4)*4 + reg
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const int j = tj * 128 + wj * 64 + jt * 16 + fr;
+            if (j >= g.J) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 128 + wi * 64 + it * 16 + fq * 4 + r;
+                if (i < g.I) atomicAdd(g.C + (long)i * g.ldc + j, acc[it][jt][r] * g.alpha);
+            }
+        }
+    if (do_bias) {
+        if (tid < 128) bred[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&bred[sc * 8 + j], bsum[j]);
+        __syncthreads();
+        if (tid < 128 && ti * 128 + tid < g.I) atomicAdd(g.dbias + ti * 128 + tid, bred[tid]);
+    }
+}
+
+extern "C" int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* dbias, int R, int I, int J,
+                                float alpha, hipStream_t stream) {
+    if (R <= 0 || I <= 0 || J <= 0 || (I % 8) || (J % 8) || (ldp % 8) || (ldq % 8)) return CXR_ERR_ARG;
+    GemmTnArgs g;
+    g.P = (const bf16_t*)P; g.ldp = ldp; g.Q = (const bf16_t*)Q; g.ldq = ldq; g.C = C; g.ldc = ldc; g.dbias = dbias;
+    g.R = R; g.I = I; g.J = J; g.alpha = alpha;
+    const int tiles_i = cdiv(I, 128);
+    g.tiles_j = cdiv(J, 128);
+    const int tiles = tiles_i * g.tiles_j;
+    const int nrt = cdiv(R, 32);
+    int splits = cdiv(320, tiles);                         // ~1.25 workgroups per CU: every split costs a 64 KB fp32 atomic tile
+    const int max_splits = nrt / 8 > 0 ? nrt / 8 : 1;      // at least 256 tokens per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    g.rt_per_split = cdiv(nrt, splits);
+    g.splits = cdiv(nrt, g.rt_per_split);
+    CXR_LAUNCH(gemm_tn_kernel, dim3(tiles * g.splits), dim3(256), 0, stream, g);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -238,7 +382,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 extern "C" int cxr_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int C, hipStream_t stream) {
     if (R <= 0 || C <= 0 || (C % 8) || (ld_in % 8) || (ld_out % 8)) return CXR_ERR_ARG;
     dim3 grid(cdiv(C, 64), cdiv(R, 64));
-    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, R, C);
+    CXR_LAUNCH(transpose_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, R, C);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -275,7 +419,7 @@ extern "C" int cxr_colsum_bf16(const void* in, long ld, float* out, int R, int C
     if (R <= 0 || C <= 0 || (C % 8) || (ld % 8)) return CXR_ERR_ARG;
     const int rows_per_block = 512;
     dim3 grid(cdiv(C, 256), cdiv(R, rows_per_block));
-    hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)in, ld, out, R, C, rows_per_block);
+    CXR_LAUNCH(colsum_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)in, ld, out, R, C, rows_per_block);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
 extern "C" int cxr_softmax_ce(const float* logits, long ld, const long* labels, long ignore_index, const float* thr, const float* row_w,
                               float* row_loss, void* dlogits, long lddl, long R, int V, hipStream_t stream) {
     if (R <= 0 || V <= 0 || (dlogits && (!row_w || (lddl % 8)))) return CXR_ERR_ARG;
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, labels, ignore_index, thr, row_w, row_loss,
+    CXR_LAUNCH(softmax_ce_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, labels, ignore_index, thr, row_w, row_loss,
                        (bf16_t*)dlogits, lddl, V);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
@@ -97,14 +97,14 @@ __global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict_
 extern "C" int cxr_ce_weights(const long* labels, long R, long ignore_index, int mode, const float* reward, int T, float* row_w,
                               hipStream_t stream) {
     if (R <= 0 || (mode == 1 && (!reward || T <= 0))) return CXR_ERR_ARG;
-    hipLaunchKernelGGL(ce_weights_kernel, dim3(cdiv(R, 256) < 64 ? cdiv(R, 256) : 64), dim3(256), 0, stream, labels, R, ignore_index, mode,
+    CXR_LAUNCH(ce_weights_kernel, dim3(cdiv(R, 256) < 64 ? cdiv(R, 256) : 64), dim3(256), 0, stream, labels, R, ignore_index, mode,
                        reward, T, row_w);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
 extern "C" int cxr_ce_reduce(const float* row_loss, const float* row_w, long R, float* loss, hipStream_t stream) {
     if (R <= 0) return CXR_ERR_ARG;
-    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, stream, row_loss, row_w, R, loss);
+    CXR_LAUNCH(ce_reduce_kernel, dim3(1), dim3(256), 0, stream, row_loss, row_w, R, loss);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __rest
 }
 extern "C" int cxr_topk_threshold(const float* logits, long ld, long R, int V, int k, float* thr, hipStream_t stream) {
     if (R <= 0 || V <= 0 || k <= 0) return CXR_ERR_ARG;
-    hipLaunchKernelGGL(topk_threshold_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, V, k, thr);
+    CXR_LAUNCH(topk_threshold_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, V, k, thr);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void select_token_kernel(const float* __restri
 extern "C" int cxr_select_token(const float* logits, long ld, long R, int V, int mode, float temperature, int top_k, const float* u, long* next,
                                 int* unfinished, long eos, long pad, float* margin, hipStream_t stream) {
     if (R <= 0 || V <= 0 || (mode == 1 && (!u || temperature <= 0.f))) return CXR_ERR_ARG;
-    hipLaunchKernelGGL(select_token_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, V, mode, temperature, top_k, u, next, unfinished,
+    CXR_LAUNCH(select_token_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, V, mode, temperature, top_k, u, next, unfinished,
                        eos, pad, margin);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(float* __restrict__ x,
 }
 extern "C" int cxr_log_softmax_rows(float* x, long ld, long R, int V, const float* add_row, hipStream_t stream) {
     if (R <= 0 || V <= 0) return CXR_ERR_ARG;
-    hipLaunchKernelGGL(log_softmax_kernel, dim3((unsigned)R), dim3(256), 0, stream, x, ld, V, add_row);
+    CXR_LAUNCH(log_softmax_kernel, dim3((unsigned)R), dim3(256), 0, stream, x, ld, V, add_row);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

@@ -1,6 +1,10 @@
 // Gather / integer / optimiser kernels of the CXRMate hot path.
 #include "common.h"
 
+extern "C" { int g_cxr_last_hip_error = 0; }
+extern "C" int cxr_last_hip_error() { return g_cxr_last_hip_error; }                       // hipError_t of the last failed launch
+extern "C" const char* cxr_last_hip_error_string() { return hipGetErrorString((hipError_t)g_cxr_last_hip_error); }
+
 // ---------------------------------------------------------------------------------------------- BERT embeddings (K8)
 // out[r] = LayerNorm(word[ids[r]] + type[tt[r]] + pos[pid[r]])   (TF5 modeling_bert.py:70-108); one wave per row, C = 768.
 // pre-LN sum is optionally kept for the backward pass.
@@ -61,7 +65,7 @@ extern "C" int cxr_bert_embed_fwd(const long* ids, const long* tt, const long* p
                                   int pos_offset, int C, hipStream_t stream) {
     if (R <= 0 || C != 768) return CXR_ERR_ARG;
     const int grid = (int)(cdiv(R, 4) < 4096 ? cdiv(R, 4) : 4096);
-    hipLaunchKernelGGL(bert_embed_fwd_kernel, dim3(grid), dim3(256), 0, stream, ids, tt, pid, (const bf16_t*)word, (const bf16_t*)type,
+    CXR_LAUNCH(bert_embed_fwd_kernel, dim3(grid), dim3(256), 0, stream, ids, tt, pid, (const bf16_t*)word, (const bf16_t*)type,
                        (const bf16_t*)posw, gamma, beta, eps, (bf16_t*)sum_out, (bf16_t*)out, stats, R, T, pos_offset);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
@@ -92,7 +96,7 @@ extern "C" int cxr_bert_embed_bwd(const void* dsum, const long* ids, const long*
                                   long R, int T, int pos_offset, long padding_idx, int C, hipStream_t stream) {
     if (R <= 0 || C != 768) return CXR_ERR_ARG;
     const int grid = (int)(cdiv(R, 4) < 4096 ? cdiv(R, 4) : 4096);
-    hipLaunchKernelGGL(bert_embed_bwd_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dsum, ids, tt, pid, dword, dtype, dpos, R, T,
+    CXR_LAUNCH(bert_embed_bwd_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dsum, ids, tt, pid, dword, dtype, dpos, R, T,
                        pos_offset, padding_idx);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
@@ -138,8 +142,8 @@ __global__ __launch_bounds__(64) void token_type_ids_past_kernel(const long* __r
 extern "C" int cxr_token_type_ids(const long* ids, long ld, int B, int T, const long* special, const long* sections, int nspecial, long* out,
                                   long ldo, int past, hipStream_t stream) {
     if (B <= 0 || T <= 0 || nspecial < 0 || nspecial > 16) return CXR_ERR_ARG;
-    if (past) hipLaunchKernelGGL(token_type_ids_past_kernel, dim3(B), dim3(64), 0, stream, ids, ld, B, T, special, sections, nspecial, out);
-    else      hipLaunchKernelGGL(token_type_ids_kernel, dim3(B), dim3(64), 0, stream, ids, ld, B, T, special, sections, nspecial, out, ldo);
+    if (past) CXR_LAUNCH(token_type_ids_past_kernel, dim3(B), dim3(64), 0, stream, ids, ld, B, T, special, sections, nspecial, out);
+    else      CXR_LAUNCH(token_type_ids_kernel, dim3(B), dim3(64), 0, stream, ids, ld, B, T, special, sections, nspecial, out, ldo);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(64) void mask_position_ids_kernel(const long* __res
 extern "C" int cxr_mask_position_ids(const long* ids, long ld, int B, int T, long mask_token_id, void* mask, long ldm, long* pos, long ldp,
                                      hipStream_t stream) {
     if (B <= 0 || T <= 0) return CXR_ERR_ARG;
-    hipLaunchKernelGGL(mask_position_ids_kernel, dim3(B), dim3(64), 0, stream, ids, ld, B, T, mask_token_id, (unsigned char*)mask, ldm, pos, ldp);
+    CXR_LAUNCH(mask_position_ids_kernel, dim3(B), dim3(64), 0, stream, ids, ld, B, T, mask_token_id, (unsigned char*)mask, ldm, pos, ldp);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -181,7 +185,7 @@ __global__ void image_mask_kernel(const float* __restrict__ px, long img_stride,
 
 extern "C" int cxr_image_mask(const float* px, long img_stride, int BN, int tokens, void* out, hipStream_t stream) {
     if (BN <= 0 || tokens <= 0) return CXR_ERR_ARG;
-    hipLaunchKernelGGL(image_mask_kernel, dim3(cdiv((long)BN * tokens, 256)), dim3(256), 0, stream, px, img_stride, BN, tokens, (unsigned char*)out);
+    CXR_LAUNCH(image_mask_kernel, dim3(cdiv((long)BN * tokens, 256)), dim3(256), 0, stream, px, img_stride, BN, tokens, (unsigned char*)out);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -218,7 +222,7 @@ extern "C" int cxr_adamw_step(float* p, const float* g, float* m, float* v, void
     if (n <= 0 || (n % 4) || step < 1) return CXR_ERR_ARG;
     const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
     const int grid = (int)(cdiv(n, 1024) < 8192 ? cdiv(n, 1024) : 8192);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p16, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2), gscale);
+    CXR_LAUNCH(adamw_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p16, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2), gscale);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -241,14 +245,14 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __rest
 extern "C" int cxr_cast_f32_to_bf16(const float* in, void* out, long n, hipStream_t stream) {
     if (n <= 0) return CXR_ERR_ARG;
     const int grid = (int)(cdiv(n, 1024) < 8192 ? cdiv(n, 1024) : 8192);
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, stream, in, (bf16_t*)out, n);
+    CXR_LAUNCH(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, stream, in, (bf16_t*)out, n);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
 extern "C" int cxr_cast_bf16_to_f32(const void* in, float* out, long n, hipStream_t stream) {
     if (n <= 0) return CXR_ERR_ARG;
     const int grid = (int)(cdiv(n, 256) < 8192 ? cdiv(n, 256) : 8192);
-    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)in, out, n);
+    CXR_LAUNCH(cast_bf16_f32_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)in, out, n);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -272,7 +276,7 @@ extern "C" int cxr_add_bf16(const void* a, long lda, const void* b, long ldb, vo
     if (rows <= 0 || (C % 8) || (lda % 8) || (ldb % 8) || (ldo % 8)) return CXR_ERR_ARG;
     const long total = rows * (C / 8);
     const int grid = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
-    hipLaunchKernelGGL(add_bf16_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)out, ldo, rows, C);
+    CXR_LAUNCH(add_bf16_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)out, ldo, rows, C);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -295,7 +299,7 @@ extern "C" int cxr_copy_rows_bf16(const void* in, long in_bs, long in_rs, void* 
     if (B <= 0 || rows <= 0 || (C % 8) || (in_rs % 8) || (out_rs % 8) || (in_bs % 8) || (out_bs % 8)) return CXR_ERR_ARG;
     const long total = (long)B * rows * (C / 8);
     const int grid = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
-    hipLaunchKernelGGL(copy_rows_bf16_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)in, in_bs, in_rs, (bf16_t*)out, out_bs, out_rs, B,
+    CXR_LAUNCH(copy_rows_bf16_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)in, in_bs, in_rs, (bf16_t*)out, out_bs, out_rs, B,
                        rows, C);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
@@ -308,7 +312,7 @@ __global__ void bcast_row_kernel(const float* __restrict__ row, bf16_t* __restri
     out[(i / C) * out_bs + (i % C)] = f2bf(row[i % C]);
 }
 extern "C" int cxr_bcast_row_f32_bf16(const float* row, void* out, long out_bs, int B, int C, hipStream_t stream) {
-    hipLaunchKernelGGL(bcast_row_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, stream, row, (bf16_t*)out, out_bs, B, C);
+    CXR_LAUNCH(bcast_row_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, stream, row, (bf16_t*)out, out_bs, B, C);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -320,7 +324,7 @@ __global__ void sum_row0_kernel(const bf16_t* __restrict__ in, long in_bs, float
     out[c] += s;
 }
 extern "C" int cxr_sum_row0_bf16_f32(const void* in, long in_bs, float* out, int B, int C, hipStream_t stream) {
-    hipLaunchKernelGGL(sum_row0_kernel, dim3(cdiv(C, 128)), dim3(128), 0, stream, (const bf16_t*)in, in_bs, out, B, C);
+    CXR_LAUNCH(sum_row0_kernel, dim3(cdiv(C, 128)), dim3(128), 0, stream, (const bf16_t*)in, in_bs, out, B, C);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
 extern "C" int cxr_gelu_bwd_bf16(const void* dy, const void* u, void* dx, long n, hipStream_t stream) {
     if (n <= 0 || (n % 8)) return CXR_ERR_ARG;
     const int grid = (int)(cdiv(n / 8, 256) < 8192 ? cdiv(n / 8, 256) : 8192);
-    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)u, (bf16_t*)dx, n / 8);
+    CXR_LAUNCH(gelu_bwd_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)u, (bf16_t*)dx, n / 8);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

@@ -152,11 +152,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
 
 #define LN_DISPATCH(C_, KERNEL, ...)                                                             \
     switch (C_) {                                                                                \
-        case 64: hipLaunchKernelGGL((KERNEL<64>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;    \
-        case 128: hipLaunchKernelGGL((KERNEL<128>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;  \
-        case 192: hipLaunchKernelGGL((KERNEL<192>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;  \
-        case 384: hipLaunchKernelGGL((KERNEL<384>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;  \
-        case 768: hipLaunchKernelGGL((KERNEL<768>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;  \
+        case 64: CXR_LAUNCH((KERNEL<64>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;    \
+        case 128: CXR_LAUNCH((KERNEL<128>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;  \
+        case 192: CXR_LAUNCH((KERNEL<192>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;  \
+        case 384: CXR_LAUNCH((KERNEL<384>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;  \
+        case 768: CXR_LAUNCH((KERNEL<768>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;  \
         default: return CXR_ERR_ARG;                                                              \
     }
 

@@ -188,9 +188,7 @@ class BertEngine:
                 dlp = torch.zeros((R, Vp), dtype=BF16, device=dlogits.device)
                 ops.copy_rows(dlogits.unsqueeze(0), dlp[:, :V].unsqueeze(0))
             word = st.w16(p + "bert.embeddings.word_embeddings.weight")
-            ops.colsum_into(dlp[:, :V], g(c + "bias"))
-            ops.gemm_nt(ops.transpose(dlp[:, :V], 64), ops.transpose(saved["tn"], 64), out=g(p + "bert.embeddings.word_embeddings.weight"),
-                        out_f32=True, accumulate=True)
+            ops.gemm_tn(dlp[:, :V], saved["tn"], g(p + "bert.embeddings.word_embeddings.weight"), dbias=g(c + "bias"))
             dtn = ops.gemm_nt(dlp, ops.transpose(word, 64))                       # K = Vp
             dt = ops.layernorm_bwd(saved["t"], dtn, st.f32(c + "transform.LayerNorm.weight"), saved["ts"], g(c + "transform.LayerNorm.weight"),
                                    g(c + "transform.LayerNorm.bias"))

@@ -28,6 +28,9 @@ def _chk(t, dtype=None):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM family
+GEMM_PROFILE = None     # bench.py: set to a list to collect (flops, start_event, end_event) per GEMM launch on the current stream
+
+
 def gemm_nt(a, w, bias=None, residual=None, act=0, aux=None, out=None, out_f32=False, accumulate=False, alpha=1.0):
     """out[M,N] = epi(alpha * a[M,K] @ w[N,K]^T). a, w bf16 2-D (row stride arbitrary, unit column stride)."""
     _chk(a, BF16); _chk(w, BF16)
@@ -43,9 +46,16 @@ def gemm_nt(a, w, bias=None, residual=None, act=0, aux=None, out=None, out_f32=F
         _chk(residual, BF16); assert residual.shape == (M, N)
     if aux is not None:
         _chk(aux, BF16); assert aux.shape == (M, N)
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     LIB.call("cxr_gemm_nt_bf16", _p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias), _p(residual),
              residual.stride(0) if residual is not None else 0, _p(aux), aux.stride(0) if aux is not None else 0,
              M, N, K, float(alpha), int(act), int(out_f32), int(accumulate), _s())
+    if prof is not None:
+        e1.record()
+        prof.append((2.0 * M * N * K, e0, e1, (M, N, K)))
     return out
 
 
@@ -66,13 +76,26 @@ def colsum_into(x, out):
     LIB.call("cxr_colsum_bf16", _p(x), x.stride(0), _p(out), x.shape[0], x.shape[1], _s())
 
 
+def gemm_tn(p, q, out, dbias=None, alpha=1.0):
+    """out[I,J] (fp32) += alpha * p[R,I]^T @ q[R,J];  dbias[I] += colsum(p). p, q bf16 row-major (row stride free)."""
+    _chk(p, BF16); _chk(q, BF16)
+    R, I = p.shape
+    R2, J = q.shape
+    assert R == R2 and out.dtype == torch.float32 and out.shape == (I, J) and out.stride(1) == 1
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    LIB.call("cxr_gemm_tn_bf16", _p(p), p.stride(0), _p(q), q.stride(0), _p(out), out.stride(0), _p(dbias), R, I, J, float(alpha), _s())
+    if prof is not None:
+        e1.record()
+        prof.append((2.0 * R * I * J, e0, e1, ("tn", I, J, R)))
+    return out
+
+
 def linear_bwd_weight(dy, x, dw, db=None):
-    """dw[N,K] += dy[M,N]^T @ x[M,K]; db[N] += colsum(dy). Both operands are re-presented K(=M)-contiguous via transposes."""
-    dyt = transpose(dy, 64)
-    xt = transpose(x, 64)
-    gemm_nt(dyt, xt, out=dw, out_f32=True, accumulate=True)
-    if db is not None:
-        colsum_into(dy, db)
+    """dw[N,K] += dy[M,N]^T @ x[M,K]; db[N] += colsum(dy)   (one split-K TN kernel; no transposes)."""
+    gemm_tn(dy, x, dw, dbias=db)
 
 
 def linear_bwd_input(dy, w_t, **kw):

@@ -35,14 +35,18 @@ class ParamStore(nn.Module):
         self._trainable = trainable
         self._offsets: Dict[str, int] = {}
         off = 0
-        for k, shp in self._shapes.items():
-            if k.endswith("num_batches_tracked"):
-                continue
-            n = 1
-            for d in shp:
-                n *= d
-            self._offsets[k] = off
-            off += ((n + ALIGN - 1) // ALIGN) * ALIGN
+        # parameters first (trainable ranges stay contiguous for the fused optimiser / gradient all-reduce), buffers after them
+        for want_buffer in (False, True):
+            for k, shp in self._shapes.items():
+                if k.endswith("num_batches_tracked") or is_buffer(k) != want_buffer:
+                    continue
+                n = 1
+                for d in shp:
+                    n *= d
+                self._offsets[k] = off
+                off += ((n + ALIGN - 1) // ALIGN) * ALIGN
+            if not want_buffer:
+                self._param_total = off
         self._total = off
         self._views32: Dict[str, torch.Tensor] = {}
         self._views16: Dict[str, torch.Tensor] = {}
@@ -161,6 +165,18 @@ class ParamStore(nn.Module):
         for k, p in self._params.items():
             if p.requires_grad:
                 p.grad = self._viewsg[k]
+
+    def trainable_ranges(self):
+        """Merged [lo, hi) element ranges of the flat buffers covered by parameters with requires_grad (alignment gaps included)."""
+        spans = sorted((self._offsets[k], self._offsets[k] + ((self._numel(k) + ALIGN - 1) // ALIGN) * ALIGN)
+                       for k, p in self._params.items() if p.requires_grad)
+        out = []
+        for lo, hi in spans:
+            if out and lo <= out[-1][1]:
+                out[-1][1] = max(out[-1][1], hi)
+            else:
+                out.append([lo, hi])
+        return [(lo, hi) for lo, hi in out]
 
     def zero_grads(self):
         if self.gflat is not None:

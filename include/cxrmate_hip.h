@@ -28,6 +28,10 @@ typedef struct ihipStream_t* hipStream_t;
  * -> store bf16 or fp32 (optionally accumulating). Requires K%32==0, N%4==0, lda/ldw%8==0. */
 int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias, const void* residual, long ldr,
                      void* aux, long ldaux, int M, int N, int K, float alpha, int act, int out_f32, int accumulate, hipStream_t stream);
+/* weight gradient: C[I,J] += alpha * sum_r P[r,I] Q[r,J]  (dW += dY^T X), dbias[I] += colsum(P); token dimension split across
+ * workgroups, fp32 atomic accumulation into the gradient buffer. Requires I%8==0, J%8==0. */
+int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* dbias, int R, int I, int J, float alpha,
+                     hipStream_t stream);
 int cxr_gemm_set_regstage(int on);   /* debug: 1 = stage operands through registers instead of LDS-DMA */
 int cxr_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int C, hipStream_t stream);
 int cxr_colsum_bf16(const void* in, long ld, float* out, int R, int C, hipStream_t stream);   /* out[c] += sum_r in[r][c] (bias grads) */

@@ -105,6 +105,29 @@ def test_transpose_colsum_weightgrad(ops):
     close(db, dy.float().sum(0), rtol=1e-3, atol=1e-3, what="db")
 
 
+@pytest.mark.parametrize("R,I,J", [(577, 192, 384), (18464, 384, 1536), (100, 64, 64), (8192, 768, 768), (4100, 1000, 768), (31, 8, 768)])
+def test_gemm_tn_weight_grad(ops, R, I, J):
+    big = dev(rnd(R, I + 64, seed=1).to(BF))
+    p, q = big[:, :I], dev(rnd(R, J, seed=2).to(BF))
+    out = dev(rnd(I, J, seed=3))
+    db = dev(rnd(I, seed=4))
+    ref = out + 0.5 * (p.float().t() @ q.float())
+    ref_b = db + p.float().sum(0)
+    ops.gemm_tn(p, q, out, dbias=db, alpha=0.5)
+    close(out, ref, rtol=1e-2, atol=1e-2, what=f"gemm_tn {R}x{I}x{J}")
+    close(db, ref_b, rtol=1e-2, atol=1e-2, what="gemm_tn dbias")
+
+
+def test_gemm_tn_exact_integers(ops):
+    # small integers are exact in bf16 and in fp32 accumulation: any row/column permutation of the transposed LDS reads shows up
+    R, I, J = 96, 128, 256
+    p = ((torch.arange(R * I).reshape(R, I) * 7) % 5 - 2).float().to(BF).cuda()
+    q = ((torch.arange(R * J).reshape(R, J) * 3) % 7 - 3).float().to(BF).cuda()
+    out = torch.zeros(I, J, device="cuda")
+    ops.gemm_tn(p, q, out)
+    assert torch.equal(out.cpu(), (p.float().t() @ q.float()).cpu())
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def ref_attention(q, k, v, heads, scale, kpm=None, causal=False, shift=0):
     B, Tq, D = q.shape
