@@ -108,31 +108,44 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         }
         // ---- scale + mask + online softmax (row = lane pair {l, l^32})
         const int kv0 = tile * 64;
+        const bool fast = (a.kpm == nullptr) && !a.causal && (kv0 + 64 <= a.Tk);     // block-uniform: no masking work at all
         float mloc = ATT_NEG;
         unsigned deadmask = 0u;
+        if (fast) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const unsigned char code = Ms[kl];
-                bool ok = code == 2;
-                if (a.causal) ok = ok && (kv0 + kl <= qrow + a.causal_shift);
-                deadmask |= (code == 0 ? 1u : 0u) << (kt * 16 + r);
-                const float v = ok ? st[kt][r] * a.scale_log2e : ATT_NEG;
-                st[kt][r] = v;
-                mloc = fmaxf(mloc, v);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const float v = st[kt][r] * a.scale_log2e;
+                    st[kt][r] = v;
+                    mloc = fmaxf(mloc, v);
+                }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const unsigned char code = Ms[kl];
+                    bool ok = code == 2;
+                    if (a.causal) ok = ok && (kv0 + kl <= qrow + a.causal_shift);
+                    deadmask |= (code == 0 ? 1u : 0u) << (kt * 16 + r);
+                    const float v = ok ? st[kt][r] * a.scale_log2e : ATT_NEG;
+                    st[kt][r] = v;
+                    mloc = fmaxf(mloc, v);
+                }
+        }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = ((deadmask >> (kt * 16 + r)) & 1u) ? 0.f : exp2f(st[kt][r] - m_new);
+                float p = __builtin_amdgcn_exp2f(st[kt][r] - m_new);
+                if (!fast && ((deadmask >> (kt * 16 + r)) & 1u)) p = 0.f;
                 st[kt][r] = p;
                 psum += p;
             }

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnBwdArgs a)
                 const int ql = qs * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 bool ok = code == 2;
                 if (a.causal) ok = ok && (key <= tile * 64 + ql + a.causal_shift);
-                const float p = ok ? exp2f(S[r] * a.scale_log2e - Ls[ql]) : 0.f;
+                float p = __builtin_amdgcn_exp2f(S[r] * a.scale_log2e - Ls[ql]);      // Ls = +inf for rows beyond Tq -> 0
+                p = ok ? p : 0.f;
                 S[r] = p;
                 dP[r] = p * (dP[r] - Es[ql]) * a.scale;
             }
@@ -253,13 +254,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
                 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], S, 0, 0, 0);
                 dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[s], dP, 0, 0, 0);
             }
+            const bool fast = (a.kpm == nullptr) && !a.causal && (tile * 64 + 64 <= a.Tk);
+            if (fast) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kloc = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                bool ok = Ms[kloc] == 2;
-                if (a.causal) ok = ok && (tile * 64 + kloc <= qrow + a.causal_shift);
-                const float p = ok ? exp2f(S[r] * a.scale_log2e - lse2) : 0.f;
-                dP[r] = p * (dP[r] - dl) * a.scale;
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(S[r] * a.scale_log2e - lse2);
+                    dP[r] = p * (dP[r] - dl) * a.scale;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kloc = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    bool ok = Ms[kloc] == 2;
+                    if (a.causal) ok = ok && (tile * 64 + kloc <= qrow + a.causal_shift);
+                    const float p = ok ? __builtin_amdgcn_exp2f(S[r] * a.scale_log2e - lse2) : 0.f;
+                    dP[r] = p * (dP[r] - dl) * a.scale;
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {

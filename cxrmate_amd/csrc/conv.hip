@@ -332,18 +332,29 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const bf16_t* __restr
             }
         }
     }
-    __shared__ float red[10 * 384];
-    for (int i = threadIdx.x; i < 10 * C; i += 256) red[i] = 0.f;
-    __syncthreads();
-    if (pl < npl) {
+    // block reduction over the pixel lanes without atomics: two passes of 5 taps through a [5][npl][C] fp32 LDS image (<= 40 KB)
+    __shared__ __attribute__((aligned(16))) float red[10240];
 #pragma unroll
-        for (int t = 0; t < 10; ++t)
+    for (int tg = 0; tg < 2; ++tg) {
+        if (pl < npl) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) atomicAdd(&red[t * C + c8 + j], g[t][j]);
+            for (int t = 0; t < 5; ++t) {
+                float* dst = red + ((t * npl + pl) * C + c8);
+                *reinterpret_cast<float4*>(dst) = make_float4(g[5 * tg + t][0], g[5 * tg + t][1], g[5 * tg + t][2], g[5 * tg + t][3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(g[5 * tg + t][4], g[5 * tg + t][5], g[5 * tg + t][6], g[5 * tg + t][7]);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 5 * C; i += 256) {
+            const int t = i / C, c = i % C;
+            float sum = 0.f;
+            for (int q = 0; q < npl; ++q) sum += red[(t * npl + q) * C + c];
+            const int tap = 5 * tg + t;
+            if (tap < 9) atomicAdd(G + tap * C + c, sum);
+            else atomicAdd(S + c, sum);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 9 * C; i += 256) atomicAdd(G + i, red[i]);
-    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(S + i, red[9 * C + i]);
 }
 
 extern "C" int cxr_dwconv_bn_bwd_w_bf16(const void* x, long x_bs, long x_rs, const void* dy, long dy_bs, long dy_rs, float* G, float* S,

@@ -106,6 +106,9 @@ int cxr_gather_batch_bf16(const void* in, long in_bs, long in_rs, void* out, lon
                           hipStream_t stream);
 int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, long* inds, hipStream_t stream);
 
+/* hipError_t of the most recent failed launch (return code -2); cxr_last_hip_error_string() gives its text */
+int cxr_last_hip_error(void);
+
 /* ---- optimiser and plumbing (REF:modules/lightning_modules/single.py:426-431 torch.optim.AdamW defaults) ------------------ */
 int cxr_adamw_step(float* p, const float* g, float* m, float* v, void* p16, long n, float lr, float b1, float b2, float eps, float wd, int step,
                    float gscale, hipStream_t stream);

@@ -224,8 +224,11 @@ def test_prompted_generate_and_scst_scores(M):
         fed, am, tt, pos = ogen.step_inputs("longitudinal", seqs, [gu.BOS, gu.SEP], gu.PAD, gu.BOS)
         lg = obert.decoder_forward(fed, sd, cfg.decoder, h, emask, am, tt, pos)
         osc = ogen.top_k_filter(lg[:, P - 1:-1].float(), 50).permute(0, 2, 1)
-        oloss = ogen.reinforce_loss(osc, seqs[:, P:], reward.cpu(), gu.PAD)
-    assert abs(loss.item() - oloss.item()) < 0.05 * max(1.0, abs(oloss.item())), (loss.item(), oloss.item())
+        onll = torch.nn.functional.nll_loss(torch.log_softmax(osc, dim=1), seqs[:, P:], ignore_index=gu.PAD, reduction="none")
+    # a token sampled at the edge of the bf16 top-50 can fall just outside the fp32 top-50 (-inf score): compare where both are finite
+    both = torch.isfinite(onll) & (seqs[:, P:] != gu.PAD)
+    assert both.float().mean() > 0.8
+    np.testing.assert_allclose(nll.detach().cpu()[both].numpy(), onll[both].numpy(), atol=0.08)
 
 
 def test_reference_sampled_sequence_scores_fixture(M):
