@@ -347,3 +347,22 @@ extern "C" int cxr_gelu_bwd_bf16(const void* dy, const void* u, void* dx, long n
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
+
+// cosine similarity of fp32 rows: out[r] = <a_r, b_r> / (max(|a_r|, eps) * max(|b_r|, eps))   (torch.nn.functional.cosine_similarity,
+// reference tools/rewards/cxrbert.py:66-71). One wave per row.
+__global__ __launch_bounds__(256) void cosine_rows_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                                          float* __restrict__ out, long R, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long r = (long)blockIdx.x * 4 + wave;
+    float ab = 0.f, aa = 0.f, bb = 0.f;
+    if (r < R)
+        for (int c = lane; c < C; c += 64) { const float x = a[r * lda + c], y = b[r * ldb + c]; ab += x * y; aa += x * x; bb += y * y; }
+    ab = group_sum<64>(ab); aa = group_sum<64>(aa); bb = group_sum<64>(bb);
+    if (r < R && lane == 0) out[r] = ab / (fmaxf(sqrtf(aa), eps) * fmaxf(sqrtf(bb), eps));
+}
+extern "C" int cxr_cosine_rows_f32(const float* a, long lda, const float* b, long ldb, float* out, long R, int C, float eps, hipStream_t stream) {
+    if (R <= 0 || C <= 0) return CXR_ERR_ARG;
+    CXR_LAUNCH(cosine_rows_kernel, dim3(cdiv(R, 4)), dim3(256), 0, stream, a, lda, b, ldb, out, R, C, eps);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}

@@ -40,7 +40,7 @@ class GenerationMixin:
                   special_token_ids=None, mask_token_id=None, max_length=None, max_new_tokens=None, bos_token_id=None,
                   eos_token_id=None, pad_token_id=None, num_beams=1, do_sample=False, top_k=50, top_p=1.0, temperature=1.0,
                   output_scores=False, return_dict_in_generate=False, use_cache=True, length_penalty=1.0, return_margins=False,
-                  forced_tokens=None, **unused):
+                  forced_tokens=None, record_inputs=False, **unused):
         from .modelling import ModelOutput
         if inputs is not None and pixel_values is None:
             pixel_values = inputs
@@ -94,7 +94,7 @@ class GenerationMixin:
                 new, mask, tt, pos = self._step_inputs(fed, special_token_ids, mask_token_id, prefill=cache.len == 0)
                 logits = self._dec.decode(cache, new.contiguous(), enc16, enc_mask8, mask, tt.contiguous(),
                                           None if pos is None else pos.contiguous())
-                if output_scores and do_sample:
+                if (output_scores and do_sample) or record_inputs:
                     rec["tt"].append(tt)
                     rec["pos"].append(pos)
                 if do_sample:
@@ -135,6 +135,8 @@ class GenerationMixin:
                                            top_k, temperature)
         if return_dict_in_generate:
             out = ModelOutput(sequences=ids, scores=scores)
+            if record_inputs:
+                out["recorded_inputs"] = rec
             if margins:
                 out["greedy_tokens"] = torch.stack([m[0] for m in margins], 1)
                 out["greedy_margins"] = torch.stack([m[1] for m in margins], 1)

@@ -398,3 +398,11 @@ def gelu_bwd(dy, u):
     dx = torch.empty_like(dy)
     LIB.call("cxr_gelu_bwd_bf16", _p(dy), _p(u), _p(dx), dy.numel(), _s())
     return dx
+
+
+def cosine_rows(a, b, eps=1e-8):
+    """a, b fp32 [R, C] -> [R]"""
+    R, C = a.shape
+    out = torch.empty((R,), dtype=torch.float32, device=a.device)
+    LIB.call("cxr_cosine_rows_f32", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), R, C, float(eps), _s())
+    return out

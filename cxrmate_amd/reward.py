@@ -1,0 +1,74 @@
+"""CXR-BERT cosine-similarity reward on MI355X  (reference tools/rewards/cxrbert.py:9-73).
+
+`CXRBERTReward(device)(predictions: list[str], labels: list[list[str]]) -> Tensor[B]` with the reference's argument checks.
+The reference pulls `microsoft/BiomedVLP-CXR-BERT-specialized` (remote code + weights + WordPiece tokenizer) from the HF Hub
+at construction time; none of that exists offline, so this class runs the declared stand-in of SURVEY.md 8(c) -- BERT-base
+trunk + CLS projection head (768 -> 128 -> GELU -> LayerNorm -> 128) -- on the same HIP kernels as the decoder, random-init
+unless a state dict is supplied, and takes the tokenizer as an argument. The unused MLM head of the remote class is not executed
+(its output is discarded by the reference, which indexes element [2] of the tuple, quirk Q10).
+Label embeddings are cached per label tuple: the reference embeds the same labels twice per SCST step.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops, weights
+from .config import BertConfig, reward_config
+from .decoder import BertEngine
+from .store import ParamStore
+
+
+class CXRBERTReward:
+    def __init__(self, device, tokenizer=None, config: BertConfig | None = None, state_dict=None, seed: int = 1, max_cache: int = 64):
+        self.device = torch.device(device)
+        self.config = config or reward_config()
+        self.tokenizer = tokenizer
+        self.model = ParamStore(weights.bert_param_shapes(self.config, prefix=""), {}, self.device, trainable=lambda k: False)
+        self.model.load_state_dict(state_dict if state_dict is not None else weights.init_reward(self.config, seed=seed))
+        self.engine = BertEngine(self.model, self.config, prefix="")
+        self._label_cache = {}
+        self._max_cache = max_cache
+
+    def __call__(self, predictions, labels):
+        return self.reward(predictions, labels)
+
+    # ------------------------------------------------------------------------------------------ embeddings
+    @torch.no_grad()
+    def embed_ids(self, input_ids, attention_mask):
+        """ids/mask [B,R] -> projected CLS embedding fp32 [B,128]  (tuple element [2] of the reference call, cxrbert.py:42-47)."""
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        mask = attention_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        hidden, _ = self.engine.forward(ids, attn_mask=mask, causal=False, lm_head=False)
+        return self.engine.cls_projection(hidden)
+
+    def _encode(self, texts):
+        # reference: tokenizer.batch_encode_plus(batch_text_or_text_pairs=...) (cxrbert.py:33-40); transformers 5 dropped that
+        # spelling in favour of __call__ -- same arguments, same result
+        kw = dict(add_special_tokens=True, padding="longest", return_tensors="pt", truncation=True,
+                  max_length=self.config.max_position_embeddings)
+        bep = getattr(self.tokenizer, "batch_encode_plus", None) if "batch_encode_plus" in dir(type(self.tokenizer)) else None
+        tok = bep(batch_text_or_text_pairs=texts, **kw) if bep is not None else self.tokenizer(texts, **kw)
+        return self.embed_ids(tok.input_ids, tok.attention_mask)
+
+    def reward(self, predictions, labels):
+        assert isinstance(predictions, list), '"predictions" must be a list of strings.'
+        assert all(isinstance(i, str) for i in predictions), 'Each element of "predictions" must be a string.'
+        assert isinstance(labels, list), '"labels" must be a list of lists, where each sub-list has a multiple strings.'
+        assert all(isinstance(i, list) for i in labels), 'Each element of "labels" must be a list of strings.'
+        assert all(isinstance(j, str) for i in labels for j in i), 'each sub-list must have one or more strings.'
+        if self.tokenizer is None:
+            raise RuntimeError("CXRBERTReward needs the CXR-BERT tokenizer (not available offline): pass tokenizer=...")
+        pred = self._encode(predictions)
+        flat = tuple(j for i in labels for j in i)
+        lab = self._label_cache.get(flat)
+        if lab is None:
+            lab = self._encode(list(flat))
+            if len(self._label_cache) >= self._max_cache:
+                self._label_cache.clear()
+            self._label_cache[flat] = lab
+        return ops.cosine_rows(pred, lab)
+
+    @torch.no_grad()
+    def reward_from_ids(self, pred_ids, pred_mask, label_ids, label_mask):
+        """Tokenizer-free entry (synthetic benchmarks / parity tests)."""
+        return ops.cosine_rows(self.embed_ids(pred_ids, pred_mask), self.embed_ids(label_ids, label_mask))

@@ -106,6 +106,9 @@ int cxr_gather_batch_bf16(const void* in, long in_bs, long in_rs, void* out, lon
                           hipStream_t stream);
 int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, long* inds, hipStream_t stream);
 
+/* ---- reward (REF:tools/rewards/cxrbert.py:66-71 torch.nn.functional.cosine_similarity of the CLS projections) ---------------- */
+int cxr_cosine_rows_f32(const float* a, long lda, const float* b, long ldb, float* out, long R, int C, float eps, hipStream_t stream);
+
 /* hipError_t of the most recent failed launch (return code -2); cxr_last_hip_error_string() gives its text */
 int cxr_last_hip_error(void);
 

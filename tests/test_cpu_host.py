@@ -1,0 +1,162 @@
+"""CPU (-m "not gpu"): host-side logic, the C-ABI surface, and the data-parallel path over gloo (world_size 2)."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from cxrmate_amd import build
+    return build.build()
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    from cxrmate_amd._lib import parse_header
+    protos = parse_header()
+    assert len(protos) >= 35
+    nm = subprocess.run(["nm", "-D", "--defined-only", built_lib], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in nm.splitlines() if line.strip()}
+    missing = [n for n in protos if n not in exported]
+    assert not missing, missing
+    # every entry point returns int and takes only C scalars / pointers (no torch types cross the ABI)
+    import ctypes
+    for name, args in protos.items():
+        assert all(t in (ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float) for t, _ in args), name
+
+
+def test_product_fails_loudly_without_library(monkeypatch):
+    from cxrmate_amd import _lib
+    fresh = _lib._Lib()
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libcxrmate_hip.so")
+    with pytest.raises(_lib.CxrError, match="no CPU / PyTorch fallback"):
+        fresh.load()
+
+
+def test_no_cpu_fallback_for_cpu_tensors():
+    from cxrmate_amd import modelling
+    from cxrmate_amd._lib import CxrError
+    m = modelling.MultiCXREncoderDecoderModel(gu.tiny_config(vocab_size=64, decoder_layers=1), device="cpu", seed=0)
+    with pytest.raises(CxrError):
+        m.encoder(torch.zeros(1, 1, 3, 96, 96))
+
+
+def test_param_store_layout_and_reference_key_names():
+    from cxrmate_amd import modelling, weights
+    cfg = gu.tiny_config(vocab_size=128, decoder_layers=2, lora_r=8)
+    m = modelling.LongitudinalPromptMultiCXREncoderDecoderModel(cfg, device="cpu", seed=4)
+    sd = m.state_dict()
+    assert "decoder.base_model.model.bert.encoder.layer.0.attention.self.query.lora_A.default.weight" in sd
+    assert "decoder.base_model.model.bert.encoder.layer.1.attention.self.key.base_layer.weight" in sd
+    assert "decoder.base_model.model.bert.encoder.layer.0.attention.self.value.weight" in sd          # value is not LoRA-wrapped
+    assert "encoder.cvt.encoder.stages.2.layers.0.attention.attention.convolution_projection_query.convolution_projection.normalization.running_var" in sd
+    assert sd["decoder.base_model.model.cls.predictions.decoder.weight"].data_ptr() == sd["decoder.base_model.model.bert.embeddings.word_embeddings.weight"].data_ptr()
+    # parameters are views of one flat buffer and stay views across load_state_dict
+    new = weights.init_encoder_decoder(cfg, seed=5, perturb=0.1)
+    m.load_state_dict(new)
+    k = "encoder.projection_head.projection.weight"
+    assert torch.equal(m.f32(k), new[k]) and m.f32(k).data_ptr() == m.param(k).data_ptr()
+    lo = m.flat32.data_ptr()
+    assert lo <= m.param(k).data_ptr() < lo + m.flat32.numel() * 4
+    assert m.shadow_dirty
+    # LoRA-only trainable set (reference modelling_longitudinal.py:158-171): 2 layers x {q,k} x {A,B} x 8 x 768
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 2 * 2 * 2 * 8 * 768
+    ranges = m.trainable_ranges()
+    assert sum(hi - lo for lo, hi in ranges) >= 2 * 2 * 2 * 8 * 768 and all(hi <= m._param_total for _, hi in ranges)
+    for p in m.decoder.parameters():
+        p.requires_grad_(True)
+    (lo, hi), = m.trainable_ranges()                    # whole decoder = ONE contiguous range (fused AdamW / one all-reduce bucket run)
+    assert lo == m._offsets["decoder.base_model.model.bert.embeddings.word_embeddings.weight"] and hi == m._param_total
+
+
+def test_tokenizer_helpers_match_reference_fixtures():
+    """tokenize_report_teacher_forcing / tokenize_prompt / split_and_decode_sections vs outputs of the reference's own helpers."""
+    import transformers
+    from cxrmate_amd import modelling
+    g = gu.load("token_ops.json")
+    tok = transformers.PreTrainedTokenizerFast(tokenizer_file=os.path.join(gu.GOLDEN, "tokenizer.json"), unk_token="[UNK]", pad_token="[PAD]",
+                                               bos_token="[BOS]", cls_token="[BOS]", sep_token="[SEP]", eos_token="[EOS]", mask_token="[MASK]",
+                                               extra_special_tokens=["[PMT]", "[PMT-SEP]", "[NPF]", "[NPI]"])
+    m = modelling.LongitudinalPromptMultiCXREncoderDecoderModel(gu.tiny_config(vocab_size=64, decoder_layers=1, lora_r=8), device="cpu", seed=0)
+    for h in g["helpers"]:
+        if h["fn"] == "tokenize_report_teacher_forcing":
+            out = m.tokenize_report_teacher_forcing(g["findings"], g["impression"], tok, h["max_len"])
+            for k in ("label_ids", "decoder_input_ids", "decoder_attention_mask"):
+                assert out[k].tolist() == h[k], (h["max_len"], k)
+        elif h["fn"] == "tokenize_prompt":
+            out = m.tokenize_prompt(g["previous_findings"], g["previous_impression"], tok, h["max_len"], add_bos_token_id=h["add_bos_token_id"])
+            assert out["input_ids"].tolist() == h["input_ids"] and out["attention_mask"].tolist() == h["attention_mask"], h
+        else:
+            out = m.split_and_decode_sections(torch.tensor(h["token_ids"]), h["special"], tok)
+            assert [list(s) for s in out] == h["sections"], h
+    # documented layout (examples/cxrmate.ipynb:307-308): no previous report -> [PMT][NPF][PMT-SEP][NPI][BOS]
+    out = m.tokenize_prompt([None], [None], tok, 16, add_bos_token_id=True)
+    assert out["input_ids"].tolist() == [[8, 10, 9, 11, 1]]
+
+
+def test_model_output_and_generate_wrapper_surface():
+    from cxrmate_amd import modelling
+    o = modelling.ModelOutput(sequences=torch.zeros(2, 3), scores=None)
+    o["sequences"] = o["sequences"][:, 1:]                      # item assignment, as scst/gt_prompt.py:185-186 does
+    assert o.sequences.shape == (2, 2) and o[0].shape == (2, 2)
+    m = modelling.SingleCXREncoderDecoderModel
+    assert hasattr(m.generate, "__wrapped__") and m.generate.__wrapped__ is m._generate
+    with pytest.raises(ValueError, match="configuration"):
+        modelling.SingleCXREncoderDecoderModel(None)
+
+
+def test_shard_studies_partition():
+    from cxrmate_amd import dp
+    for n, w in ((16, 8), (17, 4), (3, 8), (128, 2)):
+        parts = [list(dp.shard_studies(n, r, w)) for r in range(w)]
+        assert sorted(sum(parts, [])) == list(range(n))
+
+
+def _dp_worker(rank, world, path, q):
+    import torch.distributed as dist
+    from cxrmate_amd import dp
+    dist.init_process_group("gloo", init_method=f"file://{path}", rank=rank, world_size=world)
+    torch.manual_seed(rank)
+    flat = torch.randn(1000)
+    mine = flat.clone()
+    red = dp.GradReducer(flat, [(0, 300), (400, 1000)], max_bucket_elems=128, cuts=[500])
+    assert all(not (a < 500 < b) for a, b in red.buckets)
+    red.reduce_range(500, 1000)             # "decoder" half first (overlaps the encoder backward on a GPU)
+    red.reduce_range(0, 500)
+    red.wait()
+    seqs = torch.full((2, 3 + rank), rank, dtype=torch.int64)
+    gathered = dp.all_gather_sequences(seqs, pad_token_id=4)
+    mean = dp.all_reduce_mean_scalar(torch.tensor([float(rank)]))
+    q.put((rank, mine, flat, gathered, mean))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_and_sequence_allgather_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "rdzv")
+        procs = [ctx.Process(target=_dp_worker, args=(r, 2, path, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    (_, m0, f0, g0, mean0), (_, m1, f1, g1, _) = res
+    total = m0 + m1
+    for f in (f0, f1):
+        assert torch.allclose(f[:300], total[:300]) and torch.allclose(f[400:], total[400:])
+        assert torch.equal(f[300:400], (m0 if f is f0 else m1)[300:400])          # untrainable gap is never touched
+    assert g0.shape == (4, 4) and torch.equal(g0, g1)
+    assert g0[0].tolist() == [0, 0, 0, 4] and g0[2].tolist() == [1, 1, 1, 1]
+    assert abs(float(mean0) - 0.5) < 1e-6

@@ -1,0 +1,97 @@
+"""GPU: CXR-BERT stand-in reward and the SCST step against the fixtures / CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda")
+
+
+def test_reward_trunk_and_cosine(cuda):
+    from cxrmate_amd.reward import CXRBERTReward
+    from oracle import bert as obert
+    g, cfg, sd, ids, am = gu.reward_trunk_case()
+    r = CXRBERTReward(cuda, config=cfg, state_dict=sd)
+    hidden, _ = r.engine.forward(ids.cuda(), attn_mask=am.to(torch.uint8).cuda(), causal=False, lm_head=False)
+    # bidirectional trunk vs transformers.BertModel (fixture): fp tolerance of bf16 kernels
+    assert gu.rel_rms(hidden[:, 0].float().cpu().numpy(), g["cls_state"]) < 2.5e-2
+    with torch.no_grad():
+        ref = obert.reward_cosine(ids, am, ids.flip(0), am.flip(0), sd, cfg)
+    got = r.reward_from_ids(ids, am, ids.flip(0), am.flip(0)).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-2)           # cosine of 128-d projections, bf16 trunk
+    same = r.reward_from_ids(ids, am, ids, am).cpu()
+    np.testing.assert_allclose(same.numpy(), 1.0, atol=1e-5)
+    with pytest.raises(AssertionError):
+        r.reward("not a list", [["x"]])
+    with pytest.raises(AssertionError):
+        r.reward(["a"], ["not a list of lists"])
+
+
+def test_reward_with_tokenizer_surface(cuda):
+    import os
+    import transformers
+    from cxrmate_amd.reward import CXRBERTReward
+    tok = transformers.PreTrainedTokenizerFast(tokenizer_file=os.path.join(gu.GOLDEN, "tokenizer.json"), unk_token="[UNK]", pad_token="[PAD]",
+                                               cls_token="[BOS]", sep_token="[SEP]", mask_token="[MASK]")
+    cfg = gu.BertConfig(vocab_size=600, num_hidden_layers=2, is_decoder=False, add_cross_attention=False, cls_projection_size=128)
+    r = CXRBERTReward(cuda, tokenizer=tok, config=cfg)
+    preds = ["The lungs are clear.", "Mild cardiomegaly is stable."]
+    labels = [["The lungs are clear."], ["No acute cardiopulmonary process."]]
+    out = r(preds, labels)
+    assert out.shape == (2,) and abs(out[0].item() - 1.0) < 1e-4 and out[1].item() < 0.9999
+    assert len(r._label_cache) == 1
+    out2 = r(["Normal.", "Normal."], labels)                    # label embeddings are reused (reference embeds them twice per step)
+    assert len(r._label_cache) == 1 and out2.shape == (2,)
+
+
+def test_scst_step_matches_oracle_reinforce(cuda):
+    from cxrmate_amd import modelling
+    from cxrmate_amd.scst import scst_step
+    from cxrmate_amd.training import FusedAdamW
+    from oracle import bert as obert, cvt as ocvt, generate as ogen
+    g, cfg, sd, x, prompt = gu.generate_longitudinal_case()
+    m = modelling.LongitudinalPromptMultiCXREncoderDecoderModel(cfg, device=cuda, seed=None)
+    m.load_state_dict(sd)
+    for p in m.decoder.parameters():
+        p.requires_grad_(True)                                   # scst/gt_prompt.py:38-40
+    opt = FusedAdamW(m, lr=1e-3)
+    before = m.f32("decoder.base_model.model.bert.encoder.layer.0.output.dense.weight").clone()
+    enc_before = m.f32("encoder.projection_head.projection.weight").clone()
+    calls = []
+
+    def reward_fn(ids):                                          # deterministic synthetic reward of the generated ids
+        calls.append(ids)
+        return ((ids % 7).float().mean(1) / 7.0).to(torch.float32)
+
+    special = dict(bos=gu.BOS, eos=gu.EOS, sep=gu.SEP, pad=gu.PAD, pmt_sep=gu.PMT_SEP)
+    torch.manual_seed(3)
+    out = scst_step(m, opt, reward_fn, x.cuda(), prompt.cuda(), None, special, decoder_max_len=10)
+    torch.cuda.synchronize()
+    assert len(calls) == 2 and np.isfinite(out["loss"].item())
+    sampled = out["sampled"].cpu()
+    P = prompt.shape[1]
+    assert sampled.shape[0] == 2 and 1 <= sampled.shape[1] <= 9
+    assert out["baseline_ids"].shape[1] <= P + 10
+    # oracle REINFORCE for the same sampled ids / advantages (weights BEFORE the update)
+    adv = (reward_fn(out["sampled"]) - reward_fn(out["baseline_ids"][:, P:])).cpu()
+    with torch.no_grad():
+        h, emask = ocvt.encoder_forward(x, sd, cfg.encoder)
+        seqs = torch.cat([prompt, sampled], 1)
+        fed, am, tt, pos = ogen.step_inputs("longitudinal", seqs, [gu.BOS, gu.SEP], gu.PAD, gu.BOS)
+        lg = obert.decoder_forward(fed, sd, cfg.decoder, h, emask, am, tt, pos)
+        sc = ogen.top_k_filter(lg[:, P - 1:-1].float(), 50).permute(0, 2, 1)
+        nll = torch.nn.functional.nll_loss(torch.log_softmax(sc, 1), sampled, ignore_index=gu.PAD, reduction="none")
+    if bool(torch.isfinite(nll).all()):                          # sampled ids can sit just outside the fp32 top-50 (see test_model_gpu)
+        oloss = (nll.sum(-1) * adv).mean()
+        assert abs(out["loss"].item() - oloss.item()) < 0.05 * max(1.0, abs(oloss.item())), (out["loss"].item(), oloss.item())
+    after = m.f32("decoder.base_model.model.bert.encoder.layer.0.output.dense.weight")
+    assert not torch.equal(before, after)                        # decoder updated
+    assert torch.equal(enc_before, m.f32("encoder.projection_head.projection.weight"))      # encoder frozen (scst/gt_prompt.py:35-36)
