@@ -77,6 +77,65 @@ def cpu_baseline(T, vocab, budget_s=25.0):
             "sample": f"{n} TF steps (fwd+bwd+AdamW), batch {B} x 1 image 384x384, T={T}, fp32, oracle/ restatement of the reference path"}
 
 
+def scst_bench(args, rank, local, world, dev):
+    """BASELINE.json configs[3] per-GPU shape: 16 studies x 2 images, prompt [PMT][NPF][PMT-SEP][NPI][BOS], 255 sampled + 255 greedy
+    tokens (EOS disabled so the work is deterministic), CXR-BERT stand-in reward on R=128 synthetic WordPiece ids, REINFORCE + AdamW
+    on the whole decoder, RCCL all-reduce of 80.9 M gradients."""
+    from cxrmate_amd.config import EncoderDecoderConfig
+    from cxrmate_amd.modelling import LongitudinalPromptMultiCXREncoderDecoderModel
+    from cxrmate_amd.reward import CXRBERTReward
+    from cxrmate_amd.scst import scst_step
+    from cxrmate_amd.training import FusedAdamW
+    cfg = EncoderDecoderConfig()
+    B, N = 16, 2
+    model = LongitudinalPromptMultiCXREncoderDecoderModel(cfg, device=dev, seed=0)
+    for p in model.decoder.parameters():
+        p.requires_grad_(True)                                   # scst/gt_prompt.py:38-40
+    opt = FusedAdamW(model, lr=5e-6)
+    reward = CXRBERTReward(dev, seed=1)
+    g = torch.Generator().manual_seed(2000 + rank)
+    images = torch.randn(B, N, 3, 384, 384, generator=g).to(dev)
+    prompt = torch.tensor([[8, 10, 9, 11, 1]] * B, device=dev)
+    label_ids = torch.randint(1000, 30000, (B, 128), generator=g).to(dev)
+    ones = torch.ones(B, 128, dtype=torch.int64, device=dev)
+
+    def reward_fn(ids):                                           # ids [B, L] -> synthetic "re-tokenised" R=128 WordPiece ids
+        pred = torch.zeros(B, 128, dtype=torch.int64, device=dev)
+        n = min(128, ids.shape[1])
+        pred[:, :n] = ids[:, :n] % 30522
+        return reward.reward_from_ids(pred, ones, label_ids, ones)
+
+    special = dict(bos=1, eos=None, sep=3, pad=4, pmt_sep=9)
+    def step():
+        return scst_step(model, opt, reward_fn, images, prompt, None, special, decoder_max_len=args.new_tokens + 1)
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    res = {"metric": "scst_steps_per_sec", "value": world * args.steps / dt / world, "unit": "steps/s (16 studies x 2 images per GPU per step)",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "longitudinal SCST + CXR-BERT stand-in reward (BASELINE.json configs[3] per-GPU shape)", "studies_per_gpu": B,
+                      "images_per_study": N, "new_tokens": args.new_tokens, "reward_tokens": 128, "studies_per_sec": world * B * args.steps / dt,
+                      "loss": float(out["loss"].item()), "parallelism": f"dp{world}"}}
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +144,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seq-len", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="(default) launch kernels eagerly; weight-gradient kernels overlap on a side stream")
+    ap.add_argument("--graph", action="store_true", help="replay the step from hipGraphs (3 segments)")
+    ap.add_argument("--workload", default="tf", choices=["tf", "scst"], help="tf = BASELINE configs[1] (headline); scst = configs[3] per-GPU shape")
+    ap.add_argument("--new-tokens", type=int, default=255)
     args = ap.parse_args()
 
     from cxrmate_amd import dp
@@ -96,7 +159,7 @@ def main():
     from cxrmate_amd import ops
     from cxrmate_amd.config import EncoderDecoderConfig
     from cxrmate_amd.modelling import SingleCXREncoderDecoderModel
-    from cxrmate_amd.training import FusedAdamW, tf_train_step
+    from cxrmate_amd.training import FusedAdamW, GraphedTFStep, tf_train_step
 
     cfg = EncoderDecoderConfig()
     B, T, V = args.batch, args.seq_len, cfg.decoder.vocab_size
@@ -105,8 +168,16 @@ def main():
     px, inp, am, lab = synth_batch(B, T, V, dev, 1000 + rank)
     tt = model.token_ids_to_token_type_ids(inp, [3])
 
-    def step():
+    def eager_step():
         return tf_train_step(model, opt, px, inp, am, tt, lab, pad_token_id=4)
+
+    if args.workload == "scst":
+        return scst_bench(args, rank, local, world, dev)
+    if not args.graph:
+        step = eager_step
+    else:
+        graphed = GraphedTFStep(model, opt, px, inp, am, tt, lab, pad_token_id=4)          # hipGraph capture (3 segments)
+        step = lambda: graphed(px, inp, am, tt, lab)
 
     for _ in range(args.warmup):
         step()
@@ -129,7 +200,7 @@ def main():
 
     # dominant kernel = gemm_nt_kernel (bf16 MFMA): live HIP-event timing of every launch in one extra step
     ops.GEMM_PROFILE = []
-    step()
+    eager_step()
     torch.cuda.synchronize()
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in prof)
@@ -143,7 +214,7 @@ def main():
         "data": "synthetic (randn 384x384 images, uniform token ids, random-init weights)",
         "config": {"workload": "cxrmate-single-tf teacher-forcing fwd/bwd + AdamW (BASELINE.json configs[1])", "global_batch": B * world,
                    "images_per_study": 1, "seq_len": T, "encoder": "CvT-21 @384", "decoder": "BERT 6 layers, vocab 30000",
-                   "parallelism": f"dp{world}", "mode": "eval-mode BatchNorm (running statistics), dropout p=0",
+                   "parallelism": f"dp{world}", "launch": "hipGraph replay (3 segments, RCCL between)" if args.graph else "eager, weight-gradient kernels on a side stream", "mode": "eval-mode BatchNorm (running statistics), dropout p=0",
                    "loss": float(loss.item()), "tokens_per_sec_per_gpu": tokens_per_s / world,
                    "model_tflops_per_gpu": step_gf * 1e-3 / (ms_per_step * 1e-3)},
         "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<64,true> (v_mfma_f32_16x16x32_bf16)", "achieved": achieved,

@@ -66,3 +66,178 @@ extern "C" int cxr_topk_rows(const float* x, long ld, long R, int n, int K, floa
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Skinny GEMM for autoregressive decode: C[M,N] = epi(A[M,K] . W[N,K]^T), M <= 64 (B*beams rows, one token each).
+// Weight-streaming regime (cdna_hip_programming.md section 5, "GEMV / M <= 16 decode weights"): every W element is read exactly once
+// chip-wide, straight from HBM/L2 into MFMA B fragments (no LDS round trip); a workgroup owns 16 output columns, its 4 waves split K
+// and combine through LDS; all of a wave's loads are issued before its first MFMA (deep memory-level parallelism instead of occupancy).
+template <int MT>   // number of 16-row tiles of A
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
+                                                          void* __restrict__ C, long ldc, const float* __restrict__ bias,
+                                                          const bf16_t* __restrict__ residual, long ldr, int M, int N, int K, int act,
+                                                          int out_f32) {
+    __shared__ float red[4][MT][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int kslice = K / 4, k0 = wave * kslice;
+    const int nw = n0 + fr < N ? n0 + fr : N - 1;
+    const bf16_t* wp = W + (long)nw * ldw + k0 + fq * 8;
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* ap[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int m = t * 16 + fr; m = m < M ? m : M - 1;
+        ap[t] = A + (long)m * lda + k0 + fq * 8;
+    }
+    for (int kb = 0; kb < kslice; kb += 256) {                       // 8 k-steps of 32 per batch: 8 W loads + 8*MT A loads in flight per lane
+        bf16x8_t wf[8], af[MT][8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int k = kb + s * 32;
+            if (k < kslice) {
+                wf[s] = *reinterpret_cast<const bf16x8_t*>(wp + k);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) af[t][s] = *reinterpret_cast<const bf16x8_t*>(ap[t] + k);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (kb + s * 32 < kslice) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t][s], wf[s], acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][t][lane][r] = acc[t][r];
+    __syncthreads();
+    if (wave != 0) return;
+    const int n = n0 + fr;
+    if (n >= N) return;
+    const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = t * 16 + fq * 4 + r;                       // D[m][n]: lane owns column n, rows (lane>>4)*4 + r
+            if (m >= M) continue;
+            float v = red[0][t][lane][r] + red[1][t][lane][r] + red[2][t][lane][r] + red[3][t][lane][r] + b;
+            if (act == 1) v = gelu_f(v);
+            if (residual) v += bf2f(residual[(long)m * ldr + n]);
+            if (out_f32) reinterpret_cast<float*>(C)[(long)m * ldc + n] = v;
+            else reinterpret_cast<bf16_t*>(C)[(long)m * ldc + n] = f2bf(v);
+        }
+}
+
+extern "C" int cxr_gemm_skinny_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias, const void* residual,
+                                    long ldr, int M, int N, int K, int act, int out_f32, hipStream_t stream) {
+    if (M <= 0 || M > 64 || N <= 0 || K <= 0 || (K % 128) || (lda % 8) || (ldw % 8)) return CXR_ERR_ARG;
+    const int grid = cdiv(N, 16);
+    const int mt = cdiv(M, 16);
+#define SKINNY(MT_) CXR_LAUNCH((gemm_skinny_kernel<MT_>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, \
+                               bias, (const bf16_t*)residual, ldr, M, N, K, act, out_f32)
+    if (mt == 1) SKINNY(1); else if (mt == 2) SKINNY(2); else if (mt == 3) SKINNY(3); else SKINNY(4);
+#undef SKINNY
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Single-query attention for cached decode (self-attention over the KV cache, cross-attention over N*576 encoder tokens):
+// one workgroup per (batch row, head); K and V rows are streamed once, 8 lanes per 128-byte row (16 B each), HBM-bound
+// (cross-attention K/V = B*6*2*(N*576)*768*2 B per token is the dominant decode traffic).
+// Masked keys follow the teacher-forced kernel's convention (finite sentinel -> uniform over masked-only rows).
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                          bf16_t* __restrict__ O, const unsigned char* __restrict__ kpm, long q_bs, long k_bs,
+                                                          long k_rs, long v_bs, long v_rs, long o_bs, long kpm_bs, int H, int Tk, float scale) {
+    // single pass (flash-decoding): each of the 32 key groups (8 lanes x 16 B = one 128-byte K/V row per key) keeps a running
+    // (max, sum, o[64]) over keys grp, grp+32, ...; 4 keys per iteration -> 8 independent 16-byte loads in flight per lane; the 32
+    // partial states are merged through LDS at the end.
+    __shared__ float gm[32], gl[32];
+    __shared__ float go[32][64];
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x % H, b = blockIdx.x / H;
+    const int sub = tid & 7, grp = tid >> 3;
+    float qv[8];
+    unpack8(*reinterpret_cast<const uint4*>(Q + (long)b * q_bs + h * 64 + sub * 8), qv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qv[j] *= scale * 1.4426950408889634f;      // scores directly in the exp2 domain
+    const bf16_t* kb = K + (long)b * k_bs + h * 64 + sub * 8;
+    const bf16_t* vb = V + (long)b * v_bs + h * 64 + sub * 8;
+    const unsigned char* mrow = kpm ? kpm + (long)b * kpm_bs : nullptr;
+    float m_run = -1.0e30f, l_run = 0.f;
+    float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k0 = 0; k0 < Tk; k0 += 128) {
+        uint4 kr[4], vr[4];
+        bool live[4], ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = k0 + u * 32 + grp;
+            live[u] = key < Tk;
+            const int kc = live[u] ? key : Tk - 1;
+            kr[u] = *reinterpret_cast<const uint4*>(kb + (long)kc * k_rs);
+            vr[u] = *reinterpret_cast<const uint4*>(vb + (long)kc * v_rs);
+            ok[u] = live[u] && (mrow == nullptr || mrow[kc] != 0);
+        }
+        float sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float kv[8];
+            unpack8(kr[u], kv);
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d += qv[j] * kv[j];
+            d = group_sum<8>(d);
+            sv[u] = ok[u] ? d : -1.0e30f;                                    // masked (finite sentinel) ; keys beyond Tk are dropped below
+        }
+        float mloc = m_run;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (live[u]) mloc = fmaxf(mloc, sv[u]);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - mloc);
+        m_run = mloc;
+        l_run *= alpha;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] *= alpha;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float p = live[u] ? __builtin_amdgcn_exp2f(sv[u] - m_run) : 0.f;
+            float vv[8];
+            unpack8(vr[u], vv);
+            l_run += p;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += p * vv[j];
+        }
+    }
+    if (sub == 0) { gm[grp] = m_run; gl[grp] = l_run; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) go[grp][sub * 8 + j] = o[j];
+    __syncthreads();
+    if (tid < 64) {
+        float M = -1.0e30f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) M = fmaxf(M, gm[g]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+            const float w = __builtin_amdgcn_exp2f(gm[g] - M);
+            num += w * go[g][tid];
+            den += w * gl[g];
+        }
+        O[(long)b * o_bs + h * 64 + tid] = f2bf(num / den);
+    }
+}
+
+extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs,
+                                    long v_bs, long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, hipStream_t stream) {
+    if (B <= 0 || H <= 0 || Tk <= 0 || Tk > 8192 || (k_rs % 8) || (v_rs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8)) return CXR_ERR_ARG;
+    CXR_LAUNCH(attn_decode_kernel, dim3(B * H), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
+               (bf16_t*)O, (const unsigned char*)kpm, q_bs, k_bs, k_rs, v_bs, v_rs, o_bs, kpm_bs, H, Tk, scale);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}

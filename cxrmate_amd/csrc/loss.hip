@@ -170,7 +170,25 @@ __global__ __launch_bounds__(256) void select_token_kernel(const float* __restri
     long tok;
     if (mode == 0) {
         float best = -INFINITY; int bi = 0x7fffffff;
-        for (int v = threadIdx.x; v < V; v += 256) { const float a = x[v]; if (a > best) { best = a; bi = v; } }
+        if ((V & 3) == 0 && ((size_t)x & 15) == 0) {                       // 16-byte loads, 4 independent loads in flight per lane
+            const float4* x4 = reinterpret_cast<const float4*>(x);
+            const int n4 = V >> 2;
+            for (int i0 = threadIdx.x; i0 < n4; i0 += 1024) {
+                float4 f[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = i0 + u * 256; f[u] = i < n4 ? x4[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int v = (i0 + u * 256) * 4;
+                    if (f[u].x > best) { best = f[u].x; bi = v; }
+                    if (f[u].y > best) { best = f[u].y; bi = v + 1; }
+                    if (f[u].z > best) { best = f[u].z; bi = v + 2; }
+                    if (f[u].w > best) { best = f[u].w; bi = v + 3; }
+                }
+            }
+        } else {
+            for (int v = threadIdx.x; v < V; v += 256) { const float a = x[v]; if (a > best) { best = a; bi = v; } }
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);

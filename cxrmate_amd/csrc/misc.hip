@@ -196,7 +196,12 @@ extern "C" int cxr_image_mask(const float* px, long img_stride, int BN, int toke
 // One pass over the flat fp32 master buffer; also refreshes the bf16 shadow used by the MFMA kernels.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                     bf16_t* __restrict__ p16, long n, float lr, float b1, float b2, float eps, float wd,
-                                                    float bc1, float bc2_sqrt, float gscale) {
+                                                    float bc1, float bc2_sqrt, float gscale, const int* __restrict__ step_ptr) {
+    if (step_ptr) {                                   // device-resident step counter (hipGraph replay keeps the host out of the loop)
+        const float t = (float)(*step_ptr);
+        bc1 = 1.0f - powf(b1, t);
+        bc2_sqrt = sqrtf(1.0f - powf(b2, t));
+    }
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
         float4 P = *reinterpret_cast<float4*>(p + i);
         const float4 G = *reinterpret_cast<const float4*>(g + i);
@@ -217,12 +222,21 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+__global__ void increment_i32_kernel(int* p) { *p += 1; }
+extern "C" int cxr_increment_i32(int* p, hipStream_t stream) {
+    CXR_LAUNCH(increment_i32_kernel, dim3(1), dim3(1), 0, stream, p);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// step >= 1: host-side step count; step == 0: read the (already incremented) count from the device word `step_ptr`
 extern "C" int cxr_adamw_step(float* p, const float* g, float* m, float* v, void* p16, long n, float lr, float b1, float b2, float eps, float wd,
-                              int step, float gscale, hipStream_t stream) {
-    if (n <= 0 || (n % 4) || step < 1) return CXR_ERR_ARG;
-    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+                              int step, const int* step_ptr, float gscale, hipStream_t stream) {
+    if (n <= 0 || (n % 4) || (step < 1 && !step_ptr)) return CXR_ERR_ARG;
+    const float bc1 = 1.0f - powf(b1, (float)(step < 1 ? 1 : step)), bc2 = 1.0f - powf(b2, (float)(step < 1 ? 1 : step));
     const int grid = (int)(cdiv(n, 1024) < 8192 ? cdiv(n, 1024) : 8192);
-    CXR_LAUNCH(adamw_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p16, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2), gscale);
+    CXR_LAUNCH(adamw_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p16, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2), gscale,
+               step < 1 ? step_ptr : (const int*)nullptr);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

@@ -72,8 +72,8 @@ template <int C>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
                                                             const float* __restrict__ gamma, const float* __restrict__ stats,
                                                             const bf16_t* __restrict__ add, long ldadd,
-                                                            bf16_t* __restrict__ dx, long lddx, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, long rows) {
+                                                            bf16_t* __restrict__ dx, long lddx, float* __restrict__ partial /*[grid][2][C]*/,
+                                                            long rows) {
     using L = LNCfg<C>;
     __shared__ float red[2][C];
     for (int i = threadIdx.x; i < 2 * C; i += 256) (&red[0][0])[i] = 0.f;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
             }
         }
     }
-    if (dgamma) {
+    if (partial) {
 #pragma unroll
         for (int i = 0; i < L::CPL; ++i) {
             const int ch = sub + i * L::LPR;
@@ -146,7 +146,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < C; i += 256) { atomicAdd(dgamma + i, red[0][i]); atomicAdd(dbeta + i, red[1][i]); }
+        float* out = partial + (long)blockIdx.x * 2 * C;                  // plain stores: no cross-workgroup contention
+        for (int i = threadIdx.x; i < 2 * C; i += 256) out[i] = (&red[0][0])[i];
+    }
+}
+
+// dgamma[c] += sum_b partial[b][0][c]; dbeta[c] += sum_b partial[b][1][c].  Block = 32 columns x 8 partial-row lanes.
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cl;                      // index into the 2*C concatenated [gamma | beta] sums
+    float s = 0.f;
+    if (i < 2 * C)
+        for (int b = rl; b < nblocks; b += 8) s += partial[(long)b * 2 * C + i];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && i < 2 * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][cl];
+        if (i < C) dgamma[i] += t; else dbeta[i - C] += t;
     }
 }
 
@@ -176,14 +196,21 @@ extern "C" int cxr_layernorm_fwd_bf16(const void* x, long ldx, const float* gamm
     return CXR_OK;
 }
 
-extern "C" int cxr_layernorm_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, const float* gamma, const float* stats,
-                                      const void* add, long ldadd, void* dx, long lddx, float* dgamma, float* dbeta,
-                                      long rows, int C, hipStream_t stream) {
-    if (rows <= 0 || (ldx % 8) || (lddy % 8) || (lddx % 8) || (add && (ldadd % 8))) return CXR_ERR_ARG;
+// workspace: fp32 [cxr_layernorm_bwd_grid(rows, C)][2][C] (may be null when dgamma/dbeta are not wanted)
+extern "C" int cxr_layernorm_bwd_grid(long rows, int C) {
     int grid = ln_grid(rows, C);
-    grid = grid < 1024 ? grid : 1024;
+    return grid < 512 ? grid : 512;
+}
+
+extern "C" int cxr_layernorm_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, const float* gamma, const float* stats,
+                                      const void* add, long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, float* workspace,
+                                      long rows, int C, hipStream_t stream) {
+    if (rows <= 0 || (ldx % 8) || (lddy % 8) || (lddx % 8) || (add && (ldadd % 8)) || (dgamma && !workspace)) return CXR_ERR_ARG;
+    const int grid = cxr_layernorm_bwd_grid(rows, C);
+    float* partial = dgamma ? workspace : nullptr;
     LN_DISPATCH(C, layernorm_bwd_kernel, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, gamma, stats, (const bf16_t*)add, ldadd,
-                (bf16_t*)dx, lddx, dgamma, dbeta, rows);
+                (bf16_t*)dx, lddx, partial, rows);
+    if (dgamma) CXR_LAUNCH(layernorm_bwd_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, stream, partial, grid, C, dgamma, dbeta);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

@@ -26,6 +26,7 @@ class KVCache:
         self.v2 = [torch.empty((B, Tmax, D), dtype=BF16, device=device) for _ in range(layers)]
         self.ck = [None] * layers
         self.cv = [None] * layers
+        self.cross_ready = False         # ck/cv may be pre-allocated static buffers (graph replay): filled at prefill
         self.len = 0
         self.Tmax = Tmax
 
@@ -58,7 +59,7 @@ class BertEngine:
         st.refresh_shadow()
         if self._prep_version == st.shadow_version:
             return self._prep
-        prep = {}
+        prep = self._prep                      # buffers are allocated once and refreshed in place (hipGraph-captured pointers stay valid)
         cfg = self.cfg
         if cfg.lora_r:
             scale = cfg.lora_alpha / cfg.lora_r
@@ -71,7 +72,7 @@ class BertEngine:
                     a_t = ops.transpose(st.w16(base + ".lora_A.default.weight"), 32)          # [d, 32]: A^T zero padded
                     w = st.f32(base + ".base_layer.weight").clone()
                     ops.gemm_nt(b_pad, a_t, out=w, out_f32=True, accumulate=True, alpha=scale)   # W + (alpha/r) B A
-                    prep[("lora", base)] = ops.cast_to_bf16(w)
+                    prep[("lora", base)] = ops.cast_to_bf16(w, prep.get(("lora", base)))
         self._prep, self._prep_version = prep, st.shadow_version
         return prep
 
@@ -265,41 +266,58 @@ class BertEngine:
                                  st.w16(e + "token_type_embeddings.weight"), st.w16(e + "position_embeddings.weight"),
                                  st.f32(e + "LayerNorm.weight"), st.f32(e + "LayerNorm.bias"), cfg.layer_norm_eps, Tn, pos_offset=past)
         scale = cfg.head_dim ** -0.5
+        single = Tn == 1 and B <= 64          # one new token per row: weight-streaming GEMMs + single-query attention kernels
+        lin = (lambda x, w, **kw: ops.gemm_skinny(x, w, **kw)) if single else (lambda x, w, **kw: ops.gemm_nt(x, w, **kw))
         for l in range(cfg.num_hidden_layers):
             lp = p + f"bert.encoder.layer.{l}."
             wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key"); wv, bv = self._lin(lp + "attention.self.value")
-            q = ops.gemm_nt(h, wq, bias=bq).view(B, Tn, D)
+            q = lin(h, wq, bias=bq).view(B, Tn, D)
             if Tn == 1:                                                       # project straight into the cache row
-                ops.gemm_nt(h, wk, bias=bk, out=cache.k[l][:, past, :])
-                ops.gemm_nt(h, wv, bias=bv, out=cache.v[l][:, past, :])
+                lin(h, wk, bias=bk, out=cache.k[l][:, past, :])
+                lin(h, wv, bias=bv, out=cache.v[l][:, past, :])
             else:
                 ops.copy_rows(ops.gemm_nt(h, wk, bias=bk).view(B, Tn, D), cache.k[l][:, past:past + Tn, :])
                 ops.copy_rows(ops.gemm_nt(h, wv, bias=bv).view(B, Tn, D), cache.v[l][:, past:past + Tn, :])
             kk, vv = cache.k[l][:, :past + Tn, :], cache.v[l][:, :past + Tn, :]
-            ctx, _ = ops.attention(q, kk, vv, nh, scale, kpm=attn_mask_full, causal=True, causal_shift=past)
+            if single:
+                ctx = ops.attention_decode(q, kk, vv, nh, scale, kpm=attn_mask_full)
+            else:
+                ctx, _ = ops.attention(q, kk, vv, nh, scale, kpm=attn_mask_full, causal=True, causal_shift=past)
             wo, bo = self._lin(lp + "attention.output.dense")
-            a1 = ops.gemm_nt(ctx.view(R, D), wo, bias=bo, residual=h)
+            a1 = lin(ctx.view(R, D), wo, bias=bo, residual=h)
             h1, _ = ops.layernorm(a1, st.f32(lp + "attention.output.LayerNorm.weight"), st.f32(lp + "attention.output.LayerNorm.bias"), cfg.layer_norm_eps)
             if cfg.add_cross_attention and enc is not None:
                 S = enc.shape[1]
-                if cache.ck[l] is None:
+                if cache.ck[l] is None or (not cache.cross_ready and past == 0):
                     ck, cbk = self._lin(lp + "crossattention.self.key"); cv, cbv = self._lin(lp + "crossattention.self.value")
-                    cache.ck[l] = ops.gemm_nt(enc.reshape(B * S, D), ck, bias=cbk).view(B, S, D)
-                    cache.cv[l] = ops.gemm_nt(enc.reshape(B * S, D), cv, bias=cbv).view(B, S, D)
+                    okb = cache.ck[l].view(B * S, D) if cache.ck[l] is not None else None
+                    ovb = cache.cv[l].view(B * S, D) if cache.cv[l] is not None else None
+                    cache.ck[l] = ops.gemm_nt(enc.reshape(B * S, D), ck, bias=cbk, out=okb).view(B, S, D)
+                    cache.cv[l] = ops.gemm_nt(enc.reshape(B * S, D), cv, bias=cbv, out=ovb).view(B, S, D)
                 cq, cbq = self._lin(lp + "crossattention.self.query"); co, cbo = self._lin(lp + "crossattention.output.dense")
-                q2 = ops.gemm_nt(h1, cq, bias=cbq).view(B, Tn, D)
-                ctx2, _ = ops.attention(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask)
-                a2 = ops.gemm_nt(ctx2.view(R, D), co, bias=cbo, residual=h1)
+                q2 = lin(h1, cq, bias=cbq).view(B, Tn, D)
+                if single:
+                    ctx2 = ops.attention_decode(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask)
+                else:
+                    ctx2, _ = ops.attention(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask)
+                a2 = lin(ctx2.view(R, D), co, bias=cbo, residual=h1)
                 h2, _ = ops.layernorm(a2, st.f32(lp + "crossattention.output.LayerNorm.weight"), st.f32(lp + "crossattention.output.LayerNorm.bias"),
                                       cfg.layer_norm_eps)
             else:
                 h2 = h1
             w1, b1 = self._lin(lp + "intermediate.dense"); w2, b2 = self._lin(lp + "output.dense")
-            f = ops.gemm_nt(h2, w1, bias=b1, act=1)
-            a3 = ops.gemm_nt(f, w2, bias=b2, residual=h2)
+            f = lin(h2, w1, bias=b1, act=1)
+            a3 = lin(f, w2, bias=b2, residual=h2)
             h, _ = ops.layernorm(a3, st.f32(lp + "output.LayerNorm.weight"), st.f32(lp + "output.LayerNorm.bias"), cfg.layer_norm_eps)
         cache.len = past + Tn
+        if past == 0:
+            cache.cross_ready = True
         last = h.view(B, Tn, D)[:, -1, :]                                      # [B, D] view, row stride Tn*D
+        if B <= 64:
+            c = p + "cls.predictions."
+            t = ops.gemm_skinny(last, st.w16(c + "transform.dense.weight"), bias=st.f32(c + "transform.dense.bias"), act=1)
+            tn, _ = ops.layernorm(t, st.f32(c + "transform.LayerNorm.weight"), st.f32(c + "transform.LayerNorm.bias"), cfg.layer_norm_eps)
+            return ops.gemm_skinny(tn, st.w16(p + "bert.embeddings.word_embeddings.weight"), bias=st.f32(c + "bias"), out_f32=True)
         logits, _ = self._lm_head(last, False)
         return logits
 

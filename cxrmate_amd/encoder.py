@@ -205,11 +205,12 @@ class CvtEncoderEngine:
             dc = ops.gemm_nt(d.view(-1, C), ops.transpose(st.w16(ap + f"projection_{name}.weight"))).view(d.shape)
             wf, _ = prep[("fold", s, l, name)]
             projs.append((dc, wf, stride))
-            G, S = ops.dwconv_bn_bwd_w(sv["h1"], dc, H, W, stride, tok0)
             cp = ap + f"convolution_projection_{name}.convolution_projection."
-            ops.bn_fold_bwd(st.f32(cp + "convolution.weight"), st.f32(cp + "normalization.weight"), st.f32(cp + "normalization.running_mean"),
-                            st.f32(cp + "normalization.running_var"), cfg.bn_eps, G, S, g(cp + "convolution.weight"),
-                            g(cp + "normalization.weight"), g(cp + "normalization.bias"))
+            with ops._on_wgrad_stream(sv["h1"], dc):
+                G, S = ops.dwconv_bn_bwd_w(sv["h1"], dc, H, W, stride, tok0)
+                ops.bn_fold_bwd(st.f32(cp + "convolution.weight"), st.f32(cp + "normalization.weight"), st.f32(cp + "normalization.running_mean"),
+                                st.f32(cp + "normalization.running_var"), cfg.bn_eps, G, S, g(cp + "convolution.weight"),
+                                g(cp + "normalization.weight"), g(cp + "normalization.bias"))
         dh1 = ops.dwconv_bn_bwd_dx(projs, Bn, C, H, W, tok0)
         dx = ops.layernorm_bwd(sv["x"].view(-1, C), dh1.view(-1, C), st.f32(lp + "layernorm_before.weight"), sv["st1"],
                                g(lp + "layernorm_before.weight"), g(lp + "layernorm_before.bias"), add=dx2)

@@ -15,7 +15,99 @@ import torch
 from . import ops
 
 
+class DecodeSession:
+    """Static state of one cached greedy / sampling decode (fixed batch, encoder length, maximum length) plus the hipGraphs of
+    its single-token steps. A decode step is ~90 short kernels; launched eagerly it is bound by the host (~9 us per launch through
+    Python/ctypes), so every step index is captured ONCE into a graph -- all buffers the kernels touch (token ids, masks, KV cache,
+    logits, next-token word) are static, and the position-dependent scalars (cache row, attention length) are baked per step -- and
+    replayed afterwards. Sessions are cached on the model and reused by every later generate() call of the same geometry (each SCST
+    step decodes twice with identical shapes)."""
+
+    def __init__(self, model, B, S, Lmax, has_mask):
+        dev = model.device
+        self.model, self.B, self.S, self.Lmax = model, B, S, Lmax
+        D = model.config.decoder.hidden_size
+        self.ids = torch.zeros((B, Lmax), dtype=torch.int64, device=dev)
+        self.unfinished = torch.ones(B, dtype=torch.int32, device=dev)
+        self.nxt = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.enc16 = torch.empty((B, S, D), dtype=torch.bfloat16, device=dev)
+        self.enc_mask8 = torch.empty((B, S), dtype=torch.uint8, device=dev) if has_mask else None
+        self.cache = model._dec.new_cache(B, Lmax, dev)
+        L = model.config.decoder.num_hidden_layers
+        self.cache.ck = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
+        self.cache.cv = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
+        self.graphs = {}
+        self.pool = None
+        self.version = -1
+
+    def reset(self, ids0, enc16, enc_mask8):
+        m = self.model
+        m._dec.prepare()                           # weight-derived buffers (LoRA merge) are refreshed IN PLACE: captured pointers stay valid
+        if self.version != m.flat16.data_ptr():    # parameters were re-packed (.to()/.cuda()): every captured pointer is stale
+            self.graphs.clear()
+            self.version = m.flat16.data_ptr()
+        self.ids.fill_(0)
+        self.ids[:, : ids0.shape[1]] = ids0
+        self.unfinished.fill_(1)
+        self.enc16.copy_(enc16)
+        if self.enc_mask8 is not None:
+            self.enc_mask8.copy_(enc_mask8)
+        self.cache.len = 0
+        self.cache.cross_ready = False
+
+    def step(self, cur, strip, mode):
+        """Append token `cur` (0-based column of self.ids). mode = (do_sample, special_token_ids, mask_token_id, top_k, temperature, eos, pad)."""
+        key = (cur, strip, mode)
+        hit = self.graphs.get(key)
+        prefill = self.cache.len == 0
+        if prefill or not self.model.graph_decode:
+            self._run(cur, strip, mode, prefill)
+            return
+        if hit is None:
+            g = torch.cuda.CUDAGraph()
+            if self.pool is None:
+                self.pool = torch.cuda.graph_pool_handle()
+            keep = self.cache.len
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, pool=self.pool):
+                self._run(cur, strip, mode, False)
+            self.cache.len = keep                      # capture does not execute: replay below performs the step
+            hit = (g, self.last_tt, self.last_pos)     # the step's token-type / position outputs live in the graph's pool
+            self.graphs[key] = hit
+        g, self.last_tt, self.last_pos = hit
+        g.replay()
+        self.cache.len = cur - strip
+
+    def _run(self, cur, strip, mode, prefill):
+        m = self.model
+        do_sample, special, mask_token_id, top_k, temperature, eos, pad = mode
+        fed = self.ids[:, strip:cur]
+        new, mask, tt, pos = m._step_inputs(fed, list(special), mask_token_id, prefill=prefill)
+        logits = m._dec.decode(self.cache, new.contiguous(), self.enc16, self.enc_mask8, mask, tt.contiguous(),
+                               None if pos is None else pos.contiguous())
+        if do_sample:
+            u = torch.rand(self.B, device=logits.device, dtype=torch.float32)
+            ops.select_token(logits, mode=1, temperature=temperature, top_k=top_k or 0, u=u, unfinished=self.unfinished if eos is not None else None,
+                             eos=eos if eos is not None else -1, pad=pad or 0, out=self.nxt)
+        else:
+            ops.select_token(logits, unfinished=self.unfinished if eos is not None else None, eos=eos if eos is not None else -1,
+                             pad=pad or 0, out=self.nxt)
+        self.ids[:, cur] = self.nxt
+        self.last_tt, self.last_pos = tt, pos
+
+
 class GenerationMixin:
+    graph_decode = True      # replay single-token decode steps from hipGraphs (DecodeSession)
+
+    def _session(self, B, S, Lmax, has_mask):
+        cache = self.__dict__.setdefault("_decode_sessions", {})
+        key = (B, S, Lmax, has_mask)
+        if key not in cache:
+            if len(cache) >= 4:
+                cache.clear()
+            cache[key] = DecodeSession(self, B, S, Lmax, has_mask)
+        return cache[key]
+
     # ------------------------------------------------------------------------------------------ per-step inputs
     def _fed(self, ids, bos_token_id):
         if self.kind == "longitudinal" and bool(torch.all(ids[:, 0] == bos_token_id)):
@@ -85,49 +177,12 @@ class GenerationMixin:
         prompt_len = ids.shape[1]
         rec = {"tt": [], "pos": []}
         margins = []
-        with torch.no_grad():
-            cache = self._dec.new_cache(B, max_length, dev)
-            unfinished = torch.ones(B, dtype=torch.int32, device=dev)
-            step = 0
-            while ids.shape[1] < max_length:
-                fed = self._fed(ids, bos_token_id)
-                new, mask, tt, pos = self._step_inputs(fed, special_token_ids, mask_token_id, prefill=cache.len == 0)
-                logits = self._dec.decode(cache, new.contiguous(), enc16, enc_mask8, mask, tt.contiguous(),
-                                          None if pos is None else pos.contiguous())
-                if (output_scores and do_sample) or record_inputs:
-                    rec["tt"].append(tt)
-                    rec["pos"].append(pos)
-                if do_sample:
-                    u = torch.rand(B, device=dev, dtype=torch.float32)
-                    nxt, _ = ops.select_token(logits, mode=1, temperature=temperature, top_k=top_k or 0, u=u,
-                                              unfinished=unfinished if eos_token_id is not None else None,
-                                              eos=eos_token_id if eos_token_id is not None else -1, pad=pad_token_id or 0)
-                else:
-                    if forced_tokens is not None:
-                        greedy_tok, mg = ops.select_token(logits, need_margin=True)
-                        margins.append((greedy_tok, mg))
-                        nxt = forced_tokens[:, step].to(dev).clone()
-                        if eos_token_id is not None:
-                            nxt = torch.where(unfinished.bool(), nxt, torch.full_like(nxt, pad_token_id))
-                            unfinished = unfinished & (nxt != eos_token_id).int()
-                    else:
-                        nxt, mg = ops.select_token(logits, unfinished=unfinished if eos_token_id is not None else None,
-                                                   eos=eos_token_id if eos_token_id is not None else -1, pad=pad_token_id or 0,
-                                                   need_margin=return_margins)
-                        if return_margins:
-                            margins.append((nxt.clone(), mg))
-                ids = torch.cat([ids, nxt[:, None]], dim=-1)
-                step += 1
-                if forced_tokens is not None and step >= forced_tokens.shape[1]:
-                    break
-                if eos_token_id is not None and (step % 8 == 0) and int(unfinished.max()) == 0:
-                    break
-            # HF stops at the step on which the last row finishes: trim what the 8-step polling overshot
-            if eos_token_id is not None and forced_tokens is None:
-                gen = ids[:, prompt_len:]
-                is_eos = gen == eos_token_id
-                first = torch.where(is_eos.any(1), is_eos.int().argmax(1) + 1, torch.full((B,), gen.shape[1], device=dev))
-                ids = ids[:, : prompt_len + int(first.max())]
+        if forced_tokens is None and not return_margins:
+            ids = self._generate_session(ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, bos_token_id, eos_token_id,
+                                         pad_token_id, do_sample, top_k, temperature, rec if ((output_scores and do_sample) or record_inputs) else None)
+        else:
+            ids, margins = self._generate_eager(ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, bos_token_id, eos_token_id,
+                                                pad_token_id, forced_tokens, return_margins)
 
         scores = None
         if output_scores and do_sample:
@@ -142,6 +197,68 @@ class GenerationMixin:
                 out["greedy_margins"] = torch.stack([m[1] for m in margins], 1)
             return out
         return ids
+
+    def _generate_eager(self, ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, bos_token_id, eos_token_id, pad_token_id,
+                        forced_tokens, return_margins):
+        """Eagerly launched greedy loop with per-step argmax / margin capture and optional teacher forcing (parity tests)."""
+        dev = self.device
+        B = ids.shape[0]
+        prompt_len = ids.shape[1]
+        margins = []
+        with torch.no_grad():
+            cache = self._dec.new_cache(B, max_length, dev)
+            unfinished = torch.ones(B, dtype=torch.int32, device=dev)
+            step = 0
+            while ids.shape[1] < max_length:
+                fed = self._fed(ids, bos_token_id)
+                new, mask, tt, pos = self._step_inputs(fed, special_token_ids, mask_token_id, prefill=cache.len == 0)
+                logits = self._dec.decode(cache, new.contiguous(), enc16, enc_mask8, mask, tt.contiguous(), None if pos is None else pos.contiguous())
+                if forced_tokens is not None:
+                    greedy_tok, mg = ops.select_token(logits, need_margin=True)
+                    margins.append((greedy_tok, mg))
+                    nxt = forced_tokens[:, step].to(dev).clone()
+                    if eos_token_id is not None:
+                        nxt = torch.where(unfinished.bool(), nxt, torch.full_like(nxt, pad_token_id))
+                        unfinished = unfinished & (nxt != eos_token_id).int()
+                else:
+                    nxt, mg = ops.select_token(logits, unfinished=unfinished if eos_token_id is not None else None,
+                                               eos=eos_token_id if eos_token_id is not None else -1, pad=pad_token_id or 0, need_margin=True)
+                    margins.append((nxt.clone(), mg))
+                ids = torch.cat([ids, nxt[:, None]], dim=-1)
+                step += 1
+                if forced_tokens is not None and step >= forced_tokens.shape[1]:
+                    break
+                if eos_token_id is not None and forced_tokens is None and int(unfinished.max()) == 0:
+                    break
+        return ids, margins
+
+    def _generate_session(self, ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, bos_token_id, eos_token_id, pad_token_id,
+                          do_sample, top_k, temperature, rec):
+        """Greedy / top-k sampling over a DecodeSession (static buffers, graph-replayed steps, EOS polled every 8 steps)."""
+        dev = self.device
+        B, prompt_len = ids.shape
+        strip = 1 if (self.kind == "longitudinal" and bool(torch.all(ids[:, 0] == bos_token_id))) else 0
+        with torch.no_grad():
+            ses = self._session(B, enc16.shape[1], max_length, enc_mask8 is not None)
+            ses.reset(ids, enc16, enc_mask8)
+            mode = (bool(do_sample), tuple(special_token_ids), mask_token_id, int(top_k or 0), float(temperature), eos_token_id, pad_token_id)
+            cur = prompt_len
+            while cur < max_length:
+                ses.step(cur, strip, mode)
+                if rec is not None:
+                    rec["tt"].append(ses.last_tt.clone())
+                    rec["pos"].append(None if ses.last_pos is None else ses.last_pos.clone())
+                cur += 1
+                if eos_token_id is not None and ((cur - prompt_len) % 8 == 0) and int(ses.unfinished.max()) == 0:
+                    break
+            out = ses.ids[:, :cur].clone()
+            # HF stops at the step on which the last row finishes: trim what the 8-step polling overshot
+            if eos_token_id is not None:
+                gen = out[:, prompt_len:]
+                is_eos = gen == eos_token_id
+                first = torch.where(is_eos.any(1), is_eos.int().argmax(1) + 1, torch.full((B,), gen.shape[1], device=dev))
+                out = out[:, : prompt_len + int(first.max())]
+        return out
 
     generate = torch.no_grad()(_generate)          # `.generate.__wrapped__` is the grad-enabled body (reference scst/gt_prompt.py:162)
 

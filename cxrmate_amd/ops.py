@@ -93,9 +93,43 @@ def gemm_tn(p, q, out, dbias=None, alpha=1.0):
     return out
 
 
+# Weight-gradient work (split-K TN GEMMs, depthwise-conv tap sums) only feeds the optimiser, never the dX chain: when WGRAD_STREAM is
+# set (training.py) it is issued on that side stream so that these atomics-/latency-bound kernels overlap the MFMA-bound dX GEMMs and
+# attention kernels of the main stream. The side stream waits for the main stream's current position (operands are ready), operands
+# are pinned with record_stream, and the step joins the side stream before the all-reduce / optimiser (wgrad_join).
+WGRAD_STREAM = None
+
+
+class _on_wgrad_stream:
+    def __init__(self, *tensors):
+        self.tensors = tensors
+
+    def __enter__(self):
+        self.side = WGRAD_STREAM
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.ctx.__exit__(*exc)
+            for t in self.tensors:
+                if t is not None:
+                    t.record_stream(self.side)
+        return False
+
+
+def wgrad_join():
+    if WGRAD_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+
+
 def linear_bwd_weight(dy, x, dw, db=None):
     """dw[N,K] += dy[M,N]^T @ x[M,K]; db[N] += colsum(dy)   (one split-K TN kernel; no transposes)."""
-    gemm_tn(dy, x, dw, dbias=db)
+    with _on_wgrad_stream(dy, x):
+        gemm_tn(dy, x, dw, dbias=db)
 
 
 def linear_bwd_input(dy, w_t, **kw):
@@ -160,8 +194,12 @@ def layernorm_bwd(x, dy, gamma, stats, dgamma, dbeta, add=None, out=None):
     rows, C = x.shape
     if out is None:
         out = torch.empty((rows, C), device=x.device, dtype=BF16)
+    ws = None
+    if dgamma is not None:
+        nb = LIB.load().cxr_layernorm_bwd_grid(rows, C)
+        ws = torch.empty((nb, 2, C), device=x.device, dtype=torch.float32)
     LIB.call("cxr_layernorm_bwd_bf16", _p(x), x.stride(0), _p(dy), dy.stride(0), _p(gamma), _p(stats), _p(add),
-             add.stride(0) if add is not None else 0, _p(out), out.stride(0), _p(dgamma), _p(dbeta), rows, C, _s())
+             add.stride(0) if add is not None else 0, _p(out), out.stride(0), _p(dgamma), _p(dbeta), _p(ws), rows, C, _s())
     return out
 
 
@@ -258,14 +296,27 @@ def bert_embed_bwd(dsum, ids, tt, pid, dword, dtype_, dpos, T, pos_offset, paddi
              int(padding_idx), dsum.shape[1], _s())
 
 
-def token_type_ids(ids, special, sections, past=False):
-    """Device version of token_ids_to_token_type_ids[_past]; ids int64 [B,T]."""
+_SPECIAL_CACHE = {}
+
+
+def special_tensors(special, sections, device):
+    """Device copies of (special ids, section ids), cached: generation asks for the same handful every step (no per-step H2D copy)."""
+    sections = tuple(sections) if sections is not None else tuple(range(len(special) + 1))
+    key = (tuple(special), sections, str(device))
+    hit = _SPECIAL_CACHE.get(key)
+    if hit is None:
+        hit = (torch.tensor(list(special), dtype=torch.int64, device=device), torch.tensor(list(sections), dtype=torch.int64, device=device))
+        _SPECIAL_CACHE[key] = hit
+    return hit
+
+
+def token_type_ids(ids, special, sections, past=False, out=None):
+    """Device version of token_ids_to_token_type_ids[_past]; ids int64 [B,T] (row stride free)."""
     assert ids.dtype == torch.int64 and ids.stride(1) == 1
     B, T = ids.shape
-    sp = torch.tensor(list(special), dtype=torch.int64, device=ids.device)
-    sections = sections if sections is not None else list(range(len(special) + 1))
-    se = torch.tensor(list(sections), dtype=torch.int64, device=ids.device)
-    out = torch.empty((B, 1 if past else T), dtype=torch.int64, device=ids.device)
+    sp, se = special_tensors(special, sections, ids.device)
+    if out is None:
+        out = torch.empty((B, 1 if past else T), dtype=torch.int64, device=ids.device)
     LIB.call("cxr_token_type_ids", _p(ids), ids.stride(0), B, T, _p(sp), _p(se), len(special), _p(out), out.stride(0), int(past), _s())
     return out
 
@@ -317,10 +368,10 @@ def topk_threshold(logits, k):
     return thr
 
 
-def select_token(logits, mode=0, temperature=1.0, top_k=0, u=None, unfinished=None, eos=-1, pad=0, need_margin=False):
+def select_token(logits, mode=0, temperature=1.0, top_k=0, u=None, unfinished=None, eos=-1, pad=0, need_margin=False, out=None):
     R, V = logits.shape
     assert logits.dtype == torch.float32 and logits.stride(1) == 1
-    nxt = torch.empty((R,), dtype=torch.int64, device=logits.device)
+    nxt = out if out is not None else torch.empty((R,), dtype=torch.int64, device=logits.device)
     margin = torch.empty((R,), dtype=torch.float32, device=logits.device) if need_margin else None
     LIB.call("cxr_select_token", _p(logits), logits.stride(0), R, V, mode, float(temperature), int(top_k), _p(u), _p(nxt), _p(unfinished),
              int(eos), int(pad), _p(margin), _s())
@@ -333,9 +384,14 @@ def log_softmax_rows_(x, add_row=None):
 
 
 # ------------------------------------------------------------------------------------------------ optimiser / plumbing
-def adamw_step(p, g, m, v, p16, lr, b1, b2, eps, wd, step, gscale=1.0):
+def adamw_step(p, g, m, v, p16, lr, b1, b2, eps, wd, step, gscale=1.0, step_dev=None):
+    """step >= 1: host step count. step == 0 with step_dev (int32 device scalar): the kernel reads the count itself (graph replay)."""
     LIB.call("cxr_adamw_step", _p(p), _p(g), _p(m), _p(v), _p(p16), p.numel(), float(lr), float(b1), float(b2), float(eps), float(wd),
-             int(step), float(gscale), _s())
+             int(step), _p(step_dev), float(gscale), _s())
+
+
+def increment_(counter):
+    LIB.call("cxr_increment_i32", _p(counter), _s())
 
 
 def cast_to_bf16(src, dst=None):
@@ -405,4 +461,27 @@ def cosine_rows(a, b, eps=1e-8):
     R, C = a.shape
     out = torch.empty((R,), dtype=torch.float32, device=a.device)
     LIB.call("cxr_cosine_rows_f32", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), R, C, float(eps), _s())
+    return out
+
+
+def gemm_skinny(a, w, bias=None, residual=None, act=0, out=None, out_f32=False):
+    """Decode-step linear: a [M<=64, K] @ w[N, K]^T (+bias, GELU, +residual). Weight-streaming kernel (no LDS staging)."""
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else BF16)
+    LIB.call("cxr_gemm_skinny_bf16", _p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias), _p(residual),
+             residual.stride(0) if residual is not None else 0, M, N, K, int(act), int(out_f32), _s())
+    return out
+
+
+def attention_decode(q, k, v, heads, scale, kpm=None, out=None):
+    """q [B,1,H*64] (or [B,H*64]); k, v [B,Tk,H*64] views (batch/row strides free) -> [B, H*64]"""
+    B = q.shape[0]
+    D = heads * 64
+    Tk = k.shape[1]
+    if out is None:
+        out = torch.empty((B, D), device=q.device, dtype=BF16)
+    LIB.call("cxr_attn_decode_bf16", _p(q), _p(k), _p(v), _p(out), _p(kpm), q.stride(0), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+             out.stride(0), kpm.stride(0) if kpm is not None else 0, B, heads, Tk, float(scale), _s())
     return out

