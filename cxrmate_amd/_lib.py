@@ -40,6 +40,7 @@ class CxrError(RuntimeError):
 class _Lib:
     def __init__(self):
         self._dll = None
+        self._fns = {}
         self.protos = parse_header()
 
     def load(self):
@@ -56,7 +57,9 @@ class _Lib:
         return self._dll
 
     def call(self, name: str, *args):
-        fn = getattr(self.load(), name)
+        fn = self._fns.get(name)
+        if fn is None:
+            fn = self._fns[name] = getattr(self.load(), name)
         rc = fn(*args)
         if rc != 0:
             detail = ""

@@ -34,14 +34,18 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // NST = number of LDS stages. NST == 2: one tile in flight behind the math (vmcnt(0) + __syncthreads per K step).
 // NST >= 3 (LDS-DMA only): NST-1 tiles in flight across raw s_barriers with a COUNTED vmcnt, so that the HBM/L2 latency of the
 // short K loops of this model (K = 384..768 -> 6..24 steps) is covered by more than one step of MFMA work.
-template <int BK, bool GLDS, int NST>
+// BN = 128: 128x128 tile (wave tile 64x64). BN = 64: 128x64 tile (wave tile 64x32) for outputs whose 128x128 tiling would leave CUs idle
+// or waste half a tile (N = 64 / 192, or fewer than ~1.5 tiles per CU).
+template <int BK, bool GLDS, int NST, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
-    constexpr int BM = 128, BN = 128;
+    constexpr int BM = 128;
+    constexpr int NTL = BN / 32;                // 16-column MFMA tiles per wave along N
     constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
-    constexpr int SLOTS = BM * CPR;             // 16-byte slots per operand tile
+    constexpr int SLOTS = BM * CPR;             // 16-byte slots of the A tile
     constexpr int PASSES = SLOTS / 256;
+    constexpr int WPASSES = BN * CPR / 256;
     constexpr int TILE_BYTES = SLOTS * 16;
-    constexpr int LPS = 2 * PASSES;             // LDS-DMA instructions per thread per stage
+    constexpr int LPS = PASSES + WPASSES;       // LDS-DMA instructions per thread per stage
     __shared__ __attribute__((aligned(16))) unsigned char lds[NST * 2 * TILE_BYTES];   // [stage][A|W]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -59,16 +63,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
 
     // per-thread staging sources (row clamp keeps every load in bounds; out-of-range rows are never stored)
     const bf16_t* srcA[PASSES];
-    const bf16_t* srcW[PASSES];
+    const bf16_t* srcW[WPASSES];
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int s = p * 256 + tid;
         const int row = s / CPR, cp = s % CPR;
         const int c = cp ^ Swz<BK>::f(row);
         int ra = tm * BM + row; ra = ra < g.M ? ra : g.M - 1;
-        int rw = tn * BN + row; rw = rw < g.N ? rw : g.N - 1;
         srcA[p] = g.A + (long)ra * g.lda + c * 8;
-        srcW[p] = g.W + (long)rw * g.ldw + c * 8;
+        if (p < WPASSES) {
+            int rw = tn * BN + row; rw = rw < g.N ? rw : g.N - 1;
+            srcW[p] = g.W + (long)rw * g.ldw + c * 8;
+        }
     }
 
     auto stage = [&](int buf, int kt) {
@@ -81,20 +87,23 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
                 const int wbase = (p * 256 + wave * 64) * 16;      // wave-uniform; hardware adds lane*16
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[p] + k0),
                                                  (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[p] + k0),
-                                                 (__attribute__((address_space(3))) void*)(lw + wbase), 16, 0, 0);
+                if (p < WPASSES)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[p] + k0),
+                                                     (__attribute__((address_space(3))) void*)(lw + wbase), 16, 0, 0);
             } else {
                 const uint4 va = *reinterpret_cast<const uint4*>(srcA[p] + k0);
-                const uint4 vw = *reinterpret_cast<const uint4*>(srcW[p] + k0);
                 *reinterpret_cast<uint4*>(la + (p * 256 + tid) * 16) = va;
-                *reinterpret_cast<uint4*>(lw + (p * 256 + tid) * 16) = vw;
+                if (p < WPASSES) {
+                    const uint4 vw = *reinterpret_cast<const uint4*>(srcW[p] + k0);
+                    *reinterpret_cast<uint4*>(lw + (p * 256 + tid) * 16) = vw;
+                }
             }
         }
     };
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[NTL][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NTL; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -128,17 +137,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
         const unsigned char* lw = lds + (cur * 2 + 1) * TILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
-            bf16x8_t fa[4], fw[4];
+            bf16x8_t fa[4], fw[NTL];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int ra = wm * 64 + t * 16 + fr;
-                const int rw = wn * 64 + t * 16 + fr;
                 const int c = kk * 4 + fq;
                 fa[t] = *reinterpret_cast<const bf16x8_t*>(la + (ra * CPR + (c ^ Swz<BK>::f(ra))) * 16);
-                fw[t] = *reinterpret_cast<const bf16x8_t*>(lw + (rw * CPR + (c ^ Swz<BK>::f(rw))) * 16);
+                if (t < NTL) {
+                    const int rw = wn * (BN / 2) + t * 16 + fr;
+                    fw[t] = *reinterpret_cast<const bf16x8_t*>(lw + (rw * CPR + (c ^ Swz<BK>::f(rw))) * 16);
+                }
             }
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
@@ -151,8 +162,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
         const int m = tm * BM + wm * 64 + mt * 16 + fr;
         if (m >= g.M) continue;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n0 = tn * BN + wn * 64 + nt * 16 + fq * 4;
+        for (int nt = 0; nt < NTL; ++nt) {
+            const int n0 = tn * BN + wn * (BN / 2) + nt * 16 + fq * 4;
             if (n0 >= g.N) continue;
             float v[4];
 #pragma unroll
@@ -212,22 +223,30 @@ extern "C" int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = C; g.ldc = ldc;
     g.bias = bias; g.residual = (const bf16_t*)residual; g.ldr = ldr; g.aux = (bf16_t*)aux; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.act = act; g.out_f32 = out_f32; g.accumulate = accumulate;
-    const int grid = cdiv(M, 128) * cdiv(N, 128);
-    static int force_bk = -1;                 // tuning aid: CXR_GEMM_BK=32 forces the 32-deep K tile (4-5 workgroups per CU)
+    static int force_bk = -1, stages = -1, force_bn = -1;     // tuning aids: CXR_GEMM_BK=32|64, CXR_GEMM_STAGES=2|3|4, CXR_GEMM_BN=64|128
     if (force_bk < 0) { const char* e = getenv("CXR_GEMM_BK"); force_bk = e ? atoi(e) : 0; }
-    const bool bk64 = (K % 64) == 0 && force_bk != 32;
-    static int stages = -1;                   // tuning aid: CXR_GEMM_STAGES=2|3|4
     if (stages < 0) { const char* e = getenv("CXR_GEMM_STAGES"); stages = e ? atoi(e) : 2; }
+    if (force_bn < 0) { const char* e = getenv("CXR_GEMM_BN"); force_bn = e ? atoi(e) : 0; }
+    const bool bk64 = (K % 64) == 0 && force_bk != 32;
+    // narrow tile when the last N tile would be mostly empty (N = 64, 192) or when 128x128 tiling gives fewer than ~1.5 tiles per CU
+    const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128);
+    bool bn64 = (N % 128) != 0 && (N % 128) <= 64;
+    if (tiles128 < 160) bn64 = true;
+    if (force_bn == 64) bn64 = true; else if (force_bn == 128) bn64 = false;
+    const int grid = cdiv(M, 128) * cdiv(N, bn64 ? 64 : 128);
     if (g_gemm_regstage) {
-        if (bk64) CXR_LAUNCH((gemm_nt_kernel<64, false, 2>), dim3(grid), dim3(256), 0, stream, g);
-        else      CXR_LAUNCH((gemm_nt_kernel<32, false, 2>), dim3(grid), dim3(256), 0, stream, g);
+        if (bk64) CXR_LAUNCH((gemm_nt_kernel<64, false, 2, 128>), dim3(cdiv(M, 128) * cdiv(N, 128)), dim3(256), 0, stream, g);
+        else      CXR_LAUNCH((gemm_nt_kernel<32, false, 2, 128>), dim3(cdiv(M, 128) * cdiv(N, 128)), dim3(256), 0, stream, g);
     } else if (stages >= 4 && force_bk != 64) {
-        CXR_LAUNCH((gemm_nt_kernel<32, true, 4>), dim3(grid), dim3(256), 0, stream, g);
+        CXR_LAUNCH((gemm_nt_kernel<32, true, 4, 128>), dim3(cdiv(M, 128) * cdiv(N, 128)), dim3(256), 0, stream, g);
     } else if (stages == 3 && force_bk != 64) {
-        CXR_LAUNCH((gemm_nt_kernel<32, true, 3>), dim3(grid), dim3(256), 0, stream, g);
+        CXR_LAUNCH((gemm_nt_kernel<32, true, 3, 128>), dim3(cdiv(M, 128) * cdiv(N, 128)), dim3(256), 0, stream, g);
+    } else if (bn64) {
+        if (bk64) CXR_LAUNCH((gemm_nt_kernel<64, true, 2, 64>), dim3(grid), dim3(256), 0, stream, g);
+        else      CXR_LAUNCH((gemm_nt_kernel<32, true, 2, 64>), dim3(grid), dim3(256), 0, stream, g);
     } else {
-        if (bk64) CXR_LAUNCH((gemm_nt_kernel<64, true, 2>), dim3(grid), dim3(256), 0, stream, g);
-        else      CXR_LAUNCH((gemm_nt_kernel<32, true, 2>), dim3(grid), dim3(256), 0, stream, g);
+        if (bk64) CXR_LAUNCH((gemm_nt_kernel<64, true, 2, 128>), dim3(grid), dim3(256), 0, stream, g);
+        else      CXR_LAUNCH((gemm_nt_kernel<32, true, 2, 128>), dim3(grid), dim3(256), 0, stream, g);
     }
     CXR_LAUNCH_CHECK();
     return CXR_OK;

@@ -11,64 +11,72 @@ template <int C> struct LNCfg {
     static constexpr int RPW = 64 / LPR;                                // rows per wave
 };
 
-template <int C>
+// U rows per row-group per iteration: all loads of the U rows are issued before the first reduction, so every lane keeps U (forward)
+// or 2-3 U (backward) 16-byte loads in flight -- at 8 waves per CU a single row per iteration leaves the kernel latency-bound (~2 TB/s).
+template <int C, int U>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ y, long ldy,
                                                             float* __restrict__ stats, long rows, float eps) {
     using L = LNCfg<C>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % L::LPR, grp = lane / L::LPR;
-    const long rows_per_block = 4 * L::RPW;
+    const long rows_per_block = 4 * L::RPW * U;
     for (long base = (long)blockIdx.x * rows_per_block; base < rows; base += (long)gridDim.x * rows_per_block) {
-        const long row = base + wave * L::RPW + grp;
-        const bool live = row < rows;
-        float v[L::CPL][8];
-        float s = 0.f;
+        float v[U][L::CPL][8];
+        long row[U];
 #pragma unroll
-        for (int i = 0; i < L::CPL; ++i) {
-            const int ch = sub + i * L::LPR;
-            if (live && ch < L::CH) {
-                const uint4 u = *reinterpret_cast<const uint4*>(x + row * ldx + ch * 8);
-                unpack8(u, v[i]);
-            } else {
+        for (int u = 0; u < U; ++u) {
+            row[u] = base + u * 4 * L::RPW + wave * L::RPW + grp;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
-            }
+            for (int i = 0; i < L::CPL; ++i) {
+                const int ch = sub + i * L::LPR;
+                if (row[u] < rows && ch < L::CH) {
+                    unpack8(*reinterpret_cast<const uint4*>(x + row[u] * ldx + ch * 8), v[u][i]);
+                } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += v[i][j];
-        }
-        const float mean = group_sum<L::LPR>(s) * (1.0f / C);
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < L::CPL; ++i) {
-            const int ch = sub + i * L::LPR;
-            if (ch < L::CH) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+                    for (int j = 0; j < 8; ++j) v[u][i][j] = 0.f;
+                }
             }
         }
-        const float rstd = rsqrtf(group_sum<L::LPR>(q) * (1.0f / C) + eps);
-        if (!live) continue;
 #pragma unroll
-        for (int i = 0; i < L::CPL; ++i) {
-            const int ch = sub + i * L::LPR;
-            if (ch < L::CH) {
-                const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch * 8), g1 = *reinterpret_cast<const float4*>(gamma + ch * 8 + 4);
-                const float4 b0 = *reinterpret_cast<const float4*>(beta + ch * 8), b1 = *reinterpret_cast<const float4*>(beta + ch * 8 + 4);
-                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-                float o[8];
+        for (int u = 0; u < U; ++u) {
+            float s = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
-                *reinterpret_cast<uint4*>(y + row * ldy + ch * 8) = pack8(o);
+            for (int i = 0; i < L::CPL; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[u][i][j];
+            const float mean = group_sum<L::LPR>(s) * (1.0f / C);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < L::CPL; ++i) {
+                if (sub + i * L::LPR < L::CH) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float d = v[u][i][j] - mean; q += d * d; }
+                }
             }
+            const float rstd = rsqrtf(group_sum<L::LPR>(q) * (1.0f / C) + eps);
+            if (row[u] >= rows) continue;
+#pragma unroll
+            for (int i = 0; i < L::CPL; ++i) {
+                const int ch = sub + i * L::LPR;
+                if (ch < L::CH) {
+                    const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch * 8), g1 = *reinterpret_cast<const float4*>(gamma + ch * 8 + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(beta + ch * 8), b1 = *reinterpret_cast<const float4*>(beta + ch * 8 + 4);
+                    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                    float o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (v[u][i][j] - mean) * rstd * gg[j] + bb[j];
+                    *reinterpret_cast<uint4*>(y + row[u] * ldy + ch * 8) = pack8(o);
+                }
+            }
+            if (stats && sub == 0) { stats[2 * row[u]] = mean; stats[2 * row[u] + 1] = rstd; }
         }
-        if (stats && sub == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
     }
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ;  dgamma += sum dy*xhat ; dbeta += sum dy
-template <int C>
+template <int C, int U>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
                                                             const float* __restrict__ gamma, const float* __restrict__ stats,
                                                             const bf16_t* __restrict__ add, long ldadd,
@@ -80,59 +88,74 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % L::LPR, grp = lane / L::LPR;
-    const long rows_per_block = 4 * L::RPW;
-    float ag[L::CPL][8], ab[L::CPL][8];
+    const long rows_per_block = 4 * L::RPW * U;
+    float ag[L::CPL][8], ab[L::CPL][8], gam[L::CPL][8];
 #pragma unroll
-    for (int i = 0; i < L::CPL; ++i)
+    for (int i = 0; i < L::CPL; ++i) {
+        const int ch = sub + i * L::LPR;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; }
+        for (int j = 0; j < 8; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; gam[i][j] = ch < L::CH ? gamma[ch * 8 + j] : 0.f; }
+    }
     for (long base = (long)blockIdx.x * rows_per_block; base < rows; base += (long)gridDim.x * rows_per_block) {
-        const long row = base + wave * L::RPW + grp;
-        const bool live = row < rows;
-        float mean = 0.f, rstd = 0.f;
-        if (live) { mean = stats[2 * row]; rstd = stats[2 * row + 1]; }
-        float xh[L::CPL][8], g[L::CPL][8];
-        float s1 = 0.f, s2 = 0.f;
+        uint4 xr[U][L::CPL], dr[U][L::CPL], ar[U][L::CPL];
+        long row[U];
+        float mean[U], rstd[U];
 #pragma unroll
-        for (int i = 0; i < L::CPL; ++i) {
-            const int ch = sub + i * L::LPR;
-            if (live && ch < L::CH) {
-                float xv[8], dv[8];
-                unpack8(*reinterpret_cast<const uint4*>(x + row * ldx + ch * 8), xv);
-                unpack8(*reinterpret_cast<const uint4*>(dy + row * lddy + ch * 8), dv);
-                const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch * 8), g1 = *reinterpret_cast<const float4*>(gamma + ch * 8 + 4);
-                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        for (int u = 0; u < U; ++u) {
+            row[u] = base + u * 4 * L::RPW + wave * L::RPW + grp;
+            const bool live = row[u] < rows;
+            const long rc = live ? row[u] : rows - 1;
+            mean[u] = stats[2 * rc]; rstd[u] = stats[2 * rc + 1];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    xh[i][j] = (xv[j] - mean) * rstd;
-                    g[i][j] = dv[j] * gg[j];
-                    s1 += g[i][j];
-                    s2 += g[i][j] * xh[i][j];
-                    ag[i][j] += dv[j] * xh[i][j];
-                    ab[i][j] += dv[j];
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { xh[i][j] = 0.f; g[i][j] = 0.f; }
+            for (int i = 0; i < L::CPL; ++i) {
+                const int ch = sub + i * L::LPR;
+                const int cc = ch < L::CH ? ch : 0;
+                xr[u][i] = *reinterpret_cast<const uint4*>(x + rc * ldx + cc * 8);
+                dr[u][i] = *reinterpret_cast<const uint4*>(dy + rc * lddy + cc * 8);
+                if (add) ar[u][i] = *reinterpret_cast<const uint4*>(add + rc * ldadd + cc * 8);
             }
         }
-        s1 = group_sum<L::LPR>(s1) * (1.0f / C);
-        s2 = group_sum<L::LPR>(s2) * (1.0f / C);
-        if (!live) continue;
 #pragma unroll
-        for (int i = 0; i < L::CPL; ++i) {
-            const int ch = sub + i * L::LPR;
-            if (ch < L::CH) {
-                float o[8];
+        for (int u = 0; u < U; ++u) {
+            const bool live = row[u] < rows;
+            float xh[L::CPL][8], g[L::CPL][8];
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
-                if (add) {
-                    float av[8];
-                    unpack8(*reinterpret_cast<const uint4*>(add + row * ldadd + ch * 8), av);
+            for (int i = 0; i < L::CPL; ++i) {
+                const int ch = sub + i * L::LPR;
+                float xv[8], dv[8];
+                unpack8(xr[u][i], xv);
+                unpack8(dr[u][i], dv);
+                const bool on = live && ch < L::CH;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] += av[j];
+                for (int j = 0; j < 8; ++j) {
+                    xh[i][j] = on ? (xv[j] - mean[u]) * rstd[u] : 0.f;
+                    const float d = on ? dv[j] : 0.f;
+                    g[i][j] = d * gam[i][j];
+                    s1 += g[i][j];
+                    s2 += g[i][j] * xh[i][j];
+                    ag[i][j] += d * xh[i][j];
+                    ab[i][j] += d;
                 }
-                *reinterpret_cast<uint4*>(dx + row * lddx + ch * 8) = pack8(o);
+            }
+            s1 = group_sum<L::LPR>(s1) * (1.0f / C);
+            s2 = group_sum<L::LPR>(s2) * (1.0f / C);
+            if (!live) continue;
+#pragma unroll
+            for (int i = 0; i < L::CPL; ++i) {
+                const int ch = sub + i * L::LPR;
+                if (ch < L::CH) {
+                    float o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = rstd[u] * (g[i][j] - s1 - xh[i][j] * s2);
+                    if (add) {
+                        float av[8];
+                        unpack8(ar[u][i], av);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] += av[j];
+                    }
+                    *reinterpret_cast<uint4*>(dx + row[u] * lddx + ch * 8) = pack8(o);
+                }
             }
         }
     }
@@ -151,38 +174,46 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
     }
 }
 
-// dgamma[c] += sum_b partial[b][0][c]; dbeta[c] += sum_b partial[b][1][c].  Block = 32 columns x 8 partial-row lanes.
+// dgamma[c] += sum_b partial[b][0][c]; dbeta[c] += sum_b partial[b][1][c].  Block = 32 columns x 64 partial rows (8 row lanes x 8 rows each);
+// grid.y covers the partial rows, so the 6 MB of partials of a 2048-workgroup launch are summed by ~1500 workgroups, then ONE atomic per
+// (column, 64-row chunk) -- 32x fewer contended atomics than adding from the main kernel.
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int C,
                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
     __shared__ float red[8][32];
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + cl;                      // index into the 2*C concatenated [gamma | beta] sums
+    const int b0 = blockIdx.y * 64 + rl * 8;
     float s = 0.f;
-    if (i < 2 * C)
-        for (int b = rl; b < nblocks; b += 8) s += partial[(long)b * 2 * C + i];
+    if (i < 2 * C) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (b0 + u < nblocks) ? partial[(long)(b0 + u) * 2 * C + i] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
     red[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && i < 2 * C) {
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) t += red[r][cl];
-        if (i < C) dgamma[i] += t; else dbeta[i - C] += t;
+        atomicAdd(i < C ? dgamma + i : dbeta + (i - C), t);
     }
 }
 
-#define LN_DISPATCH(C_, KERNEL, ...)                                                             \
-    switch (C_) {                                                                                \
-        case 64: CXR_LAUNCH((KERNEL<64>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;    \
-        case 128: CXR_LAUNCH((KERNEL<128>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;  \
-        case 192: CXR_LAUNCH((KERNEL<192>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;  \
-        case 384: CXR_LAUNCH((KERNEL<384>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;  \
-        case 768: CXR_LAUNCH((KERNEL<768>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;  \
-        default: return CXR_ERR_ARG;                                                              \
+#define LN_DISPATCH(C_, KERNEL, U64, U128, U192, U384, U768, ...)                                                     \
+    switch (C_) {                                                                                                        \
+        case 64: CXR_LAUNCH((KERNEL<64, U64>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;                    \
+        case 128: CXR_LAUNCH((KERNEL<128, U128>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;                 \
+        case 192: CXR_LAUNCH((KERNEL<192, U192>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;                 \
+        case 384: CXR_LAUNCH((KERNEL<384, U384>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;                 \
+        case 768: CXR_LAUNCH((KERNEL<768, U768>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;                 \
+        default: return CXR_ERR_ARG;                                                                                     \
     }
 
-static inline int ln_grid(long rows, int C) {
+static inline int ln_grid(long rows, int C, int U) {
     const int lpr = C / 8 > 32 ? 64 : (C / 8 > 16 ? 32 : (C / 8 > 8 ? 16 : (C / 8 > 4 ? 8 : 4)));
-    const long rpb = 4 * (64 / lpr);
+    const long rpb = 4 * (64 / lpr) * U;
     long g = (rows + rpb - 1) / rpb;
     return (int)(g < 4096 ? g : 4096);
 }
@@ -190,15 +221,15 @@ static inline int ln_grid(long rows, int C) {
 extern "C" int cxr_layernorm_fwd_bf16(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
                                       float* stats, long rows, int C, float eps, hipStream_t stream) {
     if (rows <= 0 || (ldx % 8) || (ldy % 8)) return CXR_ERR_ARG;
-    const int grid = ln_grid(rows, C);
-    LN_DISPATCH(C, layernorm_fwd_kernel, (const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, stats, rows, eps);
+    const int grid = ln_grid(rows, C, C == 768 ? 2 : 4);
+    LN_DISPATCH(C, layernorm_fwd_kernel, 4, 4, 4, 4, 2, (const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, stats, rows, eps);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
 
 // workspace: fp32 [cxr_layernorm_bwd_grid(rows, C)][2][C] (may be null when dgamma/dbeta are not wanted)
 extern "C" int cxr_layernorm_bwd_grid(long rows, int C) {
-    int grid = ln_grid(rows, C);
+    int grid = ln_grid(rows, C, C == 768 ? 1 : 2);
     return grid < 512 ? grid : 512;
 }
 
@@ -208,9 +239,9 @@ extern "C" int cxr_layernorm_bwd_bf16(const void* x, long ldx, const void* dy, l
     if (rows <= 0 || (ldx % 8) || (lddy % 8) || (lddx % 8) || (add && (ldadd % 8)) || (dgamma && !workspace)) return CXR_ERR_ARG;
     const int grid = cxr_layernorm_bwd_grid(rows, C);
     float* partial = dgamma ? workspace : nullptr;
-    LN_DISPATCH(C, layernorm_bwd_kernel, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, gamma, stats, (const bf16_t*)add, ldadd,
+    LN_DISPATCH(C, layernorm_bwd_kernel, 2, 2, 2, 2, 1, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, gamma, stats, (const bf16_t*)add, ldadd,
                 (bf16_t*)dx, lddx, partial, rows);
-    if (dgamma) CXR_LAUNCH(layernorm_bwd_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, stream, partial, grid, C, dgamma, dbeta);
+    if (dgamma) CXR_LAUNCH(layernorm_bwd_reduce_kernel, dim3(cdiv(2 * C, 32), cdiv(grid, 64)), dim3(256), 0, stream, partial, grid, C, dgamma, dbeta);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

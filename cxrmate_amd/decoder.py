@@ -45,6 +45,7 @@ class BertEngine:
         self.p = prefix + ("base_model.model." if cfg.lora_r else "")
         self._prep_version = -1
         self._prep = {}
+        self._wt_ready = False
 
     # ------------------------------------------------------------------------------------------ parameters
     def _lin(self, base):
@@ -74,7 +75,35 @@ class BertEngine:
                     ops.gemm_nt(b_pad, a_t, out=w, out_f32=True, accumulate=True, alpha=scale)   # W + (alpha/r) B A
                     prep[("lora", base)] = ops.cast_to_bf16(w, prep.get(("lora", base)))
         self._prep, self._prep_version = prep, st.shadow_version
+        self._wt_ready = False
         return prep
+
+    def _linear_names(self):
+        cfg, p = self.cfg, self.p
+        names = []
+        for l in range(cfg.num_hidden_layers):
+            lp = p + f"bert.encoder.layer.{l}."
+            blocks = ["attention"] + (["crossattention"] if cfg.add_cross_attention else [])
+            for blk in blocks:
+                names += [lp + f"{blk}.self.query", lp + f"{blk}.self.key", lp + f"{blk}.self.value", lp + f"{blk}.output.dense"]
+            names += [lp + "intermediate.dense", lp + "output.dense"]
+        return names
+
+    def _prepare_transposes(self):
+        """W^T of every Linear (+ the padded word-embedding transpose for the LM-head dX) for the current weight version, issued on
+        the weight-gradient side stream during the training forward (off the critical path); backward joins it."""
+        if self._wt_ready:
+            return
+        st, prep, p = self.s, self._prep, self.p
+        with ops._on_wgrad_stream():
+            for base in self._linear_names():
+                prep[("wt", base)] = ops.transpose(self._lin(base)[0], out=prep.get(("wt", base)))
+            if not self.cfg.cls_projection_size:
+                k = p + "cls.predictions.transform.dense"
+                prep[("wt", k)] = ops.transpose(st.w16(k + ".weight"), out=prep.get(("wt", k)))
+                k = p + "bert.embeddings.word_embeddings.weight"
+                prep[("wt", k)] = ops.transpose(st.w16(k), 64, out=prep.get(("wt", k)))
+        self._wt_ready = True
 
     # ------------------------------------------------------------------------------------------ teacher-forced forward
     def forward(self, ids, enc=None, enc_mask=None, attn_mask=None, token_type_ids=None, position_ids=None, save=False, causal=True,
@@ -82,6 +111,8 @@ class BertEngine:
         """ids int64 [B,T]; enc bf16 [B,S,D] | None; masks uint8 (1 = attend). -> logits fp32 [B,T,V] (or hidden bf16 [B,T,D]), saved"""
         cfg, st, p = self.cfg, self.s, self.p
         self.prepare()
+        if save:
+            self._prepare_transposes()
         B, T = ids.shape
         D, nh = cfg.hidden_size, cfg.num_attention_heads
         R = B * T
@@ -168,13 +199,15 @@ class BertEngine:
         ops.gemm_nt(bt, ops.transpose(dw16), out=st.grad(base + ".lora_A.default.weight"), out_f32=True, accumulate=True, alpha=scale)
 
     def _wt(self, base):
-        return ops.transpose(self._lin(base)[0])
+        return self._prep[("wt", base)]
 
     def backward(self, saved, dlogits=None, dhidden=None, need_denc=False):
         """dlogits bf16 [R, V] (row stride may be padded to a multiple of 64) or dhidden bf16 [R, D]. Accumulates parameter
         gradients into the store; returns d(enc) bf16 [B,S,D] when need_denc."""
         cfg, st, p = self.cfg, self.s, self.p
         self.prepare()
+        self._prepare_transposes()
+        ops.wgrad_join()                                                # transposed weights (side stream) are ready
         st.ensure_grads()
         B, T = saved["B"], saved["T"]
         R, D, nh = B * T, cfg.hidden_size, cfg.num_attention_heads
@@ -190,12 +223,12 @@ class BertEngine:
                 ops.copy_rows(dlogits.unsqueeze(0), dlp[:, :V].unsqueeze(0))
             word = st.w16(p + "bert.embeddings.word_embeddings.weight")
             ops.gemm_tn(dlp[:, :V], saved["tn"], g(p + "bert.embeddings.word_embeddings.weight"), dbias=g(c + "bias"))
-            dtn = ops.gemm_nt(dlp, ops.transpose(word, 64))                       # K = Vp
+            dtn = ops.gemm_nt(dlp, self._prep[("wt", p + "bert.embeddings.word_embeddings.weight")])       # K = Vp
             dt = ops.layernorm_bwd(saved["t"], dtn, st.f32(c + "transform.LayerNorm.weight"), saved["ts"], g(c + "transform.LayerNorm.weight"),
                                    g(c + "transform.LayerNorm.bias"))
             dtu = ops.gelu_bwd(dt, saved["tu"])
             ops.linear_bwd_weight(dtu, saved["h_out"], g(c + "transform.dense.weight"), g(c + "transform.dense.bias"))
-            dh = ops.gemm_nt(dtu, ops.transpose(st.w16(c + "transform.dense.weight")))
+            dh = ops.gemm_nt(dtu, self._prep[("wt", c + "transform.dense")])
         else:
             dh = dhidden
         denc = None

@@ -20,6 +20,7 @@ class CvtEncoderEngine:
         self.s, self.cfg, self.p = store, cfg, prefix
         self._prep_version = -1
         self._prep = {}
+        self._wt_ready = False
 
     # ------------------------------------------------------------------------------------------ weight preparation
     def _stage(self, s):
@@ -52,13 +53,40 @@ class CvtEncoderEngine:
                         st.f32(cp + "convolution.weight"), st.f32(cp + "normalization.weight"), st.f32(cp + "normalization.bias"),
                         st.f32(cp + "normalization.running_mean"), st.f32(cp + "normalization.running_var"), cfg.bn_eps)
         self._prep, self._prep_version = prep, st.shadow_version
+        self._wt_ready = False
         return prep
+
+    def _prepare_transposes(self):
+        """W^T (the K-contiguous operand of every dX GEMM) for the current weight version. Issued on the weight-gradient side stream at the
+        start of a training forward, i.e. entirely off the critical path; joined at the start of backward."""
+        if self._wt_ready:
+            return
+        st, cfg, prep = self.s, self.cfg, self._prep
+        with ops._on_wgrad_stream():
+            for s in range(len(cfg.depth)):
+                sp = self._stage(s)
+                if s > 0:
+                    prep[("wt", ("embed", s))] = ops.transpose(prep[("embed", s)], out=prep.get(("wt", ("embed", s))))
+                for l in range(cfg.depth[s]):
+                    lp = sp + f"layers.{l}."
+                    for name in ("attention.attention.projection_query", "attention.attention.projection_key", "attention.attention.projection_value",
+                                 "attention.output.dense", "intermediate.dense", "output.dense"):
+                        k = lp + name + ".weight"
+                        prep[("wt", k)] = ops.transpose(st.w16(k), out=prep.get(("wt", k)))
+            k = self.p + "projection_head.projection.weight"
+            prep[("wt", k)] = ops.transpose(st.w16(k), out=prep.get(("wt", k)))
+        self._wt_ready = True
+
+    def _wt(self, key):
+        return self._prep[("wt", key)]
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, px: torch.Tensor, save: bool = False):
         """px [Bn,3,H,W] fp32 (contiguous) -> feats [Bn*tokens, projection_size] bf16, saved-activation dict | None"""
         cfg, st = self.cfg, self.s
         prep = self.prepare()
+        if save:
+            self._prepare_transposes()
         Bn = px.shape[0]
         saved = {"Bn": Bn, "stages": []} if save else None
         x = None            # [Bn, H*W, C] output of the previous stage (no class token)
@@ -137,12 +165,14 @@ class CvtEncoderEngine:
         """dfeats [Bn*tokens, projection_size] bf16. Parameter gradients are ACCUMULATED into the store's flat gradient buffer."""
         cfg, st = self.cfg, self.s
         prep = self.prepare()
+        self._prepare_transposes()
+        ops.wgrad_join()                                                # transposed weights (side stream) are ready
         st.ensure_grads()
         Bn = saved["Bn"]
         hp = self.p + "projection_head."
         C = cfg.embed_dim[-1]
         ops.linear_bwd_weight(dfeats, saved["hn"], st.grad(hp + "projection.weight"))
-        dhn = ops.gemm_nt(dfeats, ops.transpose(st.w16(hp + "projection.weight")))
+        dhn = ops.gemm_nt(dfeats, self._wt(hp + "projection.weight"))
         dx = ops.layernorm_bwd(saved["x_last"].view(-1, C), dhn, st.f32(hp + "layer_norm.weight"), saved["hstats"],
                                st.grad(hp + "layer_norm.weight"), st.grad(hp + "layer_norm.bias"))
         dx = dx.view(Bn, -1, C)                                     # grad wrt stage output tokens (no class token)
@@ -174,7 +204,7 @@ class CvtEncoderEngine:
                 gw.add_(dwp[:, :gw[0].numel()].view(gw.shape))                           # layout plumbing back to [Co,Ci,kh,kw]
             else:
                 gw.add_(dwp.view(gw.shape[0], gw.shape[2], gw.shape[3], gw.shape[1]).permute(0, 3, 1, 2))
-                dcol = ops.gemm_nt(de, ops.transpose(wp))
+                dcol = ops.gemm_nt(de, self._wt(("embed", s)))
                 Hp = Wp = cfg.grid(s - 1)
                 dx = ops.col2im_tokens(dcol, Bn, cfg.embed_dim[s - 1], Hp, Wp, cfg.patch_stride[s], cfg.patch_padding[s])
         return None
@@ -189,20 +219,20 @@ class CvtEncoderEngine:
         g = st.grad
         # MLP:  x3 = x2 + W2 gelu(W1 h2 + b1) + b2
         ops.linear_bwd_weight(dy2, sv["g"], g(lp + "output.dense.weight"), g(lp + "output.dense.bias"))
-        du = ops.gemm_nt(dy2, ops.transpose(st.w16(lp + "output.dense.weight")), act=2, aux=sv["u"])
+        du = ops.gemm_nt(dy2, self._wt(lp + "output.dense.weight"), act=2, aux=sv["u"])
         ops.linear_bwd_weight(du, sv["h2"], g(lp + "intermediate.dense.weight"), g(lp + "intermediate.dense.bias"))
-        dh2 = ops.gemm_nt(du, ops.transpose(st.w16(lp + "intermediate.dense.weight")))
+        dh2 = ops.gemm_nt(du, self._wt(lp + "intermediate.dense.weight"))
         dx2 = ops.layernorm_bwd(sv["x2"], dh2, st.f32(lp + "layernorm_after.weight"), sv["st2"], g(lp + "layernorm_after.weight"),
                                 g(lp + "layernorm_after.bias"), add=dy2)
         # attention output projection: x2 = x + Wo ctx + bo
         ops.linear_bwd_weight(dx2, sv["ctx"].view(-1, C), g(lp + "attention.output.dense.weight"), g(lp + "attention.output.dense.bias"))
-        dctx = ops.gemm_nt(dx2, ops.transpose(st.w16(lp + "attention.output.dense.weight"))).view(Bn, L, C)
+        dctx = ops.gemm_nt(dx2, self._wt(lp + "attention.output.dense.weight")).view(Bn, L, C)
         dq, dk, dv = ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, C ** -0.5)
         projs = []
         for name, d, inp, stride in (("query", dq, sv["qc"], cfg.stride_q[s]), ("key", dk, sv["kc"], cfg.stride_kv[s]),
                                      ("value", dv, sv["vc"], cfg.stride_kv[s])):
             ops.linear_bwd_weight(d.view(-1, C), inp.view(-1, C), g(ap + f"projection_{name}.weight"), g(ap + f"projection_{name}.bias"))
-            dc = ops.gemm_nt(d.view(-1, C), ops.transpose(st.w16(ap + f"projection_{name}.weight"))).view(d.shape)
+            dc = ops.gemm_nt(d.view(-1, C), self._wt(ap + f"projection_{name}.weight")).view(d.shape)
             wf, _ = prep[("fold", s, l, name)]
             projs.append((dc, wf, stride))
             cp = ap + f"convolution_projection_{name}.convolution_projection."

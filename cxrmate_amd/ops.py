@@ -17,8 +17,15 @@ def _p(t):
     return t.data_ptr()
 
 
+_DEV_INDEX = None
+
+
 def _s():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw hipStream_t of torch's current stream (fast path: no Stream object, no device queries -- this runs ~1500x per step)."""
+    global _DEV_INDEX
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(_DEV_INDEX)
 
 
 def _chk(t, dtype=None):

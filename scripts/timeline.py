@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 kernel trace of bench.py: python scripts/timeline.py gpurun_out/profX"""
+import csv, glob, collections, statistics, sys
+f = sorted(glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv'))[-1]
+rows = list(csv.DictReader(open(f)))
+for r in rows:
+    r['s'] = int(r['Start_Timestamp']); r['e'] = int(r['End_Timestamp'])
+rows.sort(key=lambda r: r['s'])
+ad = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('adamw_kernel')]
+i0, i1 = ad[-3] + 1, ad[-2] + 1
+seg = rows[i0:i1]
+t0, t1 = seg[0]['s'], seg[-1]['e']
+print('step span ms', (t1 - t0) / 1e6, 'kernels', len(seg))
+byq = collections.defaultdict(list)
+for r in seg: byq[r['Queue_Id']].append(r)
+for q, lst in byq.items():
+    print('queue', q, 'kernels', len(lst), 'busy ms', sum(r['e'] - r['s'] for r in lst) / 1e6)
+ev = sorted([(r['s'], 1) for r in seg] + [(r['e'], -1) for r in seg])
+cur = 0; last = t0; idle = 0; both = 0
+for t, d in ev:
+    if cur == 0: idle += t - last
+    if cur >= 2: both += t - last
+    cur += d; last = t
+print('idle ms', idle / 1e6, 'overlap ms', both / 1e6)
+for q, lst in sorted(byq.items(), key=lambda kv: -len(kv[1])):
+    agg = collections.Counter(); cnt = collections.Counter()
+    for r in lst: agg[r['Kernel_Name'][:48]] += r['e'] - r['s']; cnt[r['Kernel_Name'][:48]] += 1
+    print('--- queue', q)
+    for k, v in agg.most_common(12): print(f"  {k:50s} {cnt[k]:5d} {v/1e6:8.3f} ms  avg {v/cnt[k]/1e3:7.1f} us")
