@@ -111,14 +111,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         const bool fast = (a.kpm == nullptr) && !a.causal && (kv0 + 64 <= a.Tk);     // block-uniform: no masking work at all
         float mloc = ATT_NEG;
         unsigned deadmask = 0u;
+        float m_new, alpha, psum = 0.f;
         if (fast) {
+            // raw scores stay in the accumulators; the softmax scale is folded into the exp2 argument (one FMA per score)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[kt][r]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            m_new = fmaxf(m_run, mloc * a.scale_log2e);            // scale > 0
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = st[kt][r] * a.scale_log2e;
-                    st[kt][r] = v;
-                    mloc = fmaxf(mloc, v);
+                    const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], a.scale_log2e, -m_new));
+                    st[kt][r] = p;
+                    psum += p;
                 }
         } else {
 #pragma unroll
@@ -134,24 +143,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
                     st[kt][r] = v;
                     mloc = fmaxf(mloc, v);
                 }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            m_new = fmaxf(m_run, mloc);
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float p = __builtin_amdgcn_exp2f(st[kt][r] - m_new);
+                    if ((deadmask >> (kt * 16 + r)) & 1u) p = 0.f;
+                    st[kt][r] = p;
+                    psum += p;
+                }
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
-        float psum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(st[kt][r] - m_new);
-                if (!fast && ((deadmask >> (kt * 16 + r)) & 1u)) p = 0.f;
-                st[kt][r] = p;
-                psum += p;
-            }
         l_run = l_run * alpha + psum;
+        if (!__all(alpha == 1.0f)) {                               // the running max settles after a few tiles: skip the O rescale then
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        }
 
         // ---- O^T += V^T . P^T   (P accumulator -> bf16 B operand; V through transposed LDS reads)
         const int g = lane >> 4, li = lane & 15;

@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnBwdArgs a)
     __shared__ __attribute__((aligned(16))) bf16_t Qt[64 * TS];
     __shared__ __attribute__((aligned(16))) bf16_t Dr[64 * RS];
     __shared__ __attribute__((aligned(16))) bf16_t Dt[64 * TS];
-    __shared__ float Ls[64];
-    __shared__ float Es[64];
+    __shared__ __attribute__((aligned(16))) float Ls[64];
+    __shared__ __attribute__((aligned(16))) float Es[64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.y, b = blockIdx.z;
@@ -137,15 +137,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnBwdArgs a)
                 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], S, 0, 0, 0);
                 dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[s], dP, 0, 0, 0);
             }
+            // rows of this accumulator: q = 32*qs + 8*(r>>2) + 4*hh + (r&3): four consecutive queries per register quad -> float4 LDS reads
+            const bool fast = (a.kpm == nullptr) && !a.causal && (kb0 + 128 <= a.Tk);       // block-uniform
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ql = qs * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                bool ok = code == 2;
-                if (a.causal) ok = ok && (key <= tile * 64 + ql + a.causal_shift);
-                float p = __builtin_amdgcn_exp2f(S[r] * a.scale_log2e - Ls[ql]);      // Ls = +inf for rows beyond Tq -> 0
-                p = ok ? p : 0.f;
-                S[r] = p;
-                dP[r] = p * (dP[r] - Es[ql]) * a.scale;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int qb4 = qs * 32 + 8 * g4 + 4 * hh;
+                const float4 L4 = *reinterpret_cast<const float4*>(&Ls[qb4]);
+                const float4 E4 = *reinterpret_cast<const float4*>(&Es[qb4]);
+                const float Lq[4] = {L4.x, L4.y, L4.z, L4.w}, Eq[4] = {E4.x, E4.y, E4.z, E4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g4 + j;
+                    float p = __builtin_amdgcn_exp2f(fmaf(S[r], a.scale_log2e, -Lq[j]));          // Ls = +inf beyond Tq -> 0
+                    if (!fast) {
+                        bool ok = code == 2;
+                        if (a.causal) ok = ok && (key <= tile * 64 + qb4 + j + a.causal_shift);
+                        p = ok ? p : 0.f;
+                    }
+                    S[r] = p;
+                    dP[r] = p * (dP[r] - Eq[j]);                   // the softmax scale is applied once to the dK accumulators
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -163,6 +174,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnBwdArgs a)
         }
     }
 #undef BWD_GLOAD_Q
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[0][i] *= a.scale; dk[1][i] *= a.scale; }
     if (key < a.Tk) {
         bf16_t* kp = a.dK + (long)b * a.dk_bs + (long)key * a.dk_rs + head * 64;
         bf16_t* vp = a.dV + (long)b * a.dk_bs + (long)key * a.dk_rs + head * 64;
@@ -258,8 +271,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
             if (fast) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(S[r] * a.scale_log2e - lse2);
-                    dP[r] = p * (dP[r] - dl) * a.scale;
+                    const float p = __builtin_amdgcn_exp2f(fmaf(S[r], a.scale_log2e, -lse2));
+                    dP[r] = p * (dP[r] - dl);                          // softmax scale applied once to the dQ accumulators
                 }
             } else {
 #pragma unroll
@@ -267,8 +280,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
                     const int kloc = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                     bool ok = Ms[kloc] == 2;
                     if (a.causal) ok = ok && (tile * 64 + kloc <= qrow + a.causal_shift);
-                    const float p = ok ? __builtin_amdgcn_exp2f(S[r] * a.scale_log2e - lse2) : 0.f;
-                    dP[r] = p * (dP[r] - dl) * a.scale;
+                    const float p = ok ? __builtin_amdgcn_exp2f(fmaf(S[r], a.scale_log2e, -lse2)) : 0.f;
+                    dP[r] = p * (dP[r] - dl);
                 }
             }
 #pragma unroll
@@ -285,6 +298,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
         }
     }
 #undef BWD_GLOAD_KV
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dq[0][i] *= a.scale; dq[1][i] *= a.scale; }
     if (qrow < a.Tq) {
         bf16_t* qp = a.dQ + (long)b * a.dq_bs + (long)qrow * a.dq_rs + head * 64;
 #pragma unroll

@@ -72,43 +72,66 @@ extern "C" int cxr_topk_rows(const float* x, long ld, long R, int n, int K, floa
 // Weight-streaming regime (cdna_hip_programming.md section 5, "GEMV / M <= 16 decode weights"): every W element is read exactly once
 // chip-wide, straight from HBM/L2 into MFMA B fragments (no LDS round trip); a workgroup owns 16 output columns, its 4 waves split K
 // and combine through LDS; all of a wave's loads are issued before its first MFMA (deep memory-level parallelism instead of occupancy).
+struct SkinnyProb { const bf16_t* W; const float* bias; void* C; long ldw, ldc; int N; };
+struct SkinnyArgs {
+    const bf16_t* A; long lda;
+    const bf16_t* residual; long ldr;      // added to problem 0 only
+    SkinnyProb p[3];
+    int nprob, M, K, act, out_f32;
+};
+
 template <int MT>   // number of 16-row tiles of A
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
-                                                          void* __restrict__ C, long ldc, const float* __restrict__ bias,
-                                                          const bf16_t* __restrict__ residual, long ldr, int M, int N, int K, int act,
-                                                          int out_f32) {
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs g) {
     __shared__ float red[4][MT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * 16;
+    // grouped launch: blocks [0, N0/16) -> problem 0, next N1/16 -> problem 1, ... (q / k / v projections share A and one launch)
+    int blk = blockIdx.x, pi = 0;
+    while (pi + 1 < g.nprob && blk >= (g.p[pi].N + 15) / 16) { blk -= (g.p[pi].N + 15) / 16; ++pi; }
+    const SkinnyProb P = g.p[pi];
+    const int n0 = blk * 16;
     const int fr = lane & 15, fq = lane >> 4;
-    const int kslice = K / 4, k0 = wave * kslice;
-    const int nw = n0 + fr < N ? n0 + fr : N - 1;
-    const bf16_t* wp = W + (long)nw * ldw + k0 + fq * 8;
+    const int kslice = g.K / 4, k0 = wave * kslice;
+    const int nw = n0 + fr < P.N ? n0 + fr : P.N - 1;
+    const bf16_t* wp = P.W + (long)nw * P.ldw + k0 + fq * 8;
+    // epilogue operands are fetched up front by wave 0 so their latency overlaps the weight stream
+    const int n = n0 + fr;
+    float bv = 0.f, rv[MT][4];
+    if (wave == 0) {
+        if (P.bias && n < P.N) bv = P.bias[n];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = t * 16 + fq * 4 + r;
+                rv[t][r] = (g.residual && pi == 0 && m < g.M && n < P.N) ? bf2f(g.residual[(long)m * g.ldr + n]) : 0.f;
+            }
+    }
     f32x4_t acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const bf16_t* ap[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-        int m = t * 16 + fr; m = m < M ? m : M - 1;
-        ap[t] = A + (long)m * lda + k0 + fq * 8;
+        int m = t * 16 + fr; m = m < g.M ? m : g.M - 1;
+        ap[t] = g.A + (long)m * g.lda + k0 + fq * 8;
     }
-    for (int kb = 0; kb < kslice; kb += 256) {                       // 8 k-steps of 32 per batch: 8 W loads + 8*MT A loads in flight per lane
-        bf16x8_t wf[8], af[MT][8];
+    constexpr int KB = MT == 1 ? 12 : (MT == 2 ? 8 : 4);            // k-steps (of 32) whose loads are in flight together
+    for (int kb = 0; kb < kslice; kb += 32 * KB) {
+        bf16x8_t wf[KB], af[MT][KB];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int k = kb + s * 32;
+        for (int s2 = 0; s2 < KB; ++s2) {
+            const int k = kb + s2 * 32;
             if (k < kslice) {
-                wf[s] = *reinterpret_cast<const bf16x8_t*>(wp + k);
+                wf[s2] = *reinterpret_cast<const bf16x8_t*>(wp + k);
 #pragma unroll
-                for (int t = 0; t < MT; ++t) af[t][s] = *reinterpret_cast<const bf16x8_t*>(ap[t] + k);
+                for (int t = 0; t < MT; ++t) af[t][s2] = *reinterpret_cast<const bf16x8_t*>(ap[t] + k);
             }
         }
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            if (kb + s * 32 < kslice) {
+        for (int s2 = 0; s2 < KB; ++s2) {
+            if (kb + s2 * 32 < kslice) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t][s], wf[s], acc[t], 0, 0, 0);
+                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t][s2], wf[s2], acc[t], 0, 0, 0);
             }
         }
     }
@@ -117,35 +140,54 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][t][lane][r] = acc[t][r];
     __syncthreads();
-    if (wave != 0) return;
-    const int n = n0 + fr;
-    if (n >= N) return;
-    const float b = bias ? bias[n] : 0.f;
+    if (wave != 0 || n >= P.N) return;
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = t * 16 + fq * 4 + r;                       // D[m][n]: lane owns column n, rows (lane>>4)*4 + r
-            if (m >= M) continue;
-            float v = red[0][t][lane][r] + red[1][t][lane][r] + red[2][t][lane][r] + red[3][t][lane][r] + b;
-            if (act == 1) v = gelu_f(v);
-            if (residual) v += bf2f(residual[(long)m * ldr + n]);
-            if (out_f32) reinterpret_cast<float*>(C)[(long)m * ldc + n] = v;
-            else reinterpret_cast<bf16_t*>(C)[(long)m * ldc + n] = f2bf(v);
+            if (m >= g.M) continue;
+            float v = red[0][t][lane][r] + red[1][t][lane][r] + red[2][t][lane][r] + red[3][t][lane][r] + bv;
+            if (g.act == 1) v = gelu_f(v);
+            v += rv[t][r];
+            if (g.out_f32) reinterpret_cast<float*>(P.C)[(long)m * P.ldc + n] = v;
+            else reinterpret_cast<bf16_t*>(P.C)[(long)m * P.ldc + n] = f2bf(v);
         }
+}
+
+static int launch_skinny(const SkinnyArgs& g, hipStream_t stream) {
+    int grid = 0;
+    for (int i = 0; i < g.nprob; ++i) grid += cdiv(g.p[i].N, 16);
+    const int mt = cdiv(g.M, 16);
+#define SKINNY(MT_) CXR_LAUNCH((gemm_skinny_kernel<MT_>), dim3(grid), dim3(256), 0, stream, g)
+    if (mt == 1) SKINNY(1); else if (mt == 2) SKINNY(2); else if (mt == 3) SKINNY(3); else SKINNY(4);
+#undef SKINNY
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
 }
 
 extern "C" int cxr_gemm_skinny_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias, const void* residual,
                                     long ldr, int M, int N, int K, int act, int out_f32, hipStream_t stream) {
     if (M <= 0 || M > 64 || N <= 0 || K <= 0 || (K % 128) || (lda % 8) || (ldw % 8)) return CXR_ERR_ARG;
-    const int grid = cdiv(N, 16);
-    const int mt = cdiv(M, 16);
-#define SKINNY(MT_) CXR_LAUNCH((gemm_skinny_kernel<MT_>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, \
-                               bias, (const bf16_t*)residual, ldr, M, N, K, act, out_f32)
-    if (mt == 1) SKINNY(1); else if (mt == 2) SKINNY(2); else if (mt == 3) SKINNY(3); else SKINNY(4);
-#undef SKINNY
-    CXR_LAUNCH_CHECK();
-    return CXR_OK;
+    SkinnyArgs g;
+    g.A = (const bf16_t*)A; g.lda = lda; g.residual = (const bf16_t*)residual; g.ldr = ldr;
+    g.p[0].W = (const bf16_t*)W; g.p[0].bias = bias; g.p[0].C = C; g.p[0].ldw = ldw; g.p[0].ldc = ldc; g.p[0].N = N;
+    g.p[1] = g.p[0]; g.p[2] = g.p[0];
+    g.nprob = 1; g.M = M; g.K = K; g.act = act; g.out_f32 = out_f32;
+    return launch_skinny(g, stream);
+}
+
+// three projections of the same activations in one launch (decode-step q / k / v: k and v land directly in their KV-cache rows)
+extern "C" int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, const float* b0, void* C0, long ldc0, const void* W1,
+                                     const float* b1, void* C1, long ldc1, const void* W2, const float* b2, void* C2, long ldc2, long ldw,
+                                     int M, int N, int K, hipStream_t stream) {
+    if (M <= 0 || M > 64 || N <= 0 || K <= 0 || (K % 128) || (lda % 8) || (ldw % 8)) return CXR_ERR_ARG;
+    SkinnyArgs g;
+    g.A = (const bf16_t*)A; g.lda = lda; g.residual = nullptr; g.ldr = 0;
+    const void* W[3] = {W0, W1, W2}; const float* b[3] = {b0, b1, b2}; void* C[3] = {C0, C1, C2}; const long ldc[3] = {ldc0, ldc1, ldc2};
+    for (int i = 0; i < 3; ++i) { g.p[i].W = (const bf16_t*)W[i]; g.p[i].bias = b[i]; g.p[i].C = C[i]; g.p[i].ldw = ldw; g.p[i].ldc = ldc[i]; g.p[i].N = N; }
+    g.nprob = 3; g.M = M; g.K = K; g.act = 0; g.out_f32 = 0;
+    return launch_skinny(g, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -173,11 +215,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     const unsigned char* mrow = kpm ? kpm + (long)b * kpm_bs : nullptr;
     float m_run = -1.0e30f, l_run = 0.f;
     float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k0 = 0; k0 < Tk; k0 += 128) {
-        uint4 kr[4], vr[4];
-        bool live[4], ok[4];
+    constexpr int KU = 8;                                   // keys per group per iteration: 16 independent 16-byte loads in flight per lane
+    for (int k0 = 0; k0 < Tk; k0 += 32 * KU) {
+        uint4 kr[KU], vr[KU];
+        bool live[KU], ok[KU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < KU; ++u) {
             const int key = k0 + u * 32 + grp;
             live[u] = key < Tk;
             const int kc = live[u] ? key : Tk - 1;
@@ -185,9 +228,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
             vr[u] = *reinterpret_cast<const uint4*>(vb + (long)kc * v_rs);
             ok[u] = live[u] && (mrow == nullptr || mrow[kc] != 0);
         }
-        float sv[4];
+        float sv[KU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < KU; ++u) {
             float kv[8];
             unpack8(kr[u], kv);
             float d = 0.f;
@@ -198,14 +241,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         }
         float mloc = m_run;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (live[u]) mloc = fmaxf(mloc, sv[u]);
+        for (int u = 0; u < KU; ++u) if (live[u]) mloc = fmaxf(mloc, sv[u]);
         const float alpha = __builtin_amdgcn_exp2f(m_run - mloc);
         m_run = mloc;
         l_run *= alpha;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] *= alpha;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < KU; ++u) {
             const float p = live[u] ? __builtin_amdgcn_exp2f(sv[u] - m_run) : 0.f;
             float vv[8];
             unpack8(vr[u], vv);

@@ -304,11 +304,15 @@ class BertEngine:
         for l in range(cfg.num_hidden_layers):
             lp = p + f"bert.encoder.layer.{l}."
             wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key"); wv, bv = self._lin(lp + "attention.self.value")
-            q = lin(h, wq, bias=bq).view(B, Tn, D)
-            if Tn == 1:                                                       # project straight into the cache row
+            if single:                                                        # q, k, v in one launch; k/v straight into their cache rows
+                q = torch.empty((B, 1, D), dtype=BF16, device=h.device)
+                ops.gemm_skinny3(h, wq, bq, q.view(B, D), wk, bk, cache.k[l][:, past, :], wv, bv, cache.v[l][:, past, :])
+            elif Tn == 1:
+                q = lin(h, wq, bias=bq).view(B, Tn, D)
                 lin(h, wk, bias=bk, out=cache.k[l][:, past, :])
                 lin(h, wv, bias=bv, out=cache.v[l][:, past, :])
             else:
+                q = lin(h, wq, bias=bq).view(B, Tn, D)
                 ops.copy_rows(ops.gemm_nt(h, wk, bias=bk).view(B, Tn, D), cache.k[l][:, past:past + Tn, :])
                 ops.copy_rows(ops.gemm_nt(h, wv, bias=bv).view(B, Tn, D), cache.v[l][:, past:past + Tn, :])
             kk, vv = cache.k[l][:, :past + Tn, :], cache.v[l][:, :past + Tn, :]

@@ -492,3 +492,12 @@ def attention_decode(q, k, v, heads, scale, kpm=None, out=None):
     LIB.call("cxr_attn_decode_bf16", _p(q), _p(k), _p(v), _p(out), _p(kpm), q.stride(0), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
              out.stride(0), kpm.stride(0) if kpm is not None else 0, B, heads, Tk, float(scale), _s())
     return out
+
+
+def gemm_skinny3(a, w0, b0, c0, w1, b1, c1, w2, b2, c2):
+    """c_i = a @ w_i^T + b_i for three equally-shaped projections in ONE launch (outputs may be strided KV-cache rows)."""
+    M, K = a.shape
+    N = w0.shape[0]
+    assert w0.stride(0) == w1.stride(0) == w2.stride(0)
+    LIB.call("cxr_gemm_skinny3_bf16", _p(a), a.stride(0), _p(w0), _p(b0), _p(c0), c0.stride(0), _p(w1), _p(b1), _p(c1), c1.stride(0),
+             _p(w2), _p(b2), _p(c2), c2.stride(0), w0.stride(0), M, N, K, _s())

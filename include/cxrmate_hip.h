@@ -110,6 +110,9 @@ int cxr_gather_batch_bf16(const void* in, long in_bs, long in_rs, void* out, lon
  * the KV cache / the cross-attention K,V (TF5:bert:164-203,230-279 with a cache, q length 1) */
 int cxr_gemm_skinny_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias, const void* residual, long ldr,
                          int M, int N, int K, int act, int out_f32, hipStream_t stream);
+int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, const float* b0, void* C0, long ldc0, const void* W1, const float* b1,
+                          void* C1, long ldc1, const void* W2, const float* b2, void* C2, long ldc2, long ldw, int M, int N, int K,
+                          hipStream_t stream);   /* q / k / v projections of one decode step in a single launch */
 int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs, long v_bs,
                          long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, hipStream_t stream);
 int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, long* inds, hipStream_t stream);
