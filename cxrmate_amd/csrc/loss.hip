@@ -258,13 +258,123 @@ __global__ __launch_bounds__(256) void select_token_kernel(const float* __restri
     }
 }
 
+__global__ void sample_topk_lds_kernel(const float* __restrict__ logits, long ld, int V, float temperature, int top_k, const float* __restrict__ u,
+                                       long* __restrict__ next, int* __restrict__ unfinished, long eos, long pad);
+
 extern "C" int cxr_select_token(const float* logits, long ld, long R, int V, int mode, float temperature, int top_k, const float* u, long* next,
                                 int* unfinished, long eos, long pad, float* margin, hipStream_t stream) {
     if (R <= 0 || V <= 0 || (mode == 1 && (!u || temperature <= 0.f))) return CXR_ERR_ARG;
+    if (mode == 1 && !margin && (size_t)V * sizeof(float) <= 150 * 1024) {           // sampling: row-resident-in-LDS kernel
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)sample_topk_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        CXR_LAUNCH(sample_topk_lds_kernel, dim3((unsigned)R), dim3(1024), (size_t)V * sizeof(float), stream, logits, ld, V, temperature, top_k, u, next,
+                   unfinished, eos, pad);
+        CXR_LAUNCH_CHECK();
+        return CXR_OK;
+    }
     CXR_LAUNCH(select_token_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, V, mode, temperature, top_k, u, next, unfinished,
                        eos, pad, margin);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- top-k sampling with the row held in LDS
+// The decode loop samples one row per sequence (B = 16..64 rows of V = 30000 logits): too few rows to fill the chip, so each row's seven
+// passes (4 radix-select passes, max, sum, inverse-CDF search) must not go back to L2/HBM. One 1024-thread workgroup loads its row ONCE
+// into LDS (120 KB of the 160 KB) with 16-byte loads and runs every pass from there.
+__global__ __launch_bounds__(1024) void sample_topk_lds_kernel(const float* __restrict__ logits, long ld, int V, float temperature, int top_k,
+                                                               const float* __restrict__ u, long* __restrict__ next, int* __restrict__ unfinished,
+                                                               long eos, long pad) {
+    extern __shared__ __attribute__((aligned(16))) float row[];          // [V]
+    __shared__ unsigned hist[256];
+    __shared__ unsigned bc[2];
+    __shared__ float wred[16];
+    __shared__ int pick;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long r = blockIdx.x;
+    const float* x = logits + r * ld;
+    const float invt = 1.0f / temperature;
+    for (int i = tid * 4; i < V; i += 4096) {
+        if (i + 4 <= V && ((size_t)(x + i) & 15) == 0) *reinterpret_cast<float4*>(row + i) = *reinterpret_cast<const float4*>(x + i);
+        else for (int j = i; j < V && j < i + 4; ++j) row[j] = x[j];
+    }
+    __syncthreads();
+    // exact k-th largest (radix select on the order-preserving integer image)
+    float t = -INFINITY;
+    if (top_k > 0 && top_k < V) {
+        unsigned prefix = 0u, mask = 0u;
+        int remaining = top_k;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            if (tid < 256) hist[tid] = 0u;
+            __syncthreads();
+            for (int v = tid; v < V; v += 1024) {
+                const unsigned o = f2ord(row[v]);
+                if ((o & mask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0, d = 255;
+                for (; d > 0; --d) { if (acc + (int)hist[d] >= remaining) break; acc += hist[d]; }
+                bc[0] = (unsigned)d; bc[1] = (unsigned)acc;
+            }
+            __syncthreads();
+            prefix |= bc[0] << shift;
+            mask |= 255u << shift;
+            remaining -= (int)bc[1];
+            __syncthreads();
+        }
+        t = ord2f(prefix);
+    }
+    // max of the kept entries
+    float mx = -INFINITY;
+    for (int v = tid; v < V; v += 1024) { const float a = row[v]; if (a >= t) mx = fmaxf(mx, a * invt); }
+    mx = group_max<64>(mx);
+    if (lane == 0) wred[wave] = mx;
+    __syncthreads();
+    mx = wred[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, wred[w]);
+    __syncthreads();
+    // contiguous slice per thread -> prefix order == vocabulary order (torch.multinomial's category order)
+    const int per = (V + 1023) / 1024, beg = tid * per, end = min(V, beg + per);
+    float mine = 0.f;
+    for (int v = beg; v < end; ++v) { const float a = row[v]; if (a >= t) mine += __expf(a * invt - mx); }
+    float incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+    if (lane == 63) wred[wave] = incl;
+    if (tid == 0) pick = -1;
+    __syncthreads();
+    float woff = 0.f, total = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { if (w < wave) woff += wred[w]; total += wred[w]; }
+    const float target = u[r] * total;
+    const float excl = woff + incl - mine;
+    if (mine > 0.f && target >= excl && target < excl + mine) {
+        float c = excl; int p = -1;
+        for (int v = beg; v < end; ++v) { const float a = row[v]; if (a >= t) { c += __expf(a * invt - mx); p = v; if (target < c) break; } }
+        pick = p;
+    }
+    __syncthreads();
+    if (pick < 0) {                                     // numerical edge (u ~ 1): the last kept entry
+        int last = -1;
+        for (int v = tid; v < V; v += 1024) if (row[v] >= t) last = max(last, v);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+        __syncthreads();
+        if (lane == 0) atomicMax(&pick, last);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        long tok = pick;
+        if (unfinished) {
+            const int uf = unfinished[r];
+            if (!uf) tok = pad;
+            else if (tok == eos) unfinished[r] = 0;
+        }
+        next[r] = tok;
+    }
 }
 
 // log_softmax over the vocabulary, in place on fp32 rows (beam search scoring, TF5 generation/utils.py:3380)
