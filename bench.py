@@ -92,6 +92,8 @@ def scst_bench(args, rank, local, world, dev, secondary=False):
     cfg = EncoderDecoderConfig()
     B, N = 16, 2
     model = LongitudinalPromptMultiCXREncoderDecoderModel(cfg, device=dev, seed=0)
+    if not args.eval_mode:
+        model.train()          # the reference never leaves train mode inside training_step
     for p in model.decoder.parameters():
         p.requires_grad_(True)                                   # scst/gt_prompt.py:38-40
     opt = FusedAdamW(model, lr=5e-6)
@@ -133,13 +135,16 @@ def scst_bench(args, rank, local, world, dev, secondary=False):
                 "ms_per_step": dt / nsteps * 1e3, "studies_per_sec": B * nsteps / dt, "new_tokens_sampled_and_greedy": args.new_tokens,
                 "reward": "CXR-BERT stand-in (BERT-base + CLS projection), R=128 synthetic ids, 4 forwards per step (labels cached)",
                 "workload": "BASELINE.json configs[3] per-GPU shape: sample(top-k 50) + greedy baseline via hipGraph-replayed decode steps, "
-                            "REINFORCE through one teacher-forced pass, AdamW on the 80.9 M decoder parameters", "loss": float(out["loss"].item())}
+                            "REINFORCE through one teacher-forced pass, AdamW on the 80.9 M decoder parameters",
+                "mode": "eval" if args.eval_mode else "model.train(): batch-statistics BatchNorm in the frozen encoder, dropout 0.1 in both decodes and in "
+                        "the re-scoring pass (same seed)", "loss": float(out["loss"].item())}
     res = {"metric": "scst_steps_per_sec", "value": world * args.steps / dt / world, "unit": "steps/s (16 studies x 2 images per GPU per step)",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "longitudinal SCST + CXR-BERT stand-in reward (BASELINE.json configs[3] per-GPU shape)", "studies_per_gpu": B,
                       "images_per_study": N, "new_tokens": args.new_tokens, "reward_tokens": 128, "studies_per_sec": world * B * args.steps / dt,
-                      "loss": float(out["loss"].item()), "parallelism": f"dp{world}"}}
+                      "loss": float(out["loss"].item()), "parallelism": f"dp{world}",
+                      "mode": "eval" if args.eval_mode else "model.train() (batch-statistics BatchNorm, dropout 0.1 in decodes and re-scoring)"}}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
@@ -157,6 +162,7 @@ def main():
     ap.add_argument("--no-scst", action="store_true", help="skip the secondary SCST measurement (N=1 only)")
     ap.add_argument("--eager", action="store_true", help="(default) launch kernels eagerly; weight-gradient kernels overlap on a side stream")
     ap.add_argument("--graph", action="store_true", help="replay the step from hipGraphs (3 segments)")
+    ap.add_argument("--eval-mode", action="store_true", help="run the step under model.eval() (running-statistics BatchNorm, no dropout)")
     ap.add_argument("--workload", default="tf", choices=["tf", "scst"], help="tf = BASELINE configs[1] (headline); scst = configs[3] per-GPU shape")
     ap.add_argument("--new-tokens", type=int, default=255)
     args = ap.parse_args()
@@ -175,6 +181,8 @@ def main():
     cfg = EncoderDecoderConfig()
     B, T, V = args.batch, args.seq_len, cfg.decoder.vocab_size
     model = SingleCXREncoderDecoderModel(cfg, device=dev, seed=0)
+    if not args.eval_mode:
+        model.train()
     opt = FusedAdamW(model, lr=5e-5)
     px, inp, am, lab = synth_batch(B, T, V, dev, 1000 + rank)
     tt = model.token_ids_to_token_type_ids(inp, [3])
@@ -232,7 +240,8 @@ def main():
         "data": "synthetic (randn 384x384 images, uniform token ids, random-init weights)",
         "config": {"workload": "cxrmate-single-tf teacher-forcing fwd/bwd + AdamW (BASELINE.json configs[1])", "global_batch": B * world,
                    "images_per_study": 1, "seq_len": T, "encoder": "CvT-21 @384", "decoder": "BERT 6 layers, vocab 30000",
-                   "parallelism": f"dp{world}", "launch": "hipGraph replay (3 segments, RCCL between)" if args.graph else "eager, weight-gradient kernels on a side stream", "mode": "eval-mode BatchNorm (running statistics), dropout p=0",
+                   "parallelism": f"dp{world}", "launch": "hipGraph replay (3 segments, RCCL between)" if args.graph else "eager, weight-gradient kernels on a side stream", "mode": ("eval-mode BatchNorm (running statistics), dropout off" if args.eval_mode else
+                            "model.train(): batch-statistics BatchNorm + running-stat update, dropout 0.1 (hidden + attention probabilities), DropPath"),
                    "loss": float(loss.item()), "tokens_per_sec_per_gpu": tokens_per_s / world,
                    "model_tflops_per_gpu": step_gf * 1e-3 / (ms_per_step * 1e-3)},
         "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (all tile variants; v_mfma_f32_16x16x32_bf16), timed while the weight-gradient "

@@ -10,7 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "cxrmate_hip.h")
 LIB_PATH = os.path.join(HERE, "lib", "libcxrmate_hip.so")
 
-_CTYPES = {"long": ctypes.c_long, "int": ctypes.c_int, "float": ctypes.c_float, "hipStream_t": ctypes.c_void_p}
+_CTYPES = {"long": ctypes.c_long, "int": ctypes.c_int, "float": ctypes.c_float, "unsigned int": ctypes.c_uint,
+           "hipStream_t": ctypes.c_void_p}
 
 
 def parse_header(path: str = HEADER):

@@ -36,6 +36,9 @@ class CvtConfig:
     layer_norm_eps: float = 1e-12                  # used ONLY by the projection head (modelling_single.py:29)
     inner_layer_norm_eps: float = 1e-5             # nn.LayerNorm default inside CvtModel (TF5 modeling_cvt.py:79,363-364)
     bn_eps: float = 1e-5                           # nn.BatchNorm2d default (TF5 modeling_cvt.py:105)
+    bn_momentum: float = 0.1                       # nn.BatchNorm2d default: running-stat update in train mode
+    # train-mode stochastic regularisers, CvtConfig defaults of TF5 configuration_cvt.py (drop_rate / attention_drop_rate are 0 everywhere)
+    drop_path_rate: Tuple[float, ...] = (0.0, 0.0, 0.1)   # per stage: layer l uses linspace(0, rate, depth)[l] (TF5 modeling_cvt.py:416-418)
     projection_size: int = 768
 
     def grid(self, stage: int) -> int:
@@ -67,11 +70,14 @@ class BertConfig:
     layer_norm_eps: float = 1e-12
     pad_token_id: int = 0                          # BertConfig default -> nn.Embedding(padding_idx=0)
     initializer_range: float = 0.02
+    hidden_dropout_prob: float = 0.1               # BertConfig defaults; active under model.train() only
+    attention_probs_dropout_prob: float = 0.1
     is_decoder: bool = True
     add_cross_attention: bool = True
     # LoRA (longitudinal model only; modelling_longitudinal.py:163-170)
     lora_r: int = 0
     lora_alpha: int = 32
+    lora_dropout: float = 0.1
     # CXR-BERT stand-in only: CLS projection head 768 -> 128
     cls_projection_size: int = 0
 

@@ -19,6 +19,8 @@ struct AttnArgs {
     int B, H, Tq, Tk;
     float scale_log2e;                 // softmax scale * log2(e)
     int causal, causal_shift;          // key j visible to query i iff j <= i + causal_shift
+    // dropout on the attention probabilities (TF5 modeling_bert.py:131, train mode): P*keep/(1-p) feeds P.V, the softmax sums do not change
+    const uint32_t* drop_seed; uint32_t drop_site, drop_thr16; float drop_inv; int drop_t0;      // drop_thr16 == 0: off
 };
 
 constexpr int KS_STRIDE = 72;          // bf16 elements per K row in LDS (144 B)
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
     float m_run = ATT_NEG, l_run = 0.f;
+    const uint32_t drop_key = a.drop_thr16 ? dropout_row_key(*a.drop_seed, a.drop_site, (uint32_t)(b * a.H + head), (uint32_t)(qrow + a.drop_t0)) : 0u;
 
     if (ntiles > 0) ATT_GLOAD(0);
     for (int tile = 0; tile < ntiles; ++tile) {
@@ -163,6 +166,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
             for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
         }
 
+        if (a.drop_thr16) {                                        // launch-uniform; adjacent registers (r, r+1) hold adjacent keys
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int kl = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const uint32_t bits = dropout_pair_bits(drop_key, (uint32_t)(kv0 + kl) >> 1);
+                    st[kt][r] = (bits & 0xffffu) >= a.drop_thr16 ? st[kt][r] * a.drop_inv : 0.f;
+                    st[kt][r + 1] = (bits >> 16) >= a.drop_thr16 ? st[kt][r + 1] * a.drop_inv : 0.f;
+                }
+        }
         // ---- O^T += V^T . P^T   (P accumulator -> bf16 B operand; V through transposed LDS reads)
         const int g = lane >> 4, li = lane & 15;
 #pragma unroll
@@ -205,8 +219,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 extern "C" int cxr_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, float* LSE, const void* kpm,
                                  long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs, long o_rs,
                                  long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal, int causal_shift,
-                                 hipStream_t stream) {
-    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return CXR_ERR_ARG;
+                                 float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t0, hipStream_t stream) {
+    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return CXR_ERR_ARG;
     if ((q_rs % 8) || (k_rs % 8) || (v_rs % 8) || (o_rs % 4) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 4)) return CXR_ERR_ARG;
     AttnArgs a;
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.O = (bf16_t*)O; a.LSE = LSE;
@@ -214,6 +228,8 @@ extern "C" int cxr_attn_fwd_bf16(const void* Q, const void* K, const void* V, vo
     a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_rs = o_rs;
     a.kpm_bs = kpm_bs; a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk;
     a.scale_log2e = scale * 1.4426950408889634f; a.causal = causal; a.causal_shift = causal_shift;
+    a.drop_seed = drop_seed; a.drop_site = drop_site; a.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u;
+    a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_t0 = drop_t0;
     dim3 grid(cdiv(Tq, 128), H, B);
     CXR_LAUNCH(attn_fwd_kernel, grid, dim3(256), 0, stream, a);
     CXR_LAUNCH_CHECK();

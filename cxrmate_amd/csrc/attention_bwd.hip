@@ -17,6 +17,7 @@ struct AttnBwdArgs {
     int B, H, Tq, Tk;
     float scale, scale_log2e;
     int causal, causal_shift;
+    const uint32_t* drop_seed; uint32_t drop_site, drop_thr16; float drop_inv; int drop_t0;      // as in AttnArgs (attention.hip)
 };
 
 constexpr int RS = 72;     // row-image stride (bf16 elements)
@@ -65,10 +66,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnBwdArgs a)
     __shared__ __attribute__((aligned(16))) bf16_t Dt[64 * TS];
     __shared__ __attribute__((aligned(16))) float Ls[64];
     __shared__ __attribute__((aligned(16))) float Es[64];
+    __shared__ __attribute__((aligned(16))) uint32_t Rk[64];          // dropout row keys of the tile's queries
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.y, b = blockIdx.z;
     const int kb0 = blockIdx.x * 128;
+    const uint32_t drop_seed = a.drop_thr16 ? *a.drop_seed : 0u;
     const int kl = lane & 31, hh = lane >> 5;
     const int key = kb0 + wave * 32 + kl;
     const int keyc = key < a.Tk ? key : a.Tk - 1;
@@ -121,6 +124,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnBwdArgs a)
         *reinterpret_cast<uint4*>(Dr + srow0 * RS + sc * 8) = d0; *reinterpret_cast<uint4*>(Dr + srow1 * RS + sc * 8) = d1;
         *reinterpret_cast<uint4*>(Dt + srow0 * TS + sc * 8) = d0; *reinterpret_cast<uint4*>(Dt + srow1 * TS + sc * 8) = d1;
         if (tid < 64) Ls[tid] = lsev; else if (tid < 128) Es[tid - 64] = lsev;
+        else if (a.drop_thr16 && tid < 192)
+            Rk[tid - 128] = dropout_row_key(drop_seed, a.drop_site, (uint32_t)(b * a.H + head), (uint32_t)(tile * 64 + tid - 128 + a.drop_t0));
         __syncthreads();
         if (tile + 1 < ntiles) BWD_GLOAD_Q(tile + 1);
 
@@ -154,8 +159,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnBwdArgs a)
                         if (a.causal) ok = ok && (key <= tile * 64 + qb4 + j + a.causal_shift);
                         p = ok ? p : 0.f;
                     }
-                    S[r] = p;
-                    dP[r] = p * (dP[r] - Eq[j]);                   // the softmax scale is applied once to the dK accumulators
+                    float f = 1.0f;
+                    if (a.drop_thr16) {
+                        const uint32_t bits = dropout_pair_bits(Rk[qb4 + j], (uint32_t)key >> 1);
+                        f = ((key & 1) ? (bits >> 16) : (bits & 0xffffu)) >= a.drop_thr16 ? a.drop_inv : 0.f;
+                    }
+                    S[r] = p * f;                                  // dropped probabilities feed dV
+                    dP[r] = p * (f * dP[r] - Eq[j]);               // the softmax scale is applied once to the dK accumulators
                 }
             }
 #pragma unroll
@@ -214,6 +224,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
     }
     const float lse2 = a.LSE[((long)b * a.H + head) * a.Tq + qc] * 1.4426950408889634f;
     const float dl = a.delta[((long)b * a.H + head) * a.Tq + qc];
+    const uint32_t drop_key = a.drop_thr16 ? dropout_row_key(*a.drop_seed, a.drop_site, (uint32_t)(b * a.H + head), (uint32_t)(qrow + a.drop_t0)) : 0u;
 
     int ntiles = (a.Tk + 63) >> 6;
     if (a.causal) {
@@ -268,6 +279,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
                 dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[s], dP, 0, 0, 0);
             }
             const bool fast = (a.kpm == nullptr) && !a.causal && (tile * 64 + 64 <= a.Tk);
+            if (a.drop_thr16) {                                        // dP <- keep/(1-p) * dP before the softmax backward
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int kloc = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const uint32_t bits = dropout_pair_bits(drop_key, (uint32_t)(tile * 64 + kloc) >> 1);
+                    dP[r] = (bits & 0xffffu) >= a.drop_thr16 ? dP[r] * a.drop_inv : 0.f;
+                    dP[r + 1] = (bits >> 16) >= a.drop_thr16 ? dP[r + 1] * a.drop_inv : 0.f;
+                }
+            }
             if (fast) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -317,8 +337,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
 extern "C" int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* delta,
                                  void* dQ, void* dK, void* dV, const void* kpm, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
                                  long o_bs, long o_rs, long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal, int causal_shift,
-                                 hipStream_t stream) {
+                                 float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t0, hipStream_t stream) {
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || !LSE || !delta) return CXR_ERR_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return CXR_ERR_ARG;
     if ((q_rs % 8) || (k_rs % 8) || (v_rs % 8) || (o_rs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 8)) return CXR_ERR_ARG;
     AttnBwdArgs a;
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.dO = (const bf16_t*)dO; a.LSE = LSE; a.delta = delta;
@@ -327,6 +348,8 @@ extern "C" int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, co
     a.dq_rs = (long)H * 64; a.dq_bs = (long)Tq * H * 64; a.dk_rs = (long)H * 64; a.dk_bs = (long)Tk * H * 64;
     a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
     a.causal = causal; a.causal_shift = causal_shift;
+    a.drop_seed = drop_seed; a.drop_site = drop_site; a.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u;
+    a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_t0 = drop_t0;
     const long nd = (long)B * H * Tq * 8;
     CXR_LAUNCH(attn_delta_kernel, dim3(cdiv(nd, 256)), dim3(256), 0, stream, (const bf16_t*)O, (const bf16_t*)dO, o_bs, o_rs, delta, B, H, Tq);
     CXR_LAUNCH(attn_bwd_dkdv_kernel, dim3(cdiv(Tk, 128), H, B), dim3(256), 0, stream, a);

@@ -76,6 +76,26 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return s * fmaf(x * (1.0f - s), dp, 1.0f);
 }
 
+// ---- counter-based dropout: every kernel that applies (or re-applies, in backward / in the teacher-forced re-scoring of a sampled sequence)
+// a dropout mask derives the keep decision of element (site, b, t, col) from the same hash, so masks are never stored. `seed` lives in device
+// memory (graph replays see fresh seeds); site = which dropout of the network; (b, t) = sequence index / absolute position (or b*H+h, query)
+// for attention probabilities; one 32-bit hash serves two adjacent columns with 16 bits each: keep iff field >= round(p * 65536).
+__device__ __forceinline__ uint32_t cxr_mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint32_t dropout_row_key(uint32_t seed, uint32_t site, uint32_t b, uint32_t t) {
+    return cxr_mix32(cxr_mix32(seed ^ (site * 0x9E3779B9u)) + b * 0x7FEB352Du + t * 0x846CA68Bu);
+}
+__device__ __forceinline__ uint32_t dropout_pair_bits(uint32_t row_key, uint32_t col_pair) {
+    return cxr_mix32(row_key ^ (col_pair * 0x27D4EB2Fu + 0x165667B1u));
+}
+__device__ __forceinline__ bool dropout_keep(uint32_t row_key, uint32_t col, uint32_t thr16) {
+    const uint32_t bits = dropout_pair_bits(row_key, col >> 1);
+    return ((col & 1u) ? (bits >> 16) : (bits & 0xffffu)) >= thr16;
+}
+static inline uint32_t dropout_thr16(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {     // butterfly over W lanes (W power of two <= 64)
 #pragma unroll

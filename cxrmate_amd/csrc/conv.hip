@@ -369,3 +369,214 @@ extern "C" int cxr_dwconv_bn_bwd_w_bf16(const void* x, long x_bs, long x_rs, con
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- train-mode BatchNorm (batch statistics)
+// nn.BatchNorm2d in training mode (TF5 modeling_cvt.py:93-110 under model.train(); SURVEY.md quirk Q7: the "frozen" encoder of the SCST
+// stage still runs it). y = gamma*(c - mean_B)/sqrt(var_B + eps) + beta with c the raw depthwise conv output and (mean_B, var_B) the biased
+// statistics over all Bn*Ho*Wo positions of the launch; running stats move by `momentum` with the UNBIASED variance.
+// Forward = statistics pass (below: one read of the activation, conv outputs are not written) + finalize (stats -> folded taps) + the
+// ordinary folded dwconv_fwd_kernel. Cheaper than materialising c: R + (R+W) instead of (R+W) + (R+W).
+template <int NOUT>
+__global__ __launch_bounds__(256) void dwconv_stats_kernel(const bf16_t* __restrict__ x, long x_bs, long x_rs, const float* __restrict__ w0 /*[9][C] raw*/,
+                                                           const float* __restrict__ w1, float* __restrict__ stats /*[NOUT][2][C]: sum, sum of squares*/,
+                                                           int Bn, int C, int H, int W, int stride, int Ho, int Wo, int tok0, int pix_per_block) {
+    const int cch = C / 8;
+    const int cl = threadIdx.x % cch, pl = threadIdx.x / cch, npl = 256 / cch;
+    const int c8 = cl * 8;
+    float sm[NOUT][8], sq[NOUT][8];
+#pragma unroll
+    for (int q = 0; q < NOUT; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sm[q][j] = 0.f; sq[q][j] = 0.f; }
+    const long npix = (long)Bn * Ho * Wo;
+    const long beg = (long)blockIdx.x * pix_per_block, end = beg + pix_per_block < npix ? beg + pix_per_block : npix;
+    if (pl < npl) {
+        for (long pix = beg + pl; pix < end; pix += npl) {
+            const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
+            float a[NOUT][8];
+#pragma unroll
+            for (int q = 0; q < NOUT; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[q][j] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy * stride - 1 + ky;
+                if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox * stride - 1 + kx;
+                    if (ix < 0 || ix >= W) continue;
+                    float f[8];
+                    unpack8(*reinterpret_cast<const uint4*>(x + (long)b * x_bs + (long)(tok0 + iy * W + ix) * x_rs + c8), f);
+                    const float* u = w0 + (ky * 3 + kx) * C + c8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[0][j] += f[j] * u[j];
+                    if (NOUT == 2) {
+                        const float* u1 = w1 + (ky * 3 + kx) * C + c8;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a[NOUT - 1][j] += f[j] * u1[j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NOUT; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { sm[q][j] += a[q][j]; sq[q][j] += a[q][j] * a[q][j]; }
+        }
+    }
+    __shared__ __attribute__((aligned(16))) float red[4 * 2048];            // [NOUT*2][npl][C], npl*C <= 2048 for C in {64,192,384}
+    if (pl < npl) {
+#pragma unroll
+        for (int q = 0; q < NOUT; ++q) {
+            float* d0 = red + (((q * 2 + 0) * npl + pl) * C + c8);
+            float* d1 = red + (((q * 2 + 1) * npl + pl) * C + c8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { d0[j] = sm[q][j]; d1[j] = sq[q][j]; }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NOUT * 2 * C; i += 256) {
+        const int k = i / C, c = i % C;
+        float sum = 0.f;
+        for (int q = 0; q < npl; ++q) sum += red[(k * npl + q) * C + c];
+        atomicAdd(stats + i, sum);
+    }
+}
+
+// stats (zero-initialised by the caller) <- sum / sum of squares of the raw depthwise conv outputs of one (w1 == NULL) or two projections
+extern "C" int cxr_dwconv_stats_bf16(const void* x, long x_bs, long x_rs, const float* w0, const float* w1, float* stats, int Bn, int C,
+                                     int H, int W, int stride, int tok0, hipStream_t stream) {
+    if (Bn <= 0 || (C % 8) || C > 384 || (256 / (C / 8)) * C > 2048 || (stride != 1 && stride != 2)) return CXR_ERR_ARG;
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const long npix = (long)Bn * Ho * Wo;
+    int ppb = (int)cdiv(npix, 2048);
+    if (ppb < 32) ppb = 32;
+    if (w1) CXR_LAUNCH((dwconv_stats_kernel<2>), dim3(cdiv(npix, ppb)), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, w0, w1, stats, Bn, C,
+                               H, W, stride, Ho, Wo, tok0, ppb);
+    else    CXR_LAUNCH((dwconv_stats_kernel<1>), dim3(cdiv(npix, ppb)), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, w0, w0, stats, Bn, C,
+                               H, W, stride, Ho, Wo, tok0, ppb);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// stats -> batch mean / rstd (kept for backward), running-stat update (in place, fp32 master), folded taps for dwconv_fwd_kernel
+__global__ void bn_train_finalize_kernel(const float* __restrict__ stats /*[2][C]*/, float count, const float* __restrict__ w /*[C,9]*/,
+                                         const float* __restrict__ g, const float* __restrict__ b, float eps, float momentum,
+                                         float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ mean_out,
+                                         float* __restrict__ rstd_out, float* __restrict__ wf, float* __restrict__ sh, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = stats[c] / count;
+    const float var = fmaxf(stats[C + c] / count - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    mean_out[c] = mean; rstd_out[c] = rstd;
+    if (momentum > 0.f) {
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (count > 1.f ? count / (count - 1.f) : 1.f);
+    }
+    const float s = g[c] * rstd;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wf[t * C + c] = w[c * 9 + t] * s;
+    sh[c] = b[c] - mean * s;
+}
+
+extern "C" int cxr_bn_train_finalize(const float* stats, long count, const float* w, const float* g, const float* b, float eps, float momentum,
+                                     float* run_mean, float* run_var, float* mean_out, float* rstd_out, float* wf, float* sh, int C,
+                                     hipStream_t stream) {
+    if (count <= 0 || C <= 0) return CXR_ERR_ARG;
+    CXR_LAUNCH(bn_train_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, stream, stats, (float)count, w, g, b, eps, momentum, run_mean, run_var,
+                       mean_out, rstd_out, wf, sh, C);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// Backward through the batch statistics. With dy = grad wrt the BN output, x^ = (c - mean)*rstd, M positions:
+//   dgamma = sum dy*x^,  dbeta = sum dy,  dc = gamma*rstd*(dy - dbeta/M - x^ * dgamma/M)  =  a*dy + kb + kc*c
+// sum dy and sum dy*c come from the tap sums of dwconv_bwd_w_kernel on dy:  S = sum dy,  sum dy*c = sum_t w[c][t]*G[t][c].
+__global__ void bn_train_bwd_coef_kernel(const float* __restrict__ w, const float* __restrict__ g, const float* __restrict__ mean,
+                                         const float* __restrict__ rstd, const float* __restrict__ G, const float* __restrict__ S, float count,
+                                         float* __restrict__ dg, float* __restrict__ db, float* __restrict__ coef /*[3][C]: a, kb, kc*/, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float dot = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dot += w[c * 9 + t] * G[t * C + c];
+    const float r = rstd[c], mu = mean[c];
+    const float dgam = r * (dot - mu * S[c]);
+    dg[c] += dgam;
+    db[c] += S[c];
+    const float a = g[c] * r, m1 = S[c] / count, m2 = dgam / count;
+    const float kc = -a * m2 * r;
+    coef[c] = a; coef[C + c] = -a * m1 - kc * mu; coef[2 * C + c] = kc;
+}
+
+extern "C" int cxr_bn_train_bwd_coef(const float* w, const float* g, const float* mean, const float* rstd, const float* G, const float* S,
+                                     long count, float* dg, float* db, float* coef, int C, hipStream_t stream) {
+    if (count <= 0 || C <= 0) return CXR_ERR_ARG;
+    CXR_LAUNCH(bn_train_bwd_coef_kernel, dim3(cdiv(C, 128)), dim3(128), 0, stream, w, g, mean, rstd, G, S, (float)count, dg, db, coef, C);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// dy <- dc = a*dy + kb + kc*c in place, c recomputed from the activation and the raw taps (class-token rows are untouched: no BN there)
+__global__ __launch_bounds__(256) void dwconv_bn_train_dc_kernel(const bf16_t* __restrict__ x, long x_bs, long x_rs, const float* __restrict__ wr /*[9][C]*/,
+                                                                 const float* __restrict__ coef, bf16_t* __restrict__ dy, long dy_bs, long dy_rs,
+                                                                 int Bn, int C, int H, int W, int stride, int Ho, int Wo, int tok0) {
+    const int cch = C / 8;
+    const long total = (long)Bn * Ho * Wo * cch;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % cch) * 8;
+        const long t = idx / cch;
+        const int p = (int)(t % (Ho * Wo)), b = (int)(t / (Ho * Wo));
+        const int oy = p / Wo, ox = p % Wo;
+        const bf16_t* xb = x + (long)b * x_bs;
+        float c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * stride - 1 + ky;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * stride - 1 + kx;
+                if (ix < 0 || ix >= W) continue;
+                float f[8];
+                unpack8(*reinterpret_cast<const uint4*>(xb + (long)(tok0 + iy * W + ix) * x_rs + c8), f);
+                const float* u = wr + (ky * 3 + kx) * C + c8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) c[j] += f[j] * u[j];
+            }
+        }
+        bf16_t* dp = dy + (long)b * dy_bs + (long)(tok0 + p) * dy_rs + c8;
+        float d[8];
+        unpack8(*reinterpret_cast<const uint4*>(dp), d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = coef[c8 + j] * d[j] + coef[C + c8 + j] + coef[2 * C + c8 + j] * c[j];
+        *reinterpret_cast<uint4*>(dp) = pack8(d);
+    }
+}
+
+extern "C" int cxr_dwconv_bn_train_dc_bf16(const void* x, long x_bs, long x_rs, const float* wr, const float* coef, void* dy, long dy_bs,
+                                           long dy_rs, int Bn, int C, int H, int W, int stride, int tok0, hipStream_t stream) {
+    if (Bn <= 0 || (C % 8) || (stride != 1 && stride != 2)) return CXR_ERR_ARG;
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const long total = (long)Bn * Ho * Wo * (C / 8);
+    const int grid = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
+    CXR_LAUNCH(dwconv_bn_train_dc_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, wr, coef, (bf16_t*)dy, dy_bs, dy_rs,
+                       Bn, C, H, W, stride, Ho, Wo, tok0);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// dw[c][t] += G[t][c]  (tap sums of dc against the activation = gradient of the raw depthwise taps)
+__global__ void tap_grad_accum_kernel(const float* __restrict__ G, float* __restrict__ dw, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 9 * C) return;
+    const int c = i / 9, t = i % 9;
+    dw[i] += G[t * C + c];
+}
+
+extern "C" int cxr_tap_grad_accum(const float* G, float* dw, int C, hipStream_t stream) {
+    CXR_LAUNCH(tap_grad_accum_kernel, dim3(cdiv(9 * C, 256)), dim3(256), 0, stream, G, dw, C);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}

@@ -78,6 +78,8 @@ struct SkinnyArgs {
     const bf16_t* residual; long ldr;      // added to problem 0 only
     SkinnyProb p[3];
     int nprob, M, K, act, out_f32;
+    // train-mode dropout of the dense output before the residual (BertSelfOutput / BertOutput): row m = sequence, position drop_t
+    const uint32_t* drop_seed; uint32_t drop_site, drop_thr16; float drop_inv; int drop_t;       // drop_thr16 == 0: off
 };
 
 template <int MT>   // number of 16-row tiles of A
@@ -149,6 +151,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs g) {
             if (m >= g.M) continue;
             float v = red[0][t][lane][r] + red[1][t][lane][r] + red[2][t][lane][r] + red[3][t][lane][r] + bv;
             if (g.act == 1) v = gelu_f(v);
+            if (g.drop_thr16)
+                v = dropout_keep(dropout_row_key(*g.drop_seed, g.drop_site, (uint32_t)m, (uint32_t)g.drop_t), (uint32_t)n, g.drop_thr16) ? v * g.drop_inv : 0.f;
             v += rv[t][r];
             if (g.out_f32) reinterpret_cast<float*>(P.C)[(long)m * P.ldc + n] = v;
             else reinterpret_cast<bf16_t*>(P.C)[(long)m * P.ldc + n] = f2bf(v);
@@ -167,9 +171,13 @@ static int launch_skinny(const SkinnyArgs& g, hipStream_t stream) {
 }
 
 extern "C" int cxr_gemm_skinny_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias, const void* residual,
-                                    long ldr, int M, int N, int K, int act, int out_f32, hipStream_t stream) {
+                                    long ldr, int M, int N, int K, int act, int out_f32, float drop_p, const unsigned int* drop_seed,
+                                    unsigned int drop_site, int drop_t, hipStream_t stream) {
     if (M <= 0 || M > 64 || N <= 0 || K <= 0 || (K % 128) || (lda % 8) || (ldw % 8)) return CXR_ERR_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return CXR_ERR_ARG;
     SkinnyArgs g;
+    g.drop_seed = drop_seed; g.drop_site = drop_site; g.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u;
+    g.drop_inv = 1.0f / (1.0f - drop_p); g.drop_t = drop_t;
     g.A = (const bf16_t*)A; g.lda = lda; g.residual = (const bf16_t*)residual; g.ldr = ldr;
     g.p[0].W = (const bf16_t*)W; g.p[0].bias = bias; g.p[0].C = C; g.p[0].ldw = ldw; g.p[0].ldc = ldc; g.p[0].N = N;
     g.p[1] = g.p[0]; g.p[2] = g.p[0];
@@ -183,6 +191,7 @@ extern "C" int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, co
                                      int M, int N, int K, hipStream_t stream) {
     if (M <= 0 || M > 64 || N <= 0 || K <= 0 || (K % 128) || (lda % 8) || (ldw % 8)) return CXR_ERR_ARG;
     SkinnyArgs g;
+    g.drop_seed = nullptr; g.drop_site = 0; g.drop_thr16 = 0; g.drop_inv = 1.f; g.drop_t = 0;
     g.A = (const bf16_t*)A; g.lda = lda; g.residual = nullptr; g.ldr = 0;
     const void* W[3] = {W0, W1, W2}; const float* b[3] = {b0, b1, b2}; void* C[3] = {C0, C1, C2}; const long ldc[3] = {ldc0, ldc1, ldc2};
     for (int i = 0; i < 3; ++i) { g.p[i].W = (const bf16_t*)W[i]; g.p[i].bias = b[i]; g.p[i].C = C[i]; g.p[i].ldw = ldw; g.p[i].ldc = ldc[i]; g.p[i].N = N; }
@@ -197,7 +206,9 @@ extern "C" int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, co
 // Masked keys follow the teacher-forced kernel's convention (finite sentinel -> uniform over masked-only rows).
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                           bf16_t* __restrict__ O, const unsigned char* __restrict__ kpm, long q_bs, long k_bs,
-                                                          long k_rs, long v_bs, long v_rs, long o_bs, long kpm_bs, int H, int Tk, float scale) {
+                                                          long k_rs, long v_bs, long v_rs, long o_bs, long kpm_bs, int H, int Tk, float scale,
+                                                          const uint32_t* __restrict__ drop_seed, uint32_t drop_site, uint32_t drop_thr16, float drop_inv,
+                                                          int drop_t) {
     // single pass (flash-decoding): each of the 32 key groups (8 lanes x 16 B = one 128-byte K/V row per key) keeps a running
     // (max, sum, o[64]) over keys grp, grp+32, ...; 4 keys per iteration -> 8 independent 16-byte loads in flight per lane; the 32
     // partial states are merged through LDS at the end.
@@ -215,6 +226,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     const unsigned char* mrow = kpm ? kpm + (long)b * kpm_bs : nullptr;
     float m_run = -1.0e30f, l_run = 0.f;
     float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // train-mode dropout on the probabilities: same (b*H+h, query position, key) hash as the tiled kernels (attention.hip)
+    const uint32_t drop_key = drop_thr16 ? dropout_row_key(*drop_seed, drop_site, (uint32_t)(b * H + h), (uint32_t)drop_t) : 0u;
     constexpr int KU = 8;                                   // keys per group per iteration: 16 independent 16-byte loads in flight per lane
     for (int k0 = 0; k0 < Tk; k0 += 32 * KU) {
         uint4 kr[KU], vr[KU];
@@ -253,8 +266,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
             float vv[8];
             unpack8(vr[u], vv);
             l_run += p;
+            float pd = p;
+            if (drop_thr16) pd = dropout_keep(drop_key, (uint32_t)(k0 + u * 32 + grp), drop_thr16) ? p * drop_inv : 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += p * vv[j];
+            for (int j = 0; j < 8; ++j) o[j] += pd * vv[j];
         }
     }
     if (sub == 0) { gm[grp] = m_run; gl[grp] = l_run; }
@@ -277,10 +292,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 }
 
 extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs,
-                                    long v_bs, long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, hipStream_t stream) {
+                                    long v_bs, long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, float drop_p,
+                                    const unsigned int* drop_seed, unsigned int drop_site, int drop_t, hipStream_t stream) {
     if (B <= 0 || H <= 0 || Tk <= 0 || Tk > 8192 || (k_rs % 8) || (v_rs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8)) return CXR_ERR_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return CXR_ERR_ARG;
     CXR_LAUNCH(attn_decode_kernel, dim3(B * H), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
-               (bf16_t*)O, (const unsigned char*)kpm, q_bs, k_bs, k_rs, v_bs, v_rs, o_bs, kpm_bs, H, Tk, scale);
+               (bf16_t*)O, (const unsigned char*)kpm, q_bs, k_bs, k_rs, v_bs, v_rs, o_bs, kpm_bs, H, Tk, scale, drop_seed, drop_site,
+               drop_p > 0.f ? dropout_thr16(drop_p) : 0u, 1.0f / (1.0f - drop_p), drop_t);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

@@ -4,7 +4,12 @@ KV-cached decode steps over the HIP kernels. Also runs the bidirectional CXR-BER
 Mirrors transformers' BertLMHeadModel as driven by the reference forward()
 (modules/transformers/longitudinal_model/modelling_longitudinal.py:212-224; TF5 = transformers/models/bert/modeling_bert.py
 @ 5.15.0: embeddings :70-108, eager attention :111-136, layers :374-411, LM head :466-496). LoRA on self-attention query/key
-(modelling_longitudinal.py:163-170) is merged into the effective weight W + (alpha/r) B A before the GEMM (dropout is identity).
+(modelling_longitudinal.py:163-170) is merged into the effective weight W + (alpha/r) B A before the GEMM (lora_dropout is identity).
+
+Train mode (`store.training`, i.e. after model.train()): nn.Dropout(hidden_dropout_prob) after the embedding LayerNorm and after the
+attention-output / cross-attention-output / FFN-output dense layers, nn.Dropout(attention_probs_dropout_prob) on the attention
+probabilities (TF5 :106,131,298,464). Masks come from the counter-based hash of csrc/common.h keyed by (seed, site, sequence, absolute
+position, column): backward -- and the teacher-forced re-scoring of a sequence sampled with the KV cache -- regenerate them.
 """
 from __future__ import annotations
 
@@ -14,6 +19,14 @@ from . import ops
 from .config import BertConfig
 
 BF16 = torch.bfloat16
+
+SITE_EMBED = 1
+
+
+def _site(layer, k):
+    """Dropout site ids of decoder layer `layer`: k = 0 self-attention probabilities, 1 self-attention output, 2 cross-attention
+    probabilities, 3 cross-attention output, 4 FFN output."""
+    return 16 + 8 * layer + k
 
 
 class KVCache:
@@ -106,9 +119,19 @@ class BertEngine:
         self._wt_ready = True
 
     # ------------------------------------------------------------------------------------------ teacher-forced forward
+    def _dropout_cfg(self, train, seed):
+        """-> (p_hidden, p_attn, seed tensor) of this pass; zeros in eval mode."""
+        train = bool(self.s.training) if train is None else bool(train)
+        ph = float(self.cfg.hidden_dropout_prob) if train else 0.0
+        pa = float(self.cfg.attention_probs_dropout_prob) if train else 0.0
+        if (ph > 0.0 or pa > 0.0) and seed is None:
+            seed = self.s.next_dropout_seed()
+        return ph, pa, seed
+
     def forward(self, ids, enc=None, enc_mask=None, attn_mask=None, token_type_ids=None, position_ids=None, save=False, causal=True,
-                lm_head=True):
-        """ids int64 [B,T]; enc bf16 [B,S,D] | None; masks uint8 (1 = attend). -> logits fp32 [B,T,V] (or hidden bf16 [B,T,D]), saved"""
+                lm_head=True, train=None, seed=None):
+        """ids int64 [B,T]; enc bf16 [B,S,D] | None; masks uint8 (1 = attend). -> logits fp32 [B,T,V] (or hidden bf16 [B,T,D]), saved.
+        train (default: the store's nn.Module flag) enables dropout; seed: device int32 [1] to REPRODUCE the masks of an earlier pass."""
         cfg, st, p = self.cfg, self.s, self.p
         self.prepare()
         if save:
@@ -116,13 +139,23 @@ class BertEngine:
         B, T = ids.shape
         D, nh = cfg.hidden_size, cfg.num_attention_heads
         R = B * T
+        ph, pa, seed = self._dropout_cfg(train, seed)
         e = p + "bert.embeddings."
         h, esum, estats = ops.bert_embed(ids, token_type_ids, position_ids, st.w16(e + "word_embeddings.weight"),
                                          st.w16(e + "token_type_embeddings.weight"), st.w16(e + "position_embeddings.weight"),
                                          st.f32(e + "LayerNorm.weight"), st.f32(e + "LayerNorm.bias"), cfg.layer_norm_eps, T, need_sum=save)
+        if ph:
+            ops.dropout_add(h, None, ph, seed, SITE_EMBED, T, out=h)
         saved = dict(B=B, T=T, ids=ids, tt=token_type_ids, pos=position_ids, esum=esum, estats=estats, attn_mask=attn_mask, enc=enc,
-                     enc_mask=enc_mask, causal=causal, layers=[]) if save else None
+                     enc_mask=enc_mask, causal=causal, layers=[], ph=ph, pa=pa, seed=seed) if save else None
         scale = cfg.head_dim ** -0.5
+
+        def out_proj(x, w, b, resid, site):
+            """dense -> dropout -> + residual (BertSelfOutput / BertOutput before their LayerNorm)"""
+            if not ph:
+                return ops.gemm_nt(x, w, bias=b, residual=resid)
+            return ops.dropout_add(ops.gemm_nt(x, w, bias=b), resid, ph, seed, site, T)
+
         for l in range(cfg.num_hidden_layers):
             lp = p + f"bert.encoder.layer.{l}."
             sv = {}
@@ -130,9 +163,9 @@ class BertEngine:
             q = ops.gemm_nt(h, wq, bias=bq).view(B, T, D)
             k = ops.gemm_nt(h, wk, bias=bk).view(B, T, D)
             v = ops.gemm_nt(h, wv, bias=bv).view(B, T, D)
-            ctx, lse = ops.attention(q, k, v, nh, scale, kpm=attn_mask, causal=causal, need_lse=save)
+            ctx, lse = ops.attention(q, k, v, nh, scale, kpm=attn_mask, causal=causal, need_lse=save, drop=(pa, seed, _site(l, 0), 0))
             wo, bo = self._lin(lp + "attention.output.dense")
-            a1 = ops.gemm_nt(ctx.view(R, D), wo, bias=bo, residual=h)
+            a1 = out_proj(ctx.view(R, D), wo, bo, h, _site(l, 1))
             h1, s1 = ops.layernorm(a1, st.f32(lp + "attention.output.LayerNorm.weight"), st.f32(lp + "attention.output.LayerNorm.bias"),
                                    cfg.layer_norm_eps, need_stats=save)
             if save:
@@ -144,8 +177,8 @@ class BertEngine:
                 q2 = ops.gemm_nt(h1, cq, bias=cbq).view(B, T, D)
                 k2 = ops.gemm_nt(enc.view(B * S, D), ck, bias=cbk).view(B, S, D)
                 v2 = ops.gemm_nt(enc.view(B * S, D), cv, bias=cbv).view(B, S, D)
-                ctx2, lse2 = ops.attention(q2, k2, v2, nh, scale, kpm=enc_mask, need_lse=save)
-                a2 = ops.gemm_nt(ctx2.view(R, D), co, bias=cbo, residual=h1)
+                ctx2, lse2 = ops.attention(q2, k2, v2, nh, scale, kpm=enc_mask, need_lse=save, drop=(pa, seed, _site(l, 2), 0))
+                a2 = out_proj(ctx2.view(R, D), co, cbo, h1, _site(l, 3))
                 h2, s2 = ops.layernorm(a2, st.f32(lp + "crossattention.output.LayerNorm.weight"), st.f32(lp + "crossattention.output.LayerNorm.bias"),
                                        cfg.layer_norm_eps, need_stats=save)
                 if save:
@@ -155,7 +188,7 @@ class BertEngine:
             w1, b1 = self._lin(lp + "intermediate.dense"); w2, b2 = self._lin(lp + "output.dense")
             u = torch.empty((R, cfg.intermediate_size), dtype=BF16, device=ids.device) if save else None
             f = ops.gemm_nt(h2, w1, bias=b1, act=1, aux=u)
-            a3 = ops.gemm_nt(f, w2, bias=b2, residual=h2)
+            a3 = out_proj(f, w2, b2, h2, _site(l, 4))
             h, s3 = ops.layernorm(a3, st.f32(lp + "output.LayerNorm.weight"), st.f32(lp + "output.LayerNorm.bias"), cfg.layer_norm_eps, need_stats=save)
             if save:
                 sv.update(u=u, f=f, a3=a3, s3=s3, h2in=h2)
@@ -236,22 +269,31 @@ class BertEngine:
         if need_denc and enc is not None:
             denc = torch.zeros((enc.shape[0] * enc.shape[1], D), dtype=torch.float32, device=dh.device)
         scale = cfg.head_dim ** -0.5
+        ph, pa, seed = saved.get("ph", 0.0), saved.get("pa", 0.0), saved.get("seed")
+
+        def undrop(d, site):
+            """gradient of the dense output under `dense -> dropout -> + residual`: the forward mask re-applied to the sum's gradient"""
+            return ops.dropout_add(d, None, ph, seed, site, T) if ph else d
+
         for l in reversed(range(cfg.num_hidden_layers)):
             lp = p + f"bert.encoder.layer.{l}."
             sv = saved["layers"][l]
             da3 = ops.layernorm_bwd(sv["a3"], dh, st.f32(lp + "output.LayerNorm.weight"), sv["s3"], g(lp + "output.LayerNorm.weight"),
                                     g(lp + "output.LayerNorm.bias"))
-            self._wgrad(lp + "output.dense", da3, sv["f"])
-            du = ops.gemm_nt(da3, self._wt(lp + "output.dense"), act=2, aux=sv["u"])
+            dd3 = undrop(da3, _site(l, 4))
+            self._wgrad(lp + "output.dense", dd3, sv["f"])
+            du = ops.gemm_nt(dd3, self._wt(lp + "output.dense"), act=2, aux=sv["u"])
             self._wgrad(lp + "intermediate.dense", du, sv["h2in"])
             dh2 = ops.gemm_nt(du, self._wt(lp + "intermediate.dense"), residual=da3)
             if "a2" in sv:
                 S = enc.shape[1]
                 da2 = ops.layernorm_bwd(sv["a2"], dh2, st.f32(lp + "crossattention.output.LayerNorm.weight"), sv["s2"],
                                         g(lp + "crossattention.output.LayerNorm.weight"), g(lp + "crossattention.output.LayerNorm.bias"))
-                self._wgrad(lp + "crossattention.output.dense", da2, sv["ctx2"].view(R, D))
-                dctx2 = ops.gemm_nt(da2, self._wt(lp + "crossattention.output.dense")).view(B, T, D)
-                dq2, dk2, dv2 = ops.attention_bwd(sv["q2"], sv["k2"], sv["v2"], sv["ctx2"], dctx2, sv["lse2"], nh, scale, kpm=saved["enc_mask"])
+                dd2 = undrop(da2, _site(l, 3))
+                self._wgrad(lp + "crossattention.output.dense", dd2, sv["ctx2"].view(R, D))
+                dctx2 = ops.gemm_nt(dd2, self._wt(lp + "crossattention.output.dense")).view(B, T, D)
+                dq2, dk2, dv2 = ops.attention_bwd(sv["q2"], sv["k2"], sv["v2"], sv["ctx2"], dctx2, sv["lse2"], nh, scale, kpm=saved["enc_mask"],
+                                                  drop=(pa, seed, _site(l, 2), 0))
                 self._wgrad(lp + "crossattention.self.query", dq2.view(R, D), sv["h1"])
                 self._wgrad(lp + "crossattention.self.key", dk2.view(B * S, D), enc.view(B * S, D))
                 self._wgrad(lp + "crossattention.self.value", dv2.view(B * S, D), enc.view(B * S, D))
@@ -263,10 +305,11 @@ class BertEngine:
                 dh1 = dh2
             da1 = ops.layernorm_bwd(sv["a1"], dh1, st.f32(lp + "attention.output.LayerNorm.weight"), sv["s1"],
                                     g(lp + "attention.output.LayerNorm.weight"), g(lp + "attention.output.LayerNorm.bias"))
-            self._wgrad(lp + "attention.output.dense", da1, sv["ctx"].view(R, D))
-            dctx = ops.gemm_nt(da1, self._wt(lp + "attention.output.dense")).view(B, T, D)
+            dd1 = undrop(da1, _site(l, 1))
+            self._wgrad(lp + "attention.output.dense", dd1, sv["ctx"].view(R, D))
+            dctx = ops.gemm_nt(dd1, self._wt(lp + "attention.output.dense")).view(B, T, D)
             dq, dk, dv = ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, scale, kpm=saved["attn_mask"],
-                                           causal=saved["causal"])
+                                           causal=saved["causal"], drop=(pa, seed, _site(l, 0), 0))
             self._wgrad(lp + "attention.self.query", dq.view(R, D), sv["h"])
             self._wgrad(lp + "attention.self.key", dk.view(R, D), sv["h"])
             self._wgrad(lp + "attention.self.value", dv.view(R, D), sv["h"])
@@ -274,6 +317,7 @@ class BertEngine:
             t2 = ops.gemm_nt(dk.view(R, D), self._wt(lp + "attention.self.key"), residual=t1)
             dh = ops.gemm_nt(dv.view(R, D), self._wt(lp + "attention.self.value"), residual=t2)
         e = p + "bert.embeddings."
+        dh = undrop(dh, SITE_EMBED)
         dsum = ops.layernorm_bwd(saved["esum"], dh, st.f32(e + "LayerNorm.weight"), saved["estats"], g(e + "LayerNorm.weight"), g(e + "LayerNorm.bias"))
         ops.bert_embed_bwd(dsum, saved["ids"], saved["tt"], saved["pos"], g(e + "word_embeddings.weight"), g(e + "token_type_embeddings.weight"),
                            g(e + "position_embeddings.weight"), T, 0, cfg.pad_token_id)
@@ -285,22 +329,36 @@ class BertEngine:
     def new_cache(self, B, Tmax, device):
         return KVCache(self.cfg.num_hidden_layers, B, Tmax, self.cfg.hidden_size, device)
 
-    def decode(self, cache: KVCache, ids_new, enc, enc_mask, attn_mask_full, token_type_ids, position_ids):
+    def decode(self, cache: KVCache, ids_new, enc, enc_mask, attn_mask_full, token_type_ids, position_ids, train=None, seed=None):
         """One cached step. ids_new [B,Tn] (Tn = prompt length at prefill, 1 afterwards); attn_mask_full uint8 [B, len+Tn] | None.
-        Returns fp32 logits of the LAST position [B, V] (TF5 generation/utils.py:2894)."""
+        Returns fp32 logits of the LAST position [B, V] (TF5 generation/utils.py:2894). In train mode (the reference decodes under
+        model.train() inside its SCST training_step) the dropout masks are keyed by (sequence, ABSOLUTE position), so a later
+        teacher-forced pass with the same `seed` reproduces exactly the network that sampled."""
         cfg, st, p = self.cfg, self.s, self.p
         self.prepare()
         B, Tn = ids_new.shape
         D, nh = cfg.hidden_size, cfg.num_attention_heads
         past = cache.len
         R = B * Tn
+        ph, pa, seed = self._dropout_cfg(train, seed)
         e = p + "bert.embeddings."
         h, _, _ = ops.bert_embed(ids_new, token_type_ids, position_ids, st.w16(e + "word_embeddings.weight"),
                                  st.w16(e + "token_type_embeddings.weight"), st.w16(e + "position_embeddings.weight"),
                                  st.f32(e + "LayerNorm.weight"), st.f32(e + "LayerNorm.bias"), cfg.layer_norm_eps, Tn, pos_offset=past)
+        if ph:
+            ops.dropout_add(h, None, ph, seed, SITE_EMBED, Tn, t0=past, out=h)
         scale = cfg.head_dim ** -0.5
         single = Tn == 1 and B <= 64          # one new token per row: weight-streaming GEMMs + single-query attention kernels
         lin = (lambda x, w, **kw: ops.gemm_skinny(x, w, **kw)) if single else (lambda x, w, **kw: ops.gemm_nt(x, w, **kw))
+
+        def out_lin(x, w, b, resid, site):
+            """dense -> dropout -> + residual"""
+            if not ph:
+                return lin(x, w, bias=b, residual=resid)
+            if single:
+                return ops.gemm_skinny(x, w, bias=b, residual=resid, drop=(ph, seed, site, past))
+            return ops.dropout_add(ops.gemm_nt(x, w, bias=b), resid, ph, seed, site, Tn, t0=past)
+
         for l in range(cfg.num_hidden_layers):
             lp = p + f"bert.encoder.layer.{l}."
             wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key"); wv, bv = self._lin(lp + "attention.self.value")
@@ -317,11 +375,11 @@ class BertEngine:
                 ops.copy_rows(ops.gemm_nt(h, wv, bias=bv).view(B, Tn, D), cache.v[l][:, past:past + Tn, :])
             kk, vv = cache.k[l][:, :past + Tn, :], cache.v[l][:, :past + Tn, :]
             if single:
-                ctx = ops.attention_decode(q, kk, vv, nh, scale, kpm=attn_mask_full)
+                ctx = ops.attention_decode(q, kk, vv, nh, scale, kpm=attn_mask_full, drop=(pa, seed, _site(l, 0), past))
             else:
-                ctx, _ = ops.attention(q, kk, vv, nh, scale, kpm=attn_mask_full, causal=True, causal_shift=past)
+                ctx, _ = ops.attention(q, kk, vv, nh, scale, kpm=attn_mask_full, causal=True, causal_shift=past, drop=(pa, seed, _site(l, 0), past))
             wo, bo = self._lin(lp + "attention.output.dense")
-            a1 = lin(ctx.view(R, D), wo, bias=bo, residual=h)
+            a1 = out_lin(ctx.view(R, D), wo, bo, h, _site(l, 1))
             h1, _ = ops.layernorm(a1, st.f32(lp + "attention.output.LayerNorm.weight"), st.f32(lp + "attention.output.LayerNorm.bias"), cfg.layer_norm_eps)
             if cfg.add_cross_attention and enc is not None:
                 S = enc.shape[1]
@@ -334,17 +392,17 @@ class BertEngine:
                 cq, cbq = self._lin(lp + "crossattention.self.query"); co, cbo = self._lin(lp + "crossattention.output.dense")
                 q2 = lin(h1, cq, bias=cbq).view(B, Tn, D)
                 if single:
-                    ctx2 = ops.attention_decode(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask)
+                    ctx2 = ops.attention_decode(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask, drop=(pa, seed, _site(l, 2), past))
                 else:
-                    ctx2, _ = ops.attention(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask)
-                a2 = lin(ctx2.view(R, D), co, bias=cbo, residual=h1)
+                    ctx2, _ = ops.attention(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask, drop=(pa, seed, _site(l, 2), past))
+                a2 = out_lin(ctx2.view(R, D), co, cbo, h1, _site(l, 3))
                 h2, _ = ops.layernorm(a2, st.f32(lp + "crossattention.output.LayerNorm.weight"), st.f32(lp + "crossattention.output.LayerNorm.bias"),
                                       cfg.layer_norm_eps)
             else:
                 h2 = h1
             w1, b1 = self._lin(lp + "intermediate.dense"); w2, b2 = self._lin(lp + "output.dense")
             f = lin(h2, w1, bias=b1, act=1)
-            a3 = lin(f, w2, bias=b2, residual=h2)
+            a3 = out_lin(f, w2, b2, h2, _site(l, 4))
             h, _ = ops.layernorm(a3, st.f32(lp + "output.LayerNorm.weight"), st.f32(lp + "output.LayerNorm.bias"), cfg.layer_norm_eps)
         cache.len = past + Tn
         if past == 0:

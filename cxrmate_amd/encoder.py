@@ -4,8 +4,10 @@ Mirrors CvtWithProjectionHead / MultiCvtWithProjectionHead of the reference
 (modules/transformers/single_model/modelling_single.py:43-78, multi_model/modelling_multi.py:43-87) on top of
 transformers' CvtModel (TF5 = transformers/models/cvt/modeling_cvt.py @ 5.15.0). Activations are kept token-major
 [Bn, L, C] in bf16 for the whole network (the reference flips between NCHW and token-major around every conv).
-BatchNorm runs with its running statistics folded into the depthwise taps (eval semantics, SURVEY.md Q7/Q11 explain
-why parity fixtures are eval-mode); dropout / DropPath are identity.
+BatchNorm: eval mode folds the running statistics into the depthwise taps; train mode (`store.training`, i.e. after `model.train()`,
+which is how the reference runs both the TF and the SCST stage -- SURVEY.md Q7) uses the batch statistics of the launch, moves the
+running statistics, and back-propagates through the statistics. DropPath (stage 3, TF5 modeling_cvt.py:297-316,404-422) is a per-image
+keep/scale of both residual branches in train mode; CvT's other dropouts have rate 0 in the reference configuration.
 """
 from __future__ import annotations
 
@@ -21,6 +23,8 @@ class CvtEncoderEngine:
         self._prep_version = -1
         self._prep = {}
         self._wt_ready = False
+        self._bn_version = 0                        # bumped whenever a train-mode forward moves the running statistics
+        self._fold_cache = {}
 
     # ------------------------------------------------------------------------------------------ weight preparation
     def _stage(self, s):
@@ -45,16 +49,51 @@ class CvtEncoderEngine:
             else:
                 wp = w.permute(0, 2, 3, 1).reshape(co, -1).contiguous()   # K order (ky, kx, c): channel-contiguous gathers
             prep[("embed", s)] = wp
-            for l in range(cfg.depth[s]):
-                lp = sp + f"layers.{l}.attention.attention."
-                for name in ("query", "key", "value"):
-                    cp = lp + f"convolution_projection_{name}.convolution_projection."
-                    prep[("fold", s, l, name)] = ops.bn_fold(
-                        st.f32(cp + "convolution.weight"), st.f32(cp + "normalization.weight"), st.f32(cp + "normalization.bias"),
-                        st.f32(cp + "normalization.running_mean"), st.f32(cp + "normalization.running_var"), cfg.bn_eps)
         self._prep, self._prep_version = prep, st.shadow_version
         self._wt_ready = False
+        self._fold_cache = {}
         return prep
+
+    def _conv_prefix(self, s, l, name):
+        return self._stage(s) + f"layers.{l}.attention.attention.convolution_projection_{name}.convolution_projection."
+
+    def _fold_eval(self, s, l, name):
+        """Depthwise taps with the RUNNING statistics folded in (eval-mode BatchNorm): cached per weight / running-stat version."""
+        key = (s, l, name)
+        hit = self._fold_cache.get(key)
+        if hit is None or hit[0] != self._bn_version:
+            st, cp = self.s, self._conv_prefix(s, l, name)
+            fold = ops.bn_fold(st.f32(cp + "convolution.weight"), st.f32(cp + "normalization.weight"), st.f32(cp + "normalization.bias"),
+                               st.f32(cp + "normalization.running_mean"), st.f32(cp + "normalization.running_var"), self.cfg.bn_eps)
+            hit = self._fold_cache[key] = (self._bn_version, fold)
+        return hit[1]
+
+    def _raw_taps(self, s, l, name):
+        """Raw depthwise taps as [9, C] fp32 (the layout the conv kernels read); layout plumbing, cached per weight version."""
+        key = ("raw", s, l, name)
+        hit = self._fold_cache.get(key)
+        if hit is None:
+            w = self.s.f32(self._conv_prefix(s, l, name) + "convolution.weight")
+            hit = self._fold_cache[key] = w.view(w.shape[0], 9).t().contiguous()
+        return hit
+
+    def _fold_train(self, h1, H, W, stride, tok0, s, l, names):
+        """Train-mode BatchNorm of one (query) or two (key, value) depthwise projections of h1: batch statistics in one pass over h1,
+        running statistics moved in place. -> folds for dwconv_fwd, {name: (mean, rstd, count)} for backward."""
+        cfg, st = self.cfg, self.s
+        raws = [self._raw_taps(s, l, n) for n in names]
+        stats = ops.dwconv_stats(h1, H, W, stride, tok0, raws[0], raws[1] if len(raws) > 1 else None)
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        count = h1.shape[0] * Ho * Wo
+        folds, kept = [], {}
+        for i, n in enumerate(names):
+            cp = self._conv_prefix(s, l, n)
+            fold, mean, rstd = ops.bn_train_finalize(stats[i], count, st.f32(cp + "convolution.weight"), st.f32(cp + "normalization.weight"),
+                                                     st.f32(cp + "normalization.bias"), cfg.bn_eps, cfg.bn_momentum,
+                                                     st.f32(cp + "normalization.running_mean"), st.f32(cp + "normalization.running_var"))
+            folds.append(fold)
+            kept[n] = (mean, rstd, count)
+        return folds, kept
 
     def _prepare_transposes(self):
         """W^T (the K-contiguous operand of every dX GEMM) for the current weight version. Issued on the weight-gradient side stream at the
@@ -81,14 +120,23 @@ class CvtEncoderEngine:
         return self._prep[("wt", key)]
 
     # ------------------------------------------------------------------------------------------ forward
-    def forward(self, px: torch.Tensor, save: bool = False):
-        """px [Bn,3,H,W] fp32 (contiguous) -> feats [Bn*tokens, projection_size] bf16, saved-activation dict | None"""
+    def forward(self, px: torch.Tensor, save: bool = False, train: bool | None = None):
+        """px [Bn,3,H,W] fp32 (contiguous) -> feats [Bn*tokens, projection_size] bf16, saved-activation dict | None.
+        train (default: the store's nn.Module flag): batch-statistics BatchNorm + DropPath."""
         cfg, st = self.cfg, self.s
+        train = bool(st.training) if train is None else bool(train)
         prep = self.prepare()
         if save:
             self._prepare_transposes()
         Bn = px.shape[0]
-        saved = {"Bn": Bn, "stages": []} if save else None
+        saved = {"Bn": Bn, "stages": [], "train": train} if save else None
+        self._train = train
+        self._seed = None
+        if train:
+            self._bn_version += 1
+            st.num_batches_tracked.add_(1)
+            if any(self._drop_path_rate(s) > 0.0 for s in range(len(cfg.depth))):
+                self._seed = st.next_dropout_seed()
         x = None            # [Bn, H*W, C] output of the previous stage (no class token)
         H = W = None
         for s in range(len(cfg.depth)):
@@ -133,6 +181,24 @@ class CvtEncoderEngine:
             saved.update(x_last=x, hn=hn, hstats=hstats)
         return feats, saved
 
+    def _drop_path_rate(self, s):
+        """TF5 modeling_cvt.py:404-422: every layer of stage s gets linspace(0, drop_path_rate[s], depth[s])[s] -- indexed by the STAGE
+        (quirk Q2; CvT-21: 0, 0, 0.1 * 2/15)."""
+        rate, depth = self.cfg.drop_path_rate[s], self.cfg.depth[s]
+        if rate <= 0.0:
+            return 0.0
+        if depth <= s:
+            raise IndexError("list index out of range")          # what the reference raises for such a depth (quirk Q2)
+        return float(torch.linspace(0, rate, depth)[s])
+
+    def _drop_path_scales(self, s, l, Bn):
+        """Per-image factors (0 or 1/keep_prob) of the two DropPath calls of a layer, or (None, None)."""
+        rate = self._drop_path_rate(s) if self._train else 0.0
+        if rate <= 0.0:
+            return None, None
+        gl = sum(self.cfg.depth[:s]) + l
+        return tuple(ops.dropout_mask(Bn, 1, rate, self._seed, 1000 + 2 * gl + j, 1, factor=True).view(Bn) for j in (0, 1))
+
     def _layer_fwd(self, x, s, l, H, W, tok0, prep, save):
         cfg, st = self.cfg, self.s
         lp = self._stage(s) + f"layers.{l}."
@@ -142,22 +208,36 @@ class CvtEncoderEngine:
         x2d = x.view(Bn * L, C)
         h1, st1 = ops.layernorm(x2d, st.f32(lp + "layernorm_before.weight"), st.f32(lp + "layernorm_before.bias"), cfg.inner_layer_norm_eps, need_stats=save)
         h1 = h1.view(Bn, L, C)
-        qc, _ = ops.dwconv_bn(h1, H, W, cfg.stride_q[s], tok0, prep[("fold", s, l, "query")])
-        kc, vc = ops.dwconv_bn(h1, H, W, cfg.stride_kv[s], tok0, prep[("fold", s, l, "key")], prep[("fold", s, l, "value")])
+        bn = None
+        if self._train:
+            (fq,), bn = self._fold_train(h1, H, W, cfg.stride_q[s], tok0, s, l, ("query",))
+            (fk, fv), bkv = self._fold_train(h1, H, W, cfg.stride_kv[s], tok0, s, l, ("key", "value"))
+            bn.update(bkv)
+        else:
+            fq, fk, fv = (self._fold_eval(s, l, n) for n in ("query", "key", "value"))
+        qc, _ = ops.dwconv_bn(h1, H, W, cfg.stride_q[s], tok0, fq)
+        kc, vc = ops.dwconv_bn(h1, H, W, cfg.stride_kv[s], tok0, fk, fv)
         Lk = kc.shape[1]
         q = ops.gemm_nt(qc.view(-1, C), st.w16(ap + "projection_query.weight"), bias=st.f32(ap + "projection_query.bias")).view(Bn, L, C)
         k = ops.gemm_nt(kc.view(-1, C), st.w16(ap + "projection_key.weight"), bias=st.f32(ap + "projection_key.bias")).view(Bn, Lk, C)
         v = ops.gemm_nt(vc.view(-1, C), st.w16(ap + "projection_value.weight"), bias=st.f32(ap + "projection_value.bias")).view(Bn, Lk, C)
         ctx, lse = ops.attention(q, k, v, nh, C ** -0.5, need_lse=save)                  # scale = embed_dim^-0.5 (quirk Q1)
-        x2 = ops.gemm_nt(ctx.view(-1, C), st.w16(lp + "attention.output.dense.weight"), bias=st.f32(lp + "attention.output.dense.bias"), residual=x2d)
+        dp1, dp2 = self._drop_path_scales(s, l, Bn)
+        if dp1 is None:
+            x2 = ops.gemm_nt(ctx.view(-1, C), st.w16(lp + "attention.output.dense.weight"), bias=st.f32(lp + "attention.output.dense.bias"), residual=x2d)
+        else:
+            ao = ops.gemm_nt(ctx.view(-1, C), st.w16(lp + "attention.output.dense.weight"), bias=st.f32(lp + "attention.output.dense.bias"))
+            x2 = ops.dropout_add(ao, x2d, 0.0, None, 0, L, row_scale=dp1)
         h2, st2 = ops.layernorm(x2, st.f32(lp + "layernorm_after.weight"), st.f32(lp + "layernorm_after.bias"), cfg.inner_layer_norm_eps, need_stats=save)
         Ch = st.w16(lp + "intermediate.dense.weight").shape[0]
         u = torch.empty((Bn * L, Ch), dtype=torch.bfloat16, device=x.device) if save else None
         g = ops.gemm_nt(h2, st.w16(lp + "intermediate.dense.weight"), bias=st.f32(lp + "intermediate.dense.bias"), act=1, aux=u)
         x3 = ops.gemm_nt(g, st.w16(lp + "output.dense.weight"), bias=st.f32(lp + "output.dense.bias"), residual=x2)
+        if dp2 is not None:                  # the second CvtDropPath scales the WHOLE layer output, residual included (TF5:cvt:382-383, Q12)
+            ops.dropout_add(x3, None, 0.0, None, 0, L, row_scale=dp2, out=x3)
         lsave = None
         if save:
-            lsave = dict(x=x, st1=st1, h1=h1, qc=qc, kc=kc, vc=vc, q=q, k=k, v=v, ctx=ctx, lse=lse, x2=x2, st2=st2, h2=h2, u=u, g=g)
+            lsave = dict(x=x, st1=st1, h1=h1, qc=qc, kc=kc, vc=vc, q=q, k=k, v=v, ctx=ctx, lse=lse, x2=x2, st2=st2, h2=h2, u=u, g=g, bn=bn, dp=(dp1, dp2))
         return x3.view(Bn, L, C), lsave
 
     # ------------------------------------------------------------------------------------------ backward
@@ -217,25 +297,42 @@ class CvtEncoderEngine:
         nh = cfg.num_heads[s]
         dy2 = dy.reshape(Bn * L, C)
         g = st.grad
-        # MLP:  x3 = x2 + W2 gelu(W1 h2 + b1) + b2
+        # MLP:  x3 = droppath2(x2 + W2 gelu(W1 h2 + b1) + b2)
+        dp1, dp2 = sv["dp"]
+        if dp2 is not None:
+            dy2 = ops.dropout_add(dy2, None, 0.0, None, 0, L, row_scale=dp2)
         ops.linear_bwd_weight(dy2, sv["g"], g(lp + "output.dense.weight"), g(lp + "output.dense.bias"))
         du = ops.gemm_nt(dy2, self._wt(lp + "output.dense.weight"), act=2, aux=sv["u"])
         ops.linear_bwd_weight(du, sv["h2"], g(lp + "intermediate.dense.weight"), g(lp + "intermediate.dense.bias"))
         dh2 = ops.gemm_nt(du, self._wt(lp + "intermediate.dense.weight"))
         dx2 = ops.layernorm_bwd(sv["x2"], dh2, st.f32(lp + "layernorm_after.weight"), sv["st2"], g(lp + "layernorm_after.weight"),
                                 g(lp + "layernorm_after.bias"), add=dy2)
-        # attention output projection: x2 = x + Wo ctx + bo
-        ops.linear_bwd_weight(dx2, sv["ctx"].view(-1, C), g(lp + "attention.output.dense.weight"), g(lp + "attention.output.dense.bias"))
-        dctx = ops.gemm_nt(dx2, self._wt(lp + "attention.output.dense.weight")).view(Bn, L, C)
+        # attention output projection: x2 = x + droppath(Wo ctx + bo)
+        da = dx2 if dp1 is None else ops.dropout_add(dx2, None, 0.0, None, 0, L, row_scale=dp1)
+        ops.linear_bwd_weight(da, sv["ctx"].view(-1, C), g(lp + "attention.output.dense.weight"), g(lp + "attention.output.dense.bias"))
+        dctx = ops.gemm_nt(da, self._wt(lp + "attention.output.dense.weight")).view(Bn, L, C)
         dq, dk, dv = ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, C ** -0.5)
         projs = []
         for name, d, inp, stride in (("query", dq, sv["qc"], cfg.stride_q[s]), ("key", dk, sv["kc"], cfg.stride_kv[s]),
                                      ("value", dv, sv["vc"], cfg.stride_kv[s])):
             ops.linear_bwd_weight(d.view(-1, C), inp.view(-1, C), g(ap + f"projection_{name}.weight"), g(ap + f"projection_{name}.bias"))
             dc = ops.gemm_nt(d.view(-1, C), self._wt(ap + f"projection_{name}.weight")).view(d.shape)
-            wf, _ = prep[("fold", s, l, name)]
-            projs.append((dc, wf, stride))
             cp = ap + f"convolution_projection_{name}.convolution_projection."
+            if sv["bn"] is not None:
+                # batch-statistics BatchNorm: dc (grad wrt the BN output) -> grad wrt the raw conv output, in place; then raw-tap kernels
+                mean, rstd, count = sv["bn"][name]
+                wr = self._raw_taps(s, l, name)
+                G, S = ops.dwconv_bn_bwd_w(sv["h1"], dc, H, W, stride, tok0)
+                coef = ops.bn_train_bwd_coef(st.f32(cp + "convolution.weight"), st.f32(cp + "normalization.weight"), mean, rstd, G, S, count,
+                                             g(cp + "normalization.weight"), g(cp + "normalization.bias"))
+                ops.dwconv_bn_train_dc_(sv["h1"], wr, coef, dc, H, W, stride, tok0)
+                projs.append((dc, wr, stride))
+                with ops._on_wgrad_stream(sv["h1"], dc):
+                    G2, _ = ops.dwconv_bn_bwd_w(sv["h1"], dc, H, W, stride, tok0)
+                    ops.tap_grad_accum(G2, g(cp + "convolution.weight"))
+                continue
+            wf, _ = self._fold_eval(s, l, name)
+            projs.append((dc, wf, stride))
             with ops._on_wgrad_stream(sv["h1"], dc):
                 G, S = ops.dwconv_bn_bwd_w(sv["h1"], dc, H, W, stride, tok0)
                 ops.bn_fold_bwd(st.f32(cp + "convolution.weight"), st.f32(cp + "normalization.weight"), st.f32(cp + "normalization.running_mean"),

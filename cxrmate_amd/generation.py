@@ -36,6 +36,7 @@ class DecodeSession:
         L = model.config.decoder.num_hidden_layers
         self.cache.ck = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
         self.cache.cv = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
+        self.seed = torch.zeros(1, dtype=torch.int32, device=dev)     # dropout seed of the running decode (train mode); graphs read it
         self.graphs = {}
         self.pool = None
         self.version = -1
@@ -54,6 +55,8 @@ class DecodeSession:
             self.enc_mask8.copy_(enc_mask8)
         self.cache.len = 0
         self.cache.cross_ready = False
+        if m.training:
+            self.seed.copy_(m.next_dropout_seed())
 
     def step(self, cur, strip, mode):
         """Append token `cur` (0-based column of self.ids). mode = (do_sample, special_token_ids, mask_token_id, top_k, temperature, eos, pad)."""
@@ -80,11 +83,11 @@ class DecodeSession:
 
     def _run(self, cur, strip, mode, prefill):
         m = self.model
-        kind, special, mask_token_id, top_k, temperature, eos, pad = mode
+        kind, special, mask_token_id, top_k, temperature, eos, pad, train = mode
         fed = self.ids[:, strip:cur]
         new, mask, tt, pos = m._step_inputs(fed, special, mask_token_id, prefill=prefill)
         logits = m._dec.decode(self.cache, new.contiguous(), self.enc16, self.enc_mask8, mask, tt.contiguous(),
-                               None if pos is None else pos.contiguous())
+                               None if pos is None else pos.contiguous(), train=train, seed=self.seed)
         unf = self.unfinished if eos is not None else None
         eos_ = eos if eos is not None else -1
         n_smp = {"greedy": 0, "sample": self.B, "pair": self.B // 2}[kind]      # rows [0, n_smp) sample, the rest take the argmax
@@ -214,10 +217,12 @@ class GenerationMixin:
             cache = self._dec.new_cache(B, max_length, dev)
             unfinished = torch.ones(B, dtype=torch.int32, device=dev)
             step = 0
+            seed = self.next_dropout_seed() if self.training else None
             while ids.shape[1] < max_length:
                 fed = self._fed(ids, bos_token_id)
                 new, mask, tt, pos = self._step_inputs(fed, special_token_ids, mask_token_id, prefill=cache.len == 0)
-                logits = self._dec.decode(cache, new.contiguous(), enc16, enc_mask8, mask, tt.contiguous(), None if pos is None else pos.contiguous())
+                logits = self._dec.decode(cache, new.contiguous(), enc16, enc_mask8, mask, tt.contiguous(), None if pos is None else pos.contiguous(),
+                                          seed=seed)
                 if forced_tokens is not None:
                     greedy_tok, mg = ops.select_token(logits, need_margin=True)
                     margins.append((greedy_tok, mg))
@@ -250,7 +255,9 @@ class GenerationMixin:
                 kind, special = "pair", (tuple(special_token_ids[0]), tuple(special_token_ids[1]))
             else:
                 kind, special = ("sample" if do_sample else "greedy"), tuple(special_token_ids)
-            mode = (kind, special, mask_token_id, int(top_k or 0), float(temperature), eos_token_id, pad_token_id)
+            mode = (kind, special, mask_token_id, int(top_k or 0), float(temperature), eos_token_id, pad_token_id, bool(self.training))
+            if rec is not None:
+                rec["seed"] = ses.seed.clone() if self.training else None
             cur = prompt_len
             while cur < max_length:
                 ses.step(cur, strip, mode)
@@ -293,7 +300,7 @@ class GenerationMixin:
         rec = {"tt": [], "pos": []}
         out = self._generate_session(torch.cat([ids, ids], dim=0), enc16, enc_mask8, (special_sample, special_greedy), mask_token_id,
                                      max_length, bos_token_id, eos_token_id, pad_token_id, "pair", top_k, temperature, rec)
-        rec = {"tt": [t[:B] for t in rec["tt"]], "pos": [None if p_ is None else p_[:B] for p_ in rec["pos"]]}
+        rec = {"tt": [t[:B] for t in rec["tt"]], "pos": [None if p_ is None else p_[:B] for p_ in rec["pos"]], "seed": rec.get("seed")}
 
         def trim(seq):                                   # each half ends where ITS last row finished (HF stops per generate() call)
             if eos_token_id is None:
@@ -318,7 +325,7 @@ class GenerationMixin:
         tt = torch.cat(rec["tt"][:n_new], dim=1)
         pos = torch.cat(rec["pos"][:n_new], dim=1) if rec["pos"][0] is not None else None
         mask = (tf_in != mask_token_id).to(torch.uint8) if self.kind == "longitudinal" else None
-        logits = self._decode_tf(tf_in, enc, None if self.kind == "single" else enc_mask, mask, tt, pos)
+        logits = self._decode_tf(tf_in, enc, None if self.kind == "single" else enc_mask, mask, tt, pos, seed=rec.get("seed"))
         first = prompt_len - stripped - 1
         sc = logits[:, first:, :]
         if temperature is not None and float(temperature) != 1.0:
@@ -352,6 +359,7 @@ class GenerationMixin:
         top_mask = torch.arange(keep, device=dev) < nb
         batch_off = (torch.arange(B, device=dev) * nb).view(B, 1)
         cache = self._dec.new_cache(B * nb, max_length, dev)
+        seed = self.next_dropout_seed() if self.training else None
 
         def gather(t, idx):
             while idx.dim() < t.dim():
@@ -362,7 +370,8 @@ class GenerationMixin:
             flat = running[:, :, :cur].reshape(B * nb, cur)
             fed = self._fed(flat, bos)
             new, mask, tt, pos = self._step_inputs(fed, special_token_ids, mask_token_id, prefill=cache.len == 0)
-            logits = self._dec.decode(cache, new.contiguous(), enc16, enc_mask8, mask, tt.contiguous(), None if pos is None else pos.contiguous())
+            logits = self._dec.decode(cache, new.contiguous(), enc16, enc_mask8, mask, tt.contiguous(), None if pos is None else pos.contiguous(),
+                                      seed=seed)
             ops.log_softmax_rows_(logits, add_row=run_scores.view(-1).contiguous())          # log_softmax + running beam score
             topk_lp, topk_idx = ops.topk_rows(logits.view(B, nb * V), keep)
             beam_of = topk_idx // V

@@ -70,8 +70,8 @@ class _EncodeFn(torch.autograd.Function):
 
 class _DecodeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, enc, enc_mask, ids, attn_mask, tt, pos, *params):
-        logits, saved = model._dec.forward(ids, enc, enc_mask, attn_mask, tt, pos, save=True)
+    def forward(ctx, model, enc, enc_mask, ids, attn_mask, tt, pos, seed, *params):
+        logits, saved = model._dec.forward(ids, enc, enc_mask, attn_mask, tt, pos, save=True, seed=seed)
         ctx.model, ctx.saved, ctx.nparams = model, saved, len(params)
         ctx.need_denc = enc is not None and enc.requires_grad
         return logits
@@ -86,7 +86,7 @@ class _DecodeFn(torch.autograd.Function):
         d16 = ops.cast_to_bf16(d16.contiguous()) if d16.dtype == torch.float32 else d16.contiguous()
         denc = model._dec.backward(ctx.saved, dlogits=d16, need_denc=ctx.need_denc)
         ctx.saved = None
-        return (None, denc, None, None, None, None, None) + model._collect_grads("decoder.", ctx.nparams)
+        return (None, denc, None, None, None, None, None, None) + model._collect_grads("decoder.", ctx.nparams)
 
 
 # ---------------------------------------------------------------------------------------------------- sub-modules
@@ -219,7 +219,7 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
             return None
         return t.to(device=device, dtype=torch.int64).contiguous()
 
-    def _decode_tf(self, ids, enc, enc_mask, attn_mask, tt, pos):
+    def _decode_tf(self, ids, enc, enc_mask, attn_mask, tt, pos, seed=None):
         dev = self.device
         ids, tt, pos = self._i64(ids, dev), self._i64(tt, dev), self._i64(pos, dev)
         attn_mask, enc_mask = self._u8(attn_mask, dev), self._u8(enc_mask, dev)
@@ -227,8 +227,8 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
         enc = enc.contiguous()
         params = [p for _, p in self._grad_params("decoder.")]
         if torch.is_grad_enabled() and (params or enc.requires_grad):
-            return _DecodeFn.apply(self, enc, enc_mask, ids, attn_mask, tt, pos, *params)
-        logits, _ = self._dec.forward(ids, enc, enc_mask, attn_mask, tt, pos, save=False)
+            return _DecodeFn.apply(self, enc, enc_mask, ids, attn_mask, tt, pos, seed, *params)
+        logits, _ = self._dec.forward(ids, enc, enc_mask, attn_mask, tt, pos, save=False, seed=seed)
         return logits
 
 

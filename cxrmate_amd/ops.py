@@ -145,7 +145,7 @@ def linear_bwd_input(dy, w_t, **kw):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def attention(q, k, v, heads, scale, kpm=None, causal=False, causal_shift=None, need_lse=False, out=None):
+def attention(q, k, v, heads, scale, kpm=None, causal=False, causal_shift=None, need_lse=False, out=None, drop=None):
     """q [B,Tq,H*64], k/v [B,Tk,H*64] bf16 (last dim contiguous; batch/row strides free). -> out [B,Tq,H*64], lse [B,H,Tq] | None"""
     B, Tq, D = q.shape
     Tk = k.shape[1]
@@ -161,11 +161,19 @@ def attention(q, k, v, heads, scale, kpm=None, causal=False, causal_shift=None, 
         causal_shift = Tk - Tq
     LIB.call("cxr_attn_fwd_bf16", _p(q), _p(k), _p(v), _p(out), _p(lse), _p(kpm), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
              v.stride(0), v.stride(1), out.stride(0), out.stride(1), kpm.stride(0) if kpm is not None else 0, B, heads, Tq, Tk,
-             float(scale), int(causal), int(causal_shift), _s())
+             float(scale), int(causal), int(causal_shift), *_drop_args(drop), _s())
     return out, lse
 
 
-def attention_bwd(q, k, v, o, do, lse, heads, scale, kpm=None, causal=False, causal_shift=None):
+def _drop_args(drop):
+    """drop = None | (p, seed int32/uint32 device tensor [1], site, t0) -> the four trailing dropout arguments of the attention entry points"""
+    if drop is None or drop[0] <= 0.0:
+        return 0.0, None, 0, 0
+    p, seed, site, t0 = drop
+    return float(p), _p(seed), int(site), int(t0)
+
+
+def attention_bwd(q, k, v, o, do, lse, heads, scale, kpm=None, causal=False, causal_shift=None, drop=None):
     B, Tq, D = q.shape
     Tk = k.shape[1]
     dq = torch.empty((B, Tq, D), device=q.device, dtype=BF16)
@@ -180,8 +188,29 @@ def attention_bwd(q, k, v, o, do, lse, heads, scale, kpm=None, causal=False, cau
     do = do if do.stride() == o.stride() else do.contiguous()
     LIB.call("cxr_attn_bwd_bf16", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(kpm),
              q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), o.stride(0), o.stride(1),
-             kpm.stride(0) if kpm is not None else 0, B, heads, Tq, Tk, float(scale), int(causal), int(causal_shift), _s())
+             kpm.stride(0) if kpm is not None else 0, B, heads, Tq, Tk, float(scale), int(causal), int(causal_shift), *_drop_args(drop), _s())
     return dq, dk, dv
+
+
+# ------------------------------------------------------------------------------------------------ dropout / DropPath (train mode)
+def dropout_add(y, resid, p, seed, site, rows_per_b, t0=0, row_scale=None, out=None):
+    """out = resid + f*y (bf16 2-D): f = keep/(1-p) from the counter-based hash of (seed, site, row // rows_per_b, t0 + row % rows_per_b, col),
+    or f = row_scale[row // rows_per_b]. resid None -> out = f*y (the backward of the same dropout applied to a gradient)."""
+    _chk(y, BF16)
+    R, C = y.shape
+    if out is None:
+        out = torch.empty((R, C), device=y.device, dtype=BF16)
+    LIB.call("cxr_dropout_add_bf16", _p(y), y.stride(0), _p(resid), resid.stride(0) if resid is not None else 0, _p(out), out.stride(0), R, C,
+             float(p), _p(seed), int(site), int(rows_per_b), int(t0), _p(row_scale), _s())
+    return out
+
+
+def dropout_mask(R, C, p, seed, site, rows_per_b, t0=0, factor=False):
+    """Keep mask (uint8 [R,C]) or fp32 factor keep/(1-p) of one dropout site."""
+    out = torch.empty((R, C), device=seed.device, dtype=torch.float32 if factor else torch.uint8)
+    LIB.call("cxr_dropout_mask", None if factor else _p(out), _p(out) if factor else None, R, C, float(p), _p(seed), int(site), int(rows_per_b),
+             int(t0), _s())
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ normalisation
@@ -284,6 +313,44 @@ def dwconv_bn_bwd_w(x, dy, H, W, stride, tok0):
     LIB.call("cxr_dwconv_bn_bwd_w_bf16", _p(x), x.stride(0), x.stride(1), _p(dy), dy.stride(0), dy.stride(1), _p(G), _p(S), Bn, C, H, W,
              stride, tok0, _s())
     return G, S
+
+
+def dwconv_stats(x, H, W, stride, tok0, wr0, wr1=None):
+    """Sum / sum of squares per channel of the raw depthwise conv outputs -> fp32 [nproj, 2, C] (train-mode BatchNorm)."""
+    Bn, L, C = x.shape
+    n = 2 if wr1 is not None else 1
+    stats = torch.zeros((n, 2, C), device=x.device, dtype=torch.float32)
+    LIB.call("cxr_dwconv_stats_bf16", _p(x), x.stride(0), x.stride(1), _p(wr0), _p(wr1), _p(stats), Bn, C, H, W, stride, tok0, _s())
+    return stats
+
+
+def bn_train_finalize(stats, count, w, g, b, eps, momentum, run_mean, run_var):
+    """-> (wf [9,C], sh [C]) folded with the batch statistics, mean [C], rstd [C]; running stats updated in place."""
+    C = w.shape[0]
+    wf = torch.empty((9, C), device=w.device, dtype=torch.float32)
+    sh = torch.empty((C,), device=w.device, dtype=torch.float32)
+    mr = torch.empty((2, C), device=w.device, dtype=torch.float32)
+    LIB.call("cxr_bn_train_finalize", _p(stats), int(count), _p(w), _p(g), _p(b), float(eps), float(momentum), _p(run_mean), _p(run_var),
+             _p(mr[0]), _p(mr[1]), _p(wf), _p(sh), C, _s())
+    return (wf, sh), mr[0], mr[1]
+
+
+def bn_train_bwd_coef(w, g, mean, rstd, G, S, count, dg, db):
+    C = w.shape[0]
+    coef = torch.empty((3, C), device=w.device, dtype=torch.float32)
+    LIB.call("cxr_bn_train_bwd_coef", _p(w), _p(g), _p(mean), _p(rstd), _p(G), _p(S), int(count), _p(dg), _p(db), _p(coef), C, _s())
+    return coef
+
+
+def dwconv_bn_train_dc_(x, wr, coef, dy, H, W, stride, tok0):
+    Bn, _, C = x.shape
+    LIB.call("cxr_dwconv_bn_train_dc_bf16", _p(x), x.stride(0), x.stride(1), _p(wr), _p(coef), _p(dy), dy.stride(0), dy.stride(1), Bn, C, H, W,
+             stride, tok0, _s())
+    return dy
+
+
+def tap_grad_accum(G, dw):
+    LIB.call("cxr_tap_grad_accum", _p(G), _p(dw), G.shape[1], _s())
 
 
 # ------------------------------------------------------------------------------------------------ embeddings / integer ops
@@ -471,18 +538,19 @@ def cosine_rows(a, b, eps=1e-8):
     return out
 
 
-def gemm_skinny(a, w, bias=None, residual=None, act=0, out=None, out_f32=False):
-    """Decode-step linear: a [M<=64, K] @ w[N, K]^T (+bias, GELU, +residual). Weight-streaming kernel (no LDS staging)."""
+def gemm_skinny(a, w, bias=None, residual=None, act=0, out=None, out_f32=False, drop=None):
+    """Decode-step linear: a [M<=64, K] @ w[N, K]^T (+bias, GELU, dropout, +residual). Weight-streaming kernel (no LDS staging).
+    drop = (p, seed, site, t): train-mode dropout of the dense output, row m = sequence m at absolute position t."""
     M, K = a.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else BF16)
     LIB.call("cxr_gemm_skinny_bf16", _p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias), _p(residual),
-             residual.stride(0) if residual is not None else 0, M, N, K, int(act), int(out_f32), _s())
+             residual.stride(0) if residual is not None else 0, M, N, K, int(act), int(out_f32), *_drop_args(drop), _s())
     return out
 
 
-def attention_decode(q, k, v, heads, scale, kpm=None, out=None):
+def attention_decode(q, k, v, heads, scale, kpm=None, out=None, drop=None):
     """q [B,1,H*64] (or [B,H*64]); k, v [B,Tk,H*64] views (batch/row strides free) -> [B, H*64]"""
     B = q.shape[0]
     D = heads * 64
@@ -490,7 +558,7 @@ def attention_decode(q, k, v, heads, scale, kpm=None, out=None):
     if out is None:
         out = torch.empty((B, D), device=q.device, dtype=BF16)
     LIB.call("cxr_attn_decode_bf16", _p(q), _p(k), _p(v), _p(out), _p(kpm), q.stride(0), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-             out.stride(0), kpm.stride(0) if kpm is not None else 0, B, heads, Tk, float(scale), _s())
+             out.stride(0), kpm.stride(0) if kpm is not None else 0, B, heads, Tk, float(scale), *_drop_args(drop), _s())
     return out
 
 

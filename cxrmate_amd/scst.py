@@ -61,7 +61,8 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         mask = (tf_in != pad).to(torch.uint8)
         enc = eo.last_hidden_state
         enc_mask = eo.attention_mask.to(torch.uint8).contiguous()
-        logits, saved = model._dec.forward(tf_in, enc.contiguous(), enc_mask, mask, tt, pos, save=True)
+        # train mode: the same dropout seed as the cached sampling decode -> the re-scored network IS the one that sampled
+        logits, saved = model._dec.forward(tf_in, enc.contiguous(), enc_mask, mask, tt, pos, save=True, seed=rec.get("seed"))
         B, T, V = logits.shape
         sc = logits[:, P - 1:, :]                                            # scores of the n_new sampling steps
         if float(temperature) != 1.0:

@@ -56,6 +56,18 @@ class ParamStore(nn.Module):
         self.shadow_dirty = True
         self.shadow_version = 0
         self._build(torch.device(device))
+        self.static_dropout_seed = None          # set (device int32 [1]) by graph-captured training steps: advanced on the device per replay
+        self.train(False)                        # like from_pretrained(): eval until the trainer calls .train()
+
+    def next_dropout_seed(self):
+        """Device int32 [1] seed of one train-mode pass. Drawn from torch's CPU generator (reproducible under torch.manual_seed); when a
+        static seed is installed (hipGraph capture) it is advanced in place on the device instead, so every replay sees fresh masks."""
+        if self.static_dropout_seed is not None:
+            from . import ops
+            ops.increment_(self.static_dropout_seed)
+            return self.static_dropout_seed
+        val = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        return torch.full((1,), val, dtype=torch.int32, device=self.device)
 
     # ------------------------------------------------------------------------------------------ construction
     def _numel(self, k):
@@ -70,10 +82,14 @@ class ParamStore(nn.Module):
         self.flat16 = torch.zeros(self._total, dtype=torch.bfloat16, device=device)
         self.gflat = None
         self._views32.clear(); self._views16.clear(); self._viewsg.clear()
+        nbt_keys = [k for k in self._shapes if k.endswith("num_batches_tracked")]
+        self.num_batches_tracked = torch.zeros(len(nbt_keys), dtype=torch.int64, device=device)     # all BatchNorm counters: one add per step
+        for i, k in enumerate(nbt_keys):
+            if source is not None:
+                self.num_batches_tracked[i] = source[k].to(device)
+            self._register(k, self.num_batches_tracked[i], buffer=True)
         for k, shp in self._shapes.items():
             if k.endswith("num_batches_tracked"):
-                t = torch.zeros((), dtype=torch.int64, device=device) if source is None else source[k].to(device)
-                self._register(k, t, buffer=True)
                 continue
             o, n = self._offsets[k], self._numel(k)
             v = flat32[o:o + n].view(shp)

@@ -137,6 +137,9 @@ class GraphedTFStep:
                        for t in (pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids, label_ids, decoder_position_ids)]
         self.world = dp.world_size()
         px, ids, am, tt, lab, pos = self.static
+        if model.training and model.static_dropout_seed is None:
+            # captured kernels read the dropout seed from this device word; each replay advances it (store.next_dropout_seed)
+            model.static_dropout_seed = torch.full((1,), int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), dtype=torch.int32, device=dev)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                       # warm-up off the default stream (allocator + lazy kernel loading)
@@ -162,6 +165,8 @@ class GraphedTFStep:
             if src is not None and dst is not None and src.data_ptr() != dst.data_ptr():
                 dst.copy_(src, non_blocking=True)
         model, opt = self.model, self.opt
+        if model.training:
+            model._enc._bn_version += 1       # the replay moves the BatchNorm running statistics: eval-mode folds must be re-derived
         self.g1.replay()
         if self.world > 1 and self.enc_trainable:
             opt.reducer.reduce_range(opt.split, model._param_total)

@@ -39,14 +39,26 @@ int cxr_colsum_bf16(const void* in, long ld, float* out, int R, int C, hipStream
 /* ---- attention -----------------------------------------------------------------------------------------------------------
  * O = softmax(scale * Q K^T + mask) V, head_dim 64, flash-style. CvT: einsum/softmax/einsum with scale = embed_dim^-0.5
  * (TF5:cvt:152,205-209, quirk Q1); BERT eager_attention_forward (TF5:bert:111-136) with causal and/or key-padding mask
- * (kpm[B,Tk] bytes, 1 = attend). Element (b,t,h,d) of X lives at X + b*x_bs + t*x_rs + h*64 + d. LSE[B,H,Tq] (natural log) optional. */
+ * (kpm[B,Tk] bytes, 1 = attend). Element (b,t,h,d) of X lives at X + b*x_bs + t*x_rs + h*64 + d. LSE[B,H,Tq] (natural log) optional.
+ * drop_p > 0: train-mode dropout on the attention probabilities (TF5:bert:131): the keep decision of (b*H+h, drop_t0 + query, key) is the
+ * counter-based hash of cxr_dropout_mask with `drop_site`; *drop_seed is read on the device. */
 int cxr_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, float* LSE, const void* kpm, long q_bs, long q_rs, long k_bs,
                       long k_rs, long v_bs, long v_rs, long o_bs, long o_rs, long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal,
-                      int causal_shift, hipStream_t stream);
+                      int causal_shift, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t0, hipStream_t stream);
 /* backward: dQ,dK,dV (contiguous [B,T,H*64]) from dO with P recomputed from (Q,K,LSE); delta[B,H,Tq] = rowsum(dO*O) is scratch */
 int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* delta, void* dQ,
                       void* dK, void* dV, const void* kpm, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
-                      long o_rs, long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal, int causal_shift, hipStream_t stream);
+                      long o_rs, long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal, int causal_shift, float drop_p,
+                      const unsigned int* drop_seed, unsigned int drop_site, int drop_t0, hipStream_t stream);
+
+/* ---- train-mode dropout / DropPath (TF5:bert:106,298,464; TF5:cvt:297-316) ---------------------------------------------------
+ * out = resid + f * y with f = keep(seed, site, b, t, col)/(1-p) per element (b = row / rows_per_b, t = t0 + row % rows_per_b), or
+ * f = row_scale[row / rows_per_b] (DropPath: 0 or 1/keep_prob per image). Backward applies the same call to the incoming gradient
+ * (resid = NULL). cxr_dropout_mask materialises the keep bytes / factors of a site (parity tests feed them to the CPU oracle). */
+int cxr_dropout_add_bf16(const void* y, long ldy, const void* resid, long ldr, void* out, long ldo, long R, int C, float p,
+                         const unsigned int* seed, unsigned int site, int rows_per_b, int t0, const float* row_scale, hipStream_t stream);
+int cxr_dropout_mask(unsigned char* mask, float* factor, long R, int C, float p, const unsigned int* seed, unsigned int site, int rows_per_b,
+                     int t0, hipStream_t stream);
 
 /* ---- LayerNorm (TF5:cvt:79,363-364; REF:modelling_single.py:29; TF5:bert:103,292,350,478) ------------------------------- */
 int cxr_layernorm_fwd_bf16(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* stats, long rows, int C,
@@ -76,6 +88,21 @@ int cxr_dwconv_bn_bwd_dx_bf16(const void* dy0, const float* wf0, long bs0, long 
                               long dx_bs, long dx_rs, int Bn, int C, int H, int W, int tok0, hipStream_t stream);
 int cxr_dwconv_bn_bwd_w_bf16(const void* x, long x_bs, long x_rs, const void* dy, long dy_bs, long dy_rs, float* G, float* S, int Bn, int C,
                              int H, int W, int stride, int tok0, hipStream_t stream);
+
+/* train-mode BatchNorm2d (batch statistics; the reference trains under model.train(), and the "frozen" SCST encoder stays in train mode:
+ * modules/lightning_modules/longitudinal/scst/gt_prompt.py:34-36). stats fp32 [nproj][2][C] zero-initialised (sum, sum of
+ * squares of the raw depthwise conv outputs); finalize turns them into batch mean/rstd, moves the running statistics in place and emits the
+ * folded taps for cxr_dwconv_bn_fwd_bf16. Backward: tap sums of dy (cxr_dwconv_bn_bwd_w_bf16) -> coef -> dy rewritten in place as the gradient
+ * of the raw conv output -> the ordinary dx / tap-sum kernels with the RAW taps wr [9][C]. */
+int cxr_dwconv_stats_bf16(const void* x, long x_bs, long x_rs, const float* w0, const float* w1, float* stats, int Bn, int C, int H, int W,
+                          int stride, int tok0, hipStream_t stream);
+int cxr_bn_train_finalize(const float* stats, long count, const float* w, const float* g, const float* b, float eps, float momentum,
+                          float* run_mean, float* run_var, float* mean_out, float* rstd_out, float* wf, float* sh, int C, hipStream_t stream);
+int cxr_bn_train_bwd_coef(const float* w, const float* g, const float* mean, const float* rstd, const float* G, const float* S, long count,
+                          float* dg, float* db, float* coef, int C, hipStream_t stream);
+int cxr_dwconv_bn_train_dc_bf16(const void* x, long x_bs, long x_rs, const float* wr, const float* coef, void* dy, long dy_bs, long dy_rs,
+                                int Bn, int C, int H, int W, int stride, int tok0, hipStream_t stream);
+int cxr_tap_grad_accum(const float* G, float* dw, int C, hipStream_t stream);
 
 /* ---- BERT embeddings (TF5:bert:70-108) ------------------------------------------------------------------------------------ */
 int cxr_bert_embed_fwd(const long* ids, const long* tt, const long* pid, const void* word, const void* type, const void* posw,
@@ -109,12 +136,15 @@ int cxr_gather_batch_bf16(const void* in, long in_bs, long in_rs, void* out, lon
 /* decode-step (one new token per row) kernels: weight-streaming GEMM for M <= 64 rows (K % 128 == 0) and single-query attention over
  * the KV cache / the cross-attention K,V (TF5:bert:164-203,230-279 with a cache, q length 1) */
 int cxr_gemm_skinny_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias, const void* residual, long ldr,
-                         int M, int N, int K, int act, int out_f32, hipStream_t stream);
+                         int M, int N, int K, int act, int out_f32, float drop_p, const unsigned int* drop_seed, unsigned int drop_site,
+                         int drop_t, hipStream_t stream);   /* drop_p > 0: dropout of the dense output before the residual, rows = sequences
+                                                               at absolute position drop_t (same hash as cxr_dropout_add_bf16) */
 int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, const float* b0, void* C0, long ldc0, const void* W1, const float* b1,
                           void* C1, long ldc1, const void* W2, const float* b2, void* C2, long ldc2, long ldw, int M, int N, int K,
                           hipStream_t stream);   /* q / k / v projections of one decode step in a single launch */
 int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs, long v_bs,
-                         long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, hipStream_t stream);
+                         long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, float drop_p, const unsigned int* drop_seed,
+                         unsigned int drop_site, int drop_t, hipStream_t stream);   /* drop_t = absolute position of the query */
 int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, long* inds, hipStream_t stream);
 
 /* ---- reward (REF:tools/rewards/cxrbert.py:66-71 torch.nn.functional.cosine_similarity of the CLS projections) ---------------- */

@@ -247,6 +247,97 @@ def fixture_tf_single():
     print("tf_single loss", loss.item(), "gradnorm", d["grad_total_norm"])
 
 
+def fixture_tf_single_train():
+    """Reference model under .train(): batch-statistics BatchNorm (+ running-stat update), nn.Dropout 0.1 (hidden + attention probabilities),
+    DropPath in CvT stage 3. The keep masks the reference actually drew are RECORDED (torch.nn.functional.dropout is wrapped, DropPath
+    modules are hooked) so that the oracle -- which takes masks as inputs -- can be pinned on the same stochastic pass."""
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, depth=(1, 2, 3), image_size=96)
+    g = torch.Generator().manual_seed(102)
+    x = torch.randn(3, 3, 96, 96, generator=g)
+    full = rand_report_ids(g, 3, 25, 1000, [7, 11, 5], [25, 18, 12])
+    attn = (full != PAD).long()
+    inp, lab, am = full[:, :-1], full[:, 1:].clone(), attn[:, 1:]
+    import transformers.models.cvt.modeling_cvt as mcvt
+    orig_dropout = torch.nn.functional.dropout
+    for draw_seed in range(100, 200):
+        model, _ = build(SingleCXREncoderDecoderModel, cfg, seed=17, perturb=0.05)
+        tt = model.token_ids_to_token_type_ids(inp, [SEP])
+        for p_ in model.parameters():
+            p_.requires_grad_(True)
+        model.train()
+        drops, paths = [], []
+
+        def rec_dropout(inp_, p=0.5, training=True, inplace=False):
+            out = orig_dropout(inp_, p=p, training=training, inplace=False)
+            if training and p > 0.0:
+                keep = torch.where(inp_ != 0, out != 0, torch.ones_like(out, dtype=torch.bool))   # exact zeros: either answer is right
+                drops.append((float(p), keep.detach().clone()))
+            return out
+
+        hooks = []
+        for n_, m_ in model.named_modules():
+            if isinstance(m_, mcvt.CvtDropPath) and m_.drop_prob > 0.0:
+                def hook(mod, args, out, name=n_):
+                    i_ = args[0]
+                    flat_i, flat_o = i_.reshape(i_.shape[0], -1), out.reshape(out.shape[0], -1)
+                    j = flat_i.abs().argmax(1)
+                    f = flat_o[torch.arange(i_.shape[0]), j] / flat_i[torch.arange(i_.shape[0]), j]
+                    paths.append((name, float(mod.drop_prob), f.detach().clone()))
+                hooks.append(m_.register_forward_hook(hook))
+        torch.nn.functional.dropout = rec_dropout
+        try:
+            torch.manual_seed(draw_seed)
+            out = model(pixel_values=x, decoder_input_ids=inp, decoder_attention_mask=am, decoder_token_type_ids=tt, return_dict=True)
+        finally:
+            torch.nn.functional.dropout = orig_dropout
+            for h_ in hooks:
+                h_.remove()
+        if any(bool((f == 0).any()) for _, _, f in paths):
+            break                                       # a pass that actually drops a residual branch
+    loss = torch.nn.functional.cross_entropy(out.logits.permute(0, 2, 1), lab, ignore_index=PAD)
+    loss.backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    pick = ["decoder.bert.embeddings.word_embeddings.weight", "decoder.bert.encoder.layer.1.crossattention.self.key.weight",
+            "decoder.bert.encoder.layer.0.attention.self.query.weight", "decoder.bert.encoder.layer.0.attention.self.value.weight",
+            "decoder.bert.encoder.layer.0.output.LayerNorm.weight", "decoder.bert.embeddings.LayerNorm.weight",
+            "encoder.projection_head.projection.weight",
+            "encoder.cvt.encoder.stages.2.layers.2.output.dense.weight", "encoder.cvt.encoder.stages.2.cls_token",
+            "encoder.cvt.encoder.stages.2.layers.0.attention.attention.convolution_projection_key.convolution_projection.convolution.weight",
+            "encoder.cvt.encoder.stages.2.layers.0.attention.attention.convolution_projection_query.convolution_projection.normalization.weight",
+            "encoder.cvt.encoder.stages.2.layers.1.attention.attention.convolution_projection_value.convolution_projection.normalization.bias",
+            "encoder.cvt.encoder.stages.1.layers.0.attention.attention.convolution_projection_query.convolution_projection.convolution.weight",
+            "encoder.cvt.encoder.stages.1.layers.0.attention.attention.projection_value.weight",
+            "encoder.cvt.encoder.stages.0.layers.0.attention.attention.convolution_projection_value.convolution_projection.convolution.weight",
+            "encoder.cvt.encoder.stages.0.layers.0.layernorm_before.weight",
+            "encoder.cvt.encoder.stages.0.embedding.convolution_embeddings.projection.weight"]
+    d = {"seed": 17, "perturb": 0.05, "pixel_seed": 102, "draw_seed": draw_seed, "full_ids": full.numpy(), "token_type_ids": tt.numpy(),
+         "logits_sample": sample(out.logits, 16384), "logits_stats": stats(out.logits), "loss": np.array(loss.item()),
+         "grad_names": np.array(pick), "n_dropout": len(drops), "n_droppath": len(paths)}
+    # decoder dropout calls arrive in module order: embeddings, then per layer self-probs, self-out, cross-probs, cross-out, ffn-out
+    assert len(drops) == 1 + 5 * cfg.decoder.num_hidden_layers, len(drops)
+    for i, (p_, keep) in enumerate(drops):
+        d[f"drop{i}_p"] = np.array(p_)
+        d[f"drop{i}_shape"] = np.array(keep.shape)
+        d[f"drop{i}_keep"] = np.packbits(keep.numpy().reshape(-1))
+    for i, (name, p_, f) in enumerate(paths):
+        d[f"path{i}_name"] = np.array(name)
+        d[f"path{i}_p"] = np.array(p_)
+        d[f"path{i}_factor"] = f.numpy()
+    for i, n in enumerate(pick):
+        d[f"grad{i}_sample"] = sample(grads[n], 2048)
+        d[f"grad{i}_stats"] = stats(grads[n])
+    d["grad_total_norm"] = np.array(torch.sqrt(sum((v.double() ** 2).sum() for v in grads.values())).item())
+    bn = "encoder.cvt.encoder.stages.{}.layers.{}.attention.attention.convolution_projection_{}.convolution_projection.normalization."
+    msd = model.state_dict()
+    for i, (s_, l_, n_) in enumerate([(0, 0, "query"), (1, 1, "key"), (2, 2, "value")]):
+        d[f"bn{i}_key"] = np.array(bn.format(s_, l_, n_))
+        d[f"bn{i}_running_mean"] = msd[bn.format(s_, l_, n_) + "running_mean"].numpy()
+        d[f"bn{i}_running_var"] = msd[bn.format(s_, l_, n_) + "running_var"].numpy()
+        d[f"bn{i}_num_batches_tracked"] = msd[bn.format(s_, l_, n_) + "num_batches_tracked"].numpy()
+    np.savez_compressed(os.path.join(OUT, "tf_single_train.npz"), **d)
+    print("tf_single_train loss", loss.item(), "gradnorm", d["grad_total_norm"], "draw_seed", draw_seed, "paths", [(n, f.tolist()) for n, _, f in paths])
+
+
 def make_prompt(g, b, vocab, lens):
     t = max(lens)
     ids = torch.full((b, t), PAD, dtype=torch.long)
@@ -511,10 +602,10 @@ def fixture_reward_trunk():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["token_ops", "encoder", "tf_single", "tf_longitudinal", "generate", "reward_trunk"]
+    which = sys.argv[1:] or ["token_ops", "encoder", "tf_single", "tf_single_train", "tf_longitudinal", "generate", "reward_trunk"]
     meta = {"transformers": transformers.__version__, "torch": torch.__version__,
             "adapter": "SURVEY.md A.3 (D1 legacy decoder.prepare_inputs_for_generation + D2 empty-cache prefill)",
-            "reference": "/root/reference (aehrc/cxrmate @ 2025-02-22)", "mode": "eval(), fp32, CPU"}
+            "reference": "/root/reference (aehrc/cxrmate @ 2025-02-22)", "mode": "eval(), fp32, CPU; tf_single_train: train() with the drawn dropout / DropPath masks recorded"}
     json.dump(meta, open(os.path.join(OUT, "META.json"), "w"), indent=1)
     for w in which:
         globals()["fixture_" + w]()

@@ -98,3 +98,30 @@ def reward_trunk_case():
     cfg = BertConfig(vocab_size=600, num_hidden_layers=2, is_decoder=False, add_cross_attention=False, cls_projection_size=128)
     sd = weights.init_reward(cfg, seed=int(g["seed"]), perturb=float(g["perturb"]))
     return g, cfg, sd, torch.from_numpy(g["ids"]), torch.from_numpy(g["attention_mask"])
+
+
+DEC_SITES = ("self_probs", "self_out", "cross_probs", "cross_out", "ffn_out")
+
+
+def tf_single_train_case():
+    """Train-mode pass of the reference: same inputs as tf_single (different weight seed) + the dropout / DropPath masks it drew.
+    -> g, cfg, sd, x, inp, lab, am, tt, dropout {site: factor}, drop_path {(stage, layer): (f_attn, f_mlp)}"""
+    g = load("tf_single_train.npz")
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, image_size=96)
+    sd = weights.init_encoder_decoder(cfg, seed=int(g["seed"]), perturb=float(g["perturb"]))
+    gen = torch.Generator().manual_seed(int(g["pixel_seed"]))
+    x = torch.randn(3, 3, 96, 96, generator=gen)
+    full = torch.from_numpy(g["full_ids"])
+    attn = (full != PAD).long()
+    dropout = {}
+    for i in range(int(g["n_dropout"])):
+        shape = tuple(int(v) for v in g[f"drop{i}_shape"])
+        n = int(np.prod(shape))
+        keep = torch.from_numpy(np.unpackbits(g[f"drop{i}_keep"])[:n].astype(np.float32)).view(shape)
+        site = "embed" if i == 0 else ((i - 1) // 5, DEC_SITES[(i - 1) % 5])
+        dropout[site] = keep / (1.0 - float(g[f"drop{i}_p"]))
+    paths = {}
+    for i in range(0, int(g["n_droppath"]), 2):
+        name = str(g[f"path{i}_name"]).split(".")                       # encoder.cvt.encoder.stages.S.layers.L.drop_path
+        paths[(int(name[4]), int(name[6]))] = (torch.from_numpy(g[f"path{i}_factor"]), torch.from_numpy(g[f"path{i + 1}_factor"]))
+    return g, cfg, sd, x, full[:, :-1], full[:, 1:].clone(), attn[:, 1:], torch.from_numpy(g["token_type_ids"]), dropout, paths

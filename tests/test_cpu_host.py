@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     # every entry point returns int and takes only C scalars / pointers (no torch types cross the ABI)
     import ctypes
     for name, args in protos.items():
-        assert all(t in (ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float) for t, _ in args), name
+        assert all(t in (ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_uint, ctypes.c_float) for t, _ in args), name
 
 
 def test_product_fails_loudly_without_library(monkeypatch):

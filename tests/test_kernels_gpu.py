@@ -129,7 +129,7 @@ def test_gemm_tn_exact_integers(ops):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def ref_attention(q, k, v, heads, scale, kpm=None, causal=False, shift=0):
+def ref_attention(q, k, v, heads, scale, kpm=None, causal=False, shift=0, drop=None):
     B, Tq, D = q.shape
     Tk = k.shape[1]
     qh = q.float().view(B, Tq, heads, 64).transpose(1, 2)
@@ -145,6 +145,8 @@ def ref_attention(q, k, v, heads, scale, kpm=None, causal=False, shift=0):
         s = s.masked_fill((j > i + shift).view(1, 1, Tq, Tk), neg)
     p = torch.softmax(s, -1)
     lse = torch.logsumexp(s, -1)
+    if drop is not None:
+        p = p * drop                       # nn.functional.dropout on the probabilities, factor = keep/(1-p) given as data
     return (p @ vh).transpose(1, 2).reshape(B, Tq, D), lse
 
 
@@ -216,6 +218,68 @@ def test_attention_bwd(ops, B, H, Tq, Tk, causal, masked):
     close(dq, qr.grad, rtol=3e-2, atol=3e-2, what="dq")
     close(dk, kr.grad, rtol=3e-2, atol=3e-2, what="dk")
     close(dv, vr.grad, rtol=3e-2, atol=3e-2, what="dv")
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,causal,masked", [(2, 12, 40, 40, True, True), (2, 12, 256, 256, True, False), (2, 12, 70, 1152, False, True),
+                                                     (1, 3, 200, 77, False, False)])
+def test_attention_dropout_fwd_bwd(ops, B, H, Tq, Tk, causal, masked):
+    """Train-mode dropout on the probabilities: forward and both backward kernels regenerate the SAME counter-based mask that
+    cxr_dropout_mask materialises (rows = (b*H+h, query), cols = key), and match autograd of softmax -> mask/(1-p) -> .V"""
+    D = H * 64
+    q, k, v = dev(rnd(B, Tq, D).to(BF)), dev(rnd(B, Tk, D, seed=1).to(BF)), dev(rnd(B, Tk, D, seed=2).to(BF))
+    do = dev(rnd(B, Tq, D, seed=3).to(BF))
+    kpm = None
+    if masked:
+        kpm = torch.ones(B, Tk, dtype=torch.uint8)
+        kpm[0, Tk // 2:] = 0
+        kpm = kpm.cuda()
+    seed = torch.full((1,), 123457, dtype=torch.int32, device="cuda")
+    pdrop, site, t0 = 0.1, 18, 5
+    drop = (pdrop, seed, site, t0)
+    out, lse = ops.attention(q, k, v, H, 0.125, kpm=kpm, causal=causal, need_lse=True, drop=drop)
+    fac = ops.dropout_mask(B * H * Tq, Tk, pdrop, seed, site, Tq, t0, factor=True).view(B, H, Tq, Tk)
+    keep_rate = (fac > 0).float().mean().item()
+    assert abs(keep_rate - 0.9) < 4 * math.sqrt(0.09 / fac.numel()) + 1e-4, keep_rate
+    assert torch.all((fac == 0) | ((fac - 1 / 0.9).abs() < 1e-6))
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref, ref_lse = ref_attention(qr, kr, vr, H, 0.125, kpm, causal, Tk - Tq, drop=fac)
+    close(out, ref, what="attn dropout out")
+    close(lse, ref_lse, rtol=1e-3, atol=1e-3, what="lse is dropout-free")
+    dq, dk, dv = ops.attention_bwd(q, k, v, out, do, lse, H, 0.125, kpm=kpm, causal=causal, drop=drop)
+    ref.backward(do.float())
+    close(dq, qr.grad, rtol=3e-2, atol=3e-2, what="dq (dropout)")
+    close(dk, kr.grad, rtol=3e-2, atol=3e-2, what="dk (dropout)")
+    close(dv, vr.grad, rtol=3e-2, atol=3e-2, what="dv (dropout)")
+    # another seed / site / position offset gives another mask; p = 0 is the plain kernel
+    other = ops.dropout_mask(B * H * Tq, Tk, pdrop, seed, site + 1, Tq, t0).view(-1)
+    same = (other == (fac.view(-1) > 0).to(torch.uint8)).float().mean().item()
+    assert abs(same - 0.82) < 0.02, same                  # independent masks agree on 0.9^2 + 0.1^2 of the elements
+    plain, _ = ops.attention(q, k, v, H, 0.125, kpm=kpm, causal=causal)
+    off, _ = ops.attention(q, k, v, H, 0.125, kpm=kpm, causal=causal, drop=(0.0, None, 0, 0))
+    assert torch.equal(plain, off)
+
+
+def test_dropout_add_and_droppath(ops):
+    R, C, T = 96, 768, 24
+    y, res = dev(rnd(R, C).to(BF)), dev(rnd(R, C, seed=1).to(BF))
+    seed = torch.full((1,), 99, dtype=torch.int32, device="cuda")
+    fac = ops.dropout_mask(R, C, 0.1, seed, 33, T, factor=True)
+    out = ops.dropout_add(y, res, 0.1, seed, 33, T)
+    close(out, res.float() + fac * y.float(), rtol=1e-2, atol=2e-2, what="dropout_add")
+    back = ops.dropout_add(y, None, 0.1, seed, 33, T)
+    close(back, fac * y.float(), rtol=1e-2, atol=2e-2, what="dropout backward")
+    assert abs((fac > 0).float().mean().item() - 0.9) < 0.01
+    # the mask of position t of sequence b does not depend on how rows are batched: a [B,1] decode step at t0 = t sees row (b, t) of the [B,T] pass
+    step = ops.dropout_mask(R // T, C, 0.1, seed, 33, 1, 7)
+    full = ops.dropout_mask(R, C, 0.1, seed, 33, T).view(R // T, T, C)
+    assert torch.equal(step, full[:, 7, :])
+    # DropPath: per-image scale
+    scale = torch.tensor([1 / 0.9, 0.0, 1 / 0.9, 1 / 0.9], device="cuda")
+    out = ops.dropout_add(y, res, 0.0, None, 0, T, row_scale=scale)
+    close(out, res.float() + scale.repeat_interleave(T)[:, None] * y.float(), rtol=1e-2, atol=2e-2, what="droppath")
+    inplace = y.clone()
+    ops.dropout_add(inplace, None, 0.0, None, 0, T, row_scale=scale, out=inplace)
+    close(inplace, scale.repeat_interleave(T)[:, None] * y.float(), rtol=1e-2, atol=2e-2, what="droppath in place")
 
 
 @pytest.mark.parametrize("M,N,K", [(16, 768, 768), (1, 768, 768), (16, 3072, 768), (16, 768, 3072), (32, 30000, 768), (50, 768, 768), (64, 2304, 768)])
@@ -341,6 +405,58 @@ def test_dwconv_bn_fwd_bwd(ops, C, H, tok0):
         close(dw.view(C, 1, 3, 3), leaves[n]["w"].grad, what=f"dwconv dW {n}")
         close(dg, leaves[n]["g"].grad, what=f"bn dgamma {n}")
         close(db, leaves[n]["b"].grad, what=f"bn dbeta {n}")
+
+
+@pytest.mark.parametrize("C,H,tok0", [(64, 24, 0), (192, 12, 0), (384, 6, 1)])
+def test_dwconv_batchnorm_train_mode(ops, C, H, tok0):
+    """Batch-statistics BatchNorm (model.train()): statistics pass + finalize + folded conv == F.batch_norm(training=True), running
+    statistics moved like nn.BatchNorm2d(momentum=0.1), and the backward goes through the batch statistics."""
+    Bn, W = 3, H
+    x = dev((rnd(Bn, tok0 + H * W, C) + 0.3).to(BF))
+    for name, stride, seed in (("q", 1, 1), ("kv", 2, 2)):
+        n = 1 if name == "q" else 2
+        par = [dict(w=dev(rnd(C, 1, 3, 3, seed=seed + i, scale=0.3)), g=dev(1 + 0.1 * rnd(C, seed=seed + 10 + i)), b=dev(0.1 * rnd(C, seed=seed + 20 + i)),
+                    rm=dev(0.1 * rnd(C, seed=seed + 30 + i)), rv=dev(1 + 0.1 * rnd(C, seed=seed + 40 + i).abs())) for i in range(n)]
+        raws = [p["w"].view(C, 9).t().contiguous() for p in par]
+        stats = ops.dwconv_stats(x, H, W, stride, tok0, raws[0], raws[1] if n == 2 else None)
+        Ho = (H - 1) // stride + 1
+        count = Bn * Ho * Ho
+        xs = x[:, tok0:].float().transpose(1, 2).reshape(Bn, C, H, W).requires_grad_(True)
+        folds, kept, refs, leaves = [], [], [], []
+        for i, p in enumerate(par):
+            rm0, rv0 = p["rm"].clone(), p["rv"].clone()
+            fold, mean, rstd = ops.bn_train_finalize(stats[i], count, p["w"], p["g"], p["b"], 1e-5, 0.1, p["rm"], p["rv"])
+            lv = {k: p[k].clone().requires_grad_(True) for k in ("w", "g", "b")}
+            c = torch.nn.functional.conv2d(xs, lv["w"], None, stride=stride, padding=1, groups=C)
+            ref = torch.nn.functional.batch_norm(c, rm0, rv0, lv["g"], lv["b"], True, 0.1, 1e-5)
+            close(mean, c.detach().mean((0, 2, 3)), rtol=1e-3, atol=1e-3, what="batch mean")
+            close(rstd, (c.detach().var((0, 2, 3), unbiased=False) + 1e-5).rsqrt(), rtol=1e-3, atol=1e-3, what="batch rstd")
+            close(p["rm"], rm0, rtol=1e-4, atol=1e-4, what="running mean")           # F.batch_norm updated rm0/rv0 in place
+            close(p["rv"], rv0, rtol=1e-4, atol=1e-4, what="running var")
+            folds.append(fold); kept.append((mean, rstd)); refs.append(ref.flatten(2).transpose(1, 2)); leaves.append(lv)
+        ys = ops.dwconv_bn(x, H, W, stride, tok0, *folds)
+        for i in range(n):
+            close(ys[i][:, tok0:], refs[i], what=f"train-mode bn fwd {name}{i}")
+        dys = [dev(rnd(*ys[i].shape, seed=7 + i).to(BF)) for i in range(n)]
+        sum((refs[i] * dys[i][:, tok0:].float()).sum() for i in range(n)).backward()
+        projs = []
+        for i, p in enumerate(par):
+            dc = dys[i].clone()
+            G, S = ops.dwconv_bn_bwd_w(x, dc, H, W, stride, tok0)
+            dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+            coef = ops.bn_train_bwd_coef(p["w"], p["g"], kept[i][0], kept[i][1], G, S, count, dg, db)
+            ops.dwconv_bn_train_dc_(x, raws[i], coef, dc, H, W, stride, tok0)
+            if tok0:
+                assert torch.equal(dc[:, 0], dys[i][:, 0])                            # class-token rows bypass conv + BN
+            G2, _ = ops.dwconv_bn_bwd_w(x, dc, H, W, stride, tok0)
+            dw = torch.zeros(C, 9, device="cuda")
+            ops.tap_grad_accum(G2, dw)
+            close(dw.view(C, 1, 3, 3), leaves[i]["w"].grad, rtol=3e-2, atol=3e-2, what=f"train-mode dW {name}{i}")
+            close(dg, leaves[i]["g"].grad, what=f"train-mode dgamma {name}{i}")
+            close(db, leaves[i]["b"].grad, what=f"train-mode dbeta {name}{i}")
+            projs.append((dc, raws[i], stride))
+        dx = ops.dwconv_bn_bwd_dx(projs, Bn, C, H, W, tok0)
+        close(dx[:, tok0:], xs.grad.flatten(2).transpose(1, 2), rtol=3e-2, atol=3e-2, what=f"train-mode dx {name}")
 
 
 # ------------------------------------------------------------------------------------------------ embeddings / integer ops

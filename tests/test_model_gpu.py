@@ -96,6 +96,87 @@ def test_tf_single_logits_loss_grads(M):
     assert abs(l2.item() - loss.item()) < 1e-4
 
 
+def _hash_masks(m, cfg, B, T, S, enc_seed, dec_seed, Bn):
+    """The dropout / DropPath factors the kernels regenerate from their counter-based hash, materialised for the CPU oracle."""
+    from cxrmate_amd import ops
+    from cxrmate_amd.decoder import SITE_EMBED, _site
+    d, H, D = cfg.decoder, cfg.decoder.num_attention_heads, cfg.decoder.hidden_size
+    ph, pa = d.hidden_dropout_prob, d.attention_probs_dropout_prob
+    hid = lambda site: ops.dropout_mask(B * T, D, ph, dec_seed, site, T, factor=True).view(B, T, D).cpu()
+    prob = lambda site, Tk: ops.dropout_mask(B * H * T, Tk, pa, dec_seed, site, T, factor=True).view(B, H, T, Tk).cpu()
+    dropout = {"embed": hid(SITE_EMBED)}
+    for l in range(d.num_hidden_layers):
+        dropout[(l, "self_probs")], dropout[(l, "self_out")] = prob(_site(l, 0), T), hid(_site(l, 1))
+        dropout[(l, "cross_probs")], dropout[(l, "cross_out")] = prob(_site(l, 2), S), hid(_site(l, 3))
+        dropout[(l, "ffn_out")] = hid(_site(l, 4))
+    paths = {}
+    e = cfg.encoder
+    for s_ in range(len(e.depth)):
+        rate = m._enc._drop_path_rate(s_)
+        for l in range(e.depth[s_]):
+            if rate > 0:
+                gl = sum(e.depth[:s_]) + l
+                paths[(s_, l)] = tuple(ops.dropout_mask(Bn, 1, rate, enc_seed, 1000 + 2 * gl + j, 1, factor=True).view(Bn).cpu() for j in (0, 1))
+    return dropout, paths
+
+
+def test_tf_train_mode_matches_oracle_with_same_masks(M):
+    """model.train(): batch-statistics BatchNorm with running-stat updates, dropout (hidden + attention probabilities) and DropPath.
+    The oracle -- pinned against the reference's own train-mode pass in tests/test_oracle_golden.py -- gets the masks the kernels hash."""
+    from oracle import bert as obert, cvt as ocvt, generate as ogen
+    g, cfg, sd, x, inp, lab, am, tt, _, _ = gu.tf_single_train_case()
+    m = M.SingleCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    assert not m.training                                                  # constructed like from_pretrained(): eval
+    m.train()
+    torch.manual_seed(11)
+    tt_dev = m.token_ids_to_token_type_ids(inp, [gu.SEP])
+    out = m(pixel_values=x.cuda(), decoder_input_ids=inp.cuda(), decoder_attention_mask=am.cuda(), decoder_token_type_ids=tt_dev, return_dict=True)
+    logits = out.logits
+    loss = torch.nn.functional.cross_entropy(logits.permute(0, 2, 1), lab.cuda(), ignore_index=gu.PAD)
+    loss.backward()
+    torch.manual_seed(11)                                                  # the two seeds the pass drew from torch's CPU generator
+    enc_seed = torch.full((1,), int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), dtype=torch.int32, device="cuda")
+    dec_seed = torch.full((1,), int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), dtype=torch.int32, device="cuda")
+    B, T = inp.shape
+    S = cfg.encoder.tokens_per_image
+    dropout, paths = _hash_masks(m, cfg, B, T, S, enc_seed, dec_seed, x.shape[0])
+    assert len(paths) == cfg.encoder.depth[2] and abs(m._enc._drop_path_rate(2) - 0.1) < 1e-6       # linspace(0, .1, 3)[2] (quirk Q2)
+    names = [str(n) for n in g["grad_names"]]
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    leaves = {n: sd2[n].requires_grad_(True) for n in names}
+    h, _ = ocvt.encoder_forward(x, sd2, cfg.encoder, bn_train=True, bn_momentum=cfg.encoder.bn_momentum, drop_path=paths)
+    ref = obert.decoder_forward(inp, sd2, cfg.decoder, h, None, am, tt, None, dropout=dropout)
+    rloss = ogen.tf_cross_entropy(ref, lab, gu.PAD)
+    rloss.backward()
+    check_act(logits.detach().float().cpu().numpy(), ref.detach().numpy(), "train-mode logits")
+    assert abs(loss.item() - rloss.item()) < 2e-2
+    grads = _grads_by_name(m, names)
+    for n in names:
+        rn = leaves[n].grad.norm().item()
+        if rn < 1e-7:
+            # structurally zero: BatchNorm over batch statistics after a DEPTHWISE conv cancels any per-channel rescaling of the conv input,
+            # so the weight of the LayerNorm feeding q/k/v gets no gradient in train mode (fp32 reference: 6e-9)
+            assert grads[n].norm().item() < 1e-6, n
+            continue
+        r = gu.rel_rms(grads[n].numpy(), leaves[n].grad.numpy())
+        assert r < GRAD_RMS, f"{n}: rel_rms {r:.4f}"
+    got = m.state_dict()
+    for i in range(3):
+        key = str(g[f"bn{i}_key"])
+        np.testing.assert_allclose(got[key + "running_mean"].cpu().numpy(), sd2[key + "running_mean"].numpy(), rtol=2e-2, atol=2e-3)
+        np.testing.assert_allclose(got[key + "running_var"].cpu().numpy(), sd2[key + "running_var"].numpy(), rtol=2e-2, atol=2e-3)
+        assert int(got[key + "num_batches_tracked"]) == 1
+    # eval() afterwards: deterministic, uses the MOVED running statistics
+    m.eval()
+    with torch.no_grad():
+        e1 = m.encoder(x.cuda()).last_hidden_state.float().cpu()
+        e2 = m.encoder(x.cuda()).last_hidden_state.float().cpu()
+        href, _ = ocvt.encoder_forward(x, {k: v.detach() for k, v in sd2.items()}, cfg.encoder)
+    assert torch.equal(e1, e2)
+    check_act(e1.numpy(), href.numpy(), "eval after train-mode step")
+
+
 def test_tf_longitudinal_lora_prompt(M):
     g, cfg, sd, x, prompt, inp, lab, am, tt, pos = gu.tf_longitudinal_case()
     m = M.LongitudinalPromptMultiCXREncoderDecoderModel(cfg, seed=None)
@@ -242,6 +323,43 @@ def test_prompted_generate_and_scst_scores(M):
     both = torch.isfinite(onll) & (seqs[:, P:] != gu.PAD)
     assert both.float().mean() > 0.8
     np.testing.assert_allclose(nll.detach().cpu()[both].numpy(), onll[both].numpy(), atol=0.08)
+
+
+def test_train_mode_cached_decode_equals_teacher_forcing_with_same_seed(M):
+    """Under model.train() (how the reference runs its SCST decodes) every cached step applies dropout keyed by
+    (seed, site, sequence, ABSOLUTE position): a teacher-forced pass with the same seed reproduces the step logits (that is what makes
+    sample-then-rescore equal to keeping the autograd graph of the sampling loop); another seed does not."""
+    g, cfg, sd, x, prompt = gu.generate_longitudinal_case()
+    m = M.LongitudinalPromptMultiCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    m.train()
+    dev = m.device
+    ref = torch.from_numpy(g["greedy"]).cuda()                                  # any fixed token sequence [B, P + new]
+    B, L = ref.shape
+    P = prompt.shape[1]
+    special = [gu.PMT_SEP, gu.BOS, gu.SEP]
+    with torch.no_grad():
+        eo = m.encoder(x.cuda())
+        enc16, emask8 = eo.last_hidden_state.contiguous(), eo.attention_mask.to(torch.uint8).contiguous()
+        seed = torch.full((1,), 4242, dtype=torch.int32, device=dev)
+        cache = m._dec.new_cache(B, L, dev)
+        step_logits = []
+        for cur in range(P, L):                                                 # prefill on the prompt, then one token at a time
+            fed = ref[:, :cur]
+            new, mask, tt, pos = m._step_inputs(fed, special, gu.PAD, prefill=cache.len == 0)
+            step_logits.append(m._dec.decode(cache, new.contiguous(), enc16, emask8, mask, tt.contiguous(), pos.contiguous(), seed=seed).float().cpu())
+        tf_in = ref[:, :L - 1].contiguous()
+        mask, pos = __import__("cxrmate_amd.ops", fromlist=["x"]).mask_position_ids(tf_in, gu.PAD)
+        tt = m.token_ids_to_token_type_ids(tf_in, special, [0, 1, 0, 1])
+        same, _ = m._dec.forward(tf_in, enc16, emask8, mask, tt, pos, seed=seed)
+        other, _ = m._dec.forward(tf_in, enc16, emask8, mask, tt, pos, seed=seed + 1)
+        m.eval()
+        plain, _ = m._dec.forward(tf_in, enc16, emask8, mask, tt, pos)
+    steps = torch.stack(step_logits, 1).numpy()                                 # [B, L-P, V]: logits after feeding positions P-1 .. L-2
+    same, other, plain = (t[:, P - 1:].float().cpu().numpy() for t in (same, other, plain))
+    r_same, r_other, r_plain = gu.rel_rms(steps, same), gu.rel_rms(steps, other), gu.rel_rms(steps, plain)
+    assert r_same < ACT_RMS, r_same
+    assert r_other > 4 * r_same and r_plain > 4 * r_same, (r_same, r_other, r_plain)
 
 
 def test_reference_sampled_sequence_scores_fixture(M):

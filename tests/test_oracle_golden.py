@@ -76,6 +76,31 @@ def test_tf_single_logits_loss_grads():
         np.testing.assert_allclose(gu.stats(gr)[3], g[f"grad{i}_stats"][3], rtol=2e-3, err_msg=n)
 
 
+def test_tf_single_train_mode_with_recorded_masks():
+    """model.train(): batch-statistics BatchNorm (+ running statistics), dropout on hidden states / attention probabilities, DropPath.
+    The reference's drawn masks are inputs of the oracle, so the whole stochastic pass is pinned: logits, loss, gradients, running stats."""
+    g, cfg, sd, x, inp, lab, am, tt, dropout, paths = gu.tf_single_train_case()
+    assert any(bool((f == 0).any()) for pair in paths.values() for f in pair)          # a residual branch really was dropped
+    names = [str(n) for n in g["grad_names"]]
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    leaves = {n: sd2[n].requires_grad_(True) for n in names}
+    h, _ = ocvt.encoder_forward(x, sd2, cfg.encoder, bn_train=True, bn_momentum=cfg.encoder.bn_momentum, drop_path=paths)
+    logits = obert.decoder_forward(inp, sd2, cfg.decoder, h, None, am, tt, None, dropout=dropout)
+    loss = ogen.tf_cross_entropy(logits, lab, gu.PAD)
+    assert gu.rel_rms(gu.sample(logits, 16384), g["logits_sample"]) < FP32_TOL
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    loss.backward()
+    for i, n in enumerate(names):
+        assert gu.rel_rms(gu.sample(leaves[n].grad, 2048), g[f"grad{i}_sample"]) < 2e-3, n
+    for i in range(3):
+        key = str(g[f"bn{i}_key"])
+        np.testing.assert_allclose(sd2[key + "running_mean"].numpy(), g[f"bn{i}_running_mean"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(sd2[key + "running_var"].numpy(), g[f"bn{i}_running_var"], rtol=1e-4, atol=1e-6)
+        assert int(sd2[key + "num_batches_tracked"]) == int(g[f"bn{i}_num_batches_tracked"]) == 1
+    # the DropPath rate every stage-3 layer uses is linspace(0, 0.1, depth)[stage] (quirk Q2), recorded by the reference's modules
+    assert abs(float(g["path0_p"]) - float(torch.linspace(0, 0.1, cfg.encoder.depth[2])[2])) < 1e-7
+
+
 def test_tf_longitudinal_lora_prompt():
     g, cfg, sd, x, prompt, inp, lab, am, tt, pos = gu.tf_longitudinal_case()
     assert np.array_equal(token_ops.token_ids_to_token_type_ids(inp.numpy(), [gu.PMT_SEP, gu.BOS, gu.SEP], [0, 1, 0, 1]), g["token_type_ids"])
