@@ -150,6 +150,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnBwdArgs a)
                 const float4 L4 = *reinterpret_cast<const float4*>(&Ls[qb4]);
                 const float4 E4 = *reinterpret_cast<const float4*>(&Es[qb4]);
                 const float Lq[4] = {L4.x, L4.y, L4.z, L4.w}, Eq[4] = {E4.x, E4.y, E4.z, E4.w};
+                float fdrop[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+                if (a.drop_thr16) {
+                    // one hash serves the key pair (key, key^1) = lanes (l, l^1): each lane hashes the queries of its own parity and takes
+                    // the others from its neighbour (one DPP exchange instead of a second hash)
+                    const int par = key & 1;
+#pragma unroll
+                    for (int j0 = 0; j0 < 4; j0 += 2) {
+                        const uint32_t mine = dropout_pair_bits(Rk[qb4 + j0 + par], (uint32_t)key >> 1);
+                        const uint32_t other = (uint32_t)__shfl_xor((int)mine, 1, 64);
+                        const uint32_t b0 = par ? other : mine, b1 = par ? mine : other;            // bits of queries j0, j0 + 1
+                        fdrop[j0] = (par ? (b0 >> 16) : (b0 & 0xffffu)) >= a.drop_thr16 ? a.drop_inv : 0.f;
+                        fdrop[j0 + 1] = (par ? (b1 >> 16) : (b1 & 0xffffu)) >= a.drop_thr16 ? a.drop_inv : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = 4 * g4 + j;
@@ -159,11 +173,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnBwdArgs a)
                         if (a.causal) ok = ok && (key <= tile * 64 + qb4 + j + a.causal_shift);
                         p = ok ? p : 0.f;
                     }
-                    float f = 1.0f;
-                    if (a.drop_thr16) {
-                        const uint32_t bits = dropout_pair_bits(Rk[qb4 + j], (uint32_t)key >> 1);
-                        f = ((key & 1) ? (bits >> 16) : (bits & 0xffffu)) >= a.drop_thr16 ? a.drop_inv : 0.f;
-                    }
+                    const float f = fdrop[j];
                     S[r] = p * f;                                  // dropped probabilities feed dV
                     dP[r] = p * (f * dP[r] - Eq[j]);               // the softmax scale is applied once to the dK accumulators
                 }

@@ -294,9 +294,42 @@ extern "C" int cxr_dwconv_bn_bwd_dx_bf16(const void* dy0, const float* wf0, long
     return CXR_OK;
 }
 
-// Backward, tap sums: G[tap][c] += sum_{b,oy,ox} dy[b,(oy,ox),c] * x[b,(iy,ix),c],  S[c] += sum dy.   (fp32 atomics, per-block pre-reduced)
+// out[k] = sum_g ws[g][k]: second stage of the per-channel reductions below. Workgroups write one partial row each and this kernel adds the
+// rows -- same-address fp32 atomics from ~1000 workgroups serialise at ~30 ns each and were the whole cost of those kernels.
+__global__ __launch_bounds__(1024) void partial_rows_sum_kernel(const float* __restrict__ ws, int G, int K, float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 columns x 16 row lanes: <= 64 rows per thread, 8 loads in flight
+    const int k = blockIdx.x * 64 + tx;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (k < K) {
+        int g = ty;
+        for (; g + 7 * 16 < G; g += 8 * 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += ws[(long)(g + 16 * u) * K + k];
+        }
+        for (; g < G; g += 16) acc[0] += ws[(long)g * K + k];
+    }
+    red[ty][tx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (ty == 0 && k < K) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[q][tx];
+        out[k] = s;
+    }
+}
+
+static inline int dw_partial_rows(long npix, int npl) {       // workgroups of a per-channel reduction pass: 256..1024, >= 4 pixels per lane
+    long g = npix / (4L * npl);
+    g = g < 256 ? 256 : (g > 1024 ? 1024 : g);
+    const long cap = (npix + npl - 1) / npl;                 // at least one pixel per lane group
+    return (int)(g < cap ? g : cap);
+}
+
+// Backward, tap sums: G[tap][c] = sum_{b,oy,ox} dy[b,(oy,ox),c] * x[b,(iy,ix),c],  S[c] = sum dy.  Each workgroup writes its partial
+// [10][C] row (taps 0-8, then S) to `ws`; partial_rows_sum_kernel adds the rows (deterministic, no atomics).
 __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const bf16_t* __restrict__ x, long x_bs, long x_rs, const bf16_t* __restrict__ dy,
-                                                           long dy_bs, long dy_rs, float* __restrict__ G, float* __restrict__ S,
+                                                           long dy_bs, long dy_rs, float* __restrict__ ws,
                                                            int Bn, int C, int H, int W, int stride, int Ho, int Wo, int tok0, int pix_per_block) {
     // block = (C/8 channel chunks) x (256/(C/8) pixel lanes); each thread keeps 10x8 partial sums
     const int cch = C / 8;
@@ -349,26 +382,28 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const bf16_t* __restr
             const int t = i / C, c = i % C;
             float sum = 0.f;
             for (int q = 0; q < npl; ++q) sum += red[(t * npl + q) * C + c];
-            const int tap = 5 * tg + t;
-            if (tap < 9) atomicAdd(G + tap * C + c, sum);
-            else atomicAdd(S + c, sum);
+            ws[(long)blockIdx.x * 10 * C + (5 * tg + t) * C + c] = sum;
         }
         __syncthreads();
     }
 }
 
-extern "C" int cxr_dwconv_bn_bwd_w_bf16(const void* x, long x_bs, long x_rs, const void* dy, long dy_bs, long dy_rs, float* G, float* S,
+// GS [10][C] (rows 0-8 = G, row 9 = S) is OVERWRITTEN; ws = scratch of cxr_dwconv_ws_floats(C) fp32 elements.
+extern "C" int cxr_dwconv_bn_bwd_w_bf16(const void* x, long x_bs, long x_rs, const void* dy, long dy_bs, long dy_rs, float* GS, float* ws,
                                         int Bn, int C, int H, int W, int stride, int tok0, hipStream_t stream) {
-    if (Bn <= 0 || (C % 8) || C > 384 || (256 % (C / 8) != 0 && C / 8 > 256)) return CXR_ERR_ARG;
+    if (Bn <= 0 || (C % 8) || C > 384 || (256 % (C / 8) != 0 && C / 8 > 256) || !ws) return CXR_ERR_ARG;
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const long npix = (long)Bn * Ho * Wo;
-    int ppb = (int)cdiv(npix, 1024);
-    if (ppb < 32) ppb = 32;
-    CXR_LAUNCH(dwconv_bwd_w_kernel, dim3(cdiv(npix, ppb)), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, (const bf16_t*)dy, dy_bs,
-                       dy_rs, G, S, Bn, C, H, W, stride, Ho, Wo, tok0, ppb);
+    const int rows = dw_partial_rows(npix, 256 / (C / 8));
+    const int ppb = (int)cdiv(npix, rows), grid = cdiv(npix, ppb);
+    CXR_LAUNCH(dwconv_bwd_w_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, (const bf16_t*)dy, dy_bs,
+                       dy_rs, ws, Bn, C, H, W, stride, Ho, Wo, tok0, ppb);
+    CXR_LAUNCH(partial_rows_sum_kernel, dim3(cdiv(10 * C, 64)), dim3(1024), 0, stream, ws, grid, 10 * C, GS);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
+
+extern "C" int cxr_dwconv_ws_floats(int C) { return 1024 * 10 * C; }     // scratch elements of the per-channel reduction passes
 
 // ---------------------------------------------------------------------------------------------- train-mode BatchNorm (batch statistics)
 // nn.BatchNorm2d in training mode (TF5 modeling_cvt.py:93-110 under model.train(); SURVEY.md quirk Q7: the "frozen" encoder of the SCST
@@ -376,9 +411,12 @@ extern "C" int cxr_dwconv_bn_bwd_w_bf16(const void* x, long x_bs, long x_rs, con
 // statistics over all Bn*Ho*Wo positions of the launch; running stats move by `momentum` with the UNBIASED variance.
 // Forward = statistics pass (below: one read of the activation, conv outputs are not written) + finalize (stats -> folded taps) + the
 // ordinary folded dwconv_fwd_kernel. Cheaper than materialising c: R + (R+W) instead of (R+W) + (R+W).
-template <int NOUT>
+// WITH_DY = false: stats = (sum c, sum c^2)   -- forward statistics
+// WITH_DY = true : stats = (sum dy, sum dy*c)  -- the two reductions the backward through the batch statistics needs (c recomputed on the fly)
+template <int NOUT, bool WITH_DY>
 __global__ __launch_bounds__(256) void dwconv_stats_kernel(const bf16_t* __restrict__ x, long x_bs, long x_rs, const float* __restrict__ w0 /*[9][C] raw*/,
-                                                           const float* __restrict__ w1, float* __restrict__ stats /*[NOUT][2][C]: sum, sum of squares*/,
+                                                           const float* __restrict__ w1, const bf16_t* __restrict__ dy0, const bf16_t* __restrict__ dy1,
+                                                           long dy_bs, long dy_rs, float* __restrict__ ws /*[grid][NOUT][2][C] partial rows*/,
                                                            int Bn, int C, int H, int W, int stride, int Ho, int Wo, int tok0, int pix_per_block) {
     const int cch = C / 8;
     const int cl = threadIdx.x % cch, pl = threadIdx.x / cch, npl = 256 / cch;
@@ -418,10 +456,20 @@ __global__ __launch_bounds__(256) void dwconv_stats_kernel(const bf16_t* __restr
                     }
                 }
             }
+            if (WITH_DY) {
 #pragma unroll
-            for (int q = 0; q < NOUT; ++q)
+                for (int q = 0; q < NOUT; ++q) {
+                    float d[8];
+                    unpack8(*reinterpret_cast<const uint4*>((q == 0 ? dy0 : dy1) + (long)b * dy_bs + (long)(tok0 + oy * Wo + ox) * dy_rs + c8), d);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { sm[q][j] += a[q][j]; sq[q][j] += a[q][j] * a[q][j]; }
+                    for (int j = 0; j < 8; ++j) { sm[q][j] += d[j]; sq[q][j] += d[j] * a[q][j]; }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NOUT; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { sm[q][j] += a[q][j]; sq[q][j] += a[q][j] * a[q][j]; }
+            }
         }
     }
     __shared__ __attribute__((aligned(16))) float red[4 * 2048];            // [NOUT*2][npl][C], npl*C <= 2048 for C in {64,192,384}
@@ -439,22 +487,31 @@ __global__ __launch_bounds__(256) void dwconv_stats_kernel(const bf16_t* __restr
         const int k = i / C, c = i % C;
         float sum = 0.f;
         for (int q = 0; q < npl; ++q) sum += red[(k * npl + q) * C + c];
-        atomicAdd(stats + i, sum);
+        ws[(long)blockIdx.x * NOUT * 2 * C + i] = sum;
     }
 }
 
-// stats (zero-initialised by the caller) <- sum / sum of squares of the raw depthwise conv outputs of one (w1 == NULL) or two projections
-extern "C" int cxr_dwconv_stats_bf16(const void* x, long x_bs, long x_rs, const float* w0, const float* w1, float* stats, int Bn, int C,
-                                     int H, int W, int stride, int tok0, hipStream_t stream) {
-    if (Bn <= 0 || (C % 8) || C > 384 || (256 / (C / 8)) * C > 2048 || (stride != 1 && stride != 2)) return CXR_ERR_ARG;
+// stats [nproj][2][C] (overwritten) <- per-channel reductions over the raw depthwise conv outputs c of one (w1 == NULL) or two
+// projections: (sum c, sum c^2) when dy0 == NULL (forward), (sum dy, sum dy*c) otherwise (backward; dy1 pairs with w1, same strides).
+// ws = scratch of cxr_dwconv_ws_floats(C) fp32 elements.
+extern "C" int cxr_dwconv_stats_bf16(const void* x, long x_bs, long x_rs, const float* w0, const float* w1, const void* dy0, const void* dy1,
+                                     long dy_bs, long dy_rs, float* stats, float* ws, int Bn, int C, int H, int W, int stride, int tok0,
+                                     hipStream_t stream) {
+    if (Bn <= 0 || (C % 8) || C > 384 || (256 / (C / 8)) * C > 2048 || (stride != 1 && stride != 2) || !ws) return CXR_ERR_ARG;
+    if ((w1 != nullptr) != (dy1 != nullptr) && dy0) return CXR_ERR_ARG;
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const long npix = (long)Bn * Ho * Wo;
-    int ppb = (int)cdiv(npix, 2048);
-    if (ppb < 32) ppb = 32;
-    if (w1) CXR_LAUNCH((dwconv_stats_kernel<2>), dim3(cdiv(npix, ppb)), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, w0, w1, stats, Bn, C,
-                               H, W, stride, Ho, Wo, tok0, ppb);
-    else    CXR_LAUNCH((dwconv_stats_kernel<1>), dim3(cdiv(npix, ppb)), dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, w0, w0, stats, Bn, C,
-                               H, W, stride, Ho, Wo, tok0, ppb);
+    const int rows = dw_partial_rows(npix, 256 / (C / 8));
+    const int ppb = (int)cdiv(npix, rows);
+    const int nblk = cdiv(npix, ppb);
+    const dim3 grid(nblk);
+#define STATS(N_, D_) CXR_LAUNCH((dwconv_stats_kernel<N_, D_>), grid, dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, w0, w1 ? w1 : w0,        \
+                                 (const bf16_t*)dy0, (const bf16_t*)(dy1 ? dy1 : dy0), dy_bs, dy_rs, ws, Bn, C, H, W, stride, Ho, Wo, tok0, ppb)
+    if (dy0) { if (w1) STATS(2, true); else STATS(1, true); }
+    else     { if (w1) STATS(2, false); else STATS(1, false); }
+#undef STATS
+    const int K = (w1 ? 2 : 1) * 2 * C;
+    CXR_LAUNCH(partial_rows_sum_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, stream, ws, nblk, K, stats);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -492,28 +549,25 @@ extern "C" int cxr_bn_train_finalize(const float* stats, long count, const float
 
 // Backward through the batch statistics. With dy = grad wrt the BN output, x^ = (c - mean)*rstd, M positions:
 //   dgamma = sum dy*x^,  dbeta = sum dy,  dc = gamma*rstd*(dy - dbeta/M - x^ * dgamma/M)  =  a*dy + kb + kc*c
-// sum dy and sum dy*c come from the tap sums of dwconv_bwd_w_kernel on dy:  S = sum dy,  sum dy*c = sum_t w[c][t]*G[t][c].
-__global__ void bn_train_bwd_coef_kernel(const float* __restrict__ w, const float* __restrict__ g, const float* __restrict__ mean,
-                                         const float* __restrict__ rstd, const float* __restrict__ G, const float* __restrict__ S, float count,
-                                         float* __restrict__ dg, float* __restrict__ db, float* __restrict__ coef /*[3][C]: a, kb, kc*/, int C) {
+// SD = (sum dy, sum dy*c) per channel from cxr_dwconv_stats_bf16 with dy.
+__global__ void bn_train_bwd_coef_kernel(const float* __restrict__ g, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                         const float* __restrict__ SD /*[2][C]*/, float count, float* __restrict__ dg, float* __restrict__ db,
+                                         float* __restrict__ coef /*[3][C]: a, kb, kc*/, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float dot = 0.f;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) dot += w[c * 9 + t] * G[t * C + c];
-    const float r = rstd[c], mu = mean[c];
-    const float dgam = r * (dot - mu * S[c]);
+    const float r = rstd[c], mu = mean[c], S = SD[c];
+    const float dgam = r * (SD[C + c] - mu * S);
     dg[c] += dgam;
-    db[c] += S[c];
-    const float a = g[c] * r, m1 = S[c] / count, m2 = dgam / count;
+    db[c] += S;
+    const float a = g[c] * r, m1 = S / count, m2 = dgam / count;
     const float kc = -a * m2 * r;
     coef[c] = a; coef[C + c] = -a * m1 - kc * mu; coef[2 * C + c] = kc;
 }
 
-extern "C" int cxr_bn_train_bwd_coef(const float* w, const float* g, const float* mean, const float* rstd, const float* G, const float* S,
-                                     long count, float* dg, float* db, float* coef, int C, hipStream_t stream) {
+extern "C" int cxr_bn_train_bwd_coef(const float* g, const float* mean, const float* rstd, const float* SD, long count, float* dg, float* db,
+                                     float* coef, int C, hipStream_t stream) {
     if (count <= 0 || C <= 0) return CXR_ERR_ARG;
-    CXR_LAUNCH(bn_train_bwd_coef_kernel, dim3(cdiv(C, 128)), dim3(128), 0, stream, w, g, mean, rstd, G, S, (float)count, dg, db, coef, C);
+    CXR_LAUNCH(bn_train_bwd_coef_kernel, dim3(cdiv(C, 128)), dim3(128), 0, stream, g, mean, rstd, SD, (float)count, dg, db, coef, C);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

@@ -77,12 +77,12 @@ class CvtEncoderEngine:
             hit = self._fold_cache[key] = w.view(w.shape[0], 9).t().contiguous()
         return hit
 
-    def _fold_train(self, h1, H, W, stride, tok0, s, l, names):
+    def _fold_train(self, h1, H, W, stride, tok0, s, l, names, out=None):
         """Train-mode BatchNorm of one (query) or two (key, value) depthwise projections of h1: batch statistics in one pass over h1,
         running statistics moved in place. -> folds for dwconv_fwd, {name: (mean, rstd, count)} for backward."""
         cfg, st = self.cfg, self.s
         raws = [self._raw_taps(s, l, n) for n in names]
-        stats = ops.dwconv_stats(h1, H, W, stride, tok0, raws[0], raws[1] if len(raws) > 1 else None)
+        stats = ops.dwconv_stats(h1, H, W, stride, tok0, raws[0], raws[1] if len(raws) > 1 else None, out=out)
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         count = h1.shape[0] * Ho * Wo
         folds, kept = [], {}
@@ -210,8 +210,9 @@ class CvtEncoderEngine:
         h1 = h1.view(Bn, L, C)
         bn = None
         if self._train:
-            (fq,), bn = self._fold_train(h1, H, W, cfg.stride_q[s], tok0, s, l, ("query",))
-            (fk, fv), bkv = self._fold_train(h1, H, W, cfg.stride_kv[s], tok0, s, l, ("key", "value"))
+            arena = torch.empty((3, 2, C), dtype=torch.float32, device=x.device)
+            (fq,), bn = self._fold_train(h1, H, W, cfg.stride_q[s], tok0, s, l, ("query",), out=arena[0:1])
+            (fk, fv), bkv = self._fold_train(h1, H, W, cfg.stride_kv[s], tok0, s, l, ("key", "value"), out=arena[1:3])
             bn.update(bkv)
         else:
             fq, fk, fv = (self._fold_eval(s, l, n) for n in ("query", "key", "value"))
@@ -312,32 +313,41 @@ class CvtEncoderEngine:
         ops.linear_bwd_weight(da, sv["ctx"].view(-1, C), g(lp + "attention.output.dense.weight"), g(lp + "attention.output.dense.bias"))
         dctx = ops.gemm_nt(da, self._wt(lp + "attention.output.dense.weight")).view(Bn, L, C)
         dq, dk, dv = ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, C ** -0.5)
-        projs = []
-        for name, d, inp, stride in (("query", dq, sv["qc"], cfg.stride_q[s]), ("key", dk, sv["kc"], cfg.stride_kv[s]),
-                                     ("value", dv, sv["vc"], cfg.stride_kv[s])):
+        dcs = {}
+        for name, d, inp in (("query", dq, sv["qc"]), ("key", dk, sv["kc"]), ("value", dv, sv["vc"])):
             ops.linear_bwd_weight(d.view(-1, C), inp.view(-1, C), g(ap + f"projection_{name}.weight"), g(ap + f"projection_{name}.bias"))
-            dc = ops.gemm_nt(d.view(-1, C), self._wt(ap + f"projection_{name}.weight")).view(d.shape)
-            cp = ap + f"convolution_projection_{name}.convolution_projection."
-            if sv["bn"] is not None:
-                # batch-statistics BatchNorm: dc (grad wrt the BN output) -> grad wrt the raw conv output, in place; then raw-tap kernels
+            dcs[name] = ops.gemm_nt(d.view(-1, C), self._wt(ap + f"projection_{name}.weight")).view(d.shape)     # grad wrt the BatchNorm output
+        strides = {"query": cfg.stride_q[s], "key": cfg.stride_kv[s], "value": cfg.stride_kv[s]}
+        projs = []
+        h1 = sv["h1"]
+        if sv["bn"] is not None:
+            # batch-statistics BatchNorm: (sum dy, sum dy*c) per channel -> dc rewritten in place as the gradient of the RAW conv output ->
+            # the ordinary dx / tap-sum kernels with the raw taps
+            arena = torch.empty((36, C), dtype=torch.float32, device=dy.device)     # 3 x (S, D) + 3 x tap sums
+            raws = {n: self._raw_taps(s, l, n) for n in strides}
+            ops.dwconv_stats(h1, H, W, strides["query"], tok0, raws["query"], dy0=dcs["query"], out=arena[0:2].view(1, 2, C))
+            ops.dwconv_stats(h1, H, W, strides["key"], tok0, raws["key"], raws["value"], dy0=dcs["key"], dy1=dcs["value"], out=arena[2:6].view(2, 2, C))
+            for i, name in enumerate(("query", "key", "value")):
+                cp = self._conv_prefix(s, l, name)
                 mean, rstd, count = sv["bn"][name]
-                wr = self._raw_taps(s, l, name)
-                G, S = ops.dwconv_bn_bwd_w(sv["h1"], dc, H, W, stride, tok0)
-                coef = ops.bn_train_bwd_coef(st.f32(cp + "convolution.weight"), st.f32(cp + "normalization.weight"), mean, rstd, G, S, count,
+                coef = ops.bn_train_bwd_coef(st.f32(cp + "normalization.weight"), mean, rstd, arena[2 * i:2 * i + 2], count,
                                              g(cp + "normalization.weight"), g(cp + "normalization.bias"))
-                ops.dwconv_bn_train_dc_(sv["h1"], wr, coef, dc, H, W, stride, tok0)
-                projs.append((dc, wr, stride))
-                with ops._on_wgrad_stream(sv["h1"], dc):
-                    G2, _ = ops.dwconv_bn_bwd_w(sv["h1"], dc, H, W, stride, tok0)
+                ops.dwconv_bn_train_dc_(h1, raws[name], coef, dcs[name], H, W, strides[name], tok0)
+                projs.append((dcs[name], raws[name], strides[name]))
+                with ops._on_wgrad_stream(h1, dcs[name], arena):
+                    G2, _ = ops.dwconv_bn_bwd_w(h1, dcs[name], H, W, strides[name], tok0, out=arena[6 + 10 * i:16 + 10 * i])
                     ops.tap_grad_accum(G2, g(cp + "convolution.weight"))
-                continue
-            wf, _ = self._fold_eval(s, l, name)
-            projs.append((dc, wf, stride))
-            with ops._on_wgrad_stream(sv["h1"], dc):
-                G, S = ops.dwconv_bn_bwd_w(sv["h1"], dc, H, W, stride, tok0)
-                ops.bn_fold_bwd(st.f32(cp + "convolution.weight"), st.f32(cp + "normalization.weight"), st.f32(cp + "normalization.running_mean"),
-                                st.f32(cp + "normalization.running_var"), cfg.bn_eps, G, S, g(cp + "convolution.weight"),
-                                g(cp + "normalization.weight"), g(cp + "normalization.bias"))
+        else:
+            arena = torch.empty((30, C), dtype=torch.float32, device=dy.device)
+            for i, name in enumerate(("query", "key", "value")):
+                cp = self._conv_prefix(s, l, name)
+                wf, _ = self._fold_eval(s, l, name)
+                projs.append((dcs[name], wf, strides[name]))
+                with ops._on_wgrad_stream(h1, dcs[name], arena):
+                    G, S = ops.dwconv_bn_bwd_w(h1, dcs[name], H, W, strides[name], tok0, out=arena[10 * i:10 * i + 10])
+                    ops.bn_fold_bwd(st.f32(cp + "convolution.weight"), st.f32(cp + "normalization.weight"), st.f32(cp + "normalization.running_mean"),
+                                    st.f32(cp + "normalization.running_var"), cfg.bn_eps, G, S, g(cp + "convolution.weight"),
+                                    g(cp + "normalization.weight"), g(cp + "normalization.bias"))
         dh1 = ops.dwconv_bn_bwd_dx(projs, Bn, C, H, W, tok0)
         dx = ops.layernorm_bwd(sv["x"].view(-1, C), dh1.view(-1, C), st.f32(lp + "layernorm_before.weight"), sv["st1"],
                                g(lp + "layernorm_before.weight"), g(lp + "layernorm_before.bias"), add=dx2)

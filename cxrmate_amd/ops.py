@@ -306,21 +306,40 @@ def dwconv_bn_bwd_dx(projs, Bn, C, H, W, tok0):
     return dx
 
 
-def dwconv_bn_bwd_w(x, dy, H, W, stride, tok0):
+_DW_WS = {}
+
+
+def _dw_ws(C, device):
+    """Scratch for the two-stage per-channel reductions of the depthwise-conv kernels, one per (stream, C): partial rows live only
+    between the two kernels of one C-ABI call."""
+    key = (_s(), C, device)
+    ws = _DW_WS.get(key)
+    if ws is None:
+        ws = _DW_WS[key] = torch.empty(LIB.load().cxr_dwconv_ws_floats(C), device=device, dtype=torch.float32)
+    return ws
+
+
+def dwconv_bn_bwd_w(x, dy, H, W, stride, tok0, out=None):
+    """-> tap sums G [9,C], S [C] (views of `out` fp32 [10, C], overwritten)."""
     Bn, _, C = x.shape
-    G = torch.zeros((9, C), device=x.device, dtype=torch.float32)
-    S = torch.zeros((C,), device=x.device, dtype=torch.float32)
-    LIB.call("cxr_dwconv_bn_bwd_w_bf16", _p(x), x.stride(0), x.stride(1), _p(dy), dy.stride(0), dy.stride(1), _p(G), _p(S), Bn, C, H, W,
-             stride, tok0, _s())
-    return G, S
+    if out is None:
+        out = torch.empty((10, C), device=x.device, dtype=torch.float32)
+    LIB.call("cxr_dwconv_bn_bwd_w_bf16", _p(x), x.stride(0), x.stride(1), _p(dy), dy.stride(0), dy.stride(1), _p(out), _p(_dw_ws(C, x.device)),
+             Bn, C, H, W, stride, tok0, _s())
+    return out[:9], out[9]
 
 
-def dwconv_stats(x, H, W, stride, tok0, wr0, wr1=None):
-    """Sum / sum of squares per channel of the raw depthwise conv outputs -> fp32 [nproj, 2, C] (train-mode BatchNorm)."""
+def dwconv_stats(x, H, W, stride, tok0, wr0, wr1=None, dy0=None, dy1=None, out=None):
+    """Per-channel reductions over the raw depthwise conv outputs c of one or two projections -> fp32 [nproj, 2, C] (train-mode BatchNorm):
+    (sum c, sum c^2) in the forward; with dy0 (dy1) [Bn, tok0+Ho*Wo, C]: (sum dy, sum dy*c) for the backward."""
     Bn, L, C = x.shape
     n = 2 if wr1 is not None else 1
-    stats = torch.zeros((n, 2, C), device=x.device, dtype=torch.float32)
-    LIB.call("cxr_dwconv_stats_bf16", _p(x), x.stride(0), x.stride(1), _p(wr0), _p(wr1), _p(stats), Bn, C, H, W, stride, tok0, _s())
+    stats = out if out is not None else torch.empty((n, 2, C), device=x.device, dtype=torch.float32)
+    if dy1 is not None:
+        assert dy1.stride() == dy0.stride()
+    LIB.call("cxr_dwconv_stats_bf16", _p(x), x.stride(0), x.stride(1), _p(wr0), _p(wr1), _p(dy0), _p(dy1),
+             dy0.stride(0) if dy0 is not None else 0, dy0.stride(1) if dy0 is not None else 0, _p(stats), _p(_dw_ws(C, x.device)), Bn, C, H, W,
+             stride, tok0, _s())
     return stats
 
 
@@ -335,10 +354,10 @@ def bn_train_finalize(stats, count, w, g, b, eps, momentum, run_mean, run_var):
     return (wf, sh), mr[0], mr[1]
 
 
-def bn_train_bwd_coef(w, g, mean, rstd, G, S, count, dg, db):
-    C = w.shape[0]
-    coef = torch.empty((3, C), device=w.device, dtype=torch.float32)
-    LIB.call("cxr_bn_train_bwd_coef", _p(w), _p(g), _p(mean), _p(rstd), _p(G), _p(S), int(count), _p(dg), _p(db), _p(coef), C, _s())
+def bn_train_bwd_coef(g, mean, rstd, SD, count, dg, db):
+    C = g.shape[0]
+    coef = torch.empty((3, C), device=g.device, dtype=torch.float32)
+    LIB.call("cxr_bn_train_bwd_coef", _p(g), _p(mean), _p(rstd), _p(SD), int(count), _p(dg), _p(db), _p(coef), C, _s())
     return coef
 
 

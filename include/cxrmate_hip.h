@@ -86,20 +86,23 @@ int cxr_dwconv_bn_fwd_bf16(const void* x, long x_bs, long x_rs, const float* wf0
 int cxr_dwconv_bn_bwd_dx_bf16(const void* dy0, const float* wf0, long bs0, long rs0, int stride0, const void* dy1, const float* wf1, long bs1,
                               long rs1, int stride1, const void* dy2, const float* wf2, long bs2, long rs2, int stride2, int nproj, void* dx,
                               long dx_bs, long dx_rs, int Bn, int C, int H, int W, int tok0, hipStream_t stream);
-int cxr_dwconv_bn_bwd_w_bf16(const void* x, long x_bs, long x_rs, const void* dy, long dy_bs, long dy_rs, float* G, float* S, int Bn, int C,
-                             int H, int W, int stride, int tok0, hipStream_t stream);
+int cxr_dwconv_bn_bwd_w_bf16(const void* x, long x_bs, long x_rs, const void* dy, long dy_bs, long dy_rs, float* GS, float* ws, int Bn, int C,
+                             int H, int W, int stride, int tok0, hipStream_t stream);   /* GS [10][C] = tap sums G[9][C] then S[C], overwritten;
+                                                                                           ws = scratch, cxr_dwconv_ws_floats(C) fp32 */
+int cxr_dwconv_ws_floats(int C);
 
 /* train-mode BatchNorm2d (batch statistics; the reference trains under model.train(), and the "frozen" SCST encoder stays in train mode:
- * modules/lightning_modules/longitudinal/scst/gt_prompt.py:34-36). stats fp32 [nproj][2][C] zero-initialised (sum, sum of
+ * modules/lightning_modules/longitudinal/scst/gt_prompt.py:34-36). stats fp32 [nproj][2][C] (sum, sum of
  * squares of the raw depthwise conv outputs); finalize turns them into batch mean/rstd, moves the running statistics in place and emits the
- * folded taps for cxr_dwconv_bn_fwd_bf16. Backward: tap sums of dy (cxr_dwconv_bn_bwd_w_bf16) -> coef -> dy rewritten in place as the gradient
- * of the raw conv output -> the ordinary dx / tap-sum kernels with the RAW taps wr [9][C]. */
-int cxr_dwconv_stats_bf16(const void* x, long x_bs, long x_rs, const float* w0, const float* w1, float* stats, int Bn, int C, int H, int W,
-                          int stride, int tok0, hipStream_t stream);
+ * folded taps for cxr_dwconv_bn_fwd_bf16. Backward: (sum dy, sum dy*c) from the same statistics kernel -> coef -> dy rewritten in place as the
+ * gradient of the raw conv output -> the ordinary dx / tap-sum kernels with the RAW taps wr [9][C]. */
+int cxr_dwconv_stats_bf16(const void* x, long x_bs, long x_rs, const float* w0, const float* w1, const void* dy0, const void* dy1, long dy_bs,
+                          long dy_rs, float* stats, float* ws, int Bn, int C, int H, int W, int stride, int tok0, hipStream_t stream);
+                          /* dy0 == NULL: (sum c, sum c^2) of the raw conv outputs c; else (sum dy, sum dy*c) for the backward */
 int cxr_bn_train_finalize(const float* stats, long count, const float* w, const float* g, const float* b, float eps, float momentum,
                           float* run_mean, float* run_var, float* mean_out, float* rstd_out, float* wf, float* sh, int C, hipStream_t stream);
-int cxr_bn_train_bwd_coef(const float* w, const float* g, const float* mean, const float* rstd, const float* G, const float* S, long count,
-                          float* dg, float* db, float* coef, int C, hipStream_t stream);
+int cxr_bn_train_bwd_coef(const float* g, const float* mean, const float* rstd, const float* SD, long count, float* dg, float* db, float* coef,
+                          int C, hipStream_t stream);
 int cxr_dwconv_bn_train_dc_bf16(const void* x, long x_bs, long x_rs, const float* wr, const float* coef, void* dy, long dy_bs, long dy_rs,
                                 int Bn, int C, int H, int W, int stride, int tok0, hipStream_t stream);
 int cxr_tap_grad_accum(const float* G, float* dw, int C, hipStream_t stream);

@@ -442,9 +442,12 @@ def test_dwconv_batchnorm_train_mode(ops, C, H, tok0):
         projs = []
         for i, p in enumerate(par):
             dc = dys[i].clone()
-            G, S = ops.dwconv_bn_bwd_w(x, dc, H, W, stride, tok0)
+            SD = ops.dwconv_stats(x, H, W, stride, tok0, raws[i], dy0=dc)[0]             # (sum dy, sum dy*c)
+            if n == 2 and i == 1:                                                       # the paired launch (key + value) gives the same sums
+                both = ops.dwconv_stats(x, H, W, stride, tok0, raws[0], raws[1], dy0=dys[0], dy1=dys[1])
+                close(both[1], SD, rtol=1e-4, atol=1e-3, what="paired backward statistics")
             dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
-            coef = ops.bn_train_bwd_coef(p["w"], p["g"], kept[i][0], kept[i][1], G, S, count, dg, db)
+            coef = ops.bn_train_bwd_coef(p["g"], kept[i][0], kept[i][1], SD, count, dg, db)
             ops.dwconv_bn_train_dc_(x, raws[i], coef, dc, H, W, stride, tok0)
             if tok0:
                 assert torch.equal(dc[:, 0], dys[i][:, 0])                            # class-token rows bypass conv + BN
