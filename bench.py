@@ -226,11 +226,18 @@ def main():
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     nt = [p for p in prof if p[3][0] != "tn"]                # dominant kernel: gemm_nt_kernel (forward + dX products)
     tn = [p for p in prof if p[3][0] == "tn"]                # weight-gradient kernel (runs concurrently on the side stream)
-    gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in nt)
-    gemm_flops = sum(f for f, _, _, _ in nt)
-    tn_ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in tn)
-    tn_flops = sum(f for f, _, _, _ in tn)
+    gemm_ms = sum(p[1].elapsed_time(p[2]) for p in nt)
+    gemm_flops = sum(p[0] for p in nt)
+    gemm_bytes = sum(p[4] for p in nt)                        # operands + outputs (+ residual / saved pre-activation) once each
+    tn_ms = sum(p[1].elapsed_time(p[2]) for p in tn)
+    tn_flops = sum(p[0] for p in tn)
     prof = nt
+    traffic, traffic_src = None, None                        # HBM-side bytes per launch from the committed PMC passes (cannot be collected live)
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")))
+        traffic, traffic_src = pmc["gemm_nt"]["hbm_bytes_per_launch"], "profiles/r01_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+    except Exception:
+        pass
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
     step_gf = 3.0 * (ENC_FWD_GF_PER_IMAGE + dec_fwd_gf(1, T)) * B
 
@@ -246,7 +253,8 @@ def main():
                    "model_tflops_per_gpu": step_gf * 1e-3 / (ms_per_step * 1e-3)},
         "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (all tile variants; v_mfma_f32_16x16x32_bf16), timed while the weight-gradient "
                                "stream runs beside it, as in the timed region", "achieved": achieved,
-                     "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TF, "traffic": None,
+                     "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TF, "traffic": traffic,
+                     "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "algorithmic_bytes_per_launch": gemm_bytes / max(1, len(prof)),
                      "launches_per_step": len(prof), "avg_launch_us": gemm_ms * 1e3 / max(1, len(prof)),
                      "avg_launch_gflop": gemm_flops / max(1, len(prof)) * 1e-9, "gemm_share_of_step": gemm_ms / ms_per_step,
                      "weight_grad_kernel": {"kernel": "gemm_tn_kernel", "launches_per_step": len(tn), "achieved": tn_flops / (tn_ms * 1e-3) / 1e12,

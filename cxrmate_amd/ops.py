@@ -62,7 +62,8 @@ def gemm_nt(a, w, bias=None, residual=None, act=0, aux=None, out=None, out_f32=F
              M, N, K, float(alpha), int(act), int(out_f32), int(accumulate), _s())
     if prof is not None:
         e1.record()
-        prof.append((2.0 * M * N * K, e0, e1, (M, N, K)))
+        nbytes = 2.0 * (M * K + N * K) + M * N * ((4 if out_f32 else 2) + (2 if residual is not None else 0) + (2 if aux is not None else 0))
+        prof.append((2.0 * M * N * K, e0, e1, (M, N, K), nbytes))
     return out
 
 
@@ -96,7 +97,7 @@ def gemm_tn(p, q, out, dbias=None, alpha=1.0):
     LIB.call("cxr_gemm_tn_bf16", _p(p), p.stride(0), _p(q), q.stride(0), _p(out), out.stride(0), _p(dbias), R, I, J, float(alpha), _s())
     if prof is not None:
         e1.record()
-        prof.append((2.0 * R * I * J, e0, e1, ("tn", I, J, R)))
+        prof.append((2.0 * R * I * J, e0, e1, ("tn", I, J, R), 2.0 * R * (I + J) + 4.0 * I * J))
     return out
 
 

@@ -12,6 +12,7 @@ from cxrmate_amd.training import FusedAdamW, tf_train_step
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); a = ap.parse_args()
 cfg = EncoderDecoderConfig()
 m = SingleCXREncoderDecoderModel(cfg, device="cuda", seed=0)
+m.train()
 opt = FusedAdamW(m, lr=5e-5)
 px, inp, am, lab = bench.synth_batch(a.batch, 256, 30000, "cuda", 1)
 tt = m.token_ids_to_token_type_ids(inp, [3])
@@ -22,7 +23,7 @@ tf_train_step(m, opt, px, inp, am, tt, lab, 4)
 torch.cuda.synchronize()
 prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
 agg = collections.OrderedDict()
-for fl, e0, e1, shp in prof:
+for fl, e0, e1, shp, _ in prof:
     d = agg.setdefault(shp, [0, 0.0, 0.0]); d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fl
 tot = sum(v[1] for v in agg.values())
 print(f"{'M':>8} {'N':>6} {'K':>6} {'calls':>5} {'ms':>8} {'%':>5} {'TF/s':>7}")
