@@ -204,101 +204,168 @@ extern "C" int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, co
 // one workgroup per (batch row, head); K and V rows are streamed once, 8 lanes per 128-byte row (16 B each), HBM-bound
 // (cross-attention K/V = B*6*2*(N*576)*768*2 B per token is the dominant decode traffic).
 // Masked keys follow the teacher-forced kernel's convention (finite sentinel -> uniform over masked-only rows).
+// G queries share one K/V stream: query rows b, b + Bkv, ... (b < Bkv) attend to K/V row b. G = 2 is the SCST step, where the sampled and
+// the greedy decode of the same studies run as one batch and read identical cross-attention K/V (340 MB per token at 16 x 2 images).
+template <int G>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                           bf16_t* __restrict__ O, const unsigned char* __restrict__ kpm, long q_bs, long k_bs,
-                                                          long k_rs, long v_bs, long v_rs, long o_bs, long kpm_bs, int H, int Tk, float scale,
+                                                          long k_rs, long v_bs, long v_rs, long o_bs, long kpm_bs, int H, int Tk, float scale, int Bkv,
                                                           const uint32_t* __restrict__ drop_seed, uint32_t drop_site, uint32_t drop_thr16, float drop_inv,
-                                                          int drop_t) {
+                                                          int drop_t, int nsplit, int chunk, float* __restrict__ ws) {
     // single pass (flash-decoding): each of the 32 key groups (8 lanes x 16 B = one 128-byte K/V row per key) keeps a running
-    // (max, sum, o[64]) over keys grp, grp+32, ...; 4 keys per iteration -> 8 independent 16-byte loads in flight per lane; the 32
+    // (max, sum, o[64]) over keys grp, grp+32, ...; KU keys per iteration -> 2*KU independent 16-byte loads in flight per lane; the 32
     // partial states are merged through LDS at the end.
-    __shared__ float gm[32], gl[32];
-    __shared__ float go[32][64];
+    __shared__ float gm[G][32], gl[G][32];
+    __shared__ float go[G][32][64];
     const int tid = threadIdx.x;
-    const int h = blockIdx.x % H, b = blockIdx.x / H;
+    // nsplit > 1 (flash-decoding across workgroups): workgroup (b, h, split) covers keys [split*chunk, +chunk) and leaves its
+    // un-normalised state (max, denominator, numerator[64]) in ws for attn_decode_merge_kernel -- a (b, h) pair alone cannot pull
+    // HBM bandwidth when B*H is below the CU count (16 studies x 12 heads = 192 workgroups on 256 CUs).
+    const int split = blockIdx.x % nsplit, bh = blockIdx.x / nsplit;
+    const int h = bh % H, b = bh / H;                                // b indexes K/V (and the key-padding mask)
+    const int k_lo = split * chunk, k_hi = (k_lo + chunk < Tk) ? k_lo + chunk : Tk;
     const int sub = tid & 7, grp = tid >> 3;
-    float qv[8];
-    unpack8(*reinterpret_cast<const uint4*>(Q + (long)b * q_bs + h * 64 + sub * 8), qv);
+    float qv[G][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) qv[j] *= scale * 1.4426950408889634f;      // scores directly in the exp2 domain
+    for (int g = 0; g < G; ++g) {
+        unpack8(*reinterpret_cast<const uint4*>(Q + (long)(b + g * Bkv) * q_bs + h * 64 + sub * 8), qv[g]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[g][j] *= scale * 1.4426950408889634f;      // scores directly in the exp2 domain
+    }
     const bf16_t* kb = K + (long)b * k_bs + h * 64 + sub * 8;
     const bf16_t* vb = V + (long)b * v_bs + h * 64 + sub * 8;
     const unsigned char* mrow = kpm ? kpm + (long)b * kpm_bs : nullptr;
-    float m_run = -1.0e30f, l_run = 0.f;
-    float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // train-mode dropout on the probabilities: same (b*H+h, query position, key) hash as the tiled kernels (attention.hip)
-    const uint32_t drop_key = drop_thr16 ? dropout_row_key(*drop_seed, drop_site, (uint32_t)(b * H + h), (uint32_t)drop_t) : 0u;
+    float m_run[G], l_run[G], o[G][8];
+    uint32_t drop_key[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m_run[g] = -1.0e30f; l_run[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[g][j] = 0.f;
+        // train-mode dropout on the probabilities: same (b*H+h, query position, key) hash as the tiled kernels (attention.hip)
+        drop_key[g] = drop_thr16 ? dropout_row_key(*drop_seed, drop_site, (uint32_t)((b + g * Bkv) * H + h), (uint32_t)drop_t) : 0u;
+    }
     constexpr int KU = 8;                                   // keys per group per iteration: 16 independent 16-byte loads in flight per lane
-    for (int k0 = 0; k0 < Tk; k0 += 32 * KU) {
+    for (int k0 = k_lo; k0 < k_hi; k0 += 32 * KU) {
         uint4 kr[KU], vr[KU];
         bool live[KU], ok[KU];
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int key = k0 + u * 32 + grp;
-            live[u] = key < Tk;
-            const int kc = live[u] ? key : Tk - 1;
-            kr[u] = *reinterpret_cast<const uint4*>(kb + (long)kc * k_rs);
-            vr[u] = *reinterpret_cast<const uint4*>(vb + (long)kc * v_rs);
-            ok[u] = live[u] && (mrow == nullptr || mrow[kc] != 0);
+            live[u] = key < k_hi;
+            kr[u] = make_uint4(0, 0, 0, 0); vr[u] = make_uint4(0, 0, 0, 0);
+            ok[u] = false;
+            if (live[u]) {                                                   // no loads for keys past the range (they would cost bandwidth)
+                kr[u] = *reinterpret_cast<const uint4*>(kb + (long)key * k_rs);
+                vr[u] = *reinterpret_cast<const uint4*>(vb + (long)key * v_rs);
+                ok[u] = mrow == nullptr || mrow[key] != 0;
+            }
         }
-        float sv[KU];
+        float sv[G][KU];
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             float kv[8];
             unpack8(kr[u], kv);
-            float d = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d += qv[j] * kv[j];
-            d = group_sum<8>(d);
-            sv[u] = ok[u] ? d : -1.0e30f;                                    // masked (finite sentinel) ; keys beyond Tk are dropped below
+            for (int g = 0; g < G; ++g) {
+                float d = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d += qv[g][j] * kv[j];
+                d = group_sum<8>(d);
+                sv[g][u] = ok[u] ? d : -1.0e30f;                             // masked (finite sentinel); keys beyond Tk are dropped below
+            }
         }
-        float mloc = m_run;
 #pragma unroll
-        for (int u = 0; u < KU; ++u) if (live[u]) mloc = fmaxf(mloc, sv[u]);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - mloc);
-        m_run = mloc;
-        l_run *= alpha;
+        for (int g = 0; g < G; ++g) {
+            float mloc = m_run[g];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] *= alpha;
+            for (int u = 0; u < KU; ++u) if (live[u]) mloc = fmaxf(mloc, sv[g][u]);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[g] - mloc);
+            m_run[g] = mloc;
+            l_run[g] *= alpha;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[g][j] *= alpha;
+        }
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
-            const float p = live[u] ? __builtin_amdgcn_exp2f(sv[u] - m_run) : 0.f;
             float vv[8];
             unpack8(vr[u], vv);
-            l_run += p;
-            float pd = p;
-            if (drop_thr16) pd = dropout_keep(drop_key, (uint32_t)(k0 + u * 32 + grp), drop_thr16) ? p * drop_inv : 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += pd * vv[j];
+            for (int g = 0; g < G; ++g) {
+                const float p = live[u] ? __builtin_amdgcn_exp2f(sv[g][u] - m_run[g]) : 0.f;
+                l_run[g] += p;
+                float pd = p;
+                if (drop_thr16) pd = dropout_keep(drop_key[g], (uint32_t)(k0 + u * 32 + grp), drop_thr16) ? p * drop_inv : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[g][j] += pd * vv[j];
+            }
         }
     }
-    if (sub == 0) { gm[grp] = m_run; gl[grp] = l_run; }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) go[grp][sub * 8 + j] = o[j];
+    for (int g = 0; g < G; ++g) {
+        if (sub == 0) { gm[g][grp] = m_run[g]; gl[g][grp] = l_run[g]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) go[g][grp][sub * 8 + j] = o[g][j];
+    }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < 64 * G) {
+        const int g = tid >> 6, d = tid & 63;
         float M = -1.0e30f;
 #pragma unroll
-        for (int g = 0; g < 32; ++g) M = fmaxf(M, gm[g]);
+        for (int q = 0; q < 32; ++q) M = fmaxf(M, gm[g][q]);
         float num = 0.f, den = 0.f;
 #pragma unroll
-        for (int g = 0; g < 32; ++g) {
-            const float w = __builtin_amdgcn_exp2f(gm[g] - M);
-            num += w * go[g][tid];
-            den += w * gl[g];
+        for (int q = 0; q < 32; ++q) {
+            const float w = __builtin_amdgcn_exp2f(gm[g][q] - M);
+            num += w * go[g][q][d];
+            den += w * gl[g][q];
         }
-        O[(long)b * o_bs + h * 64 + tid] = f2bf(num / den);
+        if (nsplit == 1) {
+            O[(long)(b + g * Bkv) * o_bs + h * 64 + d] = f2bf(num / den);
+        } else {
+            float* w = ws + ((((long)(b + g * Bkv) * H + h) * nsplit) + split) * 66;
+            w[2 + d] = num;
+            if (d == 0) { w[0] = M; w[1] = den; }
+        }
     }
 }
 
+// O[b,h,:] from the nsplit partial states of attn_decode_kernel: one 64-lane wave per (query row, head)
+__global__ __launch_bounds__(256) void attn_decode_merge_kernel(const float* __restrict__ ws, bf16_t* __restrict__ O, long o_bs, int H, int nsplit, int rows) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), d = threadIdx.x & 63;          // r = b*H + h
+    if (r >= rows) return;
+    const float* w = ws + (long)r * nsplit * 66;
+    float M = -1.0e30f;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, w[s * 66]);
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float e = __builtin_amdgcn_exp2f(w[s * 66] - M);
+        num += e * w[s * 66 + 2 + d];
+        den += e * w[s * 66 + 1];
+    }
+    O[(long)(r / H) * o_bs + (r % H) * 64 + d] = f2bf(num / den);
+}
+
+// B query rows; K, V (and kpm) have B / kv_share rows: query rows b and b + B/kv_share read K/V row b (kv_share = 1 or 2).
 extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs,
-                                    long v_bs, long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, float drop_p,
-                                    const unsigned int* drop_seed, unsigned int drop_site, int drop_t, hipStream_t stream) {
+                                    long v_bs, long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, int kv_share, float* ws,
+                                    float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t, hipStream_t stream) {
     if (B <= 0 || H <= 0 || Tk <= 0 || Tk > 8192 || (k_rs % 8) || (v_rs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8)) return CXR_ERR_ARG;
-    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return CXR_ERR_ARG;
-    CXR_LAUNCH(attn_decode_kernel, dim3(B * H), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
-               (bf16_t*)O, (const unsigned char*)kpm, q_bs, k_bs, k_rs, v_bs, v_rs, o_bs, kpm_bs, H, Tk, scale, drop_seed, drop_site,
-               drop_p > 0.f ? dropout_thr16(drop_p) : 0u, 1.0f / (1.0f - drop_p), drop_t);
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed) || (kv_share != 1 && kv_share != 2) || (B % kv_share)) return CXR_ERR_ARG;
+    const int Bkv = B / kv_share;
+    // split the keys over workgroups (256 keys = one iteration each) while (b, h) pairs alone leave CUs idle; ws: B*H*8*66 floats
+    int nsplit = 1, chunk = Tk;
+    if (ws && Bkv * H < 512 && Tk > 256) {
+        nsplit = cdiv(Tk, 256) < 8 ? cdiv(Tk, 256) : 8;
+        chunk = 256 * cdiv(Tk, 256 * nsplit);
+        nsplit = cdiv(Tk, chunk);
+    }
+#define ATTN_DEC(G_) CXR_LAUNCH((attn_decode_kernel<G_>), dim3(Bkv * H * nsplit), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,            \
+               (const bf16_t*)V, (bf16_t*)O, (const unsigned char*)kpm, q_bs, k_bs, k_rs, v_bs, v_rs, o_bs, kpm_bs, H, Tk, scale, Bkv, drop_seed,       \
+               drop_site, drop_p > 0.f ? dropout_thr16(drop_p) : 0u, 1.0f / (1.0f - drop_p), drop_t, nsplit, chunk, ws)
+    if (kv_share == 2) ATTN_DEC(2); else ATTN_DEC(1);
+#undef ATTN_DEC
+    if (nsplit > 1) CXR_LAUNCH(attn_decode_merge_kernel, dim3(cdiv(B * H, 4)), dim3(256), 0, stream, ws, (bf16_t*)O, o_bs, H, nsplit, B * H);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

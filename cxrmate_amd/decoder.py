@@ -382,19 +382,25 @@ class BertEngine:
             a1 = out_lin(ctx.view(R, D), wo, bo, h, _site(l, 1))
             h1, _ = ops.layernorm(a1, st.f32(lp + "attention.output.LayerNorm.weight"), st.f32(lp + "attention.output.LayerNorm.bias"), cfg.layer_norm_eps)
             if cfg.add_cross_attention and enc is not None:
-                S = enc.shape[1]
+                Be, S = enc.shape[0], enc.shape[1]          # Be == B, or B/2 when two decodes of the same studies share the encoder rows
                 if cache.ck[l] is None or (not cache.cross_ready and past == 0):
                     ck, cbk = self._lin(lp + "crossattention.self.key"); cv, cbv = self._lin(lp + "crossattention.self.value")
-                    okb = cache.ck[l].view(B * S, D) if cache.ck[l] is not None else None
-                    ovb = cache.cv[l].view(B * S, D) if cache.cv[l] is not None else None
-                    cache.ck[l] = ops.gemm_nt(enc.reshape(B * S, D), ck, bias=cbk, out=okb).view(B, S, D)
-                    cache.cv[l] = ops.gemm_nt(enc.reshape(B * S, D), cv, bias=cbv, out=ovb).view(B, S, D)
+                    okb = cache.ck[l].view(Be * S, D) if cache.ck[l] is not None else None
+                    ovb = cache.cv[l].view(Be * S, D) if cache.cv[l] is not None else None
+                    cache.ck[l] = ops.gemm_nt(enc.reshape(Be * S, D), ck, bias=cbk, out=okb).view(Be, S, D)
+                    cache.cv[l] = ops.gemm_nt(enc.reshape(Be * S, D), cv, bias=cbv, out=ovb).view(Be, S, D)
                 cq, cbq = self._lin(lp + "crossattention.self.query"); co, cbo = self._lin(lp + "crossattention.output.dense")
                 q2 = lin(h1, cq, bias=cbq).view(B, Tn, D)
                 if single:
                     ctx2 = ops.attention_decode(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask, drop=(pa, seed, _site(l, 2), past))
-                else:
+                elif enc.shape[0] == B:
                     ctx2, _ = ops.attention(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask, drop=(pa, seed, _site(l, 2), past))
+                else:                                  # shared encoder rows (sample + greedy halves of one SCST step): one pass per half
+                    ctx2 = torch.empty((B, Tn, D), dtype=BF16, device=h.device)
+                    Bk = enc.shape[0]
+                    for g0 in range(0, B, Bk):
+                        ops.attention(q2[g0:g0 + Bk], cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask, out=ctx2[g0:g0 + Bk],
+                                      drop=(pa, seed, _site(l, 2), past))
                 a2 = out_lin(ctx2.view(R, D), co, cbo, h1, _site(l, 3))
                 h2, _ = ops.layernorm(a2, st.f32(lp + "crossattention.output.LayerNorm.weight"), st.f32(lp + "crossattention.output.LayerNorm.bias"),
                                       cfg.layer_norm_eps)

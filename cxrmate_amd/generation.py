@@ -23,16 +23,17 @@ class DecodeSession:
     replayed afterwards. Sessions are cached on the model and reused by every later generate() call of the same geometry (each SCST
     step decodes twice with identical shapes)."""
 
-    def __init__(self, model, B, S, Lmax, has_mask):
+    def __init__(self, model, B, S, Lmax, has_mask, share=1):
         dev = model.device
         self.model, self.B, self.S, self.Lmax = model, B, S, Lmax
         D = model.config.decoder.hidden_size
-        self.ids = torch.zeros((B, Lmax), dtype=torch.int64, device=dev)
-        self.unfinished = torch.ones(B, dtype=torch.int32, device=dev)
-        self.nxt = torch.zeros(B, dtype=torch.int64, device=dev)
+        rows, B = B, B // share          # `share` decodes of the same studies (SCST: sample + greedy) read ONE copy of the encoder rows / cross K,V
+        self.ids = torch.zeros((rows, Lmax), dtype=torch.int64, device=dev)
+        self.unfinished = torch.ones(rows, dtype=torch.int32, device=dev)
+        self.nxt = torch.zeros(rows, dtype=torch.int64, device=dev)
         self.enc16 = torch.empty((B, S, D), dtype=torch.bfloat16, device=dev)
         self.enc_mask8 = torch.empty((B, S), dtype=torch.uint8, device=dev) if has_mask else None
-        self.cache = model._dec.new_cache(B, Lmax, dev)
+        self.cache = model._dec.new_cache(rows, Lmax, dev)
         L = model.config.decoder.num_hidden_layers
         self.cache.ck = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
         self.cache.cv = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
@@ -104,13 +105,13 @@ class DecodeSession:
 class GenerationMixin:
     graph_decode = True      # replay single-token decode steps from hipGraphs (DecodeSession)
 
-    def _session(self, B, S, Lmax, has_mask):
+    def _session(self, B, S, Lmax, has_mask, share=1):
         cache = self.__dict__.setdefault("_decode_sessions", {})
-        key = (B, S, Lmax, has_mask)
+        key = (B, S, Lmax, has_mask, share)
         if key not in cache:
             if len(cache) >= 4:
                 cache.clear()
-            cache[key] = DecodeSession(self, B, S, Lmax, has_mask)
+            cache[key] = DecodeSession(self, B, S, Lmax, has_mask, share)
         return cache[key]
 
     # ------------------------------------------------------------------------------------------ per-step inputs
@@ -249,7 +250,7 @@ class GenerationMixin:
         B, prompt_len = ids.shape
         strip = 1 if (self.kind == "longitudinal" and bool(torch.all(ids[:, 0] == bos_token_id))) else 0
         with torch.no_grad():
-            ses = self._session(B, enc16.shape[1], max_length, enc_mask8 is not None)
+            ses = self._session(B, enc16.shape[1], max_length, enc_mask8 is not None, share=B // enc16.shape[0])
             ses.reset(ids, enc16, enc_mask8)
             if do_sample == "pair":
                 kind, special = "pair", (tuple(special_token_ids[0]), tuple(special_token_ids[1]))
@@ -293,10 +294,8 @@ class GenerationMixin:
         prompt = prompt_ids.to(device=dev, dtype=torch.int64)
         start = torch.full((B, 1), bos_token_id, dtype=torch.int64, device=dev)
         ids = torch.cat([start, prompt], dim=-1) if bool((prompt[:, 0] != bos_token_id).all()) else prompt
-        enc16 = (enc if enc.dtype == torch.bfloat16 else ops.cast_to_bf16(enc.float().contiguous())).detach()
-        enc16 = torch.cat([enc16, enc16], dim=0)
-        enc_mask8 = None if enc_mask is None else enc_mask.to(device=dev, dtype=torch.uint8)
-        enc_mask8 = None if enc_mask8 is None else torch.cat([enc_mask8, enc_mask8], dim=0)
+        enc16 = (enc if enc.dtype == torch.bfloat16 else ops.cast_to_bf16(enc.float().contiguous())).detach().contiguous()
+        enc_mask8 = None if enc_mask is None else enc_mask.to(device=dev, dtype=torch.uint8).contiguous()      # B rows serve the 2B decode rows
         rec = {"tt": [], "pos": []}
         out = self._generate_session(torch.cat([ids, ids], dim=0), enc16, enc_mask8, (special_sample, special_greedy), mask_token_id,
                                      max_length, bos_token_id, eos_token_id, pad_token_id, "pair", top_k, temperature, rec)

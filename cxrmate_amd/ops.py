@@ -571,14 +571,21 @@ def gemm_skinny(a, w, bias=None, residual=None, act=0, out=None, out_f32=False, 
 
 
 def attention_decode(q, k, v, heads, scale, kpm=None, out=None, drop=None):
-    """q [B,1,H*64] (or [B,H*64]); k, v [B,Tk,H*64] views (batch/row strides free) -> [B, H*64]"""
+    """q [B,1,H*64] (or [B,H*64]); k, v [B or B/2,Tk,H*64] views (batch/row strides free) -> [B, H*64]. With B/2 K/V rows, query rows
+    b and b + B/2 share K/V row b."""
     B = q.shape[0]
+    share = B // k.shape[0]
+    assert k.shape[0] * share == B and share in (1, 2)
+    key = ("attn_decode_ws", _s(), B * heads, q.device)
+    ws = _DW_WS.get(key)
+    if ws is None:
+        ws = _DW_WS[key] = torch.empty(B * heads * 8 * 66, device=q.device, dtype=torch.float32)
     D = heads * 64
     Tk = k.shape[1]
     if out is None:
         out = torch.empty((B, D), device=q.device, dtype=BF16)
     LIB.call("cxr_attn_decode_bf16", _p(q), _p(k), _p(v), _p(out), _p(kpm), q.stride(0), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-             out.stride(0), kpm.stride(0) if kpm is not None else 0, B, heads, Tk, float(scale), *_drop_args(drop), _s())
+             out.stride(0), kpm.stride(0) if kpm is not None else 0, B, heads, Tk, float(scale), share, _p(ws), *_drop_args(drop), _s())
     return out
 
 

@@ -146,8 +146,11 @@ int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, const float* 
                           void* C1, long ldc1, const void* W2, const float* b2, void* C2, long ldc2, long ldw, int M, int N, int K,
                           hipStream_t stream);   /* q / k / v projections of one decode step in a single launch */
 int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs, long v_bs,
-                         long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, float drop_p, const unsigned int* drop_seed,
-                         unsigned int drop_site, int drop_t, hipStream_t stream);   /* drop_t = absolute position of the query */
+                         long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, int kv_share, float* ws, float drop_p,
+                         const unsigned int* drop_seed, unsigned int drop_site, int drop_t, hipStream_t stream);
+                         /* kv_share = 2: K, V, kpm have B/2 rows and query rows b, b + B/2 read row b (sample + greedy halves of one SCST step
+                            share the cross-attention K/V); ws (optional, B*H*8*66 fp32): lets the launch split long key ranges over workgroups
+                            (flash-decoding) + a merge kernel; drop_t = absolute position of the query */
 int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, long* inds, hipStream_t stream);
 
 /* ---- reward (REF:tools/rewards/cxrbert.py:66-71 torch.nn.functional.cosine_similarity of the CLS projections) ---------------- */

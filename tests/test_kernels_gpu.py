@@ -312,6 +312,18 @@ def test_attention_decode_single_query(ops, B, H, Tk, masked):
     close(out, ref[:, 0], what="attn decode")
     full, _ = ops.attention(q, k, v, H, 0.125, kpm=kpm)
     close(out, full[:, 0], rtol=1e-2, atol=1e-2, what="attn decode vs tiled kernel")
+    # two query rows per K/V row (sample + greedy halves of one SCST step share the cross-attention K/V): rows b and b + B read K/V row b
+    q2 = torch.cat([q, dev(rnd(B, 1, D, seed=9).to(BF))], 0)
+    both = ops.attention_decode(q2, k, v, H, 0.125, kpm=kpm)
+    close(both[:B], out, rtol=2e-3, atol=2e-3, what="attn decode, first half of a shared launch")
+    ref2, _ = ref_attention(q2[B:], k, v, H, 0.125, kpm)
+    close(both[B:], ref2[:, 0], what="attn decode, shared K/V")
+    seed = torch.full((1,), 7, dtype=torch.int32, device="cuda")
+    dr = ops.attention_decode(q2, k, v, H, 0.125, kpm=kpm, drop=(0.1, seed, 18, 33))
+    fac = ops.dropout_mask(2 * B * H, Tk, 0.1, seed, 18, 1, 33, factor=True).view(2 * B, H, 1, Tk)
+    kk, vv = torch.cat([k, k], 0), torch.cat([v, v], 0)
+    refd, _ = ref_attention(q2, kk, vv, H, 0.125, None if kpm is None else torch.cat([kpm, kpm], 0), drop=fac)
+    close(dr, refd[:, 0], what="attn decode dropout (same hash as the tiled kernel / cxr_dropout_mask)")
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
