@@ -80,11 +80,22 @@ struct SkinnyArgs {
     int nprob, M, K, act, out_f32;
     // train-mode dropout of the dense output before the residual (BertSelfOutput / BertOutput): row m = sequence, position drop_t
     const uint32_t* drop_seed; uint32_t drop_site, drop_thr16; float drop_inv; int drop_t;       // drop_thr16 == 0: off
+    // LayerNorm folded into its consumers (a decode step is launch-bound: ~19 LayerNorm launches per token disappear):
+    //   lnA_*: A is the RAW pre-LayerNorm sum; every workgroup holds its whole K = 768 slice of A in registers anyway, so it computes the
+    //          row statistics (two-pass, fp32) and normalises the fragments before the MFMAs; workgroup 0 publishes (mean, rstd) per row.
+    //   lnR_*: the residual operand is LayerNorm(raw residual) with the published statistics.
+    const float* lnA_g; const float* lnA_b; float lnA_eps; float* lnA_stats;
+    const float* lnR_stats; const float* lnR_g; const float* lnR_b;
 };
 
-template <int MT>   // number of 16-row tiles of A
+__device__ __forceinline__ float bfv(const bf16x8_t& v, int j) {
+    return __uint_as_float(((uint32_t)(uint16_t)__builtin_bit_cast(s16x8_t, v)[j]) << 16);
+}
+
+template <int MT, bool LNA>   // MT = number of 16-row tiles of A; LNA = LayerNorm on the A operand (K == 768)
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs g) {
     __shared__ float red[4][MT][64][4];
+    __shared__ float lnbuf[2][4][MT][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // grouped launch: blocks [0, N0/16) -> problem 0, next N1/16 -> problem 1, ... (q / k / v projections share A and one launch)
     int blk = blockIdx.x, pi = 0;
@@ -108,6 +119,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs g) {
                 rv[t][r] = (g.residual && pi == 0 && m < g.M && n < P.N) ? bf2f(g.residual[(long)m * g.ldr + n]) : 0.f;
             }
     }
+    float rg = 1.f, rb = 0.f;
+    if (wave == 0 && g.lnR_stats && pi == 0 && n < P.N) { rg = g.lnR_g[n]; rb = g.lnR_b[n]; }
     f32x4_t acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs g) {
         int m = t * 16 + fr; m = m < g.M ? m : g.M - 1;
         ap[t] = g.A + (long)m * g.lda + k0 + fq * 8;
     }
-    constexpr int KB = MT == 1 ? 12 : (MT == 2 ? 8 : 4);            // k-steps (of 32) whose loads are in flight together
+    constexpr int KB = LNA ? 6 : (MT == 1 ? 12 : (MT == 2 ? 8 : 4));   // k-steps (of 32) whose loads are in flight together
     for (int kb = 0; kb < kslice; kb += 32 * KB) {
         bf16x8_t wf[KB], af[MT][KB];
 #pragma unroll
@@ -127,6 +140,56 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs g) {
                 wf[s2] = *reinterpret_cast<const bf16x8_t*>(wp + k);
 #pragma unroll
                 for (int t = 0; t < MT; ++t) af[t][s2] = *reinterpret_cast<const bf16x8_t*>(ap[t] + k);
+            }
+        }
+        if (LNA) {                                                        // kslice == 192 == 32*KB: the loop body runs once
+            float mean[MT], rstd[MT];
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    float acc1 = 0.f;
+#pragma unroll
+                    for (int s2 = 0; s2 < KB; ++s2)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float x = bfv(af[t][s2], j);
+                            acc1 += pass == 0 ? x : (x - mean[t]) * (x - mean[t]);
+                        }
+                    acc1 += __shfl_xor(acc1, 16, 64);
+                    acc1 += __shfl_xor(acc1, 32, 64);
+                    if (fq == 0) lnbuf[pass][wave][t][fr] = acc1;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const float tot = (lnbuf[pass][0][t][fr] + lnbuf[pass][1][t][fr]) + (lnbuf[pass][2][t][fr] + lnbuf[pass][3][t][fr]);
+                    if (pass == 0) mean[t] = tot * (1.0f / 768.0f);
+                    else rstd[t] = rsqrtf(tot * (1.0f / 768.0f) + g.lnA_eps);
+                }
+            }
+            if (g.lnA_stats && blockIdx.x == 0 && wave == 0 && fq == 0) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const int m = t * 16 + fr;
+                    if (m < g.M) { g.lnA_stats[2 * m] = mean[t]; g.lnA_stats[2 * m + 1] = rstd[t]; }
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < KB; ++s2) {
+                const float* gp = g.lnA_g + k0 + s2 * 32 + fq * 8;
+                const float* bp = g.lnA_b + k0 + s2 * 32 + fq * 8;
+                const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    s16x8_t o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (short)f2bf((bfv(af[t][s2], j) - mean[t]) * rstd[t] * gg[j] + bb[j]);
+                    af[t][s2] = __builtin_bit_cast(bf16x8_t, o);
+                }
             }
         }
 #pragma unroll
@@ -153,7 +216,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs g) {
             if (g.act == 1) v = gelu_f(v);
             if (g.drop_thr16)
                 v = dropout_keep(dropout_row_key(*g.drop_seed, g.drop_site, (uint32_t)m, (uint32_t)g.drop_t), (uint32_t)n, g.drop_thr16) ? v * g.drop_inv : 0.f;
-            v += rv[t][r];
+            float res = rv[t][r];
+            if (g.lnR_stats && pi == 0) res = (res - g.lnR_stats[2 * m]) * g.lnR_stats[2 * m + 1] * rg + rb;
+            v += res;
             if (g.out_f32) reinterpret_cast<float*>(P.C)[(long)m * P.ldc + n] = v;
             else reinterpret_cast<bf16_t*>(P.C)[(long)m * P.ldc + n] = f2bf(v);
         }
@@ -163,7 +228,9 @@ static int launch_skinny(const SkinnyArgs& g, hipStream_t stream) {
     int grid = 0;
     for (int i = 0; i < g.nprob; ++i) grid += cdiv(g.p[i].N, 16);
     const int mt = cdiv(g.M, 16);
-#define SKINNY(MT_) CXR_LAUNCH((gemm_skinny_kernel<MT_>), dim3(grid), dim3(256), 0, stream, g)
+    if (g.lnA_g && g.K != 768) return CXR_ERR_ARG;
+#define SKINNY(MT_) do { if (g.lnA_g) CXR_LAUNCH((gemm_skinny_kernel<MT_, true>), dim3(grid), dim3(256), 0, stream, g);        \
+                         else         CXR_LAUNCH((gemm_skinny_kernel<MT_, false>), dim3(grid), dim3(256), 0, stream, g); } while (0)
     if (mt == 1) SKINNY(1); else if (mt == 2) SKINNY(2); else if (mt == 3) SKINNY(3); else SKINNY(4);
 #undef SKINNY
     CXR_LAUNCH_CHECK();
@@ -171,13 +238,17 @@ static int launch_skinny(const SkinnyArgs& g, hipStream_t stream) {
 }
 
 extern "C" int cxr_gemm_skinny_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias, const void* residual,
-                                    long ldr, int M, int N, int K, int act, int out_f32, float drop_p, const unsigned int* drop_seed,
-                                    unsigned int drop_site, int drop_t, hipStream_t stream) {
+                                    long ldr, int M, int N, int K, int act, int out_f32, const float* lnA_gamma, const float* lnA_beta,
+                                    float lnA_eps, float* lnA_stats, const float* lnR_stats, const float* lnR_gamma, const float* lnR_beta,
+                                    float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t, hipStream_t stream) {
     if (M <= 0 || M > 64 || N <= 0 || K <= 0 || (K % 128) || (lda % 8) || (ldw % 8)) return CXR_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return CXR_ERR_ARG;
     SkinnyArgs g;
     g.drop_seed = drop_seed; g.drop_site = drop_site; g.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u;
     g.drop_inv = 1.0f / (1.0f - drop_p); g.drop_t = drop_t;
+    if ((lnA_gamma && !lnA_beta) || (lnR_stats && (!lnR_gamma || !lnR_beta || !residual))) return CXR_ERR_ARG;
+    g.lnA_g = lnA_gamma; g.lnA_b = lnA_beta; g.lnA_eps = lnA_eps; g.lnA_stats = lnA_stats;
+    g.lnR_stats = lnR_stats; g.lnR_g = lnR_gamma; g.lnR_b = lnR_beta;
     g.A = (const bf16_t*)A; g.lda = lda; g.residual = (const bf16_t*)residual; g.ldr = ldr;
     g.p[0].W = (const bf16_t*)W; g.p[0].bias = bias; g.p[0].C = C; g.p[0].ldw = ldw; g.p[0].ldc = ldc; g.p[0].N = N;
     g.p[1] = g.p[0]; g.p[2] = g.p[0];
@@ -188,10 +259,14 @@ extern "C" int cxr_gemm_skinny_bf16(const void* A, long lda, const void* W, long
 // three projections of the same activations in one launch (decode-step q / k / v: k and v land directly in their KV-cache rows)
 extern "C" int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, const float* b0, void* C0, long ldc0, const void* W1,
                                      const float* b1, void* C1, long ldc1, const void* W2, const float* b2, void* C2, long ldc2, long ldw,
-                                     int M, int N, int K, hipStream_t stream) {
+                                     int M, int N, int K, const float* lnA_gamma, const float* lnA_beta, float lnA_eps, float* lnA_stats,
+                                     hipStream_t stream) {
     if (M <= 0 || M > 64 || N <= 0 || K <= 0 || (K % 128) || (lda % 8) || (ldw % 8)) return CXR_ERR_ARG;
     SkinnyArgs g;
     g.drop_seed = nullptr; g.drop_site = 0; g.drop_thr16 = 0; g.drop_inv = 1.f; g.drop_t = 0;
+    if (lnA_gamma && !lnA_beta) return CXR_ERR_ARG;
+    g.lnA_g = lnA_gamma; g.lnA_b = lnA_beta; g.lnA_eps = lnA_eps; g.lnA_stats = lnA_stats;
+    g.lnR_stats = nullptr; g.lnR_g = nullptr; g.lnR_b = nullptr;
     g.A = (const bf16_t*)A; g.lda = lda; g.residual = nullptr; g.ldr = 0;
     const void* W[3] = {W0, W1, W2}; const float* b[3] = {b0, b1, b2}; void* C[3] = {C0, C1, C2}; const long ldc[3] = {ldc0, ldc1, ldc2};
     for (int i = 0; i < 3; ++i) { g.p[i].W = (const bf16_t*)W[i]; g.p[i].bias = b[i]; g.p[i].C = C[i]; g.p[i].ldw = ldw; g.p[i].ldc = ldc[i]; g.p[i].N = N; }
@@ -209,7 +284,7 @@ extern "C" int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, co
 template <int G>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                           bf16_t* __restrict__ O, const unsigned char* __restrict__ kpm, long q_bs, long k_bs,
-                                                          long k_rs, long v_bs, long v_rs, long o_bs, long kpm_bs, int H, int Tk, float scale, int Bkv,
+                                                          long k_rs, long v_bs, long v_rs, long o_bs, long kpm_bs, int H, int Tk, float scale, int Bkv, long kv_hs,
                                                           const uint32_t* __restrict__ drop_seed, uint32_t drop_site, uint32_t drop_thr16, float drop_inv,
                                                           int drop_t, int nsplit, int chunk, float* __restrict__ ws) {
     // single pass (flash-decoding): each of the 32 key groups (8 lanes x 16 B = one 128-byte K/V row per key) keeps a running
@@ -225,15 +300,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     const int h = bh % H, b = bh / H;                                // b indexes K/V (and the key-padding mask)
     const int k_lo = split * chunk, k_hi = (k_lo + chunk < Tk) ? k_lo + chunk : Tk;
     const int sub = tid & 7, grp = tid >> 3;
-    float qv[G][8];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        unpack8(*reinterpret_cast<const uint4*>(Q + (long)(b + g * Bkv) * q_bs + h * 64 + sub * 8), qv[g]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qv[g][j] *= scale * 1.4426950408889634f;      // scores directly in the exp2 domain
-    }
-    const bf16_t* kb = K + (long)b * k_bs + h * 64 + sub * 8;
-    const bf16_t* vb = V + (long)b * v_bs + h * 64 + sub * 8;
+    const bf16_t* kb = K + (long)b * k_bs + h * kv_hs + sub * 8;      // kv_hs = 64 for token-major [B,T,H*64], T*64 for head-major [B,H,T,64]
+    const bf16_t* vb = V + (long)b * v_bs + h * kv_hs + sub * 8;
     const unsigned char* mrow = kpm ? kpm + (long)b * kpm_bs : nullptr;
     float m_run[G], l_run[G], o[G][8];
     uint32_t drop_key[G];
@@ -246,21 +314,29 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         drop_key[g] = drop_thr16 ? dropout_row_key(*drop_seed, drop_site, (uint32_t)((b + g * Bkv) * H + h), (uint32_t)drop_t) : 0u;
     }
     constexpr int KU = 8;                                   // keys per group per iteration: 16 independent 16-byte loads in flight per lane
-    for (int k0 = k_lo; k0 < k_hi; k0 += 32 * KU) {
-        uint4 kr[KU], vr[KU];
-        bool live[KU], ok[KU];
+    uint4 kr[KU], vr[KU];
+    bool live[KU], ok[KU];
+#define ATTN_DEC_LOAD(k0_)                                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                                                        \
+        const int key = (k0_) + u * 32 + grp;                                                                               \
+        live[u] = key < k_hi;                                                                                               \
+        kr[u] = make_uint4(0, 0, 0, 0); vr[u] = make_uint4(0, 0, 0, 0);                                                     \
+        ok[u] = false;                                                                                                      \
+        if (live[u]) {                       /* no loads for keys past the range (they would cost bandwidth) */             \
+            kr[u] = *reinterpret_cast<const uint4*>(kb + (long)key * k_rs);                                                 \
+            vr[u] = *reinterpret_cast<const uint4*>(vb + (long)key * v_rs);                                                 \
+            ok[u] = mrow == nullptr || mrow[key] != 0;                                                                      \
+        }                                                                                                                   \
+    }
+    ATTN_DEC_LOAD(k_lo);                                    // the K/V stream starts before the (dependent-latency) query load is waited for
+    float qv[G][8];
 #pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            const int key = k0 + u * 32 + grp;
-            live[u] = key < k_hi;
-            kr[u] = make_uint4(0, 0, 0, 0); vr[u] = make_uint4(0, 0, 0, 0);
-            ok[u] = false;
-            if (live[u]) {                                                   // no loads for keys past the range (they would cost bandwidth)
-                kr[u] = *reinterpret_cast<const uint4*>(kb + (long)key * k_rs);
-                vr[u] = *reinterpret_cast<const uint4*>(vb + (long)key * v_rs);
-                ok[u] = mrow == nullptr || mrow[key] != 0;
-            }
-        }
+    for (int g = 0; g < G; ++g) {
+        unpack8(*reinterpret_cast<const uint4*>(Q + (long)(b + g * Bkv) * q_bs + h * 64 + sub * 8), qv[g]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[g][j] *= scale * 1.4426950408889634f;      // scores directly in the exp2 domain
+    }
+    for (int k0 = k_lo; k0 < k_hi; k0 += 32 * KU) {
         float sv[G][KU];
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
@@ -300,7 +376,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
                 for (int j = 0; j < 8; ++j) o[g][j] += pd * vv[j];
             }
         }
+        if (k0 + 32 * KU < k_hi) ATTN_DEC_LOAD(k0 + 32 * KU);
     }
+#undef ATTN_DEC_LOAD
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         if (sub == 0) { gm[g][grp] = m_run[g]; gl[g][grp] = l_run[g]; }
@@ -349,7 +427,7 @@ __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const float* __r
 // B query rows; K, V (and kpm) have B / kv_share rows: query rows b and b + B/kv_share read K/V row b (kv_share = 1 or 2).
 extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs,
                                     long v_bs, long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, int kv_share, float* ws,
-                                    float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t, hipStream_t stream) {
+                                    long kv_hs, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t, hipStream_t stream) {
     if (B <= 0 || H <= 0 || Tk <= 0 || Tk > 8192 || (k_rs % 8) || (v_rs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8)) return CXR_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed) || (kv_share != 1 && kv_share != 2) || (B % kv_share)) return CXR_ERR_ARG;
     const int Bkv = B / kv_share;
@@ -361,7 +439,7 @@ extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V,
         nsplit = cdiv(Tk, chunk);
     }
 #define ATTN_DEC(G_) CXR_LAUNCH((attn_decode_kernel<G_>), dim3(Bkv * H * nsplit), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,            \
-               (const bf16_t*)V, (bf16_t*)O, (const unsigned char*)kpm, q_bs, k_bs, k_rs, v_bs, v_rs, o_bs, kpm_bs, H, Tk, scale, Bkv, drop_seed,       \
+               (const bf16_t*)V, (bf16_t*)O, (const unsigned char*)kpm, q_bs, k_bs, k_rs, v_bs, v_rs, o_bs, kpm_bs, H, Tk, scale, Bkv, kv_hs, drop_seed, \
                drop_site, drop_p > 0.f ? dropout_thr16(drop_p) : 0u, 1.0f / (1.0f - drop_p), drop_t, nsplit, chunk, ws)
     if (kv_share == 2) ATTN_DEC(2); else ATTN_DEC(1);
 #undef ATTN_DEC

@@ -349,6 +349,8 @@ class BertEngine:
             ops.dropout_add(h, None, ph, seed, SITE_EMBED, Tn, t0=past, out=h)
         scale = cfg.head_dim ** -0.5
         single = Tn == 1 and B <= 64          # one new token per row: weight-streaming GEMMs + single-query attention kernels
+        if single and D == 768 and self.fuse_decode_layernorm:
+            return self._decode_single_fused(cache, h, enc, enc_mask, attn_mask_full, past, ph, pa, seed)
         lin = (lambda x, w, **kw: ops.gemm_skinny(x, w, **kw)) if single else (lambda x, w, **kw: ops.gemm_nt(x, w, **kw))
 
         def out_lin(x, w, b, resid, site):
@@ -421,6 +423,67 @@ class BertEngine:
             return ops.gemm_skinny(tn, st.w16(p + "bert.embeddings.word_embeddings.weight"), bias=st.f32(c + "bias"), out_f32=True)
         logits, _ = self._lm_head(last, False)
         return logits
+
+    fuse_decode_layernorm = True
+
+    def _decode_single_fused(self, cache, h, enc, enc_mask, attn_mask_full, past, ph, pa, seed):
+        """One token per row with every LayerNorm folded into its consumers: a decode step is launch-bound (~85 short kernels), and the
+        weight-streaming GEMM holds its whole slice of the activations in registers, so it normalises them itself (`ln_a`) and publishes
+        the row statistics for the later residual use of the same LayerNorm output (`ln_r`). 19 launches per token disappear.
+        h: embedding output [B, 768] (already LayerNorm'ed + dropped). Returns fp32 logits [B, V]."""
+        cfg, st, p = self.cfg, self.s, self.p
+        B, D = h.shape
+        nh, eps, scale = cfg.num_attention_heads, cfg.layer_norm_eps, cfg.head_dim ** -0.5
+        dev = h.device
+        cur, cur_ln = h, None                      # hidden state = cur when cur_ln is None, else LayerNorm(cur; cur_ln = (gamma, beta, stats))
+
+        def ln_a(ln):
+            return None if ln is None else (ln[0], ln[1], eps, ln[2])
+
+        def ln_r(ln):
+            return None if ln is None else (ln[2], ln[0], ln[1])
+
+        def new_ln(base):
+            return (st.f32(base + ".weight"), st.f32(base + ".bias"), torch.empty((B, 2), dtype=torch.float32, device=dev))
+
+        def drop(site):
+            return (ph, seed, site, past) if ph else None
+
+        for l in range(cfg.num_hidden_layers):
+            lp = p + f"bert.encoder.layer.{l}."
+            wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key"); wv, bv = self._lin(lp + "attention.self.value")
+            q = torch.empty((B, D), dtype=BF16, device=dev)
+            ops.gemm_skinny3(cur, wq, bq, q, wk, bk, cache.k[l][:, past, :], wv, bv, cache.v[l][:, past, :], ln_a=ln_a(cur_ln))
+            ctx = ops.attention_decode(q, cache.k[l][:, :past + 1, :], cache.v[l][:, :past + 1, :], nh, scale, kpm=attn_mask_full,
+                                       drop=(pa, seed, _site(l, 0), past))
+            wo, bo = self._lin(lp + "attention.output.dense")
+            a1 = ops.gemm_skinny(ctx, wo, bias=bo, residual=cur, ln_r=ln_r(cur_ln), drop=drop(_site(l, 1)))
+            cur, cur_ln = a1, new_ln(lp + "attention.output.LayerNorm")
+            if cfg.add_cross_attention and enc is not None:
+                if cache.ck[l] is None or (not cache.cross_ready and past == 0):       # one-token prompt: this step is also the prefill
+                    Be, S = enc.shape[0], enc.shape[1]
+                    ck, cbk = self._lin(lp + "crossattention.self.key"); cv, cbv = self._lin(lp + "crossattention.self.value")
+                    okb = cache.ck[l].view(Be * S, D) if cache.ck[l] is not None else None
+                    ovb = cache.cv[l].view(Be * S, D) if cache.cv[l] is not None else None
+                    cache.ck[l] = ops.gemm_nt(enc.reshape(Be * S, D), ck, bias=cbk, out=okb).view(Be, S, D)
+                    cache.cv[l] = ops.gemm_nt(enc.reshape(Be * S, D), cv, bias=cbv, out=ovb).view(Be, S, D)
+                cq, cbq = self._lin(lp + "crossattention.self.query"); co, cbo = self._lin(lp + "crossattention.output.dense")
+                q2 = ops.gemm_skinny(cur, cq, bias=cbq, ln_a=ln_a(cur_ln))
+                ctx2 = ops.attention_decode(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask, drop=(pa, seed, _site(l, 2), past))
+                a2 = ops.gemm_skinny(ctx2, co, bias=cbo, residual=cur, ln_r=ln_r(cur_ln), drop=drop(_site(l, 3)))
+                cur, cur_ln = a2, new_ln(lp + "crossattention.output.LayerNorm")
+            w1, b1 = self._lin(lp + "intermediate.dense"); w2, b2 = self._lin(lp + "output.dense")
+            f = ops.gemm_skinny(cur, w1, bias=b1, act=1, ln_a=ln_a(cur_ln))
+            a3 = ops.gemm_skinny(f, w2, bias=b2, residual=cur, ln_r=ln_r(cur_ln), drop=drop(_site(l, 4)))
+            cur, cur_ln = a3, new_ln(lp + "output.LayerNorm")
+        cache.len = past + 1
+        if past == 0:
+            cache.cross_ready = True
+        c = p + "cls.predictions."
+        t = ops.gemm_skinny(cur, st.w16(c + "transform.dense.weight"), bias=st.f32(c + "transform.dense.bias"), act=1, ln_a=ln_a(cur_ln))
+        # the vocabulary projection runs 1875 workgroups: normalising the activations in each of them costs more than one LayerNorm launch
+        tn, _ = ops.layernorm(t, st.f32(c + "transform.LayerNorm.weight"), st.f32(c + "transform.LayerNorm.bias"), eps)
+        return ops.gemm_skinny(tn, st.w16(p + "bert.embeddings.word_embeddings.weight"), bias=st.f32(c + "bias"), out_f32=True)
 
     # ------------------------------------------------------------------------------------------ CXR-BERT stand-in head
     def cls_projection(self, hidden, prefix=""):

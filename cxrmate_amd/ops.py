@@ -558,41 +558,56 @@ def cosine_rows(a, b, eps=1e-8):
     return out
 
 
-def gemm_skinny(a, w, bias=None, residual=None, act=0, out=None, out_f32=False, drop=None):
+def _ln_args(ln):
+    """ln = None | (gamma, beta, eps, stats_out | None) -> the four A-operand LayerNorm arguments of the skinny GEMM entry points"""
+    if ln is None:
+        return None, None, 0.0, None
+    return _p(ln[0]), _p(ln[1]), float(ln[2]), _p(ln[3])
+
+
+def gemm_skinny(a, w, bias=None, residual=None, act=0, out=None, out_f32=False, drop=None, ln_a=None, ln_r=None):
     """Decode-step linear: a [M<=64, K] @ w[N, K]^T (+bias, GELU, dropout, +residual). Weight-streaming kernel (no LDS staging).
-    drop = (p, seed, site, t): train-mode dropout of the dense output, row m = sequence m at absolute position t."""
+    drop = (p, seed, site, t): train-mode dropout of the dense output, row m = sequence m at absolute position t.
+    ln_a = (gamma, beta, eps, stats_out): `a` is a raw pre-LayerNorm sum, normalised inside the kernel (row statistics published to stats_out
+    fp32 [M,2]); ln_r = (stats, gamma, beta): the residual is LayerNorm(residual) with published statistics."""
     M, K = a.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else BF16)
     LIB.call("cxr_gemm_skinny_bf16", _p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias), _p(residual),
-             residual.stride(0) if residual is not None else 0, M, N, K, int(act), int(out_f32), *_drop_args(drop), _s())
+             residual.stride(0) if residual is not None else 0, M, N, K, int(act), int(out_f32), *_ln_args(ln_a),
+             *((_p(ln_r[0]), _p(ln_r[1]), _p(ln_r[2])) if ln_r is not None else (None, None, None)), *_drop_args(drop), _s())
     return out
 
 
-def attention_decode(q, k, v, heads, scale, kpm=None, out=None, drop=None):
+def attention_decode(q, k, v, heads, scale, kpm=None, out=None, drop=None, head_major=False):
     """q [B,1,H*64] (or [B,H*64]); k, v [B or B/2,Tk,H*64] views (batch/row strides free) -> [B, H*64]. With B/2 K/V rows, query rows
     b and b + B/2 share K/V row b."""
     B = q.shape[0]
     share = B // k.shape[0]
     assert k.shape[0] * share == B and share in (1, 2)
+    if head_major:                         # k, v [Bkv, H, Tk, 64] contiguous: every (b, h) K/V stream is one contiguous block
+        Tk = k.shape[2]
+        k_bs, k_rs, v_bs, v_rs, hs = k.stride(0), k.stride(2), v.stride(0), v.stride(2), k.stride(1)
+    else:
+        Tk = k.shape[1]
+        k_bs, k_rs, v_bs, v_rs, hs = k.stride(0), k.stride(1), v.stride(0), v.stride(1), 64
     key = ("attn_decode_ws", _s(), B * heads, q.device)
     ws = _DW_WS.get(key)
     if ws is None:
         ws = _DW_WS[key] = torch.empty(B * heads * 8 * 66, device=q.device, dtype=torch.float32)
     D = heads * 64
-    Tk = k.shape[1]
     if out is None:
         out = torch.empty((B, D), device=q.device, dtype=BF16)
-    LIB.call("cxr_attn_decode_bf16", _p(q), _p(k), _p(v), _p(out), _p(kpm), q.stride(0), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-             out.stride(0), kpm.stride(0) if kpm is not None else 0, B, heads, Tk, float(scale), share, _p(ws), *_drop_args(drop), _s())
+    LIB.call("cxr_attn_decode_bf16", _p(q), _p(k), _p(v), _p(out), _p(kpm), q.stride(0), k_bs, k_rs, v_bs, v_rs,
+             out.stride(0), kpm.stride(0) if kpm is not None else 0, B, heads, Tk, float(scale), share, _p(ws), int(hs), *_drop_args(drop), _s())
     return out
 
 
-def gemm_skinny3(a, w0, b0, c0, w1, b1, c1, w2, b2, c2):
+def gemm_skinny3(a, w0, b0, c0, w1, b1, c1, w2, b2, c2, ln_a=None):
     """c_i = a @ w_i^T + b_i for three equally-shaped projections in ONE launch (outputs may be strided KV-cache rows)."""
     M, K = a.shape
     N = w0.shape[0]
     assert w0.stride(0) == w1.stride(0) == w2.stride(0)
     LIB.call("cxr_gemm_skinny3_bf16", _p(a), a.stride(0), _p(w0), _p(b0), _p(c0), c0.stride(0), _p(w1), _p(b1), _p(c1), c1.stride(0),
-             _p(w2), _p(b2), _p(c2), c2.stride(0), w0.stride(0), M, N, K, _s())
+             _p(w2), _p(b2), _p(c2), c2.stride(0), w0.stride(0), M, N, K, *_ln_args(ln_a), _s())

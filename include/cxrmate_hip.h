@@ -139,18 +139,23 @@ int cxr_gather_batch_bf16(const void* in, long in_bs, long in_rs, void* out, lon
 /* decode-step (one new token per row) kernels: weight-streaming GEMM for M <= 64 rows (K % 128 == 0) and single-query attention over
  * the KV cache / the cross-attention K,V (TF5:bert:164-203,230-279 with a cache, q length 1) */
 int cxr_gemm_skinny_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias, const void* residual, long ldr,
-                         int M, int N, int K, int act, int out_f32, float drop_p, const unsigned int* drop_seed, unsigned int drop_site,
-                         int drop_t, hipStream_t stream);   /* drop_p > 0: dropout of the dense output before the residual, rows = sequences
-                                                               at absolute position drop_t (same hash as cxr_dropout_add_bf16) */
+                         int M, int N, int K, int act, int out_f32, const float* lnA_gamma, const float* lnA_beta, float lnA_eps,
+                         float* lnA_stats, const float* lnR_stats, const float* lnR_gamma, const float* lnR_beta, float drop_p,
+                         const unsigned int* drop_seed, unsigned int drop_site, int drop_t, hipStream_t stream);
+                         /* lnA_gamma != NULL (K == 768): A is a RAW pre-LayerNorm sum, normalised on the fly (TF5:bert:292,350,478); (mean, rstd)
+                            per row are published to lnA_stats [M][2]. lnR_stats != NULL: the residual is LayerNorm(residual) with those published
+                            statistics. drop_p > 0: dropout of the dense output before the residual, rows = sequences at absolute position
+                            drop_t (same hash as cxr_dropout_add_bf16) */
 int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, const float* b0, void* C0, long ldc0, const void* W1, const float* b1,
                           void* C1, long ldc1, const void* W2, const float* b2, void* C2, long ldc2, long ldw, int M, int N, int K,
-                          hipStream_t stream);   /* q / k / v projections of one decode step in a single launch */
+                          const float* lnA_gamma, const float* lnA_beta, float lnA_eps, float* lnA_stats, hipStream_t stream);
+                          /* q / k / v projections of one decode step in a single launch */
 int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs, long v_bs,
-                         long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, int kv_share, float* ws, float drop_p,
+                         long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, int kv_share, float* ws, long kv_hs, float drop_p,
                          const unsigned int* drop_seed, unsigned int drop_site, int drop_t, hipStream_t stream);
                          /* kv_share = 2: K, V, kpm have B/2 rows and query rows b, b + B/2 read row b (sample + greedy halves of one SCST step
                             share the cross-attention K/V); ws (optional, B*H*8*66 fp32): lets the launch split long key ranges over workgroups
-                            (flash-decoding) + a merge kernel; drop_t = absolute position of the query */
+                            (flash-decoding) + a merge kernel; kv_hs = head stride of K/V in elements (64 for [B,T,H*64], T*64 for head-major [B,H,T,64]); drop_t = absolute position of the query */
 int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, long* inds, hipStream_t stream);
 
 /* ---- reward (REF:tools/rewards/cxrbert.py:66-71 torch.nn.functional.cosine_similarity of the CLS projections) ---------------- */

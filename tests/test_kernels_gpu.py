@@ -296,6 +296,32 @@ def test_gemm_skinny_decode(ops, M, N, K):
     assert bool((cache[:, 2, :] == 0).all())
 
 
+@pytest.mark.parametrize("M", [1, 16, 32, 50])
+def test_gemm_skinny_fused_layernorm(ops, M):
+    """LayerNorm folded into the decode GEMMs: `ln_a` normalises the raw A rows inside the kernel and publishes (mean, rstd);
+    `ln_r` applies the same LayerNorm to the residual operand."""
+    K, N = 768, 768
+    raw = dev((rnd(M, K) * 2 + 0.3).to(BF))
+    w, bias = dev(rnd(N, K, seed=1, scale=0.05).to(BF)), dev(rnd(N, seed=2))
+    g, b = dev(1 + 0.1 * rnd(K, seed=3)), dev(0.1 * rnd(K, seed=4))
+    ln = torch.nn.functional.layer_norm(raw.float(), (K,), g, b, 1e-12)
+    stats = torch.zeros(M, 2, device="cuda")
+    out = ops.gemm_skinny(raw, w, bias=bias, act=1, ln_a=(g, b, 1e-12, stats))
+    ref = torch.nn.functional.gelu(ln.to(BF).float() @ w.float().t() + bias)
+    close(out, ref, what="skinny ln_a")
+    close(stats[:, 0], raw.float().mean(1), rtol=1e-4, atol=1e-4, what="published mean")
+    close(stats[:, 1], (raw.float().var(1, unbiased=False) + 1e-12).rsqrt(), rtol=1e-4, atol=1e-4, what="published rstd")
+    y, _ = ops.layernorm(raw, g, b, 1e-12)
+    close(out, ops.gemm_skinny(y, w, bias=bias, act=1), rtol=5e-3, atol=5e-3, what="fused vs separate LayerNorm kernel")
+    x2 = dev(rnd(M, K, seed=5).to(BF))
+    out2 = ops.gemm_skinny(x2, w, bias=bias, residual=raw, ln_r=(stats, g, b))
+    close(out2, x2.float() @ w.float().t() + bias + ln, what="skinny ln_r")
+    q, k, v = (torch.empty(M, N, dtype=BF, device="cuda") for _ in range(3))
+    ops.gemm_skinny3(raw, w, bias, q, w, None, k, w, bias, v, ln_a=(g, b, 1e-12, None))
+    close(q, ln.to(BF).float() @ w.float().t() + bias, what="skinny3 ln_a")
+    close(k, ln.to(BF).float() @ w.float().t(), what="skinny3 ln_a (no bias)")
+
+
 @pytest.mark.parametrize("B,H,Tk,masked", [(16, 12, 1152, True), (3, 12, 7, False), (2, 12, 261, True), (64, 12, 100, False)])
 def test_attention_decode_single_query(ops, B, H, Tk, masked):
     D = H * 64
