@@ -72,7 +72,8 @@ extern "C" int cxr_topk_rows(const float* x, long ld, long R, int n, int K, floa
 // Weight-streaming regime (cdna_hip_programming.md section 5, "GEMV / M <= 16 decode weights"): every W element is read exactly once
 // chip-wide, straight from HBM/L2 into MFMA B fragments (no LDS round trip); a workgroup owns 16 output columns, its 4 waves split K
 // and combine through LDS; all of a wave's loads are issued before its first MFMA (deep memory-level parallelism instead of occupancy).
-struct SkinnyProb { const bf16_t* W; const float* bias; void* C; long ldw, ldc; int N; };
+struct SkinnyProb { const bf16_t* W; const float* bias; void* C; long ldw, ldc; int N;
+                    const float* lr_t; const bf16_t* lr_B; };     // optional rank-8 term: C[m,n] += sum_r lr_t[m][r] * lr_B[n][r]  (LoRA, train mode)
 struct SkinnyArgs {
     const bf16_t* A; long lda;
     const bf16_t* residual; long ldr;      // added to problem 0 only
@@ -213,6 +214,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs g) {
             const int m = t * 16 + fq * 4 + r;                       // D[m][n]: lane owns column n, rows (lane>>4)*4 + r
             if (m >= g.M) continue;
             float v = red[0][t][lane][r] + red[1][t][lane][r] + red[2][t][lane][r] + red[3][t][lane][r] + bv;
+            if (P.lr_t) {
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) v += P.lr_t[m * 8 + r8] * bf2f(P.lr_B[(long)n * 8 + r8]);
+            }
             if (g.act == 1) v = gelu_f(v);
             if (g.drop_thr16)
                 v = dropout_keep(dropout_row_key(*g.drop_seed, g.drop_site, (uint32_t)m, (uint32_t)g.drop_t), (uint32_t)n, g.drop_thr16) ? v * g.drop_inv : 0.f;
@@ -251,6 +256,7 @@ extern "C" int cxr_gemm_skinny_bf16(const void* A, long lda, const void* W, long
     g.lnR_stats = lnR_stats; g.lnR_g = lnR_gamma; g.lnR_b = lnR_beta;
     g.A = (const bf16_t*)A; g.lda = lda; g.residual = (const bf16_t*)residual; g.ldr = ldr;
     g.p[0].W = (const bf16_t*)W; g.p[0].bias = bias; g.p[0].C = C; g.p[0].ldw = ldw; g.p[0].ldc = ldc; g.p[0].N = N;
+    g.p[0].lr_t = nullptr; g.p[0].lr_B = nullptr;
     g.p[1] = g.p[0]; g.p[2] = g.p[0];
     g.nprob = 1; g.M = M; g.K = K; g.act = act; g.out_f32 = out_f32;
     return launch_skinny(g, stream);
@@ -260,7 +266,7 @@ extern "C" int cxr_gemm_skinny_bf16(const void* A, long lda, const void* W, long
 extern "C" int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, const float* b0, void* C0, long ldc0, const void* W1,
                                      const float* b1, void* C1, long ldc1, const void* W2, const float* b2, void* C2, long ldc2, long ldw,
                                      int M, int N, int K, const float* lnA_gamma, const float* lnA_beta, float lnA_eps, float* lnA_stats,
-                                     hipStream_t stream) {
+                                     const float* lr_t0, const void* lr_B0, const float* lr_t1, const void* lr_B1, hipStream_t stream) {
     if (M <= 0 || M > 64 || N <= 0 || K <= 0 || (K % 128) || (lda % 8) || (ldw % 8)) return CXR_ERR_ARG;
     SkinnyArgs g;
     g.drop_seed = nullptr; g.drop_site = 0; g.drop_thr16 = 0; g.drop_inv = 1.f; g.drop_t = 0;
@@ -269,7 +275,9 @@ extern "C" int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, co
     g.lnR_stats = nullptr; g.lnR_g = nullptr; g.lnR_b = nullptr;
     g.A = (const bf16_t*)A; g.lda = lda; g.residual = nullptr; g.ldr = 0;
     const void* W[3] = {W0, W1, W2}; const float* b[3] = {b0, b1, b2}; void* C[3] = {C0, C1, C2}; const long ldc[3] = {ldc0, ldc1, ldc2};
-    for (int i = 0; i < 3; ++i) { g.p[i].W = (const bf16_t*)W[i]; g.p[i].bias = b[i]; g.p[i].C = C[i]; g.p[i].ldw = ldw; g.p[i].ldc = ldc[i]; g.p[i].N = N; }
+    for (int i = 0; i < 3; ++i) { g.p[i].W = (const bf16_t*)W[i]; g.p[i].bias = b[i]; g.p[i].C = C[i]; g.p[i].ldw = ldw; g.p[i].ldc = ldc[i]; g.p[i].N = N;
+                                  g.p[i].lr_t = nullptr; g.p[i].lr_B = nullptr; }
+    g.p[0].lr_t = lr_t0; g.p[0].lr_B = (const bf16_t*)lr_B0; g.p[1].lr_t = lr_t1; g.p[1].lr_B = (const bf16_t*)lr_B1;     // LoRA on query / key
     g.nprob = 3; g.M = M; g.K = K; g.act = 0; g.out_f32 = 0;
     return launch_skinny(g, stream);
 }

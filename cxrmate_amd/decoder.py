@@ -4,7 +4,8 @@ KV-cached decode steps over the HIP kernels. Also runs the bidirectional CXR-BER
 Mirrors transformers' BertLMHeadModel as driven by the reference forward()
 (modules/transformers/longitudinal_model/modelling_longitudinal.py:212-224; TF5 = transformers/models/bert/modeling_bert.py
 @ 5.15.0: embeddings :70-108, eager attention :111-136, layers :374-411, LM head :466-496). LoRA on self-attention query/key
-(modelling_longitudinal.py:163-170) is merged into the effective weight W + (alpha/r) B A before the GEMM (lora_dropout is identity).
+(modelling_longitudinal.py:163-170) is merged into the effective weight W + (alpha/r) B A before the GEMM in eval mode; under
+model.train() its lora_dropout (0.1 on the branch input) forbids the merge and the rank-8 branch runs beside the base GEMM (csrc/lora.hip).
 
 Train mode (`store.training`, i.e. after model.train()): nn.Dropout(hidden_dropout_prob) after the embedding LayerNorm and after the
 attention-output / cross-attention-output / FFN-output dense layers, nn.Dropout(attention_probs_dropout_prob) on the attention
@@ -25,7 +26,7 @@ SITE_EMBED = 1
 
 def _site(layer, k):
     """Dropout site ids of decoder layer `layer`: k = 0 self-attention probabilities, 1 self-attention output, 2 cross-attention
-    probabilities, 3 cross-attention output, 4 FFN output."""
+    probabilities, 3 cross-attention output, 4 FFN output, 5 / 6 LoRA input of the self-attention query / key."""
     return 16 + 8 * layer + k
 
 
@@ -59,6 +60,7 @@ class BertEngine:
         self._prep_version = -1
         self._prep = {}
         self._wt_ready = False
+        self._wtb_ready = False
 
     # ------------------------------------------------------------------------------------------ parameters
     def _lin(self, base):
@@ -89,6 +91,7 @@ class BertEngine:
                     prep[("lora", base)] = ops.cast_to_bf16(w, prep.get(("lora", base)))
         self._prep, self._prep_version = prep, st.shadow_version
         self._wt_ready = False
+        self._wtb_ready = False
         return prep
 
     def _linear_names(self):
@@ -102,9 +105,17 @@ class BertEngine:
             names += [lp + "intermediate.dense", lp + "output.dense"]
         return names
 
-    def _prepare_transposes(self):
+    def _prepare_transposes(self, lora_tr=False):
         """W^T of every Linear (+ the padded word-embedding transpose for the LM-head dX) for the current weight version, issued on
-        the weight-gradient side stream during the training forward (off the critical path); backward joins it."""
+        the weight-gradient side stream during the training forward (off the critical path); backward joins it. lora_tr: the LoRA-wrapped
+        projections need the transpose of their BASE weight (train mode does not merge), kept under ("wtb", base)."""
+        if lora_tr and not self._wtb_ready:
+            st, prep = self.s, self._prep
+            with ops._on_wgrad_stream():
+                for base in self._linear_names():
+                    if not st.has(base + ".weight"):
+                        prep[("wtb", base)] = ops.transpose(st.w16(base + ".base_layer.weight"), out=prep.get(("wtb", base)))
+            self._wtb_ready = True
         if self._wt_ready:
             return
         st, prep, p = self.s, self._prep, self.p
@@ -119,12 +130,22 @@ class BertEngine:
         self._wt_ready = True
 
     # ------------------------------------------------------------------------------------------ teacher-forced forward
+    def _lora_parts(self, base):
+        """(base weight bf16, bias fp32, lora_A bf16 [r,K], lora_B bf16 [N,r]) of a LoRA-wrapped Linear"""
+        st = self.s
+        return (st.w16(base + ".base_layer.weight"), st.f32(base + ".base_layer.bias"), st.w16(base + ".lora_A.default.weight"),
+                st.w16(base + ".lora_B.default.weight"))
+
+    def _lora_train(self, train):
+        train = bool(self.s.training) if train is None else bool(train)
+        return bool(self.cfg.lora_r) and train and self.cfg.lora_dropout > 0.0
+
     def _dropout_cfg(self, train, seed):
         """-> (p_hidden, p_attn, seed tensor) of this pass; zeros in eval mode."""
         train = bool(self.s.training) if train is None else bool(train)
         ph = float(self.cfg.hidden_dropout_prob) if train else 0.0
         pa = float(self.cfg.attention_probs_dropout_prob) if train else 0.0
-        if (ph > 0.0 or pa > 0.0) and seed is None:
+        if (ph > 0.0 or pa > 0.0 or self._lora_train(train)) and seed is None:
             seed = self.s.next_dropout_seed()
         return ph, pa, seed
 
@@ -134,12 +155,14 @@ class BertEngine:
         train (default: the store's nn.Module flag) enables dropout; seed: device int32 [1] to REPRODUCE the masks of an earlier pass."""
         cfg, st, p = self.cfg, self.s, self.p
         self.prepare()
+        lora_tr = self._lora_train(train)
         if save:
-            self._prepare_transposes()
+            self._prepare_transposes(lora_tr)
         B, T = ids.shape
         D, nh = cfg.hidden_size, cfg.num_attention_heads
         R = B * T
         ph, pa, seed = self._dropout_cfg(train, seed)
+        pl, ls = float(cfg.lora_dropout), (cfg.lora_alpha / cfg.lora_r if cfg.lora_r else 0.0)
         e = p + "bert.embeddings."
         h, esum, estats = ops.bert_embed(ids, token_type_ids, position_ids, st.w16(e + "word_embeddings.weight"),
                                          st.w16(e + "token_type_embeddings.weight"), st.w16(e + "position_embeddings.weight"),
@@ -147,7 +170,7 @@ class BertEngine:
         if ph:
             ops.dropout_add(h, None, ph, seed, SITE_EMBED, T, out=h)
         saved = dict(B=B, T=T, ids=ids, tt=token_type_ids, pos=position_ids, esum=esum, estats=estats, attn_mask=attn_mask, enc=enc,
-                     enc_mask=enc_mask, causal=causal, layers=[], ph=ph, pa=pa, seed=seed) if save else None
+                     enc_mask=enc_mask, causal=causal, layers=[], ph=ph, pa=pa, seed=seed, lora_tr=lora_tr) if save else None
         scale = cfg.head_dim ** -0.5
 
         def out_proj(x, w, b, resid, site):
@@ -159,9 +182,19 @@ class BertEngine:
         for l in range(cfg.num_hidden_layers):
             lp = p + f"bert.encoder.layer.{l}."
             sv = {}
-            wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key"); wv, bv = self._lin(lp + "attention.self.value")
-            q = ops.gemm_nt(h, wq, bias=bq).view(B, T, D)
-            k = ops.gemm_nt(h, wk, bias=bk).view(B, T, D)
+            wv, bv = self._lin(lp + "attention.self.value")
+            if lora_tr:
+                # peft Linear under train(): base(x) + (alpha/r) * B(A(dropout(x))): base GEMM + rank-8 branch (one launch for q and k)
+                wq, bq, aq, bq_l = self._lora_parts(lp + "attention.self.query"); wk, bk, ak, bk_l = self._lora_parts(lp + "attention.self.key")
+                tq, tk = ops.lora_down(h, aq, drop0=(pl, _site(l, 5)), W1=ak, drop1=(pl, _site(l, 6)), rows_per_b=T, seed=seed, scale=ls)
+                q = ops.lora_up_add_(ops.gemm_nt(h, wq, bias=bq), tq, bq_l, True).view(B, T, D)
+                k = ops.lora_up_add_(ops.gemm_nt(h, wk, bias=bk), tk, bk_l, True).view(B, T, D)
+                if save:
+                    sv.update(tq=tq, tk=tk)
+            else:
+                wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key")
+                q = ops.gemm_nt(h, wq, bias=bq).view(B, T, D)
+                k = ops.gemm_nt(h, wk, bias=bk).view(B, T, D)
             v = ops.gemm_nt(h, wv, bias=bv).view(B, T, D)
             ctx, lse = ops.attention(q, k, v, nh, scale, kpm=attn_mask, causal=causal, need_lse=save, drop=(pa, seed, _site(l, 0), 0))
             wo, bo = self._lin(lp + "attention.output.dense")
@@ -231,15 +264,31 @@ class BertEngine:
         bt = ops.transpose(st.w16(base + ".lora_B.default.weight"))                 # [r, d]
         ops.gemm_nt(bt, ops.transpose(dw16), out=st.grad(base + ".lora_A.default.weight"), out_f32=True, accumulate=True, alpha=scale)
 
-    def _wt(self, base):
+    def _wt(self, base, lora_tr=False):
+        if lora_tr and ("wtb", base) in self._prep:
+            return self._prep[("wtb", base)]
         return self._prep[("wt", base)]
+
+    def _wgrad_lora_train(self, base, dy, x, t, site, T, seed):
+        """Train-mode LoRA Linear y = base(x) + t B^T, t = s * dropout(x) A^T: parameter gradients; returns dt = s * dy B  [R, 8]."""
+        st, cfg = self.s, self.cfg
+        s_ = cfg.lora_alpha / cfg.lora_r
+        ops.linear_bwd_weight(dy, x, st.grad(base + ".base_layer.weight"), st.grad(base + ".base_layer.bias"))
+        B_l, A_l = st.w16(base + ".lora_B.default.weight"), st.w16(base + ".lora_A.default.weight")
+        dt = ops.lora_down(dy, B_l, w_is_b=True, scale=s_)
+        with ops._on_wgrad_stream(dy, x, t, dt):
+            ops.lora_outer_into(dy, t, st.grad(base + ".lora_B.default.weight"), cfg.lora_r, 1)                       # dB[n,r] += sum dy[m,n] t[m,r]
+            ops.lora_outer_into(x, dt, st.grad(base + ".lora_A.default.weight"), 1, x.shape[1],                       # dA[r,k] += sum drop(x)[m,k] dt[m,r]
+                                drop=(cfg.lora_dropout, site), rows_per_b=T, seed=seed)
+        return dt
 
     def backward(self, saved, dlogits=None, dhidden=None, need_denc=False):
         """dlogits bf16 [R, V] (row stride may be padded to a multiple of 64) or dhidden bf16 [R, D]. Accumulates parameter
         gradients into the store; returns d(enc) bf16 [B,S,D] when need_denc."""
         cfg, st, p = self.cfg, self.s, self.p
         self.prepare()
-        self._prepare_transposes()
+        lora_tr = bool(saved.get("lora_tr"))
+        self._prepare_transposes(lora_tr)
         ops.wgrad_join()                                                # transposed weights (side stream) are ready
         st.ensure_grads()
         B, T = saved["B"], saved["T"]
@@ -310,12 +359,20 @@ class BertEngine:
             dctx = ops.gemm_nt(dd1, self._wt(lp + "attention.output.dense")).view(B, T, D)
             dq, dk, dv = ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, scale, kpm=saved["attn_mask"],
                                            causal=saved["causal"], drop=(pa, seed, _site(l, 0), 0))
-            self._wgrad(lp + "attention.self.query", dq.view(R, D), sv["h"])
-            self._wgrad(lp + "attention.self.key", dk.view(R, D), sv["h"])
+            if lora_tr:
+                dtq = self._wgrad_lora_train(lp + "attention.self.query", dq.view(R, D), sv["h"], sv["tq"], _site(l, 5), T, seed)
+                dtk = self._wgrad_lora_train(lp + "attention.self.key", dk.view(R, D), sv["h"], sv["tk"], _site(l, 6), T, seed)
+            else:
+                self._wgrad(lp + "attention.self.query", dq.view(R, D), sv["h"])
+                self._wgrad(lp + "attention.self.key", dk.view(R, D), sv["h"])
             self._wgrad(lp + "attention.self.value", dv.view(R, D), sv["h"])
-            t1 = ops.gemm_nt(dq.view(R, D), self._wt(lp + "attention.self.query"), residual=da1)
-            t2 = ops.gemm_nt(dk.view(R, D), self._wt(lp + "attention.self.key"), residual=t1)
+            t1 = ops.gemm_nt(dq.view(R, D), self._wt(lp + "attention.self.query", lora_tr), residual=da1)
+            t2 = ops.gemm_nt(dk.view(R, D), self._wt(lp + "attention.self.key", lora_tr), residual=t1)
             dh = ops.gemm_nt(dv.view(R, D), self._wt(lp + "attention.self.value"), residual=t2)
+            if lora_tr:                                                  # dx += dropout-mask * (dt A) of both LoRA branches
+                pl = cfg.lora_dropout
+                ops.lora_up_add_(dh, dtq, st.w16(lp + "attention.self.query.lora_A.default.weight"), False, drop=(pl, _site(l, 5)), rows_per_b=T, seed=seed)
+                ops.lora_up_add_(dh, dtk, st.w16(lp + "attention.self.key.lora_A.default.weight"), False, drop=(pl, _site(l, 6)), rows_per_b=T, seed=seed)
         e = p + "bert.embeddings."
         dh = undrop(dh, SITE_EMBED)
         dsum = ops.layernorm_bwd(saved["esum"], dh, st.f32(e + "LayerNorm.weight"), saved["estats"], g(e + "LayerNorm.weight"), g(e + "LayerNorm.bias"))
@@ -349,8 +406,10 @@ class BertEngine:
             ops.dropout_add(h, None, ph, seed, SITE_EMBED, Tn, t0=past, out=h)
         scale = cfg.head_dim ** -0.5
         single = Tn == 1 and B <= 64          # one new token per row: weight-streaming GEMMs + single-query attention kernels
+        lora_tr = self._lora_train(train)
+        pl, ls = float(cfg.lora_dropout), (cfg.lora_alpha / cfg.lora_r if cfg.lora_r else 0.0)
         if single and D == 768 and self.fuse_decode_layernorm:
-            return self._decode_single_fused(cache, h, enc, enc_mask, attn_mask_full, past, ph, pa, seed)
+            return self._decode_single_fused(cache, h, enc, enc_mask, attn_mask_full, past, ph, pa, seed, lora_tr)
         lin = (lambda x, w, **kw: ops.gemm_skinny(x, w, **kw)) if single else (lambda x, w, **kw: ops.gemm_nt(x, w, **kw))
 
         def out_lin(x, w, b, resid, site):
@@ -363,10 +422,22 @@ class BertEngine:
 
         for l in range(cfg.num_hidden_layers):
             lp = p + f"bert.encoder.layer.{l}."
-            wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key"); wv, bv = self._lin(lp + "attention.self.value")
+            wv, bv = self._lin(lp + "attention.self.value")
+            lq = lk = None
+            if lora_tr:                                                       # train mode: base weights + rank-8 branch on dropout(h)
+                wq, bq, aq, bq_l = self._lora_parts(lp + "attention.self.query"); wk, bk, ak, bk_l = self._lora_parts(lp + "attention.self.key")
+                tq, tk = ops.lora_down(h, aq, drop0=(pl, _site(l, 5)), W1=ak, drop1=(pl, _site(l, 6)), rows_per_b=Tn, tpos0=past, seed=seed, scale=ls)
+                lq, lk = (tq, bq_l), (tk, bk_l)
+            else:
+                wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key")
             if single:                                                        # q, k, v in one launch; k/v straight into their cache rows
                 q = torch.empty((B, 1, D), dtype=BF16, device=h.device)
-                ops.gemm_skinny3(h, wq, bq, q.view(B, D), wk, bk, cache.k[l][:, past, :], wv, bv, cache.v[l][:, past, :])
+                ops.gemm_skinny3(h, wq, bq, q.view(B, D), wk, bk, cache.k[l][:, past, :], wv, bv, cache.v[l][:, past, :], lora0=lq, lora1=lk)
+            elif lora_tr:
+                q = ops.lora_up_add_(ops.gemm_nt(h, wq, bias=bq), tq, bq_l, True).view(B, Tn, D)
+                kf = ops.lora_up_add_(ops.gemm_nt(h, wk, bias=bk), tk, bk_l, True)
+                ops.copy_rows(kf.view(B, Tn, D), cache.k[l][:, past:past + Tn, :])
+                ops.copy_rows(ops.gemm_nt(h, wv, bias=bv).view(B, Tn, D), cache.v[l][:, past:past + Tn, :])
             elif Tn == 1:
                 q = lin(h, wq, bias=bq).view(B, Tn, D)
                 lin(h, wk, bias=bk, out=cache.k[l][:, past, :])
@@ -426,7 +497,7 @@ class BertEngine:
 
     fuse_decode_layernorm = True
 
-    def _decode_single_fused(self, cache, h, enc, enc_mask, attn_mask_full, past, ph, pa, seed):
+    def _decode_single_fused(self, cache, h, enc, enc_mask, attn_mask_full, past, ph, pa, seed, lora_tr=False):
         """One token per row with every LayerNorm folded into its consumers: a decode step is launch-bound (~85 short kernels), and the
         weight-streaming GEMM holds its whole slice of the activations in registers, so it normalises them itself (`ln_a`) and publishes
         the row statistics for the later residual use of the same LayerNorm output (`ln_r`). 19 launches per token disappear.
@@ -451,9 +522,18 @@ class BertEngine:
 
         for l in range(cfg.num_hidden_layers):
             lp = p + f"bert.encoder.layer.{l}."
-            wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key"); wv, bv = self._lin(lp + "attention.self.value")
+            wv, bv = self._lin(lp + "attention.self.value")
+            lq = lk = None
+            if lora_tr:              # train mode: base weights; the rank-8 branch on dropout(LayerNorm(cur)) enters through the GEMM epilogue
+                wq, bq, aq, bq_l = self._lora_parts(lp + "attention.self.query"); wk, bk, ak, bk_l = self._lora_parts(lp + "attention.self.key")
+                pl = float(cfg.lora_dropout)
+                tq, tk = ops.lora_down(cur, aq, drop0=(pl, _site(l, 5)), W1=ak, drop1=(pl, _site(l, 6)), rows_per_b=1, tpos0=past, seed=seed,
+                                       ln=None if cur_ln is None else (cur_ln[0], cur_ln[1], eps), scale=cfg.lora_alpha / cfg.lora_r)
+                lq, lk = (tq, bq_l), (tk, bk_l)
+            else:
+                wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key")
             q = torch.empty((B, D), dtype=BF16, device=dev)
-            ops.gemm_skinny3(cur, wq, bq, q, wk, bk, cache.k[l][:, past, :], wv, bv, cache.v[l][:, past, :], ln_a=ln_a(cur_ln))
+            ops.gemm_skinny3(cur, wq, bq, q, wk, bk, cache.k[l][:, past, :], wv, bv, cache.v[l][:, past, :], ln_a=ln_a(cur_ln), lora0=lq, lora1=lk)
             ctx = ops.attention_decode(q, cache.k[l][:, :past + 1, :], cache.v[l][:, :past + 1, :], nh, scale, kpm=attn_mask_full,
                                        drop=(pa, seed, _site(l, 0), past))
             wo, bo = self._lin(lp + "attention.output.dense")

@@ -604,10 +604,43 @@ def attention_decode(q, k, v, heads, scale, kpm=None, out=None, drop=None, head_
     return out
 
 
-def gemm_skinny3(a, w0, b0, c0, w1, b1, c1, w2, b2, c2, ln_a=None):
+def gemm_skinny3(a, w0, b0, c0, w1, b1, c1, w2, b2, c2, ln_a=None, lora0=None, lora1=None):
     """c_i = a @ w_i^T + b_i for three equally-shaped projections in ONE launch (outputs may be strided KV-cache rows)."""
     M, K = a.shape
     N = w0.shape[0]
     assert w0.stride(0) == w1.stride(0) == w2.stride(0)
     LIB.call("cxr_gemm_skinny3_bf16", _p(a), a.stride(0), _p(w0), _p(b0), _p(c0), c0.stride(0), _p(w1), _p(b1), _p(c1), c1.stride(0),
-             _p(w2), _p(b2), _p(c2), c2.stride(0), w0.stride(0), M, N, K, *_ln_args(ln_a), _s())
+             _p(w2), _p(b2), _p(c2), c2.stride(0), w0.stride(0), M, N, K, *_ln_args(ln_a),
+             *((_p(lora0[0]), _p(lora0[1])) if lora0 else (None, None)), *((_p(lora1[0]), _p(lora1[1])) if lora1 else (None, None)), _s())
+
+
+# ------------------------------------------------------------------------------------------------ LoRA branch (train mode)
+def lora_down(x, W0, t0=None, drop0=None, W1=None, drop1=None, rows_per_b=1, tpos0=0, seed=None, ln=None, scale=1.0, w_is_b=False):
+    """t_i [M,8] fp32 = scale * dropout_i(x) @ A_i^T  (w_is_b: W_i is a lora_B [N,8] and the contraction runs over its rows: dy @ B).
+    drop_i = (p, site); ln = (gamma, beta, eps) normalises the raw rows first. One launch for both problems."""
+    M, K = x.shape
+    outs = [torch.empty((M, 8), device=x.device, dtype=torch.float32) for _ in range(2 if W1 is not None else 1)]
+    st = (lambda W: (1, W.stride(0))) if w_is_b else (lambda W: (W.stride(0), 1))
+    p0, s0 = drop0 if drop0 is not None else (0.0, 0)
+    p1, s1 = drop1 if drop1 is not None else (0.0, 0)
+    LIB.call("cxr_lora_down_bf16", _p(x), x.stride(0), M, K, _p(W0), *st(W0), _p(outs[0]), float(p0), int(s0),
+             _p(W1), *(st(W1) if W1 is not None else (0, 0)), _p(outs[1]) if W1 is not None else None, float(p1), int(s1), _p(seed),
+             int(rows_per_b), int(tpos0), _p(ln[0]) if ln else None, _p(ln[1]) if ln else None, float(ln[2]) if ln else 0.0, float(scale), _s())
+    return outs if W1 is not None else outs[0]
+
+
+def lora_up_add_(y, t, W, w_is_b, drop=None, rows_per_b=1, tpos0=0, seed=None):
+    """y[m,n] += f(m,n) * sum_r t[m,r] W(r,n) in place; W = lora_B [N,8] (w_is_b) or lora_A [8,N]; drop = (p, site) re-applies a mask."""
+    M, N = y.shape
+    rs, cs = (1, W.stride(0)) if w_is_b else (W.stride(0), 1)
+    p, site = drop if drop is not None else (0.0, 0)
+    LIB.call("cxr_lora_up_add_bf16", _p(y), y.stride(0), M, N, _p(t), _p(W), rs, cs, float(p), _p(seed), int(site), int(rows_per_b), int(tpos0), _s())
+    return y
+
+
+def lora_outer_into(a, t, G, g_ks, g_rs, scale=1.0, drop=None, rows_per_b=1, tpos0=0, seed=None):
+    """G[k*g_ks + r*g_rs] += scale * sum_m f(m,k) a[m,k] t[m,r]  (fp32 G; strides in elements)."""
+    M, K = a.shape
+    p, site = drop if drop is not None else (0.0, 0)
+    LIB.call("cxr_lora_outer_bf16", _p(a), a.stride(0), M, K, _p(t), _p(G), int(g_ks), int(g_rs), float(scale), float(p), _p(seed), int(site),
+             int(rows_per_b), int(tpos0), _s())

@@ -60,6 +60,21 @@ int cxr_dropout_add_bf16(const void* y, long ldy, const void* resid, long ldr, v
 int cxr_dropout_mask(unsigned char* mask, float* factor, long R, int C, float p, const unsigned int* seed, unsigned int site, int rows_per_b,
                      int t0, hipStream_t stream);
 
+/* ---- LoRA branch with dropout on its input (peft Linear in train mode; REF:modelling_longitudinal.py:163-170: r = 8, alpha = 32,
+ * lora_dropout = 0.1 on self-attention query / key):  y = base(x) + s * B(A(dropout(x))). Eval mode merges the branch into the weight; in
+ * train mode the three rank-8 contractions run here. W is addressed as W[r*w_rs + k*w_cs] (A: w_rs = K, w_cs = 1; B [N,8]: w_rs = 1, w_cs = 8);
+ * t is fp32 [M][8]; masks are the counter-based hash of cxr_dropout_mask (site, row / rows_per_b, tpos0 + row % rows_per_b, column).
+ *   down : t[m,r] = scale * sum_k f(m,k) x[m,k] W(r,k)   (two problems per launch: query and key; optional LayerNorm of the raw row x)
+ *   up   : y[m,n] += f(m,n) * sum_r t[m,r] W(r,n)         (forward with W = B, p = 0; backward dx with W = A and the forward mask)
+ *   outer: G[k*g_ks + r*g_rs] += scale * sum_m f(m,k) a[m,k] t[m,r]   (dB from (dy, t); dA from (x with the forward mask, dt)) */
+int cxr_lora_down_bf16(const void* x, long ldx, long M, int K, const void* W0, long w0_rs, long w0_cs, float* t0, float p0, unsigned int site0,
+                       const void* W1, long w1_rs, long w1_cs, float* t1, float p1, unsigned int site1, const unsigned int* seed, int rows_per_b,
+                       int tpos0, const float* ln_gamma, const float* ln_beta, float ln_eps, float scale, hipStream_t stream);
+int cxr_lora_up_add_bf16(void* y, long ldy, long M, int N, const float* t, const void* W, long w_rs, long w_cs, float p, const unsigned int* seed,
+                         unsigned int site, int rows_per_b, int tpos0, hipStream_t stream);
+int cxr_lora_outer_bf16(const void* a, long lda, long M, int K, const float* t, float* G, long g_ks, long g_rs, float scale, float p,
+                        const unsigned int* seed, unsigned int site, int rows_per_b, int tpos0, hipStream_t stream);
+
 /* ---- LayerNorm (TF5:cvt:79,363-364; REF:modelling_single.py:29; TF5:bert:103,292,350,478) ------------------------------- */
 int cxr_layernorm_fwd_bf16(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* stats, long rows, int C,
                            float eps, hipStream_t stream);           /* stats[rows][2] = (mean, rstd), optional */
@@ -148,8 +163,10 @@ int cxr_gemm_skinny_bf16(const void* A, long lda, const void* W, long ldw, void*
                             drop_t (same hash as cxr_dropout_add_bf16) */
 int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, const float* b0, void* C0, long ldc0, const void* W1, const float* b1,
                           void* C1, long ldc1, const void* W2, const float* b2, void* C2, long ldc2, long ldw, int M, int N, int K,
-                          const float* lnA_gamma, const float* lnA_beta, float lnA_eps, float* lnA_stats, hipStream_t stream);
-                          /* q / k / v projections of one decode step in a single launch */
+                          const float* lnA_gamma, const float* lnA_beta, float lnA_eps, float* lnA_stats, const float* lr_t0, const void* lr_B0,
+                          const float* lr_t1, const void* lr_B1, hipStream_t stream);
+                          /* q / k / v projections of one decode step in a single launch; lr_t_i fp32 [M][8] / lr_B_i bf16 [N][8]: optional
+                             rank-8 LoRA term of problem i (t from cxr_lora_down_bf16) */
 int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs, long v_bs,
                          long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, int kv_share, float* ws, long kv_hs, float drop_p,
                          const unsigned int* drop_seed, unsigned int drop_site, int drop_t, hipStream_t stream);

@@ -13,12 +13,14 @@ def _ln(x, sd, key, eps):
     return F.layer_norm(x, (x.shape[-1],), sd[key + ".weight"], sd[key + ".bias"], eps)
 
 
-def linear(x, sd, base, lora_scale=None):
-    """nn.Linear, or peft LoRA Linear: base(x) + B(A(x)) * (alpha / r)  (modelling_longitudinal.py:163-170; dropout off)."""
+def linear(x, sd, base, lora_scale=None, lora_drop=None):
+    """nn.Linear, or peft LoRA Linear: base(x) + B(A(dropout(x))) * (alpha / r)  (modelling_longitudinal.py:163-170); lora_drop = the
+    factor keep/(1-p) of lora_dropout in train mode (None = eval)."""
     if base + ".weight" in sd:
         return F.linear(x, sd[base + ".weight"], sd[base + ".bias"])
     y = F.linear(x, sd[base + ".base_layer.weight"], sd[base + ".base_layer.bias"])
-    return y + F.linear(F.linear(x, sd[base + ".lora_A.default.weight"]), sd[base + ".lora_B.default.weight"]) * lora_scale
+    xd = x if lora_drop is None else x * lora_drop
+    return y + F.linear(F.linear(xd, sd[base + ".lora_A.default.weight"]), sd[base + ".lora_B.default.weight"]) * lora_scale
 
 
 def _drop(x, dropout, site):
@@ -44,8 +46,9 @@ def attention(xq, xkv, sd, p, nh, add_mask, lora_scale=None, dropout=None, site=
     """TF5:bert:111-136,164-203,230-279  eager softmax(QK^T/sqrt(d) + mask) -> dropout (:131) -> .V"""
     b, tq, d = xq.shape
     hd = d // nh
-    q = linear(xq, sd, p + "self.query", lora_scale).view(b, tq, nh, hd).transpose(1, 2)
-    k = linear(xkv, sd, p + "self.key", lora_scale).view(b, -1, nh, hd).transpose(1, 2)
+    layer = site[0] if site is not None else None
+    q = linear(xq, sd, p + "self.query", lora_scale, None if dropout is None else dropout.get((layer, "lora_q"))).view(b, tq, nh, hd).transpose(1, 2)
+    k = linear(xkv, sd, p + "self.key", lora_scale, None if dropout is None else dropout.get((layer, "lora_k"))).view(b, -1, nh, hd).transpose(1, 2)
     v = linear(xkv, sd, p + "self.value", lora_scale).view(b, -1, nh, hd).transpose(1, 2)
     w = torch.matmul(q, k.transpose(2, 3)) * (hd ** -0.5)
     if add_mask is not None:

@@ -390,6 +390,88 @@ def fixture_tf_longitudinal():
     print("tf_longitudinal loss", loss.item())
 
 
+def fixture_tf_longitudinal_train():
+    """Longitudinal model (frozen encoder, LoRA r=8 on self-attention query/key) under .train(): LoRA dropout on the branch input,
+    decoder dropouts, train-mode BatchNorm / DropPath in the frozen encoder. Masks recorded as in tf_single_train.
+    torch.nn.functional.dropout calls arrive as: embeddings, then per layer lora(query), lora(key), self-probs, self-out, cross-probs,
+    cross-out, ffn-out."""
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, depth=(1, 2, 3), image_size=96, lora_r=8)
+    model, _ = build(LongitudinalPromptMultiCXREncoderDecoderModel, cfg, seed=18, perturb=0.05, longitudinal=True)
+    g = torch.Generator().manual_seed(103)
+    x = torch.randn(2, 2, 3, 96, 96, generator=g)
+    x[0, 1] = 0.0
+    prompt = make_prompt(g, 2, 1000, [9, 5])
+    full = rand_report_ids(g, 2, 14, 1000, [4, 6], [14, 10])
+    rep_attn = (full != PAD).long()
+    inp = torch.cat([prompt, full[:, :-1]], dim=1)
+    am = torch.cat([(prompt != PAD).long(), rep_attn[:, 1:]], dim=1)
+    lab = full[:, 1:].clone()
+    pos = torch.nn.functional.relu(torch.cumsum(am, dim=1) - 1)
+    tt = model.token_ids_to_token_type_ids(inp, [PMT_SEP, BOS, SEP], [0, 1, 0, 1])
+    for p_ in model.decoder.parameters():
+        p_.requires_grad_(True)
+    model.train()
+    import transformers.models.cvt.modeling_cvt as mcvt
+    orig_dropout = torch.nn.functional.dropout
+    drops, paths = [], []
+
+    def rec_dropout(inp_, p=0.5, training=True, inplace=False):
+        out = orig_dropout(inp_, p=p, training=training, inplace=False)
+        if training and p > 0.0:
+            drops.append((float(p), torch.where(inp_ != 0, out != 0, torch.ones_like(out, dtype=torch.bool)).detach().clone()))
+        return out
+
+    hooks = []
+    for n_, m_ in model.named_modules():
+        if isinstance(m_, mcvt.CvtDropPath) and m_.drop_prob > 0.0:
+            def hook(mod, args, out, name=n_):
+                i_ = args[0]
+                fi, fo = i_.reshape(i_.shape[0], -1), out.reshape(out.shape[0], -1)
+                j = fi.abs().argmax(1)
+                paths.append((name, float(mod.drop_prob), (fo[torch.arange(i_.shape[0]), j] / fi[torch.arange(i_.shape[0]), j]).detach().clone()))
+            hooks.append(m_.register_forward_hook(hook))
+    torch.nn.functional.dropout = rec_dropout
+    try:
+        torch.manual_seed(301)
+        out = model(pixel_values=x, decoder_input_ids=inp, decoder_attention_mask=am, decoder_token_type_ids=tt, decoder_position_ids=pos,
+                    return_dict=True)
+    finally:
+        torch.nn.functional.dropout = orig_dropout
+        for h_ in hooks:
+            h_.remove()
+    logits = out.logits[:, prompt.shape[1]:]
+    loss = torch.nn.functional.cross_entropy(logits.permute(0, 2, 1), lab, ignore_index=PAD)
+    loss.backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert not any(n.startswith("encoder.") for n in grads)                      # frozen encoder
+    pick = ["decoder.base_model.model.bert.encoder.layer.0.attention.self.query.lora_A.default.weight",
+            "decoder.base_model.model.bert.encoder.layer.0.attention.self.query.lora_B.default.weight",
+            "decoder.base_model.model.bert.encoder.layer.1.attention.self.key.lora_A.default.weight",
+            "decoder.base_model.model.bert.encoder.layer.1.attention.self.key.lora_B.default.weight",
+            "decoder.base_model.model.bert.encoder.layer.0.attention.self.query.base_layer.weight",
+            "decoder.base_model.model.bert.encoder.layer.1.attention.self.value.weight",
+            "decoder.base_model.model.bert.encoder.layer.0.output.dense.weight",
+            "decoder.base_model.model.bert.embeddings.token_type_embeddings.weight"]
+    assert len(drops) == 1 + 7 * cfg.decoder.num_hidden_layers, len(drops)
+    d = {"seed": 18, "perturb": 0.05, "pixel_seed": 103, "prompt_ids": prompt.numpy(), "full_ids": full.numpy(),
+         "token_type_ids": tt.numpy(), "position_ids": pos.numpy(), "attention_mask": am.numpy(),
+         "logits_sample": sample(out.logits, 16384), "logits_stats": stats(out.logits), "loss": np.array(loss.item()),
+         "grad_names": np.array(pick), "n_dropout": len(drops), "n_droppath": len(paths)}
+    for i, (p_, keep) in enumerate(drops):
+        d[f"drop{i}_p"] = np.array(p_)
+        d[f"drop{i}_shape"] = np.array(keep.shape)
+        d[f"drop{i}_keep"] = np.packbits(keep.numpy().reshape(-1))
+    for i, (name, p_, f) in enumerate(paths):
+        d[f"path{i}_name"] = np.array(name)
+        d[f"path{i}_p"] = np.array(p_)
+        d[f"path{i}_factor"] = f.numpy()
+    for i, n in enumerate(pick):
+        d[f"grad{i}_sample"] = sample(grads[n], 2048)
+        d[f"grad{i}_stats"] = stats(grads[n])
+    np.savez_compressed(os.path.join(OUT, "tf_longitudinal_train.npz"), **d)
+    print("tf_longitudinal_train loss", loss.item(), "dropouts", len(drops), "paths", [(n, f.tolist()) for n, _, f in paths][:3])
+
+
 def nocache_greedy(model, kind, x_or_eo, steps, prompt=None, special=None, forced=None):
     """Argmax loop through the reference's own forward()/helpers without a cache."""
     eo = x_or_eo
@@ -602,7 +684,7 @@ def fixture_reward_trunk():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["token_ops", "encoder", "tf_single", "tf_single_train", "tf_longitudinal", "generate", "reward_trunk"]
+    which = sys.argv[1:] or ["token_ops", "encoder", "tf_single", "tf_single_train", "tf_longitudinal", "tf_longitudinal_train", "generate", "reward_trunk"]
     meta = {"transformers": transformers.__version__, "torch": torch.__version__,
             "adapter": "SURVEY.md A.3 (D1 legacy decoder.prepare_inputs_for_generation + D2 empty-cache prefill)",
             "reference": "/root/reference (aehrc/cxrmate @ 2025-02-22)", "mode": "eval(), fp32, CPU; tf_single_train: train() with the drawn dropout / DropPath masks recorded"}

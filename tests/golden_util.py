@@ -125,3 +125,31 @@ def tf_single_train_case():
         name = str(g[f"path{i}_name"]).split(".")                       # encoder.cvt.encoder.stages.S.layers.L.drop_path
         paths[(int(name[4]), int(name[6]))] = (torch.from_numpy(g[f"path{i}_factor"]), torch.from_numpy(g[f"path{i + 1}_factor"]))
     return g, cfg, sd, x, full[:, :-1], full[:, 1:].clone(), attn[:, 1:], torch.from_numpy(g["token_type_ids"]), dropout, paths
+
+
+LORA_DEC_SITES = ("lora_q", "lora_k") + DEC_SITES
+
+
+def tf_longitudinal_train_case():
+    """Train-mode pass of the reference's longitudinal model (LoRA dropout + decoder dropouts + train-mode encoder) with recorded masks."""
+    g = load("tf_longitudinal_train.npz")
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, image_size=96, lora_r=8)
+    sd = weights.init_encoder_decoder(cfg, seed=int(g["seed"]), perturb=float(g["perturb"]))
+    gen = torch.Generator().manual_seed(int(g["pixel_seed"]))
+    x = torch.randn(2, 2, 3, 96, 96, generator=gen)
+    x[0, 1] = 0.0
+    prompt, full = torch.from_numpy(g["prompt_ids"]), torch.from_numpy(g["full_ids"])
+    inp = torch.cat([prompt, full[:, :-1]], dim=1)
+    dropout = {}
+    for i in range(int(g["n_dropout"])):
+        shape = tuple(int(v) for v in g[f"drop{i}_shape"])
+        n = int(np.prod(shape))
+        keep = torch.from_numpy(np.unpackbits(g[f"drop{i}_keep"])[:n].astype(np.float32)).view(shape)
+        site = "embed" if i == 0 else ((i - 1) // 7, LORA_DEC_SITES[(i - 1) % 7])
+        dropout[site] = keep / (1.0 - float(g[f"drop{i}_p"]))
+    paths = {}
+    for i in range(0, int(g["n_droppath"]), 2):
+        name = str(g[f"path{i}_name"]).split(".")
+        paths[(int(name[4]), int(name[6]))] = (torch.from_numpy(g[f"path{i}_factor"]), torch.from_numpy(g[f"path{i + 1}_factor"]))
+    return (g, cfg, sd, x, prompt, inp, full[:, 1:].clone(), torch.from_numpy(g["attention_mask"]), torch.from_numpy(g["token_type_ids"]),
+            torch.from_numpy(g["position_ids"]), dropout, paths)

@@ -296,6 +296,48 @@ def test_gemm_skinny_decode(ops, M, N, K):
     assert bool((cache[:, 2, :] == 0).all())
 
 
+def test_lora_train_mode_kernels(ops):
+    """peft Linear under train(): y = base(x) + s * B(A(dropout(x))) and its backward, from the three rank-8 kernels of csrc/lora.hip."""
+    R, K, N, T, r, s_ = 96, 768, 768, 24, 8, 4.0
+    x, dy = dev(rnd(R, K).to(BF)), dev(rnd(R, N, seed=1).to(BF))
+    A, Bm = dev(rnd(r, K, seed=2, scale=0.05).to(BF)), dev(rnd(N, r, seed=3, scale=0.05).to(BF))
+    A2 = dev(rnd(r, K, seed=4, scale=0.05).to(BF))
+    seed = torch.full((1,), 77, dtype=torch.int32, device="cuda")
+    f = ops.dropout_mask(R, K, 0.1, seed, 21, T, factor=True)
+    f2 = ops.dropout_mask(R, K, 0.1, seed, 22, T, factor=True)
+    t, t2 = ops.lora_down(x, A, drop0=(0.1, 21), W1=A2, drop1=(0.1, 22), rows_per_b=T, seed=seed, scale=s_)
+    close(t, s_ * (x.float() * f) @ A.float().t(), rtol=1e-3, atol=1e-3, what="lora down")
+    close(t2, s_ * (x.float() * f2) @ A2.float().t(), rtol=1e-3, atol=1e-3, what="lora down (second problem)")
+    y0 = dev(rnd(R, N, seed=5).to(BF))
+    y = ops.lora_up_add_(y0.clone(), t, Bm, True)
+    close(y, y0.float() + t @ Bm.float().t(), what="lora up")
+    # backward pieces
+    dt = ops.lora_down(dy, Bm, w_is_b=True, scale=s_)
+    close(dt, s_ * dy.float() @ Bm.float(), rtol=1e-3, atol=1e-3, what="dt = s dy B")
+    dB = torch.zeros(N, r, device="cuda")
+    ops.lora_outer_into(dy, t, dB, r, 1)
+    close(dB, dy.float().t() @ t, rtol=1e-3, atol=1e-3, what="dB")
+    dA = torch.zeros(r, K, device="cuda")
+    ops.lora_outer_into(x, dt, dA, 1, K, drop=(0.1, 21), rows_per_b=T, seed=seed)
+    close(dA, dt.t() @ (x.float() * f), rtol=1e-3, atol=1e-3, what="dA")
+    dx0 = dev(rnd(R, K, seed=6).to(BF))
+    dx = ops.lora_up_add_(dx0.clone(), dt, A, False, drop=(0.1, 21), rows_per_b=T, seed=seed)
+    close(dx, dx0.float() + f * (dt @ A.float()), what="dx")
+    # LayerNorm of the raw row inside the down projection (decode path) and the rank-8 term in the decode GEMM epilogue
+    g_, b_ = dev(1 + 0.1 * rnd(K, seed=7)), dev(0.1 * rnd(K, seed=8))
+    raw = dev((rnd(32, K, seed=9) * 2 + 0.3).to(BF))
+    ln = torch.nn.functional.layer_norm(raw.float(), (K,), g_, b_, 1e-12).to(BF).float()
+    fl = ops.dropout_mask(32, K, 0.1, seed, 21, 1, 7, factor=True)
+    tl = ops.lora_down(raw, A, drop0=(0.1, 21), rows_per_b=1, tpos0=7, seed=seed, ln=(g_, b_, 1e-12), scale=s_)
+    close(tl, s_ * (ln * fl) @ A.float().t(), rtol=2e-3, atol=2e-3, what="lora down with fused LayerNorm")
+    w, bias = dev(rnd(N, K, seed=10, scale=0.05).to(BF)), dev(rnd(N, seed=11))
+    q, k, v = (torch.empty(32, N, dtype=BF, device="cuda") for _ in range(3))
+    ops.gemm_skinny3(raw, w, bias, q, w, bias, k, w, bias, v, ln_a=(g_, b_, 1e-12, None), lora0=(tl, Bm))
+    base = ln @ w.float().t() + bias
+    close(q, base + tl @ Bm.float().t(), what="skinny3 + rank-8 epilogue")
+    close(k, base, what="skinny3 problem without LoRA")
+
+
 @pytest.mark.parametrize("M", [1, 16, 32, 50])
 def test_gemm_skinny_fused_layernorm(ops, M):
     """LayerNorm folded into the decode GEMMs: `ln_a` normalises the raw A rows inside the kernel and publishes (mean, rstd);

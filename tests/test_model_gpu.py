@@ -106,6 +106,9 @@ def _hash_masks(m, cfg, B, T, S, enc_seed, dec_seed, Bn):
     prob = lambda site, Tk: ops.dropout_mask(B * H * T, Tk, pa, dec_seed, site, T, factor=True).view(B, H, T, Tk).cpu()
     dropout = {"embed": hid(SITE_EMBED)}
     for l in range(d.num_hidden_layers):
+        if d.lora_r:
+            lora = lambda site: ops.dropout_mask(B * T, D, d.lora_dropout, dec_seed, site, T, factor=True).view(B, T, D).cpu()
+            dropout[(l, "lora_q")], dropout[(l, "lora_k")] = lora(_site(l, 5)), lora(_site(l, 6))
         dropout[(l, "self_probs")], dropout[(l, "self_out")] = prob(_site(l, 0), T), hid(_site(l, 1))
         dropout[(l, "cross_probs")], dropout[(l, "cross_out")] = prob(_site(l, 2), S), hid(_site(l, 3))
         dropout[(l, "ffn_out")] = hid(_site(l, 4))
@@ -175,6 +178,52 @@ def test_tf_train_mode_matches_oracle_with_same_masks(M):
         href, _ = ocvt.encoder_forward(x, {k: v.detach() for k, v in sd2.items()}, cfg.encoder)
     assert torch.equal(e1, e2)
     check_act(e1.numpy(), href.numpy(), "eval after train-mode step")
+
+
+def test_tf_longitudinal_train_mode_lora_dropout(M):
+    """Longitudinal model under model.train(): frozen encoder with batch-statistics BatchNorm + DropPath, decoder dropouts, and
+    lora_dropout on the input of the rank-8 branch (which therefore cannot be merged into the weight) -- against the oracle fed with the
+    masks the kernels hash; the oracle itself is pinned on the reference's train-mode pass (tests/test_oracle_golden.py)."""
+    from oracle import bert as obert, cvt as ocvt, generate as ogen
+    g, cfg, sd, x, prompt, inp, lab, am, tt, pos, _, _ = gu.tf_longitudinal_train_case()
+    m = M.LongitudinalPromptMultiCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    for p in m.decoder.parameters():
+        p.requires_grad_(True)
+    m.train()
+    torch.manual_seed(23)
+    tt_dev = m.token_ids_to_token_type_ids(inp, [gu.PMT_SEP, gu.BOS, gu.SEP], [0, 1, 0, 1])
+    out = m(pixel_values=x.cuda(), decoder_input_ids=inp.cuda(), decoder_attention_mask=am.cuda(), decoder_token_type_ids=tt_dev,
+            decoder_position_ids=pos.cuda(), return_dict=True)
+    P = prompt.shape[1]
+    loss = torch.nn.functional.cross_entropy(out.logits[:, P:].permute(0, 2, 1), lab.cuda(), ignore_index=gu.PAD)
+    loss.backward()
+    torch.manual_seed(23)
+    enc_seed = torch.full((1,), int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), dtype=torch.int32, device="cuda")
+    dec_seed = torch.full((1,), int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), dtype=torch.int32, device="cuda")
+    B, T = inp.shape
+    S = x.shape[1] * cfg.encoder.tokens_per_image
+    dropout, paths = _hash_masks(m, cfg, B, T, S, enc_seed, dec_seed, x.shape[0] * x.shape[1])
+    assert (0, "lora_q") in dropout
+    names = [str(n) for n in g["grad_names"]]
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    leaves = {n: sd2[n].requires_grad_(True) for n in names}
+    with torch.no_grad():
+        h, emask = ocvt.encoder_forward(x, sd2, cfg.encoder, bn_train=True, bn_momentum=cfg.encoder.bn_momentum, drop_path=paths)
+    ref = obert.decoder_forward(inp, sd2, cfg.decoder, h, emask, am, tt, pos, dropout=dropout)
+    rloss = ogen.tf_cross_entropy(ref[:, P:], lab, gu.PAD)
+    rloss.backward()
+    check_act(out.logits.detach().float().cpu().numpy(), ref.detach().numpy(), "longitudinal train-mode logits")
+    assert abs(loss.item() - rloss.item()) < 2e-2
+    grads = _grads_by_name(m, names)
+    for n in names:
+        r = gu.rel_rms(grads[n].numpy(), leaves[n].grad.numpy())
+        assert r < GRAD_RMS, f"{n}: rel_rms {r:.4f}"
+    # without lora_dropout the branch would be merged: the logits must differ from the merged (eval-LoRA) computation with the same masks
+    dropout_nolora = {k: v for k, v in dropout.items() if not (isinstance(k, tuple) and str(k[1]).startswith("lora"))}
+    with torch.no_grad():
+        merged = obert.decoder_forward(inp, sd2, cfg.decoder, h, emask, am, tt, pos, dropout=dropout_nolora)
+    assert gu.rel_rms(merged.numpy(), ref.detach().numpy()) > 1e-4
 
 
 def test_tf_longitudinal_lora_prompt(M):

@@ -120,6 +120,25 @@ def test_tf_longitudinal_lora_prompt():
         assert gu.rel_rms(gu.sample(leaves[n].grad, 2048), g[f"grad{i}_sample"]) < 2e-3, n
 
 
+def test_tf_longitudinal_train_mode_lora_dropout():
+    """Longitudinal model under model.train(): lora_dropout on the rank-8 branch input (peft Linear), decoder dropouts, train-mode
+    BatchNorm / DropPath in the frozen encoder -- with the reference's recorded masks."""
+    g, cfg, sd, x, prompt, inp, lab, am, tt, pos, dropout, paths = gu.tf_longitudinal_train_case()
+    assert (0, "lora_q") in dropout and (1, "lora_k") in dropout and dropout[(0, "lora_q")].shape == (2, inp.shape[1], 768)
+    names = [str(n) for n in g["grad_names"]]
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    leaves = {n: sd2[n].requires_grad_(True) for n in names}
+    with torch.no_grad():
+        h, emask = ocvt.encoder_forward(x, sd2, cfg.encoder, bn_train=True, bn_momentum=cfg.encoder.bn_momentum, drop_path=paths)
+    logits = obert.decoder_forward(inp, sd2, cfg.decoder, h, emask, am, tt, pos, dropout=dropout)
+    assert gu.rel_rms(gu.sample(logits, 16384), g["logits_sample"]) < FP32_TOL
+    loss = ogen.tf_cross_entropy(logits[:, prompt.shape[1]:], lab, gu.PAD)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    loss.backward()
+    for i, n in enumerate(names):
+        assert gu.rel_rms(gu.sample(leaves[n].grad, 2048), g[f"grad{i}_sample"]) < 2e-3, n
+
+
 def test_greedy_and_beam_multi():
     g, cfg, sd, x = gu.generate_multi_case()
     with torch.no_grad():
