@@ -69,6 +69,14 @@ class CXRBERTReward:
         return ops.cosine_rows(pred, lab)
 
     @torch.no_grad()
+    def similarity(self, predictions, labels):
+        """Cosine similarity of the projected CLS embeddings of two equally long lists of strings, no label caching
+        (the evaluation metric's inner step, reference tools/metrics/cxr_bert.py:101-131)."""
+        if self.tokenizer is None:
+            raise RuntimeError("CXRBERTReward needs the CXR-BERT tokenizer (not available offline): pass tokenizer=...")
+        return ops.cosine_rows(self._encode(list(predictions)), self._encode(list(labels)))
+
+    @torch.no_grad()
     def reward_from_ids(self, pred_ids, pred_mask, label_ids, label_mask):
         """Tokenizer-free entry (synthetic benchmarks / parity tests)."""
         return ops.cosine_rows(self.embed_ids(pred_ids, pred_mask), self.embed_ids(label_ids, label_mask))

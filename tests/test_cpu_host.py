@@ -160,3 +160,18 @@ def test_gradient_allreduce_and_sequence_allgather_gloo_world2():
     assert g0.shape == (4, 4) and torch.equal(g0, g1)
     assert g0[0].tolist() == [0, 0, 0, 4] and g0[2].tolist() == [1, 1, 1, 1]
     assert abs(float(mean0) - 0.5) < 1e-6
+
+
+def test_cxr_bert_metric_host_logic(tmp_path):
+    """Reference tools/metrics/cxr_bert.py surface: argument checks, report collection, mini-batching; compute() needs the GPU reward."""
+    from cxrmate_amd.metrics import CXRBERT
+    m = CXRBERT("val", None, 3, str(tmp_path), accumulate_over_dicoms=False)
+    m.update(["a", "b"], [["x"], ["y"]], [1, 2])
+    assert m.reports == [{"prediction": "a", "label": ["x"], "study_id": 1}, {"prediction": "b", "label": ["y"], "study_id": 2}]
+    assert [len(c) for c in CXRBERT.mini_batch(list(range(7)), 3)] == [3, 3, 1]
+    for bad in (("a", [["x"]], [1]), (["a"], ["x"], [1]), ([1], [["x"]], [1]), (["a"], [[1]], [1])):
+        with pytest.raises(AssertionError):
+            m.update(*bad)
+    with pytest.raises(RuntimeError):
+        m.compute(epoch=0)
+    assert (tmp_path / "cxr_bert").is_dir()

@@ -52,6 +52,46 @@ def test_reward_with_tokenizer_surface(cuda):
     assert len(r._label_cache) == 1 and out2.shape == (2,)
 
 
+def test_cxr_bert_metric_matches_reference_flow(cuda, tmp_path):
+    """Evaluation-time twin of the reward (reference tools/metrics/cxr_bert.py): same update/compute surface, mini-batches, per-study
+    mean over DICOMs, CSV output; similarities equal the oracle's cosine of the stand-in embeddings."""
+    import glob
+    import os
+    import pandas as pd
+    import transformers
+    from cxrmate_amd.metrics import CXRBERT
+    from cxrmate_amd.reward import CXRBERTReward
+    from oracle import bert as obert
+    tok = transformers.PreTrainedTokenizerFast(tokenizer_file=os.path.join(gu.GOLDEN, "tokenizer.json"), unk_token="[UNK]", pad_token="[PAD]",
+                                               cls_token="[BOS]", sep_token="[SEP]", mask_token="[MASK]")
+    cfg = gu.BertConfig(vocab_size=600, num_hidden_layers=2, is_decoder=False, add_cross_attention=False, cls_projection_size=128)
+    r = CXRBERTReward(cuda, tokenizer=tok, config=cfg)
+    metric = CXRBERT("test", None, 2, str(tmp_path), accumulate_over_dicoms=True, reward=r)
+    preds = ["The lungs are clear.", "Mild cardiomegaly is stable.", "No pleural effusion.", "The lungs are clear.", "Normal."]
+    labels = [["The lungs are clear."], ["No acute cardiopulmonary process."], ["Small left pleural effusion."], ["Normal."], ["Normal."]]
+    metric.update(preds[:3], labels[:3], [10, 10, 11], ["a", "b", "c"])
+    metric.update(preds[3:], labels[3:], [12, 12], ["d", "d"])                     # duplicated dicom (DDP padding) is dropped
+    with pytest.raises(AssertionError):
+        metric.update("not a list", labels, [1], ["x"])
+    score = metric.compute(epoch=3)
+    files = glob.glob(os.path.join(str(tmp_path), "cxr_bert", "test_epoch-3_scores_*.csv"))
+    assert len(files) == 1
+    df = pd.read_csv(files[0])
+    assert list(df.columns) == ["dicom_id", "study_id", "similarity"] and len(df) == 4
+    sd = {k: v.detach().float().cpu() for k, v in r.model.state_dict().items()}
+    kw = dict(add_special_tokens=True, padding="longest", return_tensors="pt", truncation=True, max_length=cfg.max_position_embeddings)
+    want = []
+    for p_, l_ in zip(preds[:4], labels[:4]):
+        a, b = tok([p_], **kw), tok([l_[0]], **kw)
+        with torch.no_grad():
+            want.append(float(obert.reward_cosine(a.input_ids, a.attention_mask, b.input_ids, b.attention_mask, sd, cfg)))
+    np.testing.assert_allclose(df.similarity.to_numpy(), np.array(want), atol=2e-2)
+    per_study = [np.mean(want[:2]), want[2], want[3]]
+    assert abs(score - float(np.mean(per_study))) < 2e-2
+    metric.reset()
+    assert metric.reports == []
+
+
 def test_scst_step_matches_oracle_reinforce(cuda):
     from cxrmate_amd import modelling
     from cxrmate_amd.scst import scst_step
