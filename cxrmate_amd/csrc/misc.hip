@@ -380,3 +380,39 @@ extern "C" int cxr_cosine_rows_f32(const float* a, long lda, const float* b, lon
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- input pipeline tail on the GPU
+// ToTensor + Normalize + pad_sequence of the reference's collate (modules/lightning_modules/single.py:248-262 test/train transforms,
+// multi.py:155-164 collate_fn): decoded, resized and cropped uint8 HWC images of all studies of a batch, packed back to back, become the
+// fp32 NCHW `images` tensor [B, Nmax, 3, H, W]; studies with fewer than Nmax images are padded with 0.0 images (which is what the
+// cross-attention mask keys on, quirk Q3). Ships 1 byte per sample over PCIe instead of 4.
+__global__ __launch_bounds__(256) void pixels_u8_to_f32_kernel(const unsigned char* __restrict__ src, const long* __restrict__ first_image /*[B+1]*/,
+                                                               float* __restrict__ dst, int B, int Nmax, int H, int W, float3 scale, float3 shift) {
+    const long hw = (long)H * W;
+    const long total = (long)B * Nmax * hw;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long pix = idx % hw;
+        const int n = (int)((idx / hw) % Nmax), b = (int)(idx / (hw * Nmax));
+        float* o = dst + ((long)(b * Nmax + n) * 3) * hw + pix;
+        const long img = first_image[b] + n;
+        if (img < first_image[b + 1]) {
+            const unsigned char* p = src + (img * hw + pix) * 3;
+            o[0] = p[0] * scale.x + shift.x; o[hw] = p[1] * scale.y + shift.y; o[2 * hw] = p[2] * scale.z + shift.z;
+        } else {
+            o[0] = 0.f; o[hw] = 0.f; o[2 * hw] = 0.f;
+        }
+    }
+}
+
+extern "C" int cxr_pixels_u8_to_f32(const void* src, const long* first_image, float* dst, int B, int Nmax, int H, int W, float mean0,
+                                    float mean1, float mean2, float std0, float std1, float std2, hipStream_t stream) {
+    if (B <= 0 || Nmax <= 0 || H <= 0 || W <= 0 || std0 == 0.f || std1 == 0.f || std2 == 0.f) return CXR_ERR_ARG;
+    // (u/255 - mean)/std = u * (1/(255 std)) - mean/std
+    const float3 scale = make_float3(1.0f / (255.0f * std0), 1.0f / (255.0f * std1), 1.0f / (255.0f * std2));
+    const float3 shift = make_float3(-mean0 / std0, -mean1 / std1, -mean2 / std2);
+    const long total = (long)B * Nmax * H * W;
+    CXR_LAUNCH(pixels_u8_to_f32_kernel, dim3((unsigned)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384)), dim3(256), 0, stream,
+                       (const unsigned char*)src, first_image, dst, B, Nmax, H, W, scale, shift);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}

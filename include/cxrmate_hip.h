@@ -175,6 +175,12 @@ int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, c
                             (flash-decoding) + a merge kernel; kv_hs = head stride of K/V in elements (64 for [B,T,H*64], T*64 for head-major [B,H,T,64]); drop_t = absolute position of the query */
 int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, long* inds, hipStream_t stream);
 
+/* ---- input pipeline tail (next-row f3): ToTensor + Normalize + pad_sequence of the reference collate (REF:modules/lightning_modules/
+ * single.py:248-262, multi.py:155-164). src: packed uint8 HWC images of all studies; first_image int64 [B+1] (prefix sums of images per
+ * study); dst fp32 [B, Nmax, 3, H, W], absent images = 0.0 (quirk Q3). */
+int cxr_pixels_u8_to_f32(const void* src, const long* first_image, float* dst, int B, int Nmax, int H, int W, float mean0, float mean1,
+                         float mean2, float std0, float std1, float std2, hipStream_t stream);
+
 /* ---- reward (REF:tools/rewards/cxrbert.py:66-71 torch.nn.functional.cosine_similarity of the CLS projections) ---------------- */
 int cxr_cosine_rows_f32(const float* a, long lda, const float* b, long ldb, float* out, long R, int C, float eps, hipStream_t stream);
 

@@ -676,3 +676,18 @@ def test_adamw_matches_torch(ops):
         ops.increment_(t_dev)
         ops.adamw_step(p2, g * step, m2, v2, None, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0, step_dev=t_dev)
     close(p2, p, rtol=1e-6, atol=1e-6, what="adamw device step")
+
+
+def test_pixels_normalize_pad_collate(ops):
+    """ToTensor + Normalize + pad_sequence of the reference collate (single.py:248-262, multi.py:155-164) from uint8 HWC images."""
+    from cxrmate_amd.pixels import collate_images, IMAGENET_MEAN, IMAGENET_STD
+    g = torch.Generator().manual_seed(5)
+    studies = [torch.randint(0, 256, (n, 96, 96, 3), generator=g, dtype=torch.uint8) for n in (2, 1, 3)]
+    out = collate_images(studies, "cuda")
+    mean, std = torch.tensor(IMAGENET_MEAN).view(3, 1, 1), torch.tensor(IMAGENET_STD).view(3, 1, 1)
+    ref = torch.nn.utils.rnn.pad_sequence([(s.permute(0, 3, 1, 2).float() / 255.0 - mean) / std for s in studies], batch_first=True, padding_value=0.0)
+    assert out.shape == ref.shape == (3, 3, 3, 96, 96)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    assert bool((out[1, 1:] == 0).all()) and bool((out[0, 2] == 0).all())
+    # the cross-attention mask rule of the reference (first pixel of the image != 0, quirk Q3) sees exactly the padded images
+    assert (out[:, :, 0, 0, 0] != 0).cpu().tolist() == [[True, True, False], [True, False, False], [True, True, True]]
