@@ -416,3 +416,26 @@ extern "C" int cxr_pixels_u8_to_f32(const void* src, const long* first_image, fl
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
+
+// argmax over consecutive column segments of each row: out[r][s] = argmax x[r][off[s] .. off[s+1])  (lowest index wins ties, like torch.argmax)
+// -- the 14 CheXbert heads (13 x 4 classes + 1 x 2, reference tools/chexbert.py:74-81) evaluated as ONE GEMM + this kernel.
+__global__ void segment_argmax_kernel(const float* __restrict__ x, long ld, const int* __restrict__ off, int nseg, long* __restrict__ out, long R) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * nseg) return;
+    const long r = i / nseg;
+    const int s = (int)(i % nseg);
+    int best = off[s];
+    float bv = x[r * ld + best];
+    for (int c = off[s] + 1; c < off[s + 1]; ++c) {
+        const float v = x[r * ld + c];
+        if (v > bv) { bv = v; best = c; }
+    }
+    out[i] = best - off[s];
+}
+
+extern "C" int cxr_segment_argmax_f32(const float* x, long ld, const int* offsets, int nseg, long* out, long R, hipStream_t stream) {
+    if (R <= 0 || nseg <= 0) return CXR_ERR_ARG;
+    CXR_LAUNCH(segment_argmax_kernel, dim3(cdiv(R * nseg, 256)), dim3(256), 0, stream, x, ld, offsets, nseg, out, R);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}

@@ -181,6 +181,10 @@ int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, lo
 int cxr_pixels_u8_to_f32(const void* src, const long* first_image, float* dst, int B, int Nmax, int H, int W, float mean0, float mean1,
                          float mean2, float std0, float std1, float std2, hipStream_t stream);
 
+/* ---- CheXbert labeller heads (next-row f4; REF:tools/chexbert.py:74-81): out[r][s] = argmax over columns [offsets[s], offsets[s+1]) of
+ * the stacked head logits (lowest index wins ties, like torch.argmax); offsets int32 [nseg+1], out int64 [R][nseg]. */
+int cxr_segment_argmax_f32(const float* x, long ld, const int* offsets, int nseg, long* out, long R, hipStream_t stream);
+
 /* ---- reward (REF:tools/rewards/cxrbert.py:66-71 torch.nn.functional.cosine_similarity of the CLS projections) ---------------- */
 int cxr_cosine_rows_f32(const float* a, long lda, const float* b, long ldb, float* out, long R, int C, float eps, hipStream_t stream);
 

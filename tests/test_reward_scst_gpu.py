@@ -92,6 +92,42 @@ def test_cxr_bert_metric_matches_reference_flow(cuda, tmp_path):
     assert metric.reports == []
 
 
+def test_chexbert_labeller_heads(cuda):
+    """CheXbert (reference tools/chexbert.py): trunk + 14 heads as one GEMM + segmented argmax == fp32 oracle trunk + per-head argmax."""
+    import os
+    import transformers
+    from cxrmate_amd.chexbert import CheXbert, HEAD_CLASSES
+    from oracle import bert as obert
+    tok = transformers.PreTrainedTokenizerFast(tokenizer_file=os.path.join(gu.GOLDEN, "tokenizer.json"), unk_token="[UNK]", pad_token="[PAD]",
+                                               cls_token="[BOS]", sep_token="[SEP]", mask_token="[MASK]")
+    cfg = gu.BertConfig(vocab_size=600, num_hidden_layers=2, is_decoder=False, add_cross_attention=False, cls_projection_size=0)
+    cb = CheXbert(cuda, tokenizer=tok, config=cfg)
+    reports = ["  The lungs are clear.\nNo pleural effusion. ", "Mild cardiomegaly is stable.", "Support devices in place.", "Normal."]
+    labels = cb(list(reports))
+    assert labels.shape == (4, 14) and labels.dtype == torch.int64
+    assert int(labels[:, :13].max()) <= 3 and int(labels[:, 13].max()) <= 1
+    clean = [r.strip().replace("\n", " ").strip() for r in reports]
+    t = tok(clean, padding="longest", return_tensors="pt", truncation=True, max_length=cfg.max_position_embeddings)
+    got, logits = cb.label_ids(t["input_ids"], t["attention_mask"], t.get("token_type_ids"))
+    assert torch.equal(got, labels)
+    sd = {k: v.detach().float().cpu() for k, v in cb.model.state_dict().items()}
+    with torch.no_grad():
+        b, tlen = t["input_ids"].shape
+        h = obert.embeddings(t["input_ids"], t.get("token_type_ids"), None, sd, "bert.embeddings.", cfg.layer_norm_eps)
+        mask = torch.zeros(b, 1, 1, tlen).masked_fill(~t["attention_mask"].bool().view(b, 1, 1, tlen), obert.NEG)
+        cls = obert.bert_layers(h, sd, "bert.", cfg, mask, None, None, cfg.layer_norm_eps)[:, 0]
+        ref = torch.cat([torch.nn.functional.linear(cls, sd[f"linear_heads.{i}.weight"], sd[f"linear_heads.{i}.bias"]) for i in range(14)], 1)
+    np.testing.assert_allclose(logits.cpu().numpy(), ref.numpy(), atol=3e-2)
+    o = 0
+    for i, n in enumerate(HEAD_CLASSES):                              # argmax agrees wherever the fp32 margin exceeds the bf16 error
+        seg = ref[:, o:o + n]
+        top2 = seg.topk(2, dim=1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 6e-2
+        assert torch.equal(labels[:, i].cpu()[safe], seg.argmax(1)[safe]), i
+        assert torch.equal(labels[:, i], logits[:, o:o + n].argmax(1))      # segmented argmax kernel == torch.argmax on the same logits
+        o += n
+
+
 def test_scst_step_matches_oracle_reinforce(cuda):
     from cxrmate_amd import modelling
     from cxrmate_amd.scst import scst_step
