@@ -1,6 +1,7 @@
 // Autoregressive-decode helpers: beam reordering of the self-attention KV cache and the
 // top-2*beams continuation search of beam search (TF5 generation/utils.py:3388-3435).
 #include "common.h"
+#include <stdlib.h>
 
 // out[b, r, :] = in[idx[b], r, :]  for r < rows   (cache reorder after a beam step; idx is int64)
 __global__ __launch_bounds__(256) void gather_batch_kernel(const bf16_t* __restrict__ in, long in_bs, long in_rs, bf16_t* __restrict__ out,
@@ -287,6 +288,14 @@ extern "C" int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, co
 // one workgroup per (batch row, head); K and V rows are streamed once, 8 lanes per 128-byte row (16 B each), HBM-bound
 // (cross-attention K/V = B*6*2*(N*576)*768*2 B per token is the dominant decode traffic).
 // Masked keys follow the teacher-forced kernel's convention (finite sentinel -> uniform over masked-only rows).
+// K/V rows are read exactly once per token: non-temporal loads keep them from displacing the decoder weights (160 MB, re-read every token)
+// in the 256 MB Infinity Cache.
+__device__ __forceinline__ uint4 nt_load16(const bf16_t* p) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 // G queries share one K/V stream: query rows b, b + Bkv, ... (b < Bkv) attend to K/V row b. G = 2 is the SCST step, where the sampled and
 // the greedy decode of the same studies run as one batch and read identical cross-attention K/V (340 MB per token at 16 x 2 images).
 template <int G>
@@ -331,8 +340,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         kr[u] = make_uint4(0, 0, 0, 0); vr[u] = make_uint4(0, 0, 0, 0);                                                     \
         ok[u] = false;                                                                                                      \
         if (live[u]) {                       /* no loads for keys past the range (they would cost bandwidth) */             \
-            kr[u] = *reinterpret_cast<const uint4*>(kb + (long)key * k_rs);                                                 \
-            vr[u] = *reinterpret_cast<const uint4*>(vb + (long)key * v_rs);                                                 \
+            kr[u] = nt_load16(kb + (long)key * k_rs);                                                                       \
+            vr[u] = nt_load16(vb + (long)key * v_rs);                                                                       \
             ok[u] = mrow == nullptr || mrow[key] != 0;                                                                      \
         }                                                                                                                   \
     }
