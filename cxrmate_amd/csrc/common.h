@@ -41,6 +41,21 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
+// 16-byte load of data that is read once (streams): non-temporal, so it does not displace reusable lines (weights, the producer->consumer
+// activations of the next kernel) in L2 / Infinity Cache. CXR_NT_STREAMS=0 at build time turns the hint off (A/B measurements).
+#ifndef CXR_NT_STREAMS
+#define CXR_NT_STREAMS 1
+#endif
+__device__ __forceinline__ uint4 ld_stream16(const void* p) {
+#if CXR_NT_STREAMS
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
     f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
     f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);

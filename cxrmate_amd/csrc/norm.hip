@@ -110,9 +110,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
             for (int i = 0; i < L::CPL; ++i) {
                 const int ch = sub + i * L::LPR;
                 const int cc = ch < L::CH ? ch : 0;
-                xr[u][i] = *reinterpret_cast<const uint4*>(x + rc * ldx + cc * 8);
-                dr[u][i] = *reinterpret_cast<const uint4*>(dy + rc * lddy + cc * 8);
-                if (add) ar[u][i] = *reinterpret_cast<const uint4*>(add + rc * ldadd + cc * 8);
+                xr[u][i] = ld_stream16(x + rc * ldx + cc * 8);
+                dr[u][i] = ld_stream16(dy + rc * lddy + cc * 8);
+                if (add) ar[u][i] = ld_stream16(add + rc * ldadd + cc * 8);
             }
         }
 #pragma unroll
