@@ -298,8 +298,9 @@ __device__ __forceinline__ uint4 nt_load16(const bf16_t* p) {
 
 // G queries share one K/V stream: query rows b, b + Bkv, ... (b < Bkv) attend to K/V row b. G = 2 is the SCST step, where the sampled and
 // the greedy decode of the same studies run as one batch and read identical cross-attention K/V (340 MB per token at 16 x 2 images).
-template <int G>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+// NG = 8-lane key groups per workgroup (NG * 8 threads).
+template <int G, int NG>
+__global__ __launch_bounds__(NG * 8) void attn_decode_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                           bf16_t* __restrict__ O, const unsigned char* __restrict__ kpm, long q_bs, long k_bs,
                                                           long k_rs, long v_bs, long v_rs, long o_bs, long kpm_bs, int H, int Tk, float scale, int Bkv, long kv_hs,
                                                           const uint32_t* __restrict__ drop_seed, uint32_t drop_site, uint32_t drop_thr16, float drop_inv,
@@ -307,8 +308,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     // single pass (flash-decoding): each of the 32 key groups (8 lanes x 16 B = one 128-byte K/V row per key) keeps a running
     // (max, sum, o[64]) over keys grp, grp+32, ...; KU keys per iteration -> 2*KU independent 16-byte loads in flight per lane; the 32
     // partial states are merged through LDS at the end.
-    __shared__ float gm[G][32], gl[G][32];
-    __shared__ float go[G][32][64];
+    __shared__ float gm[G][NG], gl[G][NG];
+    __shared__ float go[G][NG][64];
     const int tid = threadIdx.x;
     // nsplit > 1 (flash-decoding across workgroups): workgroup (b, h, split) covers keys [split*chunk, +chunk) and leaves its
     // un-normalised state (max, denominator, numerator[64]) in ws for attn_decode_merge_kernel -- a (b, h) pair alone cannot pull
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     bool live[KU], ok[KU];
 #define ATTN_DEC_LOAD(k0_)                                                                                                  \
     _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                                                        \
-        const int key = (k0_) + u * 32 + grp;                                                                               \
+        const int key = (k0_) + u * NG + grp;                                                                               \
         live[u] = key < k_hi;                                                                                               \
         kr[u] = make_uint4(0, 0, 0, 0); vr[u] = make_uint4(0, 0, 0, 0);                                                     \
         ok[u] = false;                                                                                                      \
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) qv[g][j] *= scale * 1.4426950408889634f;      // scores directly in the exp2 domain
     }
-    for (int k0 = k_lo; k0 < k_hi; k0 += 32 * KU) {
+    for (int k0 = k_lo; k0 < k_hi; k0 += NG * KU) {
         float sv[G][KU];
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
@@ -388,12 +389,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
                 const float p = live[u] ? __builtin_amdgcn_exp2f(sv[g][u] - m_run[g]) : 0.f;
                 l_run[g] += p;
                 float pd = p;
-                if (drop_thr16) pd = dropout_keep(drop_key[g], (uint32_t)(k0 + u * 32 + grp), drop_thr16) ? p * drop_inv : 0.f;
+                if (drop_thr16) pd = dropout_keep(drop_key[g], (uint32_t)(k0 + u * NG + grp), drop_thr16) ? p * drop_inv : 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[g][j] += pd * vv[j];
             }
         }
-        if (k0 + 32 * KU < k_hi) ATTN_DEC_LOAD(k0 + 32 * KU);
+        if (k0 + NG * KU < k_hi) ATTN_DEC_LOAD(k0 + NG * KU);
     }
 #undef ATTN_DEC_LOAD
 #pragma unroll
@@ -407,10 +408,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         const int g = tid >> 6, d = tid & 63;
         float M = -1.0e30f;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) M = fmaxf(M, gm[g][q]);
+        for (int q = 0; q < NG; ++q) M = fmaxf(M, gm[g][q]);
         float num = 0.f, den = 0.f;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
+        for (int q = 0; q < NG; ++q) {
             const float w = __builtin_amdgcn_exp2f(gm[g][q] - M);
             num += w * go[g][q][d];
             den += w * gl[g][q];
@@ -448,14 +449,15 @@ extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V,
     if (B <= 0 || H <= 0 || Tk <= 0 || Tk > 8192 || (k_rs % 8) || (v_rs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8)) return CXR_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed) || (kv_share != 1 && kv_share != 2) || (B % kv_share)) return CXR_ERR_ARG;
     const int Bkv = B / kv_share;
-    // split the keys over workgroups (256 keys = one iteration each) while (b, h) pairs alone leave CUs idle; ws: B*H*8*66 floats
+    // few (b, h) pairs with long key ranges (16 studies x 12 heads over 1152 encoder tokens): split the keys over workgroups (256 keys = one
+    // iteration each) + merge kernel; ws: B*H*8*66 floats. (Measured alternative: ONE 1024-thread workgroup per (b, h) is 3x slower.)
     int nsplit = 1, chunk = Tk;
     if (ws && Bkv * H < 512 && Tk > 256) {
         nsplit = cdiv(Tk, 256) < 8 ? cdiv(Tk, 256) : 8;
         chunk = 256 * cdiv(Tk, 256 * nsplit);
         nsplit = cdiv(Tk, chunk);
     }
-#define ATTN_DEC(G_) CXR_LAUNCH((attn_decode_kernel<G_>), dim3(Bkv * H * nsplit), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,            \
+#define ATTN_DEC(G_) CXR_LAUNCH((attn_decode_kernel<G_, 32>), dim3(Bkv * H * nsplit), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,        \
                (const bf16_t*)V, (bf16_t*)O, (const unsigned char*)kpm, q_bs, k_bs, k_rs, v_bs, v_rs, o_bs, kpm_bs, H, Tk, scale, Bkv, kv_hs, drop_seed, \
                drop_site, drop_p > 0.f ? dropout_thr16(drop_p) : 0u, 1.0f / (1.0f - drop_p), drop_t, nsplit, chunk, ws)
     if (kv_share == 2) ATTN_DEC(2); else ATTN_DEC(1);
