@@ -466,10 +466,8 @@ extern "C" int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq
 // ------------------------------------------------------------------------------------------------------------------
 // 2-D transpose of a bf16 matrix (used by the backward pass to present dY^T / X^T / W^T as K-contiguous operands).
 // in [R, C] (ld_in) -> out [C, R] (ld_out). 64x64 tile through LDS, 16-byte global accesses on both sides.
-__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, long ld_in,
-                                                             bf16_t* __restrict__ out, long ld_out, int R, int C) {
-    __shared__ bf16_t tile[64][64 + 2];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+__device__ __forceinline__ void transpose_tile(const bf16_t* __restrict__ in, long ld_in, bf16_t* __restrict__ out, long ld_out, int R, int C,
+                                               int r0, int c0, bf16_t (*tile)[64 + 2]) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -497,6 +495,35 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, long ld_in,
+                                                             bf16_t* __restrict__ out, long ld_out, int R, int C) {
+    __shared__ bf16_t tile[64][64 + 2];
+    transpose_tile(in, ld_in, out, ld_out, R, C, blockIdx.y * 64, blockIdx.x * 64, tile);
+}
+
+// Many matrices in ONE launch (the per-step W^T refresh of ~190 weight matrices: each is 0.3-5 MB, i.e. launch-latency-bound on its own).
+// table[i] = {in, out, ld_in, ld_out, R, C, first_tile, tiles_x} (int64 x 8, device memory); grid = total number of 64x64 tiles.
+__global__ __launch_bounds__(256) void transpose_batched_bf16_kernel(const long* __restrict__ table, int n) {
+    __shared__ bf16_t tile[64][64 + 2];
+    const long t = blockIdx.x;
+    int lo = 0, hi = n - 1;                                  // last matrix whose first_tile <= t
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 8 + 6] <= t) lo = mid; else hi = mid - 1;
+    }
+    const long* e = table + lo * 8;
+    const long local = t - e[6];
+    const int tx = (int)(local % e[7]), ty = (int)(local / e[7]);
+    transpose_tile(reinterpret_cast<const bf16_t*>(e[0]), e[2], reinterpret_cast<bf16_t*>(e[1]), e[3], (int)e[4], (int)e[5], ty * 64, tx * 64, tile);
+}
+
+extern "C" int cxr_transpose_batched_bf16(const long* table, int n, long total_tiles, hipStream_t stream) {
+    if (n <= 0 || total_tiles <= 0 || !table) return CXR_ERR_ARG;
+    CXR_LAUNCH(transpose_batched_bf16_kernel, dim3((unsigned)total_tiles), dim3(256), 0, stream, table, n);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
 }
 
 extern "C" int cxr_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int C, hipStream_t stream) {

@@ -61,6 +61,7 @@ class BertEngine:
         self._prep = {}
         self._wt_ready = False
         self._wtb_ready = False
+        self._bt, self._bt_last = {}, None
 
     # ------------------------------------------------------------------------------------------ parameters
     def _lin(self, base):
@@ -106,28 +107,31 @@ class BertEngine:
         return names
 
     def _prepare_transposes(self, lora_tr=False):
-        """W^T of every Linear (+ the padded word-embedding transpose for the LM-head dX) for the current weight version, issued on
-        the weight-gradient side stream during the training forward (off the critical path); backward joins it. lora_tr: the LoRA-wrapped
-        projections need the transpose of their BASE weight (train mode does not merge), kept under ("wtb", base)."""
-        if lora_tr and not self._wtb_ready:
-            st, prep = self.s, self._prep
-            with ops._on_wgrad_stream():
-                for base in self._linear_names():
-                    if not st.has(base + ".weight"):
-                        prep[("wtb", base)] = ops.transpose(st.w16(base + ".base_layer.weight"), out=prep.get(("wtb", base)))
-            self._wtb_ready = True
-        if self._wt_ready:
-            return
+        """W^T of every Linear (+ the padded word-embedding transpose for the LM-head dX) for the current weight version: ONE batched launch
+        on the weight-gradient side stream during the training forward (off the critical path); backward joins it. lora_tr: the LoRA-wrapped
+        projections additionally need the transpose of their BASE weight (train mode does not merge), kept under ("wtb", base)."""
         st, prep, p = self.s, self._prep, self.p
-        with ops._on_wgrad_stream():
+        mode = bool(lora_tr)
+        if not (self._wt_ready and (self._wtb_ready or not mode)):
+            keys, srcs, pads = [], [], []
             for base in self._linear_names():
-                prep[("wt", base)] = ops.transpose(self._lin(base)[0], out=prep.get(("wt", base)))
+                keys.append(("wt", base)); srcs.append(self._lin(base)[0]); pads.append(1)
+                if mode and not st.has(base + ".weight"):
+                    keys.append(("wtb", base)); srcs.append(st.w16(base + ".base_layer.weight")); pads.append(1)
             if not self.cfg.cls_projection_size:
-                k = p + "cls.predictions.transform.dense"
-                prep[("wt", k)] = ops.transpose(st.w16(k + ".weight"), out=prep.get(("wt", k)))
-                k = p + "bert.embeddings.word_embeddings.weight"
-                prep[("wt", k)] = ops.transpose(st.w16(k), 64, out=prep.get(("wt", k)))
-        self._wt_ready = True
+                keys.append(("wt", p + "cls.predictions.transform.dense")); srcs.append(st.w16(p + "cls.predictions.transform.dense.weight")); pads.append(1)
+                keys.append(("wt", p + "bert.embeddings.word_embeddings.weight")); srcs.append(st.w16(keys[-1][1])); pads.append(64)
+            sig = (mode, tuple(x.data_ptr() for x in srcs))
+            bt = self._bt.get(mode)
+            if bt is None or bt[0] != sig:
+                bt = self._bt[mode] = (sig, ops.BatchedTranspose(srcs, pads), keys)
+            with ops._on_wgrad_stream():
+                bt[1].run()
+            self._wt_ready = True
+            self._wtb_ready = mode or self._wtb_ready
+            self._bt_last = bt
+        for k, o in zip(self._bt_last[2], self._bt_last[1].outs):
+            prep[k] = o
 
     # ------------------------------------------------------------------------------------------ teacher-forced forward
     def _lora_parts(self, base):

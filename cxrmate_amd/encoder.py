@@ -25,6 +25,8 @@ class CvtEncoderEngine:
         self._wt_ready = False
         self._bn_version = 0                        # bumped whenever a train-mode forward moves the running statistics
         self._fold_cache = {}
+        self._embed_buf = {}                        # persistent conv-as-GEMM weight re-layouts (their addresses feed the batched transpose table)
+        self._bt, self._bt_sig, self._bt_keys = None, None, None
 
     # ------------------------------------------------------------------------------------------ weight preparation
     def _stage(self, s):
@@ -41,13 +43,17 @@ class CvtEncoderEngine:
             sp = self._stage(s)
             w = st.w16(sp + "embedding.convolution_embeddings.projection.weight")
             co = w.shape[0]
+            wp = self._embed_buf.get(s)
             if s == 0:
                 k = w.shape[1] * w.shape[2] * w.shape[3]
                 kpad = ((k + 63) // 64) * 64
-                wp = torch.zeros((co, kpad), dtype=torch.bfloat16, device=w.device)
+                if wp is None or wp.device != w.device:
+                    wp = self._embed_buf[s] = torch.zeros((co, kpad), dtype=torch.bfloat16, device=w.device)
                 wp[:, :k] = w.reshape(co, k)                         # K order (c, ky, kx) = weight.view(Cout, -1)
             else:
-                wp = w.permute(0, 2, 3, 1).reshape(co, -1).contiguous()   # K order (ky, kx, c): channel-contiguous gathers
+                if wp is None or wp.device != w.device:
+                    wp = self._embed_buf[s] = torch.empty((co, w.shape[1] * w.shape[2] * w.shape[3]), dtype=torch.bfloat16, device=w.device)
+                wp.view(co, w.shape[2], w.shape[3], w.shape[1]).copy_(w.permute(0, 2, 3, 1))      # K order (ky, kx, c): channel-contiguous gathers
             prep[("embed", s)] = wp
         self._prep, self._prep_version = prep, st.shadow_version
         self._wt_ready = False
@@ -96,25 +102,29 @@ class CvtEncoderEngine:
         return folds, kept
 
     def _prepare_transposes(self):
-        """W^T (the K-contiguous operand of every dX GEMM) for the current weight version. Issued on the weight-gradient side stream at the
-        start of a training forward, i.e. entirely off the critical path; joined at the start of backward."""
-        if self._wt_ready:
-            return
+        """W^T (the K-contiguous operand of every dX GEMM) for the current weight version: ONE batched launch over all ~130 matrices, issued on
+        the weight-gradient side stream at the start of a training forward (off the critical path); joined at the start of backward."""
         st, cfg, prep = self.s, self.cfg, self._prep
-        with ops._on_wgrad_stream():
+        if not self._wt_ready:
+            keys, srcs = [], []
             for s in range(len(cfg.depth)):
                 sp = self._stage(s)
                 if s > 0:
-                    prep[("wt", ("embed", s))] = ops.transpose(prep[("embed", s)], out=prep.get(("wt", ("embed", s))))
+                    keys.append(("embed", s)); srcs.append(prep[("embed", s)])
                 for l in range(cfg.depth[s]):
                     lp = sp + f"layers.{l}."
                     for name in ("attention.attention.projection_query", "attention.attention.projection_key", "attention.attention.projection_value",
                                  "attention.output.dense", "intermediate.dense", "output.dense"):
-                        k = lp + name + ".weight"
-                        prep[("wt", k)] = ops.transpose(st.w16(k), out=prep.get(("wt", k)))
-            k = self.p + "projection_head.projection.weight"
-            prep[("wt", k)] = ops.transpose(st.w16(k), out=prep.get(("wt", k)))
-        self._wt_ready = True
+                        keys.append(lp + name + ".weight"); srcs.append(st.w16(lp + name + ".weight"))
+            keys.append(self.p + "projection_head.projection.weight"); srcs.append(st.w16(keys[-1]))
+            sig = tuple(x.data_ptr() for x in srcs)
+            if self._bt is None or self._bt_sig != sig:               # first use, or the store was re-packed (.to() / .cuda())
+                self._bt, self._bt_sig, self._bt_keys = ops.BatchedTranspose(srcs), sig, keys
+            with ops._on_wgrad_stream():
+                self._bt.run()
+            self._wt_ready = True
+        for k, o in zip(self._bt_keys, self._bt.outs):
+            prep[("wt", k)] = o
 
     def _wt(self, key):
         return self._prep[("wt", key)]

@@ -78,6 +78,31 @@ def transpose(x, pad_cols_to=1, out=None):
     return out
 
 
+class BatchedTranspose:
+    """W^T of many bf16 matrices in ONE launch. Sources and destinations are persistent buffers, so the device-side table is built once;
+    `pad_cols_to` pads the transposed row length (padding columns stay zero)."""
+
+    def __init__(self, sources, pad_cols_to=None):
+        pad_cols_to = pad_cols_to or [1] * len(sources)
+        self.outs, rows, tiles = [], [], 0
+        for x, pad in zip(sources, pad_cols_to):
+            _chk(x, BF16)
+            R, C = x.shape
+            Rp = ((R + pad - 1) // pad) * pad
+            out = (torch.zeros if Rp != R else torch.empty)((C, Rp), device=x.device, dtype=BF16)
+            tx, ty = (C + 63) // 64, (R + 63) // 64
+            rows.append([x.data_ptr(), out.data_ptr(), x.stride(0), out.stride(0), R, C, tiles, tx])
+            tiles += tx * ty
+            self.outs.append(out)
+        self.sources = list(sources)                   # keep the views alive: the table holds raw pointers
+        self.total = tiles
+        self.table = torch.tensor(rows, dtype=torch.int64).to(sources[0].device)
+
+    def run(self):
+        LIB.call("cxr_transpose_batched_bf16", _p(self.table), len(self.outs), self.total, _s())
+        return self.outs
+
+
 def colsum_into(x, out):
     """out[c] += sum_r x[r,c]  (fp32)."""
     _chk(x, BF16)

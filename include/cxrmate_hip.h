@@ -34,6 +34,8 @@ int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C,
                      hipStream_t stream);
 int cxr_gemm_set_regstage(int on);   /* debug: 1 = stage operands through registers instead of LDS-DMA */
 int cxr_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int C, hipStream_t stream);
+int cxr_transpose_batched_bf16(const long* table, int n, long total_tiles, hipStream_t stream);   /* n transposes in one launch; table (device)
+                                   int64 [n][8] = {in, out, ld_in, ld_out, R, C, first_tile, tiles_x}, 64x64 tiles numbered row-major per matrix */
 int cxr_colsum_bf16(const void* in, long ld, float* out, int R, int C, hipStream_t stream);   /* out[c] += sum_r in[r][c] (bias grads) */
 
 /* ---- attention -----------------------------------------------------------------------------------------------------------
