@@ -60,11 +60,108 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     }
 }
 
+// Register-resident variant (V <= 32768, ld % 4 == 0): 1024 threads hold the whole row (<= 8 float4 each), so the logits are read from HBM
+// exactly once (the 256-thread kernel above re-reads the 120-KB row for the sum and for the gradient).
+__global__ __launch_bounds__(1024) void softmax_ce_reg_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ labels,
+                                                              long ignore_index, const float* __restrict__ thr, const float* __restrict__ row_w,
+                                                              float* __restrict__ row_loss, bf16_t* __restrict__ dlogits, long lddl, int V) {
+    __shared__ float sh[16];
+    __shared__ float xl;
+    const long r = blockIdx.x;
+    const float* x = logits + r * ld;
+    const long label = labels[r];
+    const int tid = threadIdx.x;
+    if (label == ignore_index) {
+        if (row_loss && tid == 0) row_loss[r] = 0.f;
+        if (dlogits) for (int v = tid * 8; v < (int)lddl; v += 8192)
+            *reinterpret_cast<uint4*>(dlogits + r * lddl + v) = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const float t = thr ? thr[r] : -INFINITY;
+    // thread owns columns [8*tid + 8192*i, +8): two float4 per chunk, 4 chunks
+    float4 a[4][2];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = tid * 8 + 8192 * i;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 q = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            const int vv = v + 4 * h;
+            if (vv + 3 < V) q = *reinterpret_cast<const float4*>(x + vv);
+            else {
+                if (vv < V) q.x = x[vv];
+                if (vv + 1 < V) q.y = x[vv + 1];
+                if (vv + 2 < V) q.z = x[vv + 2];
+            }
+            a[i][h] = q;
+            if (q.x >= t) mx = fmaxf(mx, q.x);
+            if (q.y >= t) mx = fmaxf(mx, q.y);
+            if (q.z >= t) mx = fmaxf(mx, q.z);
+            if (q.w >= t) mx = fmaxf(mx, q.w);
+        }
+    }
+    mx = group_max<64>(mx);
+    if ((tid & 63) == 0) sh[tid >> 6] = mx;
+    __syncthreads();
+    mx = sh[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, sh[w]);
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float* q = reinterpret_cast<float*>(&a[i][h]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float e = q[j] >= t ? __expf(q[j] - mx) : 0.f;       // -inf padding / filtered entries -> 0
+                const int vv = tid * 8 + 8192 * i + 4 * h + j;
+                if (vv == (int)label) xl = q[j];
+                q[j] = e;
+            }
+            s += (q[0] + q[1]) + (q[2] + q[3]);
+        }
+    s = group_sum<64>(s);
+    if ((tid & 63) == 0) sh[tid >> 6] = s;
+    __syncthreads();
+    s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += sh[w];
+    if (row_loss && tid == 0) row_loss[r] = mx + __logf(s) - xl;
+    if (dlogits) {
+        const float w = row_w[r], inv = 1.0f / s;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = tid * 8 + 8192 * i;
+            if (v >= (int)lddl) continue;                                   // columns [V, lddl) are zero padding (K of the next GEMM)
+            float o[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float* q = reinterpret_cast<const float*>(&a[i][h]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int vv = v + 4 * h + j;
+                    float gv = q[j] * inv;
+                    if (vv == (int)label) gv -= 1.0f;
+                    o[4 * h + j] = vv < V ? gv * w : 0.f;
+                }
+            }
+            *reinterpret_cast<uint4*>(dlogits + r * lddl + v) = pack8(o);
+        }
+    }
+}
+
 extern "C" int cxr_softmax_ce(const float* logits, long ld, const long* labels, long ignore_index, const float* thr, const float* row_w,
                               float* row_loss, void* dlogits, long lddl, long R, int V, hipStream_t stream) {
     if (R <= 0 || V <= 0 || (dlogits && (!row_w || (lddl % 8)))) return CXR_ERR_ARG;
-    CXR_LAUNCH(softmax_ce_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, labels, ignore_index, thr, row_w, row_loss,
-                       (bf16_t*)dlogits, lddl, V);
+    if (V <= 32768 && lddl <= 32768 && (ld % 4) == 0 && (((size_t)logits) % 16) == 0)
+        CXR_LAUNCH(softmax_ce_reg_kernel, dim3((unsigned)R), dim3(1024), 0, stream, logits, ld, labels, ignore_index, thr, row_w, row_loss,
+                           (bf16_t*)dlogits, lddl, V);
+    else
+        CXR_LAUNCH(softmax_ce_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, labels, ignore_index, thr, row_w, row_loss,
+                           (bf16_t*)dlogits, lddl, V);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
