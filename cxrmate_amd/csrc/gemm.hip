@@ -23,6 +23,11 @@ struct GemmArgs {
     int act;                      // 0 none, 1 GELU(erf), 2 multiply by GELU'(aux)  (backward of 1)
     int out_f32;                  // 0: C is bf16, 1: C is f32
     int accumulate;               // out_f32 only: C += result
+    // train-mode regularisers folded into the epilogue (after the activation): element dropout by the counter-based hash of common.h
+    // (row m = sequence m / drop_rows_per_b at position drop_t0 + m % drop_rows_per_b), or a per-image DropPath factor row_scale[m / rs_rows];
+    // rs_after != 0 applies the row scale AFTER the residual (CvT's second DropPath scales the whole layer output, quirk Q12)
+    const uint32_t* drop_seed; uint32_t drop_site, drop_thr16; float drop_inv; int drop_rows_per_b, drop_t0;
+    const float* row_scale; int rs_rows, rs_after;
 };
 
 template <int BK> struct Swz;
@@ -157,10 +162,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
     }
 
     // epilogue: lane owns C[m][n0..n0+3], m = .. + (lane&15), n0 = .. + (lane>>4)*4
+    const uint32_t dseed = g.drop_thr16 ? *g.drop_seed : 0u;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = tm * BM + wm * 64 + mt * 16 + fr;
         if (m >= g.M) continue;
+        const uint32_t dkey = g.drop_thr16 ? dropout_row_key(dseed, g.drop_site, (uint32_t)(m / g.drop_rows_per_b),
+                                                             (uint32_t)(g.drop_t0 + m % g.drop_rows_per_b)) : 0u;
+        const float rscale = g.row_scale ? g.row_scale[m / g.rs_rows] : 1.0f;
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
             const int n0 = tn * BN + wn * (BN / 2) + nt * 16 + fq * 4;
@@ -184,11 +193,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
                 v[0] *= gelu_grad_f(__uint_as_float(pk.x << 16)); v[1] *= gelu_grad_f(__uint_as_float(pk.x & 0xffff0000u));
                 v[2] *= gelu_grad_f(__uint_as_float(pk.y << 16)); v[3] *= gelu_grad_f(__uint_as_float(pk.y & 0xffff0000u));
             }
+            if (g.drop_thr16) {                                 // n0 is a multiple of 4: two hashes cover the lane's four columns
+                const uint32_t b0 = dropout_pair_bits(dkey, (uint32_t)n0 >> 1), b1 = dropout_pair_bits(dkey, ((uint32_t)n0 >> 1) + 1);
+                v[0] = (b0 & 0xffffu) >= g.drop_thr16 ? v[0] * g.drop_inv : 0.f; v[1] = (b0 >> 16) >= g.drop_thr16 ? v[1] * g.drop_inv : 0.f;
+                v[2] = (b1 & 0xffffu) >= g.drop_thr16 ? v[2] * g.drop_inv : 0.f; v[3] = (b1 >> 16) >= g.drop_thr16 ? v[3] * g.drop_inv : 0.f;
+            }
+            if (g.row_scale && !g.rs_after) { v[0] *= rscale; v[1] *= rscale; v[2] *= rscale; v[3] *= rscale; }
             if (g.residual) {
                 const uint2 pk = *reinterpret_cast<const uint2*>(g.residual + (long)m * g.ldr + n0);
                 v[0] += __uint_as_float(pk.x << 16); v[1] += __uint_as_float(pk.x & 0xffff0000u);
                 v[2] += __uint_as_float(pk.y << 16); v[3] += __uint_as_float(pk.y & 0xffff0000u);
             }
+            if (g.row_scale && g.rs_after) { v[0] *= rscale; v[1] *= rscale; v[2] *= rscale; v[3] *= rscale; }
             if (g.out_f32) {
                 float* c = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n0;
                 float4 o = make_float4(v[0], v[1], v[2], v[3]);
@@ -212,8 +228,10 @@ extern "C" int cxr_gemm_set_regstage(int on) { g_gemm_regstage = on; return CXR_
 extern "C" int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc,
                                 const float* bias, const void* residual, long ldr, void* aux, long ldaux,
                                 int M, int N, int K, float alpha, int act, int out_f32, int accumulate,
-                                hipStream_t stream) {
+                                float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_rows_per_b, int drop_t0,
+                                const float* row_scale, int rs_rows, int rs_after, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return CXR_ERR_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (!drop_seed || drop_rows_per_b <= 0)) || (row_scale && rs_rows <= 0)) return CXR_ERR_ARG;
     if ((K % 32) || (N % 4) || (lda % 8) || (ldw % 8) || (ldc % 4)) return CXR_ERR_ARG;
     if (residual && (ldr % 4)) return CXR_ERR_ARG;
     if (act == 2 && !aux) return CXR_ERR_ARG;
@@ -223,6 +241,9 @@ extern "C" int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = C; g.ldc = ldc;
     g.bias = bias; g.residual = (const bf16_t*)residual; g.ldr = ldr; g.aux = (bf16_t*)aux; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.act = act; g.out_f32 = out_f32; g.accumulate = accumulate;
+    g.drop_seed = drop_seed; g.drop_site = drop_site; g.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u; g.drop_inv = 1.0f / (1.0f - drop_p);
+    g.drop_rows_per_b = drop_rows_per_b > 0 ? drop_rows_per_b : 1; g.drop_t0 = drop_t0;
+    g.row_scale = row_scale; g.rs_rows = rs_rows > 0 ? rs_rows : 1; g.rs_after = rs_after;
     static int force_bk = -1, stages = -1, force_bn = -1;     // tuning aids: CXR_GEMM_BK=32|64, CXR_GEMM_STAGES=2|3|4, CXR_GEMM_BN=64|128
     if (force_bk < 0) { const char* e = getenv("CXR_GEMM_BK"); force_bk = e ? atoi(e) : 0; }
     if (stages < 0) { const char* e = getenv("CXR_GEMM_STAGES"); stages = e ? atoi(e) : 2; }

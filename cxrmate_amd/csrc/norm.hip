@@ -75,15 +75,20 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
     }
 }
 
+// Optional second output dx2 = f * dx: the gradient of a `dense -> dropout -> + residual` (or DropPath) branch that consumes this LayerNorm's
+// input -- the forward mask re-applied (element hash, or a per-image factor row_scale[row / rows_per_b]) while dx is still in registers.
+struct LnBwdDrop { bf16_t* dx2; long lddx2; const uint32_t* seed; uint32_t site, thr16; float inv; int rows_per_b, t0; const float* row_scale; };
+
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ;  dgamma += sum dy*xhat ; dbeta += sum dy
 template <int C, int U>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
                                                             const float* __restrict__ gamma, const float* __restrict__ stats,
                                                             const bf16_t* __restrict__ add, long ldadd,
                                                             bf16_t* __restrict__ dx, long lddx, float* __restrict__ partial /*[grid][2][C]*/,
-                                                            long rows) {
+                                                            long rows, LnBwdDrop dd) {
     using L = LNCfg<C>;
     __shared__ float red[2][C];
+    const uint32_t dseed = dd.thr16 ? *dd.seed : 0u;
     for (int i = threadIdx.x; i < 2 * C; i += 256) (&red[0][0])[i] = 0.f;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -155,6 +160,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
                         for (int j = 0; j < 8; ++j) o[j] += av[j];
                     }
                     *reinterpret_cast<uint4*>(dx + row[u] * lddx + ch * 8) = pack8(o);
+                    if (dd.dx2) {
+                        if (dd.row_scale) {
+                            const float f = dd.row_scale[row[u] / dd.rows_per_b];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) o[j] *= f;
+                        } else {
+                            const uint32_t key = dropout_row_key(dseed, dd.site, (uint32_t)(row[u] / dd.rows_per_b), (uint32_t)(dd.t0 + (int)(row[u] % dd.rows_per_b)));
+#pragma unroll
+                            for (int j = 0; j < 8; j += 2) {
+                                const uint32_t bits = dropout_pair_bits(key, (uint32_t)(ch * 8 + j) >> 1);
+                                o[j] = (bits & 0xffffu) >= dd.thr16 ? o[j] * dd.inv : 0.f;
+                                o[j + 1] = (bits >> 16) >= dd.thr16 ? o[j + 1] * dd.inv : 0.f;
+                            }
+                        }
+                        *reinterpret_cast<uint4*>(dd.dx2 + row[u] * dd.lddx2 + ch * 8) = pack8(o);
+                    }
                 }
             }
         }
@@ -235,12 +256,18 @@ extern "C" int cxr_layernorm_bwd_grid(long rows, int C) {
 
 extern "C" int cxr_layernorm_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, const float* gamma, const float* stats,
                                       const void* add, long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, float* workspace,
-                                      long rows, int C, hipStream_t stream) {
+                                      long rows, int C, void* dx2, long lddx2, float drop_p, const unsigned int* drop_seed, unsigned int drop_site,
+                                      int drop_rows_per_b, int drop_t0, const float* row_scale, hipStream_t stream) {
     if (rows <= 0 || (ldx % 8) || (lddy % 8) || (lddx % 8) || (add && (ldadd % 8)) || (dgamma && !workspace)) return CXR_ERR_ARG;
+    if (dx2 && ((lddx2 % 8) || drop_rows_per_b <= 0 || (!row_scale && (drop_p <= 0.f || drop_p >= 1.f || !drop_seed)))) return CXR_ERR_ARG;
+    LnBwdDrop dd;
+    dd.dx2 = (bf16_t*)dx2; dd.lddx2 = lddx2; dd.seed = drop_seed; dd.site = drop_site; dd.thr16 = (dx2 && !row_scale) ? dropout_thr16(drop_p) : 0u;
+    dd.inv = drop_p < 1.f ? 1.0f / (1.0f - drop_p) : 1.f; dd.rows_per_b = drop_rows_per_b > 0 ? drop_rows_per_b : 1; dd.t0 = drop_t0;
+    dd.row_scale = row_scale;
     const int grid = cxr_layernorm_bwd_grid(rows, C);
     float* partial = dgamma ? workspace : nullptr;
     LN_DISPATCH(C, layernorm_bwd_kernel, 2, 2, 2, 2, 1, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, gamma, stats, (const bf16_t*)add, ldadd,
-                (bf16_t*)dx, lddx, partial, rows);
+                (bf16_t*)dx, lddx, partial, rows, dd);
     if (dgamma) CXR_LAUNCH(layernorm_bwd_reduce_kernel, dim3(cdiv(2 * C, 32), cdiv(grid, 64)), dim3(256), 0, stream, partial, grid, C, dgamma, dbeta);
     CXR_LAUNCH_CHECK();
     return CXR_OK;

@@ -179,9 +179,7 @@ class BertEngine:
 
         def out_proj(x, w, b, resid, site):
             """dense -> dropout -> + residual (BertSelfOutput / BertOutput before their LayerNorm)"""
-            if not ph:
-                return ops.gemm_nt(x, w, bias=b, residual=resid)
-            return ops.dropout_add(ops.gemm_nt(x, w, bias=b), resid, ph, seed, site, T)
+            return ops.gemm_nt(x, w, bias=b, residual=resid, drop=(ph, seed, site, T, 0) if ph else None)
 
         for l in range(cfg.num_hidden_layers):
             lp = p + f"bert.encoder.layer.{l}."
@@ -324,6 +322,10 @@ class BertEngine:
         scale = cfg.head_dim ** -0.5
         ph, pa, seed = saved.get("ph", 0.0), saved.get("pa", 0.0), saved.get("seed")
 
+        def dspec(site):
+            """second LayerNorm-backward output = the forward dropout mask of `site` re-applied to dx (None in eval mode)"""
+            return (ph, seed, site, T, 0) if ph else None
+
         def undrop(d, site):
             """gradient of the dense output under `dense -> dropout -> + residual`: the forward mask re-applied to the sum's gradient"""
             return ops.dropout_add(d, None, ph, seed, site, T) if ph else d
@@ -332,8 +334,8 @@ class BertEngine:
             lp = p + f"bert.encoder.layer.{l}."
             sv = saved["layers"][l]
             da3 = ops.layernorm_bwd(sv["a3"], dh, st.f32(lp + "output.LayerNorm.weight"), sv["s3"], g(lp + "output.LayerNorm.weight"),
-                                    g(lp + "output.LayerNorm.bias"))
-            dd3 = undrop(da3, _site(l, 4))
+                                    g(lp + "output.LayerNorm.bias"), drop=dspec(_site(l, 4)))
+            da3, dd3 = da3 if ph else (da3, da3)
             self._wgrad(lp + "output.dense", dd3, sv["f"])
             du = ops.gemm_nt(dd3, self._wt(lp + "output.dense"), act=2, aux=sv["u"])
             self._wgrad(lp + "intermediate.dense", du, sv["h2in"])
@@ -341,8 +343,9 @@ class BertEngine:
             if "a2" in sv:
                 S = enc.shape[1]
                 da2 = ops.layernorm_bwd(sv["a2"], dh2, st.f32(lp + "crossattention.output.LayerNorm.weight"), sv["s2"],
-                                        g(lp + "crossattention.output.LayerNorm.weight"), g(lp + "crossattention.output.LayerNorm.bias"))
-                dd2 = undrop(da2, _site(l, 3))
+                                        g(lp + "crossattention.output.LayerNorm.weight"), g(lp + "crossattention.output.LayerNorm.bias"),
+                                        drop=dspec(_site(l, 3)))
+                da2, dd2 = da2 if ph else (da2, da2)
                 self._wgrad(lp + "crossattention.output.dense", dd2, sv["ctx2"].view(R, D))
                 dctx2 = ops.gemm_nt(dd2, self._wt(lp + "crossattention.output.dense")).view(B, T, D)
                 dq2, dk2, dv2 = ops.attention_bwd(sv["q2"], sv["k2"], sv["v2"], sv["ctx2"], dctx2, sv["lse2"], nh, scale, kpm=saved["enc_mask"],
@@ -357,8 +360,8 @@ class BertEngine:
             else:
                 dh1 = dh2
             da1 = ops.layernorm_bwd(sv["a1"], dh1, st.f32(lp + "attention.output.LayerNorm.weight"), sv["s1"],
-                                    g(lp + "attention.output.LayerNorm.weight"), g(lp + "attention.output.LayerNorm.bias"))
-            dd1 = undrop(da1, _site(l, 1))
+                                    g(lp + "attention.output.LayerNorm.weight"), g(lp + "attention.output.LayerNorm.bias"), drop=dspec(_site(l, 1)))
+            da1, dd1 = da1 if ph else (da1, da1)
             self._wgrad(lp + "attention.output.dense", dd1, sv["ctx"].view(R, D))
             dctx = ops.gemm_nt(dd1, self._wt(lp + "attention.output.dense")).view(B, T, D)
             dq, dk, dv = ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, scale, kpm=saved["attn_mask"],
@@ -422,7 +425,7 @@ class BertEngine:
                 return lin(x, w, bias=b, residual=resid)
             if single:
                 return ops.gemm_skinny(x, w, bias=b, residual=resid, drop=(ph, seed, site, past))
-            return ops.dropout_add(ops.gemm_nt(x, w, bias=b), resid, ph, seed, site, Tn, t0=past)
+            return ops.gemm_nt(x, w, bias=b, residual=resid, drop=(ph, seed, site, Tn, past))
 
         for l in range(cfg.num_hidden_layers):
             lp = p + f"bert.encoder.layer.{l}."

@@ -234,18 +234,15 @@ class CvtEncoderEngine:
         v = ops.gemm_nt(vc.view(-1, C), st.w16(ap + "projection_value.weight"), bias=st.f32(ap + "projection_value.bias")).view(Bn, Lk, C)
         ctx, lse = ops.attention(q, k, v, nh, C ** -0.5, need_lse=save)                  # scale = embed_dim^-0.5 (quirk Q1)
         dp1, dp2 = self._drop_path_scales(s, l, Bn)
-        if dp1 is None:
-            x2 = ops.gemm_nt(ctx.view(-1, C), st.w16(lp + "attention.output.dense.weight"), bias=st.f32(lp + "attention.output.dense.bias"), residual=x2d)
-        else:
-            ao = ops.gemm_nt(ctx.view(-1, C), st.w16(lp + "attention.output.dense.weight"), bias=st.f32(lp + "attention.output.dense.bias"))
-            x2 = ops.dropout_add(ao, x2d, 0.0, None, 0, L, row_scale=dp1)
+        x2 = ops.gemm_nt(ctx.view(-1, C), st.w16(lp + "attention.output.dense.weight"), bias=st.f32(lp + "attention.output.dense.bias"), residual=x2d,
+                         row_scale=None if dp1 is None else (dp1, L, False))              # first CvtDropPath: scales the attention branch
         h2, st2 = ops.layernorm(x2, st.f32(lp + "layernorm_after.weight"), st.f32(lp + "layernorm_after.bias"), cfg.inner_layer_norm_eps, need_stats=save)
         Ch = st.w16(lp + "intermediate.dense.weight").shape[0]
         u = torch.empty((Bn * L, Ch), dtype=torch.bfloat16, device=x.device) if save else None
         g = ops.gemm_nt(h2, st.w16(lp + "intermediate.dense.weight"), bias=st.f32(lp + "intermediate.dense.bias"), act=1, aux=u)
-        x3 = ops.gemm_nt(g, st.w16(lp + "output.dense.weight"), bias=st.f32(lp + "output.dense.bias"), residual=x2)
-        if dp2 is not None:                  # the second CvtDropPath scales the WHOLE layer output, residual included (TF5:cvt:382-383, Q12)
-            ops.dropout_add(x3, None, 0.0, None, 0, L, row_scale=dp2, out=x3)
+        # the second CvtDropPath scales the WHOLE layer output, residual included (TF5:cvt:382-383, Q12)
+        x3 = ops.gemm_nt(g, st.w16(lp + "output.dense.weight"), bias=st.f32(lp + "output.dense.bias"), residual=x2,
+                         row_scale=None if dp2 is None else (dp2, L, True))
         lsave = None
         if save:
             lsave = dict(x=x, st1=st1, h1=h1, qc=qc, kc=kc, vc=vc, q=q, k=k, v=v, ctx=ctx, lse=lse, x2=x2, st2=st2, h2=h2, u=u, g=g, bn=bn, dp=(dp1, dp2))
@@ -317,9 +314,9 @@ class CvtEncoderEngine:
         ops.linear_bwd_weight(du, sv["h2"], g(lp + "intermediate.dense.weight"), g(lp + "intermediate.dense.bias"))
         dh2 = ops.gemm_nt(du, self._wt(lp + "intermediate.dense.weight"))
         dx2 = ops.layernorm_bwd(sv["x2"], dh2, st.f32(lp + "layernorm_after.weight"), sv["st2"], g(lp + "layernorm_after.weight"),
-                                g(lp + "layernorm_after.bias"), add=dy2)
+                                g(lp + "layernorm_after.bias"), add=dy2, row_scale=None if dp1 is None else (dp1, L))
+        dx2, da = dx2 if dp1 is not None else (dx2, dx2)
         # attention output projection: x2 = x + droppath(Wo ctx + bo)
-        da = dx2 if dp1 is None else ops.dropout_add(dx2, None, 0.0, None, 0, L, row_scale=dp1)
         ops.linear_bwd_weight(da, sv["ctx"].view(-1, C), g(lp + "attention.output.dense.weight"), g(lp + "attention.output.dense.bias"))
         dctx = ops.gemm_nt(da, self._wt(lp + "attention.output.dense.weight")).view(Bn, L, C)
         dq, dk, dv = ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, C ** -0.5)

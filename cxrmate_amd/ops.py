@@ -38,8 +38,10 @@ def _chk(t, dtype=None):
 GEMM_PROFILE = None     # bench.py: set to a list to collect (flops, start_event, end_event) per GEMM launch on the current stream
 
 
-def gemm_nt(a, w, bias=None, residual=None, act=0, aux=None, out=None, out_f32=False, accumulate=False, alpha=1.0):
-    """out[M,N] = epi(alpha * a[M,K] @ w[N,K]^T). a, w bf16 2-D (row stride arbitrary, unit column stride)."""
+def gemm_nt(a, w, bias=None, residual=None, act=0, aux=None, out=None, out_f32=False, accumulate=False, alpha=1.0, drop=None, row_scale=None):
+    """out[M,N] = epi(alpha * a[M,K] @ w[N,K]^T). a, w bf16 2-D (row stride arbitrary, unit column stride).
+    Train mode: drop = (p, seed, site, rows_per_b, t0) drops the dense output before the residual; row_scale = (scale fp32 [M / rows], rows,
+    after_residual) multiplies by a per-image DropPath factor."""
     _chk(a, BF16); _chk(w, BF16)
     M, K = a.shape
     N, K2 = w.shape
@@ -59,7 +61,9 @@ def gemm_nt(a, w, bias=None, residual=None, act=0, aux=None, out=None, out_f32=F
         e0.record()
     LIB.call("cxr_gemm_nt_bf16", _p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias), _p(residual),
              residual.stride(0) if residual is not None else 0, _p(aux), aux.stride(0) if aux is not None else 0,
-             M, N, K, float(alpha), int(act), int(out_f32), int(accumulate), _s())
+             M, N, K, float(alpha), int(act), int(out_f32), int(accumulate),
+             *((float(drop[0]), _p(drop[1]), int(drop[2]), int(drop[3]), int(drop[4])) if drop is not None and drop[0] > 0 else (0.0, None, 0, 1, 0)),
+             *((_p(row_scale[0]), int(row_scale[1]), int(bool(row_scale[2]))) if row_scale is not None else (None, 1, 0)), _s())
     if prof is not None:
         e1.record()
         nbytes = 2.0 * (M * K + N * K) + M * N * ((4 if out_f32 else 2) + (2 if residual is not None else 0) + (2 if aux is not None else 0))
@@ -251,18 +255,25 @@ def layernorm(x, gamma, beta, eps, need_stats=False, out=None):
     return out, stats
 
 
-def layernorm_bwd(x, dy, gamma, stats, dgamma, dbeta, add=None, out=None):
+def layernorm_bwd(x, dy, gamma, stats, dgamma, dbeta, add=None, out=None, drop=None, row_scale=None):
+    """-> dx, or (dx, dx2) with dx2 = f * dx when drop = (p, seed, site, rows_per_b, t0) (dropout mask re-applied) or row_scale =
+    (scale fp32 [rows / rows_per_b], rows_per_b) (DropPath factor) is given."""
     _chk(x, BF16); _chk(dy, BF16)
     rows, C = x.shape
     if out is None:
         out = torch.empty((rows, C), device=x.device, dtype=BF16)
+    second = drop is not None or row_scale is not None
+    out2 = torch.empty((rows, C), device=x.device, dtype=BF16) if second else None
     ws = None
     if dgamma is not None:
         nb = LIB.load().cxr_layernorm_bwd_grid(rows, C)
         ws = torch.empty((nb, 2, C), device=x.device, dtype=torch.float32)
     LIB.call("cxr_layernorm_bwd_bf16", _p(x), x.stride(0), _p(dy), dy.stride(0), _p(gamma), _p(stats), _p(add),
-             add.stride(0) if add is not None else 0, _p(out), out.stride(0), _p(dgamma), _p(dbeta), _p(ws), rows, C, _s())
-    return out
+             add.stride(0) if add is not None else 0, _p(out), out.stride(0), _p(dgamma), _p(dbeta), _p(ws), rows, C, _p(out2),
+             out2.stride(0) if second else 0, float(drop[0]) if drop is not None else 0.0, _p(drop[1]) if drop is not None else None,
+             int(drop[2]) if drop is not None else 0, int(drop[3]) if drop is not None else (int(row_scale[1]) if row_scale is not None else 1),
+             int(drop[4]) if drop is not None else 0, _p(row_scale[0]) if row_scale is not None else None, _s())
+    return (out, out2) if second else out
 
 
 # ------------------------------------------------------------------------------------------------ convolutional pieces

@@ -25,9 +25,14 @@ typedef struct ihipStream_t* hipStream_t;
  * (REF:modules/transformers/single_model/modelling_single.py:25-40), BERT q/k/v/o/FFN/LM head (TF5:bert:164-203,289-351,466-496),
  * the patch-embedding convs after im2col (TF5:cvt:77-90) and all their backward products (via cxr_transpose_bf16).
  * epi: +bias[N] (fp32) -> act (0 none | 1 GELU(erf), pre-activation optionally stored to aux | 2 multiply by GELU'(aux)) -> +residual[M,N]
- * -> store bf16 or fp32 (optionally accumulating). Requires K%32==0, N%4==0, lda/ldw%8==0. */
+ * -> store bf16 or fp32 (optionally accumulating). Requires K%32==0, N%4==0, lda/ldw%8==0.
+ * Train mode, between act and residual: drop_p > 0 = nn.Dropout of the dense output (TF5:bert:298,464) with the keep hash of cxr_dropout_mask
+ * (row m = sequence m / drop_rows_per_b at position drop_t0 + m % drop_rows_per_b); row_scale [M / rs_rows] = CvtDropPath factor per image
+ * (TF5:cvt:372), applied after the residual when rs_after != 0 (TF5:cvt:382-383 scales the whole layer output). */
 int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias, const void* residual, long ldr,
-                     void* aux, long ldaux, int M, int N, int K, float alpha, int act, int out_f32, int accumulate, hipStream_t stream);
+                     void* aux, long ldaux, int M, int N, int K, float alpha, int act, int out_f32, int accumulate, float drop_p,
+                     const unsigned int* drop_seed, unsigned int drop_site, int drop_rows_per_b, int drop_t0, const float* row_scale,
+                     int rs_rows, int rs_after, hipStream_t stream);
 /* weight gradient: C[I,J] += alpha * sum_r P[r,I] Q[r,J]  (dW += dY^T X), dbias[I] += colsum(P); token dimension split across
  * workgroups, fp32 atomic accumulation into the gradient buffer. Requires I%8==0, J%8==0. */
 int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* dbias, int R, int I, int J, float alpha,
@@ -81,8 +86,12 @@ int cxr_lora_outer_bf16(const void* a, long lda, long M, int K, const float* t, 
 int cxr_layernorm_fwd_bf16(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* stats, long rows, int C,
                            float eps, hipStream_t stream);           /* stats[rows][2] = (mean, rstd), optional */
 int cxr_layernorm_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, const float* gamma, const float* stats, const void* add,
-                           long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, float* workspace, long rows, int C,
-                           hipStream_t stream);   /* workspace: fp32 [cxr_layernorm_bwd_grid(rows,C)][2][C] partial sums */
+                           long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, float* workspace, long rows, int C, void* dx2,
+                           long lddx2, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_rows_per_b, int drop_t0,
+                           const float* row_scale, hipStream_t stream);
+                           /* workspace: fp32 [cxr_layernorm_bwd_grid(rows,C)][2][C] partial sums. dx2 (optional) = f * dx: the gradient of a
+                              dropout / DropPath branch fed by this LayerNorm's input (forward mask re-applied: element hash, or
+                              row_scale[row / drop_rows_per_b]) */
 int cxr_layernorm_bwd_grid(long rows, int C);
 
 /* ---- CvT convolutional pieces ---------------------------------------------------------------------------------------------

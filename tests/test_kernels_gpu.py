@@ -259,6 +259,21 @@ def test_attention_dropout_fwd_bwd(ops, B, H, Tq, Tk, causal, masked):
     assert torch.equal(plain, off)
 
 
+def test_gemm_epilogue_dropout_and_droppath(ops):
+    M, N, K, T = 192, 768, 256, 24
+    a, w = dev(rnd(M, K).to(BF)), dev(rnd(N, K, seed=1, scale=0.1).to(BF))
+    bias, res = dev(rnd(N, seed=2)), dev(rnd(M, N, seed=3).to(BF))
+    seed = torch.full((1,), 5, dtype=torch.int32, device="cuda")
+    base = a.float() @ w.float().t() + bias
+    fac = ops.dropout_mask(M, N, 0.1, seed, 27, T, 2, factor=True)
+    out = ops.gemm_nt(a, w, bias=bias, residual=res, drop=(0.1, seed, 27, T, 2))
+    close(out, base * fac + res.float(), what="gemm epilogue dropout")
+    scale = dev(rnd(M // T, seed=4).abs())
+    rs = scale.repeat_interleave(T)[:, None]
+    close(ops.gemm_nt(a, w, bias=bias, residual=res, row_scale=(scale, T, False)), base * rs + res.float(), what="DropPath on the branch")
+    close(ops.gemm_nt(a, w, bias=bias, residual=res, row_scale=(scale, T, True)), (base + res.float()) * rs, what="DropPath on the layer output")
+
+
 def test_dropout_add_and_droppath(ops):
     R, C, T = 96, 768, 24
     y, res = dev(rnd(R, C).to(BF)), dev(rnd(R, C, seed=1).to(BF))
@@ -413,6 +428,16 @@ def test_layernorm_fwd_bwd(ops, C):
     close(dx, xr.grad + add.float(), what=f"ln dx C={C}")
     close(dg, gr.grad, rtol=1e-2, atol=1e-2, what="ln dgamma")
     close(db, br.grad, rtol=1e-2, atol=1e-2, what="ln dbeta")
+    # second output: the forward dropout mask / DropPath factor of the branch fed by this LayerNorm's input, re-applied to dx
+    seed = torch.full((1,), 31, dtype=torch.int32, device="cuda")
+    T = 8
+    r8 = (rows // T) * T
+    dx1, dx2 = ops.layernorm_bwd(x[:r8], dy[:r8], g, stats[:r8], None, None, add=add[:r8], drop=(0.1, seed, 44, T, 3))
+    assert torch.equal(dx1, dx[:r8])
+    close(dx2, dx1.float() * ops.dropout_mask(r8, C, 0.1, seed, 44, T, 3, factor=True), rtol=1e-2, atol=2e-2, what="ln dx2 (dropout)")
+    scale = dev(rnd(r8 // T, seed=9).abs())
+    dx1, dx2 = ops.layernorm_bwd(x[:r8], dy[:r8], g, stats[:r8], None, None, row_scale=(scale, T))
+    close(dx2, dx1.float() * scale.repeat_interleave(T)[:, None], rtol=1e-2, atol=2e-2, what="ln dx2 (DropPath)")
 
 
 # ------------------------------------------------------------------------------------------------ conv pieces
