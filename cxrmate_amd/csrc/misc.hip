@@ -439,3 +439,59 @@ extern "C" int cxr_segment_argmax_f32(const float* x, long ld, const int* offset
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- cached-decode step inputs, one launch
+// Everything `prepare_inputs_for_generation` assembles for a cached step (reference modules/transformers/longitudinal_model/
+// modelling_longitudinal.py:251-295 and the single/multi variants): from the running token buffer ids[r, strip:cur]
+//   new_id[r]    = ids[r, cur-1]                                      (input_ids[:, -1:])
+//   tt[r]        = token_ids_to_token_type_ids_past(ids[r, strip:cur])  (:340-364; separator sets may differ between the two row halves:
+//                  the sampled and the greedy decode of one SCST step run as one batch)
+//   mask[r, j]   = ids[r, strip+j] != mask_token_id,  pos[r] = relu(cumsum(mask) - 1)[-1]     (:274-277; skipped when mask == NULL)
+// tt / pos are also appended to per-row histories (column cur) for the teacher-forced re-scoring of the sampled rows.
+__global__ __launch_bounds__(64) void decode_step_inputs_kernel(const long* __restrict__ ids, long ld, int rows, int strip, int cur,
+                                                                const long* __restrict__ special0, int n0, const long* __restrict__ special1, int n1,
+                                                                const long* __restrict__ sections, int half_rows, long mask_token_id,
+                                                                long* __restrict__ new_id, long* __restrict__ tt, long* __restrict__ pos,
+                                                                unsigned char* __restrict__ mask, long ldm, long* __restrict__ tt_hist,
+                                                                long* __restrict__ pos_hist, long ldh) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const long* row = ids + (long)r * ld + strip;
+    const int T = cur - strip;
+    const long* special = r < half_rows ? special0 : special1;
+    const int ns = r < half_rows ? n0 : n1;
+    long v = sections[0];
+    for (int i = 0; i < ns; ++i) {                            // separators searched in all but the last position, later separators win
+        int any = 0;
+        for (int t = lane; t < T - 1; t += 64) any |= (row[t] == special[i]);
+        if (__any(any)) v = sections[i + 1];
+    }
+    int count = 0;
+    if (mask) {
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane;
+            const int m = t < T ? (row[t] != mask_token_id) : 0;
+            if (t < T) mask[(long)r * ldm + t] = (unsigned char)m;
+            count += __popcll(__ballot(m));
+        }
+    }
+    if (lane == 0) {
+        new_id[r] = row[T - 1];
+        tt[r] = v;
+        if (tt_hist) tt_hist[(long)r * ldh + cur] = v;
+        if (mask) {
+            const long p = count > 0 ? count - 1 : 0;
+            pos[r] = p;
+            if (pos_hist) pos_hist[(long)r * ldh + cur] = p;
+        }
+    }
+}
+
+extern "C" int cxr_decode_step_inputs(const long* ids, long ld, int rows, int strip, int cur, const long* special0, int n0, const long* special1,
+                                      int n1, const long* sections, int half_rows, long mask_token_id, long* new_id, long* tt, long* pos,
+                                      void* mask, long ldm, long* tt_hist, long* pos_hist, long ldh, hipStream_t stream) {
+    if (rows <= 0 || cur - strip < 1 || !special0 || !special1 || !sections || !new_id || !tt || (mask && !pos)) return CXR_ERR_ARG;
+    CXR_LAUNCH(decode_step_inputs_kernel, dim3(rows), dim3(64), 0, stream, ids, ld, rows, strip, cur, special0, n0, special1, n1, sections, half_rows,
+                       mask_token_id, new_id, tt, pos, (unsigned char*)mask, ldm, tt_hist, pos_hist, ldh);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}

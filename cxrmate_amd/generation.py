@@ -38,6 +38,14 @@ class DecodeSession:
         self.cache.ck = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
         self.cache.cv = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
         self.seed = torch.zeros(1, dtype=torch.int32, device=dev)     # dropout seed of the running decode (train mode); graphs read it
+        # per-step inputs of the cached steps (one fused kernel writes them): last token, token type, position, attention mask, and the
+        # token-type / position history the teacher-forced re-scoring of the sampled rows needs
+        self.new_id = torch.zeros((rows, 1), dtype=torch.int64, device=dev)
+        self.tt1 = torch.zeros((rows, 1), dtype=torch.int64, device=dev)
+        self.pos1 = torch.zeros((rows, 1), dtype=torch.int64, device=dev)
+        self.mask8 = torch.zeros((rows, Lmax), dtype=torch.uint8, device=dev)
+        self.tt_hist = torch.zeros((rows, Lmax), dtype=torch.int64, device=dev)
+        self.pos_hist = torch.zeros((rows, Lmax), dtype=torch.int64, device=dev)
         self.graphs = {}
         self.pool = None
         self.version = -1
@@ -85,10 +93,21 @@ class DecodeSession:
     def _run(self, cur, strip, mode, prefill):
         m = self.model
         kind, special, mask_token_id, top_k, temperature, eos, pad, train = mode
-        fed = self.ids[:, strip:cur]
-        new, mask, tt, pos = m._step_inputs(fed, special, mask_token_id, prefill=prefill)
-        logits = m._dec.decode(self.cache, new.contiguous(), self.enc16, self.enc_mask8, mask, tt.contiguous(),
-                               None if pos is None else pos.contiguous(), train=train, seed=self.seed)
+        if prefill:
+            fed = self.ids[:, strip:cur]
+            new, mask, tt, pos = m._step_inputs(fed, special, mask_token_id, prefill=True)
+            new, tt, pos = new.contiguous(), tt.contiguous(), None if pos is None else pos.contiguous()
+        else:                                                      # one launch: last token, token type, position, mask (+ their history)
+            pair = isinstance(special, tuple) and special and isinstance(special[0], (tuple, list))
+            sp0, sp1 = (special[0], special[1]) if pair else (special, special)
+            longi = m.kind == "longitudinal"
+            ops.decode_step_inputs(self.ids, strip, cur, list(sp0), list(sp1), [0, 1, 0, 1] if longi else None, self.B // 2 if pair else self.B,
+                                   mask_token_id if longi else -1, self.new_id, self.tt1, self.pos1 if longi else None,
+                                   self.mask8 if longi else None, self.tt_hist, self.pos_hist if longi else None)
+            new, tt = self.new_id, self.tt1
+            pos = self.pos1 if longi else None
+            mask = self.mask8[:, :cur - strip] if longi else None
+        logits = m._dec.decode(self.cache, new, self.enc16, self.enc_mask8, mask, tt, pos, train=train, seed=self.seed)
         unf = self.unfinished if eos is not None else None
         eos_ = eos if eos is not None else -1
         n_smp = {"greedy": 0, "sample": self.B, "pair": self.B // 2}[kind]      # rows [0, n_smp) sample, the rest take the argmax
@@ -99,7 +118,11 @@ class DecodeSession:
         if n_smp < self.B:
             ops.select_token(logits[n_smp:], unfinished=None if unf is None else unf[n_smp:], eos=eos_, pad=pad or 0, out=self.nxt[n_smp:])
         self.ids[:, cur] = self.nxt
-        self.last_tt, self.last_pos = tt, pos
+        if prefill:
+            self.last_tt, self.last_pos = tt, pos
+        else:                                                      # views of the history columns this step wrote (stable across graph replays)
+            self.last_tt = self.tt_hist[:, cur:cur + 1]
+            self.last_pos = self.pos_hist[:, cur:cur + 1] if pos is not None else None
 
 
 class GenerationMixin:
@@ -260,15 +283,26 @@ class GenerationMixin:
             if rec is not None:
                 rec["seed"] = ses.seed.clone() if self.training else None
             cur = prompt_len
+            first_tt = first_pos = None
             while cur < max_length:
                 ses.step(cur, strip, mode)
-                if rec is not None:
-                    rec["tt"].append(ses.last_tt.clone())
-                    rec["pos"].append(None if ses.last_pos is None else ses.last_pos.clone())
+                if rec is not None and cur == prompt_len:            # the prefill step's inputs cover the whole prompt
+                    first_tt, first_pos = ses.last_tt.clone(), None if ses.last_pos is None else ses.last_pos.clone()
                 cur += 1
                 if eos_token_id is not None and ((cur - prompt_len) % 8 == 0) and int(ses.unfinished.max()) == 0:
                     break
             out = ses.ids[:, :cur].clone()
+            if rec is not None:
+                # cached steps appended their token type / position to the session's history columns: ONE copy, then per-step views
+                # (the session is reused by the next generate() call, so the history must not be handed out itself)
+                rec["tt"].append(first_tt)
+                rec["pos"].append(first_pos)
+                if cur > prompt_len + 1:
+                    th = ses.tt_hist[:, prompt_len + 1:cur].clone()
+                    ph_ = ses.pos_hist[:, prompt_len + 1:cur].clone() if first_pos is not None else None
+                    for c in range(th.shape[1]):
+                        rec["tt"].append(th[:, c:c + 1])
+                        rec["pos"].append(None if ph_ is None else ph_[:, c:c + 1])
             # HF stops at the step on which the last row finishes: trim what the 8-step polling overshot
             if eos_token_id is not None:
                 gen = out[:, prompt_len:]

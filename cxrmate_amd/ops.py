@@ -451,6 +451,17 @@ def token_type_ids(ids, special, sections, past=False, out=None):
     return out
 
 
+def decode_step_inputs(ids, strip, cur, special0, special1, sections, half_rows, mask_token_id, new_id, tt, pos, mask, tt_hist, pos_hist):
+    """One launch for the per-step input assembly of a cached decode (see cxr_decode_step_inputs). ids int64 [rows, Lmax]; outputs are the
+    caller's persistent buffers: new_id / tt / pos [rows, 1] int64, mask uint8 [rows, Lmax] | None, histories [rows, Lmax] int64 | None."""
+    rows = ids.shape[0]
+    sp0, se = special_tensors(special0, sections, ids.device)
+    sp1, _ = special_tensors(special1, sections, ids.device)
+    LIB.call("cxr_decode_step_inputs", _p(ids), ids.stride(0), rows, int(strip), int(cur), _p(sp0), len(special0), _p(sp1), len(special1), _p(se),
+             int(half_rows), int(mask_token_id if mask is not None else -1), _p(new_id), _p(tt), _p(pos), _p(mask),
+             mask.stride(0) if mask is not None else 0, _p(tt_hist), _p(pos_hist), tt_hist.stride(0) if tt_hist is not None else 0, _s())
+
+
 def mask_position_ids(ids, mask_token_id):
     assert ids.dtype == torch.int64 and ids.stride(1) == 1
     B, T = ids.shape

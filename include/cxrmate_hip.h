@@ -196,6 +196,14 @@ int cxr_pixels_u8_to_f32(const void* src, const long* first_image, float* dst, i
  * the stacked head logits (lowest index wins ties, like torch.argmax); offsets int32 [nseg+1], out int64 [R][nseg]. */
 int cxr_segment_argmax_f32(const float* x, long ld, const int* offsets, int nseg, long* out, long R, hipStream_t stream);
 
+/* ---- cached-decode step inputs in one launch (REF:modelling_longitudinal.py:251-295 prepare_inputs_for_generation and its single / multi
+ * copies): from ids[r, strip:cur] -> new_id = last token, tt = token_ids_to_token_type_ids_past (:340-364; rows < half_rows use special0, the
+ * rest special1), mask = ids != mask_token_id and pos = relu(cumsum(mask)-1)[-1] (:274-277; mask == NULL skips both); tt / pos are also written
+ * to column `cur` of the optional per-row histories. */
+int cxr_decode_step_inputs(const long* ids, long ld, int rows, int strip, int cur, const long* special0, int n0, const long* special1, int n1,
+                           const long* sections, int half_rows, long mask_token_id, long* new_id, long* tt, long* pos, void* mask, long ldm,
+                           long* tt_hist, long* pos_hist, long ldh, hipStream_t stream);
+
 /* ---- reward (REF:tools/rewards/cxrbert.py:66-71 torch.nn.functional.cosine_similarity of the CLS projections) ---------------- */
 int cxr_cosine_rows_f32(const float* a, long lda, const float* b, long ldb, float* out, long R, int C, float eps, hipStream_t stream);
 
