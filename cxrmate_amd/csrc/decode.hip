@@ -121,8 +121,23 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs g) {
                 rv[t][r] = (g.residual && pi == 0 && m < g.M && n < P.N) ? bf2f(g.residual[(long)m * g.ldr + n]) : 0.f;
             }
     }
-    float rg = 1.f, rb = 0.f;
-    if (wave == 0 && g.lnR_stats && pi == 0 && n < P.N) { rg = g.lnR_g[n]; rb = g.lnR_b[n]; }
+    float rg = 1.f, rb = 0.f, rmean[MT][4], rrstd[MT][4], lrB[8];
+    uint32_t dseed = 0u;
+    if (wave == 0) {                                 // every epilogue operand is requested now: no dependent global load after the MFMAs
+        if (g.drop_thr16) dseed = *g.drop_seed;
+        const bool lnr = g.lnR_stats && pi == 0 && n < P.N;
+        if (lnr) { rg = g.lnR_g[n]; rb = g.lnR_b[n]; }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = t * 16 + fq * 4 + r;
+                rmean[t][r] = (lnr && m < g.M) ? g.lnR_stats[2 * m] : 0.f;
+                rrstd[t][r] = (lnr && m < g.M) ? g.lnR_stats[2 * m + 1] : 1.f;
+            }
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) lrB[r8] = (P.lr_t && n < P.N) ? bf2f(P.lr_B[(long)n * 8 + r8]) : 0.f;
+    }
     f32x4_t acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -217,13 +232,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs g) {
             float v = red[0][t][lane][r] + red[1][t][lane][r] + red[2][t][lane][r] + red[3][t][lane][r] + bv;
             if (P.lr_t) {
 #pragma unroll
-                for (int r8 = 0; r8 < 8; ++r8) v += P.lr_t[m * 8 + r8] * bf2f(P.lr_B[(long)n * 8 + r8]);
+                for (int r8 = 0; r8 < 8; ++r8) v += P.lr_t[m * 8 + r8] * lrB[r8];
             }
             if (g.act == 1) v = gelu_f(v);
             if (g.drop_thr16)
-                v = dropout_keep(dropout_row_key(*g.drop_seed, g.drop_site, (uint32_t)m, (uint32_t)g.drop_t), (uint32_t)n, g.drop_thr16) ? v * g.drop_inv : 0.f;
+                v = dropout_keep(dropout_row_key(dseed, g.drop_site, (uint32_t)m, (uint32_t)g.drop_t), (uint32_t)n, g.drop_thr16) ? v * g.drop_inv : 0.f;
             float res = rv[t][r];
-            if (g.lnR_stats && pi == 0) res = (res - g.lnR_stats[2 * m]) * g.lnR_stats[2 * m + 1] * rg + rb;
+            if (g.lnR_stats && pi == 0) res = (res - rmean[t][r]) * rrstd[t][r] * rg + rb;
             v += res;
             if (g.out_f32) reinterpret_cast<float*>(P.C)[(long)m * P.ldc + n] = v;
             else reinterpret_cast<bf16_t*>(P.C)[(long)m * P.ldc + n] = f2bf(v);
