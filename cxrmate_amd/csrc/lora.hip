@@ -68,6 +68,65 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict
     }
 }
 
+// Few rows (cached decode: M = sequences, one token each): a whole 256-thread workgroup per (row, problem) -- the one-wave-per-row kernel
+// above is a 17-us latency chain there (12 strided elements and 96 weight loads per lane, in sequence).
+__global__ __launch_bounds__(256) void lora_down_row_kernel(const bf16_t* __restrict__ x, long ldx, long M, int K, LoraDownProb p0, LoraDownProb p1,
+                                                            const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps, float scale) {
+    __shared__ float sh[4][LR];
+    const LoraDownProb P = blockIdx.y == 0 ? p0 : p1;
+    const long m = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t seedv = P.drop.thr16 ? *P.drop.seed : 0u;
+    float xv[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tid + 256 * i;
+        xv[i] = k < K ? bf2f(x[m * ldx + k]) : 0.f;
+        s += xv[i];
+    }
+    if (ln_g) {
+        s = group_sum<64>(s);
+        if (lane == 0) sh[wave][0] = s;
+        __syncthreads();
+        const float mean = ((sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0])) / K;
+        __syncthreads();
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (tid + 256 * i < K) q += (xv[i] - mean) * (xv[i] - mean);
+        q = group_sum<64>(q);
+        if (lane == 0) sh[wave][0] = q;
+        __syncthreads();
+        const float rstd = rsqrtf(((sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0])) / K + ln_eps);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = tid + 256 * i;
+            if (k < K) xv[i] = bf2f(f2bf((xv[i] - mean) * rstd * ln_g[k] + ln_b[k]));
+        }
+    }
+    float acc[LR];
+#pragma unroll
+    for (int r = 0; r < LR; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tid + 256 * i;
+        if (k < K) {
+            const float v = xv[i] * lora_factor(P.drop, seedv, m, k);
+#pragma unroll
+            for (int r = 0; r < LR; ++r) acc[r] += v * bf2f(P.W[r * P.w_rs + k * P.w_cs]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < LR; ++r) acc[r] = group_sum<64>(acc[r]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < LR; ++r) sh[wave][r] = acc[r];
+    }
+    __syncthreads();
+    if (tid < LR) P.t[m * LR + tid] = ((sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid])) * scale;
+}
+
 extern "C" int cxr_lora_down_bf16(const void* x, long ldx, long M, int K, const void* W0, long w0_rs, long w0_cs, float* t0, float p0,
                                   unsigned int site0, const void* W1, long w1_rs, long w1_cs, float* t1, float p1, unsigned int site1,
                                   const unsigned int* seed, int rows_per_b, int tpos0, const float* ln_gamma, const float* ln_beta, float ln_eps,
@@ -78,8 +137,12 @@ extern "C" int cxr_lora_down_bf16(const void* x, long ldx, long M, int K, const 
         q.drop.seed = seed; q.drop.site = site; q.drop.thr16 = p > 0.f ? dropout_thr16(p) : 0u; q.drop.inv = 1.0f / (1.0f - p);
         q.drop.rows_per_b = rows_per_b; q.drop.t0 = tpos0; return q;
     };
-    CXR_LAUNCH(lora_down_kernel, dim3(cdiv(M, 4), W1 ? 2 : 1), dim3(256), 0, stream, (const bf16_t*)x, ldx, M, K, mk(W0, w0_rs, w0_cs, t0, p0, site0),
-                       mk(W1 ? W1 : W0, w1_rs, w1_cs, t1 ? t1 : t0, p1, site1), ln_gamma, ln_beta, ln_eps, scale);
+    if (M <= 256)
+        CXR_LAUNCH(lora_down_row_kernel, dim3((unsigned)M, W1 ? 2 : 1), dim3(256), 0, stream, (const bf16_t*)x, ldx, M, K, mk(W0, w0_rs, w0_cs, t0, p0, site0),
+                           mk(W1 ? W1 : W0, w1_rs, w1_cs, t1 ? t1 : t0, p1, site1), ln_gamma, ln_beta, ln_eps, scale);
+    else
+        CXR_LAUNCH(lora_down_kernel, dim3(cdiv(M, 4), W1 ? 2 : 1), dim3(256), 0, stream, (const bf16_t*)x, ldx, M, K, mk(W0, w0_rs, w0_cs, t0, p0, site0),
+                           mk(W1 ? W1 : W0, w1_rs, w1_cs, t1 ? t1 : t0, p1, site1), ln_gamma, ln_beta, ln_eps, scale);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

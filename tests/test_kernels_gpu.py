@@ -311,9 +311,10 @@ def test_gemm_skinny_decode(ops, M, N, K):
     assert bool((cache[:, 2, :] == 0).all())
 
 
-def test_lora_train_mode_kernels(ops):
+@pytest.mark.parametrize("R", [96, 528])          # <= 256 rows: one workgroup per row (decode); above: one wave per row (teacher forcing)
+def test_lora_train_mode_kernels(ops, R):
     """peft Linear under train(): y = base(x) + s * B(A(dropout(x))) and its backward, from the three rank-8 kernels of csrc/lora.hip."""
-    R, K, N, T, r, s_ = 96, 768, 768, 24, 8, 4.0
+    K, N, T, r, s_ = 768, 768, 24, 8, 4.0
     x, dy = dev(rnd(R, K).to(BF)), dev(rnd(R, N, seed=1).to(BF))
     A, Bm = dev(rnd(r, K, seed=2, scale=0.05).to(BF)), dev(rnd(N, r, seed=3, scale=0.05).to(BF))
     A2 = dev(rnd(r, K, seed=4, scale=0.05).to(BF))
