@@ -396,6 +396,93 @@ __global__ __launch_bounds__(1024) void sample_topk_lds_kernel(const float* __re
         else for (int j = i; j < V && j < i + 4; ++j) row[j] = x[j];
     }
     __syncthreads();
+    // ---- fast path (top_k <= 256): candidate filtering instead of four contended-histogram radix passes over the row.
+    //   L = k-th largest of 256 group maxima (a lower bound of the k-th largest element: those are k distinct elements >= L), so every
+    //   kept entry is among the few elements >= L; the exact threshold, the softmax and the inverse-CDF walk then run on that short list.
+    constexpr int CAND = 1024;
+    __shared__ float gmax[256];
+    __shared__ float cval[CAND];
+    __shared__ int cidx[CAND];
+    __shared__ float sval[CAND];
+    __shared__ int sidx[CAND];
+    __shared__ int ncand, nkept;
+    __shared__ float thr_s;
+    if (top_k > 0 && top_k <= 256 && top_k < V) {
+        float lm = -INFINITY;
+        for (int v = tid; v < V; v += 1024) lm = fmaxf(lm, row[v]);
+        lm = fmaxf(lm, __shfl_xor(lm, 1, 64));
+        lm = fmaxf(lm, __shfl_xor(lm, 2, 64));
+        if ((tid & 3) == 0) gmax[tid >> 2] = lm;
+        if (tid == 0) { ncand = 0; nkept = 0; thr_s = -INFINITY; pick = -1; }
+        __syncthreads();
+        if (tid < 256) {                                           // rank of my group maximum (descending, ties by lower index first)
+            const float mine = gmax[tid];
+            int rank = 0;
+            for (int j = 0; j < 256; ++j) { const float o = gmax[j]; rank += (o > mine) || (o == mine && j < tid); }
+            if (rank == top_k - 1) thr_s = mine;
+        }
+        __syncthreads();
+        const float L = thr_s;
+        for (int v = tid; v < V; v += 1024) {
+            const float a = row[v];
+            if (a >= L) { const int i = atomicAdd(&ncand, 1); if (i < CAND) { cval[i] = a; cidx[i] = v; } }
+        }
+        __syncthreads();
+        const int nc = ncand;
+        if (nc <= CAND) {
+            if (tid < nc) {                                        // the k-th largest VALUE among the candidates (entries equal to it are all kept)
+                const float a = cval[tid];
+                int gt = 0, ge = 0;
+                for (int j = 0; j < nc; ++j) { const float o = cval[j]; gt += o > a; ge += o >= a; }
+                if (gt < top_k && top_k <= ge) thr_s = a;          // every thread holding that value writes the same number
+            }
+            __syncthreads();
+            const float t = thr_s;
+            if (tid < nc && cval[tid] >= t) {                      // kept entries, sorted by vocabulary index (torch.multinomial's category order)
+                const int myi = cidx[tid];
+                int pos = 0;
+                for (int j = 0; j < nc; ++j) pos += (cval[j] >= t) && (cidx[j] < myi);
+                sval[pos] = cval[tid]; sidx[pos] = myi;
+                atomicAdd(&nkept, 1);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const int nk = nkept;
+                float mx = -INFINITY;
+                for (int i = lane; i < nk; i += 64) mx = fmaxf(mx, sval[i] * invt);
+                mx = group_max<64>(mx);
+                float tot = 0.f;
+                for (int i = lane; i < nk; i += 64) tot += __expf(sval[i] * invt - mx);
+                tot = group_sum<64>(tot);
+                const float target = u[r] * tot;
+                float carry = 0.f;
+                int found = -1;
+                for (int i0 = 0; i0 < nk && found < 0; i0 += 64) {
+                    const int i = i0 + lane;
+                    const float e = i < nk ? __expf(sval[i] * invt - mx) : 0.f;
+                    float incl = e;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const float y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+                    const bool hit = i < nk && target < carry + incl;
+                    const unsigned long long bal = __ballot(hit);
+                    if (bal) found = i0 + __ffsll((long long)bal) - 1;
+                    carry += __shfl(incl, 63, 64);
+                }
+                if (found < 0) found = nk - 1;                      // numerical edge (u ~ 1): the last kept entry
+                if (lane == 0) {
+                    long tok = sidx[found];
+                    if (unfinished) {
+                        const int uf = unfinished[r];
+                        if (!uf) tok = pad;
+                        else if (tok == eos) unfinished[r] = 0;
+                    }
+                    next[r] = tok;
+                }
+            }
+            return;
+        }
+        __syncthreads();                                           // pathological ties (more than CAND elements >= L): general path below
+    }
     // exact k-th largest (radix select on the order-preserving integer image)
     float t = -INFINITY;
     if (top_k > 0 && top_k < V) {

@@ -678,6 +678,19 @@ def test_select_token(ops):
     lo, _ = ops.select_token(row[:1], mode=1, temperature=1.0, top_k=k, u=torch.tensor([0.0]).cuda())
     hi, _ = ops.select_token(row[:1], mode=1, temperature=1.0, top_k=k, u=torch.tensor([0.999999]).cuda())
     assert lo.item() == topi.min().item() and hi.item() == topi.max().item()
+    # ties at the k-th value are all kept (TopKLogitsWarper removes only scores < the k-th): a constant row keeps the whole vocabulary
+    # (this also exercises the general radix path: more than 1024 elements reach the candidate filter's lower bound)
+    flat = torch.zeros(1, V, device="cuda")
+    a, _ = ops.select_token(flat, mode=1, temperature=1.0, top_k=k, u=torch.tensor([0.0]).cuda())
+    b, _ = ops.select_token(flat, mode=1, temperature=1.0, top_k=k, u=torch.tensor([0.5]).cuda())
+    assert a.item() == 0 and abs(b.item() - V // 2) <= 1
+    # a tie exactly at the k-th value inside the candidate path: both tied entries stay in the support
+    tied = logits[:1].clone()
+    kth, kp1 = topi[k - 1].item(), torch.topk(logits[0], k + 1)[1][k].item()
+    tied[0, kp1] = tied[0, kth]
+    many = tied.expand(2048, V).contiguous()
+    d2, _ = ops.select_token(many, mode=1, temperature=5.0, top_k=k, u=torch.rand(2048, generator=torch.Generator().manual_seed(6)).cuda())
+    assert bool(torch.isin(d2, torch.cat([topi, torch.tensor([kp1], device="cuda")])).all()) and bool((d2 == kp1).any())
 
 
 def test_adamw_matches_torch(ops):
