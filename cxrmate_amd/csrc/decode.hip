@@ -94,9 +94,11 @@ __device__ __forceinline__ float bfv(const bf16x8_t& v, int j) {
     return __uint_as_float(((uint32_t)(uint16_t)__builtin_bit_cast(s16x8_t, v)[j]) << 16);
 }
 
-template <int MT, bool LNA>   // MT = number of 16-row tiles of A; LNA = LayerNorm on the A operand (K == 768)
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs g) {
-    __shared__ float red[4][MT][64][4];
+// MT = number of 16-row tiles of A; LNA = LayerNorm on the A operand (K == 768); NW = waves per workgroup splitting K (8 for K >= 2048: the
+// 3072-wide FFN output projection otherwise runs three dependent load rounds per wave)
+template <int MT, bool LNA, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g) {
+    __shared__ float red[NW][MT][64][4];
     __shared__ float lnbuf[2][4][MT][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // grouped launch: blocks [0, N0/16) -> problem 0, next N1/16 -> problem 1, ... (q / k / v projections share A and one launch)
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs g) {
     const SkinnyProb P = g.p[pi];
     const int n0 = blk * 16;
     const int fr = lane & 15, fq = lane >> 4;
-    const int kslice = g.K / 4, k0 = wave * kslice;
+    const int kslice = g.K / NW, k0 = wave * kslice;
     const int nw = n0 + fr < P.N ? n0 + fr : P.N - 1;
     const bf16_t* wp = P.W + (long)nw * P.ldw + k0 + fq * 8;
     // epilogue operands are fetched up front by wave 0 so their latency overlaps the weight stream
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs g) {
         int m = t * 16 + fr; m = m < g.M ? m : g.M - 1;
         ap[t] = g.A + (long)m * g.lda + k0 + fq * 8;
     }
-    constexpr int KB = LNA ? 6 : (MT == 1 ? 12 : (MT == 2 ? 8 : 4));   // k-steps (of 32) whose loads are in flight together
+    constexpr int KB = LNA ? 6 : (MT == 1 ? 12 : (MT == 2 ? (NW == 8 ? 12 : 8) : 4));   // k-steps (of 32) whose loads are in flight together
     for (int kb = 0; kb < kslice; kb += 32 * KB) {
         bf16x8_t wf[KB], af[MT][KB];
 #pragma unroll
@@ -229,7 +231,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyArgs g) {
         for (int r = 0; r < 4; ++r) {
             const int m = t * 16 + fq * 4 + r;                       // D[m][n]: lane owns column n, rows (lane>>4)*4 + r
             if (m >= g.M) continue;
-            float v = red[0][t][lane][r] + red[1][t][lane][r] + red[2][t][lane][r] + red[3][t][lane][r] + bv;
+            float v = bv;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += red[w][t][lane][r];
             if (P.lr_t) {
 #pragma unroll
                 for (int r8 = 0; r8 < 8; ++r8) v += P.lr_t[m * 8 + r8] * lrB[r8];
@@ -250,8 +254,10 @@ static int launch_skinny(const SkinnyArgs& g, hipStream_t stream) {
     for (int i = 0; i < g.nprob; ++i) grid += cdiv(g.p[i].N, 16);
     const int mt = cdiv(g.M, 16);
     if (g.lnA_g && g.K != 768) return CXR_ERR_ARG;
-#define SKINNY(MT_) do { if (g.lnA_g) CXR_LAUNCH((gemm_skinny_kernel<MT_, true>), dim3(grid), dim3(256), 0, stream, g);        \
-                         else         CXR_LAUNCH((gemm_skinny_kernel<MT_, false>), dim3(grid), dim3(256), 0, stream, g); } while (0)
+    const bool wide = !g.lnA_g && g.K >= 2048 && (g.K % 256) == 0;
+#define SKINNY(MT_) do { if (g.lnA_g)  CXR_LAUNCH((gemm_skinny_kernel<MT_, true, 4>), dim3(grid), dim3(256), 0, stream, g);        \
+                         else if (wide) CXR_LAUNCH((gemm_skinny_kernel<MT_, false, 8>), dim3(grid), dim3(512), 0, stream, g);      \
+                         else          CXR_LAUNCH((gemm_skinny_kernel<MT_, false, 4>), dim3(grid), dim3(256), 0, stream, g); } while (0)
     if (mt == 1) SKINNY(1); else if (mt == 2) SKINNY(2); else if (mt == 3) SKINNY(3); else SKINNY(4);
 #undef SKINNY
     CXR_LAUNCH_CHECK();
