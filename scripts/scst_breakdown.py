@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Wall-clock breakdown of the train-mode SCST step (configs[3] per-GPU shape) into its phases."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cxrmate_amd.config import EncoderDecoderConfig
+from cxrmate_amd.modelling import LongitudinalPromptMultiCXREncoderDecoderModel
+from cxrmate_amd.reward import CXRBERTReward
+from cxrmate_amd.training import FusedAdamW
+from cxrmate_amd import ops
+
+dev = torch.device("cuda")
+B, N = 16, 2
+m = LongitudinalPromptMultiCXREncoderDecoderModel(EncoderDecoderConfig(), device=dev, seed=0).train()
+for p in m.decoder.parameters():
+    p.requires_grad_(True)
+opt = FusedAdamW(m, lr=5e-6)
+reward = CXRBERTReward(dev, seed=1)
+g = torch.Generator().manual_seed(0)
+images = torch.randn(B, N, 3, 384, 384, generator=g).to(dev)
+prompt = torch.tensor([[8, 10, 9, 11, 1]] * B, device=dev)
+ones = torch.ones(B, 128, dtype=torch.int64, device=dev)
+lab = torch.randint(1000, 30000, (B, 128), generator=g).to(dev)
+
+def T(name, fn, n=3):
+    fn(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        out = fn()
+    torch.cuda.synchronize()
+    print(f"{name:44s} {(time.perf_counter() - t) / n * 1e3:8.2f} ms")
+    return out
+
+with torch.no_grad():
+    eo = T("encoder, 32 images (train-mode BatchNorm)", lambda: m.encoder(images))
+    seqs, base, rec = T("sample + greedy, 255 steps (one 32-row decode)", lambda: m.sample_and_greedy(eo, prompt, [1, 3], [9, 1, 3], 4, 256 + 5, 1, None, 4), 2)
+    T("reward x2 (pred + cached labels), R=128", lambda: (reward.reward_from_ids(lab, ones, lab, ones), reward.reward_from_ids(lab, ones, lab, ones)))
+    s2 = seqs[:, 1:]
+    P = prompt.shape[1]
+    n_new = s2.shape[1] - P
+    tf_in = s2[:, :P + n_new - 1].contiguous()
+    tt = torch.cat(rec["tt"][:n_new], 1).contiguous(); pos = torch.cat(rec["pos"][:n_new], 1).contiguous()
+    mask = (tf_in != 4).to(torch.uint8)
+    enc, em = eo.last_hidden_state.contiguous(), eo.attention_mask.to(torch.uint8).contiguous()
+
+    def rescore():
+        opt.zero_grad()
+        logits, saved = m._dec.forward(tf_in, enc, em, mask, tt, pos, save=True, seed=rec["seed"])
+        Bq, Tq, V = logits.shape
+        flat = logits[:, P - 1:, :].contiguous().view(-1, V)
+        thr = ops.topk_threshold(flat, 50)
+        labels = s2[:, P:].reshape(-1)
+        w = ops.ce_weights(labels, 4, mode=1, reward=torch.ones(Bq, device=dev), T=n_new)
+        loss, _, dl = ops.softmax_ce(flat, labels, 4, w, thr=thr)
+        full = torch.zeros((Bq, Tq, dl.shape[1]), dtype=dl.dtype, device=dev)
+        full[:, P - 1:, :] = dl.view(Bq, n_new, -1)
+        m._dec.backward(saved, dlogits=full.view(Bq * Tq, -1), need_denc=False)
+        ops.wgrad_join()
+    T("re-score: TF fwd + REINFORCE loss + decoder bwd", rescore)
+    T("AdamW, 80.9 M decoder parameters", lambda: opt.step())
