@@ -28,6 +28,7 @@ struct GemmArgs {
     // rs_after != 0 applies the row scale AFTER the residual (CvT's second DropPath scales the whole layer output, quirk Q12)
     const uint32_t* drop_seed; uint32_t drop_site, drop_thr16; float drop_inv; int drop_rows_per_b, drop_t0;
     const float* row_scale; int rs_rows, rs_after;
+    int lds_epilogue;             // 1: every memory-facing epilogue access is 16-byte aligned -> the tile goes through LDS and is written in full rows
 };
 
 template <int BK> struct Swz;
@@ -161,8 +162,107 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
         }
     }
 
-    // epilogue: lane owns C[m][n0..n0+3], m = .. + (lane&15), n0 = .. + (lane>>4)*4
     const uint32_t dseed = g.drop_thr16 ? *g.drop_seed : 0u;
+    // ---- row-contiguous epilogue. In the MFMA layout a lane owns 4 consecutive columns of 16 different rows, so a wave's store instruction
+    // touches 16 rows x 32 bytes (bf16): quarter-line writes, and the same for the residual / saved pre-activation streams -- for this model's
+    // short K loops (6-12 steps) that was up to 40 % of a GEMM's time. Each wave parks its 64 x (BN/2) fp32 sub-tile (bias already added) in
+    // the now idle staging LDS (XOR-swizzled 16-byte slots: conflict-free both ways) and reads it back 8 columns per lane, 8 lanes per row:
+    // every global access of the epilogue is 16 bytes per lane and 128-256 contiguous bytes per row.
+    constexpr int WCOLS = BN / 2;
+    constexpr bool LDS_EPI_FITS = NST * 2 * TILE_BYTES >= 4 * 64 * WCOLS * 4;
+    if (LDS_EPI_FITS && g.lds_epilogue) {
+        __syncthreads();                                         // every wave has finished reading the last K step's fragments
+        float* stg = reinterpret_cast<float*>(lds) + wave * (64 * WCOLS);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) {
+                const int row = mt * 16 + fr, c4 = nt * 4 + fq;
+                float4 v = make_float4(acc[nt][mt][0] * g.alpha, acc[nt][mt][1] * g.alpha, acc[nt][mt][2] * g.alpha, acc[nt][mt][3] * g.alpha);
+                const int n0 = tn * BN + wn * WCOLS + c4 * 4;
+                if (g.bias && n0 < g.N) {
+                    const float4 b = *reinterpret_cast<const float4*>(g.bias + n0);
+                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                }
+                *reinterpret_cast<float4*>(stg + row * WCOLS + ((c4 ^ (row & (WCOLS / 4 - 1))) << 2)) = v;
+            }
+        __syncthreads();
+        constexpr int CPRW = WCOLS / 8;                          // 8-column chunks per sub-tile row
+#pragma unroll
+        for (int it = 0; it < CPRW; ++it) {
+            const int c = it * 64 + lane;
+            const int row = c / CPRW, cc = c % CPRW;
+            const int m = tm * BM + wm * 64 + row;
+            const int n = tn * BN + wn * WCOLS + cc * 8;
+            if (m >= g.M || n >= g.N) continue;
+            const bool full = n + 8 <= g.N;                       // N % 4 == 0: otherwise exactly 4 valid columns
+            const int sw = row & (WCOLS / 4 - 1);
+            const float4 lo = *reinterpret_cast<const float4*>(stg + row * WCOLS + (((2 * cc) ^ sw) << 2));
+            const float4 hi = *reinterpret_cast<const float4*>(stg + row * WCOLS + (((2 * cc + 1) ^ sw) << 2));
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            if (g.act == 1) {
+                if (g.aux) {
+                    bf16_t* ap = g.aux + (long)m * g.ldaux + n;
+                    if (full) *reinterpret_cast<uint4*>(ap) = pack8(v);
+                    else { uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); *reinterpret_cast<uint2*>(ap) = pk; }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+            } else if (g.act == 2) {
+                float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                const bf16_t* ap = g.aux + (long)m * g.ldaux + n;
+                if (full) unpack8(*reinterpret_cast<const uint4*>(ap), a);
+                else { const uint2 pk = *reinterpret_cast<const uint2*>(ap); a[0] = __uint_as_float(pk.x << 16); a[1] = __uint_as_float(pk.x & 0xffff0000u);
+                       a[2] = __uint_as_float(pk.y << 16); a[3] = __uint_as_float(pk.y & 0xffff0000u); }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(a[j]);
+            }
+            if (g.drop_thr16) {
+                const uint32_t dkey = dropout_row_key(dseed, g.drop_site, (uint32_t)(m / g.drop_rows_per_b), (uint32_t)(g.drop_t0 + m % g.drop_rows_per_b));
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const uint32_t bits = dropout_pair_bits(dkey, (uint32_t)(n + j) >> 1);
+                    v[j] = (bits & 0xffffu) >= g.drop_thr16 ? v[j] * g.drop_inv : 0.f;
+                    v[j + 1] = (bits >> 16) >= g.drop_thr16 ? v[j + 1] * g.drop_inv : 0.f;
+                }
+            }
+            const float rscale = g.row_scale ? g.row_scale[m / g.rs_rows] : 1.0f;
+            if (g.row_scale && !g.rs_after) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= rscale;
+            }
+            if (g.residual) {
+                float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                const bf16_t* rp = g.residual + (long)m * g.ldr + n;
+                if (full) unpack8(*reinterpret_cast<const uint4*>(rp), a);
+                else { const uint2 pk = *reinterpret_cast<const uint2*>(rp); a[0] = __uint_as_float(pk.x << 16); a[1] = __uint_as_float(pk.x & 0xffff0000u);
+                       a[2] = __uint_as_float(pk.y << 16); a[3] = __uint_as_float(pk.y & 0xffff0000u); }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += a[j];
+            }
+            if (g.row_scale && g.rs_after) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= rscale;
+            }
+            if (g.out_f32) {
+                float* cp = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n;
+                float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+                if (g.accumulate) {
+                    const float4 p0 = *reinterpret_cast<const float4*>(cp);
+                    o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;
+                    if (full) { const float4 p1 = *reinterpret_cast<const float4*>(cp + 4); o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w; }
+                }
+                *reinterpret_cast<float4*>(cp) = o0;
+                if (full) *reinterpret_cast<float4*>(cp + 4) = o1;
+            } else {
+                bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n;
+                if (full) *reinterpret_cast<uint4*>(cp) = pack8(v);
+                else { uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); *reinterpret_cast<uint2*>(cp) = pk; }
+            }
+        }
+        return;
+    }
+    // epilogue (fallback: BK = 32 tiles or operands without 16-byte alignment): lane owns C[m][n0..n0+3], m = .. + (lane&15), n0 = .. + (lane>>4)*4
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = tm * BM + wm * 64 + mt * 16 + fr;
@@ -244,6 +344,11 @@ extern "C" int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw
     g.drop_seed = drop_seed; g.drop_site = drop_site; g.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u; g.drop_inv = 1.0f / (1.0f - drop_p);
     g.drop_rows_per_b = drop_rows_per_b > 0 ? drop_rows_per_b : 1; g.drop_t0 = drop_t0;
     g.row_scale = row_scale; g.rs_rows = rs_rows > 0 ? rs_rows : 1; g.rs_after = rs_after;
+    static int lds_epi = -1;          // CXR_GEMM_LDS_EPILOGUE=0 falls back to the per-lane 8-byte epilogue (A/B aid)
+    if (lds_epi < 0) { const char* e = getenv("CXR_GEMM_LDS_EPILOGUE"); lds_epi = e ? atoi(e) : 1; }
+    auto al16 = [](const void* p, long ld, int esz) { return p == nullptr || ((((size_t)p) % 16) == 0 && ((ld * esz) % 16) == 0); };
+    g.lds_epilogue = lds_epi && (N % 4) == 0 && al16(C, ldc, out_f32 ? 4 : 2) && al16(residual, ldr, 2) && al16(aux, ldaux, 2) &&
+                     (bias == nullptr || (((size_t)bias) % 16) == 0);
     static int force_bk = -1, stages = -1, force_bn = -1;     // tuning aids: CXR_GEMM_BK=32|64, CXR_GEMM_STAGES=2|3|4, CXR_GEMM_BN=64|128
     if (force_bk < 0) { const char* e = getenv("CXR_GEMM_BK"); force_bk = e ? atoi(e) : 0; }
     if (stages < 0) { const char* e = getenv("CXR_GEMM_STAGES"); stages = e ? atoi(e) : 2; }
