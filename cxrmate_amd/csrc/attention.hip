@@ -9,6 +9,7 @@
 // lives on ONE lane pair: softmax needs a single cross-lane exchange, and the exponentiated tile is already the
 // B operand of O^T += V^T.P^T (accumulator-as-operand, k-permutation per cdna_hip_programming.md section 3).
 #include "common.h"
+#include <stdlib.h>
 
 #define ATT_NEG (-1.0e30f)      // "masked" sentinel (finite: masked-only rows become uniform, like finfo.min in the reference)
 
@@ -21,6 +22,7 @@ struct AttnArgs {
     int causal, causal_shift;          // key j visible to query i iff j <= i + causal_shift
     // dropout on the attention probabilities (TF5 modeling_bert.py:131, train mode): P*keep/(1-p) feeds P.V, the softmax sums do not change
     const uint32_t* drop_seed; uint32_t drop_site, drop_thr16; float drop_inv; int drop_t0;      // drop_thr16 == 0: off
+    int rowstore;
 };
 
 constexpr int KS_STRIDE = 72;          // bf16 elements per K row in LDS (144 B)
@@ -38,6 +40,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * KS_STRIDE];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * VS_STRIDE];
     __shared__ unsigned char Ms[64];
+    __shared__ __attribute__((aligned(16))) bf16_t Os[4][32 * 64];      // per-wave output tile for the row-contiguous store
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.y, b = blockIdx.z;
@@ -200,17 +203,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     // ---- finalize
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    {
+        const int row0 = qb0 + wave * 32;                          // first query row of this wave
+        const int valid = a.Tq - row0 < 32 ? a.Tq - row0 : 32;
+        if (a.rowstore && (a.o_rs % 8) == 0 && (a.o_bs % 8) == 0 && ((size_t)a.O % 16) == 0) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    uint2 pk;
+                    pk.x = pack2bf(o[dt][4 * rg + 0] * inv, o[dt][4 * rg + 1] * inv);
+                    pk.y = pack2bf(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
+                    TILE_PUT(Os[wave], lane, dt, rg, pk);
+                }
+            tile_rows_store(Os[wave], lane, a.O + (long)b * a.o_bs + (long)row0 * a.o_rs + head * 64, a.o_rs, valid);
+        } else if (qrow < a.Tq) {
+            bf16_t* op = a.O + (long)b * a.o_bs + (long)qrow * a.o_rs + head * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    uint2 pk;
+                    pk.x = pack2bf(o[dt][4 * rg + 0] * inv, o[dt][4 * rg + 1] * inv);
+                    pk.y = pack2bf(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
+                    *reinterpret_cast<uint2*>(op + dt * 32 + 8 * rg + 4 * hh) = pk;
+                }
+        }
+    }
     if (qrow < a.Tq) {
-        bf16_t* op = a.O + (long)b * a.o_bs + (long)qrow * a.o_rs + head * 64;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                uint2 pk;
-                pk.x = pack2bf(o[dt][4 * rg + 0] * inv, o[dt][4 * rg + 1] * inv);
-                pk.y = pack2bf(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
-                *reinterpret_cast<uint2*>(op + dt * 32 + 8 * rg + 4 * hh) = pk;
-            }
         if (a.LSE && hh == 0)
             a.LSE[((long)b * a.H + head) * a.Tq + qrow] = (m_run + log2f(l_tot)) * 0.69314718055994531f;
     }
@@ -230,6 +250,9 @@ extern "C" int cxr_attn_fwd_bf16(const void* Q, const void* K, const void* V, vo
     a.scale_log2e = scale * 1.4426950408889634f; a.causal = causal; a.causal_shift = causal_shift;
     a.drop_seed = drop_seed; a.drop_site = drop_site; a.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u;
     a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_t0 = drop_t0;
+    static int rowstore = -1;
+    if (rowstore < 0) { const char* e = getenv("CXR_ATTN_ROWSTORE"); rowstore = e ? atoi(e) : 1; }
+    a.rowstore = rowstore;
     dim3 grid(cdiv(Tq, 128), H, B);
     CXR_LAUNCH(attn_fwd_kernel, grid, dim3(256), 0, stream, a);
     CXR_LAUNCH_CHECK();

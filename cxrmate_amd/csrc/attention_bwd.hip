@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnBwdArgs a)
     __shared__ __attribute__((aligned(16))) float Ls[64];
     __shared__ __attribute__((aligned(16))) float Es[64];
     __shared__ __attribute__((aligned(16))) uint32_t Rk[64];          // dropout row keys of the tile's queries
+    __shared__ __attribute__((aligned(16))) bf16_t Os[4][32 * 64];    // per-wave tile for the row-contiguous dK / dV stores
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.y, b = blockIdx.z;
@@ -196,19 +197,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnBwdArgs a)
 #undef BWD_GLOAD_Q
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dk[0][i] *= a.scale; dk[1][i] *= a.scale; }
-    if (key < a.Tk) {
-        bf16_t* kp = a.dK + (long)b * a.dk_bs + (long)key * a.dk_rs + head * 64;
-        bf16_t* vp = a.dV + (long)b * a.dk_bs + (long)key * a.dk_rs + head * 64;
+    {
+        // dK / dV rows of this wave: 32 keys x 64 columns each, written as full 128-byte rows through the wave's LDS tile (common.h)
+        const int row0 = kb0 + wave * 32;
+        const int valid = a.Tk - row0 < 32 ? a.Tk - row0 : 32;
+        bf16_t* kp = a.dK + (long)b * a.dk_bs + (long)row0 * a.dk_rs + head * 64;
+        bf16_t* vp = a.dV + (long)b * a.dk_bs + (long)row0 * a.dk_rs + head * 64;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 uint2 pk;
                 pk.x = pack2bf(dk[dt][4 * rg], dk[dt][4 * rg + 1]); pk.y = pack2bf(dk[dt][4 * rg + 2], dk[dt][4 * rg + 3]);
-                *reinterpret_cast<uint2*>(kp + dt * 32 + 8 * rg + 4 * hh) = pk;
-                pk.x = pack2bf(dv[dt][4 * rg], dv[dt][4 * rg + 1]); pk.y = pack2bf(dv[dt][4 * rg + 2], dv[dt][4 * rg + 3]);
-                *reinterpret_cast<uint2*>(vp + dt * 32 + 8 * rg + 4 * hh) = pk;
+                TILE_PUT(Os[wave], lane, dt, rg, pk);
             }
+        tile_rows_store(Os[wave], lane, kp, a.dk_rs, valid);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                uint2 pk;
+                pk.x = pack2bf(dv[dt][4 * rg], dv[dt][4 * rg + 1]); pk.y = pack2bf(dv[dt][4 * rg + 2], dv[dt][4 * rg + 3]);
+                TILE_PUT(Os[wave], lane, dt, rg, pk);
+            }
+        tile_rows_store(Os[wave], lane, vp, a.dk_rs, valid);
     }
 }
 
@@ -217,6 +231,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t Kt[64 * TS];
     __shared__ __attribute__((aligned(16))) bf16_t Vr[64 * RS];
     __shared__ unsigned char Ms[64];
+    __shared__ __attribute__((aligned(16))) bf16_t Os[4][32 * 64];    // per-wave tile for the row-contiguous dQ store
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.y, b = blockIdx.z;
@@ -330,16 +345,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
 #undef BWD_GLOAD_KV
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dq[0][i] *= a.scale; dq[1][i] *= a.scale; }
-    if (qrow < a.Tq) {
-        bf16_t* qp = a.dQ + (long)b * a.dq_bs + (long)qrow * a.dq_rs + head * 64;
+    {
+        const int row0 = qb0 + wave * 32;
+        const int valid = a.Tq - row0 < 32 ? a.Tq - row0 : 32;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 uint2 pk;
                 pk.x = pack2bf(dq[dt][4 * rg], dq[dt][4 * rg + 1]); pk.y = pack2bf(dq[dt][4 * rg + 2], dq[dt][4 * rg + 3]);
-                *reinterpret_cast<uint2*>(qp + dt * 32 + 8 * rg + 4 * hh) = pk;
+                TILE_PUT(Os[wave], lane, dt, rg, pk);
             }
+        tile_rows_store(Os[wave], lane, a.dQ + (long)b * a.dq_bs + (long)row0 * a.dq_rs + head * 64, a.dq_rs, valid);
     }
 }
 

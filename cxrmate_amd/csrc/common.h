@@ -111,6 +111,26 @@ __device__ __forceinline__ bool dropout_keep(uint32_t row_key, uint32_t col, uin
 }
 static inline uint32_t dropout_thr16(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
 
+// Row-contiguous store of a 32-row x 64-column bf16 tile held in the swapped-MFMA accumulator layout of the attention kernels (lane = row
+// (lane & 31), half hh = lane >> 5; for dt in {0,1}, rg in 0..3 the lane owns columns dt*32 + 8*rg + 4*hh .. +3). Storing straight from that
+// layout writes 8 bytes per lane to 64 different rows per instruction; through a 4-KB LDS tile (8-byte slots XOR-swizzled by the row) every
+// global store is 16 bytes per lane and a full 128-byte row per 8 lanes. Usage: TILE_PUT for the 8 (dt, rg) groups, then tile_rows_store.
+#define TILE_PUT(tile, lane, dt, rg, pk) \
+    (*reinterpret_cast<uint2*>((tile) + ((lane) & 31) * 64 + ((((dt) * 8 + 2 * (rg) + ((lane) >> 5)) ^ ((lane) & 15)) << 2)) = (pk))
+__device__ __forceinline__ void tile_rows_store(const bf16_t* tile, int lane, bf16_t* gbase, long row_stride, int rows_valid) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = it * 64 + lane;
+        const int r = c >> 3, cc = c & 7;
+        const uint2 lo = *reinterpret_cast<const uint2*>(tile + r * 64 + (((2 * cc) ^ (r & 15)) << 2));
+        const uint2 hi = *reinterpret_cast<const uint2*>(tile + r * 64 + (((2 * cc + 1) ^ (r & 15)) << 2));
+        if (r < rows_valid) *reinterpret_cast<uint4*>(gbase + (long)r * row_stride + cc * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+}
+
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {     // butterfly over W lanes (W power of two <= 64)
 #pragma unroll
