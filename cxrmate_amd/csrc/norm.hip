@@ -255,7 +255,7 @@ extern "C" int cxr_layernorm_fwd_bf16(const void* x, long ldx, const float* gamm
 
 // workspace: fp32 [cxr_layernorm_bwd_grid(rows, C)][2][C] (may be null when dgamma/dbeta are not wanted)
 extern "C" int cxr_layernorm_bwd_grid(long rows, int C) {
-    int grid = ln_grid(rows, C, C == 768 ? 1 : 2, false);
+    int grid = ln_grid(rows, C, C == 192 ? 4 : (C == 768 ? 1 : 2), false);
     return grid < 512 ? grid : 512;
 }
 
@@ -271,7 +271,7 @@ extern "C" int cxr_layernorm_bwd_bf16(const void* x, long ldx, const void* dy, l
     dd.row_scale = row_scale;
     const int grid = cxr_layernorm_bwd_grid(rows, C);
     float* partial = dgamma ? workspace : nullptr;
-    LN_DISPATCH(C, layernorm_bwd_kernel, 2, 2, 2, 2, 1, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, gamma, stats, (const bf16_t*)add, ldadd,
+    LN_DISPATCH(C, layernorm_bwd_kernel, 2, 2, 4, 2, 1, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, gamma, stats, (const bf16_t*)add, ldadd,
                 (bf16_t*)dx, lddx, partial, rows, dd);
     if (dgamma) CXR_LAUNCH(layernorm_bwd_reduce_kernel, dim3(cdiv(2 * C, 32), cdiv(grid, 64)), dim3(256), 0, stream, partial, grid, C, dgamma, dbeta);
     CXR_LAUNCH_CHECK();
