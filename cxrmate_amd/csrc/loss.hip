@@ -237,15 +237,65 @@ __device__ float kth_largest(const float* __restrict__ x, int V, int k, unsigned
     return ord2f(prefix);
 }
 
-__global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __restrict__ logits, long ld, int V, int k, float* __restrict__ thr) {
+// TopPLogitsWarper (TF5 generation/logits_process.py, applied after the top-k warper): with the kept entries sorted ascending, entries whose
+// cumulative softmax probability is <= 1 - top_p are removed (the largest entry always stays). The survivors are a suffix of that order, so the
+// filter is a value threshold: returns the smallest surviving value among the candidates >= t_k held in LDS (cval / cidx, n entries, n small:
+// the top-k set). Ties are ordered by vocabulary index. Called by every thread of the block; *tmin_ord is LDS scratch.
+__device__ float topp_threshold_from_list(const float* cval, const int* cidx, int n, float t_k, float top_p, float invt, unsigned* tmin_ord) {
+    if (threadIdx.x == 0) *tmin_ord = 0xffffffffu;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float vi = cval[i];
+        if (!(vi >= t_k)) continue;
+        const int ii = cidx[i];
+        float mx = -INFINITY;
+        for (int j = 0; j < n; ++j) if (cval[j] >= t_k) mx = fmaxf(mx, cval[j] * invt);
+        float tot = 0.f, cum = 0.f;
+        bool is_max = true;
+        for (int j = 0; j < n; ++j) {
+            const float vj = cval[j];
+            if (!(vj >= t_k)) continue;
+            const float e = __expf(vj * invt - mx);
+            tot += e;
+            const bool before = vj < vi || (vj == vi && cidx[j] <= ii);        // j sorts at or before i (ascending, index breaks ties)
+            if (before) cum += e; else is_max = false;
+        }
+        const bool removed = !is_max && (cum / tot <= 1.0f - top_p);
+        if (!removed) atomicMin(tmin_ord, f2ord(vi));
+    }
+    __syncthreads();
+    const float t = ord2f(*tmin_ord);
+    __syncthreads();
+    return fmaxf(t, t_k);
+}
+
+__global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __restrict__ logits, long ld, int V, int k, float top_p, float invt,
+                                                             float* __restrict__ thr) {
     __shared__ unsigned hist[256];
     __shared__ unsigned bc[2];
-    const float t = kth_largest(logits + (long)blockIdx.x * ld, V, k < V ? k : V, hist, bc);
+    __shared__ float cval[1024];
+    __shared__ int cidx[1024];
+    __shared__ int ncand;
+    __shared__ unsigned tmin;
+    const float* x = logits + (long)blockIdx.x * ld;
+    float t = kth_largest(x, V, k < V ? k : V, hist, bc);
+    if (top_p < 1.0f) {                                          // top-p on top of the top-k set (<= 1024 entries, else top-k only)
+        if (threadIdx.x == 0) ncand = 0;
+        __syncthreads();
+        for (int v = threadIdx.x; v < V; v += 256) {
+            const float a = x[v];
+            if (a >= t) { const int i = atomicAdd(&ncand, 1); if (i < 1024) { cval[i] = a; cidx[i] = v; } }
+        }
+        __syncthreads();
+        const int n = ncand;
+        if (n <= 1024) t = topp_threshold_from_list(cval, cidx, n, t, top_p, invt, &tmin);
+    }
     if (threadIdx.x == 0) thr[blockIdx.x] = t;
 }
-extern "C" int cxr_topk_threshold(const float* logits, long ld, long R, int V, int k, float* thr, hipStream_t stream) {
-    if (R <= 0 || V <= 0 || k <= 0) return CXR_ERR_ARG;
-    CXR_LAUNCH(topk_threshold_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, V, k, thr);
+// thr[r] = the value below which TopKLogitsWarper(k) followed by TopPLogitsWarper(top_p) (at the given temperature) remove row r's entries
+extern "C" int cxr_topk_threshold(const float* logits, long ld, long R, int V, int k, float top_p, float temperature, float* thr, hipStream_t stream) {
+    if (R <= 0 || V <= 0 || k <= 0 || !(top_p > 0.f) || temperature <= 0.f) return CXR_ERR_ARG;
+    CXR_LAUNCH(topk_threshold_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, V, k, top_p, 1.0f / temperature, thr);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
@@ -355,17 +405,18 @@ __global__ __launch_bounds__(256) void select_token_kernel(const float* __restri
     }
 }
 
-__global__ void sample_topk_lds_kernel(const float* __restrict__ logits, long ld, int V, float temperature, int top_k, const float* __restrict__ u,
-                                       long* __restrict__ next, int* __restrict__ unfinished, long eos, long pad);
+__global__ void sample_topk_lds_kernel(const float* __restrict__ logits, long ld, int V, float temperature, int top_k, float top_p,
+                                       const float* __restrict__ u, long* __restrict__ next, int* __restrict__ unfinished, long eos, long pad);
 
-extern "C" int cxr_select_token(const float* logits, long ld, long R, int V, int mode, float temperature, int top_k, const float* u, long* next,
-                                int* unfinished, long eos, long pad, float* margin, hipStream_t stream) {
-    if (R <= 0 || V <= 0 || (mode == 1 && (!u || temperature <= 0.f))) return CXR_ERR_ARG;
-    if (mode == 1 && !margin && (size_t)V * sizeof(float) <= 150 * 1024) {           // sampling: row-resident-in-LDS kernel
+extern "C" int cxr_select_token(const float* logits, long ld, long R, int V, int mode, float temperature, int top_k, float top_p, const float* u,
+                                long* next, int* unfinished, long eos, long pad, float* margin, hipStream_t stream) {
+    if (R <= 0 || V <= 0 || (mode == 1 && (!u || temperature <= 0.f || !(top_p > 0.f)))) return CXR_ERR_ARG;
+    if (mode == 1 && top_p < 1.0f && !(top_k > 0 && top_k <= 256 && !margin && (size_t)V * sizeof(float) <= 130 * 1024)) return CXR_ERR_ARG;
+    if (mode == 1 && !margin && (size_t)V * sizeof(float) <= 130 * 1024) {           // sampling: row-resident-in-LDS kernel
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)sample_topk_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
-        CXR_LAUNCH(sample_topk_lds_kernel, dim3((unsigned)R), dim3(1024), (size_t)V * sizeof(float), stream, logits, ld, V, temperature, top_k, u, next,
-                   unfinished, eos, pad);
+        CXR_LAUNCH(sample_topk_lds_kernel, dim3((unsigned)R), dim3(1024), (size_t)V * sizeof(float), stream, logits, ld, V, temperature, top_k, top_p, u,
+                   next, unfinished, eos, pad);
         CXR_LAUNCH_CHECK();
         return CXR_OK;
     }
@@ -380,8 +431,8 @@ extern "C" int cxr_select_token(const float* logits, long ld, long R, int V, int
 // passes (4 radix-select passes, max, sum, inverse-CDF search) must not go back to L2/HBM. One 1024-thread workgroup loads its row ONCE
 // into LDS (120 KB of the 160 KB) with 16-byte loads and runs every pass from there.
 __global__ __launch_bounds__(1024) void sample_topk_lds_kernel(const float* __restrict__ logits, long ld, int V, float temperature, int top_k,
-                                                               const float* __restrict__ u, long* __restrict__ next, int* __restrict__ unfinished,
-                                                               long eos, long pad) {
+                                                               float top_p, const float* __restrict__ u, long* __restrict__ next,
+                                                               int* __restrict__ unfinished, long eos, long pad) {
     extern __shared__ __attribute__((aligned(16))) float row[];          // [V]
     __shared__ unsigned hist[256];
     __shared__ unsigned bc[2];
@@ -437,7 +488,11 @@ __global__ __launch_bounds__(1024) void sample_topk_lds_kernel(const float* __re
                 if (gt < top_k && top_k <= ge) thr_s = a;          // every thread holding that value writes the same number
             }
             __syncthreads();
-            const float t = thr_s;
+            float t = thr_s;
+            if (top_p < 1.0f) {                                    // TopPLogitsWarper on the top-k set (uniform branch)
+                __shared__ unsigned tmin;
+                t = topp_threshold_from_list(cval, cidx, nc, t, top_p, invt, &tmin);
+            }
             if (tid < nc && cval[tid] >= t) {                      // kept entries, sorted by vocabulary index (torch.multinomial's category order)
                 const int myi = cidx[tid];
                 int pos = 0;

@@ -92,7 +92,7 @@ class DecodeSession:
 
     def _run(self, cur, strip, mode, prefill):
         m = self.model
-        kind, special, mask_token_id, top_k, temperature, eos, pad, train = mode
+        kind, special, mask_token_id, top_k, temperature, eos, pad, train, top_p = mode
         if prefill:
             fed = self.ids[:, strip:cur]
             new, mask, tt, pos = m._step_inputs(fed, special, mask_token_id, prefill=True)
@@ -114,7 +114,7 @@ class DecodeSession:
         if n_smp:
             u = torch.rand(n_smp, device=logits.device, dtype=torch.float32)
             ops.select_token(logits[:n_smp], mode=1, temperature=temperature, top_k=top_k or 0, u=u, unfinished=None if unf is None else unf[:n_smp],
-                             eos=eos_, pad=pad or 0, out=self.nxt[:n_smp])
+                             eos=eos_, pad=pad or 0, out=self.nxt[:n_smp], top_p=top_p)
         if n_smp < self.B:
             ops.select_token(logits[n_smp:], unfinished=None if unf is None else unf[n_smp:], eos=eos_, pad=pad or 0, out=self.nxt[n_smp:])
         self.ids[:, cur] = self.nxt
@@ -172,8 +172,9 @@ class GenerationMixin:
             raise ValueError("special_token_ids is required (reference prepare_inputs_for_generation signature)")
         if self.kind == "longitudinal" and mask_token_id is None:
             raise ValueError("mask_token_id is required for the longitudinal model")
-        if top_p is not None and float(top_p) < 1.0:
-            raise NotImplementedError("top_p < 1 is not on the accelerated path (the reference samples with top_p=1.0)")
+        top_p = 1.0 if top_p is None else float(top_p)
+        if do_sample and top_p < 1.0 and not (top_k and 0 < int(top_k) <= 256):
+            raise NotImplementedError("top_p < 1 is applied on top of a top-k set of at most 256 entries (the reference samples with top_k=50)")
         with torch.no_grad():
             if encoder_outputs is None:
                 encoder_outputs = self._encode(pixel_values)
@@ -211,7 +212,8 @@ class GenerationMixin:
         margins = []
         if forced_tokens is None and not return_margins:
             ids = self._generate_session(ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, bos_token_id, eos_token_id,
-                                         pad_token_id, do_sample, top_k, temperature, rec if ((output_scores and do_sample) or record_inputs) else None)
+                                         pad_token_id, do_sample, top_k, temperature, rec if ((output_scores and do_sample) or record_inputs) else None,
+                                         top_p=top_p)
         else:
             ids, margins = self._generate_eager(ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, bos_token_id, eos_token_id,
                                                 pad_token_id, forced_tokens, return_margins)
@@ -219,7 +221,7 @@ class GenerationMixin:
         scores = None
         if output_scores and do_sample:
             scores = self._rescore_sampled(ids, prompt_len, rec, enc, enc_mask, special_token_ids, mask_token_id, bos_token_id,
-                                           top_k, temperature)
+                                           top_k, temperature, top_p)
         if return_dict_in_generate:
             out = ModelOutput(sequences=ids, scores=scores)
             if record_inputs:
@@ -267,7 +269,7 @@ class GenerationMixin:
         return ids, margins
 
     def _generate_session(self, ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, bos_token_id, eos_token_id, pad_token_id,
-                          do_sample, top_k, temperature, rec):
+                          do_sample, top_k, temperature, rec, top_p=1.0):
         """Greedy / top-k sampling over a DecodeSession (static buffers, graph-replayed steps, EOS polled every 8 steps)."""
         dev = self.device
         B, prompt_len = ids.shape
@@ -279,7 +281,7 @@ class GenerationMixin:
                 kind, special = "pair", (tuple(special_token_ids[0]), tuple(special_token_ids[1]))
             else:
                 kind, special = ("sample" if do_sample else "greedy"), tuple(special_token_ids)
-            mode = (kind, special, mask_token_id, int(top_k or 0), float(temperature), eos_token_id, pad_token_id, bool(self.training))
+            mode = (kind, special, mask_token_id, int(top_k or 0), float(temperature), eos_token_id, pad_token_id, bool(self.training), float(top_p))
             if rec is not None:
                 rec["seed"] = ses.seed.clone() if self.training else None
             cur = prompt_len
@@ -313,7 +315,7 @@ class GenerationMixin:
 
     @torch.no_grad()
     def sample_and_greedy(self, encoder_outputs, prompt_ids, special_sample, special_greedy, mask_token_id, max_length, bos_token_id,
-                          eos_token_id, pad_token_id, top_k=50, temperature=1.0):
+                          eos_token_id, pad_token_id, top_k=50, temperature=1.0, top_p=1.0):
         """The two decodes of one SCST step (reference scst/gt_prompt.py:162-180 sample, :94-112 greedy baseline) as ONE batch of 2B
         rows over the same studies: a cached decode step is bound by streaming the decoder weights, so both halves share every weight
         read and every launch. Rows [0,B) are sampled (top-k, temperature) with the separator set `special_sample`, rows [B,2B) take the
@@ -332,7 +334,7 @@ class GenerationMixin:
         enc_mask8 = None if enc_mask is None else enc_mask.to(device=dev, dtype=torch.uint8).contiguous()      # B rows serve the 2B decode rows
         rec = {"tt": [], "pos": []}
         out = self._generate_session(torch.cat([ids, ids], dim=0), enc16, enc_mask8, (special_sample, special_greedy), mask_token_id,
-                                     max_length, bos_token_id, eos_token_id, pad_token_id, "pair", top_k, temperature, rec)
+                                     max_length, bos_token_id, eos_token_id, pad_token_id, "pair", top_k, temperature, rec, top_p=top_p)
         rec = {"tt": [t[:B] for t in rec["tt"]], "pos": [None if p_ is None else p_[:B] for p_ in rec["pos"]], "seed": rec.get("seed")}
 
         def trim(seq):                                   # each half ends where ITS last row finished (HF stops per generate() call)
@@ -347,7 +349,7 @@ class GenerationMixin:
     generate = torch.no_grad()(_generate)          # `.generate.__wrapped__` is the grad-enabled body (reference scst/gt_prompt.py:162)
 
     # ------------------------------------------------------------------------------------------ differentiable scores
-    def _rescore_sampled(self, ids, prompt_len, rec, enc, enc_mask, special_token_ids, mask_token_id, bos_token_id, top_k, temperature):
+    def _rescore_sampled(self, ids, prompt_len, rec, enc, enc_mask, special_token_ids, mask_token_id, bos_token_id, top_k, temperature, top_p=1.0):
         """Processed scores of every sampling step, [B,V] each, with autograd through the decoder (and encoder_outputs)."""
         fed = self._fed(ids, bos_token_id)
         stripped = ids.shape[1] - fed.shape[1]
@@ -364,10 +366,10 @@ class GenerationMixin:
         if temperature is not None and float(temperature) != 1.0:
             sc = sc / float(temperature)
         if top_k:
-            with torch.no_grad():
+            with torch.no_grad():                                            # sc is already temperature-scaled: warpers see temperature 1
                 flat = sc.detach().reshape(-1, sc.shape[-1]).contiguous()
-                thr = ops.topk_threshold(flat, int(top_k)).view(sc.shape[0], sc.shape[1], 1)
-            sc = sc.masked_fill(sc < thr, float("-inf"))                    # TopKLogitsWarper semantics (ties at the k-th value kept)
+                thr = ops.topk_threshold(flat, int(top_k), top_p, 1.0).view(sc.shape[0], sc.shape[1], 1)
+            sc = sc.masked_fill(sc < thr, float("-inf"))                    # TopK (+ TopP) LogitsWarper semantics (ties at the threshold kept)
         return tuple(sc[:, t, :] for t in range(sc.shape[1]))
 
     # ------------------------------------------------------------------------------------------ beam search

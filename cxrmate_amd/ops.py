@@ -501,19 +501,20 @@ def softmax_ce(logits, labels, ignore_index, row_w, thr=None, need_grad=True):
     return loss, row_loss, (dl[:, :V] if dl is not None else None)
 
 
-def topk_threshold(logits, k):
+def topk_threshold(logits, k, top_p=1.0, temperature=1.0):
+    """Per-row value threshold of TopKLogitsWarper(k) followed by TopPLogitsWarper(top_p) at `temperature` (logits are the RAW scores)."""
     R, V = logits.shape
     thr = torch.empty((R,), dtype=torch.float32, device=logits.device)
-    LIB.call("cxr_topk_threshold", _p(logits), logits.stride(0), R, V, int(k), _p(thr), _s())
+    LIB.call("cxr_topk_threshold", _p(logits), logits.stride(0), R, V, int(k), float(top_p), float(temperature), _p(thr), _s())
     return thr
 
 
-def select_token(logits, mode=0, temperature=1.0, top_k=0, u=None, unfinished=None, eos=-1, pad=0, need_margin=False, out=None):
+def select_token(logits, mode=0, temperature=1.0, top_k=0, u=None, unfinished=None, eos=-1, pad=0, need_margin=False, out=None, top_p=1.0):
     R, V = logits.shape
     assert logits.dtype == torch.float32 and logits.stride(1) == 1
     nxt = out if out is not None else torch.empty((R,), dtype=torch.int64, device=logits.device)
     margin = torch.empty((R,), dtype=torch.float32, device=logits.device) if need_margin else None
-    LIB.call("cxr_select_token", _p(logits), logits.stride(0), R, V, mode, float(temperature), int(top_k), _p(u), _p(nxt), _p(unfinished),
+    LIB.call("cxr_select_token", _p(logits), logits.stride(0), R, V, mode, float(temperature), int(top_k), float(top_p), _p(u), _p(nxt), _p(unfinished),
              int(eos), int(pad), _p(margin), _s())
     return nxt, margin
 

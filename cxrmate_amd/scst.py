@@ -22,7 +22,7 @@ from . import dp, ops
 
 
 def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, decoder_max_len, top_k=50, temperature=1.0,
-              fused_decode=True):
+              fused_decode=True, top_p=1.0):
     """special = dict(bos, eos, sep, pad, pmt_sep). reward_fn(sequences_without_prompt [B,L] int64) -> fp32 [B] given the caller's
     labels (closure); decode/re-tokenise round trips live inside reward_fn so that benchmarks can swap them for synthetic ids.
     Returns dict(loss, reward, baseline, seq_len)."""
@@ -34,11 +34,11 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         if fused_decode:
             # sample + greedy baseline as one 2B-row cached decode (same per-row inputs as the two separate calls below)
             seqs, base, rec = model.sample_and_greedy(eo, prompt_ids, [bos, sep], [pmt_sep, bos, sep], pad, decoder_max_len + P, bos, eos, pad,
-                                                      top_k=top_k, temperature=temperature)
+                                                      top_k=top_k, temperature=temperature, top_p=top_p)
         else:
             smp = model.generate(input_ids=prompt_ids, special_token_ids=[bos, sep], encoder_outputs=eo, bos_token_id=bos, eos_token_id=eos,
                                  pad_token_id=pad, mask_token_id=pad, return_dict_in_generate=True, do_sample=True, num_beams=1, use_cache=True,
-                                 top_k=top_k, top_p=1.0, temperature=temperature, max_new_tokens=decoder_max_len - 1, record_inputs=True)
+                                 top_k=top_k, top_p=top_p, temperature=temperature, max_new_tokens=decoder_max_len - 1, record_inputs=True)
             seqs, rec = smp["sequences"], smp["recorded_inputs"]
             base = model.generate(encoder_outputs=eo, decoder_input_ids=prompt_ids, special_token_ids=[pmt_sep, bos, sep],
                                   max_length=decoder_max_len + P, bos_token_id=bos, eos_token_id=eos, pad_token_id=pad, mask_token_id=pad,
@@ -68,7 +68,7 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         if float(temperature) != 1.0:
             raise NotImplementedError("temperature != 1 (the reference trains with 1.0)")
         flat = sc.reshape(-1, V) if sc.is_contiguous() else sc.contiguous().view(-1, V)
-        thr = ops.topk_threshold(flat, top_k) if top_k else None
+        thr = ops.topk_threshold(flat, top_k, top_p, temperature) if top_k else None
         labels = sampled.reshape(-1)
         w = ops.ce_weights(labels, pad, mode=1, reward=adv, T=n_new)
         loss, _, dl = ops.softmax_ce(flat, labels, pad, w, thr=thr)

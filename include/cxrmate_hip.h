@@ -154,8 +154,9 @@ int cxr_softmax_ce(const float* logits, long ld, const long* labels, long ignore
                    void* dlogits, long lddl, long R, int V, hipStream_t stream);
 int cxr_ce_weights(const long* labels, long R, long ignore_index, int mode, const float* reward, int T, float* row_w, hipStream_t stream);
 int cxr_ce_reduce(const float* row_loss, const float* row_w, long R, float* loss, hipStream_t stream);
-int cxr_topk_threshold(const float* logits, long ld, long R, int V, int k, float* thr, hipStream_t stream);
-int cxr_select_token(const float* logits, long ld, long R, int V, int mode, float temperature, int top_k, const float* u, long* next,
+int cxr_topk_threshold(const float* logits, long ld, long R, int V, int k, float top_p, float temperature, float* thr, hipStream_t stream);
+                       /* thr[r] = value below which TopKLogitsWarper(k) then TopPLogitsWarper(top_p) at `temperature` remove entries (top_p = 1: top-k only) */
+int cxr_select_token(const float* logits, long ld, long R, int V, int mode, float temperature, int top_k, float top_p, const float* u, long* next,
                      int* unfinished, long eos, long pad, float* margin, hipStream_t stream);
 int cxr_log_softmax_rows(float* x, long ld, long R, int V, const float* add_row, hipStream_t stream);
 

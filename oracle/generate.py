@@ -46,6 +46,17 @@ def top_k_filter(scores, top_k):
     return scores.masked_fill(scores < kth, float("-inf"))
 
 
+def top_p_filter(scores, top_p, min_tokens_to_keep=1):
+    """TopPLogitsWarper (TF5 logits_process.py): sort ascending, remove entries whose cumulative softmax probability is <= 1 - top_p,
+    always keep the `min_tokens_to_keep` largest. Applied after top_k_filter (its -inf entries carry zero probability)."""
+    sorted_logits, sorted_indices = torch.sort(scores, descending=False)
+    cumulative_probs = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+    remove = cumulative_probs <= (1 - top_p)
+    remove[..., -min_tokens_to_keep:] = False
+    remove = remove.scatter(-1, sorted_indices, remove)
+    return scores.masked_fill(remove, float("-inf"))
+
+
 def greedy(logits_fn, kind, batch_size, special_token_ids, bos_token_id, eos_token_id, pad_token_id, max_length,
            prompt_ids=None, mask_token_id=None, max_new_tokens=None, forced_tokens=None, return_margins=False):
     """TF5:gen:2783-2973 with do_sample=False. `logits_fn(ids, attn_mask, token_type_ids, position_ids) -> [B,T,V]`.

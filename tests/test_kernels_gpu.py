@@ -730,3 +730,23 @@ def test_pixels_normalize_pad_collate(ops):
     assert bool((out[1, 1:] == 0).all()) and bool((out[0, 2] == 0).all())
     # the cross-attention mask rule of the reference (first pixel of the image != 0, quirk Q3) sees exactly the padded images
     assert (out[:, :, 0, 0, 0] != 0).cpu().tolist() == [[True, True, False], [True, False, False], [True, True, True]]
+
+
+def test_top_p_threshold_and_sampling(ops):
+    """TopKLogitsWarper(50) + TopPLogitsWarper(p): the threshold kernel marks exactly the oracle's surviving set, and sampling never leaves it."""
+    from oracle import generate as ogen
+    R, V, k = 8, 30000, 50
+    logits = dev(rnd(R, V) * 2.0)
+    for p, temp in ((0.9, 1.0), (0.5, 0.7), (0.05, 1.0), (1.0, 1.0)):
+        thr = ops.topk_threshold(logits, k, p, temp)
+        want = ogen.top_p_filter(ogen.top_k_filter(logits.cpu() / temp, k), p) if p < 1.0 else ogen.top_k_filter(logits.cpu() / temp, k)
+        kept = (logits >= thr[:, None]).cpu()
+        assert torch.equal(kept, torch.isfinite(want)), (p, temp, kept.sum(-1), torch.isfinite(want).sum(-1))
+        row = logits[:1].expand(2048, V).contiguous()
+        u = torch.rand(2048, generator=torch.Generator().manual_seed(3)).cuda()
+        draws, _ = ops.select_token(row, mode=1, temperature=temp, top_k=k, top_p=p, u=u)
+        support = torch.nonzero(torch.isfinite(want[0]))[:, 0].cuda()
+        assert bool(torch.isin(draws, support).all())
+        probs = torch.softmax(want[0][support.cpu()], -1)
+        freq = torch.stack([(draws == i).float().mean() for i in support]).cpu()
+        assert (freq - probs).abs().max().item() < 0.04

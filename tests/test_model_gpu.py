@@ -353,6 +353,16 @@ def test_prompted_generate_and_scst_scores(M):
     finite = torch.isfinite(scores).sum(1)
     assert bool((finite >= 50).all()) and bool((finite <= 52).all())
     assert bool(torch.isfinite(torch.gather(scores, 1, sampled[:, None, :])).all())     # every sampled id lies inside its step's top-k set
+    # nucleus sampling on top of top-k (scst_sample_top_p < 1): processed scores keep between 1 and 50 entries, sampled ids inside them
+    torch.manual_seed(1)
+    nuc = m.generate.__wrapped__(m, input_ids=prompt.cuda(), special_token_ids=[gu.BOS, gu.SEP], encoder_outputs=eo, bos_token_id=gu.BOS,
+                                 eos_token_id=gu.EOS, pad_token_id=gu.PAD, mask_token_id=gu.PAD, return_dict_in_generate=True, do_sample=True,
+                                 num_beams=1, use_cache=True, output_scores=True, top_p=0.6, top_k=50, temperature=1.0, max_new_tokens=new)
+    nsc = torch.stack(nuc["scores"], dim=-1)
+    nseq = nuc["sequences"][:, 1:] if torch.all(nuc["sequences"][:, 0] == 1) else nuc["sequences"]
+    nfin = torch.isfinite(nsc).sum(1)
+    assert bool((nfin >= 1).all()) and bool((nfin <= 52).all())
+    assert bool(torch.isfinite(torch.gather(nsc, 1, nseq[:, P:][:, None, :]))[nseq[:, P:][:, None, :] != gu.PAD].all())
     reward = torch.tensor([0.37, -0.21], device="cuda")
     nll = torch.nn.functional.nll_loss(torch.log_softmax(scores, dim=1), sampled, ignore_index=gu.PAD, reduction="none")
     loss = (nll.sum(-1) * reward).mean()

@@ -205,3 +205,19 @@ def test_reward_trunk_matches_transformers_bert():
         assert cos.shape == (3,) and bool((cos.abs() <= 1.0 + 1e-6).all())
         same = obert.reward_cosine(ids, am, ids, am, sd, cfg)
         np.testing.assert_allclose(same.numpy(), 1.0, atol=1e-5)
+
+
+def test_top_k_top_p_filters_match_transformers_warpers():
+    """The oracle's logits warpers against the classes the reference's generate() runs (TF5 generation/logits_process.py)."""
+    from transformers.generation.logits_process import TopKLogitsWarper, TopPLogitsWarper
+    g = torch.Generator().manual_seed(0)
+    scores = torch.randn(6, 500, generator=g) * 3
+    ids = torch.zeros(6, 1, dtype=torch.long)
+    for k, p in ((50, 1.0), (50, 0.9), (20, 0.5), (50, 0.05)):
+        ref = TopKLogitsWarper(top_k=k)(ids, scores.clone())
+        got = ogen.top_k_filter(scores, k)
+        if p < 1.0:
+            ref = TopPLogitsWarper(top_p=p)(ids, ref)
+            got = ogen.top_p_filter(got, p)
+        assert torch.equal(torch.isfinite(ref), torch.isfinite(got)) and torch.equal(ref[torch.isfinite(ref)], got[torch.isfinite(got)])
+        assert bool((torch.isfinite(got).sum(-1) >= 1).all())
