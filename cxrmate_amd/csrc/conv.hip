@@ -572,6 +572,131 @@ extern "C" int cxr_bn_train_bwd_coef(const float* g, const float* mean, const fl
     return CXR_OK;
 }
 
+// ---- statistics pass + row sum + per-channel epilogue in one C-ABI call (two launches instead of 3-4 per projection pair): the row-sum kernel
+// of the statistics partials finishes with the per-channel work that used to be separate 4-us launches on the critical path
+// (bn_train_finalize / bn_train_bwd_coef): 126 launches per training step.
+struct BnFwdProj { const float* w; const float* g; const float* b; float* run_mean; float* run_var; float* mean_out; float* rstd_out; float* wf; float* sh; };
+struct BnBwdProj { const float* g; const float* mean; const float* rstd; float* dg; float* db; float* coef; };
+
+// ws [G][nproj][2][C] partial rows -> per projection q (blockIdx.y) and channel c: (sum0, sum1) = column sums of [q][0][c], [q][1][c]
+__device__ __forceinline__ void bn_rows_sum2(const float* __restrict__ ws, int G, int K, int col0, int col1, float& s0, float& s1, float (*red)[64][2]) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f;
+    {
+        float u0[4] = {0, 0, 0, 0}, u1[4] = {0, 0, 0, 0};                    // 8 independent loads in flight per lane
+        int g = ty;
+        for (; g + 3 * 16 < G; g += 4 * 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { u0[u] += ws[(long)(g + 16 * u) * K + col0]; u1[u] += ws[(long)(g + 16 * u) * K + col1]; }
+        }
+        for (; g < G; g += 16) { u0[0] += ws[(long)g * K + col0]; u1[0] += ws[(long)g * K + col1]; }
+        a0 = (u0[0] + u0[1]) + (u0[2] + u0[3]); a1 = (u1[0] + u1[1]) + (u1[2] + u1[3]);
+    }
+    red[ty][tx][0] = a0; red[ty][tx][1] = a1;
+    __syncthreads();
+    s0 = 0.f; s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { s0 += red[q][tx][0]; s1 += red[q][tx][1]; }
+}
+
+__global__ __launch_bounds__(1024) void bn_train_reduce_finalize_kernel(const float* __restrict__ ws, int G, int C, int nproj, float count, float eps,
+                                                                        float momentum, BnFwdProj p0, BnFwdProj p1, float* __restrict__ stats) {
+    __shared__ float red[16][64][2];
+    const int q = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const BnFwdProj P = q == 0 ? p0 : p1;
+    const int K = nproj * 2 * C;
+    const int cc = c < C ? c : C - 1;
+    float s0, s1;
+    bn_rows_sum2(ws, G, K, (q * 2 + 0) * C + cc, (q * 2 + 1) * C + cc, s0, s1, red);
+    if ((threadIdx.x >> 6) != 0 || c >= C) return;
+    if (stats) { stats[(q * 2 + 0) * C + c] = s0; stats[(q * 2 + 1) * C + c] = s1; }
+    const float mean = s0 / count;
+    const float var = fmaxf(s1 / count - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    P.mean_out[c] = mean; P.rstd_out[c] = rstd;
+    if (momentum > 0.f) {
+        P.run_mean[c] = (1.f - momentum) * P.run_mean[c] + momentum * mean;
+        P.run_var[c] = (1.f - momentum) * P.run_var[c] + momentum * var * (count > 1.f ? count / (count - 1.f) : 1.f);
+    }
+    const float sc = P.g[c] * rstd;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) P.wf[t * C + c] = P.w[c * 9 + t] * sc;
+    P.sh[c] = P.b[c] - mean * sc;
+}
+
+__global__ __launch_bounds__(1024) void bn_train_reduce_coef_kernel(const float* __restrict__ ws, int G, int C, int nproj, float count, BnBwdProj p0,
+                                                                    BnBwdProj p1) {
+    __shared__ float red[16][64][2];
+    const int q = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const BnBwdProj P = q == 0 ? p0 : p1;
+    const int K = nproj * 2 * C;
+    const int cc = c < C ? c : C - 1;
+    float S, D;
+    bn_rows_sum2(ws, G, K, (q * 2 + 0) * C + cc, (q * 2 + 1) * C + cc, S, D, red);
+    if ((threadIdx.x >> 6) != 0 || c >= C) return;
+    const float r = P.rstd[c], mu = P.mean[c];
+    const float dgam = r * (D - mu * S);
+    P.dg[c] += dgam;
+    P.db[c] += S;
+    const float a = P.g[c] * r, m1 = S / count, m2 = dgam / count;
+    const float kc = -a * m2 * r;
+    P.coef[c] = a; P.coef[C + c] = -a * m1 - kc * mu; P.coef[2 * C + c] = kc;
+}
+
+static int launch_dwconv_stats_partials(const void* x, long x_bs, long x_rs, const float* w0, const float* w1, const void* dy0, const void* dy1, long dy_bs,
+                                        long dy_rs, float* ws, int Bn, int C, int H, int W, int stride, int tok0, hipStream_t stream, int* nblk_out,
+                                        long* count_out) {
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const long npix = (long)Bn * Ho * Wo;
+    const int rows = dw_partial_rows(npix, 256 / (C / 8));
+    const int ppb = (int)cdiv(npix, rows);
+    const int nblk = cdiv(npix, ppb);
+    const dim3 grid(nblk);
+#define STATS(N_, D_) CXR_LAUNCH((dwconv_stats_kernel<N_, D_>), grid, dim3(256), 0, stream, (const bf16_t*)x, x_bs, x_rs, w0, w1 ? w1 : w0,        \
+                                 (const bf16_t*)dy0, (const bf16_t*)(dy1 ? dy1 : dy0), dy_bs, dy_rs, ws, Bn, C, H, W, stride, Ho, Wo, tok0, ppb)
+    if (dy0) { if (w1) STATS(2, true); else STATS(1, true); }
+    else     { if (w1) STATS(2, false); else STATS(1, false); }
+#undef STATS
+    *nblk_out = nblk; *count_out = npix;
+    return CXR_OK;
+}
+
+// Forward of train-mode BatchNorm for one (wraw1 == NULL) or two projections: statistics of the raw conv outputs, batch mean / rstd, running-stat
+// update and the folded taps for cxr_dwconv_bn_fwd_bf16. Per projection i: wt_i raw taps [9][C] (conv layout for the kernels), w_i [C,9] (parameter
+// layout), gamma, beta, running mean / var (updated in place), outputs mean_i / rstd_i [C], wf_i [9][C], sh_i [C].
+extern "C" int cxr_dwconv_bn_train_fwd_stats_bf16(const void* x, long x_bs, long x_rs, int Bn, int C, int H, int W, int stride, int tok0, float eps,
+                                                  float momentum, float* ws, const float* wt0, const float* w0, const float* g0, const float* b0,
+                                                  float* rm0, float* rv0, float* mean0, float* rstd0, float* wf0, float* sh0, const float* wt1,
+                                                  const float* w1, const float* g1, const float* b1, float* rm1, float* rv1, float* mean1, float* rstd1,
+                                                  float* wf1, float* sh1, hipStream_t stream) {
+    if (Bn <= 0 || (C % 8) || C > 384 || (256 / (C / 8)) * C > 2048 || (stride != 1 && stride != 2) || !ws || !wt0) return CXR_ERR_ARG;
+    int nblk; long count;
+    launch_dwconv_stats_partials(x, x_bs, x_rs, wt0, wt1, nullptr, nullptr, 0, 0, ws, Bn, C, H, W, stride, tok0, stream, &nblk, &count);
+    BnFwdProj p0{w0, g0, b0, rm0, rv0, mean0, rstd0, wf0, sh0}, p1{w1, g1, b1, rm1, rv1, mean1, rstd1, wf1, sh1};
+    const int nproj = wt1 ? 2 : 1;
+    CXR_LAUNCH(bn_train_reduce_finalize_kernel, dim3(cdiv(C, 64), nproj), dim3(1024), 0, stream, ws, nblk, C, nproj, (float)count, eps, momentum, p0,
+                       nproj == 2 ? p1 : p0, (float*)nullptr);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// Backward counterpart: (sum dy, sum dy*c) per channel, then dgamma / dbeta (accumulated) and the coefficients (a, kb, kc) [3][C] of
+// dc = a*dy + kb + kc*c for cxr_dwconv_bn_train_dc_bf16.
+extern "C" int cxr_dwconv_bn_train_bwd_stats_bf16(const void* x, long x_bs, long x_rs, int Bn, int C, int H, int W, int stride, int tok0, float* ws,
+                                                  const float* wt0, const void* dy0, const float* g0, const float* mean0, const float* rstd0, float* dg0,
+                                                  float* db0, float* coef0, const float* wt1, const void* dy1, const float* g1, const float* mean1,
+                                                  const float* rstd1, float* dg1, float* db1, float* coef1, long dy_bs, long dy_rs, hipStream_t stream) {
+    if (Bn <= 0 || (C % 8) || C > 384 || (256 / (C / 8)) * C > 2048 || (stride != 1 && stride != 2) || !ws || !wt0 || !dy0) return CXR_ERR_ARG;
+    if ((wt1 != nullptr) != (dy1 != nullptr)) return CXR_ERR_ARG;
+    int nblk; long count;
+    launch_dwconv_stats_partials(x, x_bs, x_rs, wt0, wt1, dy0, dy1, dy_bs, dy_rs, ws, Bn, C, H, W, stride, tok0, stream, &nblk, &count);
+    BnBwdProj p0{g0, mean0, rstd0, dg0, db0, coef0}, p1{g1, mean1, rstd1, dg1, db1, coef1};
+    const int nproj = wt1 ? 2 : 1;
+    CXR_LAUNCH(bn_train_reduce_coef_kernel, dim3(cdiv(C, 64), nproj), dim3(1024), 0, stream, ws, nblk, C, nproj, (float)count, p0, nproj == 2 ? p1 : p0);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
 // dy <- dc = a*dy + kb + kc*c in place, c recomputed from the activation and the raw taps (class-token rows are untouched: no BN there)
 __global__ __launch_bounds__(256) void dwconv_bn_train_dc_kernel(const bf16_t* __restrict__ x, long x_bs, long x_rs, const float* __restrict__ wr /*[9][C]*/,
                                                                  const float* __restrict__ coef, bf16_t* __restrict__ dy, long dy_bs, long dy_rs,

@@ -83,23 +83,18 @@ class CvtEncoderEngine:
             hit = self._fold_cache[key] = w.view(w.shape[0], 9).t().contiguous()
         return hit
 
-    def _fold_train(self, h1, H, W, stride, tok0, s, l, names, out=None):
+    def _fold_train(self, h1, H, W, stride, tok0, s, l, names):
         """Train-mode BatchNorm of one (query) or two (key, value) depthwise projections of h1: batch statistics in one pass over h1,
-        running statistics moved in place. -> folds for dwconv_fwd, {name: (mean, rstd, count)} for backward."""
+        running statistics moved in place (two launches per call). -> folds for dwconv_fwd, {name: (mean, rstd, count)} for backward."""
         cfg, st = self.cfg, self.s
-        raws = [self._raw_taps(s, l, n) for n in names]
-        stats = ops.dwconv_stats(h1, H, W, stride, tok0, raws[0], raws[1] if len(raws) > 1 else None, out=out)
-        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-        count = h1.shape[0] * Ho * Wo
-        folds, kept = [], {}
-        for i, n in enumerate(names):
+        projs = []
+        for n in names:
             cp = self._conv_prefix(s, l, n)
-            fold, mean, rstd = ops.bn_train_finalize(stats[i], count, st.f32(cp + "convolution.weight"), st.f32(cp + "normalization.weight"),
-                                                     st.f32(cp + "normalization.bias"), cfg.bn_eps, cfg.bn_momentum,
-                                                     st.f32(cp + "normalization.running_mean"), st.f32(cp + "normalization.running_var"))
-            folds.append(fold)
-            kept[n] = (mean, rstd, count)
-        return folds, kept
+            projs.append(dict(wt=self._raw_taps(s, l, n), w=st.f32(cp + "convolution.weight"), g=st.f32(cp + "normalization.weight"),
+                              b=st.f32(cp + "normalization.bias"), run_mean=st.f32(cp + "normalization.running_mean"),
+                              run_var=st.f32(cp + "normalization.running_var")))
+        outs, count = ops.dwconv_bn_train_fwd_stats(h1, H, W, stride, tok0, cfg.bn_eps, cfg.bn_momentum, projs)
+        return [o[0] for o in outs], {n: (o[1], o[2], count) for n, o in zip(names, outs)}
 
     def _prepare_transposes(self):
         """W^T (the K-contiguous operand of every dX GEMM) for the current weight version: ONE batched launch over all ~130 matrices, issued on
@@ -220,9 +215,8 @@ class CvtEncoderEngine:
         h1 = h1.view(Bn, L, C)
         bn = None
         if self._train:
-            arena = torch.empty((3, 2, C), dtype=torch.float32, device=x.device)
-            (fq,), bn = self._fold_train(h1, H, W, cfg.stride_q[s], tok0, s, l, ("query",), out=arena[0:1])
-            (fk, fv), bkv = self._fold_train(h1, H, W, cfg.stride_kv[s], tok0, s, l, ("key", "value"), out=arena[1:3])
+            (fq,), bn = self._fold_train(h1, H, W, cfg.stride_q[s], tok0, s, l, ("query",))
+            (fk, fv), bkv = self._fold_train(h1, H, W, cfg.stride_kv[s], tok0, s, l, ("key", "value"))
             bn.update(bkv)
         else:
             fq, fk, fv = (self._fold_eval(s, l, n) for n in ("query", "key", "value"))
@@ -330,19 +324,22 @@ class CvtEncoderEngine:
         if sv["bn"] is not None:
             # batch-statistics BatchNorm: (sum dy, sum dy*c) per channel -> dc rewritten in place as the gradient of the RAW conv output ->
             # the ordinary dx / tap-sum kernels with the raw taps
-            arena = torch.empty((36, C), dtype=torch.float32, device=dy.device)     # 3 x (S, D) + 3 x tap sums
+            arena = torch.empty((30, C), dtype=torch.float32, device=dy.device)     # 3 x tap-sum outputs
             raws = {n: self._raw_taps(s, l, n) for n in strides}
-            ops.dwconv_stats(h1, H, W, strides["query"], tok0, raws["query"], dy0=dcs["query"], out=arena[0:2].view(1, 2, C))
-            ops.dwconv_stats(h1, H, W, strides["key"], tok0, raws["key"], raws["value"], dy0=dcs["key"], dy1=dcs["value"], out=arena[2:6].view(2, 2, C))
+
+            def bproj(name):
+                cp = self._conv_prefix(s, l, name)
+                mean, rstd, _ = sv["bn"][name]
+                return dict(wt=raws[name], dy=dcs[name], g=st.f32(cp + "normalization.weight"), mean=mean, rstd=rstd,
+                            dg=g(cp + "normalization.weight"), db=g(cp + "normalization.bias"))
+            coefs = dict(zip(("query",), ops.dwconv_bn_train_bwd_stats(h1, H, W, strides["query"], tok0, [bproj("query")])))
+            coefs.update(zip(("key", "value"), ops.dwconv_bn_train_bwd_stats(h1, H, W, strides["key"], tok0, [bproj("key"), bproj("value")])))
             for i, name in enumerate(("query", "key", "value")):
                 cp = self._conv_prefix(s, l, name)
-                mean, rstd, count = sv["bn"][name]
-                coef = ops.bn_train_bwd_coef(st.f32(cp + "normalization.weight"), mean, rstd, arena[2 * i:2 * i + 2], count,
-                                             g(cp + "normalization.weight"), g(cp + "normalization.bias"))
-                ops.dwconv_bn_train_dc_(h1, raws[name], coef, dcs[name], H, W, strides[name], tok0)
+                ops.dwconv_bn_train_dc_(h1, raws[name], coefs[name], dcs[name], H, W, strides[name], tok0)
                 projs.append((dcs[name], raws[name], strides[name]))
                 with ops._on_wgrad_stream(h1, dcs[name], arena):
-                    G2, _ = ops.dwconv_bn_bwd_w(h1, dcs[name], H, W, strides[name], tok0, out=arena[6 + 10 * i:16 + 10 * i])
+                    G2, _ = ops.dwconv_bn_bwd_w(h1, dcs[name], H, W, strides[name], tok0, out=arena[10 * i:10 * i + 10])
                     ops.tap_grad_accum(G2, g(cp + "convolution.weight"))
         else:
             arena = torch.empty((30, C), dtype=torch.float32, device=dy.device)

@@ -379,6 +379,42 @@ def dwconv_stats(x, H, W, stride, tok0, wr0, wr1=None, dy0=None, dy1=None, out=N
     return stats
 
 
+def dwconv_bn_train_fwd_stats(x, H, W, stride, tok0, eps, momentum, projs):
+    """Train-mode BatchNorm forward bookkeeping of one or two depthwise projections of x in ONE call. projs: list of dicts with wt (raw taps
+    [9,C]), w ([C,1,3,3] parameter), g, b, run_mean, run_var. -> per projection ((wf, sh), mean, rstd); count."""
+    Bn, L, C = x.shape
+    outs, args = [], []
+    for p in projs:
+        wf = torch.empty((9, C), device=x.device, dtype=torch.float32)
+        aux = torch.empty((3, C), device=x.device, dtype=torch.float32)                 # sh, mean, rstd
+        outs.append(((wf, aux[0]), aux[1], aux[2]))
+        args += [_p(p["wt"]), _p(p["w"]), _p(p["g"]), _p(p["b"]), _p(p["run_mean"]), _p(p["run_var"]), _p(aux[1]), _p(aux[2]), _p(wf), _p(aux[0])]
+    if len(projs) == 1:
+        args += [None] * 10
+    LIB.call("cxr_dwconv_bn_train_fwd_stats_bf16", _p(x), x.stride(0), x.stride(1), Bn, C, H, W, int(stride), int(tok0), float(eps), float(momentum),
+             _p(_dw_ws(C, x.device)), *args, _s())
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    return outs, Bn * Ho * Wo
+
+
+def dwconv_bn_train_bwd_stats(x, H, W, stride, tok0, projs):
+    """Train-mode BatchNorm backward bookkeeping in ONE call. projs: list of dicts with wt, dy, g, mean, rstd, dg, db. -> coef [3,C] per projection."""
+    Bn, L, C = x.shape
+    coefs, args = [], []
+    for p in projs:
+        coef = torch.empty((3, C), device=x.device, dtype=torch.float32)
+        coefs.append(coef)
+        args += [_p(p["wt"]), _p(p["dy"]), _p(p["g"]), _p(p["mean"]), _p(p["rstd"]), _p(p["dg"]), _p(p["db"]), _p(coef)]
+    if len(projs) == 1:
+        args += [None] * 8
+    else:
+        assert projs[0]["dy"].stride() == projs[1]["dy"].stride()
+    dy = projs[0]["dy"]
+    LIB.call("cxr_dwconv_bn_train_bwd_stats_bf16", _p(x), x.stride(0), x.stride(1), Bn, C, H, W, int(stride), int(tok0), _p(_dw_ws(C, x.device)),
+             *args, dy.stride(0), dy.stride(1), _s())
+    return coefs
+
+
 def bn_train_finalize(stats, count, w, g, b, eps, momentum, run_mean, run_var):
     """-> (wf [9,C], sh [C]) folded with the batch statistics, mean [C], rstd [C]; running stats updated in place."""
     C = w.shape[0]

@@ -125,6 +125,17 @@ int cxr_dwconv_ws_floats(int C);
 int cxr_dwconv_stats_bf16(const void* x, long x_bs, long x_rs, const float* w0, const float* w1, const void* dy0, const void* dy1, long dy_bs,
                           long dy_rs, float* stats, float* ws, int Bn, int C, int H, int W, int stride, int tok0, hipStream_t stream);
                           /* dy0 == NULL: (sum c, sum c^2) of the raw conv outputs c; else (sum dy, sum dy*c) for the backward */
+/* statistics pass + per-channel epilogue in ONE call (two launches) for one (wt1 == NULL) or two projections; wt_i = raw taps [9][C], w_i = the
+ * conv parameter [C,9]; see cxr_dwconv_stats_bf16 / cxr_bn_train_finalize / cxr_bn_train_bwd_coef for the pieces */
+int cxr_dwconv_bn_train_fwd_stats_bf16(const void* x, long x_bs, long x_rs, int Bn, int C, int H, int W, int stride, int tok0, float eps,
+                                       float momentum, float* ws, const float* wt0, const float* w0, const float* g0, const float* b0, float* rm0,
+                                       float* rv0, float* mean0, float* rstd0, float* wf0, float* sh0, const float* wt1, const float* w1,
+                                       const float* g1, const float* b1, float* rm1, float* rv1, float* mean1, float* rstd1, float* wf1, float* sh1,
+                                       hipStream_t stream);
+int cxr_dwconv_bn_train_bwd_stats_bf16(const void* x, long x_bs, long x_rs, int Bn, int C, int H, int W, int stride, int tok0, float* ws,
+                                       const float* wt0, const void* dy0, const float* g0, const float* mean0, const float* rstd0, float* dg0, float* db0,
+                                       float* coef0, const float* wt1, const void* dy1, const float* g1, const float* mean1, const float* rstd1,
+                                       float* dg1, float* db1, float* coef1, long dy_bs, long dy_rs, hipStream_t stream);
 int cxr_bn_train_finalize(const float* stats, long count, const float* w, const float* g, const float* b, float eps, float momentum,
                           float* run_mean, float* run_var, float* mean_out, float* rstd_out, float* wf, float* sh, int C, hipStream_t stream);
 int cxr_bn_train_bwd_coef(const float* g, const float* mean, const float* rstd, const float* SD, long count, float* dg, float* db, float* coef,

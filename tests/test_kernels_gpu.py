@@ -529,6 +529,7 @@ def test_dwconv_batchnorm_train_mode(ops, C, H, tok0):
         count = Bn * Ho * Ho
         xs = x[:, tok0:].float().transpose(1, 2).reshape(Bn, C, H, W).requires_grad_(True)
         folds, kept, refs, leaves = [], [], [], []
+        rm_start, rv_start = [p["rm"].clone() for p in par], [p["rv"].clone() for p in par]
         for i, p in enumerate(par):
             rm0, rv0 = p["rm"].clone(), p["rv"].clone()
             fold, mean, rstd = ops.bn_train_finalize(stats[i], count, p["w"], p["g"], p["b"], 1e-5, 0.1, p["rm"], p["rv"])
@@ -543,8 +544,21 @@ def test_dwconv_batchnorm_train_mode(ops, C, H, tok0):
         ys = ops.dwconv_bn(x, H, W, stride, tok0, *folds)
         for i in range(n):
             close(ys[i][:, tok0:], refs[i], what=f"train-mode bn fwd {name}{i}")
+        # the one-call variant (statistics + row sum + finalize in two launches) gives the same folds / statistics / running-stat update
+        fresh = [dict(wt=raws[i], w=par[i]["w"], g=par[i]["g"], b=par[i]["b"], run_mean=rm_start[i].clone(), run_var=rv_start[i].clone()) for i in range(n)]
+        fused, cnt = ops.dwconv_bn_train_fwd_stats(x, H, W, stride, tok0, 1e-5, 0.1, fresh)
+        assert cnt == count
+        for i in range(n):
+            close(fused[i][0][0], folds[i][0], rtol=1e-4, atol=1e-5, what="fused folded taps")
+            close(fused[i][0][1], folds[i][1], rtol=1e-4, atol=1e-4, what="fused shift")
+            close(fused[i][1], kept[i][0], rtol=1e-4, atol=1e-5, what="fused mean"); close(fused[i][2], kept[i][1], rtol=1e-4, atol=1e-4, what="fused rstd")
+            close(fresh[i]["run_mean"], par[i]["rm"], rtol=1e-5, atol=1e-6, what="fused running mean")
+            close(fresh[i]["run_var"], par[i]["rv"], rtol=1e-5, atol=1e-6, what="fused running var")
         dys = [dev(rnd(*ys[i].shape, seed=7 + i).to(BF)) for i in range(n)]
         sum((refs[i] * dys[i][:, tok0:].float()).sum() for i in range(n)).backward()
+        fdg, fdb = [torch.zeros(C, device="cuda") for _ in range(n)], [torch.zeros(C, device="cuda") for _ in range(n)]
+        fcoefs = ops.dwconv_bn_train_bwd_stats(x, H, W, stride, tok0, [dict(wt=raws[i], dy=dys[i], g=par[i]["g"], mean=kept[i][0], rstd=kept[i][1],
+                                                                             dg=fdg[i], db=fdb[i]) for i in range(n)])
         projs = []
         for i, p in enumerate(par):
             dc = dys[i].clone()
@@ -554,6 +568,8 @@ def test_dwconv_batchnorm_train_mode(ops, C, H, tok0):
                 close(both[1], SD, rtol=1e-4, atol=1e-3, what="paired backward statistics")
             dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
             coef = ops.bn_train_bwd_coef(p["g"], kept[i][0], kept[i][1], SD, count, dg, db)
+            close(fcoefs[i], coef, rtol=1e-4, atol=1e-5, what="fused backward coefficients")
+            close(fdg[i], dg, rtol=1e-4, atol=1e-4, what="fused dgamma"); close(fdb[i], db, rtol=1e-4, atol=1e-4, what="fused dbeta")
             ops.dwconv_bn_train_dc_(x, raws[i], coef, dc, H, W, stride, tok0)
             if tok0:
                 assert torch.equal(dc[:, 0], dys[i][:, 0])                            # class-token rows bypass conv + BN
