@@ -305,8 +305,8 @@ extern "C" int cxr_topk_threshold(const float* logits, long ld, long R, int V, i
 // (index order = torch.multinomial's category order). Finished rows (unfinished[r]==0) emit pad (TF5 generation/utils.py:2932-2933),
 // and a row that emits eos clears its unfinished flag.
 __global__ __launch_bounds__(256) void select_token_kernel(const float* __restrict__ logits, long ld, int V, int mode, float temperature, int top_k,
-                                                           const float* __restrict__ u, long* __restrict__ next, int* __restrict__ unfinished,
-                                                           long eos, long pad, float* __restrict__ margin) {
+                                                           const float* __restrict__ u, long* __restrict__ next, long next_stride,
+                                                           int* __restrict__ unfinished, long eos, long pad, float* __restrict__ margin) {
     __shared__ unsigned hist[256];
     __shared__ unsigned bc[2];
     __shared__ float shf[4];
@@ -401,26 +401,29 @@ __global__ __launch_bounds__(256) void select_token_kernel(const float* __restri
             if (!uf) tok = pad;
             else if (tok == eos) unfinished[r] = 0;
         }
-        next[r] = tok;
+        next[r * next_stride] = tok;
     }
 }
 
 __global__ void sample_topk_lds_kernel(const float* __restrict__ logits, long ld, int V, float temperature, int top_k, float top_p,
-                                       const float* __restrict__ u, long* __restrict__ next, int* __restrict__ unfinished, long eos, long pad);
+                                       const float* __restrict__ u, long* __restrict__ next, long next_stride, int* __restrict__ unfinished, long eos,
+                                       long pad, int n_sample);
 
 extern "C" int cxr_select_token(const float* logits, long ld, long R, int V, int mode, float temperature, int top_k, float top_p, const float* u,
-                                long* next, int* unfinished, long eos, long pad, float* margin, hipStream_t stream) {
-    if (R <= 0 || V <= 0 || (mode == 1 && (!u || temperature <= 0.f || !(top_p > 0.f)))) return CXR_ERR_ARG;
+                                long* next, long next_stride, int* unfinished, long eos, long pad, float* margin, int n_sample, hipStream_t stream) {
+    if (R <= 0 || V <= 0 || next_stride <= 0 || (mode == 1 && (!u || temperature <= 0.f || !(top_p > 0.f)))) return CXR_ERR_ARG;
+    if (n_sample < 0 || n_sample > R) n_sample = (int)R;                      // rows [0, n_sample) sample, rows [n_sample, R) take the argmax (mode 1)
+    if (mode == 1 && n_sample < R && !(!margin && (size_t)V * sizeof(float) <= 130 * 1024)) return CXR_ERR_ARG;
     if (mode == 1 && top_p < 1.0f && !(top_k > 0 && top_k <= 256 && !margin && (size_t)V * sizeof(float) <= 130 * 1024)) return CXR_ERR_ARG;
     if (mode == 1 && !margin && (size_t)V * sizeof(float) <= 130 * 1024) {           // sampling: row-resident-in-LDS kernel
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)sample_topk_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
         CXR_LAUNCH(sample_topk_lds_kernel, dim3((unsigned)R), dim3(1024), (size_t)V * sizeof(float), stream, logits, ld, V, temperature, top_k, top_p, u,
-                   next, unfinished, eos, pad);
+                   next, next_stride, unfinished, eos, pad, n_sample);
         CXR_LAUNCH_CHECK();
         return CXR_OK;
     }
-    CXR_LAUNCH(select_token_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, V, mode, temperature, top_k, u, next, unfinished,
+    CXR_LAUNCH(select_token_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, V, mode, temperature, top_k, u, next, next_stride, unfinished,
                        eos, pad, margin);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
@@ -431,8 +434,8 @@ extern "C" int cxr_select_token(const float* logits, long ld, long R, int V, int
 // passes (4 radix-select passes, max, sum, inverse-CDF search) must not go back to L2/HBM. One 1024-thread workgroup loads its row ONCE
 // into LDS (120 KB of the 160 KB) with 16-byte loads and runs every pass from there.
 __global__ __launch_bounds__(1024) void sample_topk_lds_kernel(const float* __restrict__ logits, long ld, int V, float temperature, int top_k,
-                                                               float top_p, const float* __restrict__ u, long* __restrict__ next,
-                                                               int* __restrict__ unfinished, long eos, long pad) {
+                                                               float top_p, const float* __restrict__ u, long* __restrict__ next, long next_stride,
+                                                               int* __restrict__ unfinished, long eos, long pad, int n_sample) {
     extern __shared__ __attribute__((aligned(16))) float row[];          // [V]
     __shared__ unsigned hist[256];
     __shared__ unsigned bc[2];
@@ -447,6 +450,31 @@ __global__ __launch_bounds__(1024) void sample_topk_lds_kernel(const float* __re
         else for (int j = i; j < V && j < i + 4; ++j) row[j] = x[j];
     }
     __syncthreads();
+    if (r >= n_sample) {
+        // argmax row in the same launch (the greedy half of an SCST decode batch): first maximal index, like torch.argmax
+        __shared__ float gbest[16];
+        __shared__ int gidx[16];
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int v = tid; v < V; v += 1024) { const float a = row[v]; if (a > best) { best = a; bi = v; } }     // ascending v: first maximum per thread
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { gbest[wave] = best; gidx[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 16; ++w) if (gbest[w] > best || (gbest[w] == best && gidx[w] < bi)) { best = gbest[w]; bi = gidx[w]; }
+            long tok = bi;
+            if (unfinished) {
+                const int uf = unfinished[r];
+                if (!uf) tok = pad;
+                else if (tok == eos) unfinished[r] = 0;
+            }
+            next[r * next_stride] = tok;
+        }
+        return;
+    }
     // ---- fast path (top_k <= 256): candidate filtering instead of four contended-histogram radix passes over the row.
     //   L = k-th largest of 256 group maxima (a lower bound of the k-th largest element: those are k distinct elements >= L), so every
     //   kept entry is among the few elements >= L; the exact threshold, the softmax and the inverse-CDF walk then run on that short list.
@@ -531,7 +559,7 @@ __global__ __launch_bounds__(1024) void sample_topk_lds_kernel(const float* __re
                         if (!uf) tok = pad;
                         else if (tok == eos) unfinished[r] = 0;
                     }
-                    next[r] = tok;
+                    next[r * next_stride] = tok;
                 }
             }
             return;
@@ -612,7 +640,7 @@ __global__ __launch_bounds__(1024) void sample_topk_lds_kernel(const float* __re
             if (!uf) tok = pad;
             else if (tok == eos) unfinished[r] = 0;
         }
-        next[r] = tok;
+        next[r * next_stride] = tok;
     }
 }
 

@@ -12,8 +12,11 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const long* __restr
                                                              const bf16_t* __restrict__ word, const bf16_t* __restrict__ type,
                                                              const bf16_t* __restrict__ posw, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, bf16_t* __restrict__ sum_out,
-                                                             bf16_t* __restrict__ out, float* __restrict__ stats, long R, int T, int pos_offset) {
+                                                             bf16_t* __restrict__ out, float* __restrict__ stats, long R, int T, int pos_offset,
+                                                             const uint32_t* __restrict__ drop_seed, uint32_t drop_site, uint32_t drop_thr16,
+                                                             float drop_inv) {
     constexpr int C = 768, CH = 96;
+    const uint32_t dseed = drop_thr16 ? *drop_seed : 0u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (long row = (long)blockIdx.x * 4 + wave; row < R; row += (long)gridDim.x * 4) {
         const long id = ids[row];
@@ -53,6 +56,15 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const long* __restr
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j];
+                if (drop_thr16) {                                  // embeddings dropout (TF5:bert:106), row = (sequence row / T, pos_offset + row % T)
+                    const uint32_t key = dropout_row_key(dseed, drop_site, (uint32_t)(row / T), (uint32_t)(pos_offset + (int)(row % T)));
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const uint32_t bits = dropout_pair_bits(key, (uint32_t)(ch * 8 + j) >> 1);
+                        o[j] = (bits & 0xffffu) >= drop_thr16 ? o[j] * drop_inv : 0.f;
+                        o[j + 1] = (bits >> 16) >= drop_thr16 ? o[j + 1] * drop_inv : 0.f;
+                    }
+                }
                 *reinterpret_cast<uint4*>(out + row * C + ch * 8) = pack8(o);
             }
         }
@@ -62,11 +74,12 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const long* __restr
 
 extern "C" int cxr_bert_embed_fwd(const long* ids, const long* tt, const long* pid, const void* word, const void* type, const void* posw,
                                   const float* gamma, const float* beta, float eps, void* sum_out, void* out, float* stats, long R, int T,
-                                  int pos_offset, int C, hipStream_t stream) {
-    if (R <= 0 || C != 768) return CXR_ERR_ARG;
+                                  int pos_offset, int C, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, hipStream_t stream) {
+    if (R <= 0 || C != 768 || T <= 0 || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return CXR_ERR_ARG;
     const int grid = (int)(cdiv(R, 4) < 4096 ? cdiv(R, 4) : 4096);
     CXR_LAUNCH(bert_embed_fwd_kernel, dim3(grid), dim3(256), 0, stream, ids, tt, pid, (const bf16_t*)word, (const bf16_t*)type,
-                       (const bf16_t*)posw, gamma, beta, eps, (bf16_t*)sum_out, (bf16_t*)out, stats, R, T, pos_offset);
+                       (const bf16_t*)posw, gamma, beta, eps, (bf16_t*)sum_out, (bf16_t*)out, stats, R, T, pos_offset, drop_seed, drop_site,
+                       drop_p > 0.f ? dropout_thr16(drop_p) : 0u, 1.0f / (1.0f - drop_p));
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

@@ -170,9 +170,8 @@ class BertEngine:
         e = p + "bert.embeddings."
         h, esum, estats = ops.bert_embed(ids, token_type_ids, position_ids, st.w16(e + "word_embeddings.weight"),
                                          st.w16(e + "token_type_embeddings.weight"), st.w16(e + "position_embeddings.weight"),
-                                         st.f32(e + "LayerNorm.weight"), st.f32(e + "LayerNorm.bias"), cfg.layer_norm_eps, T, need_sum=save)
-        if ph:
-            ops.dropout_add(h, None, ph, seed, SITE_EMBED, T, out=h)
+                                         st.f32(e + "LayerNorm.weight"), st.f32(e + "LayerNorm.bias"), cfg.layer_norm_eps, T, need_sum=save,
+                                         drop=(ph, seed, SITE_EMBED) if ph else None)
         saved = dict(B=B, T=T, ids=ids, tt=token_type_ids, pos=position_ids, esum=esum, estats=estats, attn_mask=attn_mask, enc=enc,
                      enc_mask=enc_mask, causal=causal, layers=[], ph=ph, pa=pa, seed=seed, lora_tr=lora_tr) if save else None
         scale = cfg.head_dim ** -0.5
@@ -408,9 +407,8 @@ class BertEngine:
         e = p + "bert.embeddings."
         h, _, _ = ops.bert_embed(ids_new, token_type_ids, position_ids, st.w16(e + "word_embeddings.weight"),
                                  st.w16(e + "token_type_embeddings.weight"), st.w16(e + "position_embeddings.weight"),
-                                 st.f32(e + "LayerNorm.weight"), st.f32(e + "LayerNorm.bias"), cfg.layer_norm_eps, Tn, pos_offset=past)
-        if ph:
-            ops.dropout_add(h, None, ph, seed, SITE_EMBED, Tn, t0=past, out=h)
+                                 st.f32(e + "LayerNorm.weight"), st.f32(e + "LayerNorm.bias"), cfg.layer_norm_eps, Tn, pos_offset=past,
+                                 drop=(ph, seed, SITE_EMBED) if ph else None)
         scale = cfg.head_dim ** -0.5
         single = Tn == 1 and B <= 64          # one new token per row: weight-streaming GEMMs + single-query attention kernels
         lora_tr = self._lora_train(train)

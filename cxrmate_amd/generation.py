@@ -111,13 +111,13 @@ class DecodeSession:
         unf = self.unfinished if eos is not None else None
         eos_ = eos if eos is not None else -1
         n_smp = {"greedy": 0, "sample": self.B, "pair": self.B // 2}[kind]      # rows [0, n_smp) sample, the rest take the argmax
-        if n_smp:
+        col = self.ids[:, cur]                                                  # the selection kernels write straight into the id buffer
+        if n_smp:                                                               # one launch for sampled + greedy rows
             u = torch.rand(n_smp, device=logits.device, dtype=torch.float32)
-            ops.select_token(logits[:n_smp], mode=1, temperature=temperature, top_k=top_k or 0, u=u, unfinished=None if unf is None else unf[:n_smp],
-                             eos=eos_, pad=pad or 0, out=self.nxt[:n_smp], top_p=top_p)
-        if n_smp < self.B:
-            ops.select_token(logits[n_smp:], unfinished=None if unf is None else unf[n_smp:], eos=eos_, pad=pad or 0, out=self.nxt[n_smp:])
-        self.ids[:, cur] = self.nxt
+            ops.select_token(logits, mode=1, temperature=temperature, top_k=top_k or 0, u=u, unfinished=unf, eos=eos_, pad=pad or 0, out=col,
+                             top_p=top_p, n_sample=n_smp)
+        else:
+            ops.select_token(logits, unfinished=unf, eos=eos_, pad=pad or 0, out=col)
         if prefill:
             self.last_tt, self.last_pos = tt, pos
         else:                                                      # views of the history columns this step wrote (stable across graph replays)

@@ -445,14 +445,14 @@ def tap_grad_accum(G, dw):
 
 
 # ------------------------------------------------------------------------------------------------ embeddings / integer ops
-def bert_embed(ids, tt, pid, word, typ, posw, gamma, beta, eps, T, pos_offset=0, need_sum=False):
+def bert_embed(ids, tt, pid, word, typ, posw, gamma, beta, eps, T, pos_offset=0, need_sum=False, drop=None):
     R = ids.numel()
     C = word.shape[1]
     out = torch.empty((R, C), device=ids.device, dtype=BF16)
     ssum = torch.empty((R, C), device=ids.device, dtype=BF16) if need_sum else None
     stats = torch.empty((R, 2), device=ids.device, dtype=torch.float32) if need_sum else None
     LIB.call("cxr_bert_embed_fwd", _p(ids), _p(tt), _p(pid), _p(word), _p(typ), _p(posw), _p(gamma), _p(beta), float(eps), _p(ssum), _p(out),
-             _p(stats), R, T, pos_offset, C, _s())
+             _p(stats), R, T, pos_offset, C, *((float(drop[0]), _p(drop[1]), int(drop[2])) if drop is not None and drop[0] > 0 else (0.0, None, 0)), _s())
     return out, ssum, stats
 
 
@@ -545,13 +545,17 @@ def topk_threshold(logits, k, top_p=1.0, temperature=1.0):
     return thr
 
 
-def select_token(logits, mode=0, temperature=1.0, top_k=0, u=None, unfinished=None, eos=-1, pad=0, need_margin=False, out=None, top_p=1.0):
+def select_token(logits, mode=0, temperature=1.0, top_k=0, u=None, unfinished=None, eos=-1, pad=0, need_margin=False, out=None, top_p=1.0,
+                 n_sample=-1):
+    """out: int64 [R] (element stride free: a column view of the running id buffer works). mode 1, n_sample < R: rows [0, n_sample) are sampled,
+    rows [n_sample, R) take the argmax in the same launch."""
     R, V = logits.shape
     assert logits.dtype == torch.float32 and logits.stride(1) == 1
     nxt = out if out is not None else torch.empty((R,), dtype=torch.int64, device=logits.device)
+    assert nxt.dim() == 1 and nxt.shape[0] == R
     margin = torch.empty((R,), dtype=torch.float32, device=logits.device) if need_margin else None
-    LIB.call("cxr_select_token", _p(logits), logits.stride(0), R, V, mode, float(temperature), int(top_k), float(top_p), _p(u), _p(nxt), _p(unfinished),
-             int(eos), int(pad), _p(margin), _s())
+    LIB.call("cxr_select_token", _p(logits), logits.stride(0), R, V, mode, float(temperature), int(top_k), float(top_p), _p(u), _p(nxt),
+             nxt.stride(0) if R > 1 else 1, _p(unfinished), int(eos), int(pad), _p(margin), int(n_sample), _s())
     return nxt, margin
 
 

@@ -147,7 +147,8 @@ int cxr_tap_grad_accum(const float* G, float* dw, int C, hipStream_t stream);
 /* ---- BERT embeddings (TF5:bert:70-108) ------------------------------------------------------------------------------------ */
 int cxr_bert_embed_fwd(const long* ids, const long* tt, const long* pid, const void* word, const void* type, const void* posw,
                        const float* gamma, const float* beta, float eps, void* sum_out, void* out, float* stats, long R, int T, int pos_offset,
-                       int C, hipStream_t stream);
+                       int C, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, hipStream_t stream);
+                       /* drop_p > 0: embeddings dropout (TF5:bert:106) on the LayerNorm output, keyed (row / T, pos_offset + row % T, column) */
 int cxr_bert_embed_bwd(const void* dsum, const long* ids, const long* tt, const long* pid, float* dword, float* dtype, float* dpos, long R,
                        int T, int pos_offset, long padding_idx, int C, hipStream_t stream);
 
@@ -168,7 +169,9 @@ int cxr_ce_reduce(const float* row_loss, const float* row_w, long R, float* loss
 int cxr_topk_threshold(const float* logits, long ld, long R, int V, int k, float top_p, float temperature, float* thr, hipStream_t stream);
                        /* thr[r] = value below which TopKLogitsWarper(k) then TopPLogitsWarper(top_p) at `temperature` remove entries (top_p = 1: top-k only) */
 int cxr_select_token(const float* logits, long ld, long R, int V, int mode, float temperature, int top_k, float top_p, const float* u, long* next,
-                     int* unfinished, long eos, long pad, float* margin, hipStream_t stream);
+                     long next_stride, int* unfinished, long eos, long pad, float* margin, int n_sample, hipStream_t stream);
+                     /* next[r * next_stride] (e.g. a column of the running id buffer); mode 1 with n_sample < R: rows [0, n_sample) are sampled,
+                        the rest take the argmax in the same launch (negative n_sample = all rows) */
 int cxr_log_softmax_rows(float* x, long ld, long R, int V, const float* add_row, hipStream_t stream);
 
 /* ---- autoregressive decode helpers (TF5:gen:3388-3485 beam continuation search + cache reorder) ------------------------- */

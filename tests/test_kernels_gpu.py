@@ -694,6 +694,13 @@ def test_select_token(ops):
     lo, _ = ops.select_token(row[:1], mode=1, temperature=1.0, top_k=k, u=torch.tensor([0.0]).cuda())
     hi, _ = ops.select_token(row[:1], mode=1, temperature=1.0, top_k=k, u=torch.tensor([0.999999]).cuda())
     assert lo.item() == topi.min().item() and hi.item() == topi.max().item()
+    # sampled and greedy rows in ONE launch, written into a strided column of a wider id buffer (the cached decode of an SCST step)
+    buf = torch.full((R, 7), -1, dtype=torch.int64, device="cuda")
+    uu = torch.rand(R // 2, generator=torch.Generator().manual_seed(8)).cuda()
+    ops.select_token(logits, mode=1, temperature=1.0, top_k=k, u=uu, out=buf[:, 3], n_sample=R // 2)
+    assert torch.equal(buf[R // 2:, 3], logits[R // 2:].argmax(-1)) and bool((buf[:, 2] == -1).all()) and bool((buf[:, 4] == -1).all())
+    alone, _ = ops.select_token(logits[: R // 2], mode=1, temperature=1.0, top_k=k, u=uu)
+    assert torch.equal(buf[: R // 2, 3], alone)
     # ties at the k-th value are all kept (TopKLogitsWarper removes only scores < the k-th): a constant row keeps the whole vocabulary
     # (this also exercises the general radix path: more than 1024 elements reach the candidate filter's lower bound)
     flat = torch.zeros(1, V, device="cuda")
