@@ -23,6 +23,9 @@ def init_from_env(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = backend or os.environ.get("CXR_DIST_BACKEND") or None       # test hook: gloo lets several ranks share ONE GPU
+    if os.environ.get("CXR_SINGLE_DEVICE"):                               # test hook: every rank on device 0 (multi-rank flow on a 1-GPU box)
+        local = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
