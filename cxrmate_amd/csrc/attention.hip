@@ -22,7 +22,6 @@ struct AttnArgs {
     int causal, causal_shift;          // key j visible to query i iff j <= i + causal_shift
     // dropout on the attention probabilities (TF5 modeling_bert.py:131, train mode): P*keep/(1-p) feeds P.V, the softmax sums do not change
     const uint32_t* drop_seed; uint32_t drop_site, drop_thr16; float drop_inv; int drop_t0;      // drop_thr16 == 0: off
-    int rowstore;
 };
 
 constexpr int KS_STRIDE = 72;          // bf16 elements per K row in LDS (144 B)
@@ -206,29 +205,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     {
         const int row0 = qb0 + wave * 32;                          // first query row of this wave
         const int valid = a.Tq - row0 < 32 ? a.Tq - row0 : 32;
-        if (a.rowstore && (a.o_rs % 8) == 0 && (a.o_bs % 8) == 0 && ((size_t)a.O % 16) == 0) {
+        // output rows through the wave's LDS tile: 16 bytes per lane, one full 128-byte head row per 8 lanes (common.h)
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    uint2 pk;
-                    pk.x = pack2bf(o[dt][4 * rg + 0] * inv, o[dt][4 * rg + 1] * inv);
-                    pk.y = pack2bf(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
-                    TILE_PUT(Os[wave], lane, dt, rg, pk);
-                }
-            tile_rows_store(Os[wave], lane, a.O + (long)b * a.o_bs + (long)row0 * a.o_rs + head * 64, a.o_rs, valid);
-        } else if (qrow < a.Tq) {
-            bf16_t* op = a.O + (long)b * a.o_bs + (long)qrow * a.o_rs + head * 64;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    uint2 pk;
-                    pk.x = pack2bf(o[dt][4 * rg + 0] * inv, o[dt][4 * rg + 1] * inv);
-                    pk.y = pack2bf(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
-                    *reinterpret_cast<uint2*>(op + dt * 32 + 8 * rg + 4 * hh) = pk;
-                }
-        }
+            for (int rg = 0; rg < 4; ++rg) {
+                uint2 pk;
+                pk.x = pack2bf(o[dt][4 * rg + 0] * inv, o[dt][4 * rg + 1] * inv);
+                pk.y = pack2bf(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
+                TILE_PUT(Os[wave], lane, dt, rg, pk);
+            }
+        tile_rows_store(Os[wave], lane, a.O + (long)b * a.o_bs + (long)row0 * a.o_rs + head * 64, a.o_rs, valid);
     }
     if (qrow < a.Tq) {
         if (a.LSE && hh == 0)
@@ -241,7 +228,7 @@ extern "C" int cxr_attn_fwd_bf16(const void* Q, const void* K, const void* V, vo
                                  long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal, int causal_shift,
                                  float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t0, hipStream_t stream) {
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return CXR_ERR_ARG;
-    if ((q_rs % 8) || (k_rs % 8) || (v_rs % 8) || (o_rs % 4) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 4)) return CXR_ERR_ARG;
+    if ((q_rs % 8) || (k_rs % 8) || (v_rs % 8) || (o_rs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 8) || (((size_t)O) % 16)) return CXR_ERR_ARG;
     AttnArgs a;
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.O = (bf16_t*)O; a.LSE = LSE;
     a.kpm = (const unsigned char*)kpm;
@@ -250,9 +237,6 @@ extern "C" int cxr_attn_fwd_bf16(const void* Q, const void* K, const void* V, vo
     a.scale_log2e = scale * 1.4426950408889634f; a.causal = causal; a.causal_shift = causal_shift;
     a.drop_seed = drop_seed; a.drop_site = drop_site; a.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u;
     a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_t0 = drop_t0;
-    static int rowstore = -1;
-    if (rowstore < 0) { const char* e = getenv("CXR_ATTN_ROWSTORE"); rowstore = e ? atoi(e) : 1; }
-    a.rowstore = rowstore;
     dim3 grid(cdiv(Tq, 128), H, B);
     CXR_LAUNCH(attn_fwd_kernel, grid, dim3(256), 0, stream, a);
     CXR_LAUNCH_CHECK();

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     if (idx < total && (idx & 7) == 0) delta[bhq] = s;   // delta laid out [B,H,Tq]: bhq = (b*H + h)*Tq + q
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t Qr[64 * RS];
     __shared__ __attribute__((aligned(16))) bf16_t Qt[64 * TS];
     __shared__ __attribute__((aligned(16))) bf16_t Dr[64 * RS];
