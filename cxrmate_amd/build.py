@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcxrmate_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "attention_bwd.hip", "norm.hip", "conv.hip", "misc.hip", "loss.hip", "decode.hip", "dropout.hip", "lora.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "attention_bwd.hip", "norm.hip", "conv.hip", "misc.hip", "loss.hip", "decode.hip", "dropout.hip", "lora.hip", "dwproj.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 
 
@@ -28,6 +28,8 @@ def _digest() -> str:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode())
             h.update(f.read())
+    with open(os.path.join(os.path.dirname(HERE), "include", "cxrmate_hip.h"), "rb") as f:      # dwproj.hip includes the ABI header
+        h.update(f.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 

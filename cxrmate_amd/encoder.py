@@ -11,6 +11,8 @@ keep/scale of both residual branches in train mode; CvT's other dropouts have ra
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -25,6 +27,7 @@ class CvtEncoderEngine:
         self._wt_ready = False
         self._bn_version = 0                        # bumped whenever a train-mode forward moves the running statistics
         self._fold_cache = {}
+        self._fused_proj = os.environ.get("CXR_DWPROJ", "1") != "0"      # A/B switch: 0 = per-projection kernels of conv.hip
         self._embed_buf = {}                        # persistent conv-as-GEMM weight re-layouts (their addresses feed the batched transpose table)
         self._bt, self._bt_sig, self._bt_keys = None, None, None
 
@@ -81,6 +84,22 @@ class CvtEncoderEngine:
         if hit is None:
             w = self.s.f32(self._conv_prefix(s, l, name) + "convolution.weight")
             hit = self._fold_cache[key] = w.view(w.shape[0], 9).t().contiguous()
+        return hit
+
+    def _dwproj_params(self, s, l):
+        """Static half of the cxr_dwproj descriptors of layer (s, l): raw taps in conv layout + the BatchNorm parameters (views of the flat store)."""
+        key = ("dwp", s, l)
+        hit = self._fold_cache.get(key)
+        if hit is None:
+            cfg, st = self.cfg, self.s
+            hit = []
+            for n, sd in (("query", cfg.stride_q[s]), ("key", cfg.stride_kv[s]), ("value", cfg.stride_kv[s])):
+                cp = self._conv_prefix(s, l, n)
+                w = st.f32(cp + "convolution.weight")
+                hit.append(dict(stride=sd, taps=self._raw_taps(s, l, n), w=w.view(w.shape[0], 9), gamma=st.f32(cp + "normalization.weight"),
+                                beta=st.f32(cp + "normalization.bias"), run_mean=st.f32(cp + "normalization.running_mean"),
+                                run_var=st.f32(cp + "normalization.running_var")))
+            self._fold_cache[key] = hit
         return hit
 
     def _fold_train(self, h1, H, W, stride, tok0, s, l, names):
@@ -214,14 +233,25 @@ class CvtEncoderEngine:
         h1, st1 = ops.layernorm(x2d, st.f32(lp + "layernorm_before.weight"), st.f32(lp + "layernorm_before.bias"), cfg.inner_layer_norm_eps, need_stats=save)
         h1 = h1.view(Bn, L, C)
         bn = None
-        if self._train:
-            (fq,), bn = self._fold_train(h1, H, W, cfg.stride_q[s], tok0, s, l, ("query",))
-            (fk, fv), bkv = self._fold_train(h1, H, W, cfg.stride_kv[s], tok0, s, l, ("key", "value"))
-            bn.update(bkv)
+        names = ("query", "key", "value")
+        strides = (cfg.stride_q[s], cfg.stride_kv[s], cfg.stride_kv[s])
+        if self._fused_proj and C % 64 == 0:
+            # all three convolutional projections from ONE LDS-staged pass over h1 (csrc/dwproj.hip)
+            if self._train:
+                folds = ops.dwproj_bn_train_stats(h1, H, W, tok0, cfg.bn_eps, cfg.bn_momentum, self._dwproj_params(s, l))
+                bn = {n: (f["mean"], f["rstd"], f["count"]) for n, f in zip(names, folds)}
+            else:
+                folds = [dict(stride=sd, taps=f[0], shift=f[1]) for sd, f in zip(strides, (self._fold_eval(s, l, n) for n in names))]
+            qc, kc, vc = ops.dwproj_apply(h1, H, W, tok0, folds)
         else:
-            fq, fk, fv = (self._fold_eval(s, l, n) for n in ("query", "key", "value"))
-        qc, _ = ops.dwconv_bn(h1, H, W, cfg.stride_q[s], tok0, fq)
-        kc, vc = ops.dwconv_bn(h1, H, W, cfg.stride_kv[s], tok0, fk, fv)
+            if self._train:
+                (fq,), bn = self._fold_train(h1, H, W, cfg.stride_q[s], tok0, s, l, ("query",))
+                (fk, fv), bkv = self._fold_train(h1, H, W, cfg.stride_kv[s], tok0, s, l, ("key", "value"))
+                bn.update(bkv)
+            else:
+                fq, fk, fv = (self._fold_eval(s, l, n) for n in names)
+            qc, _ = ops.dwconv_bn(h1, H, W, cfg.stride_q[s], tok0, fq)
+            kc, vc = ops.dwconv_bn(h1, H, W, cfg.stride_kv[s], tok0, fk, fv)
         Lk = kc.shape[1]
         q = ops.gemm_nt(qc.view(-1, C), st.w16(ap + "projection_query.weight"), bias=st.f32(ap + "projection_query.bias")).view(Bn, L, C)
         k = ops.gemm_nt(kc.view(-1, C), st.w16(ap + "projection_key.weight"), bias=st.f32(ap + "projection_key.bias")).view(Bn, Lk, C)
@@ -321,7 +351,24 @@ class CvtEncoderEngine:
         strides = {"query": cfg.stride_q[s], "key": cfg.stride_kv[s], "value": cfg.stride_kv[s]}
         projs = []
         h1 = sv["h1"]
-        if sv["bn"] is not None:
+        fused = self._fused_proj and C % 64 == 0
+        if sv["bn"] is not None and fused:
+            # batch-statistics BatchNorm, all three projections per pass: (sum dy, sum dy*c) -> coefficients, dgamma, dbeta -> dc in place + raw-tap
+            # gradient (tap sums ride along with the dc pass) -> dx
+            names = ("query", "key", "value")
+            base = self._dwproj_params(s, l)
+            bp = []
+            for n, b in zip(names, base):
+                cp = self._conv_prefix(s, l, n)
+                mean, rstd, _ = sv["bn"][n]
+                bp.append(dict(stride=b["stride"], taps=b["taps"], y=dcs[n], gamma=b["gamma"], mean=mean, rstd=rstd,
+                               dgamma=g(cp + "normalization.weight"), dbeta=g(cp + "normalization.bias"), dw=g(cp + "convolution.weight").view(C, 9)))
+            coefs = ops.dwproj_bn_train_bwd_stats(h1, H, W, tok0, bp)
+            for b, cf in zip(bp, coefs):
+                b["coef"] = cf
+            ops.dwproj_dc_taps_(h1, H, W, tok0, bp)
+            dh1 = ops.dwproj_dx(bp, Bn, C, H, W, tok0)
+        elif sv["bn"] is not None:
             # batch-statistics BatchNorm: (sum dy, sum dy*c) per channel -> dc rewritten in place as the gradient of the RAW conv output ->
             # the ordinary dx / tap-sum kernels with the raw taps
             arena = torch.empty((30, C), dtype=torch.float32, device=dy.device)     # 3 x tap-sum outputs
@@ -341,6 +388,7 @@ class CvtEncoderEngine:
                 with ops._on_wgrad_stream(h1, dcs[name], arena):
                     G2, _ = ops.dwconv_bn_bwd_w(h1, dcs[name], H, W, strides[name], tok0, out=arena[10 * i:10 * i + 10])
                     ops.tap_grad_accum(G2, g(cp + "convolution.weight"))
+            dh1 = ops.dwconv_bn_bwd_dx(projs, Bn, C, H, W, tok0)
         else:
             arena = torch.empty((30, C), dtype=torch.float32, device=dy.device)
             for i, name in enumerate(("query", "key", "value")):
@@ -352,7 +400,10 @@ class CvtEncoderEngine:
                     ops.bn_fold_bwd(st.f32(cp + "convolution.weight"), st.f32(cp + "normalization.weight"), st.f32(cp + "normalization.running_mean"),
                                     st.f32(cp + "normalization.running_var"), cfg.bn_eps, G, S, g(cp + "convolution.weight"),
                                     g(cp + "normalization.weight"), g(cp + "normalization.bias"))
-        dh1 = ops.dwconv_bn_bwd_dx(projs, Bn, C, H, W, tok0)
+            if fused:
+                dh1 = ops.dwproj_dx([dict(stride=sd, taps=wf, y=d) for d, wf, sd in projs], Bn, C, H, W, tok0)
+            else:
+                dh1 = ops.dwconv_bn_bwd_dx(projs, Bn, C, H, W, tok0)
         dx = ops.layernorm_bwd(sv["x"].view(-1, C), dh1.view(-1, C), st.f32(lp + "layernorm_before.weight"), sv["st1"],
                                g(lp + "layernorm_before.weight"), g(lp + "layernorm_before.bias"), add=dx2)
         return dx.view(Bn, L, C)

@@ -444,6 +444,118 @@ def tap_grad_accum(G, dw):
     LIB.call("cxr_tap_grad_accum", _p(G), _p(dw), G.shape[1], _s())
 
 
+# ---- fused query / key / value convolutional projections (csrc/dwproj.hip): one LDS-staged pass per layer and step of the BatchNorm algebra
+import ctypes as _ct
+
+
+class DwProj(_ct.Structure):
+    """Mirror of `cxr_dwproj` (include/cxrmate_hip.h): one depthwise projection of the shared activation; device pointers as integers."""
+    _fields_ = [("stride", _ct.c_int), ("taps", _ct.c_void_p), ("shift", _ct.c_void_p), ("y", _ct.c_void_p), ("y_bs", _ct.c_long), ("y_rs", _ct.c_long),
+                ("w", _ct.c_void_p), ("gamma", _ct.c_void_p), ("beta", _ct.c_void_p), ("run_mean", _ct.c_void_p), ("run_var", _ct.c_void_p),
+                ("mean", _ct.c_void_p), ("rstd", _ct.c_void_p), ("taps_out", _ct.c_void_p), ("shift_out", _ct.c_void_p),
+                ("dgamma", _ct.c_void_p), ("dbeta", _ct.c_void_p), ("coef", _ct.c_void_p), ("GS", _ct.c_void_p), ("dw", _ct.c_void_p)]
+
+
+_DWP_PTRS = ("taps", "shift", "w", "gamma", "beta", "run_mean", "run_var", "mean", "rstd", "taps_out", "shift_out", "dgamma", "dbeta", "coef", "GS", "dw")
+_DWP_WS = {}
+
+
+def _dwproj_ws(Bn, C, H, W, device):
+    key = (_s(), Bn, C, H, W, device)
+    ws = _DWP_WS.get(key)
+    if ws is None:
+        n = LIB.load().cxr_dwproj_ws_floats(Bn, C, H, W)
+        if n <= 0:
+            raise CxrError(f"cxr_dwproj_ws_floats({Bn}, {C}, {H}, {W}) -> {n}")
+        ws = _DWP_WS[key] = torch.empty(n, device=device, dtype=torch.float32)
+    return ws
+
+
+def _dwproj_array(projs):
+    """projs: list of dicts {stride, <tensor fields of cxr_dwproj>, y: bf16 [Bn, L, C]} -> (ctypes array, keep-alive list)"""
+    arr = (DwProj * len(projs))()
+    for d, p in zip(arr, projs):
+        d.stride = int(p["stride"])
+        for k in _DWP_PTRS:
+            t = p.get(k)
+            if t is not None:
+                assert t.dtype == torch.float32 and t.is_contiguous(), k
+                setattr(d, k, _p(t))
+        y = p.get("y")
+        if y is not None:
+            assert y.dtype == BF16 and y.stride(2) == 1
+            d.y, d.y_bs, d.y_rs = _p(y), y.stride(0), y.stride(1)
+    return arr
+
+
+def _dwproj_geo(x, H, W, tok0):
+    Bn, L, C = x.shape
+    assert L == tok0 + H * W and x.dtype == BF16 and x.stride(2) == 1, (x.shape, H, W, tok0)
+    return Bn, C
+
+
+def dwproj_apply(x, H, W, tok0, projs):
+    """projs: [{stride, taps (folded [9,C]), shift [C]}] -> list of y [Bn, tok0+Ho*Wo, C]; class rows copied through."""
+    Bn, C = _dwproj_geo(x, H, W, tok0)
+    ys = []
+    for p in projs:
+        Ho, Wo = (H - 1) // p["stride"] + 1, (W - 1) // p["stride"] + 1
+        ys.append(torch.empty((Bn, tok0 + Ho * Wo, C), device=x.device, dtype=BF16))
+    arr = _dwproj_array([dict(p, y=y) for p, y in zip(projs, ys)])
+    LIB.call("cxr_dwproj_apply_bf16", _p(x), x.stride(0), x.stride(1), Bn, C, H, W, int(tok0), _ct.addressof(arr), len(projs), _s())
+    return ys
+
+
+def dwproj_bn_train_stats(x, H, W, tok0, eps, momentum, projs):
+    """Train-mode BatchNorm statistics of all projections in one pass. projs: [{stride, taps (raw [9,C]), w [C,9], gamma, beta, run_mean, run_var}]
+    (running statistics moved in place) -> per projection dict(taps=folded, shift=, mean=, rstd=, count=, stride=)."""
+    Bn, C = _dwproj_geo(x, H, W, tok0)
+    outs = torch.empty((len(projs), 12, C), device=x.device, dtype=torch.float32)         # folded taps [9,C], shift, mean, rstd
+    full = []
+    for i, p in enumerate(projs):
+        full.append(dict(p, taps_out=outs[i, :9], shift_out=outs[i, 9], mean=outs[i, 10], rstd=outs[i, 11]))
+    arr = _dwproj_array(full)
+    LIB.call("cxr_dwproj_bn_train_stats_bf16", _p(x), x.stride(0), x.stride(1), Bn, C, H, W, int(tok0), float(eps), float(momentum), _ct.addressof(arr),
+             len(projs), _p(_dwproj_ws(Bn, C, H, W, x.device)), _s())
+    res = []
+    for i, p in enumerate(projs):
+        Ho, Wo = (H - 1) // p["stride"] + 1, (W - 1) // p["stride"] + 1
+        res.append(dict(stride=p["stride"], taps=outs[i, :9], shift=outs[i, 9], mean=outs[i, 10], rstd=outs[i, 11], count=Bn * Ho * Wo))
+    return res
+
+
+def dwproj_bn_train_bwd_stats(x, H, W, tok0, projs):
+    """projs: [{stride, taps (raw), y = dL/d(BN out), gamma, mean, rstd, dgamma, dbeta (accumulated)}] -> coef list ([3,C] each: a, kb, kc)."""
+    Bn, C = _dwproj_geo(x, H, W, tok0)
+    coefs = torch.empty((len(projs), 3, C), device=x.device, dtype=torch.float32)
+    arr = _dwproj_array([dict(p, coef=coefs[i]) for i, p in enumerate(projs)])
+    LIB.call("cxr_dwproj_bn_train_bwd_stats_bf16", _p(x), x.stride(0), x.stride(1), Bn, C, H, W, int(tok0), _ct.addressof(arr), len(projs),
+             _p(_dwproj_ws(Bn, C, H, W, x.device)), _s())
+    return [coefs[i] for i in range(len(projs))]
+
+
+def dwproj_dc_taps_(x, H, W, tok0, projs, need_GS=False):
+    """projs: [{stride, taps (raw), y (rewritten in place as dc when coef is given), coef or None, dw [C,9] (+= tap sums) or None}]
+    -> GS [nproj, 10, C] (9 tap sums, then sum dc) when need_GS (or when a projection has no dw)."""
+    Bn, C = _dwproj_geo(x, H, W, tok0)
+    GS = None
+    if need_GS or any(p.get("dw") is None for p in projs):
+        GS = torch.empty((len(projs), 10, C), device=x.device, dtype=torch.float32)
+    arr = _dwproj_array([dict(p, GS=None if GS is None else GS[i]) for i, p in enumerate(projs)])
+    LIB.call("cxr_dwproj_dc_taps_bf16", _p(x), x.stride(0), x.stride(1), Bn, C, H, W, int(tok0), _ct.addressof(arr), len(projs),
+             _p(_dwproj_ws(Bn, C, H, W, x.device)), _s())
+    return GS
+
+
+def dwproj_dx(projs, Bn, C, H, W, tok0):
+    """projs: [{stride, taps, y = dc}] -> dx [Bn, tok0+H*W, C]"""
+    dx = torch.empty((Bn, tok0 + H * W, C), device=projs[0]["y"].device, dtype=BF16)
+    arr = _dwproj_array(projs)
+    LIB.call("cxr_dwproj_dx_bf16", _p(dx), dx.stride(0), dx.stride(1), Bn, C, H, W, int(tok0), _ct.addressof(arr), len(projs), _s())
+    return dx
+
+
+
 # ------------------------------------------------------------------------------------------------ embeddings / integer ops
 def bert_embed(ids, tt, pid, word, typ, posw, gamma, beta, eps, T, pos_offset=0, need_sum=False, drop=None):
     R = ids.numel()

@@ -144,6 +144,40 @@ int cxr_dwconv_bn_train_dc_bf16(const void* x, long x_bs, long x_rs, const float
                                 int Bn, int C, int H, int W, int stride, int tok0, hipStream_t stream);
 int cxr_tap_grad_accum(const float* G, float* dw, int C, hipStream_t stream);
 
+/* ---- fused query / key / value convolutional projections (TF5:cvt:93-130: depthwise 3x3, pad 1, stride 1 | 2, + BatchNorm2d) ----------------
+ * The three projections of a CvT layer read the same layer-normed activation x [Bn, tok0 + H*W, C] (C % 64 == 0). These entry points stage
+ * each (image, row band, 64-channel slice) of x once in LDS and serve all taps of all `nproj` <= 3 projections from there; they supersede the
+ * per-projection cxr_dwconv_* calls above on the training path (same arithmetic, 4-10x less L1 traffic, 8 launches per layer instead of 23).
+ * `projs` is a HOST array of descriptors; all pointers inside are device pointers. Fields read per call:
+ *   apply            : stride, taps (BatchNorm-folded [9][C]), shift [C], y/y_bs/y_rs (output [Bn, tok0 + Ho*Wo, C]; class rows copied through)
+ *   bn_train_stats   : stride, taps (raw [9][C]), w [C,9], gamma, beta, run_mean / run_var (moved in place by `momentum`), outputs mean, rstd [C],
+ *                      taps_out [9][C], shift_out [C] (the fold apply takes)          -- nn.BatchNorm2d under model.train()
+ *   bn_train_bwd_stats: stride, taps (raw), y = dL/d(BN output), gamma, mean, rstd; dgamma / dbeta are ACCUMULATED, coef [3][C] written
+ *   dc_taps          : stride, taps (raw), y (rewritten in place as dc = a*dy + kb + kc*c when coef != NULL; untouched when coef == NULL =
+ *                      eval-mode fold), GS [10][C] (9 tap sums sum dc*x_t, then sum dc; may be NULL) and/or dw [C,9] (+= tap sums)
+ *   dx               : stride, taps (raw in train mode, folded in eval mode), y = dc -> dx [Bn, tok0 + H*W, C] (class row = sum of class rows)
+ * ws = fp32 scratch of cxr_dwproj_ws_floats(Bn, C, H, W) elements (partial rows of the per-channel reductions; no atomics, deterministic). */
+typedef struct cxr_dwproj {
+    int stride;
+    const float* taps; const float* shift;
+    void* y; long y_bs, y_rs;
+    const float* w; const float* gamma; const float* beta; float* run_mean; float* run_var;
+    float* mean; float* rstd; float* taps_out; float* shift_out;
+    float* dgamma; float* dbeta; float* coef;
+    float* GS; float* dw;
+} cxr_dwproj;
+int cxr_dwproj_ws_floats(int Bn, int C, int H, int W);      /* returns the element count (> 0) or a negative error */
+int cxr_dwproj_apply_bf16(const void* x, long x_bs, long x_rs, int Bn, int C, int H, int W, int tok0, const cxr_dwproj* projs, int nproj,
+                          hipStream_t stream);
+int cxr_dwproj_bn_train_stats_bf16(const void* x, long x_bs, long x_rs, int Bn, int C, int H, int W, int tok0, float eps, float momentum,
+                                   const cxr_dwproj* projs, int nproj, float* ws, hipStream_t stream);
+int cxr_dwproj_bn_train_bwd_stats_bf16(const void* x, long x_bs, long x_rs, int Bn, int C, int H, int W, int tok0, const cxr_dwproj* projs, int nproj,
+                                       float* ws, hipStream_t stream);
+int cxr_dwproj_dc_taps_bf16(const void* x, long x_bs, long x_rs, int Bn, int C, int H, int W, int tok0, const cxr_dwproj* projs, int nproj, float* ws,
+                            hipStream_t stream);
+int cxr_dwproj_dx_bf16(void* dx, long dx_bs, long dx_rs, int Bn, int C, int H, int W, int tok0, const cxr_dwproj* projs, int nproj,
+                       hipStream_t stream);
+
 /* ---- BERT embeddings (TF5:bert:70-108) ------------------------------------------------------------------------------------ */
 int cxr_bert_embed_fwd(const long* ids, const long* tt, const long* pid, const void* word, const void* type, const void* posw,
                        const float* gamma, const float* beta, float eps, void* sum_out, void* out, float* stats, long R, int T, int pos_offset,

@@ -584,6 +584,108 @@ def test_dwconv_batchnorm_train_mode(ops, C, H, tok0):
         close(dx[:, tok0:], xs.grad.flatten(2).transpose(1, 2), rtol=3e-2, atol=3e-2, what=f"train-mode dx {name}")
 
 
+DWPROJ_SHAPES = [(3, 64, 24, 24, 0), (3, 192, 12, 12, 0), (3, 384, 6, 6, 1), (2, 64, 7, 5, 1), (2, 128, 9, 20, 0), (32, 384, 24, 24, 1), (8, 64, 96, 96, 0)]
+
+
+def _dwproj_params(C, seeds=(1, 2, 3)):
+    par = []
+    for seed in seeds:
+        par.append(dict(w=dev(rnd(C, 1, 3, 3, seed=seed, scale=0.3)), g=dev(1 + 0.1 * rnd(C, seed=seed + 10)), b=dev(0.1 * rnd(C, seed=seed + 20)),
+                        rm=dev(0.1 * rnd(C, seed=seed + 30)), rv=dev(1 + 0.1 * rnd(C, seed=seed + 40).abs())))
+    return par
+
+
+@pytest.mark.parametrize("Bn,C,H,W,tok0", DWPROJ_SHAPES)
+def test_dwproj_fused_eval(ops, Bn, C, H, W, tok0):
+    """Fused q/k/v projections with the running statistics folded in (model.eval()): forward, input gradient, tap sums."""
+    strides = (1, 2, 2)
+    x = dev((rnd(Bn, tok0 + H * W, C) + 0.2).to(BF))
+    par = _dwproj_params(C)
+    folds = [ops.bn_fold(p["w"], p["g"], p["b"], p["rm"], p["rv"], 1e-5) for p in par]
+    ys = ops.dwproj_apply(x, H, W, tok0, [dict(stride=st, taps=f[0], shift=f[1]) for st, f in zip(strides, folds)])
+    xs = x[:, tok0:].float().transpose(1, 2).reshape(Bn, C, H, W).requires_grad_(True)
+    leaves = [{k: p[k].clone().requires_grad_(True) for k in ("w", "g", "b")} for p in par]
+    refs = []
+    for st, p, lv in zip(strides, par, leaves):
+        c = torch.nn.functional.conv2d(xs, lv["w"], None, stride=st, padding=1, groups=C)
+        refs.append(torch.nn.functional.batch_norm(c, p["rm"], p["rv"], lv["g"], lv["b"], False, 0.0, 1e-5).flatten(2).transpose(1, 2))
+    for i, (y, r) in enumerate(zip(ys, refs)):
+        assert y.shape == (Bn, tok0 + r.shape[1], C)
+        close(y[:, tok0:], r, what=f"dwproj eval fwd {i}")
+        if tok0:
+            assert torch.equal(y[:, :tok0], x[:, :tok0])
+    dys = [dev(rnd(*y.shape, seed=7 + i).to(BF)) for i, y in enumerate(ys)]
+    sum((r * d[:, tok0:].float()).sum() for r, d in zip(refs, dys)).backward()
+    keep = [d.clone() for d in dys]
+    GS = ops.dwproj_dc_taps_(x, H, W, tok0, [dict(stride=st, taps=f[0], y=d) for st, f, d in zip(strides, folds, dys)])
+    for d, k in zip(dys, keep):
+        assert torch.equal(d, k)                                                     # no coefficients: gradients are not rewritten
+    for i, (p, lv) in enumerate(zip(par, leaves)):
+        dw, dg, db = torch.zeros(C, 9, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        ops.bn_fold_bwd(p["w"], p["g"], p["rm"], p["rv"], 1e-5, GS[i, :9], GS[i, 9], dw, dg, db)
+        close(dw.view(C, 1, 3, 3), lv["w"].grad, what=f"dwproj eval dW {i}")
+        close(dg, lv["g"].grad, what=f"dwproj eval dgamma {i}")
+        close(db, lv["b"].grad, what=f"dwproj eval dbeta {i}")
+    dx = ops.dwproj_dx([dict(stride=st, taps=f[0], y=d) for st, f, d in zip(strides, folds, dys)], Bn, C, H, W, tok0)
+    close(dx[:, tok0:], xs.grad.flatten(2).transpose(1, 2), what="dwproj eval dx")
+    if tok0:
+        close(dx[:, 0], sum(d[:, 0].float() for d in dys), what="dwproj dx cls")
+    # the per-projection kernels of conv.hip compute the same thing
+    yq, _ = ops.dwconv_bn(x, H, W, 1, tok0, folds[0])
+    close(ys[0], yq, rtol=1e-3, atol=1e-2, what="dwproj vs dwconv q")
+
+
+@pytest.mark.parametrize("Bn,C,H,W,tok0", DWPROJ_SHAPES)
+def test_dwproj_fused_train(ops, Bn, C, H, W, tok0):
+    """Fused q/k/v projections under model.train(): batch statistics, running-stat update, forward, and the backward through the statistics
+    (dgamma, dbeta, raw-tap gradient, dx) against autograd of conv2d + batch_norm(training=True)."""
+    strides = (1, 2, 2)
+    x = dev((rnd(Bn, tok0 + H * W, C) + 0.3).to(BF))
+    par = _dwproj_params(C)
+    raws = [p["w"].view(C, 9).t().contiguous() for p in par]
+    rm0, rv0 = [p["rm"].clone() for p in par], [p["rv"].clone() for p in par]
+    st = ops.dwproj_bn_train_stats(x, H, W, tok0, 1e-5, 0.1, [dict(stride=s_, taps=r, w=p["w"].view(C, 9), gamma=p["g"], beta=p["b"], run_mean=p["rm"], run_var=p["rv"])
+                                                              for s_, r, p in zip(strides, raws, par)])
+    xs = x[:, tok0:].float().transpose(1, 2).reshape(Bn, C, H, W).requires_grad_(True)
+    leaves = [{k: p[k].clone().requires_grad_(True) for k in ("w", "g", "b")} for p in par]
+    refs = []
+    for i, (s_, lv) in enumerate(zip(strides, leaves)):
+        c = torch.nn.functional.conv2d(xs, lv["w"], None, stride=s_, padding=1, groups=C)
+        ref = torch.nn.functional.batch_norm(c, rm0[i], rv0[i], lv["g"], lv["b"], True, 0.1, 1e-5)      # moves rm0 / rv0 in place
+        assert st[i]["count"] == c.numel() // C
+        close(st[i]["mean"], c.detach().mean((0, 2, 3)), rtol=1e-3, atol=1e-3, what=f"batch mean {i}")
+        close(st[i]["rstd"], (c.detach().var((0, 2, 3), unbiased=False) + 1e-5).rsqrt(), rtol=1e-3, atol=1e-3, what=f"batch rstd {i}")
+        close(par[i]["rm"], rm0[i], rtol=1e-4, atol=1e-4, what=f"running mean {i}")
+        close(par[i]["rv"], rv0[i], rtol=1e-4, atol=1e-4, what=f"running var {i}")
+        refs.append(ref.flatten(2).transpose(1, 2))
+    ys = ops.dwproj_apply(x, H, W, tok0, st)
+    for i, (y, r) in enumerate(zip(ys, refs)):
+        close(y[:, tok0:], r, what=f"dwproj train fwd {i}")
+    dys = [dev(rnd(*y.shape, seed=7 + i).to(BF)) for i, y in enumerate(ys)]
+    sum((r * d[:, tok0:].float()).sum() for r, d in zip(refs, dys)).backward()
+    keep = [d.clone() for d in dys]
+    dg = [torch.zeros(C, device="cuda") for _ in par]
+    db = [torch.zeros(C, device="cuda") for _ in par]
+    dw = [torch.zeros(C, 9, device="cuda") for _ in par]
+    coefs = ops.dwproj_bn_train_bwd_stats(x, H, W, tok0, [dict(stride=s_, taps=r, y=d, gamma=p["g"], mean=t["mean"], rstd=t["rstd"], dgamma=a, dbeta=b)
+                                                          for s_, r, d, p, t, a, b in zip(strides, raws, dys, par, st, dg, db)])
+    GS = ops.dwproj_dc_taps_(x, H, W, tok0, [dict(stride=s_, taps=r, y=d, coef=cf, dw=w_) for s_, r, d, cf, w_ in zip(strides, raws, dys, coefs, dw)], need_GS=True)
+    for i, lv in enumerate(leaves):
+        if tok0:
+            assert torch.equal(dys[i][:, :tok0], keep[i][:, :tok0])                   # class-token rows bypass conv + BN
+        close(dg[i], lv["g"].grad, what=f"dwproj train dgamma {i}")
+        close(db[i], lv["b"].grad, what=f"dwproj train dbeta {i}")
+        close(dw[i].view(C, 1, 3, 3), lv["w"].grad, rtol=3e-2, atol=3e-2, what=f"dwproj train dW {i}")
+        close(GS[i, :9].t(), dw[i], rtol=1e-5, atol=1e-5, what=f"dwproj GS rows {i}")
+    dx = ops.dwproj_dx([dict(stride=s_, taps=r, y=d) for s_, r, d in zip(strides, raws, dys)], Bn, C, H, W, tok0)
+    close(dx[:, tok0:], xs.grad.flatten(2).transpose(1, 2), rtol=3e-2, atol=3e-2, what="dwproj train dx")
+    # second call accumulates into dgamma / dbeta / dw (gradient-buffer semantics)
+    d2 = [k.clone() for k in keep]
+    ops.dwproj_bn_train_bwd_stats(x, H, W, tok0, [dict(stride=s_, taps=r, y=d, gamma=p["g"], mean=t["mean"], rstd=t["rstd"], dgamma=a, dbeta=b)
+                                                  for s_, r, d, p, t, a, b in zip(strides, raws, d2, par, st, dg, db)])
+    close(dg[0], 2 * leaves[0]["g"].grad, what="dgamma accumulates")
+
+
 # ------------------------------------------------------------------------------------------------ embeddings / integer ops
 def test_bert_embed_fwd_bwd(ops):
     V, T, B, C = 500, 20, 3, 768
