@@ -15,6 +15,8 @@
 //             -> dw3_dc_taps (dc in place + tap sums G[t] = sum dc * x_t, the raw-tap gradient) -> dw3_reduce_taps -> dw3_dx
 // Eval mode (running statistics folded into the taps) uses dw3_apply / dw3_dc_taps without coefficients / dw3_dx with the folded taps.
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 #include "../../include/cxrmate_hip.h"
 
 namespace {
@@ -22,6 +24,7 @@ namespace {
 constexpr int DW3_THREADS = 256;
 constexpr int DW3_PL = 32;                         // pixel lanes per workgroup (256 threads / 8 chunks)
 constexpr int DW3_LDS_CAP = 80 * 1024;             // two workgroups per CU (160 KB): dynamic tile + static reduction scratch
+constexpr int DW3_LDS_MAX = 156 * 1024;            // one workgroup per CU: only when not even a 2-row band fits DW3_LDS_CAP (W = 96 input gradient)
 
 struct Dw3Geo {
     const bf16_t* x; long x_bs, x_rs;              // activation / dx / staged gradient: [Bn, tok0 + H*W, C]
@@ -105,6 +108,20 @@ __device__ __forceinline__ void dw3_conv(const uint4* tile, int base, int pitch8
 #pragma unroll
             for (int j = 0; j < 8; ++j) c[j] = fmaf(f[j], w[ky * 3 + kx][j], c[j]);
         }
+}
+
+// taps (9 rows) + `naux` rows of P.aux of this workgroup's 64-channel slice -> wl[q][12][64] (LDS): kernels whose accumulators leave no room for
+// 72 tap registers read the taps from LDS per output instead (18 ds_read_b128; the LDS pipe is otherwise idle).
+__device__ __forceinline__ void dw3_stage_taps(float (*wl)[12][64], const Dw3Geo& g, const Dw3P& p0, const Dw3P& p1, const Dw3P& p2, int slice, int naux) {
+    const int rows = 9 + naux;
+    for (int i = threadIdx.x; i < g.nproj * rows * 64; i += DW3_THREADS) {
+        const int q = i / (rows * 64), r = (i / 64) % rows, c = i % 64;
+        const Dw3P& P = q == 0 ? p0 : (q == 1 ? p1 : p2);
+        float v = 0.f;
+        if (r < 9) v = P.taps[r * g.C + slice * 64 + c];
+        else if (P.aux) v = P.aux[(r - 9) * g.C + slice * 64 + c];
+        wl[q][r][c] = v;
+    }
 }
 
 // ---- workgroup reductions over the 32 pixel lanes: lanes differing in bits 3..5 inside a wave, then the 4 waves through `dw3_red`
@@ -274,9 +291,11 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_bwd_stats_kernel(const Dw3
 // (G[t] = sum dc * x_t for the 9 taps, S = sum dc)
 __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_dc_taps_kernel(const Dw3Geo g, const Dw3P p0, const Dw3P p1, const Dw3P p2, float* __restrict__ ws) {
     __shared__ float red[DW3_RED_TAPS];
+    __shared__ __attribute__((aligned(16))) float wl[3][12][64];      // per projection: 9 raw taps + (a, kb, kc) of this slice
     extern __shared__ uint4 dw3_tile[];
     const Dw3Blk k = dw3_block(g);
     const int pitch = g.W + 2, pitch8 = pitch * 8;
+    dw3_stage_taps(wl, g, p0, p1, p2, k.slice, 3);
     dw3_stage(dw3_tile, g.x + (long)k.b * g.x_bs + (long)g.tok0 * g.x_rs + k.slice * 64, g.x_rs, g.H, g.W, k.band_i * g.band - 1, g.band + 2, -1, pitch);
     __syncthreads();
     float* row = ws + (long)(k.b * g.nbands + k.band_i) * g.nproj * 10 * g.C;
@@ -285,8 +304,7 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_dc_taps_kernel(const Dw3Ge
         const Dw3P P = q == 0 ? p0 : (q == 1 ? p1 : p2);
         bf16_t* yb = P.y + (long)k.b * P.y_bs + k.c0;
         const bool train = P.aux != nullptr;
-        float w[9][8];
-        if (train) dw3_load_taps(P.taps, g.C, k.c0, w);
+        const float* wq = &wl[q][0][k.ch * 8];
         float G[80];
 #pragma unroll
         for (int i = 0; i < 80; ++i) G[i] = 0.f;
@@ -298,27 +316,34 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_dc_taps_kernel(const Dw3Ge
             bf16_t* dp = yb + (long)(g.tok0 + (oy0 + oyl) * P.Wo + ox) * P.y_rs;
             float d[8];
             unpack8(*reinterpret_cast<const uint4*>(dp), d);
+            float f[9][8];                                       // the 3 x 3 input window, unpacked ONCE for the conv and the tap sums
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) unpack8(dw3_tile[base + ky * pitch8 + kx * 8], f[ky * 3 + kx]);
             if (train) {
                 float c[8];
-                dw3_conv(dw3_tile, base, pitch8, w, c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) c[j] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    float wt[8];
+                    dw3_load8(wq + t * 64, wt);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) c[j] = fmaf(f[t][j], wt[j], c[j]);
+                }
                 float ca[8], cb[8], cc[8];
-                dw3_load8(P.aux + k.c0, ca); dw3_load8(P.aux + g.C + k.c0, cb); dw3_load8(P.aux + 2 * g.C + k.c0, cc);
+                dw3_load8(wq + 9 * 64, ca); dw3_load8(wq + 10 * 64, cb); dw3_load8(wq + 11 * 64, cc);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) d[j] = fmaf(ca[j], d[j], fmaf(cc[j], c[j], cb[j]));
                 const uint4 pk = pack8(d);
                 *reinterpret_cast<uint4*>(dp) = pk;
                 unpack8(pk, d);                                  // the tap sums see the bf16 dc that dx and the GEMMs see
             }
-            // second read of the taps from LDS (cheaper than holding 9 x 4 registers across the conv: the kernel sits at the 256-VGPR budget)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    float f[8];
-                    unpack8(dw3_tile[base + ky * pitch8 + kx * 8], f);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) G[(ky * 3 + kx) * 8 + j] = fmaf(d[j], f[j], G[(ky * 3 + kx) * 8 + j]);
-                }
+                for (int j = 0; j < 8; ++j) G[t * 8 + j] = fmaf(d[j], f[t][j], G[t * 8 + j]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) G[72 + j] += d[j];
         }
@@ -327,9 +352,59 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_dc_taps_kernel(const Dw3Ge
 }
 
 // ------------------------------------------------------------------------------------------------------------------ input gradient
+template <int py, int px>
+__device__ __forceinline__ void dw3_dx_class(const Dw3Geo& g, const Dw3P& p0, const Dw3P& p1, const Dw3P& p2, const uint4* dw3_tile, const float (*wl)[12][64],
+                                             int toff1, int toff2, int nrow, int ch, bf16_t* drow) {
+    const int wave = threadIdx.x >> 6, lpl = (threadIdx.x & 63) >> 3;
+    const int nr = (nrow - py + 1) >> 1, nc = (g.W - px + 1) >> 1;
+    const int n = nr * nc;
+    for (int grp = (wave - (py * 2 + px)) & 3; grp * 8 < n; grp += 4) {
+        const int idx = grp * 8 + lpl;
+        if (idx >= n) continue;
+        const int ry = idx / nc, rx = idx - ry * nc;
+        const int iyl = 2 * ry + py, ix = 2 * rx + px;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+        for (int q = 0; q < g.nproj; ++q) {
+            const int stride = q == 0 ? p0.stride : (q == 1 ? p1.stride : p2.stride);
+            const float* wq = &wl[q][0][ch * 8];
+            const uint4* tile = dw3_tile + (q == 0 ? 0 : (q == 1 ? toff1 : toff2));
+            const int cols8 = (stride == 1 ? g.W + 2 : g.W / 2 + 1) * 8;
+            if (stride == 1) {
+                // source (iy+1-ky, ix+1-kx) -> tile row iyl + 2 - ky, column ix + 2 - kx
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float f[8], wt[8];
+                        unpack8(tile[(iyl + 2 - ky) * cols8 + (ix + 2 - kx) * 8 + ch], f);
+                        dw3_load8(wq + (ky * 3 + kx) * 64, wt);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(f[j], wt[j], acc[j]);
+                    }
+            } else {
+                // band is even, so the parity of iy + 1 - ky is that of iyl + 1 - ky; tile row = (iyl + 1 - ky) / 2, column = (ix + 1 - kx) / 2
+#pragma unroll
+                for (int ky = (py ? 0 : 1); ky < 3; ky += 2)
+#pragma unroll
+                    for (int kx = (px ? 0 : 1); kx < 3; kx += 2) {
+                        float f[8], wt[8];
+                        unpack8(tile[((iyl + 1 - ky) >> 1) * cols8 + ((ix + 1 - kx) >> 1) * 8 + ch], f);
+                        dw3_load8(wq + (ky * 3 + kx) * 64, wt);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(f[j], wt[j], acc[j]);
+                    }
+            }
+        }
+        *reinterpret_cast<uint4*>(drow + (long)(iyl * g.W + ix) * g.x_rs) = pack8(acc);
+    }
+}
+
+
 // dx[b,(iy,ix)] = sum_q sum_taps taps_q[ky][kx] * dc_q[b, ((iy+1-ky)/st, (ix+1-kx)/st)] (terms with a non-integer or out-of-range source
 // vanish); class row: dx[b,0] = sum_q dc_q[b,0]. g.x is the OUTPUT here; each projection's gradient band is staged in LDS.
 __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_dx_kernel(const Dw3Geo g, const Dw3P p0, const Dw3P p1, const Dw3P p2) {
+    __shared__ __attribute__((aligned(16))) float wl[3][12][64];      // taps of this slice (the class loops index them by compile-time tap)
     extern __shared__ uint4 dw3_tile[];
     const Dw3Blk k = dw3_block(g);
     // tile of projection q: stride 1 -> [band + 2][W + 2] starting at (band_i*band - 1, -1); stride 2 -> [band/2 + 1][W/2 + 1] at (band_i*band/2, 0)
@@ -343,6 +418,7 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_dx_kernel(const Dw3Geo g, 
         dw3_stage(dw3_tile + off, P.y + (long)k.b * P.y_bs + (long)g.tok0 * P.y_rs + k.slice * 64, P.y_rs, P.Ho, P.Wo,
                   P.stride == 1 ? k.band_i * g.band - 1 : (k.band_i * g.band) / 2, t_rows(P), P.stride == 1 ? -1 : 0, t_cols(P));
     }
+    dw3_stage_taps(wl, g, p0, p1, p2, k.slice, 0);
     __syncthreads();
     bf16_t* db = const_cast<bf16_t*>(g.x) + (long)k.b * g.x_bs + k.c0;
     if (g.tok0 && k.band_i == 0 && threadIdx.x < 8) {
@@ -360,63 +436,16 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_dx_kernel(const Dw3Geo g, 
     }
     int nrow = g.band;
     if (k.band_i * g.band + nrow > g.H) nrow = g.H - k.band_i * g.band;
-    const int npix = nrow > 0 ? nrow * g.W : 0;
-    // the taps of all projections do not fit in registers next to each other: outer loop over projections, partial sums kept per pixel
-    // (at most ceil(band*W/32) pixels per thread -> processed in register chunks of 4 pixels)
-    for (int o0 = k.pl; o0 < npix; o0 += DW3_PL * 4) {
-        float acc[4][8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[u][j] = 0.f;
-#pragma unroll 1
-        for (int q = 0; q < g.nproj; ++q) {
-            const Dw3P P = q == 0 ? p0 : (q == 1 ? p1 : p2);
-            float w[9][8];
-            dw3_load_taps(P.taps, g.C, k.c0, w);
-            const uint4* tile = dw3_tile + (q == 0 ? 0 : (q == 1 ? toff1 : toff2));
-            const int cols8 = t_cols(P) * 8;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int o = o0 + u * DW3_PL;
-                if (o >= npix) break;
-                const int iyl = o / g.W, ix = o - iyl * g.W;
-                if (P.stride == 1) {
-                    // source (iy+1-ky, ix+1-kx) -> tile row iyl + 2 - ky, column ix + 2 - kx
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            float f[8];
-                            unpack8(tile[(iyl + 2 - ky) * cols8 + (ix + 2 - kx) * 8 + k.ch], f);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) acc[u][j] = fmaf(f[j], w[ky * 3 + kx][j], acc[u][j]);
-                        }
-                } else {
-                    // ty = iy + 1 - ky must be even; band is even so its parity is that of iyl + 1 - ky; tile row = (iyl + 1 - ky) / 2
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const int ty = iyl + 1 - ky;
-                        if (ty < 0 || (ty & 1)) continue;
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const int tx = ix + 1 - kx;
-                            if (tx < 0 || (tx & 1)) continue;
-                            float f[8];
-                            unpack8(tile[(ty >> 1) * cols8 + (tx >> 1) * 8 + k.ch], f);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) acc[u][j] = fmaf(f[j], w[ky * 3 + kx][j], acc[u][j]);
-                        }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int o = o0 + u * DW3_PL;
-            if (o < npix) *reinterpret_cast<uint4*>(db + (long)(g.tok0 + k.band_i * g.band * g.W + o) * g.x_rs) = pack8(acc[u]);
-        }
-    }
+    if (nrow <= 0) return;
+    // A stride-2 projection reaches input pixel (iy, ix) only through the taps whose source (iy+1-ky, ix+1-kx) is even in both coordinates:
+    // 1, 2, 2 or 4 of the 9, decided by the parities of iy and ix. Pixels are therefore processed per parity class with the class's tap list
+    // compiled in (no per-lane predication: 2.25 taps per pixel on average instead of 9 masked ones); every wave serves all four classes, taking
+    // every 4th group of 8 pixels with a class-dependent rotation so the waves stay balanced.
+    bf16_t* drow = db + (long)(g.tok0 + k.band_i * g.band * g.W) * g.x_rs;
+    dw3_dx_class<0, 0>(g, p0, p1, p2, dw3_tile, wl, toff1, toff2, nrow, k.ch, drow);
+    dw3_dx_class<0, 1>(g, p0, p1, p2, dw3_tile, wl, toff1, toff2, nrow, k.ch, drow);
+    dw3_dx_class<1, 0>(g, p0, p1, p2, dw3_tile, wl, toff1, toff2, nrow, k.ch, drow);
+    dw3_dx_class<1, 1>(g, p0, p1, p2, dw3_tile, wl, toff1, toff2, nrow, k.ch, drow);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ row reductions
@@ -512,14 +541,19 @@ __global__ __launch_bounds__(1024) void dw3_reduce_taps_kernel(const float* __re
 struct Dw3Plan { Dw3Geo g; Dw3P p[3]; size_t lds; int grid; };
 
 static int dw3_pick_band(int Bn, int H, int W, int nslices, size_t (*bytes)(int band, int W, const int* strides, int nproj), const int* strides, int nproj,
-                         size_t static_lds) {
+                         size_t static_lds, size_t cap) {
     // even band that fits the LDS budget; among those giving >= 384 workgroups (1.5 per CU) the one staging the fewest rows in total
     // (nbands * (band + 2)), otherwise the one giving the most workgroups
+    {
+        static int forced = -1;
+        if (forced < 0) { const char* e = getenv("CXR_DW3_BAND"); forced = e ? atoi(e) : 0; }        // tuning aid: force the band height
+        if (forced >= 2 && !(forced & 1) && bytes(forced, W, strides, nproj) + static_lds <= cap) return forced;
+    }
     int best = 0, fallback = 0;
     long best_cost = 0;
     const int hmax = (H + 1) & ~1;
     for (int band = 2; band <= hmax; band += 2) {
-        if (bytes(band, W, strides, nproj) + static_lds > (size_t)DW3_LDS_CAP) break;
+        if (bytes(band, W, strides, nproj) + static_lds > cap) break;
         const int nb = (H + band - 1) / band;
         if (!fallback) fallback = band;
         if ((long)Bn * nb * nslices < 384) continue;
@@ -547,7 +581,8 @@ static int dw3_plan(Dw3Plan& pl, const void* x, long x_bs, long x_rs, int Bn, in
     Dw3Geo& g = pl.g;
     g.x = (const bf16_t*)x; g.x_bs = x_bs; g.x_rs = x_rs; g.Bn = Bn; g.C = C; g.H = H; g.W = W; g.tok0 = tok0; g.nproj = nproj;
     g.nslices = C / 64;
-    g.band = dw3_pick_band(Bn, H, W, g.nslices, for_dx ? dw3_bytes_dx : dw3_bytes_x, strides, nproj, (size_t)red_floats * 4);
+    g.band = dw3_pick_band(Bn, H, W, g.nslices, for_dx ? dw3_bytes_dx : dw3_bytes_x, strides, nproj, (size_t)red_floats * 4, DW3_LDS_CAP);
+    if (g.band < 2) g.band = dw3_pick_band(Bn, H, W, g.nslices, for_dx ? dw3_bytes_dx : dw3_bytes_x, strides, nproj, (size_t)red_floats * 4, DW3_LDS_MAX);
     if (g.band < 2) return CXR_ERR_ARG;                     // a 2-row band does not fit the LDS budget: W too large for this kernel family
     g.nbands = (H + g.band - 1) / g.band;
     pl.lds = for_dx ? dw3_bytes_dx(g.band, W, strides, nproj) : dw3_bytes_x(g.band, W, strides, nproj);
@@ -569,7 +604,7 @@ static bool dw3_y_ok(const cxr_dwproj* projs, int nproj) {
 
 template <typename K>
 static void dw3_allow_big_lds(K kernel, bool& done) {
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW3_LDS_CAP); done = true; }
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW3_LDS_MAX); done = true; }
 }
 
 }  // namespace
@@ -636,7 +671,7 @@ extern "C" int cxr_dwproj_bn_train_bwd_stats_bf16(const void* x, long x_bs, long
 extern "C" int cxr_dwproj_dc_taps_bf16(const void* x, long x_bs, long x_rs, int Bn, int C, int H, int W, int tok0, const cxr_dwproj* projs, int nproj,
                                        float* ws, hipStream_t stream) {
     Dw3Plan pl;
-    const int rc = dw3_plan(pl, x, x_bs, x_rs, Bn, C, H, W, tok0, projs, nproj, false, DW3_RED_TAPS);
+    const int rc = dw3_plan(pl, x, x_bs, x_rs, Bn, C, H, W, tok0, projs, nproj, false, DW3_RED_TAPS + 3 * 12 * 64);
     if (rc) return rc;
     if (!ws || !dw3_y_ok(projs, nproj) || (((size_t)x) % 16)) return CXR_ERR_ARG;
     Dw3Taps f[3];
@@ -656,7 +691,7 @@ extern "C" int cxr_dwproj_dc_taps_bf16(const void* x, long x_bs, long x_rs, int 
 extern "C" int cxr_dwproj_dx_bf16(void* dx, long dx_bs, long dx_rs, int Bn, int C, int H, int W, int tok0, const cxr_dwproj* projs, int nproj,
                                   hipStream_t stream) {
     Dw3Plan pl;
-    const int rc = dw3_plan(pl, dx, dx_bs, dx_rs, Bn, C, H, W, tok0, projs, nproj, true, 0);
+    const int rc = dw3_plan(pl, dx, dx_bs, dx_rs, Bn, C, H, W, tok0, projs, nproj, true, 3 * 12 * 64);
     if (rc) return rc;
     if (!dw3_y_ok(projs, nproj) || (((size_t)dx) % 16)) return CXR_ERR_ARG;
     { static bool big = false; dw3_allow_big_lds(dw3_dx_kernel, big); }

@@ -9,6 +9,7 @@
 // accesses for bias / residual / store. 1-D grid with an XCD-aware (bijective) tile remap so the 8 private L2s
 // each see a contiguous run of N-tiles sharing one A panel.
 #include "common.h"
+#include "../../include/cxrmate_hip.h"
 #include <stdlib.h>
 
 struct GemmArgs {
@@ -43,7 +44,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // BN = 128: 128x128 tile (wave tile 64x64). BN = 64: 128x64 tile (wave tile 64x32) for outputs whose 128x128 tiling would leave CUs idle
 // or waste half a tile (N = 64 / 192, or fewer than ~1.5 tiles per CU).
 template <int BK, bool GLDS, int NST, int BN>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm_nt_body(const GemmArgs& g, const int bid, const int nwg) {
     constexpr int BM = 128;
     constexpr int NTL = BN / 32;                // 16-column MFMA tiles per wave along N
     constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
@@ -61,7 +62,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
     const int tiles_n = (g.N + BN - 1) / BN;
     int swz;
     {
-        const int nwg = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
@@ -321,44 +321,76 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
     }
 }
 
+template <int BK, bool GLDS, int NST, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
+    gemm_nt_body<BK, GLDS, NST, BN>(g, blockIdx.x, gridDim.x);
+}
+
+// Up to three independent problems with the same N, K and epilogue class in ONE launch (workgroups [start[p], start[p+1]) serve problem p):
+// the query / key / value projections of a CvT layer have 145..577 rows per image -- the key and value GEMMs alone fill under half of the
+// 256 CUs (111 tiles at batch 32) and cost a launch latency each; grouped with the query GEMM they ride in its tail.
+struct GemmGroupArgs { GemmArgs g[3]; int start[3]; int n; };
+template <int BK, bool GLDS, int NST, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_group_kernel(const GemmGroupArgs gg) {
+    const int b = blockIdx.x;
+    const int p = (gg.n > 2 && b >= gg.start[2]) ? 2 : ((gg.n > 1 && b >= gg.start[1]) ? 1 : 0);
+    const int end = p + 1 < gg.n ? gg.start[p + 1] : (int)gridDim.x;
+    if (p == 0)      gemm_nt_body<BK, GLDS, NST, BN>(gg.g[0], b, end);
+    else if (p == 1) gemm_nt_body<BK, GLDS, NST, BN>(gg.g[1], b - gg.start[1], end - gg.start[1]);
+    else             gemm_nt_body<BK, GLDS, NST, BN>(gg.g[2], b - gg.start[2], end - gg.start[2]);
+}
+
 static int g_gemm_regstage = 0;     // debugging aid: 1 = stage through registers instead of LDS-DMA
 
 extern "C" int cxr_gemm_set_regstage(int on) { g_gemm_regstage = on; return CXR_OK; }
+
+static int gemm_nt_fill(GemmArgs& g, const cxr_gemm_nt_desc& d) {
+    if (d.M <= 0 || d.N <= 0 || d.K <= 0) return CXR_ERR_ARG;
+    if (d.drop_p < 0.f || d.drop_p >= 1.f || (d.drop_p > 0.f && (!d.drop_seed || d.drop_rows_per_b <= 0)) || (d.row_scale && d.rs_rows <= 0)) return CXR_ERR_ARG;
+    if ((d.K % 32) || (d.N % 4) || (d.lda % 8) || (d.ldw % 8) || (d.ldc % 4)) return CXR_ERR_ARG;
+    if (d.residual && (d.ldr % 4)) return CXR_ERR_ARG;
+    if (d.act == 2 && !d.aux) return CXR_ERR_ARG;
+    if (d.aux && (d.ldaux % 4)) return CXR_ERR_ARG;
+    if (d.accumulate && !d.out_f32) return CXR_ERR_ARG;
+    g.A = (const bf16_t*)d.A; g.lda = d.lda; g.W = (const bf16_t*)d.W; g.ldw = d.ldw; g.C = d.C; g.ldc = d.ldc;
+    g.bias = d.bias; g.residual = (const bf16_t*)d.residual; g.ldr = d.ldr; g.aux = (bf16_t*)d.aux; g.ldaux = d.ldaux;
+    g.M = d.M; g.N = d.N; g.K = d.K; g.alpha = d.alpha; g.act = d.act; g.out_f32 = d.out_f32; g.accumulate = d.accumulate;
+    g.drop_seed = d.drop_seed; g.drop_site = d.drop_site; g.drop_thr16 = d.drop_p > 0.f ? dropout_thr16(d.drop_p) : 0u; g.drop_inv = 1.0f / (1.0f - d.drop_p);
+    g.drop_rows_per_b = d.drop_rows_per_b > 0 ? d.drop_rows_per_b : 1; g.drop_t0 = d.drop_t0;
+    g.row_scale = d.row_scale; g.rs_rows = d.rs_rows > 0 ? d.rs_rows : 1; g.rs_after = d.rs_after;
+    static int lds_epi = -1;          // CXR_GEMM_LDS_EPILOGUE=0 falls back to the per-lane 8-byte epilogue (A/B aid)
+    if (lds_epi < 0) { const char* e = getenv("CXR_GEMM_LDS_EPILOGUE"); lds_epi = e ? atoi(e) : 1; }
+    auto al16 = [](const void* p, long ld, int esz) { return p == nullptr || ((((size_t)p) % 16) == 0 && ((ld * esz) % 16) == 0); };
+    g.lds_epilogue = lds_epi && (d.N % 4) == 0 && al16(d.C, d.ldc, d.out_f32 ? 4 : 2) && al16(d.residual, d.ldr, 2) && al16(d.aux, d.ldaux, 2) &&
+                     (d.bias == nullptr || (((size_t)d.bias) % 16) == 0);
+    return CXR_OK;
+}
+
+// tile shape: narrow (128x64) when the last N tile would be mostly empty (N = 64, 192) or when 128x128 tiling gives fewer than ~1.5 tiles per CU
+static bool gemm_nt_narrow(int N, long tiles128) {
+    static int force_bn = -1;         // tuning aid: CXR_GEMM_BN=64|128
+    if (force_bn < 0) { const char* e = getenv("CXR_GEMM_BN"); force_bn = e ? atoi(e) : 0; }
+    bool bn64 = (N % 128) != 0 && (N % 128) <= 64;
+    if (tiles128 < 160) bn64 = true;
+    if (force_bn == 64) bn64 = true; else if (force_bn == 128) bn64 = false;
+    return bn64;
+}
 
 extern "C" int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc,
                                 const float* bias, const void* residual, long ldr, void* aux, long ldaux,
                                 int M, int N, int K, float alpha, int act, int out_f32, int accumulate,
                                 float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_rows_per_b, int drop_t0,
                                 const float* row_scale, int rs_rows, int rs_after, hipStream_t stream) {
-    if (M <= 0 || N <= 0 || K <= 0) return CXR_ERR_ARG;
-    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (!drop_seed || drop_rows_per_b <= 0)) || (row_scale && rs_rows <= 0)) return CXR_ERR_ARG;
-    if ((K % 32) || (N % 4) || (lda % 8) || (ldw % 8) || (ldc % 4)) return CXR_ERR_ARG;
-    if (residual && (ldr % 4)) return CXR_ERR_ARG;
-    if (act == 2 && !aux) return CXR_ERR_ARG;
-    if (aux && (ldaux % 4)) return CXR_ERR_ARG;
-    if (accumulate && !out_f32) return CXR_ERR_ARG;
+    const cxr_gemm_nt_desc d{A, lda, W, ldw, C, ldc, bias, residual, ldr, aux, ldaux, M, N, K, alpha, act, out_f32, accumulate,
+                             drop_p, drop_seed, drop_site, drop_rows_per_b, drop_t0, row_scale, rs_rows, rs_after};
     GemmArgs g;
-    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = C; g.ldc = ldc;
-    g.bias = bias; g.residual = (const bf16_t*)residual; g.ldr = ldr; g.aux = (bf16_t*)aux; g.ldaux = ldaux;
-    g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.act = act; g.out_f32 = out_f32; g.accumulate = accumulate;
-    g.drop_seed = drop_seed; g.drop_site = drop_site; g.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u; g.drop_inv = 1.0f / (1.0f - drop_p);
-    g.drop_rows_per_b = drop_rows_per_b > 0 ? drop_rows_per_b : 1; g.drop_t0 = drop_t0;
-    g.row_scale = row_scale; g.rs_rows = rs_rows > 0 ? rs_rows : 1; g.rs_after = rs_after;
-    static int lds_epi = -1;          // CXR_GEMM_LDS_EPILOGUE=0 falls back to the per-lane 8-byte epilogue (A/B aid)
-    if (lds_epi < 0) { const char* e = getenv("CXR_GEMM_LDS_EPILOGUE"); lds_epi = e ? atoi(e) : 1; }
-    auto al16 = [](const void* p, long ld, int esz) { return p == nullptr || ((((size_t)p) % 16) == 0 && ((ld * esz) % 16) == 0); };
-    g.lds_epilogue = lds_epi && (N % 4) == 0 && al16(C, ldc, out_f32 ? 4 : 2) && al16(residual, ldr, 2) && al16(aux, ldaux, 2) &&
-                     (bias == nullptr || (((size_t)bias) % 16) == 0);
-    static int force_bk = -1, stages = -1, force_bn = -1;     // tuning aids: CXR_GEMM_BK=32|64, CXR_GEMM_STAGES=2|3|4, CXR_GEMM_BN=64|128
+    const int rc = gemm_nt_fill(g, d);
+    if (rc) return rc;
+    static int force_bk = -1, stages = -1;     // tuning aids: CXR_GEMM_BK=32|64, CXR_GEMM_STAGES=2|3|4
     if (force_bk < 0) { const char* e = getenv("CXR_GEMM_BK"); force_bk = e ? atoi(e) : 0; }
     if (stages < 0) { const char* e = getenv("CXR_GEMM_STAGES"); stages = e ? atoi(e) : 2; }
-    if (force_bn < 0) { const char* e = getenv("CXR_GEMM_BN"); force_bn = e ? atoi(e) : 0; }
     const bool bk64 = (K % 64) == 0 && force_bk != 32;
-    // narrow tile when the last N tile would be mostly empty (N = 64, 192) or when 128x128 tiling gives fewer than ~1.5 tiles per CU
-    const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128);
-    bool bn64 = (N % 128) != 0 && (N % 128) <= 64;
-    if (tiles128 < 160) bn64 = true;
-    if (force_bn == 64) bn64 = true; else if (force_bn == 128) bn64 = false;
+    const bool bn64 = gemm_nt_narrow(N, (long)cdiv(M, 128) * cdiv(N, 128));
     const int grid = cdiv(M, 128) * cdiv(N, bn64 ? 64 : 128);
     if (g_gemm_regstage) {
         if (bk64) CXR_LAUNCH((gemm_nt_kernel<64, false, 2, 128>), dim3(cdiv(M, 128) * cdiv(N, 128)), dim3(256), 0, stream, g);
@@ -373,6 +405,38 @@ extern "C" int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw
     } else {
         if (bk64) CXR_LAUNCH((gemm_nt_kernel<64, true, 2, 128>), dim3(grid), dim3(256), 0, stream, g);
         else      CXR_LAUNCH((gemm_nt_kernel<32, true, 2, 128>), dim3(grid), dim3(256), 0, stream, g);
+    }
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// n <= 3 problems with equal N and K in one launch (see gemm_nt_group_kernel); epilogues may differ per problem
+extern "C" int cxr_gemm_nt_group_bf16(const cxr_gemm_nt_desc* d, int n, hipStream_t stream) {
+    if (!d || n < 1 || n > 3) return CXR_ERR_ARG;
+    GemmGroupArgs gg;
+    long tiles128 = 0;
+    for (int i = 0; i < n; ++i) {
+        if (d[i].N != d[0].N || d[i].K != d[0].K) return CXR_ERR_ARG;
+        const int rc = gemm_nt_fill(gg.g[i], d[i]);
+        if (rc) return rc;
+        tiles128 += (long)cdiv(d[i].M, 128) * cdiv(d[i].N, 128);
+    }
+    for (int i = n; i < 3; ++i) gg.g[i] = gg.g[0];
+    const int N = d[0].N, K = d[0].K;
+    const bool bk64 = (K % 64) == 0;
+    const bool bn64 = gemm_nt_narrow(N, tiles128);
+    int grid = 0;
+    for (int i = 0; i < 3; ++i) {
+        gg.start[i] = grid;
+        if (i < n) grid += cdiv(d[i].M, 128) * cdiv(N, bn64 ? 64 : 128);
+    }
+    gg.n = n;
+    if (bn64) {
+        if (bk64) CXR_LAUNCH((gemm_nt_group_kernel<64, true, 2, 64>), dim3(grid), dim3(256), 0, stream, gg);
+        else      CXR_LAUNCH((gemm_nt_group_kernel<32, true, 2, 64>), dim3(grid), dim3(256), 0, stream, gg);
+    } else {
+        if (bk64) CXR_LAUNCH((gemm_nt_group_kernel<64, true, 2, 128>), dim3(grid), dim3(256), 0, stream, gg);
+        else      CXR_LAUNCH((gemm_nt_group_kernel<32, true, 2, 128>), dim3(grid), dim3(256), 0, stream, gg);
     }
     CXR_LAUNCH_CHECK();
     return CXR_OK;

@@ -253,9 +253,10 @@ class CvtEncoderEngine:
             qc, _ = ops.dwconv_bn(h1, H, W, cfg.stride_q[s], tok0, fq)
             kc, vc = ops.dwconv_bn(h1, H, W, cfg.stride_kv[s], tok0, fk, fv)
         Lk = kc.shape[1]
-        q = ops.gemm_nt(qc.view(-1, C), st.w16(ap + "projection_query.weight"), bias=st.f32(ap + "projection_query.bias")).view(Bn, L, C)
-        k = ops.gemm_nt(kc.view(-1, C), st.w16(ap + "projection_key.weight"), bias=st.f32(ap + "projection_key.bias")).view(Bn, Lk, C)
-        v = ops.gemm_nt(vc.view(-1, C), st.w16(ap + "projection_value.weight"), bias=st.f32(ap + "projection_value.bias")).view(Bn, Lk, C)
+        # the three linear projections in one grouped launch (the key / value GEMMs alone would leave most CUs idle)
+        q, k, v = ops.gemm_nt_group([(t_.view(-1, C), st.w16(ap + f"projection_{n}.weight"), st.f32(ap + f"projection_{n}.bias"))
+                                     for n, t_ in (("query", qc), ("key", kc), ("value", vc))])
+        q, k, v = q.view(Bn, L, C), k.view(Bn, Lk, C), v.view(Bn, Lk, C)
         ctx, lse = ops.attention(q, k, v, nh, C ** -0.5, need_lse=save)                  # scale = embed_dim^-0.5 (quirk Q1)
         dp1, dp2 = self._drop_path_scales(s, l, Bn)
         x2 = ops.gemm_nt(ctx.view(-1, C), st.w16(lp + "attention.output.dense.weight"), bias=st.f32(lp + "attention.output.dense.bias"), residual=x2d,
@@ -344,10 +345,11 @@ class CvtEncoderEngine:
         ops.linear_bwd_weight(da, sv["ctx"].view(-1, C), g(lp + "attention.output.dense.weight"), g(lp + "attention.output.dense.bias"))
         dctx = ops.gemm_nt(da, self._wt(lp + "attention.output.dense.weight")).view(Bn, L, C)
         dq, dk, dv = ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, C ** -0.5)
-        dcs = {}
         for name, d, inp in (("query", dq, sv["qc"]), ("key", dk, sv["kc"]), ("value", dv, sv["vc"])):
             ops.linear_bwd_weight(d.view(-1, C), inp.view(-1, C), g(ap + f"projection_{name}.weight"), g(ap + f"projection_{name}.bias"))
-            dcs[name] = ops.gemm_nt(d.view(-1, C), self._wt(ap + f"projection_{name}.weight")).view(d.shape)     # grad wrt the BatchNorm output
+        # gradients wrt the three BatchNorm outputs, one grouped launch
+        outs = ops.gemm_nt_group([(d.view(-1, C), self._wt(ap + f"projection_{name}.weight"), None) for name, d in (("query", dq), ("key", dk), ("value", dv))])
+        dcs = {name: o.view(d.shape) for (name, d), o in zip((("query", dq), ("key", dk), ("value", dv)), outs)}
         strides = {"query": cfg.stride_q[s], "key": cfg.stride_kv[s], "value": cfg.stride_kv[s]}
         projs = []
         h1 = sv["h1"]

@@ -2,6 +2,8 @@
 every function here allocates outputs with torch.empty/zeros and hands raw device pointers to libcxrmate_hip.so."""
 from __future__ import annotations
 
+import ctypes as _ct
+
 import torch
 
 from ._lib import LIB, CxrError
@@ -69,6 +71,41 @@ def gemm_nt(a, w, bias=None, residual=None, act=0, aux=None, out=None, out_f32=F
         nbytes = 2.0 * (M * K + N * K) + M * N * ((4 if out_f32 else 2) + (2 if residual is not None else 0) + (2 if aux is not None else 0))
         prof.append((2.0 * M * N * K, e0, e1, (M, N, K), nbytes))
     return out
+
+
+_GEMM_GROUP = __import__("os").environ.get("CXR_GEMM_GROUP", "1") != "0"
+
+
+class _GemmNtDesc(_ct.Structure):
+    """Mirror of `cxr_gemm_nt_desc` (include/cxrmate_hip.h)."""
+    _fields_ = [("A", _ct.c_void_p), ("lda", _ct.c_long), ("W", _ct.c_void_p), ("ldw", _ct.c_long), ("C", _ct.c_void_p), ("ldc", _ct.c_long),
+                ("bias", _ct.c_void_p), ("residual", _ct.c_void_p), ("ldr", _ct.c_long), ("aux", _ct.c_void_p), ("ldaux", _ct.c_long),
+                ("M", _ct.c_int), ("N", _ct.c_int), ("K", _ct.c_int), ("alpha", _ct.c_float), ("act", _ct.c_int), ("out_f32", _ct.c_int),
+                ("accumulate", _ct.c_int), ("drop_p", _ct.c_float), ("drop_seed", _ct.c_void_p), ("drop_site", _ct.c_uint),
+                ("drop_rows_per_b", _ct.c_int), ("drop_t0", _ct.c_int), ("row_scale", _ct.c_void_p), ("rs_rows", _ct.c_int), ("rs_after", _ct.c_int)]
+
+
+def gemm_nt_group(problems):
+    """Up to three gemm_nt problems with equal N and K in one launch. problems: [(a [M_i,K], w [N,K], bias | None)] -> [out_i [M_i,N] bf16]."""
+    assert 1 <= len(problems) <= 3
+    if GEMM_PROFILE is not None or not _GEMM_GROUP:       # per-GEMM profiling wants one launch per problem; CXR_GEMM_GROUP=0: A/B switch
+        return [gemm_nt(a, w, bias=b) for a, w, b in problems]
+    arr = (_GemmNtDesc * len(problems))()
+    outs = []
+    for d, (a, w, bias) in zip(arr, problems):
+        _chk(a, BF16); _chk(w, BF16)
+        M, K = a.shape
+        N, K2 = w.shape
+        assert K == K2, (a.shape, w.shape)
+        out = torch.empty((M, N), device=a.device, dtype=BF16)
+        if bias is not None:
+            assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+            d.bias = _p(bias)
+        d.A, d.lda, d.W, d.ldw, d.C, d.ldc = _p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0)
+        d.M, d.N, d.K, d.alpha, d.drop_rows_per_b, d.rs_rows = M, N, K, 1.0, 1, 1
+        outs.append(out)
+    LIB.call("cxr_gemm_nt_group_bf16", _ct.addressof(arr), len(problems), _s())
+    return outs
 
 
 def transpose(x, pad_cols_to=1, out=None):
@@ -445,9 +482,6 @@ def tap_grad_accum(G, dw):
 
 
 # ---- fused query / key / value convolutional projections (csrc/dwproj.hip): one LDS-staged pass per layer and step of the BatchNorm algebra
-import ctypes as _ct
-
-
 class DwProj(_ct.Structure):
     """Mirror of `cxr_dwproj` (include/cxrmate_hip.h): one depthwise projection of the shared activation; device pointers as integers."""
     _fields_ = [("stride", _ct.c_int), ("taps", _ct.c_void_p), ("shift", _ct.c_void_p), ("y", _ct.c_void_p), ("y_bs", _ct.c_long), ("y_rs", _ct.c_long),

@@ -33,6 +33,15 @@ int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw, void* C, 
                      void* aux, long ldaux, int M, int N, int K, float alpha, int act, int out_f32, int accumulate, float drop_p,
                      const unsigned int* drop_seed, unsigned int drop_site, int drop_rows_per_b, int drop_t0, const float* row_scale,
                      int rs_rows, int rs_after, hipStream_t stream);
+/* up to three cxr_gemm_nt_bf16 problems with equal N and K in ONE launch (the query / key / value projections of a CvT or BERT layer and their
+ * input-gradient products: the small key / value GEMMs ride in the tail of the query GEMM instead of paying a launch and half-empty CUs each).
+ * `d` is a HOST array; fields = the arguments of cxr_gemm_nt_bf16 in order. */
+typedef struct cxr_gemm_nt_desc {
+    const void* A; long lda; const void* W; long ldw; void* C; long ldc; const float* bias; const void* residual; long ldr; void* aux; long ldaux;
+    int M, N, K; float alpha; int act, out_f32, accumulate; float drop_p; const unsigned int* drop_seed; unsigned int drop_site;
+    int drop_rows_per_b, drop_t0; const float* row_scale; int rs_rows, rs_after;
+} cxr_gemm_nt_desc;
+int cxr_gemm_nt_group_bf16(const cxr_gemm_nt_desc* d, int n, hipStream_t stream);
 /* weight gradient: C[I,J] += alpha * sum_r P[r,I] Q[r,J]  (dW += dY^T X), dbias[I] += colsum(P); token dimension split across
  * workgroups, fp32 atomic accumulation into the gradient buffer. Requires I%8==0, J%8==0. */
 int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* dbias, int R, int I, int J, float alpha,
