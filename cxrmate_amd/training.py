@@ -12,6 +12,8 @@ critical path. The RCCL all-reduces stay OUTSIDE the graphs, between the segment
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import dp, ops
@@ -91,7 +93,7 @@ class wgrad_overlap:
     _stream = None
 
     def __enter__(self):
-        if wgrad_overlap._stream is None:
+        if wgrad_overlap._stream is None and os.environ.get("CXR_WGRAD_OVERLAP", "1") != "0":      # 0: A/B switch, everything on one stream
             wgrad_overlap._stream = torch.cuda.Stream()
         self.prev, ops.WGRAD_STREAM = ops.WGRAD_STREAM, wgrad_overlap._stream
         return self

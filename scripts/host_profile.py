@@ -7,6 +7,7 @@ from cxrmate_amd.config import EncoderDecoderConfig
 from cxrmate_amd.modelling import SingleCXREncoderDecoderModel
 from cxrmate_amd.training import FusedAdamW, tf_train_step
 m = SingleCXREncoderDecoderModel(EncoderDecoderConfig(), device="cuda", seed=0)
+m.train()
 opt = FusedAdamW(m, lr=5e-5)
 px, inp, am, lab = bench.synth_batch(32, 256, 30000, "cuda", 1)
 tt = m.token_ids_to_token_type_ids(inp, [3])
