@@ -90,10 +90,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
                                                             bf16_t* __restrict__ dx, long lddx, float* __restrict__ partial /*[grid][2][C]*/,
                                                             long rows, LnBwdDrop dd) {
     using L = LNCfg<C>;
-    __shared__ float red[2][C];
+    __shared__ float red[4][2][C];
     const uint32_t dseed = dd.thr16 ? *dd.seed : 0u;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) (&red[0][0])[i] = 0.f;
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % L::LPR, grp = lane / L::LPR;
     const long rows_per_block = 4 * L::RPW * U;
@@ -184,17 +182,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
         }
     }
     if (partial) {
+        // workgroup sum of the per-lane (dgamma, dbeta) partials without LDS atomics (those serialised 4-8 ways per address and cost as much as
+        // the streaming part of the kernel): row groups inside a wave by butterfly, then one plain store per wave and a 4-way sum
 #pragma unroll
-        for (int i = 0; i < L::CPL; ++i) {
-            const int ch = sub + i * L::LPR;
-            if (ch < L::CH) {
+        for (int i = 0; i < L::CPL; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { atomicAdd(&red[0][ch * 8 + j], ag[i][j]); atomicAdd(&red[1][ch * 8 + j], ab[i][j]); }
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int o = L::LPR; o < 64; o <<= 1) { ag[i][j] += __shfl_xor(ag[i][j], o, 64); ab[i][j] += __shfl_xor(ab[i][j], o, 64); }
+            }
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < L::CPL; ++i) {
+                const int ch = sub + i * L::LPR;
+                if (ch < L::CH) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { red[wave][0][ch * 8 + j] = ag[i][j]; red[wave][1][ch * 8 + j] = ab[i][j]; }
+                }
             }
         }
         __syncthreads();
         float* out = partial + (long)blockIdx.x * 2 * C;                  // plain stores: no cross-workgroup contention
-        for (int i = threadIdx.x; i < 2 * C; i += 256) out[i] = (&red[0][0])[i];
+        for (int i = threadIdx.x; i < 2 * C; i += 256)
+            out[i] = ((&red[0][0][0])[i] + (&red[1][0][0])[i]) + ((&red[2][0][0])[i] + (&red[3][0][0])[i]);
     }
 }
 
@@ -263,17 +273,27 @@ extern "C" int cxr_layernorm_bwd_bf16(const void* x, long ldx, const void* dy, l
                                       const void* add, long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, float* workspace,
                                       long rows, int C, void* dx2, long lddx2, float drop_p, const unsigned int* drop_seed, unsigned int drop_site,
                                       int drop_rows_per_b, int drop_t0, const float* row_scale, hipStream_t stream) {
-    if (rows <= 0 || (ldx % 8) || (lddy % 8) || (lddx % 8) || (add && (ldadd % 8)) || (dgamma && !workspace)) return CXR_ERR_ARG;
+    if (rows <= 0 || (ldx % 8) || (lddy % 8) || (lddx % 8) || (add && (ldadd % 8)) || (dgamma && (!workspace || !dbeta))) return CXR_ERR_ARG;
     if (dx2 && ((lddx2 % 8) || drop_rows_per_b <= 0 || (!row_scale && (drop_p <= 0.f || drop_p >= 1.f || !drop_seed)))) return CXR_ERR_ARG;
     LnBwdDrop dd;
     dd.dx2 = (bf16_t*)dx2; dd.lddx2 = lddx2; dd.seed = drop_seed; dd.site = drop_site; dd.thr16 = (dx2 && !row_scale) ? dropout_thr16(drop_p) : 0u;
     dd.inv = drop_p < 1.f ? 1.0f / (1.0f - drop_p) : 1.f; dd.rows_per_b = drop_rows_per_b > 0 ? drop_rows_per_b : 1; dd.t0 = drop_t0;
     dd.row_scale = row_scale;
     const int grid = cxr_layernorm_bwd_grid(rows, C);
-    float* partial = dgamma ? workspace : nullptr;
+    float* partial = workspace;                                   // partial rows are written whenever a workspace is given; the caller may run
+                                                                  // cxr_layernorm_bwd_reduce on another stream (dgamma == NULL here)
     LN_DISPATCH(C, layernorm_bwd_kernel, 2, 2, 4, 2, 1, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, gamma, stats, (const bf16_t*)add, ldadd,
                 (bf16_t*)dx, lddx, partial, rows, dd);
     if (dgamma) CXR_LAUNCH(layernorm_bwd_reduce_kernel, dim3(cdiv(2 * C, 32), cdiv(grid, 64)), dim3(256), 0, stream, partial, grid, C, dgamma, dbeta);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// second half of cxr_layernorm_bwd_bf16 on its own (parameter gradients only feed the optimiser: the caller may put this on a side stream)
+extern "C" int cxr_layernorm_bwd_reduce(const float* workspace, long rows, int C, float* dgamma, float* dbeta, hipStream_t stream) {
+    if (!workspace || !dgamma || !dbeta || rows <= 0) return CXR_ERR_ARG;
+    const int grid = cxr_layernorm_bwd_grid(rows, C);
+    CXR_LAUNCH(layernorm_bwd_reduce_kernel, dim3(cdiv(2 * C, 32), cdiv(grid, 64)), dim3(256), 0, stream, workspace, grid, C, dgamma, dbeta);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

@@ -304,11 +304,15 @@ def layernorm_bwd(x, dy, gamma, stats, dgamma, dbeta, add=None, out=None, drop=N
     if dgamma is not None:
         nb = LIB.load().cxr_layernorm_bwd_grid(rows, C)
         ws = torch.empty((nb, 2, C), device=x.device, dtype=torch.float32)
+    side = WGRAD_STREAM is not None and dgamma is not None       # row sum of the (dgamma, dbeta) partials off the critical path
     LIB.call("cxr_layernorm_bwd_bf16", _p(x), x.stride(0), _p(dy), dy.stride(0), _p(gamma), _p(stats), _p(add),
-             add.stride(0) if add is not None else 0, _p(out), out.stride(0), _p(dgamma), _p(dbeta), _p(ws), rows, C, _p(out2),
+             add.stride(0) if add is not None else 0, _p(out), out.stride(0), None if side else _p(dgamma), None if side else _p(dbeta), _p(ws), rows, C, _p(out2),
              out2.stride(0) if second else 0, float(drop[0]) if drop is not None else 0.0, _p(drop[1]) if drop is not None else None,
              int(drop[2]) if drop is not None else 0, int(drop[3]) if drop is not None else (int(row_scale[1]) if row_scale is not None else 1),
              int(drop[4]) if drop is not None else 0, _p(row_scale[0]) if row_scale is not None else None, _s())
+    if side:
+        with _on_wgrad_stream(ws):
+            LIB.call("cxr_layernorm_bwd_reduce", _p(ws), rows, C, _p(dgamma), _p(dbeta), _s())
     return (out, out2) if second else out
 
 

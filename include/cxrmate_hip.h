@@ -98,6 +98,9 @@ int cxr_layernorm_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, c
                            long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, float* workspace, long rows, int C, void* dx2,
                            long lddx2, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_rows_per_b, int drop_t0,
                            const float* row_scale, hipStream_t stream);
+/* workspace != NULL and dgamma == NULL: the per-workgroup (dgamma, dbeta) partial rows are left in `workspace` and this second half adds them
+ * into dgamma / dbeta later (parameter gradients only feed the optimiser: the host puts it on the weight-gradient side stream) */
+int cxr_layernorm_bwd_reduce(const float* workspace, long rows, int C, float* dgamma, float* dbeta, hipStream_t stream);
                            /* workspace: fp32 [cxr_layernorm_bwd_grid(rows,C)][2][C] partial sums. dx2 (optional) = f * dx: the gradient of a
                               dropout / DropPath branch fed by this LayerNorm's input (forward mask re-applied: element hash, or
                               row_scale[row / drop_rows_per_b]) */
