@@ -14,14 +14,19 @@ position, column): backward -- and the teacher-forced re-scoring of a sequence s
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
-from . import ops
+from . import ops, weights
 from .config import BertConfig
 
 BF16 = torch.bfloat16
 
 SITE_EMBED = 1
+
+
+_CROSS_KV_FUSED = os.environ.get("CXR_CROSS_KV_FUSED", "1") != "0"      # A/B switch: 0 = one K / V GEMM per layer
 
 
 def _site(layer, k):
@@ -95,6 +100,20 @@ class BertEngine:
         self._wtb_ready = False
         return prep
 
+    def _cross_kv_all(self):
+        """(W bf16 [layers*2*d, d], bias fp32 [layers*2*d], keys) of the cross-attention key / value projections of ALL layers as one matrix (they
+        are stored back to back: weights.bert_param_shapes), or None (no cross-attention / CXR_CROSS_KV_FUSED=0)."""
+        cfg, st = self.cfg, self.s
+        if not cfg.add_cross_attention or not _CROSS_KV_FUSED:
+            return None
+        prefix = self.p[:-len("base_model.model.")] if cfg.lora_r else self.p
+        wk, bk = weights.cross_kv_keys(cfg, prefix, ".weight"), weights.cross_kv_keys(cfg, prefix, ".bias")
+        w, b = st.span(wk, "w16"), st.span(bk, "f32")
+        if w is None or b is None:
+            return None
+        d = cfg.hidden_size
+        return w.view(len(wk) * d, d), b, wk, bk
+
     def _linear_names(self):
         cfg, p = self.cfg, self.p
         names = []
@@ -118,6 +137,9 @@ class BertEngine:
                 keys.append(("wt", base)); srcs.append(self._lin(base)[0]); pads.append(1)
                 if mode and not st.has(base + ".weight"):
                     keys.append(("wtb", base)); srcs.append(st.w16(base + ".base_layer.weight")); pads.append(1)
+            kv_all = self._cross_kv_all()
+            if kv_all is not None:
+                keys.append(("wt", "cross_kv_all")); srcs.append(kv_all[0]); pads.append(1)
             if not self.cfg.cls_projection_size:
                 keys.append(("wt", p + "cls.predictions.transform.dense")); srcs.append(st.w16(p + "cls.predictions.transform.dense.weight")); pads.append(1)
                 keys.append(("wt", p + "bert.embeddings.word_embeddings.weight")); srcs.append(st.w16(keys[-1][1])); pads.append(64)
@@ -175,6 +197,15 @@ class BertEngine:
         saved = dict(B=B, T=T, ids=ids, tt=token_type_ids, pos=position_ids, esum=esum, estats=estats, attn_mask=attn_mask, enc=enc,
                      enc_mask=enc_mask, causal=causal, layers=[], ph=ph, pa=pa, seed=seed, lora_tr=lora_tr) if save else None
         scale = cfg.head_dim ** -0.5
+        kv_all = None
+        if cfg.add_cross_attention and enc is not None:
+            kva = self._cross_kv_all()
+            if kva is not None:
+                # cross-attention K and V of every layer in one GEMM: [B*S, d] x [d, layers*2*d] (all layers project the same encoder output)
+                S_ = enc.shape[1]
+                kv_all = ops.gemm_nt(enc.reshape(B * S_, D), kva[0], bias=kva[1]).view(B, S_, -1)
+                if save:
+                    saved["kv_all"] = True
 
         def out_proj(x, w, b, resid, site):
             """dense -> dropout -> + residual (BertSelfOutput / BertOutput before their LayerNorm)"""
@@ -209,8 +240,11 @@ class BertEngine:
                 cq, cbq = self._lin(lp + "crossattention.self.query"); ck, cbk = self._lin(lp + "crossattention.self.key")
                 cv, cbv = self._lin(lp + "crossattention.self.value"); co, cbo = self._lin(lp + "crossattention.output.dense")
                 q2 = ops.gemm_nt(h1, cq, bias=cbq).view(B, T, D)
-                k2 = ops.gemm_nt(enc.view(B * S, D), ck, bias=cbk).view(B, S, D)
-                v2 = ops.gemm_nt(enc.view(B * S, D), cv, bias=cbv).view(B, S, D)
+                if kv_all is not None:
+                    k2, v2 = kv_all[:, :, 2 * l * D:(2 * l + 1) * D], kv_all[:, :, (2 * l + 1) * D:(2 * l + 2) * D]
+                else:
+                    k2 = ops.gemm_nt(enc.view(B * S, D), ck, bias=cbk).view(B, S, D)
+                    v2 = ops.gemm_nt(enc.view(B * S, D), cv, bias=cbv).view(B, S, D)
                 ctx2, lse2 = ops.attention(q2, k2, v2, nh, scale, kpm=enc_mask, need_lse=save, drop=(pa, seed, _site(l, 2), 0))
                 a2 = out_proj(ctx2.view(R, D), co, cbo, h1, _site(l, 3))
                 h2, s2 = ops.layernorm(a2, st.f32(lp + "crossattention.output.LayerNorm.weight"), st.f32(lp + "crossattention.output.LayerNorm.bias"),
@@ -320,6 +354,11 @@ class BertEngine:
             denc = torch.zeros((enc.shape[0] * enc.shape[1], D), dtype=torch.float32, device=dh.device)
         scale = cfg.head_dim ** -0.5
         ph, pa, seed = saved.get("ph", 0.0), saved.get("pa", 0.0), saved.get("seed")
+        dkv_all = None
+        if saved.get("kv_all") and enc is not None:
+            # dK / dV of every layer's cross-attention land in ONE [B*S, layers*2*d] matrix: one GEMM each for d(enc) and for the weight gradients
+            dkv_all = torch.empty((enc.shape[0], enc.shape[1], 2 * cfg.num_hidden_layers * D), dtype=BF16, device=dh.device)
+            denc = None
 
         def dspec(site):
             """second LayerNorm-backward output = the forward dropout mask of `site` re-applied to dx (None in eval mode)"""
@@ -347,14 +386,20 @@ class BertEngine:
                 da2, dd2 = da2 if ph else (da2, da2)
                 self._wgrad(lp + "crossattention.output.dense", dd2, sv["ctx2"].view(R, D))
                 dctx2 = ops.gemm_nt(dd2, self._wt(lp + "crossattention.output.dense")).view(B, T, D)
-                dq2, dk2, dv2 = ops.attention_bwd(sv["q2"], sv["k2"], sv["v2"], sv["ctx2"], dctx2, sv["lse2"], nh, scale, kpm=saved["enc_mask"],
-                                                  drop=(pa, seed, _site(l, 2), 0))
-                self._wgrad(lp + "crossattention.self.query", dq2.view(R, D), sv["h1"])
-                self._wgrad(lp + "crossattention.self.key", dk2.view(B * S, D), enc.view(B * S, D))
-                self._wgrad(lp + "crossattention.self.value", dv2.view(B * S, D), enc.view(B * S, D))
-                if denc is not None:
-                    ops.gemm_nt(dk2.view(B * S, D), self._wt(lp + "crossattention.self.key"), out=denc, out_f32=True, accumulate=True)
-                    ops.gemm_nt(dv2.view(B * S, D), self._wt(lp + "crossattention.self.value"), out=denc, out_f32=True, accumulate=True)
+                if dkv_all is not None:
+                    dq2, _, _ = ops.attention_bwd(sv["q2"], sv["k2"], sv["v2"], sv["ctx2"], dctx2, sv["lse2"], nh, scale, kpm=saved["enc_mask"],
+                                                  drop=(pa, seed, _site(l, 2), 0), dk_out=dkv_all[:, :, 2 * l * D:(2 * l + 1) * D],
+                                                  dv_out=dkv_all[:, :, (2 * l + 1) * D:(2 * l + 2) * D])
+                    self._wgrad(lp + "crossattention.self.query", dq2.view(R, D), sv["h1"])
+                else:
+                    dq2, dk2, dv2 = ops.attention_bwd(sv["q2"], sv["k2"], sv["v2"], sv["ctx2"], dctx2, sv["lse2"], nh, scale, kpm=saved["enc_mask"],
+                                                      drop=(pa, seed, _site(l, 2), 0))
+                    self._wgrad(lp + "crossattention.self.query", dq2.view(R, D), sv["h1"])
+                    self._wgrad(lp + "crossattention.self.key", dk2.view(B * S, D), enc.view(B * S, D))
+                    self._wgrad(lp + "crossattention.self.value", dv2.view(B * S, D), enc.view(B * S, D))
+                    if denc is not None:
+                        ops.gemm_nt(dk2.view(B * S, D), self._wt(lp + "crossattention.self.key"), out=denc, out_f32=True, accumulate=True)
+                        ops.gemm_nt(dv2.view(B * S, D), self._wt(lp + "crossattention.self.value"), out=denc, out_f32=True, accumulate=True)
                 dh1 = ops.gemm_nt(dq2.view(R, D), self._wt(lp + "crossattention.self.query"), residual=da2)
             else:
                 dh1 = dh2
@@ -384,6 +429,12 @@ class BertEngine:
         dsum = ops.layernorm_bwd(saved["esum"], dh, st.f32(e + "LayerNorm.weight"), saved["estats"], g(e + "LayerNorm.weight"), g(e + "LayerNorm.bias"))
         ops.bert_embed_bwd(dsum, saved["ids"], saved["tt"], saved["pos"], g(e + "word_embeddings.weight"), g(e + "token_type_embeddings.weight"),
                            g(e + "position_embeddings.weight"), T, 0, cfg.pad_token_id)
+        if dkv_all is not None:
+            kva = self._cross_kv_all()
+            BS = enc.shape[0] * enc.shape[1]
+            d2 = dkv_all.view(BS, -1)
+            ops.linear_bwd_weight(d2, enc.reshape(BS, D), st.span(kva[2], "grad").view(d2.shape[1], D), st.span(kva[3], "grad"))
+            return ops.gemm_nt(d2, self._prep[("wt", "cross_kv_all")]).view(enc.shape) if need_denc else None
         if denc is not None:
             return ops.cast_to_bf16(denc).view(enc.shape)
         return None

@@ -22,9 +22,14 @@ def _p(t):
 _DEV_INDEX = None
 
 
+_SIDE_RAW = None        # raw handle of the weight-gradient stream while a _side_launch block is open (see below)
+
+
 def _s():
     """Raw hipStream_t of torch's current stream (fast path: no Stream object, no device queries -- this runs ~1500x per step)."""
     global _DEV_INDEX
+    if _SIDE_RAW is not None:
+        return _SIDE_RAW
     if _DEV_INDEX is None:
         _DEV_INDEX = torch.cuda.current_device()
     return torch._C._cuda_getCurrentRawStream(_DEV_INDEX)
@@ -158,11 +163,12 @@ def gemm_tn(p, q, out, dbias=None, alpha=1.0):
     assert R == R2 and out.dtype == torch.float32 and out.shape == (I, J) and out.stride(1) == 1
     prof = GEMM_PROFILE
     if prof is not None:
+        pstream = WGRAD_STREAM if _SIDE_RAW is not None else None           # the stream the kernel is launched on
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record(pstream)
     LIB.call("cxr_gemm_tn_bf16", _p(p), p.stride(0), _p(q), q.stride(0), _p(out), out.stride(0), _p(dbias), R, I, J, float(alpha), _s())
     if prof is not None:
-        e1.record()
+        e1.record(pstream)
         prof.append((2.0 * R * I * J, e0, e1, ("tn", I, J, R), 2.0 * R * (I + J) + 4.0 * I * J))
     return out
 
@@ -195,14 +201,43 @@ class _on_wgrad_stream:
         return False
 
 
+class _side_launch:
+    """Light variant of _on_wgrad_stream for blocks that only issue C-ABI launches and allocate nothing: the launches get the side stream's raw
+    handle (no torch stream switch), ordering is one event record + wait, and the operands are kept alive until the next wgrad_join() instead
+    of record_stream (after the join nothing on the side stream can still read them). The torch context manager cost ~25 us of host time per
+    weight-gradient launch -- 250 of them per step, in the backward pass where the GPU waits for the host."""
+    _pending = []
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+
+    def __enter__(self):
+        global _SIDE_RAW
+        self.side = WGRAD_STREAM
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record()                                    # main stream position: the operands are complete
+            self.side.wait_event(ev)
+            _SIDE_RAW = self.side.cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        global _SIDE_RAW
+        if self.side is not None:
+            _SIDE_RAW = None
+            _side_launch._pending.append(self.tensors)
+        return False
+
+
 def wgrad_join():
     if WGRAD_STREAM is not None:
         torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+    _side_launch._pending.clear()
 
 
 def linear_bwd_weight(dy, x, dw, db=None):
     """dw[N,K] += dy[M,N]^T @ x[M,K]; db[N] += colsum(dy)   (one split-K TN kernel; no transposes)."""
-    with _on_wgrad_stream(dy, x):
+    with _side_launch(dy, x, dw, db):
         gemm_tn(dy, x, dw, dbias=db)
 
 
@@ -240,21 +275,25 @@ def _drop_args(drop):
     return float(p), _p(seed), int(site), int(t0)
 
 
-def attention_bwd(q, k, v, o, do, lse, heads, scale, kpm=None, causal=False, causal_shift=None, drop=None):
+def attention_bwd(q, k, v, o, do, lse, heads, scale, kpm=None, causal=False, causal_shift=None, drop=None, dk_out=None, dv_out=None):
+    """dk_out / dv_out: optional pre-allocated [B,Tk,D] views with EQUAL (batch, row) strides (column slices of one wider matrix)."""
     B, Tq, D = q.shape
     Tk = k.shape[1]
     dq = torch.empty((B, Tq, D), device=q.device, dtype=BF16)
-    dk = torch.empty((B, Tk, D), device=q.device, dtype=BF16)
-    dv = torch.empty((B, Tk, D), device=q.device, dtype=BF16)
+    dk = dk_out if dk_out is not None else torch.empty((B, Tk, D), device=q.device, dtype=BF16)
+    dv = dv_out if dv_out is not None else torch.empty((B, Tk, D), device=q.device, dtype=BF16)
+    assert dk.shape == (B, Tk, D) and dv.shape == (B, Tk, D) and dk.stride() == dv.stride() and dk.stride(2) == 1 and dk.dtype == BF16 and dv.dtype == BF16
     delta = torch.empty((B, heads, Tq), device=q.device, dtype=torch.float32)
     for t in (q, k, v, o, do):
         assert t.dtype == BF16 and t.stride(2) == 1
     if causal_shift is None:
         causal_shift = Tk - Tq
     do = do if do.stride() == o.stride() else do.contiguous()
+    strided = not dk.is_contiguous()
     LIB.call("cxr_attn_bwd_bf16", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(kpm),
              q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), o.stride(0), o.stride(1),
-             kpm.stride(0) if kpm is not None else 0, B, heads, Tq, Tk, float(scale), int(causal), int(causal_shift), *_drop_args(drop), _s())
+             kpm.stride(0) if kpm is not None else 0, B, heads, Tq, Tk, float(scale), int(causal), int(causal_shift), *_drop_args(drop),
+             dk.stride(0) if strided else 0, dk.stride(1) if strided else 0, _s())
     return dq, dk, dv
 
 
@@ -311,7 +350,7 @@ def layernorm_bwd(x, dy, gamma, stats, dgamma, dbeta, add=None, out=None, drop=N
              int(drop[2]) if drop is not None else 0, int(drop[3]) if drop is not None else (int(row_scale[1]) if row_scale is not None else 1),
              int(drop[4]) if drop is not None else 0, _p(row_scale[0]) if row_scale is not None else None, _s())
     if side:
-        with _on_wgrad_stream(ws):
+        with _side_launch(ws, dgamma, dbeta):
             LIB.call("cxr_layernorm_bwd_reduce", _p(ws), rows, C, _p(dgamma), _p(dbeta), _s())
     return (out, out2) if second else out
 

@@ -164,6 +164,20 @@ class ParamStore(nn.Module):
             self.ensure_grads()
         return self._viewsg[k]
 
+    def span(self, keys, kind="w16"):
+        """One flat view over several parameters that lie back to back in storage order (kind: 'f32' master, 'w16' bf16 shadow, 'grad'), or
+        None when they do not."""
+        off = self._offsets[keys[0]]
+        end = off
+        for k in keys:
+            if self._offsets.get(k) != end:
+                return None
+            end += self._numel(k)
+        if kind == "grad" and self.gflat is None:
+            self.ensure_grads()
+        flat = {"f32": self.flat32, "w16": self.flat16, "grad": self.gflat}[kind]
+        return flat[off:end]
+
     def param(self, k) -> nn.Parameter:
         return self._params[self._aliases.get(k, k)]
 

@@ -75,7 +75,7 @@ def _lin(out, base, n, k, lora_r=0):
         out[base + ".bias"] = (n,)
 
 
-def bert_param_shapes(cfg: BertConfig, prefix: str = "decoder.") -> "OrderedDict[str, Tuple[int, ...]]":
+def bert_param_shapes(cfg: BertConfig, prefix: str = "decoder.", storage_order: bool = True) -> "OrderedDict[str, Tuple[int, ...]]":
     """BertLMHeadModel (decoder) or the CXR-BERT stand-in (cls_projection_size > 0, no LM head)."""
     out: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     p = prefix + ("base_model.model." if cfg.lora_r else "")
@@ -118,7 +118,22 @@ def bert_param_shapes(cfg: BertConfig, prefix: str = "decoder.") -> "OrderedDict
         # tied copies present in HF state dicts (TF5 models/bert/modeling_bert.py:778-781):
         out[c + "decoder.weight"] = (cfg.vocab_size, d)
         out[c + "decoder.bias"] = (cfg.vocab_size,)
+    if cfg.add_cross_attention and storage_order:       # (random initialisation iterates the HF order: storage_order=False)
+        # storage order only (names are unchanged): the cross-attention key / value projections of ALL layers sit back to back -- K0 V0 K1 V1 ...,
+        # weights then biases -- so that the flat parameter / shadow / gradient buffers expose them as ONE [layers*2*d, d] matrix: every layer
+        # projects the same encoder output, which makes them one GEMM forward, one for the encoder-output gradient and one for the weight gradient
+        front = cross_kv_keys(cfg, prefix, ".weight") + cross_kv_keys(cfg, prefix, ".bias")
+        re = OrderedDict((k, out[k]) for k in front)
+        for k, v in out.items():
+            if k not in re:
+                re[k] = v
+        out = re
     return out
+
+
+def cross_kv_keys(cfg: BertConfig, prefix: str = "decoder.", suffix: str = ".weight"):
+    p = prefix + ("base_model.model." if cfg.lora_r else "")
+    return [p + f"bert.encoder.layer.{l}.crossattention.self.{n}{suffix}" for l in range(cfg.num_hidden_layers) for n in ("key", "value")]
 
 
 def tied_aliases(cfg: BertConfig, prefix: str = "decoder.") -> Dict[str, str]:
@@ -132,9 +147,9 @@ def tied_aliases(cfg: BertConfig, prefix: str = "decoder.") -> Dict[str, str]:
     }
 
 
-def encoder_decoder_param_shapes(cfg: EncoderDecoderConfig):
+def encoder_decoder_param_shapes(cfg: EncoderDecoderConfig, storage_order: bool = True):
     out = cvt_param_shapes(cfg.encoder)
-    out.update(bert_param_shapes(cfg.decoder))
+    out.update(bert_param_shapes(cfg.decoder, storage_order=storage_order))
     return out
 
 
@@ -193,7 +208,7 @@ def init_state_dict(shapes, seed: int = 0, std: float = 0.02, perturb: float = 0
 
 
 def init_encoder_decoder(cfg: EncoderDecoderConfig, seed: int = 0, perturb: float = 0.0):
-    shapes = encoder_decoder_param_shapes(cfg)
+    shapes = encoder_decoder_param_shapes(cfg, storage_order=False)
     aliases = tied_aliases(cfg.decoder)
     p = "decoder." + ("base_model.model." if cfg.decoder.lora_r else "")
     return init_state_dict(shapes, seed=seed, std=cfg.decoder.initializer_range, perturb=perturb, aliases=aliases,
@@ -201,6 +216,6 @@ def init_encoder_decoder(cfg: EncoderDecoderConfig, seed: int = 0, perturb: floa
 
 
 def init_reward(cfg: BertConfig, seed: int = 1, perturb: float = 0.0):
-    shapes = bert_param_shapes(cfg, prefix="")
+    shapes = bert_param_shapes(cfg, prefix="", storage_order=False)
     return init_state_dict(shapes, seed=seed, std=cfg.initializer_range, perturb=perturb,
                            pad_row_zero=["bert.embeddings.word_embeddings.weight"])

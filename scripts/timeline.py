@@ -27,3 +27,15 @@ for q, lst in sorted(byq.items(), key=lambda kv: -len(kv[1])):
     for r in lst: agg[r['Kernel_Name'][:48]] += r['e'] - r['s']; cnt[r['Kernel_Name'][:48]] += 1
     print('--- queue', q)
     for k, v in agg.most_common(12): print(f"  {k:50s} {cnt[k]:5d} {v/1e6:8.3f} ms  avg {v/cnt[k]/1e3:7.1f} us")
+# main-queue idle gaps (the queue with the most kernels): how long the critical stream waited, and for what
+main = max(byq.items(), key=lambda kv: len(kv[1]))[1]
+gaps = []
+for a, b in zip(main, main[1:]):
+    if b['s'] > a['e']:
+        gaps.append((b['s'] - a['e'], a['Kernel_Name'][:40], b['Kernel_Name'][:40]))
+tot = sum(g[0] for g in gaps)
+print(f"main-queue gaps: {len(gaps)} totalling {tot/1e6:.3f} ms; >20us: {sum(1 for g in gaps if g[0] > 20000)} totalling {sum(g[0] for g in gaps if g[0] > 20000)/1e6:.3f} ms")
+for g in sorted(gaps, reverse=True)[:12]:
+    print(f"   {g[0]/1e3:8.1f} us after {g[1]:40s} before {g[2]}")
+hist = collections.Counter(min(int(g[0] / 1000), 20) for g in gaps)
+print("gap histogram (us: count):", dict(sorted(hist.items())))

@@ -74,7 +74,13 @@ def test_param_store_layout_and_reference_key_names():
     for p in m.decoder.parameters():
         p.requires_grad_(True)
     (lo, hi), = m.trainable_ranges()                    # whole decoder = ONE contiguous range (fused AdamW / one all-reduce bucket run)
-    assert lo == m._offsets["decoder.base_model.model.bert.embeddings.word_embeddings.weight"] and hi == m._param_total
+    first = "decoder.base_model.model.bert.encoder.layer.0.crossattention.self.key.weight"     # cross-attention K / V of all layers lead the decoder block
+    assert lo == m._offsets[first] == min(o for k, o in m._offsets.items() if k.startswith("decoder.")) and hi == m._param_total
+    # ... stored back to back (K0 V0 K1 V1, weights then biases): one [layers*2*d, d] matrix for the fused projection / gradient GEMMs
+    kv = weights.cross_kv_keys(cfg.decoder, "decoder.", ".weight")
+    assert m.span(kv, "w16").numel() == 2 * 2 * 768 * 768 and m.span(kv, "f32").data_ptr() == m.f32(kv[0]).data_ptr()
+    assert m.span(weights.cross_kv_keys(cfg.decoder, "decoder.", ".bias"), "f32").numel() == 2 * 2 * 768
+    assert m.span([kv[0], kv[2]], "w16") is None                                               # not adjacent -> no span
 
 
 def test_tokenizer_helpers_match_reference_fixtures():

@@ -596,6 +596,20 @@ def test_gemm_nt_group_equals_single_launches(ops, Ms, N, K):
         close(o, a.float() @ w.float().t() + (b if b is not None else 0), what="grouped gemm")
 
 
+def test_attention_bwd_strided_dkdv_outputs(ops):
+    """dK / dV written as column slices of one wider matrix (the decoder's fused cross-attention gradient buffer) == the contiguous outputs."""
+    B, Tq, Tk, H = 2, 70, 150, 3
+    D = H * 64
+    q, k, v = (dev(rnd(B, T, D, seed=i).to(BF)) for i, T in enumerate((Tq, Tk, Tk)))
+    o, lse = ops.attention(q, k, v, H, 0.125, need_lse=True)
+    do = dev(rnd(B, Tq, D, seed=5).to(BF))
+    dq0, dk0, dv0 = ops.attention_bwd(q, k, v, o, do, lse, H, 0.125)
+    wide = torch.zeros(B, Tk, 5 * D, device="cuda", dtype=BF)
+    dq1, dk1, dv1 = ops.attention_bwd(q, k, v, o, do, lse, H, 0.125, dk_out=wide[:, :, D:2 * D], dv_out=wide[:, :, 3 * D:4 * D])
+    assert torch.equal(dq0, dq1) and torch.equal(dk0, wide[:, :, D:2 * D]) and torch.equal(dv0, wide[:, :, 3 * D:4 * D])
+    assert float(wide[:, :, :D].abs().max()) == 0 and float(wide[:, :, 2 * D:3 * D].abs().max()) == 0 and float(wide[:, :, 4 * D:].abs().max()) == 0
+
+
 DWPROJ_SHAPES = [(3, 64, 24, 24, 0), (3, 192, 12, 12, 0), (3, 384, 6, 6, 1), (2, 64, 7, 5, 1), (2, 128, 9, 20, 0), (32, 384, 24, 24, 1), (8, 64, 96, 96, 0)]
 
 
