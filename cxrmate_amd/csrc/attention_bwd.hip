@@ -8,8 +8,8 @@
 #include "common.h"
 
 struct AttnBwdArgs {
-    const bf16_t* Q; const bf16_t* K; const bf16_t* V; const bf16_t* dO;
-    const float* LSE; const float* delta;
+    const bf16_t* Q; const bf16_t* K; const bf16_t* V; const bf16_t* dO; const bf16_t* O;
+    const float* LSE; float* delta;          // delta[B,H,Tq] = rowsum(dO*O): written by the dQ kernel, read by the dK/dV kernel
     bf16_t* dQ; bf16_t* dK; bf16_t* dV;
     const unsigned char* kpm;
     long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, kpm_bs;
@@ -38,27 +38,7 @@ __device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& x, int s) {
     return __builtin_bit_cast(bf16x8_t, pv);
 }
 
-// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, long o_bs, long o_rs,
-                                                         float* __restrict__ delta, int B, int H, int Tq) {
-    const long total = (long)B * H * Tq * 8;             // 8 lanes per (b,h,q): 8 elements each
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    float s = 0.f;
-    long bhq = idx >> 3;
-    if (idx < total) {
-        const int c = (int)(idx & 7);
-        const int q = (int)(bhq % Tq), h = (int)((bhq / Tq) % H), b = (int)(bhq / ((long)Tq * H));
-        const long off = (long)b * o_bs + (long)q * o_rs + h * 64 + c * 8;
-        float x[8], y[8];
-        unpack8(*reinterpret_cast<const uint4*>(O + off), x);
-        unpack8(*reinterpret_cast<const uint4*>(dO + off), y);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += x[j] * y[j];
-    }
-    s = group_sum<8>(s);
-    if (idx < total && (idx & 7) == 0) delta[bhq] = s;   // delta laid out [B,H,Tq]: bhq = (b*H + h)*Tq + q
-}
-
+// (delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d] is produced by attn_bwd_dq_kernel, which runs first)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t Qr[64 * RS];
     __shared__ __attribute__((aligned(16))) bf16_t Qt[64 * TS];
@@ -248,7 +228,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
         for (int s = 0; s < 4; ++s) { qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + s * 16); dof[s] = *reinterpret_cast<const bf16x8_t*>(dp + s * 16); }
     }
     const float lse2 = a.LSE[((long)b * a.H + head) * a.Tq + qc] * 1.4426950408889634f;
-    const float dl = a.delta[((long)b * a.H + head) * a.Tq + qc];
+    // delta = rowsum(dO * O) of this lane's query row: the lane pair (hh = 0 / 1) holds the row's 64 dO values between them, O is read the same
+    // way. Computed here instead of a separate pass over O and dO (33 launches per training step), and left in a.delta for the dK/dV kernel.
+    float dl;
+    {
+        const bf16_t* op = a.O + (long)b * a.o_bs + (long)qc * a.o_rs + head * 64 + hh * 8;
+        float part = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float ov[8], dv[8];
+            unpack8(*reinterpret_cast<const uint4*>(op + s * 16), ov);
+            unpack8(__builtin_bit_cast(uint4, dof[s]), dv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part = fmaf(ov[j], dv[j], part);
+        }
+        dl = part + __shfl_xor(part, 32, 64);
+        if (hh == 0 && qrow < a.Tq) a.delta[((long)b * a.H + head) * a.Tq + qrow] = dl;
+    }
     const uint32_t drop_key = a.drop_thr16 ? dropout_row_key(*a.drop_seed, a.drop_site, (uint32_t)(b * a.H + head), (uint32_t)(qrow + a.drop_t0)) : 0u;
 
     int ntiles = (a.Tk + 63) >> 6;
@@ -367,12 +363,12 @@ extern "C" int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, co
                                  long o_bs, long o_rs, long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal, int causal_shift,
                                  float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t0, long dkv_bs, long dkv_rs,
                                  hipStream_t stream) {
-    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || !LSE || !delta) return CXR_ERR_ARG;
+    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || !LSE || !delta || !O) return CXR_ERR_ARG;
     if ((dkv_rs % 8) || (dkv_bs % 8) || ((dkv_rs != 0) != (dkv_bs != 0)) || (dkv_rs && ((((size_t)dK) % 16) || (((size_t)dV) % 16)))) return CXR_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return CXR_ERR_ARG;
     if ((q_rs % 8) || (k_rs % 8) || (v_rs % 8) || (o_rs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 8)) return CXR_ERR_ARG;
     AttnBwdArgs a;
-    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.dO = (const bf16_t*)dO; a.LSE = LSE; a.delta = delta;
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.dO = (const bf16_t*)dO; a.O = (const bf16_t*)O; a.LSE = LSE; a.delta = delta;
     a.dQ = (bf16_t*)dQ; a.dK = (bf16_t*)dK; a.dV = (bf16_t*)dV; a.kpm = (const unsigned char*)kpm;
     a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_rs = o_rs; a.kpm_bs = kpm_bs;
     a.dq_rs = (long)H * 64; a.dq_bs = (long)Tq * H * 64; a.dk_rs = dkv_rs ? dkv_rs : (long)H * 64; a.dk_bs = dkv_rs ? dkv_bs : (long)Tk * H * 64;
@@ -380,10 +376,8 @@ extern "C" int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, co
     a.causal = causal; a.causal_shift = causal_shift;
     a.drop_seed = drop_seed; a.drop_site = drop_site; a.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u;
     a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_t0 = drop_t0;
-    const long nd = (long)B * H * Tq * 8;
-    CXR_LAUNCH(attn_delta_kernel, dim3(cdiv(nd, 256)), dim3(256), 0, stream, (const bf16_t*)O, (const bf16_t*)dO, o_bs, o_rs, delta, B, H, Tq);
+    CXR_LAUNCH(attn_bwd_dq_kernel, dim3(cdiv(Tq, 128), H, B), dim3(256), 0, stream, a);          // also writes delta = rowsum(dO * O)
     CXR_LAUNCH(attn_bwd_dkdv_kernel, dim3(cdiv(Tk, 128), H, B), dim3(256), 0, stream, a);
-    CXR_LAUNCH(attn_bwd_dq_kernel, dim3(cdiv(Tq, 128), H, B), dim3(256), 0, stream, a);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
