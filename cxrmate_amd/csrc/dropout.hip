@@ -77,3 +77,21 @@ extern "C" int cxr_dropout_mask(unsigned char* mask, float* factor, long R, int 
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
+
+// DropPath factors of `nsites` consecutive sites in one launch: factor[s][b] = keep(seed, site0 + s, sequence b, position 0, column 0) / (1 - p)
+// -- exactly what cxr_dropout_mask(R = Bn, C = 1, rows_per_b = 1, site = site0 + s) writes, for all layers of a CvT stage at once.
+__global__ __launch_bounds__(256) void dropout_site_factors_kernel(float* __restrict__ factor, int nsites, int Bn, uint32_t thr16, float inv_keep,
+                                                                   const uint32_t* __restrict__ seed_ptr, uint32_t site0) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nsites * Bn) return;
+    const int s = idx / Bn, b = idx - s * Bn;
+    factor[idx] = dropout_keep(dropout_row_key(*seed_ptr, site0 + (uint32_t)s, (uint32_t)b, 0u), 0u, thr16) ? inv_keep : 0.f;
+}
+
+extern "C" int cxr_dropout_site_factors(float* factor, int nsites, int Bn, float p, const unsigned int* seed, unsigned int site0, hipStream_t stream) {
+    if (!factor || nsites <= 0 || Bn <= 0 || p < 0.f || p >= 1.f || !seed) return CXR_ERR_ARG;
+    CXR_LAUNCH(dropout_site_factors_kernel, dim3(cdiv(nsites * Bn, 256)), dim3(256), 0, stream, factor, nsites, Bn, dropout_thr16(p), 1.0f / (1.0f - p),
+               seed, site0);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}

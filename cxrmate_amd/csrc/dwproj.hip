@@ -699,3 +699,26 @@ extern "C" int cxr_dwproj_dx_bf16(void* dx, long dx_bs, long dx_rs, int Bn, int 
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
+
+// Raw depthwise taps of many projections from the parameter layout [C, 9] to the conv layout [9, C] the kernels above read, in one launch
+// (63 projections per CvT-21; re-run once per weight version). table (device) int64 [n][4] = {src, dst, C, first_block}; one workgroup per
+// 256 consecutive elements of a destination.
+__global__ __launch_bounds__(256) void dw3_taps_layout_kernel(const long* __restrict__ table, int n) {
+    int e = 0;
+    while (e + 1 < n && (long)blockIdx.x >= table[(e + 1) * 4 + 3]) ++e;
+    const float* src = reinterpret_cast<const float*>(table[e * 4 + 0]);
+    float* dst = reinterpret_cast<float*>(table[e * 4 + 1]);
+    const int C = (int)table[e * 4 + 2];
+    const int i = ((int)blockIdx.x - (int)table[e * 4 + 3]) * 256 + threadIdx.x;      // destination index t*C + c
+    if (i < 9 * C) {
+        const int t = i / C, c = i - t * C;
+        dst[i] = src[c * 9 + t];
+    }
+}
+
+extern "C" int cxr_dwproj_taps_layout(const long* table, int n, int total_blocks, hipStream_t stream) {
+    if (!table || n <= 0 || total_blocks <= 0) return CXR_ERR_ARG;
+    CXR_LAUNCH(dw3_taps_layout_kernel, dim3(total_blocks), dim3(256), 0, stream, table, n);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}

@@ -27,6 +27,8 @@ class CvtEncoderEngine:
         self._wt_ready = False
         self._bn_version = 0                        # bumped whenever a train-mode forward moves the running statistics
         self._fold_cache = {}
+        self._taps, self._taps_version, self._taps_index = None, -1, {}
+        self._dp_rate, self._dp_factors = {}, {}
         self._fused_proj = os.environ.get("CXR_DWPROJ", "1") != "0"      # A/B switch: 0 = per-projection kernels of conv.hip
         self._embed_buf = {}                        # persistent conv-as-GEMM weight re-layouts (their addresses feed the batched transpose table)
         self._bt, self._bt_sig, self._bt_keys = None, None, None
@@ -78,13 +80,19 @@ class CvtEncoderEngine:
         return hit[1]
 
     def _raw_taps(self, s, l, name):
-        """Raw depthwise taps as [9, C] fp32 (the layout the conv kernels read); layout plumbing, cached per weight version."""
-        key = ("raw", s, l, name)
-        hit = self._fold_cache.get(key)
-        if hit is None:
-            w = self.s.f32(self._conv_prefix(s, l, name) + "convolution.weight")
-            hit = self._fold_cache[key] = w.view(w.shape[0], 9).t().contiguous()
-        return hit
+        """Raw depthwise taps as [9, C] fp32 (the layout the conv kernels read): persistent copies of the [C,1,3,3] parameters, all 3 x 21
+        projections refreshed by ONE launch per weight version (layout plumbing)."""
+        st = self.s
+        if self._taps is None or self._taps_version != st.shadow_version:
+            names = [(s_, l_, n_) for s_ in range(len(self.cfg.depth)) for l_ in range(self.cfg.depth[s_]) for n_ in ("query", "key", "value")]
+            srcs = [st.f32(self._conv_prefix(*k) + "convolution.weight") for k in names]
+            srcs = [w.view(w.shape[0], 9) for w in srcs]
+            if self._taps is None or self._taps.sig != tuple(w.data_ptr() for w in srcs):       # first use, or the store was re-packed
+                self._taps = ops.TapsLayout(srcs)
+                self._taps_index = {k: i for i, k in enumerate(names)}
+            self._taps.run()
+            self._taps_version = st.shadow_version
+        return self._taps.outs[self._taps_index[(s, l, name)]]
 
     def _dwproj_params(self, s, l):
         """Static half of the cxr_dwproj descriptors of layer (s, l): raw taps in conv layout + the BatchNorm parameters (views of the flat store)."""
@@ -156,6 +164,7 @@ class CvtEncoderEngine:
         saved = {"Bn": Bn, "stages": [], "train": train} if save else None
         self._train = train
         self._seed = None
+        self._dp_factors = {}
         if train:
             self._bn_version += 1
             st.num_batches_tracked.add_(1)
@@ -208,20 +217,30 @@ class CvtEncoderEngine:
     def _drop_path_rate(self, s):
         """TF5 modeling_cvt.py:404-422: every layer of stage s gets linspace(0, drop_path_rate[s], depth[s])[s] -- indexed by the STAGE
         (quirk Q2; CvT-21: 0, 0, 0.1 * 2/15)."""
+        hit = self._dp_rate.get(s)
+        if hit is not None:
+            return hit
         rate, depth = self.cfg.drop_path_rate[s], self.cfg.depth[s]
         if rate <= 0.0:
-            return 0.0
-        if depth <= s:
-            raise IndexError("list index out of range")          # what the reference raises for such a depth (quirk Q2)
-        return float(torch.linspace(0, rate, depth)[s])
+            hit = 0.0
+        else:
+            if depth <= s:
+                raise IndexError("list index out of range")          # what the reference raises for such a depth (quirk Q2)
+            hit = float(torch.linspace(0, rate, depth)[s])
+        self._dp_rate[s] = hit
+        return hit
 
     def _drop_path_scales(self, s, l, Bn):
-        """Per-image factors (0 or 1/keep_prob) of the two DropPath calls of a layer, or (None, None)."""
+        """Per-image factors (0 or 1/keep_prob) of the two DropPath calls of a layer, or (None, None). Sites 1000 + 2*(global layer) + {0, 1}; the
+        factors of all layers of a stage come from one launch per forward (every layer of a stage has the same rate, quirk Q2)."""
         rate = self._drop_path_rate(s) if self._train else 0.0
         if rate <= 0.0:
             return None, None
-        gl = sum(self.cfg.depth[:s]) + l
-        return tuple(ops.dropout_mask(Bn, 1, rate, self._seed, 1000 + 2 * gl + j, 1, factor=True).view(Bn) for j in (0, 1))
+        f = self._dp_factors.get(s)
+        if f is None:
+            gl0 = sum(self.cfg.depth[:s])
+            f = self._dp_factors[s] = ops.dropout_site_factors(2 * self.cfg.depth[s], Bn, rate, self._seed, 1000 + 2 * gl0)
+        return f[2 * l], f[2 * l + 1]
 
     def _layer_fwd(self, x, s, l, H, W, tok0, prep, save):
         cfg, st = self.cfg, self.s

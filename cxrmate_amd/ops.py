@@ -318,6 +318,35 @@ def dropout_mask(R, C, p, seed, site, rows_per_b, t0=0, factor=False):
     return out
 
 
+def dropout_site_factors(nsites, Bn, p, seed, site0):
+    """DropPath factors [nsites, Bn] fp32 of the consecutive sites site0 .. site0 + nsites - 1 (one launch)."""
+    out = torch.empty((nsites, Bn), device=seed.device, dtype=torch.float32)
+    LIB.call("cxr_dropout_site_factors", _p(out), int(nsites), int(Bn), float(p), _p(seed), int(site0), _s())
+    return out
+
+
+class TapsLayout:
+    """Raw depthwise taps [C,9] (views of the fp32 parameter buffer) -> persistent [9,C] copies, all projections in ONE launch per weight version."""
+
+    def __init__(self, sources):
+        rows, blocks = [], 0
+        self.outs = []
+        for w in sources:
+            C = w.shape[0]
+            assert w.dtype == torch.float32 and w.is_contiguous() and w.numel() == 9 * C
+            out = torch.empty((9, C), device=w.device, dtype=torch.float32)
+            rows.append([w.data_ptr(), out.data_ptr(), C, blocks])
+            blocks += (9 * C + 255) // 256
+            self.outs.append(out)
+        self.sources, self.blocks = list(sources), blocks
+        self.sig = tuple(w.data_ptr() for w in sources)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(sources[0].device)
+
+    def run(self):
+        LIB.call("cxr_dwproj_taps_layout", _p(self.table), len(self.outs), self.blocks, _s())
+        return self.outs
+
+
 # ------------------------------------------------------------------------------------------------ normalisation
 def layernorm(x, gamma, beta, eps, need_stats=False, out=None):
     """x [rows, C] bf16 (row stride free) -> y, stats[rows,2] | None"""

@@ -76,6 +76,8 @@ int cxr_dropout_add_bf16(const void* y, long ldy, const void* resid, long ldr, v
                          const unsigned int* seed, unsigned int site, int rows_per_b, int t0, const float* row_scale, hipStream_t stream);
 int cxr_dropout_mask(unsigned char* mask, float* factor, long R, int C, float p, const unsigned int* seed, unsigned int site, int rows_per_b,
                      int t0, hipStream_t stream);
+int cxr_dropout_site_factors(float* factor, int nsites, int Bn, float p, const unsigned int* seed, unsigned int site0, hipStream_t stream);
+                                   /* factor[s][b] = DropPath factor of site site0 + s for image b (= cxr_dropout_mask(R = Bn, C = 1) per site), one launch */
 
 /* ---- LoRA branch with dropout on its input (peft Linear in train mode; REF:modelling_longitudinal.py:163-170: r = 8, alpha = 32,
  * lora_dropout = 0.1 on self-attention query / key):  y = base(x) + s * B(A(dropout(x))). Eval mode merges the branch into the weight; in
@@ -190,6 +192,8 @@ int cxr_dwproj_dc_taps_bf16(const void* x, long x_bs, long x_rs, int Bn, int C, 
                             hipStream_t stream);
 int cxr_dwproj_dx_bf16(void* dx, long dx_bs, long dx_rs, int Bn, int C, int H, int W, int tok0, const cxr_dwproj* projs, int nproj,
                        hipStream_t stream);
+int cxr_dwproj_taps_layout(const long* table, int n, int total_blocks, hipStream_t stream);   /* raw taps [C,9] -> [9,C] for n projections in one launch;
+                                   table (device) int64 [n][4] = {src, dst, C, first_block}, one workgroup per 256 destination elements */
 
 /* ---- BERT embeddings (TF5:bert:70-108) ------------------------------------------------------------------------------------ */
 int cxr_bert_embed_fwd(const long* ids, const long* tt, const long* pid, const void* word, const void* type, const void* posw,
