@@ -356,22 +356,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
     }
 }
 
-// dQ [B,Tq,H*64] is written contiguously; dK / dV [B,Tk,H*64] contiguously (dkv_rs == 0) or with batch / row strides dkv_bs / dkv_rs (the
+// dQ [B,Tq,H*64] and dK / dV [B,Tk,H*64] are written contiguously (dq_rs == 0, dkv_rs == 0) or with batch / row strides (the self-attention
+// gradients of a layer as the three column blocks of one [B*T, 3*D] matrix; the
 // decoder writes the cross-attention dK / dV of all layers into one [B*S, layers*2*D] matrix: one dX and one dW GEMM for all of them).
 extern "C" int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* delta,
                                  void* dQ, void* dK, void* dV, const void* kpm, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
                                  long o_bs, long o_rs, long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal, int causal_shift,
                                  float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t0, long dkv_bs, long dkv_rs,
-                                 hipStream_t stream) {
+                                 long dq_bs, long dq_rs, hipStream_t stream) {
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || !LSE || !delta || !O) return CXR_ERR_ARG;
     if ((dkv_rs % 8) || (dkv_bs % 8) || ((dkv_rs != 0) != (dkv_bs != 0)) || (dkv_rs && ((((size_t)dK) % 16) || (((size_t)dV) % 16)))) return CXR_ERR_ARG;
+    if ((dq_rs % 8) || (dq_bs % 8) || ((dq_rs != 0) != (dq_bs != 0)) || (dq_rs && (((size_t)dQ) % 16))) return CXR_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return CXR_ERR_ARG;
     if ((q_rs % 8) || (k_rs % 8) || (v_rs % 8) || (o_rs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 8)) return CXR_ERR_ARG;
     AttnBwdArgs a;
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.dO = (const bf16_t*)dO; a.O = (const bf16_t*)O; a.LSE = LSE; a.delta = delta;
     a.dQ = (bf16_t*)dQ; a.dK = (bf16_t*)dK; a.dV = (bf16_t*)dV; a.kpm = (const unsigned char*)kpm;
     a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_rs = o_rs; a.kpm_bs = kpm_bs;
-    a.dq_rs = (long)H * 64; a.dq_bs = (long)Tq * H * 64; a.dk_rs = dkv_rs ? dkv_rs : (long)H * 64; a.dk_bs = dkv_rs ? dkv_bs : (long)Tk * H * 64;
+    a.dq_rs = dq_rs ? dq_rs : (long)H * 64; a.dq_bs = dq_rs ? dq_bs : (long)Tq * H * 64; a.dk_rs = dkv_rs ? dkv_rs : (long)H * 64; a.dk_bs = dkv_rs ? dkv_bs : (long)Tk * H * 64;
     a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
     a.causal = causal; a.causal_shift = causal_shift;
     a.drop_seed = drop_seed; a.drop_site = drop_site; a.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u;

@@ -27,6 +27,7 @@ SITE_EMBED = 1
 
 
 _CROSS_KV_FUSED = os.environ.get("CXR_CROSS_KV_FUSED", "1") != "0"      # A/B switch: 0 = one K / V GEMM per layer
+_SELF_QKV_FUSED = os.environ.get("CXR_SELF_QKV_FUSED", "1") != "0"      # A/B switch: 0 = separate query / key / value GEMMs
 
 
 def _site(layer, k):
@@ -67,6 +68,7 @@ class BertEngine:
         self._wt_ready = False
         self._wtb_ready = False
         self._bt, self._bt_last = {}, None
+        self._qkv_cache = {}
 
     # ------------------------------------------------------------------------------------------ parameters
     def _lin(self, base):
@@ -114,6 +116,20 @@ class BertEngine:
         d = cfg.hidden_size
         return w.view(len(wk) * d, d), b, wk, bk
 
+    def _self_qkv(self, l):
+        """(W bf16 [3*d, d], bias fp32 [3*d], weight keys, bias keys) of layer l's self-attention query / key / value as one matrix, or None
+        (LoRA-wrapped projections, parameters not adjacent, CXR_SELF_QKV_FUSED=0)."""
+        cfg, st = self.cfg, self.s
+        if cfg.lora_r or not _SELF_QKV_FUSED:
+            return None
+        hit = self._qkv_cache.get(l)
+        if hit is None or hit[0] is not st.flat16:                    # (re-packed store: new flat buffers)
+            wk, bk = weights.self_qkv_keys(cfg, l, self.p, ".weight"), weights.self_qkv_keys(cfg, l, self.p, ".bias")
+            w, b = (st.span(wk, "w16"), st.span(bk, "f32")) if all(st.has(k) for k in wk + bk) else (None, None)
+            d = cfg.hidden_size
+            hit = self._qkv_cache[l] = (st.flat16, None if w is None or b is None else (w.view(3 * d, d), b, wk, bk))
+        return hit[1]
+
     def _linear_names(self):
         cfg, p = self.cfg, self.p
         names = []
@@ -140,6 +156,10 @@ class BertEngine:
             kv_all = self._cross_kv_all()
             if kv_all is not None:
                 keys.append(("wt", "cross_kv_all")); srcs.append(kv_all[0]); pads.append(1)
+            for l in range(self.cfg.num_hidden_layers):
+                qkv = self._self_qkv(l)
+                if qkv is not None:
+                    keys.append(("wt", ("self_qkv", l))); srcs.append(qkv[0]); pads.append(1)
             if not self.cfg.cls_projection_size:
                 keys.append(("wt", p + "cls.predictions.transform.dense")); srcs.append(st.w16(p + "cls.predictions.transform.dense.weight")); pads.append(1)
                 keys.append(("wt", p + "bert.embeddings.word_embeddings.weight")); srcs.append(st.w16(keys[-1][1])); pads.append(64)
@@ -223,11 +243,20 @@ class BertEngine:
                 k = ops.lora_up_add_(ops.gemm_nt(h, wk, bias=bk), tk, bk_l, True).view(B, T, D)
                 if save:
                     sv.update(tq=tq, tk=tk)
+                v = ops.gemm_nt(h, wv, bias=bv).view(B, T, D)
             else:
-                wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key")
-                q = ops.gemm_nt(h, wq, bias=bq).view(B, T, D)
-                k = ops.gemm_nt(h, wk, bias=bk).view(B, T, D)
-            v = ops.gemm_nt(h, wv, bias=bv).view(B, T, D)
+                qkv_w = self._self_qkv(l)
+                if qkv_w is not None:
+                    # query, key and value of the layer in one GEMM: [R, d] x [d, 3d]; q / k / v are its three column blocks
+                    qkv = ops.gemm_nt(h, qkv_w[0], bias=qkv_w[1]).view(B, T, 3 * D)
+                    q, k, v = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+                    if save:
+                        sv["qkv_fused"] = True
+                else:
+                    wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key")
+                    q = ops.gemm_nt(h, wq, bias=bq).view(B, T, D)
+                    k = ops.gemm_nt(h, wk, bias=bk).view(B, T, D)
+                    v = ops.gemm_nt(h, wv, bias=bv).view(B, T, D)
             ctx, lse = ops.attention(q, k, v, nh, scale, kpm=attn_mask, causal=causal, need_lse=save, drop=(pa, seed, _site(l, 0), 0))
             wo, bo = self._lin(lp + "attention.output.dense")
             a1 = out_proj(ctx.view(R, D), wo, bo, h, _site(l, 1))
@@ -408,6 +437,15 @@ class BertEngine:
             da1, dd1 = da1 if ph else (da1, da1)
             self._wgrad(lp + "attention.output.dense", dd1, sv["ctx"].view(R, D))
             dctx = ops.gemm_nt(dd1, self._wt(lp + "attention.output.dense")).view(B, T, D)
+            if sv.get("qkv_fused"):
+                qkv_w = self._self_qkv(l)
+                dqkv = torch.empty((B, T, 3 * D), dtype=BF16, device=dctx.device)
+                ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, scale, kpm=saved["attn_mask"], causal=saved["causal"],
+                                  drop=(pa, seed, _site(l, 0), 0), dq_out=dqkv[:, :, :D], dk_out=dqkv[:, :, D:2 * D], dv_out=dqkv[:, :, 2 * D:])
+                d2 = dqkv.view(R, 3 * D)
+                ops.linear_bwd_weight(d2, sv["h"], st.span(qkv_w[2], "grad").view(3 * D, D), st.span(qkv_w[3], "grad"))
+                dh = ops.gemm_nt(d2, self._prep[("wt", ("self_qkv", l))], residual=da1)
+                continue
             dq, dk, dv = ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, scale, kpm=saved["attn_mask"],
                                            causal=saved["causal"], drop=(pa, seed, _site(l, 0), 0))
             if lora_tr:

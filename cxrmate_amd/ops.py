@@ -275,25 +275,26 @@ def _drop_args(drop):
     return float(p), _p(seed), int(site), int(t0)
 
 
-def attention_bwd(q, k, v, o, do, lse, heads, scale, kpm=None, causal=False, causal_shift=None, drop=None, dk_out=None, dv_out=None):
-    """dk_out / dv_out: optional pre-allocated [B,Tk,D] views with EQUAL (batch, row) strides (column slices of one wider matrix)."""
+def attention_bwd(q, k, v, o, do, lse, heads, scale, kpm=None, causal=False, causal_shift=None, drop=None, dk_out=None, dv_out=None, dq_out=None):
+    """dq_out / dk_out / dv_out: optional pre-allocated [B,T,D] views (column slices of one wider matrix); dk_out and dv_out must have EQUAL strides."""
     B, Tq, D = q.shape
     Tk = k.shape[1]
-    dq = torch.empty((B, Tq, D), device=q.device, dtype=BF16)
+    dq = dq_out if dq_out is not None else torch.empty((B, Tq, D), device=q.device, dtype=BF16)
     dk = dk_out if dk_out is not None else torch.empty((B, Tk, D), device=q.device, dtype=BF16)
     dv = dv_out if dv_out is not None else torch.empty((B, Tk, D), device=q.device, dtype=BF16)
     assert dk.shape == (B, Tk, D) and dv.shape == (B, Tk, D) and dk.stride() == dv.stride() and dk.stride(2) == 1 and dk.dtype == BF16 and dv.dtype == BF16
+    assert dq.shape == (B, Tq, D) and dq.stride(2) == 1 and dq.dtype == BF16
     delta = torch.empty((B, heads, Tq), device=q.device, dtype=torch.float32)
     for t in (q, k, v, o, do):
         assert t.dtype == BF16 and t.stride(2) == 1
     if causal_shift is None:
         causal_shift = Tk - Tq
     do = do if do.stride() == o.stride() else do.contiguous()
-    strided = not dk.is_contiguous()
+    ks, qs = not dk.is_contiguous(), not dq.is_contiguous()
     LIB.call("cxr_attn_bwd_bf16", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(kpm),
              q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), o.stride(0), o.stride(1),
              kpm.stride(0) if kpm is not None else 0, B, heads, Tq, Tk, float(scale), int(causal), int(causal_shift), *_drop_args(drop),
-             dk.stride(0) if strided else 0, dk.stride(1) if strided else 0, _s())
+             dk.stride(0) if ks else 0, dk.stride(1) if ks else 0, dq.stride(0) if qs else 0, dq.stride(1) if qs else 0, _s())
     return dq, dk, dv
 
 

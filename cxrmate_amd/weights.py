@@ -123,12 +123,21 @@ def bert_param_shapes(cfg: BertConfig, prefix: str = "decoder.", storage_order: 
         # weights then biases -- so that the flat parameter / shadow / gradient buffers expose them as ONE [layers*2*d, d] matrix: every layer
         # projects the same encoder output, which makes them one GEMM forward, one for the encoder-output gradient and one for the weight gradient
         front = cross_kv_keys(cfg, prefix, ".weight") + cross_kv_keys(cfg, prefix, ".bias")
+        if not cfg.lora_r:
+            # ... and the self-attention query / key / value of a layer (weights, then biases): one [3*d, d] projection of the layer input
+            for l in range(cfg.num_hidden_layers):
+                front += self_qkv_keys(cfg, l, prefix, ".weight") + self_qkv_keys(cfg, l, prefix, ".bias")
         re = OrderedDict((k, out[k]) for k in front)
         for k, v in out.items():
             if k not in re:
                 re[k] = v
         out = re
     return out
+
+
+def self_qkv_keys(cfg: BertConfig, layer: int, prefix: str = "decoder.", suffix: str = ".weight"):
+    p = prefix + ("base_model.model." if cfg.lora_r else "")
+    return [p + f"bert.encoder.layer.{layer}.attention.self.{n}{suffix}" for n in ("query", "key", "value")]
 
 
 def cross_kv_keys(cfg: BertConfig, prefix: str = "decoder.", suffix: str = ".weight"):

@@ -65,8 +65,8 @@ int cxr_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, floa
 int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* delta, void* dQ,
                       void* dK, void* dV, const void* kpm, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
                       long o_rs, long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal, int causal_shift, float drop_p,
-                      const unsigned int* drop_seed, unsigned int drop_site, int drop_t0, long dkv_bs, long dkv_rs, hipStream_t stream);
-                      /* dkv_rs != 0: dK / dV are written with batch / row strides dkv_bs / dkv_rs (elements) instead of contiguously */
+                      const unsigned int* drop_seed, unsigned int drop_site, int drop_t0, long dkv_bs, long dkv_rs, long dq_bs, long dq_rs, hipStream_t stream);
+                      /* dkv_rs != 0 / dq_rs != 0: dK, dV / dQ are written with these batch / row strides (elements) instead of contiguously */
 
 /* ---- train-mode dropout / DropPath (TF5:bert:106,298,464; TF5:cvt:297-316) ---------------------------------------------------
  * out = resid + f * y with f = keep(seed, site, b, t, col)/(1-p) per element (b = row / rows_per_b, t = t0 + row % rows_per_b), or
