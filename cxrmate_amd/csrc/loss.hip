@@ -62,13 +62,17 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
 
 // Register-resident variant (V <= 32768, ld % 4 == 0): 1024 threads hold the whole row (<= 8 float4 each), so the logits are read from HBM
 // exactly once (the 256-thread kernel above re-reads the 120-KB row for the sum and for the gradient).
-__global__ __launch_bounds__(1024) void softmax_ce_reg_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ labels,
+// BF16IN: the logits are bf16 (what the LM head produces under the reference's bf16 autocast; the softmax still runs in fp32): half the bytes of
+// the largest tensor of a training step, written by the LM-head GEMM and read here.
+template <bool BF16IN>
+__global__ __launch_bounds__(1024) void softmax_ce_reg_kernel(const void* __restrict__ logits, long ld, const long* __restrict__ labels,
                                                               long ignore_index, const float* __restrict__ thr, const float* __restrict__ row_w,
                                                               float* __restrict__ row_loss, bf16_t* __restrict__ dlogits, long lddl, int V) {
     __shared__ float sh[16];
     __shared__ float xl;
     const long r = blockIdx.x;
-    const float* x = logits + r * ld;
+    const float* x = reinterpret_cast<const float*>(logits) + r * ld;
+    const bf16_t* x16 = reinterpret_cast<const bf16_t*>(logits) + r * ld;
     const long label = labels[r];
     const int tid = threadIdx.x;
     if (label == ignore_index) {
@@ -84,11 +88,22 @@ __global__ __launch_bounds__(1024) void softmax_ce_reg_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int v = tid * 8 + 8192 * i;
+        float f8[8];
+        if (BF16IN) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f8[j] = -INFINITY;
+            if (v + 7 < V) unpack8(*reinterpret_cast<const uint4*>(x16 + v), f8);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (v + j < V) f8[j] = bf2f(x16[v + j]);
+            }
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float4 q = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
             const int vv = v + 4 * h;
-            if (vv + 3 < V) q = *reinterpret_cast<const float4*>(x + vv);
+            if (BF16IN) q = make_float4(f8[4 * h], f8[4 * h + 1], f8[4 * h + 2], f8[4 * h + 3]);
+            else if (vv + 3 < V) q = *reinterpret_cast<const float4*>(x + vv);
             else {
                 if (vv < V) q.x = x[vv];
                 if (vv + 1 < V) q.y = x[vv + 1];
@@ -153,14 +168,18 @@ __global__ __launch_bounds__(1024) void softmax_ce_reg_kernel(const float* __res
     }
 }
 
-extern "C" int cxr_softmax_ce(const float* logits, long ld, const long* labels, long ignore_index, const float* thr, const float* row_w,
-                              float* row_loss, void* dlogits, long lddl, long R, int V, hipStream_t stream) {
+extern "C" int cxr_softmax_ce(const void* logits, long ld, const long* labels, long ignore_index, const float* thr, const float* row_w,
+                              float* row_loss, void* dlogits, long lddl, long R, int V, int logits_bf16, hipStream_t stream) {
     if (R <= 0 || V <= 0 || (dlogits && (!row_w || (lddl % 8)))) return CXR_ERR_ARG;
-    if (V <= 32768 && lddl <= 32768 && (ld % 4) == 0 && (((size_t)logits) % 16) == 0)
-        CXR_LAUNCH(softmax_ce_reg_kernel, dim3((unsigned)R), dim3(1024), 0, stream, logits, ld, labels, ignore_index, thr, row_w, row_loss,
+    if (logits_bf16) {
+        if (V > 32768 || lddl > 32768 || (ld % 8) || (((size_t)logits) % 16)) return CXR_ERR_ARG;
+        CXR_LAUNCH((softmax_ce_reg_kernel<true>), dim3((unsigned)R), dim3(1024), 0, stream, logits, ld, labels, ignore_index, thr, row_w, row_loss,
+                           (bf16_t*)dlogits, lddl, V);
+    } else if (V <= 32768 && lddl <= 32768 && (ld % 4) == 0 && (((size_t)logits) % 16) == 0)
+        CXR_LAUNCH((softmax_ce_reg_kernel<false>), dim3((unsigned)R), dim3(1024), 0, stream, logits, ld, labels, ignore_index, thr, row_w, row_loss,
                            (bf16_t*)dlogits, lddl, V);
     else
-        CXR_LAUNCH(softmax_ce_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, labels, ignore_index, thr, row_w, row_loss,
+        CXR_LAUNCH(softmax_ce_kernel, dim3((unsigned)R), dim3(256), 0, stream, (const float*)logits, ld, labels, ignore_index, thr, row_w, row_loss,
                            (bf16_t*)dlogits, lddl, V);
     CXR_LAUNCH_CHECK();
     return CXR_OK;

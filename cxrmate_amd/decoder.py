@@ -196,7 +196,7 @@ class BertEngine:
         return ph, pa, seed
 
     def forward(self, ids, enc=None, enc_mask=None, attn_mask=None, token_type_ids=None, position_ids=None, save=False, causal=True,
-                lm_head=True, train=None, seed=None):
+                lm_head=True, train=None, seed=None, logits_bf16=False):
         """ids int64 [B,T]; enc bf16 [B,S,D] | None; masks uint8 (1 = attend). -> logits fp32 [B,T,V] (or hidden bf16 [B,T,D]), saved.
         train (default: the store's nn.Module flag) enables dropout; seed: device int32 [1] to REPRODUCE the masks of an earlier pass."""
         cfg, st, p = self.cfg, self.s, self.p
@@ -294,19 +294,20 @@ class BertEngine:
             if save:
                 saved["h_out"] = h
             return h.view(B, T, D), saved
-        logits, hs = self._lm_head(h, save)
+        logits, hs = self._lm_head(h, save, logits_bf16)
         if save:
             saved.update(h_out=h, **hs)
         return logits.view(B, T, -1), saved
 
-    def _lm_head(self, h, save):
-        """BertLMPredictionHead (TF5:bert:466-496): dense -> GELU -> LayerNorm -> tied projection + bias; logits fp32."""
+    def _lm_head(self, h, save, logits_bf16=False):
+        """BertLMPredictionHead (TF5:bert:466-496): dense -> GELU -> LayerNorm -> tied projection + bias; logits fp32 (API default) or bf16
+        (the training step: the dtype the reference's bf16 autocast gives them; the loss kernel upcasts)."""
         cfg, st, p = self.cfg, self.s, self.p
         c = p + "cls.predictions."
         tu = torch.empty((h.shape[0], cfg.hidden_size), dtype=BF16, device=h.device) if save else None
         t = ops.gemm_nt(h, st.w16(c + "transform.dense.weight"), bias=st.f32(c + "transform.dense.bias"), act=1, aux=tu)
         tn, ts = ops.layernorm(t, st.f32(c + "transform.LayerNorm.weight"), st.f32(c + "transform.LayerNorm.bias"), cfg.layer_norm_eps, need_stats=save)
-        logits = ops.gemm_nt(tn, st.w16(p + "bert.embeddings.word_embeddings.weight"), bias=st.f32(c + "bias"), out_f32=True)
+        logits = ops.gemm_nt(tn, st.w16(p + "bert.embeddings.word_embeddings.weight"), bias=st.f32(c + "bias"), out_f32=not logits_bf16)
         return logits, dict(tu=tu, t=t, ts=ts, tn=tn)
 
     # ------------------------------------------------------------------------------------------ backward

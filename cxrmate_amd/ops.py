@@ -743,14 +743,16 @@ def ce_weights(labels, ignore_index, mode=0, reward=None, T=0):
 
 
 def softmax_ce(logits, labels, ignore_index, row_w, thr=None, need_grad=True):
-    """logits fp32 [R,V]; -> loss scalar tensor (fp32, [1]), row_loss [R], dlogits bf16 [R,V] | None"""
+    """logits fp32 or bf16 [R,V]; -> loss scalar tensor (fp32, [1]), row_loss [R], dlogits bf16 [R,V] | None"""
     R, V = logits.shape
-    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    assert logits.dtype in (torch.float32, BF16) and logits.stride(1) == 1
+    if logits.dtype == BF16 and (logits.stride(0) % 8 or V > 32768 or logits.data_ptr() % 16):
+        logits = logits.float()              # the bf16 kernel keeps a whole row in registers and reads 16-byte vectors
     row_loss = torch.empty((R,), dtype=torch.float32, device=logits.device)
     Vp = ((V + 63) // 64) * 64            # zero-padded so that V can be the K dimension of the LM-head backward GEMMs
     dl = torch.empty((R, Vp), dtype=BF16, device=logits.device) if need_grad else None
     LIB.call("cxr_softmax_ce", _p(logits), logits.stride(0), _p(labels), int(ignore_index), _p(thr), _p(row_w), _p(row_loss), _p(dl),
-             dl.stride(0) if dl is not None else 0, R, V, _s())
+             dl.stride(0) if dl is not None else 0, R, V, int(logits.dtype == BF16), _s())
     loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
     LIB.call("cxr_ce_reduce", _p(row_loss), _p(row_w), R, _p(loss), _s())
     return loss, row_loss, (dl[:, :V] if dl is not None else None)

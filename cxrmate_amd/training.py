@@ -65,7 +65,8 @@ def _phase_fwd_loss_decbwd(model, opt, px, ids, am, tt, lab, pad_token_id, pos, 
     B = px.shape[0]
     enc = feats.view(B, -1, feats.shape[-1])
     enc_mask = ops.image_mask(px, tokens) if (multi and model.kind != "single") else None
-    logits, dsaved = model._dec.forward(model._i64(ids, dev), enc, enc_mask, model._u8(am, dev), model._i64(tt, dev), model._i64(pos, dev), save=True)
+    logits, dsaved = model._dec.forward(model._i64(ids, dev), enc, enc_mask, model._u8(am, dev), model._i64(tt, dev), model._i64(pos, dev), save=True,
+                                        logits_bf16=_BF16_LOGITS)
     Bq, T, V = logits.shape
     lg = logits[:, logits_slice_from:, :]
     labels = model._i64(lab, dev).reshape(-1)
@@ -86,6 +87,9 @@ def _phase_encbwd(model, esaved, denc):
     if esaved is not None:
         model._enc.backward(esaved, denc.view(-1, denc.shape[-1]))
     ops.wgrad_join()
+
+
+_BF16_LOGITS = os.environ.get("CXR_BF16_LOGITS", "1") != "0"      # training step: bf16 logits as under the reference's autocast (0: fp32)
 
 
 class wgrad_overlap:

@@ -213,8 +213,9 @@ int cxr_image_mask(const float* px, long img_stride, int BN, int tokens, void* o
 
 /* ---- losses and token selection (REF:modules/lightning_modules/single.py:467-469;
  *      REF:modules/lightning_modules/longitudinal/scst/gt_prompt.py:211-246; TF5:gen:2894-2937; TopKLogitsWarper) ------------ */
-int cxr_softmax_ce(const float* logits, long ld, const long* labels, long ignore_index, const float* thr, const float* row_w, float* row_loss,
-                   void* dlogits, long lddl, long R, int V, hipStream_t stream);
+int cxr_softmax_ce(const void* logits, long ld, const long* labels, long ignore_index, const float* thr, const float* row_w, float* row_loss,
+                   void* dlogits, long lddl, long R, int V, int logits_bf16, hipStream_t stream);
+                   /* logits fp32, or bf16 when logits_bf16 != 0 (the LM head's output dtype under the reference's bf16 autocast; softmax in fp32) */
 int cxr_ce_weights(const long* labels, long R, long ignore_index, int mode, const float* reward, int T, float* row_w, hipStream_t stream);
 int cxr_ce_reduce(const float* row_loss, const float* row_w, long R, float* loss, hipStream_t stream);
 int cxr_topk_threshold(const float* logits, long ld, long R, int V, int k, float top_p, float temperature, float* thr, hipStream_t stream);

@@ -775,6 +775,14 @@ def test_softmax_ce_and_reinforce(ops):
     ref.backward()
     assert abs(loss.item() - ref.item()) < 1e-4
     close(dl, lr.grad, rtol=2e-2, atol=2e-2, what="dlogits")
+    # bf16 logits (the training step's LM-head output): same loss / gradient as the fp32 kernel on the rounded values, ragged vocabulary too
+    for Vb in (V, 1000, 29992):
+        l16 = logits[:, :Vb].to(BF).contiguous()
+        lab = labels.clamp(max=Vb - 1)
+        wb = ops.ce_weights(lab, 4)
+        a = ops.softmax_ce(l16, lab, 4, wb)
+        b = ops.softmax_ce(l16.float(), lab, 4, wb)
+        assert abs(a[0].item() - b[0].item()) < 1e-5 and torch.allclose(a[1], b[1], atol=1e-5) and torch.equal(a[2], b[2])
     # REINFORCE over top-k filtered scores: B=3, T=5
     B, T, k = 3, 5, 50
     logits = dev(rnd(B * T, V, seed=2) * 2)
