@@ -69,13 +69,19 @@ class GradReducer:
         self._pending = []
         self._stream = torch.cuda.Stream() if flat.is_cuda else None
 
-    def reduce_range(self, lo: int, hi: int, async_op: bool = True):
-        """Start reducing every bucket inside [lo, hi). Safe to call while later kernels write OTHER ranges."""
+    def reduce_range(self, lo: int, hi: int, async_op: bool = True, after=None):
+        """Start reducing every bucket inside [lo, hi). Safe to call while later kernels write OTHER ranges. after: an extra stream whose
+        queued work (weight-gradient kernels) must finish before the collective reads the gradients."""
         if world_size() == 1:
             return
         todo = [(a, b) for a, b in self.buckets if a >= lo and b <= hi]
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
+            if after is not None:
+                self._stream.wait_stream(after)
+        elif after is not None:
+            torch.cuda.current_stream().wait_stream(after)          # no private stream (gloo on device tensors): the collective runs on the current one
+        if self._stream is not None:
             with torch.cuda.stream(self._stream):
                 for a, b in todo:
                     self._pending.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=async_op))

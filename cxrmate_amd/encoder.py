@@ -28,6 +28,7 @@ class CvtEncoderEngine:
         self._bn_version = 0                        # bumped whenever a train-mode forward moves the running statistics
         self._fold_cache = {}
         self._taps, self._taps_version, self._taps_index = None, -1, {}
+        self._wt_event = None
         self._dp_rate, self._dp_factors = {}, {}
         self._fused_proj = os.environ.get("CXR_DWPROJ", "1") != "0"      # A/B switch: 0 = per-projection kernels of conv.hip
         self._embed_buf = {}                        # persistent conv-as-GEMM weight re-layouts (their addresses feed the batched transpose table)
@@ -144,6 +145,7 @@ class CvtEncoderEngine:
                 self._bt, self._bt_sig, self._bt_keys = ops.BatchedTranspose(srcs), sig, keys
             with ops._on_wgrad_stream():
                 self._bt.run()
+            self._wt_event = ops.wgrad_mark()
             self._wt_ready = True
         for k, o in zip(self._bt_keys, self._bt.outs):
             prep[("wt", k)] = o
@@ -298,7 +300,7 @@ class CvtEncoderEngine:
         cfg, st = self.cfg, self.s
         prep = self.prepare()
         self._prepare_transposes()
-        ops.wgrad_join()                                                # transposed weights (side stream) are ready
+        ops.wgrad_wait(self._wt_event)                                  # transposed weights are ready (NOT a join: the decoder's weight-gradient backlog keeps running)
         st.ensure_grads()
         Bn = saved["Bn"]
         hp = self.p + "projection_head."

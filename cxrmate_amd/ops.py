@@ -235,6 +235,21 @@ def wgrad_join():
     _side_launch._pending.clear()
 
 
+def wgrad_mark():
+    """Event at the side stream's current position (None without a side stream): lets a later consumer wait for exactly the work issued so far
+    (the W^T transposes of a forward pass) instead of joining the whole weight-gradient backlog."""
+    if WGRAD_STREAM is None:
+        return None
+    ev = torch.cuda.Event()
+    ev.record(WGRAD_STREAM)
+    return ev
+
+
+def wgrad_wait(ev):
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+
+
 def linear_bwd_weight(dy, x, dw, db=None):
     """dw[N,K] += dy[M,N]^T @ x[M,K]; db[N] += colsum(dy)   (one split-K TN kernel; no transposes)."""
     with _side_launch(dy, x, dw, db):
@@ -676,8 +691,9 @@ def bert_embed(ids, tt, pid, word, typ, posw, gamma, beta, eps, T, pos_offset=0,
 
 
 def bert_embed_bwd(dsum, ids, tt, pid, dword, dtype_, dpos, T, pos_offset, padding_idx):
-    LIB.call("cxr_bert_embed_bwd", _p(dsum), _p(ids), _p(tt), _p(pid), _p(dword), _p(dtype_), _p(dpos), ids.numel(), T, pos_offset,
-             int(padding_idx), dsum.shape[1], _s())
+    with _side_launch(dsum, ids, tt, pid):                       # embedding-table gradients only feed the optimiser: weight-gradient stream
+        LIB.call("cxr_bert_embed_bwd", _p(dsum), _p(ids), _p(tt), _p(pid), _p(dword), _p(dtype_), _p(dpos), ids.numel(), T, pos_offset,
+                 int(padding_idx), dsum.shape[1], _s())
 
 
 _SPECIAL_CACHE = {}

@@ -52,7 +52,7 @@ class FusedAdamW:
 
 
 # ---------------------------------------------------------------------------------------------------- step phases
-def _phase_fwd_loss_decbwd(model, opt, px, ids, am, tt, lab, pad_token_id, pos, logits_slice_from):
+def _phase_fwd_loss_decbwd(model, opt, px, ids, am, tt, lab, pad_token_id, pos, logits_slice_from, join=True):
     """zero grads -> encoder fwd -> decoder fwd -> fused CE (loss + dlogits) -> decoder bwd. Returns (loss, esaved, denc)."""
     dev = model.device
     opt.zero_grad()
@@ -79,7 +79,8 @@ def _phase_fwd_loss_decbwd(model, opt, px, ids, am, tt, lab, pad_token_id, pos, 
         full[:, logits_slice_from:, :] = dl.view(Bq, T - logits_slice_from, -1)
         dl = full.view(Bq * T, -1)
     denc = model._dec.backward(dsaved, dlogits=dl, need_denc=enc_trainable)
-    ops.wgrad_join()                      # decoder weight gradients complete (their all-reduce may start now)
+    if join:
+        ops.wgrad_join()                  # decoder weight gradients complete (graph capture needs the fork joined; an all-reduce may start now)
     return loss, esaved, denc
 
 
@@ -117,13 +118,16 @@ def tf_train_step(model, opt: FusedAdamW, pixel_values, decoder_input_ids, decod
 
 def _tf_train_step(model, opt, pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids, label_ids, pad_token_id,
                    decoder_position_ids, logits_slice_from):
+    # eager launches: the main stream goes straight from the decoder backward into the encoder backward; the decoder's weight-gradient
+    # kernels still queued on the side stream keep running beside it (one join at the end of the step)
     loss, esaved, denc = _phase_fwd_loss_decbwd(model, opt, pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids,
-                                                label_ids, pad_token_id, decoder_position_ids, logits_slice_from)
+                                                label_ids, pad_token_id, decoder_position_ids, logits_slice_from, join=False)
     world = dp.world_size()
     enc_trainable = esaved is not None
     if world > 1 and enc_trainable:
-        # decoder parameters sit after the encoder's in the flat buffer: reduce them while the encoder backward runs
-        opt.reducer.reduce_range(opt.split, model._param_total)
+        # decoder parameters sit after the encoder's in the flat buffer: reduce them while the encoder backward runs (the reducer's stream
+        # waits for the weight-gradient stream, the main stream does not)
+        opt.reducer.reduce_range(opt.split, model._param_total, after=ops.WGRAD_STREAM)
     _phase_encbwd(model, esaved, denc)
     if world > 1:
         opt.reducer.reduce_range(0, opt.split if enc_trainable else model._param_total)
