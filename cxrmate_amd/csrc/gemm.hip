@@ -642,7 +642,13 @@ extern "C" int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq
     g.tiles_j = cdiv(J, 128);
     const int tiles = tiles_i * g.tiles_j;
     const int nrt = cdiv(R, 32);
-    int splits = cdiv(320, tiles);                         // ~1.25 workgroups per CU: every split costs a 64 KB fp32 atomic tile
+    // Workgroups a launch aims for. These kernels run on the weight-gradient stream BESIDE the critical dX / attention kernels and every
+    // workgroup holds 64 KB of LDS (half a CU's co-residency): ~0.7 workgroups per CU leaves the main stream its slots and halves the
+    // atomic traffic (one 64 KB fp32 tile per split). Measured on the training step: 448 -> 32.5 ms, 320 -> 31.7, 224 -> 31.3, 176 -> 31.0,
+    // 128 -> 31.5 (same box); alone, a single launch is up to 1.4x faster at 320. CXR_TN_WGS overrides.
+    static int target_wgs = -1;
+    if (target_wgs < 0) { const char* e = getenv("CXR_TN_WGS"); target_wgs = e ? atoi(e) : 176; if (target_wgs < 1) target_wgs = 176; }
+    int splits = cdiv(target_wgs, tiles);
     const int max_splits = nrt / 8 > 0 ? nrt / 8 : 1;      // at least 256 tokens per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
