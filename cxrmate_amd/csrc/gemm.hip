@@ -487,9 +487,10 @@ __device__ __forceinline__ bf16x8_t tn_frag_join(const s16x4_t& lo, const s16x4_
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+template <int NST>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
-    constexpr int BR = 32, NST = 4, TILE = BR * 256, LPS = 4;      // 4 LDS-DMA instructions per thread per stage (2 per operand)
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * 2 * TILE];      // 64 KB: [stage][P|Q]
+    constexpr int BR = 32, TILE = BR * 256, LPS = 4;               // 4 LDS-DMA instructions per thread per stage (2 per operand)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * 2 * TILE];      // [stage][P|Q]: 64 KB at 4 stages, 32 KB at 2
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave & 1, wj = wave >> 1;
@@ -601,24 +602,29 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
     // buffer one ROW per wave-instruction: 64 lanes x 4 B = 256 contiguous bytes, the shape at which global float atomics run at full rate
     const int fr = lane & 15, fq = lane >> 4;
     __syncthreads();                                           // every wave is done reading the staging tiles
-    float* wtile = reinterpret_cast<float*>(lds) + wave * (64 * 64);
+    // the staging LDS holds HALVES x (rows per pass) of every wave's 64-row sub-tile: all 64 rows at 4 stages (64 KB), 32 rows per pass at 2
+    constexpr int PASS_ROWS = (NST * 2 * TILE) / (4 * 64 * 4) >= 64 ? 64 : 32;
+    float* wtile = reinterpret_cast<float*>(lds) + wave * (PASS_ROWS * 64);
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
+    for (int half = 0; half < 64 / PASS_ROWS; ++half) {
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+        for (int it = 0; it < PASS_ROWS / 16; ++it)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) wtile[(it * 16 + fq * 4 + r) * 64 + jt * 16 + fr] = acc[it][jt][r] * g.alpha;
-    __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0): own writes landed (each wave reads back only its own tile)
-    {
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    wtile[(it * 16 + fq * 4 + r) * 64 + jt * 16 + fr] = acc[half * (PASS_ROWS / 16) + it][jt][r] * g.alpha;
+        __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0): own writes landed (each wave reads back only its own tile)
         const int j = tj * 128 + wj * 64 + lane;
-        const int ibase = ti * 128 + wi * 64;
+        const int ibase = ti * 128 + wi * 64 + half * PASS_ROWS;
         if (j < g.J) {
 #pragma unroll 8
-            for (int row = 0; row < 64; ++row) {
+            for (int row = 0; row < PASS_ROWS; ++row) {
                 const int i = ibase + row;
                 if (i < g.I) atomicAdd(g.C + (long)i * g.ldc + j, wtile[row * 64 + lane]);
             }
         }
+        if (half + 1 < 64 / PASS_ROWS) __builtin_amdgcn_s_waitcnt(0xC07F);          // the next pass overwrites the rows just read
     }
     if (do_bias && fr == 0) {
 #pragma unroll
@@ -654,7 +660,10 @@ extern "C" int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq
     if (splits < 1) splits = 1;
     g.rt_per_split = cdiv(nrt, splits);
     g.splits = cdiv(nrt, g.rt_per_split);
-    CXR_LAUNCH(gemm_tn_kernel, dim3(tiles * g.splits), dim3(256), 0, stream, g);
+    static int stages = -1;                                // CXR_TN_STAGES = 2 | 4 (LDS 32 | 64 KB per workgroup)
+    if (stages < 0) { const char* e = getenv("CXR_TN_STAGES"); stages = e ? atoi(e) : 4; }
+    if (stages == 2) CXR_LAUNCH(gemm_tn_kernel<2>, dim3(tiles * g.splits), dim3(256), 0, stream, g);
+    else             CXR_LAUNCH(gemm_tn_kernel<4>, dim3(tiles * g.splits), dim3(256), 0, stream, g);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
