@@ -321,13 +321,14 @@ class BertEngine:
         scale = cfg.lora_alpha / cfg.lora_r
         dw = torch.zeros(st.f32(base + ".base_layer.weight").shape, dtype=torch.float32, device=dy.device)
         ops.linear_bwd_weight(dy, x, dw, st.grad(base + ".base_layer.bias"))
-        st.grad(base + ".base_layer.weight").add_(dw)
-        dw16 = ops.cast_to_bf16(dw)
-        # dB[n,r] = s * sum_k dW[n,k] A[r,k] ;  dA[r,k] = s * sum_n B[n,r] dW[n,k]
-        ops.gemm_nt(dw16, st.w16(base + ".lora_A.default.weight"), out=st.grad(base + ".lora_B.default.weight"), out_f32=True,
-                    accumulate=True, alpha=scale)
-        bt = ops.transpose(st.w16(base + ".lora_B.default.weight"))                 # [r, d]
-        ops.gemm_nt(bt, ops.transpose(dw16), out=st.grad(base + ".lora_A.default.weight"), out_f32=True, accumulate=True, alpha=scale)
+        with ops._on_wgrad_stream(dw):                       # consumers of dw: same stream as the weight-gradient GEMM that fills it
+            st.grad(base + ".base_layer.weight").add_(dw)
+            dw16 = ops.cast_to_bf16(dw)
+            # dB[n,r] = s * sum_k dW[n,k] A[r,k] ;  dA[r,k] = s * sum_n B[n,r] dW[n,k]
+            ops.gemm_nt(dw16, st.w16(base + ".lora_A.default.weight"), out=st.grad(base + ".lora_B.default.weight"), out_f32=True,
+                        accumulate=True, alpha=scale)
+            bt = ops.transpose(st.w16(base + ".lora_B.default.weight"))             # [r, d]
+            ops.gemm_nt(bt, ops.transpose(dw16), out=st.grad(base + ".lora_A.default.weight"), out_f32=True, accumulate=True, alpha=scale)
 
     def _wt(self, base, lora_tr=False):
         if lora_tr and ("wtb", base) in self._prep:

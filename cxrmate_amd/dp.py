@@ -67,6 +67,7 @@ class GradReducer:
             if hi > lo:
                 self.buckets.append((lo, hi))
         self._pending = []
+        self._started = set()
         self._stream = torch.cuda.Stream() if flat.is_cuda else None
 
     def reduce_range(self, lo: int, hi: int, async_op: bool = True, after=None):
@@ -74,7 +75,8 @@ class GradReducer:
         queued work (weight-gradient kernels) must finish before the collective reads the gradients."""
         if world_size() == 1:
             return
-        todo = [(a, b) for a, b in self.buckets if a >= lo and b <= hi]
+        todo = [(a, b) for a, b in self.buckets if a >= lo and b <= hi and (a, b) not in self._started]
+        self._started.update(todo)                                   # a later, wider reduce_range only picks up what is still missing
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
             if after is not None:
@@ -94,6 +96,7 @@ class GradReducer:
             if w is not None:
                 w.wait()
         self._pending = []
+        self._started = set()
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
 

@@ -295,8 +295,10 @@ class CvtEncoderEngine:
         return x3.view(Bn, L, C), lsave
 
     # ------------------------------------------------------------------------------------------ backward
-    def backward(self, saved, dfeats: torch.Tensor):
-        """dfeats [Bn*tokens, projection_size] bf16. Parameter gradients are ACCUMULATED into the store's flat gradient buffer."""
+    def backward(self, saved, dfeats: torch.Tensor, on_stage_done=None):
+        """dfeats [Bn*tokens, projection_size] bf16. Parameter gradients are ACCUMULATED into the store's flat gradient buffer.
+        on_stage_done(s): called when every gradient launch of stage s (and of the later stages and the projection head) has been issued --
+        data parallelism starts the all-reduce of that stage's parameters while the earlier stages are still in backward."""
         cfg, st = self.cfg, self.s
         prep = self.prepare()
         self._prepare_transposes()
@@ -334,13 +336,17 @@ class CvtEncoderEngine:
             dwp = torch.zeros(wp.shape, dtype=torch.float32, device=dx.device)
             ops.linear_bwd_weight(de, ss["col"], dwp, st.grad(ep + "projection.bias"))
             gw = st.grad(ep + "projection.weight")
-            if s == 0:
-                gw.add_(dwp[:, :gw[0].numel()].view(gw.shape))                           # layout plumbing back to [Co,Ci,kh,kw]
-            else:
-                gw.add_(dwp.view(gw.shape[0], gw.shape[2], gw.shape[3], gw.shape[1]).permute(0, 3, 1, 2))
+            with ops._on_wgrad_stream(dwp):                  # same stream as the weight-gradient GEMM that fills dwp (ordered after it)
+                if s == 0:
+                    gw.add_(dwp[:, :gw[0].numel()].view(gw.shape))                       # layout plumbing back to [Co,Ci,kh,kw]
+                else:
+                    gw.add_(dwp.view(gw.shape[0], gw.shape[2], gw.shape[3], gw.shape[1]).permute(0, 3, 1, 2))
+            if s > 0:
                 dcol = ops.gemm_nt(de, self._wt(("embed", s)))
                 Hp = Wp = cfg.grid(s - 1)
                 dx = ops.col2im_tokens(dcol, Bn, cfg.embed_dim[s - 1], Hp, Wp, cfg.patch_stride[s], cfg.patch_padding[s])
+            if on_stage_done is not None:
+                on_stage_done(s)
         return None
 
     def _layer_bwd(self, dy, sv, s, l, H, W, tok0, prep):

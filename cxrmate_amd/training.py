@@ -31,7 +31,12 @@ class FusedAdamW:
         self.v = torch.zeros_like(model.flat32)
         self.t_dev = torch.zeros((), dtype=torch.int32, device=model.device)       # step counter lives on the device (graph replay)
         self.split = model._offsets[next(k for k in model._offsets if k.startswith("decoder."))]
-        self.reducer = dp.GradReducer(model.gflat, self.ranges, cuts=[self.split])
+        # flat-buffer offset where the parameters of the LAST encoder stage begin (CvT-21: 29 of the encoder's 31 M parameters sit behind it, followed
+        # by the projection head): their gradients are complete when that stage's backward is, long before the first stages finish
+        last = max((int(k.split(".")[4]) for k in model._offsets if k.startswith("encoder.cvt.encoder.stages.")), default=None)
+        self.enc_tail = None if last is None else min(o for k, o in model._offsets.items() if k.startswith(f"encoder.cvt.encoder.stages.{last}."))
+        self.enc_last_stage = last
+        self.reducer = dp.GradReducer(model.gflat, self.ranges, cuts=[self.split] + ([self.enc_tail] if self.enc_tail else []))
 
     @property
     def t(self):
@@ -84,9 +89,9 @@ def _phase_fwd_loss_decbwd(model, opt, px, ids, am, tt, lab, pad_token_id, pos, 
     return loss, esaved, denc
 
 
-def _phase_encbwd(model, esaved, denc):
+def _phase_encbwd(model, esaved, denc, on_stage_done=None):
     if esaved is not None:
-        model._enc.backward(esaved, denc.view(-1, denc.shape[-1]))
+        model._enc.backward(esaved, denc.view(-1, denc.shape[-1]), on_stage_done=on_stage_done)
     ops.wgrad_join()
 
 
@@ -128,9 +133,15 @@ def _tf_train_step(model, opt, pixel_values, decoder_input_ids, decoder_attentio
         # decoder parameters sit after the encoder's in the flat buffer: reduce them while the encoder backward runs (the reducer's stream
         # waits for the weight-gradient stream, the main stream does not)
         opt.reducer.reduce_range(opt.split, model._param_total, after=ops.WGRAD_STREAM)
-    _phase_encbwd(model, esaved, denc)
+    early = None
+    if world > 1 and enc_trainable and opt.enc_tail:
+        # ... and the last encoder stage + projection head (93 % of the encoder's parameters) while the first stages are still in backward
+        def early(s):
+            if s == opt.enc_last_stage:
+                opt.reducer.reduce_range(opt.enc_tail, opt.split, after=ops.WGRAD_STREAM)
+    _phase_encbwd(model, esaved, denc, early)
     if world > 1:
-        opt.reducer.reduce_range(0, opt.split if enc_trainable else model._param_total)
+        opt.reducer.reduce_range(0, opt.split if enc_trainable else model._param_total)      # whatever has not been started yet
         opt.reducer.wait()
     opt.step(gscale=1.0 / world)
     return loss

@@ -96,6 +96,37 @@ def test_tf_single_logits_loss_grads(M):
     assert abs(l2.item() - loss.item()) < 1e-4
 
 
+def test_training_step_gradients_do_not_depend_on_stream_overlap(M):
+    """The eager training step puts every weight-gradient kernel (and the embedding-table / LayerNorm parameter sums) on a side stream and joins
+    it once per step: the gradients it leaves in the flat buffer must equal those of the same step issued on ONE stream (fp32 atomics reorder,
+    nothing else), and the bf16-logits loss must match the fp32-logits loss."""
+    from cxrmate_amd import ops, training
+    g, cfg, sd, x, inp, lab, am, tt = gu.tf_single_case()
+    res = {}
+    for overlap in (True, False):
+        m = M.SingleCXREncoderDecoderModel(cfg, seed=None)
+        m.load_state_dict(sd)
+        opt = training.FusedAdamW(m, lr=0.0)
+        ttd = m.token_ids_to_token_type_ids(inp, [gu.SEP])
+        args = (m, opt, x.cuda(), inp.cuda(), am.cuda(), ttd, lab.cuda(), gu.PAD, None, 0)
+        for rep in range(3):                                      # repeated: a missing cross-stream dependency shows up as run-to-run noise
+            if overlap:
+                with training.wgrad_overlap():
+                    loss, esaved, denc = training._phase_fwd_loss_decbwd(*args, join=False)
+                    training._phase_encbwd(m, esaved, denc)
+            else:
+                assert ops.WGRAD_STREAM is None
+                loss, esaved, denc = training._phase_fwd_loss_decbwd(*args)
+                training._phase_encbwd(m, esaved, denc)
+            torch.cuda.synchronize()
+            res.setdefault(overlap, []).append((float(loss.item()), m.gflat.clone()))
+    (l0, g0) = res[False][0]
+    for l1, g1 in res[True] + res[False][1:]:
+        assert abs(l1 - l0) < 1e-5
+        err = float((g1 - g0).norm() / g0.norm())
+        assert err < 2e-4, err
+
+
 def _hash_masks(m, cfg, B, T, S, enc_seed, dec_seed, Bn):
     """The dropout / DropPath factors the kernels regenerate from their counter-based hash, materialised for the CPU oracle."""
     from cxrmate_amd import ops
