@@ -202,8 +202,9 @@ def main():
     # and the device itself -- the first ~second of work on a fresh box runs 5-8 % slow (36.5 vs 34.0 ms/step measured back to back), which
     # 3 warm-up steps (0.1 s) do not cover. At least 2 steps and 1.5 s of them; the W requested warm-up steps follow.
     t_pre, n_pre = time.perf_counter(), 0
-    while n_pre < 2 or (time.perf_counter() - t_pre < 1.5 and n_pre < 64):
-        step()
+    n_fixed = int(os.environ.get("CXR_BENCH_PREWARM", "48"))          # world > 1 only (a rehearsal of the multi-rank flow on one GPU sets it to 2)
+    while (n_pre < n_fixed) if world > 1 else (n_pre < 2 or (time.perf_counter() - t_pre < 1.5 and n_pre < 64)):
+        step()                              # (every rank must run the SAME number of steps -- each one all-reduces: fixed count when world > 1)
         if n_pre % 4 == 3:
             torch.cuda.synchronize()
         n_pre += 1
