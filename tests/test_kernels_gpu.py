@@ -610,6 +610,38 @@ def test_attention_bwd_strided_dkdv_outputs(ops):
     assert float(wide[:, :, :D].abs().max()) == 0 and float(wide[:, :, 2 * D:3 * D].abs().max()) == 0 and float(wide[:, :, 4 * D:].abs().max()) == 0
 
 
+def test_batched_layout_and_mask_launches_equal_their_single_launch_forms(ops):
+    """One-launch-per-step helpers: DropPath factors of consecutive sites, raw-tap re-layout of many projections, LayerNorm parameter-gradient
+    row sum issued separately -- each equals the per-item / fused launch it replaces."""
+    seed = torch.tensor([12345], dtype=torch.int32, device="cuda")
+    f = ops.dropout_site_factors(6, 37, 0.2, seed, 1010)
+    for s_ in range(6):
+        assert torch.equal(f[s_], ops.dropout_mask(37, 1, 0.2, seed, 1010 + s_, 1, factor=True).view(37))
+    ws = [dev(rnd(C, 9, seed=i)) for i, C in enumerate((64, 192, 384, 64))]
+    tl = ops.TapsLayout(ws)
+    for w, o in zip(ws, tl.run()):
+        assert torch.equal(o, w.t().contiguous())
+    ws[2].mul_(2.0)
+    assert torch.equal(tl.run()[2], ws[2].t().contiguous())                     # persistent destinations, refreshed in place
+    rows, C = 1000, 384
+    x, dy = dev(rnd(rows, C).to(BF)), dev(rnd(rows, C, seed=1).to(BF))
+    g = dev(1 + 0.1 * rnd(C, seed=2))
+    _, st = ops.layernorm(x, g, g, 1e-5, need_stats=True)
+    dg0, db0 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx0 = ops.layernorm_bwd(x, dy, g, st, dg0, db0)
+    side = torch.cuda.Stream()
+    ops.WGRAD_STREAM = side
+    try:
+        dg1, db1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        dx1 = ops.layernorm_bwd(x, dy, g, st, dg1, db1)                          # partial rows on this stream, row sum on the side stream
+        ops.wgrad_join()
+    finally:
+        ops.WGRAD_STREAM = None
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1)
+    close(dg1, dg0, rtol=1e-5, atol=1e-4, what="dgamma via side-stream row sum"); close(db1, db0, rtol=1e-5, atol=1e-4, what="dbeta via side-stream row sum")
+
+
 DWPROJ_SHAPES = [(3, 64, 24, 24, 0), (3, 192, 12, 12, 0), (3, 384, 6, 6, 1), (2, 64, 7, 5, 1), (2, 128, 9, 20, 0), (32, 384, 24, 24, 1), (8, 64, 96, 96, 0)]
 
 
