@@ -370,7 +370,7 @@ static int gemm_nt_fill(GemmArgs& g, const cxr_gemm_nt_desc& d) {
 static bool gemm_nt_narrow(int N, long tiles128) {
     static int force_bn = -1;         // tuning aid: CXR_GEMM_BN=64|128
     if (force_bn < 0) { const char* e = getenv("CXR_GEMM_BN"); force_bn = e ? atoi(e) : 0; }
-    bool bn64 = (N % 128) != 0 && (N % 128) <= 64;
+    bool bn64 = (N % 128) != 0 && (N % 128) <= 64 && N < 1024;      // (a ragged last tile of a wide N -- the 30000-column LM head -- is 1 tile in 235)
     if (tiles128 < 160) bn64 = true;
     if (force_bn == 64) bn64 = true; else if (force_bn == 128) bn64 = false;
     return bn64;
