@@ -74,7 +74,10 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         loss, _, dl = ops.softmax_ce(flat, labels, pad, w, thr=thr)
         full = torch.zeros((B, T, dl.shape[1]), dtype=dl.dtype, device=dev)
         full[:, P - 1:, :] = dl.view(B, n_new, -1)
-        model._dec.backward(saved, dlogits=full.view(B * T, -1), need_denc=False)
+        from .training import wgrad_overlap
+        with wgrad_overlap():                                                # weight-gradient GEMMs beside the dX chain, as in the TF step
+            model._dec.backward(saved, dlogits=full.view(B * T, -1), need_denc=False)
+            ops.wgrad_join()
         world = dp.world_size()
         if world > 1:
             opt.reducer.reduce_range(0, model._param_total)
