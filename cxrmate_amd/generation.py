@@ -38,6 +38,9 @@ class DecodeSession:
         self.cache.ck = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
         self.cache.cv = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
         self.seed = torch.zeros(1, dtype=torch.int32, device=dev)     # dropout seed of the running decode (train mode); graphs read it
+        # uniforms of every sampling step of a decode, drawn by ONE torch call in reset(): a torch.rand inside a captured step costs three extra
+        # tiny launches per replay (the generator's seed / offset refresh in front of the graph + the fill kernel itself)
+        self.u_all = torch.zeros((Lmax, rows), dtype=torch.float32, device=dev)
         # per-step inputs of the cached steps (one fused kernel writes them): last token, token type, position, attention mask, and the
         # token-type / position history the teacher-forced re-scoring of the sampled rows needs
         self.new_id = torch.zeros((rows, 1), dtype=torch.int64, device=dev)
@@ -66,6 +69,7 @@ class DecodeSession:
         self.cache.cross_ready = False
         if m.training:
             self.seed.copy_(m.next_dropout_seed())
+        self.u_all.uniform_()                      # torch's CUDA generator: reproducible under torch.manual_seed
 
     def step(self, cur, strip, mode):
         """Append token `cur` (0-based column of self.ids). mode = (do_sample, special_token_ids, mask_token_id, top_k, temperature, eos, pad)."""
@@ -113,7 +117,7 @@ class DecodeSession:
         n_smp = {"greedy": 0, "sample": self.B, "pair": self.B // 2}[kind]      # rows [0, n_smp) sample, the rest take the argmax
         col = self.ids[:, cur]                                                  # the selection kernels write straight into the id buffer
         if n_smp:                                                               # one launch for sampled + greedy rows
-            u = torch.rand(n_smp, device=logits.device, dtype=torch.float32)
+            u = self.u_all[cur, :n_smp]
             ops.select_token(logits, mode=1, temperature=temperature, top_k=top_k or 0, u=u, unfinished=unf, eos=eos_, pad=pad or 0, out=col,
                              top_p=top_p, n_sample=n_smp)
         else:
