@@ -41,6 +41,7 @@ class DecodeSession:
         # uniforms of every sampling step of a decode, drawn by ONE torch call in reset(): a torch.rand inside a captured step costs three extra
         # tiny launches per replay (the generator's seed / offset refresh in front of the graph + the fill kernel itself)
         self.u_all = torch.zeros((Lmax, rows), dtype=torch.float32, device=dev)
+        self.poll_host = torch.zeros(1, dtype=torch.int32).pin_memory()          # landing pad of the asynchronous EOS poll
         # per-step inputs of the cached steps (one fused kernel writes them): last token, token type, position, attention mask, and the
         # token-type / position history the teacher-forced re-scoring of the sampled rows needs
         self.new_id = torch.zeros((rows, 1), dtype=torch.int64, device=dev)
@@ -290,13 +291,25 @@ class GenerationMixin:
                 rec["seed"] = ses.seed.clone() if self.training else None
             cur = prompt_len
             first_tt = first_pos = None
+            poll = None                      # (pinned host word, event): "any row unfinished?" as of the PREVIOUS poll -- read without stalling the queue
             while cur < max_length:
                 ses.step(cur, strip, mode)
                 if rec is not None and cur == prompt_len:            # the prefill step's inputs cover the whole prompt
                     first_tt, first_pos = ses.last_tt.clone(), None if ses.last_pos is None else ses.last_pos.clone()
                 cur += 1
-                if eos_token_id is not None and ((cur - prompt_len) % 8 == 0) and int(ses.unfinished.max()) == 0:
-                    break
+                if eos_token_id is not None and ((cur - prompt_len) % 8 == 0):
+                    # EOS polling every 8 steps, one poll behind: the copy of this poll's flag is only waited for at the NEXT poll, so the host
+                    # keeps enqueueing steps while the GPU works (a blocking .item() drained the queue 32 times per decode); the up to 16 steps of
+                    # overshoot are trimmed below, as the 8 of a blocking poll were
+                    if poll is not None:
+                        poll[1].synchronize()
+                        if int(poll[0][0]) == 0:
+                            break
+                    host = ses.poll_host
+                    host.copy_(ses.unfinished.max().reshape(1), non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    poll = (host, ev)
             out = ses.ids[:, :cur].clone()
             if rec is not None:
                 # cached steps appended their token type / position to the session's history columns: ONE copy, then per-step views
