@@ -196,7 +196,7 @@ class BertEngine:
         return ph, pa, seed
 
     def forward(self, ids, enc=None, enc_mask=None, attn_mask=None, token_type_ids=None, position_ids=None, save=False, causal=True,
-                lm_head=True, train=None, seed=None, logits_bf16=False):
+                lm_head=True, train=None, seed=None, logits_bf16=False, inputs_embeds=None):
         """ids int64 [B,T]; enc bf16 [B,S,D] | None; masks uint8 (1 = attend). -> logits fp32 [B,T,V] (or hidden bf16 [B,T,D]), saved.
         train (default: the store's nn.Module flag) enables dropout; seed: device int32 [1] to REPRODUCE the masks of an earlier pass."""
         cfg, st, p = self.cfg, self.s, self.p
@@ -204,18 +204,25 @@ class BertEngine:
         lora_tr = self._lora_train(train)
         if save:
             self._prepare_transposes(lora_tr)
+        word = None
+        if inputs_embeds is not None:
+            # BertEmbeddings with inputs_embeds (TF5:bert:84-108): the given vectors replace the word-embedding lookup; position / token-type
+            # embeddings, LayerNorm and dropout are unchanged. Same kernel: the vectors are the "table", row r looks up row r.
+            assert ids is None and inputs_embeds.dim() == 3, "specify exactly one of decoder_input_ids / decoder_inputs_embeds"
+            word = inputs_embeds.to(BF16).contiguous().view(-1, inputs_embeds.shape[-1])
+            ids = torch.arange(word.shape[0], device=word.device, dtype=torch.int64).view(inputs_embeds.shape[0], inputs_embeds.shape[1])
         B, T = ids.shape
         D, nh = cfg.hidden_size, cfg.num_attention_heads
         R = B * T
         ph, pa, seed = self._dropout_cfg(train, seed)
         pl, ls = float(cfg.lora_dropout), (cfg.lora_alpha / cfg.lora_r if cfg.lora_r else 0.0)
         e = p + "bert.embeddings."
-        h, esum, estats = ops.bert_embed(ids, token_type_ids, position_ids, st.w16(e + "word_embeddings.weight"),
+        h, esum, estats = ops.bert_embed(ids, token_type_ids, position_ids, st.w16(e + "word_embeddings.weight") if word is None else word,
                                          st.w16(e + "token_type_embeddings.weight"), st.w16(e + "position_embeddings.weight"),
                                          st.f32(e + "LayerNorm.weight"), st.f32(e + "LayerNorm.bias"), cfg.layer_norm_eps, T, need_sum=save,
                                          drop=(ph, seed, SITE_EMBED) if ph else None)
         saved = dict(B=B, T=T, ids=ids, tt=token_type_ids, pos=position_ids, esum=esum, estats=estats, attn_mask=attn_mask, enc=enc,
-                     enc_mask=enc_mask, causal=causal, layers=[], ph=ph, pa=pa, seed=seed, lora_tr=lora_tr) if save else None
+                     enc_mask=enc_mask, causal=causal, layers=[], ph=ph, pa=pa, seed=seed, lora_tr=lora_tr, from_embeds=word is not None) if save else None
         scale = cfg.head_dim ** -0.5
         kv_all = None
         if cfg.add_cross_attention and enc is not None:
@@ -467,8 +474,16 @@ class BertEngine:
         e = p + "bert.embeddings."
         dh = undrop(dh, SITE_EMBED)
         dsum = ops.layernorm_bwd(saved["esum"], dh, st.f32(e + "LayerNorm.weight"), saved["estats"], g(e + "LayerNorm.weight"), g(e + "LayerNorm.bias"))
-        ops.bert_embed_bwd(dsum, saved["ids"], saved["tt"], saved["pos"], g(e + "word_embeddings.weight"), g(e + "token_type_embeddings.weight"),
-                           g(e + "position_embeddings.weight"), T, 0, cfg.pad_token_id)
+        if saved.get("from_embeds"):
+            # the "word table" was the caller's inputs_embeds: its gradient is d(inputs_embeds) (kept in saved["d_embeds"], fp32 [B*T, D]);
+            # the word-embedding parameter only receives its tied LM-head gradient
+            d_emb = torch.zeros((R, D), dtype=torch.float32, device=dsum.device)
+            ops.bert_embed_bwd(dsum, saved["ids"], saved["tt"], saved["pos"], d_emb, g(e + "token_type_embeddings.weight"),
+                               g(e + "position_embeddings.weight"), T, 0, -1)
+            saved["d_embeds"] = d_emb
+        else:
+            ops.bert_embed_bwd(dsum, saved["ids"], saved["tt"], saved["pos"], g(e + "word_embeddings.weight"), g(e + "token_type_embeddings.weight"),
+                               g(e + "position_embeddings.weight"), T, 0, cfg.pad_token_id)
         if dkv_all is not None:
             kva = self._cross_kv_all()
             BS = enc.shape[0] * enc.shape[1]

@@ -70,10 +70,11 @@ class _EncodeFn(torch.autograd.Function):
 
 class _DecodeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, enc, enc_mask, ids, attn_mask, tt, pos, seed, *params):
-        logits, saved = model._dec.forward(ids, enc, enc_mask, attn_mask, tt, pos, save=True, seed=seed)
+    def forward(ctx, model, enc, enc_mask, ids, attn_mask, tt, pos, seed, embeds, *params):
+        logits, saved = model._dec.forward(ids, enc, enc_mask, attn_mask, tt, pos, save=True, seed=seed, inputs_embeds=embeds)
         ctx.model, ctx.saved, ctx.nparams = model, saved, len(params)
         ctx.need_denc = enc is not None and enc.requires_grad
+        ctx.embeds_like = embeds if (embeds is not None and embeds.requires_grad) else None
         return logits
 
     @staticmethod
@@ -85,8 +86,11 @@ class _DecodeFn(torch.autograd.Function):
         d16 = dlogits.reshape(B * T, V)
         d16 = ops.cast_to_bf16(d16.contiguous()) if d16.dtype == torch.float32 else d16.contiguous()
         denc = model._dec.backward(ctx.saved, dlogits=d16, need_denc=ctx.need_denc)
+        d_emb = None
+        if ctx.embeds_like is not None:
+            d_emb = ctx.saved["d_embeds"].view(ctx.embeds_like.shape).to(ctx.embeds_like.dtype)
         ctx.saved = None
-        return (None, denc, None, None, None, None, None, None) + model._collect_grads("decoder.", ctx.nparams)
+        return (None, denc, None, None, None, None, None, None, d_emb) + model._collect_grads("decoder.", ctx.nparams)
 
 
 # ---------------------------------------------------------------------------------------------------- sub-modules
@@ -195,10 +199,12 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
         enc_mask = encoder_outputs.get("attention_mask") if isinstance(encoder_outputs, dict) else None
         if self.kind == "single":
             enc_mask = None                                                  # modelling_single.py:176
-        if decoder_inputs_embeds is not None or past_key_values is not None:
-            raise NotImplementedError("decoder_inputs_embeds / external past_key_values are not part of the accelerated path")
+        if past_key_values is not None:
+            raise NotImplementedError("external past_key_values are not part of the accelerated path (generate() owns the KV cache)")
+        if (decoder_input_ids is None) == (decoder_inputs_embeds is None):
+            raise ValueError("You have to specify exactly one of decoder_input_ids or decoder_inputs_embeds")
         logits = self._decode_tf(decoder_input_ids, enc, enc_mask, decoder_attention_mask, kwargs_decoder.get("token_type_ids"),
-                                 kwargs_decoder.get("position_ids"))
+                                 kwargs_decoder.get("position_ids"), embeds=decoder_inputs_embeds)
         loss = None
         if labels is not None:
             loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1))
@@ -219,16 +225,18 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
             return None
         return t.to(device=device, dtype=torch.int64).contiguous()
 
-    def _decode_tf(self, ids, enc, enc_mask, attn_mask, tt, pos, seed=None):
+    def _decode_tf(self, ids, enc, enc_mask, attn_mask, tt, pos, seed=None, embeds=None):
         dev = self.device
         ids, tt, pos = self._i64(ids, dev), self._i64(tt, dev), self._i64(pos, dev)
+        if embeds is not None:
+            embeds = embeds.to(dev)
         attn_mask, enc_mask = self._u8(attn_mask, dev), self._u8(enc_mask, dev)
         enc = enc if enc.dtype == torch.bfloat16 else ops.cast_to_bf16(enc.float().contiguous())
         enc = enc.contiguous()
         params = [p for _, p in self._grad_params("decoder.")]
-        if torch.is_grad_enabled() and (params or enc.requires_grad):
-            return _DecodeFn.apply(self, enc, enc_mask, ids, attn_mask, tt, pos, seed, *params)
-        logits, _ = self._dec.forward(ids, enc, enc_mask, attn_mask, tt, pos, save=False, seed=seed)
+        if torch.is_grad_enabled() and (params or enc.requires_grad or (embeds is not None and embeds.requires_grad)):
+            return _DecodeFn.apply(self, enc, enc_mask, ids, attn_mask, tt, pos, seed, embeds, *params)
+        logits, _ = self._dec.forward(ids, enc, enc_mask, attn_mask, tt, pos, save=False, seed=seed, inputs_embeds=embeds)
         return logits
 
 

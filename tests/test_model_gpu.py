@@ -96,6 +96,32 @@ def test_tf_single_logits_loss_grads(M):
     assert abs(l2.item() - loss.item()) < 1e-4
 
 
+def test_decoder_inputs_embeds_equals_input_ids(M):
+    """forward(decoder_inputs_embeds=E[ids]) == forward(decoder_input_ids=ids) (BertEmbeddings with inputs_embeds, TF5:bert:84-108); the gradient
+    wrt the given vectors is what the word-embedding rows would have received through the lookup."""
+    g, cfg, sd, x, inp, lab, am, tt = gu.tf_single_case()
+    m = M.SingleCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    ttd = m.token_ids_to_token_type_ids(inp, [gu.SEP])
+    kw = dict(pixel_values=x.cuda(), decoder_attention_mask=am.cuda(), decoder_token_type_ids=ttd, return_dict=True)
+    wkey = "decoder.bert.embeddings.word_embeddings.weight"
+    a = m(decoder_input_ids=inp.cuda(), **kw).logits
+    a.float().square().mean().backward()
+    gw_ids = m.param(wkey).grad.clone()
+    for p_ in m.parameters():
+        p_.grad = None
+    E = m.f32(wkey)[inp.cuda()].to(torch.bfloat16).float().requires_grad_(True)          # the bf16 table rows the lookup reads
+    b = m(decoder_inputs_embeds=E, **kw).logits
+    assert torch.equal(a, b)
+    b.float().square().mean().backward()
+    gw_emb = m.param(wkey).grad                                                           # only the tied LM-head part is left on the table
+    scat = torch.zeros_like(gw_ids).index_add_(0, inp.cuda().reshape(-1), E.grad.reshape(-1, E.shape[-1]))
+    err = float((gw_emb + scat - gw_ids).norm() / gw_ids.norm())
+    assert err < 2e-3, err
+    with pytest.raises(ValueError):
+        m(decoder_input_ids=inp.cuda(), decoder_inputs_embeds=E, **kw)
+
+
 def test_training_step_gradients_do_not_depend_on_stream_overlap(M):
     """The eager training step puts every weight-gradient kernel (and the embedding-table / LayerNorm parameter sums) on a side stream and joins
     it once per step: the gradients it leaves in the flat buffer must equal those of the same step issued on ONE stream (fp32 atomics reorder,
