@@ -288,6 +288,55 @@ __device__ float topp_threshold_from_list(const float* cval, const int* cidx, in
     return fmaxf(t, t_k);
 }
 
+// TopPLogitsWarper over an arbitrarily large kept set (no top-k, or a top-k set too large for the list form above): the smallest kept VALUE
+// among the entries >= t_k of x at temperature 1/invt. HF keeps a token iff the probability mass ranked strictly above it is < top_p
+// (TF5 generation/logits_process.py TopPLogitsWarper: ascending sort, drop cumulative <= 1 - top_p), i.e. the minimal top set whose mass reaches
+// top_p. Radix select on the order-preserving integer image, 4 passes of 8 bits, each pass histogramming probability MASS per digit (fp32 LDS
+// atomics); entries equal to the threshold value are all kept. Scratch: histf [256], sf [2], su [2] in LDS. Works for any blockDim.
+__device__ float topp_threshold_mass(const float* x, int V, float t_k, float top_p, float invt, float* histf, float* sf, unsigned* su) {
+    const int nt = blockDim.x;
+    if (threadIdx.x == 0) { su[0] = 0u; sf[0] = 0.f; }
+    __syncthreads();
+    unsigned lm = 0u;
+    for (int v = threadIdx.x; v < V; v += nt) { const float a = x[v]; if (a >= t_k) { const unsigned o = f2ord(a * invt); lm = o > lm ? o : lm; } }
+    atomicMax(&su[0], lm);
+    __syncthreads();
+    const float mx = ord2f(su[0]);
+    float z = 0.f;
+    for (int v = threadIdx.x; v < V; v += nt) { const float a = x[v]; if (a >= t_k) z += __expf(a * invt - mx); }
+    z = group_sum<64>(z);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sf[0], z);
+    __syncthreads();
+    const float target = top_p * sf[0];
+    unsigned prefix = 0u, mask = 0u;
+    float above = 0.f;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 256; i += nt) histf[i] = 0.f;
+        __syncthreads();
+        for (int v = threadIdx.x; v < V; v += nt) {
+            const float a = x[v];
+            if (!(a >= t_k)) continue;
+            const unsigned o = f2ord(a);
+            if ((o & mask) == prefix) atomicAdd(&histf[(o >> shift) & 255u], __expf(a * invt - mx));
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float acc = above;
+            int d = 255;
+            for (; d > 0; --d) { if (acc + histf[d] >= target) break; acc += histf[d]; }
+            su[1] = (unsigned)d; sf[1] = acc;
+        }
+        __syncthreads();
+        prefix |= su[1] << shift;
+        mask |= 255u << shift;
+        above = sf[1];
+    }
+    __syncthreads();
+    return fmaxf(ord2f(prefix), t_k);
+}
+
 __global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __restrict__ logits, long ld, int V, int k, float top_p, float invt,
                                                              float* __restrict__ thr) {
     __shared__ unsigned hist[256];
@@ -296,9 +345,11 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __rest
     __shared__ int cidx[1024];
     __shared__ int ncand;
     __shared__ unsigned tmin;
+    __shared__ float histf[256];
+    __shared__ float sf[2];
     const float* x = logits + (long)blockIdx.x * ld;
-    float t = kth_largest(x, V, k < V ? k : V, hist, bc);
-    if (top_p < 1.0f) {                                          // top-p on top of the top-k set (<= 1024 entries, else top-k only)
+    float t = (k > 0 && k < V) ? kth_largest(x, V, k, hist, bc) : -INFINITY;
+    if (top_p < 1.0f) {                                          // top-p on top of the top-k set: list form up to 1024 entries, mass radix select beyond
         if (threadIdx.x == 0) ncand = 0;
         __syncthreads();
         for (int v = threadIdx.x; v < V; v += 256) {
@@ -308,12 +359,13 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __rest
         __syncthreads();
         const int n = ncand;
         if (n <= 1024) t = topp_threshold_from_list(cval, cidx, n, t, top_p, invt, &tmin);
+        else t = topp_threshold_mass(x, V, t, top_p, invt, histf, sf, bc);
     }
     if (threadIdx.x == 0) thr[blockIdx.x] = t;
 }
 // thr[r] = the value below which TopKLogitsWarper(k) followed by TopPLogitsWarper(top_p) (at the given temperature) remove row r's entries
 extern "C" int cxr_topk_threshold(const float* logits, long ld, long R, int V, int k, float top_p, float temperature, float* thr, hipStream_t stream) {
-    if (R <= 0 || V <= 0 || k <= 0 || !(top_p > 0.f) || temperature <= 0.f) return CXR_ERR_ARG;
+    if (R <= 0 || V <= 0 || (k <= 0 && !(top_p < 1.f)) || !(top_p > 0.f) || temperature <= 0.f) return CXR_ERR_ARG;      // k <= 0: no top-k (top-p only)
     CXR_LAUNCH(topk_threshold_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, ld, V, k, top_p, 1.0f / temperature, thr);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
@@ -433,7 +485,7 @@ extern "C" int cxr_select_token(const float* logits, long ld, long R, int V, int
     if (R <= 0 || V <= 0 || next_stride <= 0 || (mode == 1 && (!u || temperature <= 0.f || !(top_p > 0.f)))) return CXR_ERR_ARG;
     if (n_sample < 0 || n_sample > R) n_sample = (int)R;                      // rows [0, n_sample) sample, rows [n_sample, R) take the argmax (mode 1)
     if (mode == 1 && n_sample < R && !(!margin && (size_t)V * sizeof(float) <= 130 * 1024)) return CXR_ERR_ARG;
-    if (mode == 1 && top_p < 1.0f && !(top_k > 0 && top_k <= 256 && !margin && (size_t)V * sizeof(float) <= 130 * 1024)) return CXR_ERR_ARG;
+    if (mode == 1 && top_p < 1.0f && !(!margin && (size_t)V * sizeof(float) <= 130 * 1024)) return CXR_ERR_ARG;       // top-p lives in the row-in-LDS kernel
     if (mode == 1 && !margin && (size_t)V * sizeof(float) <= 130 * 1024) {           // sampling: row-resident-in-LDS kernel
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)sample_topk_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
@@ -611,6 +663,12 @@ __global__ __launch_bounds__(1024) void sample_topk_lds_kernel(const float* __re
             __syncthreads();
         }
         t = ord2f(prefix);
+    }
+    if (top_p < 1.0f) {                                  // nucleus over a large kept set (no top-k, top-k > 256, or > 1024 ties): mass radix select
+        __shared__ float histf[256];
+        __shared__ float sf[2];
+        __syncthreads();
+        t = topp_threshold_mass(row, V, t, top_p, invt, histf, sf, bc);
     }
     // max of the kept entries
     float mx = -INFINITY;

@@ -178,8 +178,6 @@ class GenerationMixin:
         if self.kind == "longitudinal" and mask_token_id is None:
             raise ValueError("mask_token_id is required for the longitudinal model")
         top_p = 1.0 if top_p is None else float(top_p)
-        if do_sample and top_p < 1.0 and not (top_k and 0 < int(top_k) <= 256):
-            raise NotImplementedError("top_p < 1 is applied on top of a top-k set of at most 256 entries (the reference samples with top_k=50)")
         with torch.no_grad():
             if encoder_outputs is None:
                 encoder_outputs = self._encode(pixel_values)
@@ -382,10 +380,10 @@ class GenerationMixin:
         sc = logits[:, first:, :]
         if temperature is not None and float(temperature) != 1.0:
             sc = sc / float(temperature)
-        if top_k:
+        if top_k or top_p < 1.0:
             with torch.no_grad():                                            # sc is already temperature-scaled: warpers see temperature 1
                 flat = sc.detach().reshape(-1, sc.shape[-1]).contiguous()
-                thr = ops.topk_threshold(flat, int(top_k), top_p, 1.0).view(sc.shape[0], sc.shape[1], 1)
+                thr = ops.topk_threshold(flat, int(top_k or 0), top_p, 1.0).view(sc.shape[0], sc.shape[1], 1)
             sc = sc.masked_fill(sc < thr, float("-inf"))                    # TopK (+ TopP) LogitsWarper semantics (ties at the threshold kept)
         return tuple(sc[:, t, :] for t in range(sc.shape[1]))
 

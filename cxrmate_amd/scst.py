@@ -68,7 +68,7 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         if float(temperature) != 1.0:
             raise NotImplementedError("temperature != 1 (the reference trains with 1.0)")
         flat = sc.reshape(-1, V) if sc.is_contiguous() else sc.contiguous().view(-1, V)
-        thr = ops.topk_threshold(flat, top_k, top_p, temperature) if top_k else None
+        thr = ops.topk_threshold(flat, int(top_k or 0), top_p, temperature) if (top_k or top_p < 1.0) else None
         labels = sampled.reshape(-1)
         w = ops.ce_weights(labels, pad, mode=1, reward=adv, T=n_new)
         loss, _, dl = ops.softmax_ce(flat, labels, pad, w, thr=thr)

@@ -219,7 +219,8 @@ int cxr_softmax_ce(const void* logits, long ld, const long* labels, long ignore_
 int cxr_ce_weights(const long* labels, long R, long ignore_index, int mode, const float* reward, int T, float* row_w, hipStream_t stream);
 int cxr_ce_reduce(const float* row_loss, const float* row_w, long R, float* loss, hipStream_t stream);
 int cxr_topk_threshold(const float* logits, long ld, long R, int V, int k, float top_p, float temperature, float* thr, hipStream_t stream);
-                       /* thr[r] = value below which TopKLogitsWarper(k) then TopPLogitsWarper(top_p) at `temperature` remove entries (top_p = 1: top-k only) */
+                       /* thr[r] = value below which TopKLogitsWarper(k) then TopPLogitsWarper(top_p) at `temperature` remove entries (top_p = 1: top-k only;
+                          k <= 0: top-p only, over the whole vocabulary) */
 int cxr_select_token(const float* logits, long ld, long R, int V, int mode, float temperature, int top_k, float top_p, const float* u, long* next,
                      long next_stride, int* unfinished, long eos, long pad, float* margin, int n_sample, hipStream_t stream);
                      /* next[r * next_stride] (e.g. a column of the running id buffer); mode 1 with n_sample < R: rows [0, n_sample) are sampled,

@@ -642,6 +642,41 @@ def test_batched_layout_and_mask_launches_equal_their_single_launch_forms(ops):
     close(dg1, dg0, rtol=1e-5, atol=1e-4, what="dgamma via side-stream row sum"); close(db1, db0, rtol=1e-5, atol=1e-4, what="dbeta via side-stream row sum")
 
 
+def test_top_p_without_top_k_matches_hf_warper_semantics(ops):
+    """Nucleus filtering over the whole vocabulary (no top-k): the kept set is the minimal top set whose softmax mass reaches top_p
+    (TF5 generation/logits_process.py TopPLogitsWarper), and sampling draws only from it."""
+    R, V = 12, 30000
+    for scale, top_p, temp in ((3.0, 0.9, 1.0), (0.5, 0.5, 1.0), (6.0, 0.95, 0.7), (0.1, 0.3, 1.0)):
+        logits = dev(rnd(R, V, seed=int(scale * 10)) * scale)
+        thr = ops.topk_threshold(logits, 0, top_p, temp)
+        sc = (logits / temp).double()
+        srt, idx = torch.sort(sc, dim=-1, descending=False)
+        cum = srt.softmax(-1).cumsum(-1)
+        remove = cum <= (1 - top_p)
+        remove[:, -1:] = False
+        ref_keep = torch.zeros_like(remove).scatter(1, idx, ~remove)
+        keep = logits >= thr[:, None]
+        # fp32 mass sums vs the float64 reference may move the boundary by a token or two when the cumulative mass sits within rounding of top_p
+        diff = (keep != ref_keep).sum(1)
+        assert int(diff.max()) <= 2, diff
+        assert bool((keep.sum(1) >= 1).all())
+        u = torch.rand(R, device="cuda")
+        tok = ops.select_token(logits, mode=1, temperature=temp, top_k=0, u=u, top_p=top_p)
+        tok = tok[0] if isinstance(tok, tuple) else tok
+        assert bool(keep.gather(1, tok[:, None]).all())                          # every sample lies inside the nucleus
+    # large top-k (> the 256-entry list path) + top-p takes the same route
+    logits = dev(rnd(R, V, seed=3) * 2)
+    thr = ops.topk_threshold(logits, 2000, 0.8, 1.0)
+    kth = torch.topk(logits, 2000)[0][:, -1]
+    assert bool((thr >= kth).all())
+    sc = logits.double().masked_fill(logits < kth[:, None], float("-inf"))
+    srt, idx = torch.sort(sc, dim=-1, descending=False)
+    remove = srt.softmax(-1).cumsum(-1) <= 0.2
+    remove[:, -1:] = False
+    ref_keep = torch.zeros_like(remove).scatter(1, idx, ~remove) & (logits >= kth[:, None])
+    assert int(((logits >= thr[:, None]) != ref_keep).sum(1).max()) <= 2
+
+
 DWPROJ_SHAPES = [(3, 64, 24, 24, 0), (3, 192, 12, 12, 0), (3, 384, 6, 6, 1), (2, 64, 7, 5, 1), (2, 128, 9, 20, 0), (32, 384, 24, 24, 1), (8, 64, 96, 96, 0)]
 
 
