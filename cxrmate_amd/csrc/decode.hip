@@ -74,7 +74,8 @@ extern "C" int cxr_topk_rows(const float* x, long ld, long R, int n, int K, floa
 // chip-wide, straight from HBM/L2 into MFMA B fragments (no LDS round trip); a workgroup owns 16 output columns, its 4 waves split K
 // and combine through LDS; all of a wave's loads are issued before its first MFMA (deep memory-level parallelism instead of occupancy).
 struct SkinnyProb { const bf16_t* W; const float* bias; void* C; long ldw, ldc; int N;
-                    const float* lr_t; const bf16_t* lr_B; };     // optional rank-8 term: C[m,n] += sum_r lr_t[m][r] * lr_B[n][r]  (LoRA, train mode)
+                    const float* lr_t; const bf16_t* lr_B;        // optional rank-8 term: C[m,n] += sum_r lr_t[m][r] * lr_B[n][r]  (LoRA, train mode)
+                    const bf16_t* lr_A; uint32_t lr_site; };      // lr_A [8,K] given (LNA kernels): t = lr_scale * dropout(LN(a)) . lr_A^T is computed HERE
 struct SkinnyArgs {
     const bf16_t* A; long lda;
     const bf16_t* residual; long ldr;      // added to problem 0 only
@@ -88,6 +89,8 @@ struct SkinnyArgs {
     //   lnR_*: the residual operand is LayerNorm(raw residual) with the published statistics.
     const float* lnA_g; const float* lnA_b; float lnA_eps; float* lnA_stats;
     const float* lnR_stats; const float* lnR_g; const float* lnR_b;
+    // in-kernel LoRA down-projection (SkinnyProb::lr_A): dropout of the branch input keyed by (lr_seed, site, row, position lr_t) as in lora.hip
+    const uint32_t* lr_seed; uint32_t lr_thr16; float lr_inv, lr_scale; int lr_t;
 };
 
 __device__ __forceinline__ float bfv(const bf16x8_t& v, int j) {
@@ -99,6 +102,7 @@ __device__ __forceinline__ float bfv(const bf16x8_t& v, int j) {
 template <int MT, bool LNA, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g) {
     __shared__ float red[NW][MT][64][4];
+    __shared__ float redl[LNA ? NW : 1][LNA ? MT : 1][64][4];          // LoRA down-projection partials (rank 8 = columns 0..7 of a 16-wide tile)
     __shared__ float lnbuf[2][4][MT][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // grouped launch: blocks [0, N0/16) -> problem 0, next N1/16 -> problem 1, ... (q / k / v projections share A and one launch)
@@ -138,11 +142,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g
                 rrstd[t][r] = (lnr && m < g.M) ? g.lnR_stats[2 * m + 1] : 1.f;
             }
 #pragma unroll
-        for (int r8 = 0; r8 < 8; ++r8) lrB[r8] = (P.lr_t && n < P.N) ? bf2f(P.lr_B[(long)n * 8 + r8]) : 0.f;
+        for (int r8 = 0; r8 < 8; ++r8) lrB[r8] = ((P.lr_t || P.lr_A) && n < P.N) ? bf2f(P.lr_B[(long)n * 8 + r8]) : 0.f;
     }
-    f32x4_t acc[MT];
+    f32x4_t acc[MT], accl[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MT; ++t) { acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accl[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    const bool lora_in = LNA && P.lr_A != nullptr;
     const bf16_t* ap[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -210,6 +215,34 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g
                     af[t][s2] = __builtin_bit_cast(bf16x8_t, o);
                 }
             }
+            if (lora_in) {
+                // rank-8 LoRA down-projection of the SAME normalised rows, with the branch's own input dropout: one more 16-wide MFMA tile per
+                // k-step whose B operand is lr_A (rows 0..7; lanes 8..15 of a row group feed zeros) -- replaces a separate launch per layer
+                const uint32_t lseed = g.lr_thr16 ? *g.lr_seed : 0u;
+#pragma unroll
+                for (int s2 = 0; s2 < KB; ++s2) {
+                    const int kcol = k0 + s2 * 32 + fq * 8;
+                    bf16x8_t wl = __builtin_bit_cast(bf16x8_t, s16x8_t{0, 0, 0, 0, 0, 0, 0, 0});
+                    if (fr < 8) wl = *reinterpret_cast<const bf16x8_t*>(P.lr_A + (long)fr * g.K + kcol);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        bf16x8_t ad = af[t][s2];
+                        if (g.lr_thr16) {
+                            int m = t * 16 + fr; m = m < g.M ? m : g.M - 1;
+                            const uint32_t key = dropout_row_key(lseed, P.lr_site, (uint32_t)m, (uint32_t)g.lr_t);
+                            s16x8_t o;
+#pragma unroll
+                            for (int j = 0; j < 8; j += 2) {
+                                const uint32_t bits = dropout_pair_bits(key, (uint32_t)(kcol + j) >> 1);
+                                o[j] = (short)f2bf((bits & 0xffffu) >= g.lr_thr16 ? bfv(ad, j) * g.lr_inv : 0.f);
+                                o[j + 1] = (short)f2bf((bits >> 16) >= g.lr_thr16 ? bfv(ad, j + 1) * g.lr_inv : 0.f);
+                            }
+                            ad = __builtin_bit_cast(bf16x8_t, o);
+                        }
+                        accl[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad, wl, accl[t], 0, 0, 0);
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int s2 = 0; s2 < KB; ++s2) {
@@ -222,7 +255,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][t][lane][r] = acc[t][r];
+        for (int r = 0; r < 4; ++r) {
+            red[wave][t][lane][r] = acc[t][r];
+            if (LNA) { if (lora_in) redl[wave][t][lane][r] = accl[t][r]; }
+        }
     __syncthreads();
     if (wave != 0 || n >= P.N) return;
 #pragma unroll
@@ -237,6 +273,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g
             if (P.lr_t) {
 #pragma unroll
                 for (int r8 = 0; r8 < 8; ++r8) v += P.lr_t[m * 8 + r8] * lrB[r8];
+            }
+            if (LNA) {
+                if (lora_in) {                                   // t[m][r8] sits in column r8 of the LoRA tile: lane fq*16 + r8, element r
+                    float la = 0.f;
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        float tv = 0.f;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) tv += redl[w][t][fq * 16 + r8][r];
+                        la += tv * lrB[r8];
+                    }
+                    v += la * g.lr_scale;
+                }
             }
             if (g.act == 1) v = gelu_f(v);
             if (g.drop_thr16)
@@ -278,7 +327,8 @@ extern "C" int cxr_gemm_skinny_bf16(const void* A, long lda, const void* W, long
     g.lnR_stats = lnR_stats; g.lnR_g = lnR_gamma; g.lnR_b = lnR_beta;
     g.A = (const bf16_t*)A; g.lda = lda; g.residual = (const bf16_t*)residual; g.ldr = ldr;
     g.p[0].W = (const bf16_t*)W; g.p[0].bias = bias; g.p[0].C = C; g.p[0].ldw = ldw; g.p[0].ldc = ldc; g.p[0].N = N;
-    g.p[0].lr_t = nullptr; g.p[0].lr_B = nullptr;
+    g.p[0].lr_t = nullptr; g.p[0].lr_B = nullptr; g.p[0].lr_A = nullptr; g.p[0].lr_site = 0;
+    g.lr_seed = nullptr; g.lr_thr16 = 0u; g.lr_inv = 1.f; g.lr_scale = 0.f; g.lr_t = 0;
     g.p[1] = g.p[0]; g.p[2] = g.p[0];
     g.nprob = 1; g.M = M; g.K = K; g.act = act; g.out_f32 = out_f32;
     return launch_skinny(g, stream);
@@ -288,9 +338,13 @@ extern "C" int cxr_gemm_skinny_bf16(const void* A, long lda, const void* W, long
 extern "C" int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, const float* b0, void* C0, long ldc0, const void* W1,
                                      const float* b1, void* C1, long ldc1, const void* W2, const float* b2, void* C2, long ldc2, long ldw,
                                      int M, int N, int K, const float* lnA_gamma, const float* lnA_beta, float lnA_eps, float* lnA_stats,
-                                     const float* lr_t0, const void* lr_B0, const float* lr_t1, const void* lr_B1, hipStream_t stream) {
+                                     const float* lr_t0, const void* lr_B0, const float* lr_t1, const void* lr_B1, const void* lr_A0, const void* lr_A1,
+                                     float lr_p, const unsigned int* lr_seed, unsigned int lr_site0, unsigned int lr_site1, int lr_tpos, float lr_scale,
+                                     hipStream_t stream) {
     if (M <= 0 || M > 64 || N <= 0 || K <= 0 || (K % 128) || (lda % 8) || (ldw % 8)) return CXR_ERR_ARG;
+    if ((lr_A0 || lr_A1) && (!lnA_gamma || lr_p < 0.f || lr_p >= 1.f || (lr_p > 0.f && !lr_seed) || (lr_A0 && !lr_B0) || (lr_A1 && !lr_B1))) return CXR_ERR_ARG;
     SkinnyArgs g;
+    g.lr_seed = lr_seed; g.lr_thr16 = lr_p > 0.f ? dropout_thr16(lr_p) : 0u; g.lr_inv = 1.0f / (1.0f - lr_p); g.lr_scale = lr_scale; g.lr_t = lr_tpos;
     g.drop_seed = nullptr; g.drop_site = 0; g.drop_thr16 = 0; g.drop_inv = 1.f; g.drop_t = 0;
     if (lnA_gamma && !lnA_beta) return CXR_ERR_ARG;
     g.lnA_g = lnA_gamma; g.lnA_b = lnA_beta; g.lnA_eps = lnA_eps; g.lnA_stats = lnA_stats;
@@ -298,8 +352,9 @@ extern "C" int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, co
     g.A = (const bf16_t*)A; g.lda = lda; g.residual = nullptr; g.ldr = 0;
     const void* W[3] = {W0, W1, W2}; const float* b[3] = {b0, b1, b2}; void* C[3] = {C0, C1, C2}; const long ldc[3] = {ldc0, ldc1, ldc2};
     for (int i = 0; i < 3; ++i) { g.p[i].W = (const bf16_t*)W[i]; g.p[i].bias = b[i]; g.p[i].C = C[i]; g.p[i].ldw = ldw; g.p[i].ldc = ldc[i]; g.p[i].N = N;
-                                  g.p[i].lr_t = nullptr; g.p[i].lr_B = nullptr; }
+                                  g.p[i].lr_t = nullptr; g.p[i].lr_B = nullptr; g.p[i].lr_A = nullptr; g.p[i].lr_site = 0; }
     g.p[0].lr_t = lr_t0; g.p[0].lr_B = (const bf16_t*)lr_B0; g.p[1].lr_t = lr_t1; g.p[1].lr_B = (const bf16_t*)lr_B1;     // LoRA on query / key
+    g.p[0].lr_A = (const bf16_t*)lr_A0; g.p[0].lr_site = lr_site0; g.p[1].lr_A = (const bf16_t*)lr_A1; g.p[1].lr_site = lr_site1;
     g.nprob = 3; g.M = M; g.K = K; g.act = 0; g.out_f32 = 0;
     return launch_skinny(g, stream);
 }

@@ -27,6 +27,7 @@ SITE_EMBED = 1
 
 
 _CROSS_KV_FUSED = os.environ.get("CXR_CROSS_KV_FUSED", "1") != "0"      # A/B switch: 0 = one K / V GEMM per layer
+_LORA_IN_KERNEL = os.environ.get("CXR_LORA_IN_KERNEL", "1") != "0"        # A/B switch: 0 = separate LoRA down-projection launch per decode layer
 _SELF_QKV_FUSED = os.environ.get("CXR_SELF_QKV_FUSED", "1") != "0"      # A/B switch: 0 = separate query / key / value GEMMs
 
 
@@ -634,17 +635,23 @@ class BertEngine:
         for l in range(cfg.num_hidden_layers):
             lp = p + f"bert.encoder.layer.{l}."
             wv, bv = self._lin(lp + "attention.self.value")
-            lq = lk = None
+            lq = lk = lin_ = None
             if lora_tr:              # train mode: base weights; the rank-8 branch on dropout(LayerNorm(cur)) enters through the GEMM epilogue
                 wq, bq, aq, bq_l = self._lora_parts(lp + "attention.self.query"); wk, bk, ak, bk_l = self._lora_parts(lp + "attention.self.key")
                 pl = float(cfg.lora_dropout)
-                tq, tk = ops.lora_down(cur, aq, drop0=(pl, _site(l, 5)), W1=ak, drop1=(pl, _site(l, 6)), rows_per_b=1, tpos0=past, seed=seed,
-                                       ln=None if cur_ln is None else (cur_ln[0], cur_ln[1], eps), scale=cfg.lora_alpha / cfg.lora_r)
-                lq, lk = (tq, bq_l), (tk, bk_l)
+                if cur_ln is not None and _LORA_IN_KERNEL:
+                    # (layers >= 1: the input is a LayerNorm the GEMM applies itself) both down-projections inside the q/k/v launch
+                    lin_ = dict(A0=aq, B0=bq_l, A1=ak, B1=bk_l, p=pl, seed=seed, site0=_site(l, 5), site1=_site(l, 6), tpos=past,
+                                scale=cfg.lora_alpha / cfg.lora_r)
+                else:
+                    tq, tk = ops.lora_down(cur, aq, drop0=(pl, _site(l, 5)), W1=ak, drop1=(pl, _site(l, 6)), rows_per_b=1, tpos0=past, seed=seed,
+                                           ln=None if cur_ln is None else (cur_ln[0], cur_ln[1], eps), scale=cfg.lora_alpha / cfg.lora_r)
+                    lq, lk = (tq, bq_l), (tk, bk_l)
             else:
                 wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key")
             q = torch.empty((B, D), dtype=BF16, device=dev)
-            ops.gemm_skinny3(cur, wq, bq, q, wk, bk, cache.k[l][:, past, :], wv, bv, cache.v[l][:, past, :], ln_a=ln_a(cur_ln), lora0=lq, lora1=lk)
+            ops.gemm_skinny3(cur, wq, bq, q, wk, bk, cache.k[l][:, past, :], wv, bv, cache.v[l][:, past, :], ln_a=ln_a(cur_ln), lora0=lq, lora1=lk,
+                             lora_in=lin_)
             ctx = ops.attention_decode(q, cache.k[l][:, :past + 1, :], cache.v[l][:, :past + 1, :], nh, scale, kpm=attn_mask_full,
                                        drop=(pa, seed, _site(l, 0), past))
             wo, bo = self._lin(lp + "attention.output.dense")

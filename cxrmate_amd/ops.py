@@ -928,14 +928,23 @@ def attention_decode(q, k, v, heads, scale, kpm=None, out=None, drop=None, head_
     return out
 
 
-def gemm_skinny3(a, w0, b0, c0, w1, b1, c1, w2, b2, c2, ln_a=None, lora0=None, lora1=None):
-    """c_i = a @ w_i^T + b_i for three equally-shaped projections in ONE launch (outputs may be strided KV-cache rows)."""
+def gemm_skinny3(a, w0, b0, c0, w1, b1, c1, w2, b2, c2, ln_a=None, lora0=None, lora1=None, lora_in=None):
+    """c_i = a @ w_i^T + b_i for three equally-shaped projections in ONE launch (outputs may be strided KV-cache rows).
+    lora0 / lora1 = (t fp32 [M,8], B bf16 [N,8]): rank-8 term of problem 0 / 1 with a precomputed down-projection t; or
+    lora_in = dict(A0, B0, A1, B1, p, seed, site0, site1, tpos, scale) (needs ln_a): the down-projections are computed inside the kernel."""
     M, K = a.shape
     N = w0.shape[0]
     assert w0.stride(0) == w1.stride(0) == w2.stride(0)
+    li = lora_in
+    if li is not None:
+        assert ln_a is not None and li["A0"].is_contiguous() and li["A1"].is_contiguous()
+        extra = (None, _p(li["B0"]), None, _p(li["B1"]), _p(li["A0"]), _p(li["A1"]), float(li["p"]), _p(li["seed"]), int(li["site0"]), int(li["site1"]),
+                 int(li["tpos"]), float(li["scale"]))
+    else:
+        extra = (*((_p(lora0[0]), _p(lora0[1])) if lora0 else (None, None)), *((_p(lora1[0]), _p(lora1[1])) if lora1 else (None, None)),
+                 None, None, 0.0, None, 0, 0, 0, 0.0)
     LIB.call("cxr_gemm_skinny3_bf16", _p(a), a.stride(0), _p(w0), _p(b0), _p(c0), c0.stride(0), _p(w1), _p(b1), _p(c1), c1.stride(0),
-             _p(w2), _p(b2), _p(c2), c2.stride(0), w0.stride(0), M, N, K, *_ln_args(ln_a),
-             *((_p(lora0[0]), _p(lora0[1])) if lora0 else (None, None)), *((_p(lora1[0]), _p(lora1[1])) if lora1 else (None, None)), _s())
+             _p(w2), _p(b2), _p(c2), c2.stride(0), w0.stride(0), M, N, K, *_ln_args(ln_a), *extra, _s())
 
 
 # ------------------------------------------------------------------------------------------------ LoRA branch (train mode)

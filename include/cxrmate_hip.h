@@ -243,9 +243,13 @@ int cxr_gemm_skinny_bf16(const void* A, long lda, const void* W, long ldw, void*
 int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, const float* b0, void* C0, long ldc0, const void* W1, const float* b1,
                           void* C1, long ldc1, const void* W2, const float* b2, void* C2, long ldc2, long ldw, int M, int N, int K,
                           const float* lnA_gamma, const float* lnA_beta, float lnA_eps, float* lnA_stats, const float* lr_t0, const void* lr_B0,
-                          const float* lr_t1, const void* lr_B1, hipStream_t stream);
+                          const float* lr_t1, const void* lr_B1, const void* lr_A0, const void* lr_A1, float lr_p, const unsigned int* lr_seed,
+                          unsigned int lr_site0, unsigned int lr_site1, int lr_tpos, float lr_scale, hipStream_t stream);
                           /* q / k / v projections of one decode step in a single launch; lr_t_i fp32 [M][8] / lr_B_i bf16 [N][8]: optional
-                             rank-8 LoRA term of problem i (t from cxr_lora_down_bf16) */
+                             rank-8 LoRA term of problem i (t from cxr_lora_down_bf16) 
+                             lr_A_i bf16 [8][K] given (with lnA_gamma): the down-projection t_i = lr_scale * dropout(LN(A)) . lr_A_i^T is computed
+                             inside the kernel (input dropout lr_p keyed by (lr_seed, lr_site_i, row, lr_tpos) as in cxr_lora_down_bf16); lr_t_i is
+                             then not read */
 int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs, long v_bs,
                          long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, int kv_share, float* ws, long kv_hs, float drop_p,
                          const unsigned int* drop_seed, unsigned int drop_site, int drop_t, hipStream_t stream);
