@@ -102,7 +102,7 @@ __device__ __forceinline__ float bfv(const bf16x8_t& v, int j) {
 template <int MT, bool LNA, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g) {
     __shared__ float red[NW][MT][64][4];
-    __shared__ float redl[LNA ? NW : 1][LNA ? MT : 1][64][4];          // LoRA down-projection partials (rank 8 = columns 0..7 of a 16-wide tile)
+    __shared__ float redl[NW == 4 ? NW : 1][NW == 4 ? MT : 1][64][4];  // LoRA down-projection partials (rank 8 = columns 0..7 of a 16-wide tile; K = 768 kernels)
     __shared__ float lnbuf[2][4][MT][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // grouped launch: blocks [0, N0/16) -> problem 0, next N1/16 -> problem 1, ... (q / k / v projections share A and one launch)
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g
     f32x4_t acc[MT], accl[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) { acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accl[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-    const bool lora_in = LNA && P.lr_A != nullptr;
+    const bool lora_in = NW == 4 && P.lr_A != nullptr;
     const bf16_t* ap[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -215,32 +215,33 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g
                     af[t][s2] = __builtin_bit_cast(bf16x8_t, o);
                 }
             }
-            if (lora_in) {
-                // rank-8 LoRA down-projection of the SAME normalised rows, with the branch's own input dropout: one more 16-wide MFMA tile per
-                // k-step whose B operand is lr_A (rows 0..7; lanes 8..15 of a row group feed zeros) -- replaces a separate launch per layer
-                const uint32_t lseed = g.lr_thr16 ? *g.lr_seed : 0u;
+        }
+        if (lora_in) {
+            // rank-8 LoRA down-projection of the SAME normalised rows, with the branch's own input dropout: one more 16-wide MFMA tile per
+            // k-step whose B operand is lr_A (rows 0..7; lanes 8..15 of a row group feed zeros) -- replaces a separate launch per layer
+            const uint32_t lseed = g.lr_thr16 ? *g.lr_seed : 0u;
 #pragma unroll
-                for (int s2 = 0; s2 < KB; ++s2) {
-                    const int kcol = k0 + s2 * 32 + fq * 8;
-                    bf16x8_t wl = __builtin_bit_cast(bf16x8_t, s16x8_t{0, 0, 0, 0, 0, 0, 0, 0});
-                    if (fr < 8) wl = *reinterpret_cast<const bf16x8_t*>(P.lr_A + (long)fr * g.K + kcol);
+            for (int s2 = 0; s2 < KB; ++s2) {
+                if (kb + s2 * 32 >= kslice) continue;
+                const int kcol = k0 + kb + s2 * 32 + fq * 8;
+                bf16x8_t wl = __builtin_bit_cast(bf16x8_t, s16x8_t{0, 0, 0, 0, 0, 0, 0, 0});
+                if (fr < 8) wl = *reinterpret_cast<const bf16x8_t*>(P.lr_A + (long)fr * g.K + kcol);
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) {
-                        bf16x8_t ad = af[t][s2];
-                        if (g.lr_thr16) {
-                            int m = t * 16 + fr; m = m < g.M ? m : g.M - 1;
-                            const uint32_t key = dropout_row_key(lseed, P.lr_site, (uint32_t)m, (uint32_t)g.lr_t);
-                            s16x8_t o;
+                for (int t = 0; t < MT; ++t) {
+                    bf16x8_t ad = af[t][s2];
+                    if (g.lr_thr16) {
+                        int m = t * 16 + fr; m = m < g.M ? m : g.M - 1;
+                        const uint32_t key = dropout_row_key(lseed, P.lr_site, (uint32_t)m, (uint32_t)g.lr_t);
+                        s16x8_t o;
 #pragma unroll
-                            for (int j = 0; j < 8; j += 2) {
-                                const uint32_t bits = dropout_pair_bits(key, (uint32_t)(kcol + j) >> 1);
-                                o[j] = (short)f2bf((bits & 0xffffu) >= g.lr_thr16 ? bfv(ad, j) * g.lr_inv : 0.f);
-                                o[j + 1] = (short)f2bf((bits >> 16) >= g.lr_thr16 ? bfv(ad, j + 1) * g.lr_inv : 0.f);
-                            }
-                            ad = __builtin_bit_cast(bf16x8_t, o);
+                        for (int j = 0; j < 8; j += 2) {
+                            const uint32_t bits = dropout_pair_bits(key, (uint32_t)(kcol + j) >> 1);
+                            o[j] = (short)f2bf((bits & 0xffffu) >= g.lr_thr16 ? bfv(ad, j) * g.lr_inv : 0.f);
+                            o[j + 1] = (short)f2bf((bits >> 16) >= g.lr_thr16 ? bfv(ad, j + 1) * g.lr_inv : 0.f);
                         }
-                        accl[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad, wl, accl[t], 0, 0, 0);
+                        ad = __builtin_bit_cast(bf16x8_t, o);
                     }
+                    accl[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad, wl, accl[t], 0, 0, 0);
                 }
             }
         }
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             red[wave][t][lane][r] = acc[t][r];
-            if (LNA) { if (lora_in) redl[wave][t][lane][r] = accl[t][r]; }
+            if (NW == 4) { if (lora_in) redl[wave][t][lane][r] = accl[t][r]; }
         }
     __syncthreads();
     if (wave != 0 || n >= P.N) return;
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g
 #pragma unroll
                 for (int r8 = 0; r8 < 8; ++r8) v += P.lr_t[m * 8 + r8] * lrB[r8];
             }
-            if (LNA) {
+            if (NW == 4) {
                 if (lora_in) {                                   // t[m][r8] sits in column r8 of the LoRA tile: lane fq*16 + r8, element r
                     float la = 0.f;
 #pragma unroll
@@ -342,7 +343,7 @@ extern "C" int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, co
                                      float lr_p, const unsigned int* lr_seed, unsigned int lr_site0, unsigned int lr_site1, int lr_tpos, float lr_scale,
                                      hipStream_t stream) {
     if (M <= 0 || M > 64 || N <= 0 || K <= 0 || (K % 128) || (lda % 8) || (ldw % 8)) return CXR_ERR_ARG;
-    if ((lr_A0 || lr_A1) && (!lnA_gamma || lr_p < 0.f || lr_p >= 1.f || (lr_p > 0.f && !lr_seed) || (lr_A0 && !lr_B0) || (lr_A1 && !lr_B1))) return CXR_ERR_ARG;
+    if ((lr_A0 || lr_A1) && (K != 768 || lr_p < 0.f || lr_p >= 1.f || (lr_p > 0.f && !lr_seed) || (lr_A0 && !lr_B0) || (lr_A1 && !lr_B1))) return CXR_ERR_ARG;
     SkinnyArgs g;
     g.lr_seed = lr_seed; g.lr_thr16 = lr_p > 0.f ? dropout_thr16(lr_p) : 0u; g.lr_inv = 1.0f / (1.0f - lr_p); g.lr_scale = lr_scale; g.lr_t = lr_tpos;
     g.drop_seed = nullptr; g.drop_site = 0; g.drop_thr16 = 0; g.drop_inv = 1.f; g.drop_t = 0;

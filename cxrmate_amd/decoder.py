@@ -639,8 +639,8 @@ class BertEngine:
             if lora_tr:              # train mode: base weights; the rank-8 branch on dropout(LayerNorm(cur)) enters through the GEMM epilogue
                 wq, bq, aq, bq_l = self._lora_parts(lp + "attention.self.query"); wk, bk, ak, bk_l = self._lora_parts(lp + "attention.self.key")
                 pl = float(cfg.lora_dropout)
-                if cur_ln is not None and _LORA_IN_KERNEL:
-                    # (layers >= 1: the input is a LayerNorm the GEMM applies itself) both down-projections inside the q/k/v launch
+                if _LORA_IN_KERNEL and D == 768:
+                    # both down-projections inside the q/k/v launch (on the rows the GEMM holds in registers, after its LayerNorm if it applies one)
                     lin_ = dict(A0=aq, B0=bq_l, A1=ak, B1=bk_l, p=pl, seed=seed, site0=_site(l, 5), site1=_site(l, 6), tpos=past,
                                 scale=cfg.lora_alpha / cfg.lora_r)
                 else:

@@ -931,13 +931,13 @@ def attention_decode(q, k, v, heads, scale, kpm=None, out=None, drop=None, head_
 def gemm_skinny3(a, w0, b0, c0, w1, b1, c1, w2, b2, c2, ln_a=None, lora0=None, lora1=None, lora_in=None):
     """c_i = a @ w_i^T + b_i for three equally-shaped projections in ONE launch (outputs may be strided KV-cache rows).
     lora0 / lora1 = (t fp32 [M,8], B bf16 [N,8]): rank-8 term of problem 0 / 1 with a precomputed down-projection t; or
-    lora_in = dict(A0, B0, A1, B1, p, seed, site0, site1, tpos, scale) (needs ln_a): the down-projections are computed inside the kernel."""
+    lora_in = dict(A0, B0, A1, B1, p, seed, site0, site1, tpos, scale) (K = 768): the down-projections are computed inside the kernel."""
     M, K = a.shape
     N = w0.shape[0]
     assert w0.stride(0) == w1.stride(0) == w2.stride(0)
     li = lora_in
     if li is not None:
-        assert ln_a is not None and li["A0"].is_contiguous() and li["A1"].is_contiguous()
+        assert K == 768 and li["A0"].is_contiguous() and li["A1"].is_contiguous()
         extra = (None, _p(li["B0"]), None, _p(li["B1"]), _p(li["A0"]), _p(li["A1"]), float(li["p"]), _p(li["seed"]), int(li["site0"]), int(li["site1"]),
                  int(li["tpos"]), float(li["scale"]))
     else:

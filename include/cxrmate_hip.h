@@ -247,7 +247,7 @@ int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, const float* 
                           unsigned int lr_site0, unsigned int lr_site1, int lr_tpos, float lr_scale, hipStream_t stream);
                           /* q / k / v projections of one decode step in a single launch; lr_t_i fp32 [M][8] / lr_B_i bf16 [N][8]: optional
                              rank-8 LoRA term of problem i (t from cxr_lora_down_bf16) 
-                             lr_A_i bf16 [8][K] given (with lnA_gamma): the down-projection t_i = lr_scale * dropout(LN(A)) . lr_A_i^T is computed
+                             lr_A_i bf16 [8][K] given (K == 768): the down-projection t_i = lr_scale * dropout(LN(A)) . lr_A_i^T is computed
                              inside the kernel (input dropout lr_p keyed by (lr_seed, lr_site_i, row, lr_tpos) as in cxr_lora_down_bf16); lr_t_i is
                              then not read */
 int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs, long v_bs,
