@@ -118,11 +118,11 @@ def bert_param_shapes(cfg: BertConfig, prefix: str = "decoder.", storage_order: 
         # tied copies present in HF state dicts (TF5 models/bert/modeling_bert.py:778-781):
         out[c + "decoder.weight"] = (cfg.vocab_size, d)
         out[c + "decoder.bias"] = (cfg.vocab_size,)
-    if cfg.add_cross_attention and storage_order:       # (random initialisation iterates the HF order: storage_order=False)
+    if storage_order and (cfg.add_cross_attention or not cfg.lora_r):       # (random initialisation iterates the HF order: storage_order=False)
         # storage order only (names are unchanged): the cross-attention key / value projections of ALL layers sit back to back -- K0 V0 K1 V1 ...,
         # weights then biases -- so that the flat parameter / shadow / gradient buffers expose them as ONE [layers*2*d, d] matrix: every layer
         # projects the same encoder output, which makes them one GEMM forward, one for the encoder-output gradient and one for the weight gradient
-        front = cross_kv_keys(cfg, prefix, ".weight") + cross_kv_keys(cfg, prefix, ".bias")
+        front = (cross_kv_keys(cfg, prefix, ".weight") + cross_kv_keys(cfg, prefix, ".bias")) if cfg.add_cross_attention else []
         if not cfg.lora_r:
             # ... and the self-attention query / key / value of a layer (weights, then biases): one [3*d, d] projection of the layer input
             for l in range(cfg.num_hidden_layers):
