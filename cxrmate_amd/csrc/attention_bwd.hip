@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdArgs
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t Kr[64 * RS];
     __shared__ __attribute__((aligned(16))) bf16_t Kt[64 * TS];
     __shared__ __attribute__((aligned(16))) bf16_t Vr[64 * RS];
