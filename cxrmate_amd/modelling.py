@@ -148,8 +148,10 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
         self.attach_grads()
 
     def zero_grads_prefix(self, prefix):
+        """Zero the gradient range of the PARAMETERS under `prefix` (buffers are stored behind all parameters and have no gradient: including
+        their offsets would stretch the span over every later parameter)."""
         self.ensure_grads()
-        offs = [(self._offsets[k], self._numel(k)) for k in self._offsets if k.startswith(prefix)]
+        offs = [(self._offsets[k], self._numel(k)) for k in self._offsets if k.startswith(prefix) and self._offsets[k] < self._param_total]
         lo, hi = min(o for o, _ in offs), max(o + n for o, n in offs)
         self.gflat[lo:hi].zero_()
 

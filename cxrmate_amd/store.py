@@ -55,6 +55,7 @@ class ParamStore(nn.Module):
         self.flat32 = self.flat16 = self.gflat = None
         self.shadow_dirty = True
         self.shadow_version = 0
+        self._master_version = -1
         self._build(torch.device(device))
         self.static_dropout_seed = None          # set (device int32 [1]) by graph-captured training steps: advanced on the device per replay
         self.train(False)                        # like from_pretrained(): eval until the trainer calls .train()
@@ -213,7 +214,16 @@ class ParamStore(nn.Module):
             self.gflat.zero_()
 
     def refresh_shadow(self, force=False):
-        """fp32 master -> bf16 shadow (one pass over the flat buffer)."""
+        """fp32 master -> bf16 shadow (one pass over the flat buffer).
+
+        Besides the explicit flag, an in-place torch edit of ANY parameter marks the shadow stale: the nn.Parameters are views of the master
+        buffer and share its autograd version counter, so `torch.optim.AdamW.step()` (the reference's optimiser, single.py:426-431),
+        `p.data.copy_()`, `p.add_()` ... all move `flat32._version`. The fused AdamW kernel writes master and shadow together through raw
+        pointers and does not move it."""
+        ver = self.flat32._version
+        if ver != self._master_version:
+            self._master_version = ver
+            self.shadow_dirty = True
         if self.shadow_dirty or force:
             ops.cast_to_bf16(self.flat32, self.flat16)
             self.shadow_dirty = False

@@ -196,4 +196,8 @@ class GraphedTFStep:
             opt.reducer.reduce_range(0, opt.split if self.enc_trainable else model._param_total)
             opt.reducer.wait()
         self.g3.replay()
+        # the captured AdamW rewrote master + shadow: what FusedAdamW.step does on the host side (engines key their per-version weight re-layouts,
+        # LoRA merges, W^T copies and decode sessions on shadow_version)
+        model.shadow_dirty = False
+        model.shadow_version += 1
         return self.loss
