@@ -144,4 +144,9 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
+// "decode activation layout" (csrc/decode_gemm.hip): element offset of (m, k) in an [16*MT, K] matrix stored in MFMA A-fragment order
+__device__ __forceinline__ long dal_off(int m, int k, int MT) {
+    return ((long)((k >> 5) * MT + (m >> 4)) << 9) + (((((k & 31) >> 3) << 4) + (m & 15)) << 3) + (k & 7);
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -3,6 +3,10 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef CXR_STAMP
+#define CXR_STAMP(i)            /* scripts/lab defines it to record s_memrealtime per wave; nothing in the product build */
+#endif
+
 // out[b, r, :] = in[idx[b], r, :]  for r < rows   (cache reorder after a beam step; idx is int64)
 __global__ __launch_bounds__(256) void gather_batch_kernel(const bf16_t* __restrict__ in, long in_bs, long in_rs, bf16_t* __restrict__ out,
                                                            long out_bs, long out_rs, const long* __restrict__ idx, int B, int rows, int C) {
@@ -104,6 +108,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g
     __shared__ float red[NW][MT][64][4];
     __shared__ float redl[NW == 4 ? NW : 1][NW == 4 ? MT : 1][64][4];  // LoRA down-projection partials (rank 8 = columns 0..7 of a 16-wide tile; K = 768 kernels)
     __shared__ float lnbuf[2][4][MT][16];
+    CXR_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // grouped launch: blocks [0, N0/16) -> problem 0, next N1/16 -> problem 1, ... (q / k / v projections share A and one launch)
     int blk = blockIdx.x, pi = 0;
@@ -166,6 +171,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g
                 for (int t = 0; t < MT; ++t) af[t][s2] = *reinterpret_cast<const bf16x8_t*>(ap[t] + k);
             }
         }
+        CXR_STAMP(1);
         if (LNA) {                                                        // kslice == 192 == 32*KB: the loop body runs once
             float mean[MT], rstd[MT];
 #pragma unroll
@@ -216,6 +222,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g
                 }
             }
         }
+        CXR_STAMP(2);
         if (lora_in) {
             // rank-8 LoRA down-projection of the SAME normalised rows, with the branch's own input dropout: one more 16-wide MFMA tile per
             // k-step whose B operand is lr_A (rows 0..7; lanes 8..15 of a row group feed zeros) -- replaces a separate launch per layer
@@ -260,7 +267,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g
             red[wave][t][lane][r] = acc[t][r];
             if (NW == 4) { if (lora_in) redl[wave][t][lane][r] = accl[t][r]; }
         }
+    CXR_STAMP(3);
     __syncthreads();
+    CXR_STAMP(4);
     if (wave != 0 || n >= P.N) return;
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -297,6 +306,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const SkinnyArgs g
             if (g.out_f32) reinterpret_cast<float*>(P.C)[(long)m * P.ldc + n] = v;
             else reinterpret_cast<bf16_t*>(P.C)[(long)m * P.ldc + n] = f2bf(v);
         }
+    CXR_STAMP(5);
 }
 
 static int launch_skinny(const SkinnyArgs& g, hipStream_t stream) {
@@ -375,61 +385,77 @@ __device__ __forceinline__ uint4 nt_load16(const bf16_t* p) {
 
 // G queries share one K/V stream: query rows b, b + Bkv, ... (b < Bkv) attend to K/V row b. G = 2 is the SCST step, where the sampled and
 // the greedy decode of the same studies run as one batch and read identical cross-attention K/V (340 MB per token at 16 x 2 images).
-// NG = 8-lane key groups per workgroup (NG * 8 threads).
-template <int G, int NG>
-__global__ __launch_bounds__(NG * 8) void attn_decode_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
-                                                          bf16_t* __restrict__ O, const unsigned char* __restrict__ kpm, long q_bs, long k_bs,
-                                                          long k_rs, long v_bs, long v_rs, long o_bs, long kpm_bs, int H, int Tk, float scale, int Bkv, long kv_hs,
-                                                          const uint32_t* __restrict__ drop_seed, uint32_t drop_site, uint32_t drop_thr16, float drop_inv,
-                                                          int drop_t, int nsplit, int chunk, float* __restrict__ ws) {
-    // single pass (flash-decoding): each of the 32 key groups (8 lanes x 16 B = one 128-byte K/V row per key) keeps a running
-    // (max, sum, o[64]) over keys grp, grp+32, ...; KU keys per iteration -> 2*KU independent 16-byte loads in flight per lane; the 32
-    // partial states are merged through LDS at the end.
+// NG = 8-lane key groups per workgroup (NG * 8 threads), KU = keys per group per pass: one pass covers NG * KU keys with 2 * KU independent
+// 16-byte loads in flight per lane. KU = 9 tiles the encoder's 576 tokens per image exactly (64 groups x 9).
+//
+// The load phase is BRANCH-FREE: keys past the range re-read the last valid row (an L1 hit) and are discarded by a select, the key-padding
+// byte is always read (from a stand-in address when there is no mask). hipcc guards a conditional load with an exec-mask branch and parks
+// `s_waitcnt vmcnt(0)` behind it: the round-1 kernel thereby waited for every K/V row before requesting the next one -- eight dependent HBM
+// round trips per workgroup, 31 us for 57 MB (scripts/lab/decode_lab.hip).
+struct AttnDecArgs {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O; const unsigned char* kpm; const uint32_t* drop_seed; float* ws;
+    long q_bs, k_bs, k_rs, v_bs, v_rs, o_bs, kpm_bs, kv_hs;
+    int H, Tk, Bkv, nsplit, chunk, drop_t;
+    float scale, drop_inv; uint32_t drop_site, drop_thr16, has_kpm; int o_mt;          // o_mt > 0: O in the decode activation layout of [16*o_mt, H*64]
+};
+
+template <int G, int KU, int NG>
+__global__ __launch_bounds__(NG * 8) void attn_decode_kernel(const AttnDecArgs a) {
     __shared__ float gm[G][NG], gl[G][NG];
     __shared__ float go[G][NG][64];
+    CXR_STAMP(0);
+    asm volatile("" :: "s"(a.Q), "s"(a.K), "s"(a.V), "s"(a.kpm), "s"(a.drop_seed), "s"(a.q_bs), "s"(a.k_bs), "s"(a.k_rs), "s"(a.v_bs), "s"(a.v_rs),
+                 "s"(a.kpm_bs), "s"(a.kv_hs), "s"(a.H), "s"(a.Tk), "s"(a.Bkv), "s"(a.nsplit), "s"(a.chunk));
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     const int tid = threadIdx.x;
     // nsplit > 1 (flash-decoding across workgroups): workgroup (b, h, split) covers keys [split*chunk, +chunk) and leaves its
-    // un-normalised state (max, denominator, numerator[64]) in ws for attn_decode_merge_kernel -- a (b, h) pair alone cannot pull
-    // HBM bandwidth when B*H is below the CU count (16 studies x 12 heads = 192 workgroups on 256 CUs).
-    const int split = blockIdx.x % nsplit, bh = blockIdx.x / nsplit;
-    const int h = bh % H, b = bh / H;                                // b indexes K/V (and the key-padding mask)
-    const int k_lo = split * chunk, k_hi = (k_lo + chunk < Tk) ? k_lo + chunk : Tk;
+    // un-normalised state (max, denominator, numerator[64]) in ws for attn_decode_merge_kernel
+    const int split = blockIdx.x % a.nsplit, bh = blockIdx.x / a.nsplit;
+    const int h = bh % a.H, b = bh / a.H;                            // b indexes K/V (and the key-padding mask)
+    const int k_lo = split * a.chunk, k_hi = (k_lo + a.chunk < a.Tk) ? k_lo + a.chunk : a.Tk;
     const int sub = tid & 7, grp = tid >> 3;
-    const bf16_t* kb = K + (long)b * k_bs + h * kv_hs + sub * 8;      // kv_hs = 64 for token-major [B,T,H*64], T*64 for head-major [B,H,T,64]
-    const bf16_t* vb = V + (long)b * v_bs + h * kv_hs + sub * 8;
-    const unsigned char* mrow = kpm ? kpm + (long)b * kpm_bs : nullptr;
+    const bf16_t* kb = a.K + (long)b * a.k_bs + h * a.kv_hs + sub * 8;      // kv_hs = 64 for token-major [B,T,H*64], T*64 for head-major [B,H,T,64]
+    const bf16_t* vb = a.V + (long)b * a.v_bs + h * a.kv_hs + sub * 8;
+    const unsigned char* mrow = a.kpm + (long)b * a.kpm_bs;
     float m_run[G], l_run[G], o[G][8];
-    uint32_t drop_key[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         m_run[g] = -1.0e30f; l_run[g] = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[g][j] = 0.f;
-        // train-mode dropout on the probabilities: same (b*H+h, query position, key) hash as the tiled kernels (attention.hip)
-        drop_key[g] = drop_thr16 ? dropout_row_key(*drop_seed, drop_site, (uint32_t)((b + g * Bkv) * H + h), (uint32_t)drop_t) : 0u;
     }
-    constexpr int KU = 8;                                   // keys per group per iteration: 16 independent 16-byte loads in flight per lane
     uint4 kr[KU], vr[KU];
-    bool live[KU], ok[KU];
-#define ATTN_DEC_LOAD(k0_)                                                                                                  \
-    _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                                                        \
-        const int key = (k0_) + u * NG + grp;                                                                               \
-        live[u] = key < k_hi;                                                                                               \
-        kr[u] = make_uint4(0, 0, 0, 0); vr[u] = make_uint4(0, 0, 0, 0);                                                     \
-        ok[u] = false;                                                                                                      \
-        if (live[u]) {                       /* no loads for keys past the range (they would cost bandwidth) */             \
-            kr[u] = nt_load16(kb + (long)key * k_rs);                                                                       \
-            vr[u] = nt_load16(vb + (long)key * v_rs);                                                                       \
-            ok[u] = mrow == nullptr || mrow[key] != 0;                                                                      \
-        }                                                                                                                   \
+    unsigned char mk[KU];
+    // the K/V rows of a pass are requested FIRST (oldest in the memory queue), everything small behind them; a compiler barrier keeps hipcc
+    // from hoisting the small loads (and a wait for them) in front of the stream
+#define ATTN_DEC_LOAD(k0_)                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                                         \
+        int key = (k0_) + u * NG + grp; key = key < k_hi ? key : k_hi - 1;                                   \
+        kr[u] = nt_load16(kb + (long)key * a.k_rs);                                                          \
+        vr[u] = nt_load16(vb + (long)key * a.v_rs);                                                          \
+    }                                                                                                        \
+    asm volatile("" ::: "memory");                                                                           \
+    _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                                         \
+        int key = (k0_) + u * NG + grp; key = key < k_hi ? key : k_hi - 1;                                   \
+        mk[u] = mrow[key];                                                                                   \
     }
-    ATTN_DEC_LOAD(k_lo);                                    // the K/V stream starts before the (dependent-latency) query load is waited for
+    ATTN_DEC_LOAD(k_lo);
+    asm volatile("" ::: "memory");
+    const uint32_t dseed = a.drop_seed[vzero];
+    uint4 qraw[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) qraw[g] = *reinterpret_cast<const uint4*>(a.Q + (long)(b + g * a.Bkv) * a.q_bs + h * 64 + sub * 8);
+    CXR_STAMP(1);
     float qv[G][8];
+    uint32_t drop_key[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        unpack8(*reinterpret_cast<const uint4*>(Q + (long)(b + g * Bkv) * q_bs + h * 64 + sub * 8), qv[g]);
+        unpack8(qraw[g], qv[g]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qv[g][j] *= scale * 1.4426950408889634f;      // scores directly in the exp2 domain
+        for (int j = 0; j < 8; ++j) qv[g][j] *= a.scale * 1.4426950408889634f;      // scores directly in the exp2 domain
+        // train-mode dropout on the probabilities: same (b*H+h, query position, key) hash as the tiled kernels (attention.hip)
+        drop_key[g] = dropout_row_key(dseed, a.drop_site, (uint32_t)((b + g * a.Bkv) * a.H + h), (uint32_t)a.drop_t);
     }
     for (int k0 = k_lo; k0 < k_hi; k0 += NG * KU) {
         float sv[G][KU];
@@ -437,20 +463,22 @@ __global__ __launch_bounds__(NG * 8) void attn_decode_kernel(const bf16_t* __res
         for (int u = 0; u < KU; ++u) {
             float kv[8];
             unpack8(kr[u], kv);
+            const bool live = k0 + u * NG + grp < k_hi;
+            const bool ok = !a.has_kpm || mk[u] != 0;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 float d = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) d += qv[g][j] * kv[j];
                 d = group_sum<8>(d);
-                sv[g][u] = ok[u] ? d : -1.0e30f;                             // masked (finite sentinel); keys beyond Tk are dropped below
+                sv[g][u] = live ? (ok ? d : -1.0e30f) : -3.0e38f;            // masked: finite sentinel; beyond the range: never wins the max, p = 0
             }
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float mloc = m_run[g];
 #pragma unroll
-            for (int u = 0; u < KU; ++u) if (live[u]) mloc = fmaxf(mloc, sv[g][u]);
+            for (int u = 0; u < KU; ++u) mloc = fmaxf(mloc, sv[g][u]);
             const float alpha = __builtin_amdgcn_exp2f(m_run[g] - mloc);
             m_run[g] = mloc;
             l_run[g] *= alpha;
@@ -461,19 +489,21 @@ __global__ __launch_bounds__(NG * 8) void attn_decode_kernel(const bf16_t* __res
         for (int u = 0; u < KU; ++u) {
             float vv[8];
             unpack8(vr[u], vv);
+            const bool live = k0 + u * NG + grp < k_hi;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const float p = live[u] ? __builtin_amdgcn_exp2f(sv[g][u] - m_run[g]) : 0.f;
+                const float p = live ? __builtin_amdgcn_exp2f(sv[g][u] - m_run[g]) : 0.f;
                 l_run[g] += p;
                 float pd = p;
-                if (drop_thr16) pd = dropout_keep(drop_key[g], (uint32_t)(k0 + u * NG + grp), drop_thr16) ? p * drop_inv : 0.f;
+                if (a.drop_thr16) pd = dropout_keep(drop_key[g], (uint32_t)(k0 + u * NG + grp), a.drop_thr16) ? p * a.drop_inv : 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[g][j] += pd * vv[j];
             }
         }
-        if (k0 + NG * KU < k_hi) ATTN_DEC_LOAD(k0 + NG * KU);
+        if (k0 + NG * KU < k_hi) { ATTN_DEC_LOAD(k0 + NG * KU); }          // wave-uniform: the next pass's rows (the registers are free again)
     }
 #undef ATTN_DEC_LOAD
+    CXR_STAMP(2);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         if (sub == 0) { gm[g][grp] = m_run[g]; gl[g][grp] = l_run[g]; }
@@ -481,65 +511,96 @@ __global__ __launch_bounds__(NG * 8) void attn_decode_kernel(const bf16_t* __res
         for (int j = 0; j < 8; ++j) go[g][grp][sub * 8 + j] = o[g][j];
     }
     __syncthreads();
-    if (tid < 64 * G) {
-        const int g = tid >> 6, d = tid & 63;
+    CXR_STAMP(3);
+    for (int e = tid; e < 64 * G; e += NG * 8) {
+        const int g = e >> 6, d = e & 63;
         float M = -1.0e30f;
-#pragma unroll
+#pragma unroll 8
         for (int q = 0; q < NG; ++q) M = fmaxf(M, gm[g][q]);
         float num = 0.f, den = 0.f;
-#pragma unroll
+#pragma unroll 8
         for (int q = 0; q < NG; ++q) {
             const float w = __builtin_amdgcn_exp2f(gm[g][q] - M);
             num += w * go[g][q][d];
             den += w * gl[g][q];
         }
-        if (nsplit == 1) {
-            O[(long)(b + g * Bkv) * o_bs + h * 64 + d] = f2bf(num / den);
+        if (a.nsplit == 1) {
+            const int row = b + g * a.Bkv;
+            a.O[a.o_mt ? dal_off(row, h * 64 + d, a.o_mt) : (long)row * a.o_bs + h * 64 + d] = f2bf(num / den);
         } else {
-            float* w = ws + ((((long)(b + g * Bkv) * H + h) * nsplit) + split) * 66;
+            float* w = a.ws + ((((long)(b + g * a.Bkv) * a.H + h) * a.nsplit) + split) * 66;
             w[2 + d] = num;
             if (d == 0) { w[0] = M; w[1] = den; }
         }
     }
+    CXR_STAMP(4);
 }
 
-// O[b,h,:] from the nsplit partial states of attn_decode_kernel: one 64-lane wave per (query row, head)
-__global__ __launch_bounds__(256) void attn_decode_merge_kernel(const float* __restrict__ ws, bf16_t* __restrict__ O, long o_bs, int H, int nsplit, int rows) {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), d = threadIdx.x & 63;          // r = b*H + h
-    if (r >= rows) return;
+// O[b,h,:] from the nsplit (<= 8) partial states of attn_decode_kernel: one 64-lane wave per (query row, head). All partial states are
+// requested up front (unused slots re-read slot 0), so the launch costs one memory round trip.
+__global__ __launch_bounds__(256) void attn_decode_merge_kernel(const float* __restrict__ ws, bf16_t* __restrict__ O, long o_bs, int H, int nsplit, int rows,
+                                                                int o_mt) {
+    asm volatile("" :: "s"(ws), "s"(O), "s"(o_bs), "s"(H), "s"(nsplit), "s"(rows));
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int d = threadIdx.x & 63;          // r = b*H + h
+    const bool live = r < rows;
+    r = live ? r : rows - 1;
     const float* w = ws + (long)r * nsplit * 66;
-    float M = -1.0e30f;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, w[s * 66]);
-    float num = 0.f, den = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float e = __builtin_amdgcn_exp2f(w[s * 66] - M);
-        num += e * w[s * 66 + 2 + d];
-        den += e * w[s * 66 + 1];
+    float m[8], den[8], num[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int sc = s < nsplit ? s : 0;
+        m[s] = w[sc * 66]; den[s] = w[sc * 66 + 1]; num[s] = w[sc * 66 + 2 + d];
     }
-    O[(long)(r / H) * o_bs + (r % H) * 64 + d] = f2bf(num / den);
+    asm volatile("" ::: "memory");
+    float M = -1.0e30f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) M = fmaxf(M, s < nsplit ? m[s] : -1.0e30f);
+    float n_ = 0.f, d_ = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const float e = s < nsplit ? __builtin_amdgcn_exp2f(m[s] - M) : 0.f;
+        n_ += e * num[s];
+        d_ += e * den[s];
+    }
+    if (live) O[o_mt ? dal_off(r / H, (r % H) * 64 + d, o_mt) : (long)(r / H) * o_bs + (r % H) * 64 + d] = f2bf(n_ / d_);
 }
 
 // B query rows; K, V (and kpm) have B / kv_share rows: query rows b and b + B/kv_share read K/V row b (kv_share = 1 or 2).
 extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs,
                                     long v_bs, long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, int kv_share, float* ws,
-                                    long kv_hs, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t, hipStream_t stream) {
+                                    long kv_hs, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t, int wg_keys,
+                                    int o_dal, hipStream_t stream) {
     if (B <= 0 || H <= 0 || Tk <= 0 || Tk > 8192 || (k_rs % 8) || (v_rs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8)) return CXR_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed) || (kv_share != 1 && kv_share != 2) || (B % kv_share)) return CXR_ERR_ARG;
     const int Bkv = B / kv_share;
-    // few (b, h) pairs with long key ranges (16 studies x 12 heads over 1152 encoder tokens): split the keys over workgroups (256 keys = one
-    // iteration each) + merge kernel; ws: B*H*8*66 floats. (Measured alternative: ONE 1024-thread workgroup per (b, h) is 3x slower.)
+    // keys per workgroup pass (= NG key groups x KU keys): 256 = 32 x 8 (KV-cache self-attention: one pass up to 256 cached tokens), 288 = 32 x 9
+    // and 576 = 64 x 9 (cross-attention: the encoder emits 576 tokens per image; a 1024-thread pass of 1152 keys does not fit 128 registers). With `ws`, ranges longer than one pass are split over
+    // workgroups (flash-decoding, B*H*8*66 floats) + the merge kernel; without it the workgroup loops.
+    const bool no_split = wg_keys < 0;                  // negative: |wg_keys| per pass, one looping workgroup per (row, head) even when ws is given
+    if (no_split) wg_keys = -wg_keys;
+    if (wg_keys == 0) wg_keys = (Tk % 576 == 0) ? 576 : 256;
+    if (wg_keys != 256 && wg_keys != 288 && wg_keys != 576) return CXR_ERR_ARG;
     int nsplit = 1, chunk = Tk;
-    if (ws && Bkv * H < 512 && Tk > 256) {
-        nsplit = cdiv(Tk, 256) < 8 ? cdiv(Tk, 256) : 8;
-        chunk = 256 * cdiv(Tk, 256 * nsplit);
-        nsplit = cdiv(Tk, chunk);
-    }
-#define ATTN_DEC(G_) CXR_LAUNCH((attn_decode_kernel<G_, 32>), dim3(Bkv * H * nsplit), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,        \
-               (const bf16_t*)V, (bf16_t*)O, (const unsigned char*)kpm, q_bs, k_bs, k_rs, v_bs, v_rs, o_bs, kpm_bs, H, Tk, scale, Bkv, kv_hs, drop_seed, \
-               drop_site, drop_p > 0.f ? dropout_thr16(drop_p) : 0u, 1.0f / (1.0f - drop_p), drop_t, nsplit, chunk, ws)
-    if (kv_share == 2) ATTN_DEC(2); else ATTN_DEC(1);
+    if (ws && Tk > wg_keys && cdiv(Tk, wg_keys) <= 8 && !no_split) { nsplit = cdiv(Tk, wg_keys); chunk = wg_keys; }
+    AttnDecArgs a;
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.O = (bf16_t*)O;
+    a.kpm = kpm ? (const unsigned char*)kpm : (const unsigned char*)K; a.has_kpm = kpm ? 1u : 0u; a.kpm_bs = kpm ? kpm_bs : 0;
+    a.drop_seed = drop_seed ? drop_seed : (const uint32_t*)K; a.ws = ws;
+    a.q_bs = q_bs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs; a.o_bs = o_bs; a.kv_hs = kv_hs;
+    a.H = H; a.Tk = Tk; a.Bkv = Bkv; a.nsplit = nsplit; a.chunk = chunk; a.drop_t = drop_t; a.scale = scale;
+    a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_site = drop_site; a.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u;
+    a.o_mt = o_dal ? (cdiv(B, 16) == 3 ? 4 : cdiv(B, 16)) : 0;
+    if (o_dal && B > 64) return CXR_ERR_ARG;
+    const dim3 grid(Bkv * H * nsplit);
+#define ATTN_DEC(G_, KU_, NG_) CXR_LAUNCH((attn_decode_kernel<G_, KU_, NG_>), grid, dim3(NG_ * 8), 0, stream, a)
+#define ATTN_DEC_G(KU_, NG_) do { if (kv_share == 2) ATTN_DEC(2, KU_, NG_); else ATTN_DEC(1, KU_, NG_); } while (0)
+    if (wg_keys == 256) ATTN_DEC_G(8, 32);
+    else if (wg_keys == 288) ATTN_DEC_G(9, 32);
+    else ATTN_DEC_G(9, 64);
+#undef ATTN_DEC_G
 #undef ATTN_DEC
-    if (nsplit > 1) CXR_LAUNCH(attn_decode_merge_kernel, dim3(cdiv(B * H, 4)), dim3(256), 0, stream, ws, (bf16_t*)O, o_bs, H, nsplit, B * H);
+    if (nsplit > 1) CXR_LAUNCH(attn_decode_merge_kernel, dim3(cdiv(B * H, 4)), dim3(256), 0, stream, ws, (bf16_t*)O, o_bs, H, nsplit, B * H, a.o_mt);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const long* __restr
                                                              const float* __restrict__ beta, float eps, bf16_t* __restrict__ sum_out,
                                                              bf16_t* __restrict__ out, float* __restrict__ stats, long R, int T, int pos_offset,
                                                              const uint32_t* __restrict__ drop_seed, uint32_t drop_site, uint32_t drop_thr16,
-                                                             float drop_inv) {
+                                                             float drop_inv, int out_mt) {
     constexpr int C = 768, CH = 96;
     const uint32_t dseed = drop_thr16 ? *drop_seed : 0u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const long* __restr
                         o[j + 1] = (bits >> 16) >= drop_thr16 ? o[j + 1] * drop_inv : 0.f;
                     }
                 }
-                *reinterpret_cast<uint4*>(out + row * C + ch * 8) = pack8(o);
+                *reinterpret_cast<uint4*>(out + (out_mt ? dal_off((int)row, ch * 8, out_mt) : row * C + ch * 8)) = pack8(o);
             }
         }
         if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
@@ -74,12 +74,14 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const long* __restr
 
 extern "C" int cxr_bert_embed_fwd(const long* ids, const long* tt, const long* pid, const void* word, const void* type, const void* posw,
                                   const float* gamma, const float* beta, float eps, void* sum_out, void* out, float* stats, long R, int T,
-                                  int pos_offset, int C, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, hipStream_t stream) {
-    if (R <= 0 || C != 768 || T <= 0 || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return CXR_ERR_ARG;
+                                  int pos_offset, int C, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int out_dal,
+                                  hipStream_t stream) {
+    if (R <= 0 || C != 768 || T <= 0 || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed) || (out_dal && R > 64)) return CXR_ERR_ARG;
+    const int out_mt = out_dal ? (cdiv(R, 16) == 3 ? 4 : cdiv(R, 16)) : 0;
     const int grid = (int)(cdiv(R, 4) < 4096 ? cdiv(R, 4) : 4096);
     CXR_LAUNCH(bert_embed_fwd_kernel, dim3(grid), dim3(256), 0, stream, ids, tt, pid, (const bf16_t*)word, (const bf16_t*)type,
                        (const bf16_t*)posw, gamma, beta, eps, (bf16_t*)sum_out, (bf16_t*)out, stats, R, T, pos_offset, drop_seed, drop_site,
-                       drop_p > 0.f ? dropout_thr16(drop_p) : 0u, 1.0f / (1.0f - drop_p));
+                       drop_p > 0.f ? dropout_thr16(drop_p) : 0u, 1.0f / (1.0f - drop_p), out_mt);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

@@ -29,6 +29,7 @@ SITE_EMBED = 1
 _CROSS_KV_FUSED = os.environ.get("CXR_CROSS_KV_FUSED", "1") != "0"      # A/B switch: 0 = one K / V GEMM per layer
 _LORA_IN_KERNEL = os.environ.get("CXR_LORA_IN_KERNEL", "1") != "0"        # A/B switch: 0 = separate LoRA down-projection launch per decode layer
 _SELF_QKV_FUSED = os.environ.get("CXR_SELF_QKV_FUSED", "1") != "0"      # A/B switch: 0 = separate query / key / value GEMMs
+_CROSS_WG_KEYS = int(os.environ.get("CXR_CROSS_WG_KEYS", "-576"))          # cached cross-attention geometry (ops.attention_decode wg_keys)
 
 
 def _site(layer, k):
@@ -70,6 +71,7 @@ class BertEngine:
         self._wtb_ready = False
         self._bt, self._bt_last = {}, None
         self._qkv_cache = {}
+        self._packs, self._pack_key = {}, None
 
     # ------------------------------------------------------------------------------------------ parameters
     def _lin(self, base):
@@ -512,16 +514,18 @@ class BertEngine:
         R = B * Tn
         ph, pa, seed = self._dropout_cfg(train, seed)
         e = p + "bert.embeddings."
+        single = Tn == 1 and B <= 64          # one new token per row: weight-streaming GEMMs + single-query attention kernels
+        lora_tr = self._lora_train(train)
+        fused = (single and D == 768 and cfg.intermediate_size == 3072 and self.fuse_decode_layernorm and cfg.add_cross_attention and enc is not None
+                 and cache.cross_ready and cfg.vocab_size % 2 == 0)
         h, _, _ = ops.bert_embed(ids_new, token_type_ids, position_ids, st.w16(e + "word_embeddings.weight"),
                                  st.w16(e + "token_type_embeddings.weight"), st.w16(e + "position_embeddings.weight"),
                                  st.f32(e + "LayerNorm.weight"), st.f32(e + "LayerNorm.bias"), cfg.layer_norm_eps, Tn, pos_offset=past,
-                                 drop=(ph, seed, SITE_EMBED) if ph else None)
+                                 drop=(ph, seed, SITE_EMBED) if ph else None, out_dal=fused)
         scale = cfg.head_dim ** -0.5
-        single = Tn == 1 and B <= 64          # one new token per row: weight-streaming GEMMs + single-query attention kernels
-        lora_tr = self._lora_train(train)
         pl, ls = float(cfg.lora_dropout), (cfg.lora_alpha / cfg.lora_r if cfg.lora_r else 0.0)
-        if single and D == 768 and self.fuse_decode_layernorm:
-            return self._decode_single_fused(cache, h, enc, enc_mask, attn_mask_full, past, ph, pa, seed, lora_tr)
+        if fused:
+            return self._decode_single_fused(cache, h, B, enc_mask, attn_mask_full, past, ph, pa, seed, lora_tr)
         lin = (lambda x, w, **kw: ops.gemm_skinny(x, w, **kw)) if single else (lambda x, w, **kw: ops.gemm_nt(x, w, **kw))
 
         def out_lin(x, w, b, resid, site):
@@ -609,79 +613,117 @@ class BertEngine:
 
     fuse_decode_layernorm = True
 
-    def _decode_single_fused(self, cache, h, enc, enc_mask, attn_mask_full, past, ph, pa, seed, lora_tr=False):
-        """One token per row with every LayerNorm folded into its consumers: a decode step is launch-bound (~85 short kernels), and the
-        weight-streaming GEMM holds its whole slice of the activations in registers, so it normalises them itself (`ln_a`) and publishes
-        the row statistics for the later residual use of the same LayerNorm output (`ln_r`). 19 launches per token disappear.
-        h: embedding output [B, 768] (already LayerNorm'ed + dropped). Returns fp32 logits [B, V]."""
+    def _decode_packs(self, lora_tr):
+        """Per weight version: every Linear a cached decode step streams, re-laid out in MFMA-fragment order with the LayerNorm that FEEDS it
+        folded in (csrc/decode_gemm.hip), the (gamma, beta) pairs of the LayerNorms that are applied to a residual operand, and the LoRA
+        down-projections [A diag(gamma); A diag(beta)]. Buffers are refreshed in place: hipGraph-captured pointers stay valid."""
+        st, cfg, p = self.s, self.cfg, self.p
+        self.prepare()
+        key = (st.shadow_version, bool(lora_tr), st.flat16.data_ptr())
+        if self._pack_key == key:
+            return self._packs
+        if self._pack_key is not None and self._pack_key[2] != key[2]:
+            self._packs = {}                                     # re-packed store (.to()/.cuda())
+        pk = self._packs
+
+        def ln(base):
+            return (None, None) if base is None else (st.f32(base + ".weight"), st.f32(base + ".bias"))
+
+        def pack(name, w, bias, fold):
+            g, b = ln(fold)
+            pk[name] = ops.dec_pack_weight(w, g, b, bias, out=pk.get(name))
+
+        def rgb(base):
+            t = pk.get(("rgb", base))
+            if t is None:
+                t = pk[("rgb", base)] = torch.empty((cfg.hidden_size, 2), dtype=torch.float32, device=st.device)
+            t[:, 0].copy_(st.f32(base + ".weight")); t[:, 1].copy_(st.f32(base + ".bias"))
+
+        L = cfg.num_hidden_layers
+        for l in range(L):
+            lp = p + f"bert.encoder.layer.{l}."
+            prev = None if l == 0 else p + f"bert.encoder.layer.{l - 1}.output.LayerNorm"
+            for nm in ("query", "key", "value"):
+                base = lp + "attention.self." + nm
+                if lora_tr and not st.has(base + ".weight"):         # train mode: base weight here, rank-8 branch beside it
+                    w, b_ = st.w16(base + ".base_layer.weight"), st.f32(base + ".base_layer.bias")
+                    g, bt = ln(prev)
+                    pk[(l, "lora_" + nm)] = ops.dec_pack_lora(st.w16(base + ".lora_A.default.weight"), g, bt, out=pk.get((l, "lora_" + nm)))
+                else:
+                    w, b_ = self._lin(base)
+                pack((l, nm), w, b_, prev)
+            pack((l, "attn_out"), *self._lin(lp + "attention.output.dense"), None)
+            pack((l, "cq"), *self._lin(lp + "crossattention.self.query"), lp + "attention.output.LayerNorm")
+            pack((l, "cout"), *self._lin(lp + "crossattention.output.dense"), None)
+            pack((l, "ffn1"), *self._lin(lp + "intermediate.dense"), lp + "crossattention.output.LayerNorm")
+            pack((l, "ffn2"), *self._lin(lp + "output.dense"), None)
+            for nm in ("attention.output.LayerNorm", "crossattention.output.LayerNorm", "output.LayerNorm"):
+                rgb(lp + nm)
+        c = p + "cls.predictions."
+        pack("transform", st.w16(c + "transform.dense.weight"), st.f32(c + "transform.dense.bias"), p + f"bert.encoder.layer.{L - 1}.output.LayerNorm")
+        pack("lm_head", st.w16(p + "bert.embeddings.word_embeddings.weight"), st.f32(c + "bias"), c + "transform.LayerNorm")
+        self._pack_key = key
+        return pk
+
+    def refresh_decode_packs(self, train=None):
+        """Bring the packed decode weights up to the current weight version / train mode (in place). Graph-replayed decode steps do not run
+        the Python that would otherwise notice a stale version: DecodeSession.reset calls this before the first step of every decode."""
+        cfg = self.cfg
+        if self.fuse_decode_layernorm and cfg.hidden_size == 768 and cfg.intermediate_size == 3072 and cfg.add_cross_attention and cfg.vocab_size % 2 == 0:
+            self._decode_packs(self._lora_train(train))
+
+    def _decode_single_fused(self, cache, x0, B, enc_mask, attn_mask_full, past, ph, pa, seed, lora_tr=False):
+        """One new token per row on the decode-step kernels of csrc/decode_gemm.hip: activations stay in the decode activation layout between
+        kernels, every LayerNorm is folded into the weights of the Linear it feeds (its row statistics are published by the GEMM that produced
+        its input) or applied to the residual operand in an epilogue, the LM head's transform LayerNorm included: 8 launches per layer + 2.
+        x0: embedding output (already LayerNorm'ed + dropped) in the decode activation layout. Returns fp32 logits [B, V]."""
         cfg, st, p = self.cfg, self.s, self.p
-        B, D = h.shape
+        D, F, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
         nh, eps, scale = cfg.num_attention_heads, cfg.layer_norm_eps, cfg.head_dim ** -0.5
-        dev = h.device
-        cur, cur_ln = h, None                      # hidden state = cur when cur_ln is None, else LayerNorm(cur; cur_ln = (gamma, beta, stats))
+        dev = x0.device
+        pk = self._decode_packs(lora_tr)
+        cur, cur_st, cur_ln = x0, None, None           # hidden state = cur when cur_ln is None, else LayerNorm_{cur_ln}(cur) with row statistics cur_st
 
-        def ln_a(ln):
-            return None if ln is None else (ln[0], ln[1], eps, ln[2])
-
-        def ln_r(ln):
-            return None if ln is None else (ln[2], ln[0], ln[1])
-
-        def new_ln(base):
-            return (st.f32(base + ".weight"), st.f32(base + ".bias"), torch.empty((B, 2), dtype=torch.float32, device=dev))
+        def prob(name, N, out=None, lora=None):
+            wp, bc = pk[name]
+            return dict(wp=wp, bc=bc, N=N, fold=cur_ln is not None and name[1] not in ("attn_out", "cout", "ffn2"), out=out, lora=lora)
 
         def drop(site):
             return (ph, seed, site, past) if ph else None
 
+        def res_kw():
+            return dict(residual=cur, stats=cur_st, rgb=pk[("rgb", cur_ln)], eps=eps) if cur_ln is not None else dict(residual=cur)
+
+        lora_kw = dict(lora=(float(cfg.lora_dropout), seed, cfg.lora_alpha / cfg.lora_r, past)) if lora_tr else {}
         for l in range(cfg.num_hidden_layers):
             lp = p + f"bert.encoder.layer.{l}."
-            wv, bv = self._lin(lp + "attention.self.value")
-            lq = lk = lin_ = None
-            if lora_tr:              # train mode: base weights; the rank-8 branch on dropout(LayerNorm(cur)) enters through the GEMM epilogue
-                wq, bq, aq, bq_l = self._lora_parts(lp + "attention.self.query"); wk, bk, ak, bk_l = self._lora_parts(lp + "attention.self.key")
-                pl = float(cfg.lora_dropout)
-                if _LORA_IN_KERNEL and D == 768:
-                    # both down-projections inside the q/k/v launch (on the rows the GEMM holds in registers, after its LayerNorm if it applies one)
-                    lin_ = dict(A0=aq, B0=bq_l, A1=ak, B1=bk_l, p=pl, seed=seed, site0=_site(l, 5), site1=_site(l, 6), tpos=past,
-                                scale=cfg.lora_alpha / cfg.lora_r)
-                else:
-                    tq, tk = ops.lora_down(cur, aq, drop0=(pl, _site(l, 5)), W1=ak, drop1=(pl, _site(l, 6)), rows_per_b=1, tpos0=past, seed=seed,
-                                           ln=None if cur_ln is None else (cur_ln[0], cur_ln[1], eps), scale=cfg.lora_alpha / cfg.lora_r)
-                    lq, lk = (tq, bq_l), (tk, bk_l)
-            else:
-                wq, bq = self._lin(lp + "attention.self.query"); wk, bk = self._lin(lp + "attention.self.key")
             q = torch.empty((B, D), dtype=BF16, device=dev)
-            ops.gemm_skinny3(cur, wq, bq, q, wk, bk, cache.k[l][:, past, :], wv, bv, cache.v[l][:, past, :], ln_a=ln_a(cur_ln), lora0=lq, lora1=lk,
-                             lora_in=lin_)
+            lq = lk = None
+            if lora_tr:
+                lq = (pk[(l, "lora_query")], st.w16(lp + "attention.self.query.lora_B.default.weight"), _site(l, 5))
+                lk = (pk[(l, "lora_key")], st.w16(lp + "attention.self.key.lora_B.default.weight"), _site(l, 6))
+            # q / k / v in one launch; k and v land in their KV-cache rows
+            ops.dec_gemm(cur, B, D, [prob((l, "query"), D, q, lq), prob((l, "key"), D, cache.k[l][:, past, :], lk),
+                                     prob((l, "value"), D, cache.v[l][:, past, :])], stats=cur_st, eps=eps, **lora_kw)
             ctx = ops.attention_decode(q, cache.k[l][:, :past + 1, :], cache.v[l][:, :past + 1, :], nh, scale, kpm=attn_mask_full,
-                                       drop=(pa, seed, _site(l, 0), past))
-            wo, bo = self._lin(lp + "attention.output.dense")
-            a1 = ops.gemm_skinny(ctx, wo, bias=bo, residual=cur, ln_r=ln_r(cur_ln), drop=drop(_site(l, 1)))
-            cur, cur_ln = a1, new_ln(lp + "attention.output.LayerNorm")
-            if cfg.add_cross_attention and enc is not None:
-                if cache.ck[l] is None or (not cache.cross_ready and past == 0):       # one-token prompt: this step is also the prefill
-                    Be, S = enc.shape[0], enc.shape[1]
-                    ck, cbk = self._lin(lp + "crossattention.self.key"); cv, cbv = self._lin(lp + "crossattention.self.value")
-                    okb = cache.ck[l].view(Be * S, D) if cache.ck[l] is not None else None
-                    ovb = cache.cv[l].view(Be * S, D) if cache.cv[l] is not None else None
-                    cache.ck[l] = ops.gemm_nt(enc.reshape(Be * S, D), ck, bias=cbk, out=okb).view(Be, S, D)
-                    cache.cv[l] = ops.gemm_nt(enc.reshape(Be * S, D), cv, bias=cbv, out=ovb).view(Be, S, D)
-                cq, cbq = self._lin(lp + "crossattention.self.query"); co, cbo = self._lin(lp + "crossattention.output.dense")
-                q2 = ops.gemm_skinny(cur, cq, bias=cbq, ln_a=ln_a(cur_ln))
-                ctx2 = ops.attention_decode(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask, drop=(pa, seed, _site(l, 2), past))
-                a2 = ops.gemm_skinny(ctx2, co, bias=cbo, residual=cur, ln_r=ln_r(cur_ln), drop=drop(_site(l, 3)))
-                cur, cur_ln = a2, new_ln(lp + "crossattention.output.LayerNorm")
-            w1, b1 = self._lin(lp + "intermediate.dense"); w2, b2 = self._lin(lp + "output.dense")
-            f = ops.gemm_skinny(cur, w1, bias=b1, act=1, ln_a=ln_a(cur_ln))
-            a3 = ops.gemm_skinny(f, w2, bias=b2, residual=cur, ln_r=ln_r(cur_ln), drop=drop(_site(l, 4)))
-            cur, cur_ln = a3, new_ln(lp + "output.LayerNorm")
+                                       drop=(pa, seed, _site(l, 0), past), wg_keys=256, out_dal=True)
+            (a1,), st1 = ops.dec_gemm(ctx, B, D, [prob((l, "attn_out"), D)], out_stats=True, drop=drop(_site(l, 1)), **res_kw())
+            cur, cur_st, cur_ln = a1, st1, lp + "attention.output.LayerNorm"
+            q2 = torch.empty((B, D), dtype=BF16, device=dev)
+            ops.dec_gemm(cur, B, D, [prob((l, "cq"), D, q2)], stats=cur_st, eps=eps)
+            ctx2 = ops.attention_decode(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask, drop=(pa, seed, _site(l, 2), past),
+                                        wg_keys=_CROSS_WG_KEYS, out_dal=True)
+            (a2,), st2 = ops.dec_gemm(ctx2, B, D, [prob((l, "cout"), D)], out_stats=True, drop=drop(_site(l, 3)), **res_kw())
+            cur, cur_st, cur_ln = a2, st2, lp + "crossattention.output.LayerNorm"
+            (f,), _ = ops.dec_gemm(cur, B, D, [prob((l, "ffn1"), F)], act=1, stats=cur_st, eps=eps)
+            (a3,), st3 = ops.dec_gemm(f, B, F, [prob((l, "ffn2"), D)], out_stats=True, drop=drop(_site(l, 4)), **res_kw())
+            cur, cur_st, cur_ln = a3, st3, lp + "output.LayerNorm"
         cache.len = past + 1
-        if past == 0:
-            cache.cross_ready = True
-        c = p + "cls.predictions."
-        t = ops.gemm_skinny(cur, st.w16(c + "transform.dense.weight"), bias=st.f32(c + "transform.dense.bias"), act=1, ln_a=ln_a(cur_ln))
-        # the vocabulary projection runs 1875 workgroups: normalising the activations in each of them costs more than one LayerNorm launch
-        tn, _ = ops.layernorm(t, st.f32(c + "transform.LayerNorm.weight"), st.f32(c + "transform.LayerNorm.bias"), eps)
-        return ops.gemm_skinny(tn, st.w16(p + "bert.embeddings.word_embeddings.weight"), bias=st.f32(c + "bias"), out_f32=True)
+        wp, bc = pk["transform"]
+        (t,), stt = ops.dec_gemm(cur, B, D, [dict(wp=wp, bc=bc, N=D, fold=True)], act=1, stats=cur_st, eps=eps, out_stats=True)
+        wp, bc = pk["lm_head"]
+        (logits,), _ = ops.dec_gemm(t, B, D, [dict(wp=wp, bc=bc, N=V, fold=True)], out_f32=True, stats=stt, eps=eps)
+        return logits
 
     # ------------------------------------------------------------------------------------------ CXR-BERT stand-in head
     def cls_projection(self, hidden, prefix=""):

@@ -57,6 +57,7 @@ class DecodeSession:
     def reset(self, ids0, enc16, enc_mask8):
         m = self.model
         m._dec.prepare()                           # weight-derived buffers (LoRA merge) are refreshed IN PLACE: captured pointers stay valid
+        m._dec.refresh_decode_packs()              # ... as are the packed / LayerNorm-folded decode weights the replayed steps stream
         if self.version != m.flat16.data_ptr():    # parameters were re-packed (.to()/.cuda()): every captured pointer is stale
             self.graphs.clear()
             self.version = m.flat16.data_ptr()

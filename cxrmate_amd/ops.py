@@ -679,14 +679,16 @@ def dwproj_dx(projs, Bn, C, H, W, tok0):
 
 
 # ------------------------------------------------------------------------------------------------ embeddings / integer ops
-def bert_embed(ids, tt, pid, word, typ, posw, gamma, beta, eps, T, pos_offset=0, need_sum=False, drop=None):
+def bert_embed(ids, tt, pid, word, typ, posw, gamma, beta, eps, T, pos_offset=0, need_sum=False, drop=None, out_dal=False):
+    """out_dal: the output rows in the decode activation layout (dal_rows(R) x C elements, see dec_gemm)."""
     R = ids.numel()
     C = word.shape[1]
-    out = torch.empty((R, C), device=ids.device, dtype=BF16)
+    out = torch.empty((dal_rows(R) if out_dal else R, C), device=ids.device, dtype=BF16)
     ssum = torch.empty((R, C), device=ids.device, dtype=BF16) if need_sum else None
     stats = torch.empty((R, 2), device=ids.device, dtype=torch.float32) if need_sum else None
     LIB.call("cxr_bert_embed_fwd", _p(ids), _p(tt), _p(pid), _p(word), _p(typ), _p(posw), _p(gamma), _p(beta), float(eps), _p(ssum), _p(out),
-             _p(stats), R, T, pos_offset, C, *((float(drop[0]), _p(drop[1]), int(drop[2])) if drop is not None and drop[0] > 0 else (0.0, None, 0)), _s())
+             _p(stats), R, T, pos_offset, C, *((float(drop[0]), _p(drop[1]), int(drop[2])) if drop is not None and drop[0] > 0 else (0.0, None, 0)),
+             int(bool(out_dal)), _s())
     return out, ssum, stats
 
 
@@ -904,7 +906,7 @@ def gemm_skinny(a, w, bias=None, residual=None, act=0, out=None, out_f32=False, 
     return out
 
 
-def attention_decode(q, k, v, heads, scale, kpm=None, out=None, drop=None, head_major=False):
+def attention_decode(q, k, v, heads, scale, kpm=None, out=None, drop=None, head_major=False, wg_keys=0, out_dal=False):
     """q [B,1,H*64] (or [B,H*64]); k, v [B or B/2,Tk,H*64] views (batch/row strides free) -> [B, H*64]. With B/2 K/V rows, query rows
     b and b + B/2 share K/V row b."""
     B = q.shape[0]
@@ -922,10 +924,114 @@ def attention_decode(q, k, v, heads, scale, kpm=None, out=None, drop=None, head_
         ws = _DW_WS[key] = torch.empty(B * heads * 8 * 66, device=q.device, dtype=torch.float32)
     D = heads * 64
     if out is None:
-        out = torch.empty((B, D), device=q.device, dtype=BF16)
+        out = torch.empty((dal_rows(B) if out_dal else B, D), device=q.device, dtype=BF16)
     LIB.call("cxr_attn_decode_bf16", _p(q), _p(k), _p(v), _p(out), _p(kpm), q.stride(0), k_bs, k_rs, v_bs, v_rs,
-             out.stride(0), kpm.stride(0) if kpm is not None else 0, B, heads, Tk, float(scale), share, _p(ws), int(hs), *_drop_args(drop), _s())
+             out.stride(0), kpm.stride(0) if kpm is not None else 0, B, heads, Tk, float(scale), share, _p(ws), int(hs), *_drop_args(drop),
+             int(wg_keys), int(bool(out_dal)), _s())
     return out
+
+
+# ------------------------------------------------------------------------------------------------ decode-step linear layers (csrc/decode_gemm.hip)
+def dal_rows(M):
+    """rows of the buffer that holds M rows in the decode activation layout (16-row tiles; 3 tiles are stored as 4)"""
+    t = (M + 15) // 16
+    return 16 * (4 if t == 3 else t)
+
+
+class _DecProb(_ct.Structure):
+    """Mirror of `cxr_dec_gemm_prob` (include/cxrmate_hip.h)."""
+    _fields_ = [("Wp", _ct.c_void_p), ("bc", _ct.c_void_p), ("C", _ct.c_void_p), ("ldc", _ct.c_long), ("N", _ct.c_int), ("c_dal", _ct.c_int),
+                ("fold", _ct.c_int), ("no_bias", _ct.c_int), ("lr_Ap", _ct.c_void_p), ("lr_B", _ct.c_void_p), ("lr_site", _ct.c_uint)]
+
+
+class _DecDesc(_ct.Structure):
+    """Mirror of `cxr_dec_gemm_desc`."""
+    _fields_ = [("A", _ct.c_void_p), ("M", _ct.c_int), ("K", _ct.c_int), ("nprob", _ct.c_int), ("act", _ct.c_int), ("out_f32", _ct.c_int),
+                ("nc_hint", _ct.c_int), ("p", _DecProb * 3), ("stats", _ct.c_void_p), ("stats_tiles", _ct.c_int), ("eps", _ct.c_float),
+                ("residual", _ct.c_void_p), ("ldr", _ct.c_long), ("rgb", _ct.c_void_p), ("out_stats", _ct.c_void_p),
+                ("drop_p", _ct.c_float), ("drop_seed", _ct.c_void_p), ("drop_site", _ct.c_uint), ("drop_t", _ct.c_int),
+                ("lr_p", _ct.c_float), ("lr_seed", _ct.c_void_p), ("lr_scale", _ct.c_float), ("lr_t", _ct.c_int)]
+
+
+def dec_pack_weight(w, gamma=None, beta=None, bias=None, out=None):
+    """w bf16 [N, K] row-major -> (Wp bf16 [N*K] in MFMA-fragment order, bc fp32 [N, 2] = (bias', colsum)); gamma / beta: the LayerNorm folded
+    into the weights (W' = W diag(gamma), bias' = bias + W beta). `out` = (Wp, bc) refreshes existing buffers in place (graph-captured pointers)."""
+    N, K = w.shape
+    assert w.dtype == BF16 and w.stride(1) == 1
+    wp, bc = out if out is not None else (torch.empty(((N + 15) // 16) * 16 * K, device=w.device, dtype=BF16),
+                                          torch.empty((N, 2), device=w.device, dtype=torch.float32))
+    LIB.call("cxr_dec_pack_weight_bf16", _p(w), w.stride(0), _p(gamma), _p(beta), _p(bias), _p(wp), _p(bc), N, K, _s())
+    return wp, bc
+
+
+def dec_pack_lora(a, gamma=None, beta=None, out=None):
+    """LoRA A bf16 [8, K] -> fragment-ordered B operand [A diag(gamma); A diag(beta)] (bf16 [16*K])"""
+    r, K = a.shape
+    assert r == 8 and a.is_contiguous()
+    o = out if out is not None else torch.empty(16 * K, device=a.device, dtype=BF16)
+    LIB.call("cxr_dec_pack_lora_bf16", _p(a), _p(gamma), _p(beta), _p(o), K, _s())
+    return o
+
+
+def dec_to_dal(x, want_stats=False, want_out=True):
+    """row-major bf16 [M, K] -> (decode-activation-layout copy | None, per-16-column-tile row statistics fp32 [K/16, M, 2] | None)"""
+    M, K = x.shape
+    out = torch.empty((dal_rows(M), K), device=x.device, dtype=BF16) if want_out else None
+    st = torch.empty((K // 16, M, 2), device=x.device, dtype=torch.float32) if want_stats else None
+    LIB.call("cxr_dec_to_dal_bf16", _p(x), x.stride(0), M, K, _p(out), _p(st), _s())
+    return out, st
+
+
+def dec_from_dal(x, M, K):
+    out = torch.empty((M, K), device=x.device, dtype=BF16)
+    LIB.call("cxr_dec_from_dal_bf16", _p(x), M, K, _p(out), out.stride(0), _s())
+    return out
+
+
+def dec_gemm(a, M, K, probs, act=0, out_f32=False, stats=None, eps=0.0, residual=None, rgb=None, out_stats=False, drop=None, lora=None, nc_hint=0):
+    """Decode-step linear layer(s) on `a` (bf16, decode activation layout of [M, K]). probs: 1-3 dicts {wp, bc, N, fold=False, out=None |
+    row-major tensor view [M, N] (e.g. KV-cache rows), lora=(Ap, B, site) | None}; a problem without `out` gets a fresh DAL buffer.
+    stats = (partials fp32 [tiles, M, 2]) of the LayerNorm input (of `a` for folded problems, of `residual` with rgb = fp32 [N, 2] (gamma, beta));
+    residual: DAL buffer added to problem 0; out_stats: also return problem 0's output partials; drop = (p, seed, site, t);
+    lora = (p, seed, scale, t). Returns ([outputs], out_stats | None)."""
+    d = _DecDesc()
+    d.A, d.M, d.K, d.nprob, d.act, d.out_f32, d.nc_hint = _p(a), M, K, len(probs), int(act), int(out_f32), int(nc_hint)
+    outs = []
+    for i, pr in enumerate(probs):
+        q = d.p[i]
+        N = pr["N"]
+        out = pr.get("out")
+        if out is None:
+            if out_f32:
+                out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+                q.c_dal, q.ldc = 0, N
+            else:
+                out = torch.empty((dal_rows(M), N), device=a.device, dtype=BF16)
+                q.c_dal, q.ldc = 1, 0
+        else:
+            assert out.shape[0] == M and out.shape[1] == N and out.stride(1) == 1
+            q.c_dal, q.ldc = 0, out.stride(0)
+        outs.append(out)
+        q.Wp, q.bc, q.C, q.N, q.fold, q.no_bias = _p(pr["wp"]), _p(pr["bc"]), _p(out), N, int(bool(pr.get("fold"))), 0
+        lo = pr.get("lora")
+        if lo is not None:
+            q.lr_Ap, q.lr_B, q.lr_site = _p(lo[0]), _p(lo[1]), int(lo[2])
+    if stats is not None:
+        d.stats, d.stats_tiles, d.eps = _p(stats), stats.shape[0], float(eps)
+    if residual is not None:
+        d.residual, d.ldr = _p(residual), 0
+        if rgb is not None:
+            d.rgb = _p(rgb)
+    ost = None
+    if out_stats:
+        ost = torch.empty((probs[0]["N"] // 16, M, 2), device=a.device, dtype=torch.float32)
+        d.out_stats = _p(ost)
+    if drop is not None and drop[0] > 0:
+        d.drop_p, d.drop_seed, d.drop_site, d.drop_t = float(drop[0]), _p(drop[1]), int(drop[2]), int(drop[3])
+    if lora is not None:
+        d.lr_p, d.lr_seed, d.lr_scale, d.lr_t = float(lora[0]), _p(lora[1]), float(lora[2]), int(lora[3])
+    LIB.call("cxr_dec_gemm_bf16", _ct.addressof(d), _s())
+    return outs, ost
 
 
 def gemm_skinny3(a, w0, b0, c0, w1, b1, c1, w2, b2, c2, ln_a=None, lora0=None, lora1=None, lora_in=None):

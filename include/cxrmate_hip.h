@@ -198,7 +198,8 @@ int cxr_dwproj_taps_layout(const long* table, int n, int total_blocks, hipStream
 /* ---- BERT embeddings (TF5:bert:70-108) ------------------------------------------------------------------------------------ */
 int cxr_bert_embed_fwd(const long* ids, const long* tt, const long* pid, const void* word, const void* type, const void* posw,
                        const float* gamma, const float* beta, float eps, void* sum_out, void* out, float* stats, long R, int T, int pos_offset,
-                       int C, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, hipStream_t stream);
+                       int C, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int out_dal, hipStream_t stream);
+                       /* out_dal != 0 (R <= 64): `out` in the decode activation layout of cxr_dec_gemm_bf16 */
                        /* drop_p > 0: embeddings dropout (TF5:bert:106) on the LayerNorm output, keyed (row / T, pos_offset + row % T, column) */
 int cxr_bert_embed_bwd(const void* dsum, const long* ids, const long* tt, const long* pid, float* dword, float* dtype, float* dpos, long R,
                        int T, int pos_offset, long padding_idx, int C, hipStream_t stream);
@@ -252,10 +253,47 @@ int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, const float* 
                              then not read */
 int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs, long v_bs,
                          long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, int kv_share, float* ws, long kv_hs, float drop_p,
-                         const unsigned int* drop_seed, unsigned int drop_site, int drop_t, hipStream_t stream);
+                         const unsigned int* drop_seed, unsigned int drop_site, int drop_t, int wg_keys, int o_dal, hipStream_t stream);
                          /* kv_share = 2: K, V, kpm have B/2 rows and query rows b, b + B/2 read row b (sample + greedy halves of one SCST step
                             share the cross-attention K/V); ws (optional, B*H*8*66 fp32): lets the launch split long key ranges over workgroups
-                            (flash-decoding) + a merge kernel; kv_hs = head stride of K/V in elements (64 for [B,T,H*64], T*64 for head-major [B,H,T,64]); drop_t = absolute position of the query */
+                            (flash-decoding) + a merge kernel; wg_keys = keys per workgroup pass: 0 (auto), 256, 288 or 576 (288 / 576 tile the encoder's 576 tokens per
+                            image); negative = that many keys per pass but never split (one looping workgroup per row and head); o_dal != 0: O is
+                            written in the decode activation layout of cxr_dec_gemm_bf16 (B <= 64); kv_hs = head stride of K/V in elements (64 for [B,T,H*64], T*64 for head-major [B,H,T,64]); drop_t = absolute position of the query */
+/* Decode-step linear layers (TF5:bert:164-203,289-351,466-496 at query length 1) in the form csrc/decode_gemm.hip explains:
+ *  - weights re-laid out once per weight version into MFMA-fragment order by cxr_dec_pack_weight_bf16, optionally with the LayerNorm that feeds
+ *    the layer FOLDED in: LN(x) . W^T + b = rstd * (x . W'^T - mean * colsum) + b', W' = W diag(gamma); bc fp32 [N][2] = (b', colsum);
+ *  - activations between the kernels of one decode step in the "decode activation layout" (DAL): element (m, k) of an [Mpad, K] matrix,
+ *    Mpad = 16 * ceil(M / 16) (48 -> 64), at ((k/32)*(Mpad/16) + m/16)*512 + ((k%32)/8*16 + m%16)*8 + k%8; cxr_dec_to_dal_bf16 /
+ *    cxr_dec_from_dal_bf16 convert from / to row-major;
+ *  - row statistics travel as per-16-column-tile partials: a launch with out_stats != NULL publishes (sum, M2 about the tile mean) per row for
+ *    each 16-column tile of problem 0's (rounded) output, fp32 [N0/16][M][2]; a consumer names them as `stats` (+ stats_tiles = N/16) and
+ *    combines them itself (Chan's update: deterministic). `stats` serves EITHER the A operand (problems with fold != 0) OR the residual
+ *    (rgb != NULL: residual = LN(residual), rgb fp32 [N][2] = (gamma, beta) of that LayerNorm).
+ * Up to three problems (same A) per launch; epilogue per problem: LN-fold -> +bias -> LoRA term -> act (1 = GELU) -> dropout (drop_p, rows =
+ * sequences at absolute position drop_t) -> + residual (problem 0; DAL when ldr == 0) -> store (c_dal: bf16 in DAL; else row-major bf16 / fp32
+ * with ldc). LoRA (train mode, REF:modelling_longitudinal.py:162-171): lr_Ap = cxr_dec_pack_lora_bf16 of A [8][K] with the feeding LayerNorm's
+ * gamma / beta (NULL for a problem without fold), lr_B bf16 [N][8]: C += lr_scale * dropout_{lr_p}(LN(x)) . A^T . B^T with the mask of
+ * (lr_seed, lr_site, row, lr_t). Requires M <= 64, K = 768 or 3072 (the instantiated reductions: BERT-base hidden / intermediate size),
+ * N even (Wp holds 16 * ceil(N / 16) rows, zero padded; out_stats needs N % 16 == 0). nc_hint: 0, or 16-column tiles per workgroup (1, 4; default 4 for vocabulary-sized N). */
+typedef struct cxr_dec_gemm_prob {
+    const void* Wp; const float* bc; void* C; long ldc; int N, c_dal, fold, no_bias;
+    const void* lr_Ap; const void* lr_B; unsigned int lr_site;
+} cxr_dec_gemm_prob;
+typedef struct cxr_dec_gemm_desc {
+    const void* A; int M, K, nprob, act, out_f32, nc_hint;
+    cxr_dec_gemm_prob p[3];
+    const float* stats; int stats_tiles; float eps;
+    const void* residual; long ldr; const float* rgb;
+    float* out_stats;
+    float drop_p; const unsigned int* drop_seed; unsigned int drop_site; int drop_t;
+    float lr_p; const unsigned int* lr_seed; float lr_scale; int lr_t;
+} cxr_dec_gemm_desc;
+int cxr_dec_gemm_bf16(const cxr_dec_gemm_desc* d, hipStream_t stream);      /* d is a HOST struct (device pointers inside) */
+int cxr_dec_pack_weight_bf16(const void* W, long ldw, const float* gamma, const float* beta, const float* bias, void* Wp, float* bc, int N, int K,
+                             hipStream_t stream);      /* W bf16 [N,K] row-major; gamma / beta NULL: no fold (colsum still written) */
+int cxr_dec_pack_lora_bf16(const void* A, const float* gamma, const float* beta, void* out, int K, hipStream_t stream);   /* A bf16 [8][K] -> out bf16 [16*K] */
+int cxr_dec_to_dal_bf16(const void* x, long ldx, int M, int K, void* out, float* stats, hipStream_t stream);   /* out and/or the out_stats partials of x */
+int cxr_dec_from_dal_bf16(const void* x, int M, int K, void* out, long ldo, hipStream_t stream);
 int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, long* inds, hipStream_t stream);
 
 /* ---- input pipeline tail (next-row f3): ToTensor + Normalize + pad_sequence of the reference collate (REF:modules/lightning_modules/

@@ -410,6 +410,128 @@ def test_attention_decode_single_query(ops, B, H, Tk, masked):
     close(dr, refd[:, 0], what="attn decode dropout (same hash as the tiled kernel / cxr_dropout_mask)")
 
 
+# ------------------------------------------------------------------------------------------------ decode-step linear layers (csrc/decode_gemm.hip)
+def _dal(ops, x):
+    return ops.dec_to_dal(x, want_stats=True)
+
+
+@pytest.mark.parametrize("M", [1, 16, 32, 50, 64])
+def test_dec_gemm_fold_residual_stats(ops, M):
+    """cxr_dec_gemm_bf16: LayerNorm folded into packed weights (rstd * (x W'^T - mean * colsum) + b'), LayerNorm on the residual operand, published
+    per-tile row statistics, decode-activation-layout input / output, grouped problems writing strided row-major rows (KV cache)."""
+    K, N = 768, 768
+    raw = dev((rnd(M, K) * 2 + 0.3).to(BF))
+    w, bias = dev(rnd(N, K, seed=1, scale=0.05).to(BF)), dev(rnd(N, seed=2))
+    g, b = dev(1 + 0.1 * rnd(K, seed=3)), dev(0.1 * rnd(K, seed=4))
+    ln = torch.nn.functional.layer_norm(raw.float(), (K,), g, b, 1e-12)
+    a_dal, st = _dal(ops, raw)
+    assert torch.equal(ops.dec_from_dal(a_dal, M, K), raw)                                   # layout round trip is exact
+    close(st[..., 0].sum(0), raw.float().sum(1), rtol=1e-5, atol=1e-3, what="tile sums")
+    wf, bcf = ops.dec_pack_weight(w, g, b, bias)
+    (out,), ost = ops.dec_gemm(a_dal, M, K, [dict(wp=wf, bc=bcf, N=N, fold=True)], act=1, stats=st, eps=1e-12, out_stats=True)
+    ref = torch.nn.functional.gelu(ln @ w.float().t() + bias)
+    got = ops.dec_from_dal(out, M, N)
+    close(got, ref, rtol=1e-2, what="LN-folded GEMM + GELU")
+    # the published statistics describe the rounded output: Chan-combined they give its mean / variance
+    gf = got.float()
+    mean = ost[..., 0].sum(0) / N
+    m2 = (ost[..., 1] + 16.0 * (ost[..., 0] / 16.0 - mean) ** 2).sum(0)
+    close(mean, gf.mean(1), rtol=1e-4, atol=1e-4, what="published mean")
+    close(m2 / N, gf.var(1, unbiased=False), rtol=1e-3, atol=1e-4, what="published variance")
+    # plain weights + LayerNorm(residual) + fp32 row-major output
+    x2 = dev(rnd(M, K, seed=5).to(BF))
+    x2d, _ = ops.dec_to_dal(x2)
+    wp, bcp = ops.dec_pack_weight(w, None, None, bias)
+    rgb = torch.stack([g, b], 1).contiguous()
+    (o32,), _ = ops.dec_gemm(x2d, M, K, [dict(wp=wp, bc=bcp, N=N)], out_f32=True, stats=st, eps=1e-12, residual=a_dal, rgb=rgb)
+    close(o32, x2.float() @ w.float().t() + bias + ln, rtol=5e-3, what="plain GEMM + LN(residual)")
+    (o_raw,), _ = ops.dec_gemm(x2d, M, K, [dict(wp=wp, bc=bcp, N=N)], out_f32=True, residual=a_dal)
+    close(o_raw, x2.float() @ w.float().t() + bias + raw.float(), rtol=5e-3, what="plain GEMM + raw residual")
+    # three grouped problems, k / v landing in strided cache rows; output dropout with the shared hash
+    cache = torch.zeros(M, 5, 2 * N, dtype=BF, device="cuda")
+    q = torch.empty(M, N, dtype=BF, device="cuda")
+    ops.dec_gemm(a_dal, M, K, [dict(wp=wf, bc=bcf, N=N, fold=True, out=q), dict(wp=wf, bc=bcf, N=N, fold=True, out=cache[:, 3, :N]),
+                              dict(wp=wp, bc=bcp, N=N, out=cache[:, 3, N:])], stats=st, eps=1e-12)
+    close(q, ln @ w.float().t() + bias, rtol=1e-2, what="grouped q")
+    close(cache[:, 3, :N], q, rtol=1e-6, atol=1e-6, what="grouped k (strided rows)")
+    close(cache[:, 3, N:], raw.float() @ w.float().t() + bias, rtol=1e-2, what="grouped v (unfolded problem in the same launch)")
+    assert float(cache[:, 2].abs().sum()) == 0 and float(cache[:, 4].abs().sum()) == 0
+    seed = torch.full((1,), 11, dtype=torch.int32, device="cuda")
+    (od,), _ = ops.dec_gemm(x2d, M, K, [dict(wp=wp, bc=bcp, N=N)], out_f32=True, residual=a_dal, drop=(0.1, seed, 19, 7))
+    f = ops.dropout_mask(M, N, 0.1, seed, 19, 1, 7, factor=True)
+    close(od, (x2.float() @ w.float().t() + bias) * f + raw.float(), rtol=5e-3, what="output dropout (hash of cxr_dropout_mask)")
+
+
+def test_dec_gemm_wide_and_vocab(ops):
+    """K = 3072 (FFN output projection, 16 waves) and a vocabulary-sized N that is not a multiple of the 64-column workgroup tile."""
+    M = 32
+    x = dev(rnd(M, 3072, scale=0.5).to(BF))
+    w, bias = dev(rnd(768, 3072, seed=1, scale=0.03).to(BF)), dev(rnd(768, seed=2))
+    xd, _ = ops.dec_to_dal(x)
+    wp, bc = ops.dec_pack_weight(w, None, None, bias)
+    (o,), _ = ops.dec_gemm(xd, M, 3072, [dict(wp=wp, bc=bc, N=768)], out_f32=True)
+    close(o, x.float() @ w.float().t() + bias, rtol=5e-3, what="K = 3072")
+    for V in (30000, 1000):
+        h = dev((rnd(M, 768, seed=3) + 0.2).to(BF))
+        hd, st = ops.dec_to_dal(h, want_stats=True)
+        g, b = dev(1 + 0.1 * rnd(768, seed=4)), dev(0.1 * rnd(768, seed=5))
+        wv, bv = dev(rnd(V, 768, seed=6, scale=0.05).to(BF)), dev(rnd(V, seed=7))
+        wf, bcf = ops.dec_pack_weight(wv, g, b, bv)
+        ref = torch.nn.functional.layer_norm(h.float(), (768,), g, b, 1e-12) @ wv.float().t() + bv
+        for nc in (1, 4):
+            (lg,), _ = ops.dec_gemm(hd, M, 768, [dict(wp=wf, bc=bcf, N=V, fold=True)], out_f32=True, stats=st, eps=1e-12, nc_hint=nc)
+            close(lg, ref, rtol=1e-2, what=f"LM head V={V} nc={nc}")
+
+
+def test_dec_gemm_lora_train_mode(ops):
+    """Train-mode LoRA inside the folded GEMM: C += s * dropout(LN(x)) A^T B^T with the branch's own input mask (hash of csrc/lora.hip)."""
+    M, K, N, s_ = 32, 768, 768, 4.0
+    raw = dev((rnd(M, K) * 2 + 0.3).to(BF))
+    w, bias = dev(rnd(N, K, seed=1, scale=0.05).to(BF)), dev(rnd(N, seed=2))
+    g, b = dev(1 + 0.1 * rnd(K, seed=3)), dev(0.1 * rnd(K, seed=4))
+    A, Bm = dev(rnd(8, K, seed=5, scale=0.05).to(BF)), dev(rnd(N, 8, seed=6, scale=0.05).to(BF))
+    ln = torch.nn.functional.layer_norm(raw.float(), (K,), g, b, 1e-12)
+    seed = torch.full((1,), 77, dtype=torch.int32, device="cuda")
+    a_dal, st = _dal(ops, raw)
+    wf, bcf = ops.dec_pack_weight(w, g, b, bias)
+    Ap = ops.dec_pack_lora(A, g, b)
+    for p_ in (0.0, 0.1):
+        fl = ops.dropout_mask(M, K, p_, seed, 21, 1, 7, factor=True) if p_ else torch.ones(M, K, device="cuda")
+        q = torch.empty(M, N, dtype=BF, device="cuda")
+        v = torch.empty(M, N, dtype=BF, device="cuda")
+        ops.dec_gemm(a_dal, M, K, [dict(wp=wf, bc=bcf, N=N, fold=True, out=q, lora=(Ap, Bm, 21)), dict(wp=wf, bc=bcf, N=N, fold=True, out=v)],
+                     stats=st, eps=1e-12, lora=(p_, seed, s_, 7))
+        base = ln @ w.float().t() + bias
+        close(q, base + s_ * ((ln * fl) @ A.float().t()) @ Bm.float().t(), rtol=1e-2, what=f"folded LoRA branch p={p_}")
+        close(v, base, rtol=1e-2, what="problem without LoRA in the same launch")
+    # no LayerNorm in front (first decoder layer: the embedding output is already normalised)
+    Ap0 = ops.dec_pack_lora(A)
+    wp, bcp = ops.dec_pack_weight(w, None, None, bias)
+    fl = ops.dropout_mask(M, K, 0.1, seed, 22, 1, 3, factor=True)
+    q = torch.empty(M, N, dtype=BF, device="cuda")
+    ops.dec_gemm(a_dal, M, K, [dict(wp=wp, bc=bcp, N=N, out=q, lora=(Ap0, Bm, 22))], lora=(0.1, seed, s_, 3))
+    close(q, raw.float() @ w.float().t() + bias + s_ * ((raw.float() * fl) @ A.float().t()) @ Bm.float().t(), rtol=1e-2, what="LoRA without fold")
+
+
+@pytest.mark.parametrize("B,H,Tk,wg", [(16, 12, 1152, -576), (16, 12, 1152, 576), (16, 12, 1152, 288), (16, 12, 1152, 256), (4, 12, 72, -576),
+                                       (3, 12, 300, 256), (3, 12, 300, -256)])
+def test_attention_decode_geometries_and_layout(ops, B, H, Tk, wg):
+    """Every workgroup geometry of the single-query attention kernel (split + merge, looping) gives the same result, also when written in the
+    decode activation layout."""
+    D = H * 64
+    q, kv = dev(rnd(2 * B, 1, D).to(BF)), dev(rnd(B, Tk, 2 * D, seed=1).to(BF))
+    k, v = kv[:, :, :D], kv[:, :, D:]
+    kpm = torch.ones(B, Tk, dtype=torch.uint8)
+    kpm[0, Tk // 2:] = 0
+    kpm[-1, 1:3] = 0
+    kpm = kpm.cuda()
+    ref, _ = ref_attention(q, torch.cat([k, k], 0), torch.cat([v, v], 0), H, 0.125, torch.cat([kpm, kpm], 0))
+    out = ops.attention_decode(q, k, v, H, 0.125, kpm=kpm, wg_keys=wg)
+    close(out, ref[:, 0], what=f"attn decode wg_keys={wg}")
+    od = ops.attention_decode(q, k, v, H, 0.125, kpm=kpm, wg_keys=wg, out_dal=True)
+    assert torch.equal(ops.dec_from_dal(od, 2 * B, D), out)
+
+
 # ------------------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("C", [64, 128, 192, 384, 768])
 def test_layernorm_fwd_bwd(ops, C):

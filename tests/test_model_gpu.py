@@ -147,34 +147,38 @@ def test_torch_optimizer_updates_reach_the_kernels(M):
     assert torch.equal(m.w16(key), m.f32(key).to(torch.bfloat16))                      # shadow == master after the refresh
 
 
-def test_graphed_tf_step_equals_eager_steps(M):
-    """K replays of GraphedTFStep followed by an eval forward == K eager tf_train_step calls followed by the same forward (the replayed AdamW must
-    advance the weight version the engines key their derived buffers on: BN folds, LoRA merges, transposed copies, decode sessions)."""
+def test_graphed_tf_step_leaves_no_stale_weight_copies(M):
+    """After K replays of GraphedTFStep every weight-derived buffer the engines cache per weight version (BN folds, tap re-layouts, LoRA merges,
+    transposed copies, packed decode weights, decode sessions) must describe the CURRENT weights: forward and generate of the stepped model ==
+    those of a fresh model loaded with its state_dict. (Graphed and eager steps themselves agree only up to the fp32-atomics noise Adam
+    amplifies on near-zero gradients, so they are compared through the loss.)"""
     from cxrmate_amd import training
     g, cfg, sd, x, inp, lab, am, tt = gu.tf_single_case()
-    outs = []
+    res = {}
     for graphed in (False, True):
         m = M.SingleCXREncoderDecoderModel(cfg, seed=None)
         m.load_state_dict(sd)
         opt = training.FusedAdamW(m, lr=1e-3)
         ttd = m.token_ids_to_token_type_ids(inp, [gu.SEP])
         args = (x.cuda(), inp.cuda(), am.cuda(), ttd, lab.cuda())
+        kw = dict(pixel_values=args[0], decoder_input_ids=args[1], decoder_attention_mask=args[2], decoder_token_type_ids=ttd)
+        gen = dict(pixel_values=args[0], special_token_ids=[gu.SEP], max_length=8, bos_token_id=gu.BOS, eos_token_id=None, pad_token_id=gu.PAD)
         with torch.no_grad():
-            m(pixel_values=args[0], decoder_input_ids=args[1], decoder_attention_mask=args[2], decoder_token_type_ids=ttd)   # derive the version-keyed buffers
+            m(**kw); m.generate(**gen)                                     # derive the version-keyed buffers (and a decode session) BEFORE stepping
             if graphed:
                 step = training.GraphedTFStep(m, opt, *args, gu.PAD, warmup=2)         # two eager steps inside, then three replays
-                for _ in range(3):
-                    step(*args)
+                losses = [float(step(*args)) for _ in range(3)]
             else:
-                for _ in range(5):
-                    training.tf_train_step(m, opt, *args, gu.PAD)
-            lg = m(pixel_values=args[0], decoder_input_ids=args[1], decoder_attention_mask=args[2], decoder_token_type_ids=ttd).logits
-            seq = m.generate(pixel_values=args[0], special_token_ids=[gu.SEP], max_length=8, bos_token_id=gu.BOS, eos_token_id=None, pad_token_id=gu.PAD)
-        outs.append((lg.float().cpu(), seq.cpu(), m.flat32.clone().cpu()))
-    (l0, s0, w0), (l1, s1, w1) = outs
-    assert float((w1 - w0).norm() / w0.norm()) < 1e-5                                   # the same five optimiser steps (fp32 atomics reorder only)
-    assert gu.rel_rms(l1.numpy(), l0.numpy()) < 2e-3                                    # ... seen by the forward that follows them
-    assert torch.equal(s0[:, :2], s1[:, :2])
+                losses = [float(training.tf_train_step(m, opt, *args, gu.PAD)) for _ in range(5)][2:]
+            lg, seq = m(**kw).logits, m.generate(**gen)
+            fresh = M.SingleCXREncoderDecoderModel(cfg, seed=None)
+            fresh.load_state_dict(m.state_dict())
+            lg2, seq2 = fresh(**kw).logits, fresh.generate(**gen)
+        assert torch.equal(lg, lg2), float((lg - lg2).abs().max())
+        assert torch.equal(seq, seq2)
+        res[graphed] = losses
+    assert res[True][0] > res[True][-1]                                   # the replayed steps train
+    np.testing.assert_allclose(res[True], res[False], rtol=2e-2)
 
 
 def test_training_step_gradients_do_not_depend_on_stream_overlap(M):
