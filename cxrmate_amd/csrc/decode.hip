@@ -399,10 +399,15 @@ struct AttnDecArgs {
     float scale, drop_inv; uint32_t drop_site, drop_thr16, has_kpm; int o_mt;          // o_mt > 0: O in the decode activation layout of [16*o_mt, H*64]
 };
 
-template <int G, int KU, int NG>
+// MASK: 0 = no key-padding mask, 1 = mask bytes at any alignment (KU byte loads per lane), 2 = mask rows 8-byte aligned and KU == 8 (one 8-byte
+// load per lane), 3 = `kpm` holds BIT words (uint32 per 32 keys, row stride kpm_bs BYTES; cxr_pack_mask_bits): two dword loads per lane.
+// A lane group owns KU CONSECUTIVE keys of a pass (keys k0 + grp*KU .. +KU), so its mask bits are one short run.
+// LOOP = false: the host guarantees one pass per workgroup (chunk <= NG * KU): without the loop-carried row registers the kernel needs ~40
+// registers less.
+template <int G, int KU, int NG, int MASK, bool LOOP>
 __global__ __launch_bounds__(NG * 8) void attn_decode_kernel(const AttnDecArgs a) {
-    __shared__ float gm[G][NG], gl[G][NG];
-    __shared__ float go[G][NG][64];
+    __shared__ float gm[G][NG / 8], gl[G][NG / 8];      // per-wave partial states
+    __shared__ float go[G][NG / 8][64];
     CXR_STAMP(0);
     asm volatile("" :: "s"(a.Q), "s"(a.K), "s"(a.V), "s"(a.kpm), "s"(a.drop_seed), "s"(a.q_bs), "s"(a.k_bs), "s"(a.k_rs), "s"(a.v_bs), "s"(a.v_rs),
                  "s"(a.kpm_bs), "s"(a.kv_hs), "s"(a.H), "s"(a.Tk), "s"(a.Bkv), "s"(a.nsplit), "s"(a.chunk));
@@ -415,8 +420,11 @@ __global__ __launch_bounds__(NG * 8) void attn_decode_kernel(const AttnDecArgs a
     const int h = bh % a.H, b = bh / a.H;                            // b indexes K/V (and the key-padding mask)
     const int k_lo = split * a.chunk, k_hi = (k_lo + a.chunk < a.Tk) ? k_lo + a.chunk : a.Tk;
     const int sub = tid & 7, grp = tid >> 3;
-    const bf16_t* kb = a.K + (long)b * a.k_bs + h * a.kv_hs + sub * 8;      // kv_hs = 64 for token-major [B,T,H*64], T*64 for head-major [B,H,T,64]
-    const bf16_t* vb = a.V + (long)b * a.v_bs + h * a.kv_hs + sub * 8;
+    // wave-uniform bases (SGPRs) + 32-bit per-lane element offsets: one address register per load instead of a 64-bit pair (the key range of
+    // one (row, head) spans < 2^31 elements: Tk <= 8192 rows)
+    const bf16_t* kb = a.K + (long)b * a.k_bs + h * a.kv_hs;              // kv_hs = 64 for token-major [B,T,H*64], T*64 for head-major [B,H,T,64]
+    const bf16_t* vb = a.V + (long)b * a.v_bs + h * a.kv_hs;
+    const uint32_t k_rs32 = (uint32_t)a.k_rs, v_rs32 = (uint32_t)a.v_rs, sub8 = (uint32_t)sub * 8u;
     const unsigned char* mrow = a.kpm + (long)b * a.kpm_bs;
     float m_run[G], l_run[G], o[G][8];
 #pragma unroll
@@ -426,19 +434,32 @@ __global__ __launch_bounds__(NG * 8) void attn_decode_kernel(const AttnDecArgs a
         for (int j = 0; j < 8; ++j) o[g][j] = 0.f;
     }
     uint4 kr[KU], vr[KU];
-    unsigned char mk[KU];
-    // the K/V rows of a pass are requested FIRST (oldest in the memory queue), everything small behind them; a compiler barrier keeps hipcc
-    // from hoisting the small loads (and a wait for them) in front of the stream
+    uint32_t mw[MASK == 1 ? KU : 2];                     // mask bytes / words of this lane's KU keys
+    // the K/V rows of a pass are requested FIRST (oldest in the memory queue), everything small behind them; keys past the range re-read the
+    // last valid row (an L1 hit) and are discarded by a select: no branch in the load phase
 #define ATTN_DEC_LOAD(k0_)                                                                                   \
-    _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                                         \
-        int key = (k0_) + u * NG + grp; key = key < k_hi ? key : k_hi - 1;                                   \
-        kr[u] = nt_load16(kb + (long)key * a.k_rs);                                                          \
-        vr[u] = nt_load16(vb + (long)key * a.v_rs);                                                          \
-    }                                                                                                        \
-    asm volatile("" ::: "memory");                                                                           \
-    _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                                         \
-        int key = (k0_) + u * NG + grp; key = key < k_hi ? key : k_hi - 1;                                   \
-        mk[u] = mrow[key];                                                                                   \
+    {                                                                                                        \
+        const int key0 = (k0_) + grp * KU;                                                                   \
+        _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                                     \
+            int key = key0 + u; key = key < k_hi ? key : k_hi - 1;                                           \
+            kr[u] = nt_load16(kb + ((uint32_t)key * k_rs32 + sub8));                                         \
+            vr[u] = nt_load16(vb + ((uint32_t)key * v_rs32 + sub8));                                         \
+        }                                                                                                    \
+        asm volatile("" ::: "memory");                                                                       \
+        if (MASK == 1) {                                                                                     \
+            _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                                 \
+                int key = key0 + u; key = key < k_hi ? key : k_hi - 1;                                       \
+                mw[u] = mrow[key];                                                                           \
+            }                                                                                                \
+        } else if (MASK == 2) {                                                                              \
+            const int kc = key0 < k_hi ? key0 : 0;          /* (a wholly dead group reads the row start) */ \
+            const uint2 t2 = *reinterpret_cast<const uint2*>(mrow + kc);                                     \
+            mw[0] = t2.x; mw[1] = t2.y;                                                                      \
+        } else if (MASK == 3) {                                                                              \
+            const int w0 = (key0 < k_hi ? key0 : 0) >> 5, wl = (k_hi - 1) >> 5;                              \
+            mw[0] = reinterpret_cast<const uint32_t*>(mrow)[w0];                                             \
+            mw[1] = reinterpret_cast<const uint32_t*>(mrow)[w0 < wl ? w0 + 1 : wl];                          \
+        }                                                                                                    \
     }
     ATTN_DEC_LOAD(k_lo);
     asm volatile("" ::: "memory");
@@ -447,30 +468,42 @@ __global__ __launch_bounds__(NG * 8) void attn_decode_kernel(const AttnDecArgs a
 #pragma unroll
     for (int g = 0; g < G; ++g) qraw[g] = *reinterpret_cast<const uint4*>(a.Q + (long)(b + g * a.Bkv) * a.q_bs + h * 64 + sub * 8);
     CXR_STAMP(1);
-    float qv[G][8];
     uint32_t drop_key[G];
+    const float qscale = a.scale * 1.4426950408889634f;                         // scores directly in the exp2 domain
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        unpack8(qraw[g], qv[g]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qv[g][j] *= a.scale * 1.4426950408889634f;      // scores directly in the exp2 domain
-        // train-mode dropout on the probabilities: same (b*H+h, query position, key) hash as the tiled kernels (attention.hip)
+    for (int g = 0; g < G; ++g)     // train-mode dropout on the probabilities: same (b*H+h, query position, key) hash as the tiled kernels (attention.hip)
         drop_key[g] = dropout_row_key(dseed, a.drop_site, (uint32_t)((b + g * a.Bkv) * a.H + h), (uint32_t)a.drop_t);
-    }
     for (int k0 = k_lo; k0 < k_hi; k0 += NG * KU) {
+        const int key0 = k0 + grp * KU;
+        // bit u of `okbits`: key0 + u may be attended to
+        uint32_t okbits = (1u << KU) - 1u;
+        if (MASK == 1) {
+            okbits = 0u;
+#pragma unroll
+            for (int u = 0; u < KU; ++u) okbits |= (mw[u] != 0u ? 1u : 0u) << u;
+        } else if (MASK == 2) {
+            okbits = 0u;
+#pragma unroll
+            for (int u = 0; u < KU; ++u) okbits |= (((u < 4 ? mw[0] >> (8 * u) : mw[1] >> (8 * (u - 4))) & 0xffu) != 0u ? 1u : 0u) << u;
+        } else if (MASK == 3) {
+            const uint64_t win = ((uint64_t)mw[1] << 32) | mw[0];
+            const int w0 = (key0 < k_hi ? key0 : 0) >> 5;
+            okbits = (uint32_t)(win >> (key0 - (w0 << 5))) & ((1u << KU) - 1u);          // (key0 >= k_hi: every key of the group is dead anyway)
+        }
         float sv[G][KU];
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             float kv[8];
             unpack8(kr[u], kv);
-            const bool live = k0 + u * NG + grp < k_hi;
-            const bool ok = !a.has_kpm || mk[u] != 0;
+            const bool live = key0 + u < k_hi;
+            const bool ok = (okbits >> u) & 1u;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                float d = 0.f;
+                float qv[8], d = 0.f;                                          // the query stays packed (4 registers per row)
+                unpack8(qraw[g], qv);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) d += qv[g][j] * kv[j];
-                d = group_sum<8>(d);
+                for (int j = 0; j < 8; ++j) d += qv[j] * kv[j];
+                d = group_sum<8>(d) * qscale;
                 sv[g][u] = live ? (ok ? d : -1.0e30f) : -3.0e38f;            // masked: finite sentinel; beyond the range: never wins the max, p = 0
             }
         }
@@ -485,41 +518,74 @@ __global__ __launch_bounds__(NG * 8) void attn_decode_kernel(const AttnDecArgs a
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[g][j] *= alpha;
         }
+        // dropout keep bits of this group's KU keys: each of the 8 lanes of a group hashes ONE (or two) of them, the group shares them by
+        // shuffle (every lane hashing every key was a quarter of the kernel's VALU work)
+        uint32_t keepbits[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            keepbits[g] = (1u << KU) - 1u;
+            if (a.drop_thr16) {
+                uint32_t mine = 0u;
+#pragma unroll
+                for (int u = sub; u < KU; u += 8) mine |= (dropout_keep(drop_key[g], (uint32_t)(key0 + u), a.drop_thr16) ? 1u : 0u) << u;
+                mine |= __shfl_xor(mine, 1, 64); mine |= __shfl_xor(mine, 2, 64); mine |= __shfl_xor(mine, 4, 64);
+                keepbits[g] = mine;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             float vv[8];
             unpack8(vr[u], vv);
-            const bool live = k0 + u * NG + grp < k_hi;
+            const bool live = key0 + u < k_hi;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const float p = live ? __builtin_amdgcn_exp2f(sv[g][u] - m_run[g]) : 0.f;
                 l_run[g] += p;
-                float pd = p;
-                if (a.drop_thr16) pd = dropout_keep(drop_key[g], (uint32_t)(k0 + u * NG + grp), a.drop_thr16) ? p * a.drop_inv : 0.f;
+                const float pd = ((keepbits[g] >> u) & 1u) ? p * a.drop_inv : 0.f;      // drop_inv == 1 without dropout
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[g][j] += pd * vv[j];
             }
         }
-        if (k0 + NG * KU < k_hi) { ATTN_DEC_LOAD(k0 + NG * KU); }          // wave-uniform: the next pass's rows (the registers are free again)
+        if (!LOOP) break;
+        if (k0 + NG * KU < k_hi) ATTN_DEC_LOAD(k0 + NG * KU);            // wave-uniform: the next pass's rows (the registers are free again)
     }
 #undef ATTN_DEC_LOAD
     CXR_STAMP(2);
+    // merge the running states: first the 8 key groups of each wave by butterfly (lanes 8, 16, 32 apart hold the same 8 output dims of other
+    // groups), then the NG/8 wave states through LDS (a serial loop over all NG groups by 64*G threads was 2 us of the kernel)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        if (sub == 0) { gm[g][grp] = m_run[g]; gl[g][grp] = l_run[g]; }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) go[g][grp][sub * 8 + j] = o[g][j];
+        for (int off = 8; off < 64; off <<= 1) {
+            const float mo = __shfl_xor(m_run[g], off, 64), lo = __shfl_xor(l_run[g], off, 64);
+            const float mn = fmaxf(m_run[g], mo);
+            const float wa = __builtin_amdgcn_exp2f(m_run[g] - mn), wb = __builtin_amdgcn_exp2f(mo - mn);
+            l_run[g] = l_run[g] * wa + lo * wb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[g][j] = o[g][j] * wa + __shfl_xor(o[g][j], off, 64) * wb;
+            m_run[g] = mn;
+        }
+    }
+    constexpr int NWV = NG / 8;                          // waves per workgroup
+    const int wv = tid >> 6;
+    if ((tid & 63) < 8) {                                // lanes 0..7 of each wave hold the wave's state (dims sub*8 .. +8)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (sub == 0) { gm[g][wv] = m_run[g]; gl[g][wv] = l_run[g]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) go[g][wv][sub * 8 + j] = o[g][j];
+        }
     }
     __syncthreads();
     CXR_STAMP(3);
     for (int e = tid; e < 64 * G; e += NG * 8) {
         const int g = e >> 6, d = e & 63;
         float M = -1.0e30f;
-#pragma unroll 8
-        for (int q = 0; q < NG; ++q) M = fmaxf(M, gm[g][q]);
+#pragma unroll
+        for (int q = 0; q < NWV; ++q) M = fmaxf(M, gm[g][q]);
         float num = 0.f, den = 0.f;
-#pragma unroll 8
-        for (int q = 0; q < NG; ++q) {
+#pragma unroll
+        for (int q = 0; q < NWV; ++q) {
             const float w = __builtin_amdgcn_exp2f(gm[g][q] - M);
             num += w * go[g][q][d];
             den += w * gl[g][q];
@@ -534,6 +600,25 @@ __global__ __launch_bounds__(NG * 8) void attn_decode_kernel(const AttnDecArgs a
         }
     }
     CXR_STAMP(4);
+}
+
+// key-padding mask bytes [B, T] -> bit words uint32 [B, words] (bit k%32 of word k/32 = key k may be attended to); one thread per word
+__global__ __launch_bounds__(256) void pack_mask_bits_kernel(const unsigned char* __restrict__ kpm, long kpm_bs, int B, int T, uint32_t* __restrict__ out, int words) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * words) return;
+    const int b = i / words, w = i % words;
+    uint32_t bits = 0u;
+    for (int j = 0; j < 32; ++j) {
+        const int k = w * 32 + j;
+        if (k < T && kpm[(long)b * kpm_bs + k] != 0) bits |= 1u << j;
+    }
+    out[i] = bits;
+}
+extern "C" int cxr_pack_mask_bits(const void* kpm, long kpm_bs, int B, int T, unsigned int* out, int words, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || words < cdiv(T, 32)) return CXR_ERR_ARG;
+    CXR_LAUNCH(pack_mask_bits_kernel, dim3(cdiv((long)B * words, 256)), dim3(256), 0, stream, (const unsigned char*)kpm, kpm_bs, B, T, out, words);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
 }
 
 // O[b,h,:] from the nsplit (<= 8) partial states of attn_decode_kernel: one 64-lane wave per (query row, head). All partial states are
@@ -570,19 +655,23 @@ __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const float* __r
 extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs,
                                     long v_bs, long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, int kv_share, float* ws,
                                     long kv_hs, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t, int wg_keys,
-                                    int o_dal, hipStream_t stream) {
+                                    int o_dal, int kpm_bits, hipStream_t stream) {
     if (B <= 0 || H <= 0 || Tk <= 0 || Tk > 8192 || (k_rs % 8) || (v_rs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8)) return CXR_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed) || (kv_share != 1 && kv_share != 2) || (B % kv_share)) return CXR_ERR_ARG;
+    if (k_rs <= 0 || v_rs <= 0 || (long)Tk * k_rs >= (1L << 31) || (long)Tk * v_rs >= (1L << 31)) return CXR_ERR_ARG;      // 32-bit in-range offsets
+    if (kpm_bits && (!kpm || (kpm_bs % 4) || ((uintptr_t)kpm % 4))) return CXR_ERR_ARG;
     const int Bkv = B / kv_share;
-    // keys per workgroup pass (= NG key groups x KU keys): 256 = 32 x 8 (KV-cache self-attention: one pass up to 256 cached tokens), 288 = 32 x 9
-    // and 576 = 64 x 9 (cross-attention: the encoder emits 576 tokens per image; a 1024-thread pass of 1152 keys does not fit 128 registers). With `ws`, ranges longer than one pass are split over
-    // workgroups (flash-decoding, B*H*8*66 floats) + the merge kernel; without it the workgroup loops.
-    const bool no_split = wg_keys < 0;                  // negative: |wg_keys| per pass, one looping workgroup per (row, head) even when ws is given
+    // keys per workgroup pass (= NG key groups x KU consecutive keys): 256 = 32 x 8 (KV-cache self-attention: one pass up to 256 cached tokens),
+    // 576 = 64 x 9 and 1152 = 128 x 9 (cross-attention: the encoder emits 576 tokens per image; 1152 = a 2-image study in ONE pass: no split,
+    // no merge launch). With `ws`, ranges longer than one pass are split over workgroups (flash-decoding, B*H*8*66 floats) + the merge kernel;
+    // negative wg_keys (or no ws): the workgroup loops.
+    const bool no_split = wg_keys < 0;
     if (no_split) wg_keys = -wg_keys;
-    if (wg_keys == 0) wg_keys = (Tk % 576 == 0) ? 576 : 256;
-    if (wg_keys != 256 && wg_keys != 288 && wg_keys != 576) return CXR_ERR_ARG;
+    if (wg_keys == 0) wg_keys = (Tk % 576 == 0) ? (Tk == 1152 ? 1152 : 576) : 256;       // whole studies of 1 / 2 images in one pass; more: 576-key splits
+    if (wg_keys != 256 && wg_keys != 288 && wg_keys != 576 && wg_keys != 1152) return CXR_ERR_ARG;
     int nsplit = 1, chunk = Tk;
     if (ws && Tk > wg_keys && cdiv(Tk, wg_keys) <= 8 && !no_split) { nsplit = cdiv(Tk, wg_keys); chunk = wg_keys; }
+    const bool loop = chunk > wg_keys;
     AttnDecArgs a;
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.O = (bf16_t*)O;
     a.kpm = kpm ? (const unsigned char*)kpm : (const unsigned char*)K; a.has_kpm = kpm ? 1u : 0u; a.kpm_bs = kpm ? kpm_bs : 0;
@@ -592,13 +681,21 @@ extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V,
     a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_site = drop_site; a.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u;
     a.o_mt = o_dal ? (cdiv(B, 16) == 3 ? 4 : cdiv(B, 16)) : 0;
     if (o_dal && B > 64) return CXR_ERR_ARG;
+    // mask form: bit words (two loads per lane), 8-byte-aligned byte rows with 8 keys per lane (one load), bytes (KU loads), none
+    const int mask = !kpm ? 0 : (kpm_bits ? 3 : ((wg_keys == 256 && (kpm_bs % 8) == 0 && ((uintptr_t)kpm % 8) == 0 && (nsplit == 1 || (chunk % 8) == 0)) ? 2 : 1));
     const dim3 grid(Bkv * H * nsplit);
-#define ATTN_DEC(G_, KU_, NG_) CXR_LAUNCH((attn_decode_kernel<G_, KU_, NG_>), grid, dim3(NG_ * 8), 0, stream, a)
-#define ATTN_DEC_G(KU_, NG_) do { if (kv_share == 2) ATTN_DEC(2, KU_, NG_); else ATTN_DEC(1, KU_, NG_); } while (0)
+#define ATTN_DEC(G_, KU_, NG_, MK_, L_) CXR_LAUNCH((attn_decode_kernel<G_, KU_, NG_, MK_, L_>), grid, dim3(NG_ * 8), 0, stream, a)
+#define ATTN_DEC_L(G_, KU_, NG_, MK_) do { if (loop) ATTN_DEC(G_, KU_, NG_, MK_, true); else ATTN_DEC(G_, KU_, NG_, MK_, false); } while (0)
+#define ATTN_DEC_M(G_, KU_, NG_) do { if (mask == 0) ATTN_DEC_L(G_, KU_, NG_, 0); else if (mask == 1) ATTN_DEC_L(G_, KU_, NG_, 1);          \
+                                      else if (mask == 3) ATTN_DEC_L(G_, KU_, NG_, 3); else ATTN_DEC_L(G_, 8, 32, 2); } while (0)
+#define ATTN_DEC_G(KU_, NG_) do { if (kv_share == 2) ATTN_DEC_M(2, KU_, NG_); else ATTN_DEC_M(1, KU_, NG_); } while (0)
     if (wg_keys == 256) ATTN_DEC_G(8, 32);
     else if (wg_keys == 288) ATTN_DEC_G(9, 32);
-    else ATTN_DEC_G(9, 64);
+    else if (wg_keys == 576) ATTN_DEC_G(9, 64);
+    else ATTN_DEC_G(9, 128);
 #undef ATTN_DEC_G
+#undef ATTN_DEC_M
+#undef ATTN_DEC_L
 #undef ATTN_DEC
     if (nsplit > 1) CXR_LAUNCH(attn_decode_merge_kernel, dim3(cdiv(B * H, 4)), dim3(256), 0, stream, ws, (bf16_t*)O, o_bs, H, nsplit, B * H, a.o_mt);
     CXR_LAUNCH_CHECK();

@@ -44,11 +44,13 @@ struct DecArgs {
     const uint32_t* drop_seed; const uint32_t* lr_seed;
     long ldr;                                                                    // 0: residual in decode activation layout
     int M, K, act, out_f32, stats_tiles; uint32_t flags;                          // flags: 1 residual, 2 residual is LayerNorm'ed, 4 out_stats, 8 stats given
-    float eps; uint32_t drop_site, drop_thr16; float drop_inv; int drop_t; uint32_t lr_thr16; float lr_inv, lr_scale; int lr_t, pad_;
+    float eps; uint32_t drop_site, drop_thr16; float drop_inv; int drop_t; uint32_t lr_thr16; float lr_inv, lr_scale; int lr_t;
+    int mtl;                                                                     // 16-row tiles of the activation LAYOUT (>= MT of one workgroup)
     DecProb p[3];
 };
 
-// MT = 16-row tiles of A (M <= 16*MT); NW = waves per workgroup, each owning KB k-steps of 32 (K = NW*KB*32); NC = 16-column tiles per
+// MT = 16-row tiles of A per workgroup (blockIdx.z selects the tile group: with MT = 1 a 32-row step runs as two workgroups per column tile,
+// each pulling half of the activations through its CU); NW = waves per workgroup, each owning KB k-steps of 32 (K = NW*KB*32); NC = 16-column tiles per
 // workgroup sharing the A fragments (4 for the vocabulary projection); LORA = the launch carries a LoRA branch.
 template <int MT, int NW, int KB, int NC, bool LORA>
 __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(const DecArgs g) {
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(const DecArgs g) {
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));      // a zero hipcc cannot see through: the seed reads stay plain per-lane loads (a uniform
     CXR_STAMP(6);                                       // address makes it wait for the value and v_readfirstlane it in the middle of the load phase)
     const int tile0 = blockIdx.x * NC;                  // (tiles beyond a narrower grouped problem compute on the last tile and store nothing)
+    const int row0 = blockIdx.z * ROWS, MTL = g.mtl;
     const int ntiles = (P.N + 15) >> 4;                 // (the packed weights are zero-padded to whole 16-column tiles)
     // ---- the weight stream and the activation rows first: every load of the wave is in flight before anything waits
     bf16x8_t wf[NC][KB], af[MT][KB], lf[LORA ? KB : 1];
@@ -86,11 +89,11 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(const DecArgs g) {
         for (int s = 0; s < KB; ++s) wf[c][s] = *reinterpret_cast<const bf16x8_t*>(wp + s * 512);
     }
     {
-        const bf16_t* ap = g.A + ((long)(wave * KB * MT) * 64 + lane) * 8;
+        const bf16_t* ap = g.A + ((long)(wave * KB * MTL + blockIdx.z * MT) * 64 + lane) * 8;
 #pragma unroll
         for (int s = 0; s < KB; ++s)
 #pragma unroll
-            for (int t = 0; t < MT; ++t) af[t][s] = *reinterpret_cast<const bf16x8_t*>(ap + (s * MT + t) * 512);
+            for (int t = 0; t < MT; ++t) af[t][s] = *reinterpret_cast<const bf16x8_t*>(ap + (s * MTL + t) * 512);
     }
     if (LORA) {
         const bf16_t* lp = P.lr_Ap + ((long)(wave * KB) * 64 + lane) * 8;
@@ -106,11 +109,11 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(const DecArgs g) {
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int e = tid + i * NT;                                               // pair index: row = e / (TW/2), columns 2*(e % (TW/2)), +1
-        int row = e / (TW / 2), n = n0 + 2 * (e % (TW / 2));
+        int row = row0 + e / (TW / 2), n = n0 + 2 * (e % (TW / 2));
         row = row < g.M ? row : g.M - 1; n = n < P.N ? n : P.N - 2;
         e_bc[i] = *reinterpret_cast<const float4*>(P.bc + n);
         e_rgb[i] = *reinterpret_cast<const float4*>(g.rgb + n);
-        e_res[i] = *reinterpret_cast<const uint32_t*>(g.residual + (g.ldr ? (long)row * g.ldr + n : dal_off(row, n, MT)));
+        e_res[i] = *reinterpret_cast<const uint32_t*>(g.residual + (g.ldr ? (long)row * g.ldr + n : dal_off(row, n, MTL)));
         if (LORA) {
             e_lb[i][0] = *reinterpret_cast<const uint4*>(P.lr_B + (long)n * 8);
             e_lb[i][1] = *reinterpret_cast<const uint4*>(P.lr_B + (long)n * 8 + 8);
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(const DecArgs g) {
     const int srow = tid / TPR, spart = tid % TPR;
     float2 pst[MAXP];
     {
-        const int r_ = srow < g.M ? srow : g.M - 1;
+        const int r_ = row0 + srow < g.M ? row0 + srow : g.M - 1;
 #pragma unroll
         for (int j = 0; j < MAXP; ++j) {
             int tile = spart + j * TPR; tile = tile < g.stats_tiles ? tile : 0;
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(const DecArgs g) {
                 const int kcol = (wave * KB + s) * 32 + fq * 8;
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
-                    int m = t * 16 + fr; m = m < g.M ? m : g.M - 1;
+                    int m = row0 + t * 16 + fr; m = m < g.M ? m : g.M - 1;
                     s16x8_t xm = __builtin_bit_cast(s16x8_t, af[t][s]), mk;
                     const uint32_t key = dropout_row_key(lseed, P.lr_site, (uint32_t)m, (uint32_t)g.lr_t);
 #pragma unroll
@@ -224,15 +227,15 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(const DecArgs g) {
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int e = tid + i * NT;
-        const int row = e / (TW / 2), col = 2 * (e % (TW / 2)), n = n0 + col;
-        const int t = row >> 4, l1 = ((row & 15) >> 2) * 16 + (col & 15), rr = row & 3, ct = col >> 4;
+        const int lrow = e / (TW / 2), row = row0 + lrow, col = 2 * (e % (TW / 2)), n = n0 + col;       // lrow: row inside this workgroup's tiles
+        const int t = lrow >> 4, l1 = ((lrow & 15) >> 2) * 16 + (col & 15), rr = lrow & 3, ct = col >> 4;
         const bool in_tile = e < PAIRS;
         float v0 = 0.f, v1 = 0.f;
         if (in_tile) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) { v0 += red[w][t][ct][l1][rr]; v1 += red[w][t][ct][l1 + 1][rr]; }
         }
-        const float mean = (has_stats && in_tile) ? s_mean[row] : 0.f, rstd = (has_stats && in_tile) ? s_rstd[row] : 1.f;
+        const float mean = (has_stats && in_tile) ? s_mean[lrow] : 0.f, rstd = (has_stats && in_tile) ? s_rstd[lrow] : 1.f;
         if (fold) { v0 = rstd * (v0 - mean * e_bc[i].y); v1 = rstd * (v1 - mean * e_bc[i].w); }
         if (P.flags & 1u) { v0 += e_bc[i].x; v1 += e_bc[i].z; }
         if (LORA) {
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(const DecArgs g) {
                 float lb0[8], lb1[8];
                 unpack8(e_lb[i][0], lb0); unpack8(e_lb[i][1], lb1);
 #pragma unroll
-                for (int r8 = 0; r8 < 8; ++r8) { const float tv = s_t[row][r8]; v0 += tv * lb0[r8]; v1 += tv * lb1[r8]; }
+                for (int r8 = 0; r8 < 8; ++r8) { const float tv = s_t[lrow][r8]; v0 += tv * lb0[r8]; v1 += tv * lb1[r8]; }
             }
         }
         if (g.act == 1) { v0 = gelu_f(v0); v1 = gelu_f(v1); }
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(const DecArgs g) {
         if (g.out_f32) { if (ok) *reinterpret_cast<float2*>(reinterpret_cast<float*>(P.C) + (long)row * P.ldc + n) = make_float2(v0, v1); }
         else {
             const uint32_t pk = pack2bf(v0, v1);
-            if (ok) *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(P.C) + (P.c_dal ? dal_off(row, n, MT) : (long)row * P.ldc + n)) = pk;
+            if (ok) *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(P.C) + (P.c_dal ? dal_off(row, n, MTL) : (long)row * P.ldc + n)) = pk;
             v0 = __uint_as_float(pk << 16); v1 = __uint_as_float(pk & 0xffff0000u);    // the statistics describe what the consumers will read
         }
         o_val[i][0] = ok ? v0 : 0.f; o_val[i][1] = ok ? v1 : 0.f;
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(const DecArgs g) {
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
                 const int e = tid + i * NT;
-                const int row = e >> 3;
+                const int row = row0 + (e >> 3);
                 const float S = group_sum<8>(o_val[i][0] + o_val[i][1]);
                 const float d0 = o_val[i][0] - S * (1.0f / 16.0f), d1 = o_val[i][1] - S * (1.0f / 16.0f);
                 const float M2 = group_sum<8>(d0 * d0 + d1 * d1);
@@ -389,13 +392,19 @@ extern "C" int cxr_dec_gemm_bf16(const cxr_dec_gemm_desc* d, hipStream_t stream)
     g.drop_thr16 = d->drop_p > 0.f ? dropout_thr16(d->drop_p) : 0u; g.drop_inv = 1.0f / (1.0f - d->drop_p); g.drop_t = d->drop_t;
     g.lr_seed = d->lr_seed ? d->lr_seed : (const uint32_t*)dummy; g.lr_thr16 = d->lr_p > 0.f ? dropout_thr16(d->lr_p) : 0u;
     g.lr_inv = 1.0f / (1.0f - d->lr_p); g.lr_scale = d->lr_scale; g.lr_t = d->lr_t;
-    const int mt = cdiv(g.M, 16) == 3 ? 4 : cdiv(g.M, 16);
-    // geometry: K = 768 -> 8 waves x 3 k-steps; K = 3072 -> 16 waves x 6 k-steps; vocabulary-sized problems take 64 columns per workgroup
+    const int mtl = cdiv(g.M, 16) == 3 ? 4 : cdiv(g.M, 16);
+    g.mtl = mtl;
+    // geometry: K = 768 -> 8 waves x 3 k-steps; K = 3072 -> 16 waves x 6 k-steps; vocabulary-sized problems take 64 columns per workgroup.
+    // Row tiles: launches that still fit one workgroup per CU afterwards (the 768-wide single problems: 48 column tiles) run ONE 16-row tile
+    // per workgroup (grid.z = tiles): a CU retires ~46 GB/s of loads whatever the mix, so halving the activation rows per workgroup shortens
+    // the load phase (768x768: 6.2 -> 5.7 us, 768x3072: 9.1 -> 8.2); wider launches lose more to the second wave of workgroups than they gain
     int nc = (d->nprob == 1 && nmax >= 8192 && !d->out_stats && !any_lora) ? 4 : 1;
     if (d->nc_hint == 1 || (d->nc_hint == 4 && !d->out_stats && !any_lora)) nc = d->nc_hint;
     if (g.K != 768 && g.K != 3072) return CXR_ERR_ARG;            // instantiated reductions: BERT-base hidden / intermediate size
     if (g.K == 3072 && (any_lora || nc != 1)) return CXR_ERR_ARG;
-    const dim3 grid(cdiv(nmax, 16 * nc), d->nprob);
+    const bool fits = (long)cdiv(nmax, 16 * nc) * d->nprob * mtl <= 256;                          // one workgroup per CU after the split
+    const int mt = (d->mt_hint > 0 ? d->mt_hint == 1 : (fits && mtl > 1)) ? 1 : mtl;               // tiles per workgroup
+    const dim3 grid(cdiv(nmax, 16 * nc), d->nprob, mtl / mt);
 #define DG(MT_, NW_, KB_, NC_, L_) CXR_LAUNCH((dec_gemm_kernel<MT_, NW_, KB_, NC_, L_>), grid, dim3(NW_ * 64), 0, stream, g)
 #define DGM(MT_) do {                                                                                              \
         if (g.K == 3072) DG(MT_, 16, 6, 1, false);                                                                  \

@@ -29,7 +29,7 @@ SITE_EMBED = 1
 _CROSS_KV_FUSED = os.environ.get("CXR_CROSS_KV_FUSED", "1") != "0"      # A/B switch: 0 = one K / V GEMM per layer
 _LORA_IN_KERNEL = os.environ.get("CXR_LORA_IN_KERNEL", "1") != "0"        # A/B switch: 0 = separate LoRA down-projection launch per decode layer
 _SELF_QKV_FUSED = os.environ.get("CXR_SELF_QKV_FUSED", "1") != "0"      # A/B switch: 0 = separate query / key / value GEMMs
-_CROSS_WG_KEYS = int(os.environ.get("CXR_CROSS_WG_KEYS", "-576"))          # cached cross-attention geometry (ops.attention_decode wg_keys)
+_CROSS_WG_KEYS = int(os.environ.get("CXR_CROSS_WG_KEYS", "0"))          # cached cross-attention geometry (ops.attention_decode wg_keys)
 
 
 def _site(layer, k):
@@ -49,6 +49,7 @@ class KVCache:
         self.ck = [None] * layers
         self.cv = [None] * layers
         self.cross_ready = False         # ck/cv may be pre-allocated static buffers (graph replay): filled at prefill
+        self.enc_bits = None             # optional: the encoder key-padding mask as bit words (ops.pack_mask_bits), read by the cached steps
         self.len = 0
         self.Tmax = Tmax
 
@@ -712,7 +713,7 @@ class BertEngine:
             q2 = torch.empty((B, D), dtype=BF16, device=dev)
             ops.dec_gemm(cur, B, D, [prob((l, "cq"), D, q2)], stats=cur_st, eps=eps)
             ctx2 = ops.attention_decode(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask, drop=(pa, seed, _site(l, 2), past),
-                                        wg_keys=_CROSS_WG_KEYS, out_dal=True)
+                                        wg_keys=_CROSS_WG_KEYS, out_dal=True, kpm_bits=cache.enc_bits if enc_mask is not None else None)
             (a2,), st2 = ops.dec_gemm(ctx2, B, D, [prob((l, "cout"), D)], out_stats=True, drop=drop(_site(l, 3)), **res_kw())
             cur, cur_st, cur_ln = a2, st2, lp + "crossattention.output.LayerNorm"
             (f,), _ = ops.dec_gemm(cur, B, D, [prob((l, "ffn1"), F)], act=1, stats=cur_st, eps=eps)

@@ -33,6 +33,7 @@ class DecodeSession:
         self.nxt = torch.zeros(rows, dtype=torch.int64, device=dev)
         self.enc16 = torch.empty((B, S, D), dtype=torch.bfloat16, device=dev)
         self.enc_mask8 = torch.empty((B, S), dtype=torch.uint8, device=dev) if has_mask else None
+        self.enc_bits = torch.zeros((B, (S + 31) // 32), dtype=torch.int32, device=dev) if has_mask else None      # the same mask as bit words (decode kernels)
         self.cache = model._dec.new_cache(rows, Lmax, dev)
         L = model.config.decoder.num_hidden_layers
         self.cache.ck = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
@@ -47,7 +48,7 @@ class DecodeSession:
         self.new_id = torch.zeros((rows, 1), dtype=torch.int64, device=dev)
         self.tt1 = torch.zeros((rows, 1), dtype=torch.int64, device=dev)
         self.pos1 = torch.zeros((rows, 1), dtype=torch.int64, device=dev)
-        self.mask8 = torch.zeros((rows, Lmax), dtype=torch.uint8, device=dev)
+        self.mask8 = torch.zeros((rows, (Lmax + 7) // 8 * 8), dtype=torch.uint8, device=dev)[:, :Lmax]      # 8-byte aligned rows: one load per lane
         self.tt_hist = torch.zeros((rows, Lmax), dtype=torch.int64, device=dev)
         self.pos_hist = torch.zeros((rows, Lmax), dtype=torch.int64, device=dev)
         self.graphs = {}
@@ -67,6 +68,8 @@ class DecodeSession:
         self.enc16.copy_(enc16)
         if self.enc_mask8 is not None:
             self.enc_mask8.copy_(enc_mask8)
+            ops.pack_mask_bits(self.enc_mask8, out=self.enc_bits)
+        self.cache.enc_bits = self.enc_bits
         self.cache.len = 0
         self.cache.cross_ready = False
         if m.training:

@@ -906,7 +906,16 @@ def gemm_skinny(a, w, bias=None, residual=None, act=0, out=None, out_f32=False, 
     return out
 
 
-def attention_decode(q, k, v, heads, scale, kpm=None, out=None, drop=None, head_major=False, wg_keys=0, out_dal=False):
+def pack_mask_bits(kpm, out=None):
+    """key-padding mask uint8 [B, T] (1 = attend) -> bit words int32 [B, ceil(T/32)] for attention_decode(kpm_bits=...)"""
+    B, T = kpm.shape
+    if out is None:
+        out = torch.empty((B, (T + 31) // 32), device=kpm.device, dtype=torch.int32)
+    LIB.call("cxr_pack_mask_bits", _p(kpm), kpm.stride(0), B, T, _p(out), out.shape[1], _s())
+    return out
+
+
+def attention_decode(q, k, v, heads, scale, kpm=None, out=None, drop=None, head_major=False, wg_keys=0, out_dal=False, kpm_bits=None):
     """q [B,1,H*64] (or [B,H*64]); k, v [B or B/2,Tk,H*64] views (batch/row strides free) -> [B, H*64]. With B/2 K/V rows, query rows
     b and b + B/2 share K/V row b."""
     B = q.shape[0]
@@ -925,9 +934,13 @@ def attention_decode(q, k, v, heads, scale, kpm=None, out=None, drop=None, head_
     D = heads * 64
     if out is None:
         out = torch.empty((dal_rows(B) if out_dal else B, D), device=q.device, dtype=BF16)
-    LIB.call("cxr_attn_decode_bf16", _p(q), _p(k), _p(v), _p(out), _p(kpm), q.stride(0), k_bs, k_rs, v_bs, v_rs,
-             out.stride(0), kpm.stride(0) if kpm is not None else 0, B, heads, Tk, float(scale), share, _p(ws), int(hs), *_drop_args(drop),
-             int(wg_keys), int(bool(out_dal)), _s())
+    if kpm_bits is not None:                                    # bit words from pack_mask_bits (row stride in bytes)
+        mask, mask_bs, bits = kpm_bits, kpm_bits.stride(0) * 4, 1
+    else:
+        mask, mask_bs, bits = kpm, (kpm.stride(0) if kpm is not None else 0), 0
+    LIB.call("cxr_attn_decode_bf16", _p(q), _p(k), _p(v), _p(out), _p(mask), q.stride(0), k_bs, k_rs, v_bs, v_rs,
+             out.stride(0), mask_bs, B, heads, Tk, float(scale), share, _p(ws), int(hs), *_drop_args(drop),
+             int(wg_keys), int(bool(out_dal)), bits, _s())
     return out
 
 
@@ -947,7 +960,7 @@ class _DecProb(_ct.Structure):
 class _DecDesc(_ct.Structure):
     """Mirror of `cxr_dec_gemm_desc`."""
     _fields_ = [("A", _ct.c_void_p), ("M", _ct.c_int), ("K", _ct.c_int), ("nprob", _ct.c_int), ("act", _ct.c_int), ("out_f32", _ct.c_int),
-                ("nc_hint", _ct.c_int), ("p", _DecProb * 3), ("stats", _ct.c_void_p), ("stats_tiles", _ct.c_int), ("eps", _ct.c_float),
+                ("nc_hint", _ct.c_int), ("mt_hint", _ct.c_int), ("p", _DecProb * 3), ("stats", _ct.c_void_p), ("stats_tiles", _ct.c_int), ("eps", _ct.c_float),
                 ("residual", _ct.c_void_p), ("ldr", _ct.c_long), ("rgb", _ct.c_void_p), ("out_stats", _ct.c_void_p),
                 ("drop_p", _ct.c_float), ("drop_seed", _ct.c_void_p), ("drop_site", _ct.c_uint), ("drop_t", _ct.c_int),
                 ("lr_p", _ct.c_float), ("lr_seed", _ct.c_void_p), ("lr_scale", _ct.c_float), ("lr_t", _ct.c_int)]
@@ -988,14 +1001,15 @@ def dec_from_dal(x, M, K):
     return out
 
 
-def dec_gemm(a, M, K, probs, act=0, out_f32=False, stats=None, eps=0.0, residual=None, rgb=None, out_stats=False, drop=None, lora=None, nc_hint=0):
+def dec_gemm(a, M, K, probs, act=0, out_f32=False, stats=None, eps=0.0, residual=None, rgb=None, out_stats=False, drop=None, lora=None, nc_hint=0,
+             mt_hint=0):
     """Decode-step linear layer(s) on `a` (bf16, decode activation layout of [M, K]). probs: 1-3 dicts {wp, bc, N, fold=False, out=None |
     row-major tensor view [M, N] (e.g. KV-cache rows), lora=(Ap, B, site) | None}; a problem without `out` gets a fresh DAL buffer.
     stats = (partials fp32 [tiles, M, 2]) of the LayerNorm input (of `a` for folded problems, of `residual` with rgb = fp32 [N, 2] (gamma, beta));
     residual: DAL buffer added to problem 0; out_stats: also return problem 0's output partials; drop = (p, seed, site, t);
     lora = (p, seed, scale, t). Returns ([outputs], out_stats | None)."""
     d = _DecDesc()
-    d.A, d.M, d.K, d.nprob, d.act, d.out_f32, d.nc_hint = _p(a), M, K, len(probs), int(act), int(out_f32), int(nc_hint)
+    d.A, d.M, d.K, d.nprob, d.act, d.out_f32, d.nc_hint, d.mt_hint = _p(a), M, K, len(probs), int(act), int(out_f32), int(nc_hint), int(mt_hint)
     outs = []
     for i, pr in enumerate(probs):
         q = d.p[i]

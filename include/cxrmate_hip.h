@@ -253,11 +253,13 @@ int cxr_gemm_skinny3_bf16(const void* A, long lda, const void* W0, const float* 
                              then not read */
 int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs, long v_bs,
                          long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, int kv_share, float* ws, long kv_hs, float drop_p,
-                         const unsigned int* drop_seed, unsigned int drop_site, int drop_t, int wg_keys, int o_dal, hipStream_t stream);
+                         const unsigned int* drop_seed, unsigned int drop_site, int drop_t, int wg_keys, int o_dal, int kpm_bits,
+                         hipStream_t stream);
                          /* kv_share = 2: K, V, kpm have B/2 rows and query rows b, b + B/2 read row b (sample + greedy halves of one SCST step
                             share the cross-attention K/V); ws (optional, B*H*8*66 fp32): lets the launch split long key ranges over workgroups
-                            (flash-decoding) + a merge kernel; wg_keys = keys per workgroup pass: 0 (auto), 256, 288 or 576 (288 / 576 tile the encoder's 576 tokens per
-                            image); negative = that many keys per pass but never split (one looping workgroup per row and head); o_dal != 0: O is
+                            (flash-decoding) + a merge kernel; wg_keys = keys per workgroup pass: 0 (auto), 256, 288, 576 or 1152 (288 / 576 / 1152 tile the encoder's 576
+                            tokens per image); negative = that many keys per pass but never split (one looping workgroup per row and
+                            head); kpm_bits != 0: kpm holds bit words from cxr_pack_mask_bits (row stride kpm_bs in BYTES) instead of bytes; o_dal != 0: O is
                             written in the decode activation layout of cxr_dec_gemm_bf16 (B <= 64); kv_hs = head stride of K/V in elements (64 for [B,T,H*64], T*64 for head-major [B,H,T,64]); drop_t = absolute position of the query */
 /* Decode-step linear layers (TF5:bert:164-203,289-351,466-496 at query length 1) in the form csrc/decode_gemm.hip explains:
  *  - weights re-laid out once per weight version into MFMA-fragment order by cxr_dec_pack_weight_bf16, optionally with the LayerNorm that feeds
@@ -274,13 +276,14 @@ int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, c
  * with ldc). LoRA (train mode, REF:modelling_longitudinal.py:162-171): lr_Ap = cxr_dec_pack_lora_bf16 of A [8][K] with the feeding LayerNorm's
  * gamma / beta (NULL for a problem without fold), lr_B bf16 [N][8]: C += lr_scale * dropout_{lr_p}(LN(x)) . A^T . B^T with the mask of
  * (lr_seed, lr_site, row, lr_t). Requires M <= 64, K = 768 or 3072 (the instantiated reductions: BERT-base hidden / intermediate size),
- * N even (Wp holds 16 * ceil(N / 16) rows, zero padded; out_stats needs N % 16 == 0). nc_hint: 0, or 16-column tiles per workgroup (1, 4; default 4 for vocabulary-sized N). */
+ * N even (Wp holds 16 * ceil(N / 16) rows, zero padded; out_stats needs N % 16 == 0). mt_hint: 0 auto, 1 = one 16-row tile per workgroup,
+ * 2 = all rows in one workgroup. nc_hint: 0, or 16-column tiles per workgroup (1, 4; default 4 for vocabulary-sized N). */
 typedef struct cxr_dec_gemm_prob {
     const void* Wp; const float* bc; void* C; long ldc; int N, c_dal, fold, no_bias;
     const void* lr_Ap; const void* lr_B; unsigned int lr_site;
 } cxr_dec_gemm_prob;
 typedef struct cxr_dec_gemm_desc {
-    const void* A; int M, K, nprob, act, out_f32, nc_hint;
+    const void* A; int M, K, nprob, act, out_f32, nc_hint, mt_hint;
     cxr_dec_gemm_prob p[3];
     const float* stats; int stats_tiles; float eps;
     const void* residual; long ldr; const float* rgb;
@@ -294,6 +297,8 @@ int cxr_dec_pack_weight_bf16(const void* W, long ldw, const float* gamma, const 
 int cxr_dec_pack_lora_bf16(const void* A, const float* gamma, const float* beta, void* out, int K, hipStream_t stream);   /* A bf16 [8][K] -> out bf16 [16*K] */
 int cxr_dec_to_dal_bf16(const void* x, long ldx, int M, int K, void* out, float* stats, hipStream_t stream);   /* out and/or the out_stats partials of x */
 int cxr_dec_from_dal_bf16(const void* x, int M, int K, void* out, long ldo, hipStream_t stream);
+int cxr_pack_mask_bits(const void* kpm, long kpm_bs, int B, int T, unsigned int* out, int words, hipStream_t stream);
+                       /* key-padding bytes [B,T] (1 = attend) -> uint32 [B][words], bit k%32 of word k/32 */
 int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, long* inds, hipStream_t stream);
 
 /* ---- input pipeline tail (next-row f3): ToTensor + Normalize + pad_sequence of the reference collate (REF:modules/lightning_modules/

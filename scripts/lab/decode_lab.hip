@@ -285,6 +285,7 @@ int main(int argc, char** argv) {
     };
     auto prob = [&](const void* Wp, const float* bc, void* Cc, int N, int fold, int dal, long ldc) {
         cxr_dec_gemm_prob q; memset(&q, 0, sizeof(q)); q.Wp = Wp; q.bc = bc; q.C = Cc; q.N = N; q.fold = fold; q.c_dal = dal; q.ldc = ldc; return q; };
+    newgemm("new 768x768 LN-fold, all rows per WG", 48, 8, [&](int i, cxr_dec_gemm_desc& d) { d.p[0] = prob(Wf768[i % NSET], bcf768[i % NSET], Cd, D, 1, 1, 0); d.stats = stA; d.stats_tiles = 48; d.mt_hint = 2; }, 48);
     newgemm("new 768x768 plain", 48, 8, [&](int i, cxr_dec_gemm_desc& d) { d.p[0] = prob(Wp768[i % NSET], bcp768[i % NSET], Cd, D, 0, 1, 0); }, 48);
     newgemm("new 768x768 LN-fold", 48, 8, [&](int i, cxr_dec_gemm_desc& d) { d.p[0] = prob(Wf768[i % NSET], bcf768[i % NSET], Cd, D, 1, 1, 0); d.stats = stA; d.stats_tiles = 48; }, 48);
     newgemm("new 768x768 res-LN + drop + out_stats", 48, 8, [&](int i, cxr_dec_gemm_desc& d) {
@@ -326,37 +327,35 @@ int main(int argc, char** argv) {
         float* ws = dalloc<float>((size_t)B * H * 8 * 66);
         unsigned int* wc = dalloc<unsigned int>(B * H);
         unsigned char* kpm = dalloc<unsigned char>((size_t)Bkv * S); HC(hipMemset(kpm, 1, (size_t)Bkv * S));
-        struct { const char* name; int wg; int blocks; int waves; } geo[] = {
-            {"cross-attn 256 keys/WG split 5 + merge", 256, 960, 4}, {"cross-attn 288 keys/WG split 4 + merge", 288, 768, 4},
-            {"cross-attn 576 keys/WG split 2 + merge", 576, 384, 8}, {"cross-attn 576 keys/pass, 1 looping WG per pair", -576, 192, 8},
-            {"cross-attn 288 keys/pass, 1 looping WG per pair", -288, 192, 4}};
+        unsigned int* kbits = dalloc<unsigned int>((size_t)Bkv * 36);
+        RC(cxr_pack_mask_bits(kpm, S, Bkv, S, kbits, 36, 0));
+        struct { const char* name; int wg; int blocks; int waves; int bits; } geo[] = {
+            {"cross-attn 256 keys/WG split 5 + merge, byte mask", 256, 960, 4, 0}, {"cross-attn 288 keys/WG split 4 + merge, bit mask", 288, 768, 4, 1},
+            {"cross-attn 576 keys/WG split 2 + merge, bit mask", 576, 384, 8, 1}, {"cross-attn 576 keys/pass looping, bit mask", -576, 192, 8, 1},
+            {"cross-attn 576 keys/pass looping, byte mask", -576, 192, 8, 0},
+            {"cross-attn 1152 keys in ONE pass (1024 threads), bit mask", 1152, 192, 16, 1}, {"cross-attn 1152 keys in ONE pass, byte mask", 1152, 192, 16, 0}};
         std::vector<uint16_t> ref((size_t)B * D), got((size_t)B * D);
         for (auto& gm : geo) {
+            const void* mk = gm.bits ? (const void*)kbits : (const void*)kpm; const long mbs = gm.bits ? 36 * 4 : S;
             bench(gm.name, 24, [&](int i, hipStream_t s) {
-                RC(cxr_attn_decode_bf16(q, K[i % NKV], Vv[i % NKV], o, kpm, D, (long)S * D, D, (long)S * D, D, D, S, B, H, S, 0.125f, 2, ws, 64, 0.1f, seed, 3, 9, gm.wg, s)); }, gm.blocks, gm.waves, 5);
-            RC(cxr_attn_decode_bf16(q, K[0], Vv[0], o2, kpm, D, (long)S * D, D, (long)S * D, D, D, S, B, H, S, 0.125f, 2, ws, 64, 0.1f, seed, 3, 9, gm.wg, 0));
+                RC(cxr_attn_decode_bf16(q, K[i % NKV], Vv[i % NKV], o, mk, D, (long)S * D, D, (long)S * D, D, D, mbs, B, H, S, 0.125f, 2, ws, 64, 0.1f, seed, 3, 9, gm.wg, 0, gm.bits, s)); }, gm.blocks, gm.waves, 5);
+            RC(cxr_attn_decode_bf16(q, K[0], Vv[0], o2, mk, D, (long)S * D, D, (long)S * D, D, D, mbs, B, H, S, 0.125f, 2, ws, 64, 0.1f, seed, 3, 9, gm.wg, 0, gm.bits, 0));
             HC(hipDeviceSynchronize());
             HC(hipMemcpy(got.data(), o2, got.size() * 2, hipMemcpyDeviceToHost));
             if (gm.wg == 256) ref = got;
             double e = 0, r2 = 0; for (size_t i = 0; i < got.size(); ++i) { double a_ = b2f(got[i]), b_ = b2f(ref[i]); e += (a_ - b_) * (a_ - b_); r2 += b_ * b_; }
             if (!g_filter || strstr(gm.name, g_filter)) printf("    rel-rms vs the 256-key geometry: %.6f\n", sqrt(e / (r2 + 1e-30)));
         }
-        bench("cross-attn 576 split + merge, head-major K/V", 24, [&](int i, hipStream_t s) {
-            RC(cxr_attn_decode_bf16(q, K[i % NKV], Vv[i % NKV], o2, kpm, D, (long)S * D, 64, (long)S * D, 64, D, S, B, H, S, 0.125f, 2, ws, (long)S * 64, 0.1f, seed, 3, 9, 576, s)); }, 384, 8, 5);
-        bench("cross-attn 576 split + merge, no dropout", 24, [&](int i, hipStream_t s) {
-            RC(cxr_attn_decode_bf16(q, K[i % NKV], Vv[i % NKV], o2, kpm, D, (long)S * D, D, (long)S * D, D, D, S, B, H, S, 0.125f, 2, ws, 64, 0.f, nullptr, 0, 0, 576, s)); }, 384, 8, 5);
-        bench("cross-attn 576 split + merge, no mask", 24, [&](int i, hipStream_t s) {
-            RC(cxr_attn_decode_bf16(q, K[i % NKV], Vv[i % NKV], o2, nullptr, D, (long)S * D, D, (long)S * D, D, D, 0, B, H, S, 0.125f, 2, ws, 64, 0.1f, seed, 3, 9, 576, s)); }, 384, 8, 5);
         // self-attention over a 128-token cache, 32 rows
-        const int T = 128, Tmax = 261;
+        const int T = 128, Tmax = 264;
         uint16_t* Ks = dbf16((size_t)B * Tmax * D, 1.0f); uint16_t* Vs = dbf16((size_t)B * Tmax * D, 1.0f);
         unsigned char* am = dalloc<unsigned char>((size_t)B * Tmax); HC(hipMemset(am, 1, (size_t)B * Tmax));
         bench("self-attn T=128 (32 rows x 12 heads)", 48, [&](int i, hipStream_t s) {
-            RC(cxr_attn_decode_bf16(q, Ks, Vs, o, am, D, (long)Tmax * D, D, (long)Tmax * D, D, D, Tmax, B, H, T, 0.125f, 1, ws, 64, 0.1f, seed, 3, 9, 256, s)); }, 384, 4, 5);
+            RC(cxr_attn_decode_bf16(q, Ks, Vs, o, am, D, (long)Tmax * D, D, (long)Tmax * D, D, D, Tmax, B, H, T, 0.125f, 1, ws, 64, 0.1f, seed, 3, 9, 256, 0, 0, s)); }, 384, 4, 5);
         bench("self-attn T=250", 48, [&](int i, hipStream_t s) {
-            RC(cxr_attn_decode_bf16(q, Ks, Vs, o, am, D, (long)Tmax * D, D, (long)Tmax * D, D, D, Tmax, B, H, 250, 0.125f, 1, ws, 64, 0.1f, seed, 3, 9, 256, s)); }, 384, 4, 5);
+            RC(cxr_attn_decode_bf16(q, Ks, Vs, o, am, D, (long)Tmax * D, D, (long)Tmax * D, D, D, Tmax, B, H, 250, 0.125f, 1, ws, 64, 0.1f, seed, 3, 9, 256, 0, 0, s)); }, 384, 4, 5);
         bench("self-attn T=6 (start of a decode)", 48, [&](int i, hipStream_t s) {
-            RC(cxr_attn_decode_bf16(q, Ks, Vs, o, am, D, (long)Tmax * D, D, (long)Tmax * D, D, D, Tmax, B, H, 6, 0.125f, 1, ws, 64, 0.1f, seed, 3, 9, 256, s)); }, 384, 4, 5);
+            RC(cxr_attn_decode_bf16(q, Ks, Vs, o, am, D, (long)Tmax * D, D, (long)Tmax * D, D, D, Tmax, B, H, 6, 0.125f, 1, ws, 64, 0.1f, seed, 3, 9, 256, 0, 0, s)); }, 384, 4, 5);
     }
     // ---------------------------------------------------------------- token selection (16 sampled rows top-k 50 + 16 greedy rows)
     {

@@ -432,6 +432,9 @@ def test_dec_gemm_fold_residual_stats(ops, M):
     ref = torch.nn.functional.gelu(ln @ w.float().t() + bias)
     got = ops.dec_from_dal(out, M, N)
     close(got, ref, rtol=1e-2, what="LN-folded GEMM + GELU")
+    for mt_hint in (1, 2):                        # one 16-row tile per workgroup / all rows in one workgroup: the same numbers
+        (o2,), ost2 = ops.dec_gemm(a_dal, M, K, [dict(wp=wf, bc=bcf, N=N, fold=True)], act=1, stats=st, eps=1e-12, out_stats=True, mt_hint=mt_hint)
+        assert torch.equal(ops.dec_from_dal(o2, M, N), got) and torch.equal(ost2, ost)
     # the published statistics describe the rounded output: Chan-combined they give its mean / variance
     gf = got.float()
     mean = ost[..., 0].sum(0) / N
