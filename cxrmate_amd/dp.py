@@ -124,3 +124,19 @@ def all_reduce_mean_scalar(x: torch.Tensor) -> torch.Tensor:
     y = x.clone()
     dist.all_reduce(y, op=dist.ReduceOp.SUM)
     return y / w
+
+
+def gather_scst_statistics(sampled: torch.Tensor, greedy: torch.Tensor, reward: torch.Tensor, baseline: torch.Tensor, pad_token_id: int):
+    """The SCST step's per-rank results -> what every rank needs for GLOBAL reward / baseline statistics (north_star: "all-gather of sampled /
+    greedy sequences for the SCST baseline"; the reference logs per-rank means, longitudinal/scst/gt_prompt.py:135-140, and leaves the reduction
+    to Lightning's sync_dist). Studies stay sharded: nothing here feeds the gradient, which is still reward - baseline per study.
+    sampled / greedy int64 [B, L*] (lengths may differ per rank), reward / baseline fp32 [B] -> dict(sampled [W*B, Ls], greedy [W*B, Lg],
+    reward [W*B], baseline [W*B]) in rank order. world_size 1: the inputs themselves."""
+    if world_size() == 1:
+        return {"sampled": sampled, "greedy": greedy, "reward": reward, "baseline": baseline}
+    rb = torch.stack([reward.float(), baseline.float()], dim=1).contiguous()
+    out = [torch.empty_like(rb) for _ in range(world_size())]
+    dist.all_gather(out, rb)
+    rb = torch.cat(out, dim=0)
+    return {"sampled": all_gather_sequences(sampled.contiguous(), pad_token_id), "greedy": all_gather_sequences(greedy.contiguous(), pad_token_id),
+            "reward": rb[:, 0], "baseline": rb[:, 1]}

@@ -51,6 +51,9 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         reward = reward_fn(sampled)
         baseline = reward_fn(base[:, P:].contiguous())
         adv = (reward - baseline).float().contiguous()
+        # data parallel: the sampled / greedy sequences and their rewards of ALL ranks (RCCL all-gather over xGMI, <= 64 KB per rank) for the
+        # global reward / baseline statistics the step reports; the advantage above stays per study, as in the reference (gt_prompt.py:129-132)
+        glob = dp.gather_scst_statistics(sampled, base[:, P:].contiguous(), reward, baseline, pad)
 
         # ---- REINFORCE through one teacher-forced pass
         opt.zero_grad()
@@ -83,5 +86,6 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
             opt.reducer.reduce_range(0, model._param_total)
             opt.reducer.wait()
         opt.step(gscale=1.0 / world)
-        seq_len = (sampled != pad).sum(-1).float().mean()
-    return {"loss": loss, "reward": reward.mean(), "baseline": baseline.mean(), "seq_len": seq_len, "sampled": sampled, "baseline_ids": base}
+        seq_len = (glob["sampled"] != pad).sum(-1).float().mean()
+    return {"loss": loss, "reward": glob["reward"].mean(), "baseline": glob["baseline"].mean(), "seq_len": seq_len, "sampled": sampled,
+            "baseline_ids": base, "global": glob}

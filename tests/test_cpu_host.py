@@ -141,6 +141,10 @@ def _dp_worker(rank, world, path, q):
     seqs = torch.full((2, 3 + rank), rank, dtype=torch.int64)
     gathered = dp.all_gather_sequences(seqs, pad_token_id=4)
     mean = dp.all_reduce_mean_scalar(torch.tensor([float(rank)]))
+    # SCST statistics: ragged sampled / greedy lengths per rank, rewards in rank order
+    st = dp.gather_scst_statistics(torch.full((2, 4 + rank), 10 + rank, dtype=torch.int64), torch.full((2, 6 - rank), 20 + rank, dtype=torch.int64),
+                                   torch.tensor([0.1, 0.2]) + rank, torch.tensor([0.3, 0.4]) + rank, pad_token_id=4)
+    gathered = (gathered, st)
     q.put((rank, mine, flat, gathered, mean))
     dist.destroy_process_group()
 
@@ -158,7 +162,12 @@ def test_gradient_allreduce_and_sequence_allgather_gloo_world2():
         for p in procs:
             p.join(60)
             assert p.exitcode == 0
-    (_, m0, f0, g0, mean0), (_, m1, f1, g1, _) = res
+    (_, m0, f0, (g0, st0), mean0), (_, m1, f1, (g1, st1), _) = res
+    for k in st0:
+        assert torch.equal(st0[k], st1[k])                                  # every rank holds the same global view
+    assert st0["sampled"].shape == (4, 5) and st0["sampled"][0].tolist() == [10, 10, 10, 10, 4] and st0["sampled"][3].tolist() == [11] * 5
+    assert st0["greedy"].shape == (4, 6) and st0["greedy"][2].tolist() == [21] * 5 + [4]
+    assert torch.allclose(st0["reward"], torch.tensor([0.1, 0.2, 1.1, 1.2])) and torch.allclose(st0["baseline"], torch.tensor([0.3, 0.4, 1.3, 1.4]))
     total = m0 + m1
     for f in (f0, f1):
         assert torch.allclose(f[:300], total[:300]) and torch.allclose(f[400:], total[400:])
