@@ -2,16 +2,25 @@
 """Headline benchmark of the CXRMate hot path on MI355X (contract: README of the build driver).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N ...                                  # no torchrun environment: starts N ranks itself (before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" = one teacher-forcing optimisation step (forward, cross-entropy, backward, AdamW; BASELINE.json configs[1]:
-cxrmate-single-tf, batch 32 x 1 image 384x384, T = 256, CvT-21 + 6-layer BERT decoder, vocab 30000, bf16 MFMA with fp32
-accumulation and fp32 master weights) on synthetic data with random-init weights. Per-GPU work is fixed (weak scaling, pure data
-parallel); gradients are all-reduced over RCCL. Prints ONE JSON line on rank 0.
+BASELINE.json `metric` = "SCST steps/sec + TF tokens/sec/GPU, 2-image 384x384 studies":
+  * headline (`value`): teacher-forcing tokens/s of the MULTI-image model (reference modules/lightning_modules/multi.py:182-210): 32 studies x 2
+    images 384x384 per GPU, T = 256, CvT-21 + 6-layer BERT decoder, vocab 30000; one step = forward, cross-entropy, backward, AdamW under
+    model.train(), bf16 MFMA with fp32 accumulation and fp32 master weights, synthetic data, random-init weights. Weak scaling (pure data
+    parallel, study-level sharding), gradients all-reduced over RCCL.
+  * `scst`: SCST steps/s at the per-GPU shape of configs[3] (16 studies x 2 images, 255 sampled + 255 greedy tokens, CXR-BERT stand-in reward,
+    REINFORCE + AdamW on the decoder), with the roofline of its cached decode token-step.
+  * `tf_single`: configs[1] (single-image studies, batch 32), `forward_only`: bf16 MFMA utilisation of the encoder + decoder FORWARD (the
+    north_star's >= 40 % target is defined on it), `cpu_baseline`: the oracle/ restatement of the reference path on the host cores.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,15 +32,25 @@ sys.path.insert(0, ROOT)
 # algorithmic work: forward FLOPs, training = 3x forward for trainable parts
 ENC_FWD_GF_PER_IMAGE = 50.04
 MFMA_BF16_PEAK_TF = 2500.0
+HBM_PEAK_GBS = 8000.0
 
 
 def dec_fwd_gf(n_images, T):
     return 8.15 * n_images + T * (146.4 + 10.6 * n_images + 0.0184 * T) * 1e-3
 
 
-def synth_batch(B, T, vocab, device, seed):
+def decode_step_bytes(rows, studies, n_images, t_ctx, layers=6, d=768, vocab=30000):
+    """Algorithmic bytes of ONE cached decode token-step: decoder weights once (bf16), cross-attention K/V of every study once
+    (the sampled and the greedy row of a study share them), self-attention K/V of every row up to context t, fp32 logits."""
+    weights = 160e6
+    cross = studies * layers * 2 * (n_images * 576) * d * 2
+    self_kv = rows * layers * 2 * t_ctx * d * 2
+    return weights + cross + self_kv + rows * vocab * 4
+
+
+def synth_batch(B, T, vocab, device, seed, n_images=1):
     g = torch.Generator().manual_seed(seed)
-    px = torch.randn(B, 3, 384, 384, generator=g)
+    px = torch.randn(B, 3, 384, 384, generator=g) if n_images == 1 else torch.randn(B, n_images, 3, 384, 384, generator=g)
     full = torch.randint(12, vocab, (B, T + 1), generator=g)
     full[:, 0] = 1
     full[:, T // 2] = 3
@@ -40,9 +59,9 @@ def synth_batch(B, T, vocab, device, seed):
     return px.to(device), inp.to(device), am.to(device), lab.to(device)
 
 
-def cpu_baseline(T, vocab, budget_s=25.0, threads=None):
-    """The CPU restatement of the reference path (oracle/, fp32): TF fwd + bwd + AdamW on a bounded sample. Thread count: measured best
-    on the GPU host for this small-batch workload (8/16/32/64/128 threads gave 259/291/222/106/29 tokens/s); reported as `cores`."""
+def cpu_baseline(T, vocab, n_images, budget_s=25.0, threads=None):
+    """The CPU restatement of the reference path (oracle/, fp32): multi-image TF fwd + bwd + AdamW on a bounded sample. Thread count: measured
+    best on the GPU host for this small-batch workload (8/16/32/64/128 threads gave 259/291/222/106/29 tokens/s); reported as `cores`."""
     threads = threads or int(os.environ.get("CXR_CPU_THREADS", min(16, os.cpu_count() or 1)))
     torch.set_num_threads(threads)
     from cxrmate_amd import weights
@@ -57,13 +76,13 @@ def cpu_baseline(T, vocab, budget_s=25.0, threads=None):
     sd2.update(leaves)
     opt = torch.optim.AdamW(list(leaves.values()), lr=5e-5)
     B = 1
-    px, inp, am, lab = synth_batch(B, T, vocab, "cpu", 123)
+    px, inp, am, lab = synth_batch(B, T, vocab, "cpu", 123, n_images)
     tt = torch.from_numpy(__import__("oracle.token_ops", fromlist=["x"]).token_ids_to_token_type_ids(inp.numpy(), [3]))
 
     def step():
         opt.zero_grad(set_to_none=True)
-        h, _ = ocvt.encoder_forward(px, sd2, cfg.encoder)
-        logits = obert.decoder_forward(inp, sd2, cfg.decoder, h, None, am, tt, None)
+        h, mask = ocvt.encoder_forward(px, sd2, cfg.encoder)
+        logits = obert.decoder_forward(inp, sd2, cfg.decoder, h, mask, am, tt, None)
         loss = ogen.tf_cross_entropy(logits, lab, 4)
         loss.backward()
         opt.step()
@@ -77,13 +96,33 @@ def cpu_baseline(T, vocab, budget_s=25.0, threads=None):
         if dt > budget_s * 0.6 or n >= 8:
             break
     return {"value": n * B * T / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} TF steps (fwd+bwd+AdamW), batch {B} x 1 image 384x384, T={T}, fp32, oracle/ restatement of the reference path"}
+            "sample": f"{n} TF steps (fwd+bwd+AdamW), batch {B} study x {n_images} images 384x384, T={T}, fp32, oracle/ restatement of the reference path"}
 
 
-def scst_bench(args, rank, local, world, dev, secondary=False):
-    """BASELINE.json configs[3] per-GPU shape: 16 studies x 2 images, prompt [PMT][NPF][PMT-SEP][NPI][BOS], 255 sampled + 255 greedy
-    tokens (EOS disabled so the work is deterministic), CXR-BERT stand-in reward on R=128 synthetic WordPiece ids, REINFORCE + AdamW
-    on the whole decoder, RCCL all-reduce of 80.9 M gradients."""
+def timed(step, steps, world, dev):
+    """barrier + synchronize, exactly `steps` steps, synchronize + barrier; MAX over ranks. -> (seconds, last result)"""
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, out
+
+
+def scst_bench(args, rank, world, dev, steps):
+    """BASELINE.json configs[3] per-GPU shape: 16 studies x 2 images, prompt [PMT][NPF][PMT-SEP][NPI][BOS], 255 sampled + 255 greedy tokens
+    (EOS disabled so the work is deterministic), CXR-BERT stand-in reward on R = 128 synthetic WordPiece ids, REINFORCE + AdamW on the whole
+    decoder, RCCL all-reduce of 80.9 M gradients + all-gather of the sequences."""
     from cxrmate_amd.config import EncoderDecoderConfig
     from cxrmate_amd.modelling import LongitudinalPromptMultiCXREncoderDecoderModel
     from cxrmate_amd.reward import CXRBERTReward
@@ -111,98 +150,66 @@ def scst_bench(args, rank, local, world, dev, secondary=False):
         return reward.reward_from_ids(pred, ones, label_ids, ones)
 
     special = dict(bos=1, eos=None, sep=3, pad=4, pmt_sep=9)
+
     def step():
         return scst_step(model, opt, reward_fn, images, prompt, None, special, decoder_max_len=args.new_tokens + 1)
-    nsteps = 3 if secondary else args.steps
-    for _ in range(2 if secondary else max(2, args.warmup)):       # the first two steps capture the decode hipGraphs (sample + greedy)
+
+    for _ in range(max(2, args.warmup)):                          # the first two steps capture the decode hipGraphs (sample + greedy)
         step()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(nsteps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    if secondary:
-        return {"metric": "scst_steps_per_sec", "value": nsteps / dt, "unit": "steps/s per GPU (16 studies x 2 images per step)", "steps": nsteps,
-                "ms_per_step": dt / nsteps * 1e3, "studies_per_sec": B * nsteps / dt, "new_tokens_sampled_and_greedy": args.new_tokens,
-                "reward": "CXR-BERT stand-in (BERT-base + CLS projection), R=128 synthetic ids, 4 forwards per step (labels cached)",
-                "workload": "BASELINE.json configs[3] per-GPU shape: sample(top-k 50) + greedy baseline via hipGraph-replayed decode steps, "
-                            "REINFORCE through one teacher-forced pass, AdamW on the 80.9 M decoder parameters",
-                "mode": "eval" if args.eval_mode else "model.train(): batch-statistics BatchNorm in the frozen encoder, dropout 0.1 in both decodes and in "
-                        "the re-scoring pass (same seed)", "loss": float(out["loss"].item())}
-    res = {"metric": "scst_steps_per_sec", "value": world * args.steps / dt / world, "unit": "steps/s (16 studies x 2 images per GPU per step)",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": "longitudinal SCST + CXR-BERT stand-in reward (BASELINE.json configs[3] per-GPU shape)", "studies_per_gpu": B,
-                      "images_per_study": N, "new_tokens": args.new_tokens, "reward_tokens": 128, "studies_per_sec": world * B * args.steps / dt,
-                      "loss": float(out["loss"].item()), "parallelism": f"dp{world}",
-                      "mode": "eval" if args.eval_mode else "model.train() (batch-statistics BatchNorm, dropout 0.1 in decodes and re-scoring)"}}
-    if rank == 0:
-        print(json.dumps(res))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    dt, out = timed(step, steps, world, dev)
+    # the cached decode of one step, timed live with HIP events on the launch stream (the graph replays run on torch's current stream)
+    with torch.no_grad():
+        eo = model.encoder(images)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        model.sample_and_greedy(eo, prompt, [1, 3], [9, 1, 3], 4, args.new_tokens + 1 + prompt.shape[1], 1, None, 4)
+        e1.record()
+        torch.cuda.synchronize()
+    n_tok = args.new_tokens
+    dec_ms = e0.elapsed_time(e1)
+    t_ctx = prompt.shape[1] + n_tok / 2.0                          # mean self-attention context over the decode
+    step_bytes = decode_step_bytes(2 * B, B, N, t_ctx)
+    achieved = step_bytes / (dec_ms * 1e-3 / n_tok) / 1e9
+    return {"metric": "scst_steps_per_sec", "value": world * steps / dt, "unit": "steps/s (16 studies x 2 images per GPU per step; all GPUs)",
+            "steps_per_sec_per_gpu": steps / dt, "steps": steps, "ms_per_step": dt / steps * 1e3, "studies_per_sec": world * B * steps / dt,
+            "new_tokens_sampled_and_greedy": n_tok,
+            "reward": "CXR-BERT stand-in (BERT-base + CLS projection head: architecture assumed, PARITY UNPINNED -- SURVEY.md 8c), R = 128 SYNTHETIC "
+                      "ids in place of the decode -> re-tokenise string round trip, 4 forwards per step (labels cached)",
+            "workload": "BASELINE.json configs[3] per-GPU shape: sample (top-k 50) + greedy baseline as one 32-row cached decode replayed from "
+                        "hipGraphs, REINFORCE through one teacher-forced pass, AdamW on the 80.9 M decoder parameters",
+            "mode": "eval" if args.eval_mode else "model.train(): batch-statistics BatchNorm in the frozen encoder, dropout 0.1 in both decodes and in "
+                    "the re-scoring pass (same seed)", "loss": float(out["loss"].item()),
+            "roofline": {"bound": "hbm", "kernel": "cached decode token-step (one hipGraph of ~54 kernels: dec_gemm_kernel x38, attn_decode_kernel x12, "
+                         "embedding, step inputs, token selection), 32 rows", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_token_step": step_bytes,
+                         "decode_ms_per_step": dec_ms, "us_per_token_step": dec_ms * 1e3 / n_tok,
+                         "decode_share_of_step": dec_ms / (dt / steps * 1e3),
+                         "profile": "profiles/r02_scst_decode_v1_kernel_stats.csv (rocprofv3 --kernel-trace of scripts/scst_decode_profile.py)"}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--seq-len", type=int, default=256)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-scst", action="store_true", help="skip the secondary SCST measurement (N=1 only)")
-    ap.add_argument("--eager", action="store_true", help="(default) launch kernels eagerly; weight-gradient kernels overlap on a side stream")
-    ap.add_argument("--graph", action="store_true", help="replay the step from hipGraphs (3 segments)")
-    ap.add_argument("--eval-mode", action="store_true", help="run the step under model.eval() (running-statistics BatchNorm, no dropout)")
-    ap.add_argument("--workload", default="tf", choices=["tf", "scst"], help="tf = BASELINE configs[1] (headline); scst = configs[3] per-GPU shape")
-    ap.add_argument("--new-tokens", type=int, default=255)
-    args = ap.parse_args()
-
-    from cxrmate_amd import dp
-    rank, local, world = dp.init_from_env()
-    assert world == args.gpus or world == 1, (world, args.gpus)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
+def tf_bench(args, rank, world, dev, model, n_images, steps, profile_gemm):
+    """One teacher-forcing optimisation step = forward, CE, backward, (all-reduce,) AdamW. -> dict with tokens/s, ms/step and, optionally, the
+    live GEMM profile."""
     from cxrmate_amd import ops
-    from cxrmate_amd.config import EncoderDecoderConfig
-    from cxrmate_amd.modelling import SingleCXREncoderDecoderModel
     from cxrmate_amd.training import FusedAdamW, GraphedTFStep, tf_train_step
-
-    cfg = EncoderDecoderConfig()
-    B, T, V = args.batch, args.seq_len, cfg.decoder.vocab_size
-    model = SingleCXREncoderDecoderModel(cfg, device=dev, seed=0)
-    if not args.eval_mode:
-        model.train()
+    B, T, V = args.batch, args.seq_len, model.config.decoder.vocab_size
     opt = FusedAdamW(model, lr=5e-5)
-    px, inp, am, lab = synth_batch(B, T, V, dev, 1000 + rank)
+    px, inp, am, lab = synth_batch(B, T, V, dev, 1000 + rank, n_images)
     tt = model.token_ids_to_token_type_ids(inp, [3])
 
     def eager_step():
         return tf_train_step(model, opt, px, inp, am, tt, lab, pad_token_id=4)
 
-    if args.workload == "scst":
-        return scst_bench(args, rank, local, world, dev)
     if not args.graph:
         step = eager_step
     else:
         graphed = GraphedTFStep(model, opt, px, inp, am, tt, lab, pad_token_id=4)          # hipGraph capture (3 segments)
         step = lambda: graphed(px, inp, am, tt, lab)
-
     # untimed pre-warm-up: lazy kernel loading, caching-allocator growth on both streams, first-use buffers (transposed weights, LoRA merges)
-    # and the device itself -- the first ~second of work on a fresh box runs 5-8 % slow (36.5 vs 34.0 ms/step measured back to back), which
-    # 3 warm-up steps (0.1 s) do not cover. At least 2 steps and 1.5 s of them; the W requested warm-up steps follow.
+    # and the device itself -- the first ~second of work on a fresh box runs 5-8 % slow, which 3 warm-up steps do not cover. At least 2 steps
+    # and 1.5 s of them; the W requested warm-up steps follow.
     t_pre, n_pre = time.perf_counter(), 0
-    n_fixed = int(os.environ.get("CXR_BENCH_PREWARM", "48"))          # world > 1 only (a rehearsal of the multi-rank flow on one GPU sets it to 2)
+    n_fixed = int(os.environ.get("CXR_BENCH_PREWARM", "32"))          # world > 1 only (a rehearsal of the multi-rank flow on one GPU sets it to 2)
     while (n_pre < n_fixed) if world > 1 else (n_pre < 2 or (time.perf_counter() - t_pre < 1.5 and n_pre < 64)):
         step()                              # (every rank must run the SAME number of steps -- each one all-reduces: fixed count when world > 1)
         if n_pre % 4 == 3:
@@ -210,74 +217,168 @@ def main():
         n_pre += 1
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
-    tokens_per_s = world * B * T * args.steps / dt
+    dt, loss = timed(step, steps, world, dev)
+    res = {"ms_per_step": dt / steps * 1e3, "tokens_per_s": world * B * T * steps / dt, "loss": float(loss.item()),
+           "step_gflop_per_gpu": 3.0 * (ENC_FWD_GF_PER_IMAGE * n_images + dec_fwd_gf(n_images, T)) * B}
+    if profile_gemm:
+        # dominant kernel = gemm_nt_kernel (bf16 MFMA): live HIP-event timing of every launch in one extra step
+        ops.GEMM_PROFILE = []
+        eager_step()
+        torch.cuda.synchronize()
+        prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+        nt = [p for p in prof if p[3][0] != "tn"]                # dominant kernel: gemm_nt_kernel (forward + dX products)
+        tn = [p for p in prof if p[3][0] == "tn"]                # weight-gradient kernel (runs concurrently on the side stream)
+        res["gemm"] = dict(nt_ms=sum(p[1].elapsed_time(p[2]) for p in nt), nt_flops=sum(p[0] for p in nt), nt_bytes=sum(p[4] for p in nt),
+                           nt_n=len(nt), tn_ms=sum(p[1].elapsed_time(p[2]) for p in tn), tn_flops=sum(p[0] for p in tn), tn_n=len(tn))
+    del opt
+    return res
 
-    # dominant kernel = gemm_nt_kernel (bf16 MFMA): live HIP-event timing of every launch in one extra step
-    ops.GEMM_PROFILE = []
-    eager_step()
-    torch.cuda.synchronize()
-    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
-    nt = [p for p in prof if p[3][0] != "tn"]                # dominant kernel: gemm_nt_kernel (forward + dX products)
-    tn = [p for p in prof if p[3][0] == "tn"]                # weight-gradient kernel (runs concurrently on the side stream)
-    gemm_ms = sum(p[1].elapsed_time(p[2]) for p in nt)
-    gemm_flops = sum(p[0] for p in nt)
-    gemm_bytes = sum(p[4] for p in nt)                        # operands + outputs (+ residual / saved pre-activation) once each
-    tn_ms = sum(p[1].elapsed_time(p[2]) for p in tn)
-    tn_flops = sum(p[0] for p in tn)
-    prof = nt
+
+def forward_only(args, dev, model, n_images):
+    """bf16 MFMA utilisation of the encoder + decoder FORWARD (no saved activations, no loss): algorithmic FLOPs of BASELINE.md section 2 over
+    HIP-event time on the launch stream."""
+    B, T, V = args.batch, args.seq_len, model.config.decoder.vocab_size
+    px, inp, am, lab = synth_batch(B, T, V, dev, 77, n_images)
+    tt = model.token_ids_to_token_type_ids(inp, [3])
+    with torch.no_grad():
+        def fwd():
+            return model(pixel_values=px, decoder_input_ids=inp, decoder_attention_mask=am, decoder_token_type_ids=tt).logits
+        for _ in range(3):
+            fwd()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 8
+        e0.record()
+        for _ in range(n):
+            fwd()
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    gf = (ENC_FWD_GF_PER_IMAGE * n_images + dec_fwd_gf(n_images, T)) * B
+    tf = gf * 1e-3 / (ms * 1e-3)
+    return {"ms": ms, "gflop": gf, "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
+            "what": f"encoder + decoder forward, {B} studies x {n_images} images, T = {T}, "
+                    + ("model.train()" if model.training else "model.eval()") + ", algorithmic FLOPs (2 x MAC) / HIP-event time"}
+
+
+def spawn_ranks(n):
+    """`--gpus N` without a torchrun environment: start N fresh ranks of this script (one per GPU) BEFORE this process touches the GPU, relay
+    rank 0's output, exit with the worst return code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="studies per GPU")
+    ap.add_argument("--seq-len", type=int, default=256)
+    ap.add_argument("--images", type=int, default=2, help="images per study of the headline teacher-forcing workload")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scst", action="store_true", help="skip the SCST measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip tf_single and forward_only")
+    ap.add_argument("--scst-steps", type=int, default=10)
+    ap.add_argument("--graph", action="store_true", help="replay the TF step from hipGraphs (3 segments)")
+    ap.add_argument("--eval-mode", action="store_true", help="run the steps under model.eval() (running-statistics BatchNorm, no dropout)")
+    ap.add_argument("--new-tokens", type=int, default=255)
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
+
+    from cxrmate_amd import dp
+    rank, local, world = dp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the process group has {world} rank(s): refusing to report a {world}-GPU number")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from cxrmate_amd.config import EncoderDecoderConfig
+    from cxrmate_amd.modelling import MultiCXREncoderDecoderModel, SingleCXREncoderDecoderModel
+
+    cfg = EncoderDecoderConfig()
+    B, T, V = args.batch, args.seq_len, cfg.decoder.vocab_size
+    N = args.images
+    model = (MultiCXREncoderDecoderModel if N > 1 else SingleCXREncoderDecoderModel)(cfg, device=dev, seed=0)
+    if not args.eval_mode:
+        model.train()
+    main_res = tf_bench(args, rank, world, dev, model, N, args.steps, profile_gemm=True)
+    ms_per_step, tokens_per_s = main_res["ms_per_step"], main_res["tokens_per_s"]
+    gm = main_res["gemm"]
     traffic, traffic_src = None, None                        # HBM-side bytes per launch from the committed PMC passes (cannot be collected live)
-    try:
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")))
-        traffic, traffic_src = pmc["gemm_nt"]["hbm_bytes_per_launch"], "profiles/r01_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
-    except Exception:
-        pass
-    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
-    step_gf = 3.0 * (ENC_FWD_GF_PER_IMAGE + dec_fwd_gf(1, T)) * B
-
+    for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            traffic = pmc["gemm_nt"]["hbm_bytes_per_launch"]
+            traffic_src = f"profiles/{name} (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes" + ("" if name.startswith("r02") else "; collected on configs[1] in round 1") + ")"
+            break
+        except Exception:
+            pass
+    achieved = gm["nt_flops"] / (gm["nt_ms"] * 1e-3) / 1e12
+    mode = ("eval-mode BatchNorm (running statistics), dropout off" if args.eval_mode else
+            "model.train(): batch-statistics BatchNorm + running-stat update, dropout 0.1 (hidden + attention probabilities), DropPath")
     out = {
         "metric": "tf_tokens_per_sec", "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic (randn 384x384 images, uniform token ids, random-init weights)",
-        "config": {"workload": "cxrmate-single-tf teacher-forcing fwd/bwd + AdamW (BASELINE.json configs[1])", "global_batch": B * world,
-                   "images_per_study": 1, "seq_len": T, "encoder": "CvT-21 @384", "decoder": "BERT 6 layers, vocab 30000",
-                   "parallelism": f"dp{world}", "launch": "hipGraph replay (3 segments, RCCL between)" if args.graph else "eager, weight-gradient kernels on a side stream", "mode": ("eval-mode BatchNorm (running statistics), dropout off" if args.eval_mode else
-                            "model.train(): batch-statistics BatchNorm + running-stat update, dropout 0.1 (hidden + attention probabilities), DropPath"),
-                   "loss": float(loss.item()), "tokens_per_sec_per_gpu": tokens_per_s / world,
-                   "model_tflops_per_gpu": step_gf * 1e-3 / (ms_per_step * 1e-3)},
+        "config": {"workload": f"cxrmate-multi-tf teacher-forcing fwd/bwd + AdamW on {N}-image 384x384 studies (BASELINE.json metric; reference "
+                               "modules/lightning_modules/multi.py:182-210)", "global_batch": B * world, "studies_per_gpu": B, "images_per_study": N,
+                   "seq_len": T, "encoder": "CvT-21 @384", "decoder": "BERT 6 layers, vocab 30000", "parallelism": f"dp{world}",
+                   "rccl_ranks": world, "launch": "hipGraph replay (3 segments, RCCL between)" if args.graph else "eager, weight-gradient kernels on a side stream",
+                   "mode": mode, "loss": main_res["loss"], "tokens_per_sec_per_gpu": tokens_per_s / world,
+                   "model_tflops_per_gpu": main_res["step_gflop_per_gpu"] * 1e-3 / (ms_per_step * 1e-3)},
         "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (all tile variants; v_mfma_f32_16x16x32_bf16), timed while the weight-gradient "
                                "stream runs beside it, as in the timed region", "achieved": achieved,
                      "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TF, "traffic": traffic,
-                     "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "algorithmic_bytes_per_launch": gemm_bytes / max(1, len(prof)),
-                     "launches_per_step": len(prof), "avg_launch_us": gemm_ms * 1e3 / max(1, len(prof)),
-                     "avg_launch_gflop": gemm_flops / max(1, len(prof)) * 1e-9, "gemm_share_of_step": gemm_ms / ms_per_step,
-                     "weight_grad_kernel": {"kernel": "gemm_tn_kernel", "launches_per_step": len(tn), "achieved": tn_flops / (tn_ms * 1e-3) / 1e12,
-                                            "avg_launch_us": tn_ms * 1e3 / max(1, len(tn))}},
+                     "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "algorithmic_bytes_per_launch": gm["nt_bytes"] / max(1, gm["nt_n"]),
+                     "launches_per_step": gm["nt_n"], "avg_launch_us": gm["nt_ms"] * 1e3 / max(1, gm["nt_n"]),
+                     "avg_launch_gflop": gm["nt_flops"] / max(1, gm["nt_n"]) * 1e-9, "gemm_share_of_step": gm["nt_ms"] / ms_per_step,
+                     "weight_grad_kernel": {"kernel": "gemm_tn_kernel", "launches_per_step": gm["tn_n"],
+                                            "achieved": gm["tn_flops"] / (gm["tn_ms"] * 1e-3) / 1e12 if gm["tn_ms"] else None,
+                                            "avg_launch_us": gm["tn_ms"] * 1e3 / max(1, gm["tn_n"])}},
     }
-    if world == 1 and not args.no_scst:
+    if world == 1 and not args.no_extras:
         try:
-            del model, opt
-            torch.cuda.empty_cache()
-            out["scst"] = scst_bench(args, rank, local, world, dev, secondary=True)
+            out["forward_only"] = forward_only(args, dev, model, N)
         except Exception as e:
+            out["forward_only"] = {"error": str(e)}
+    del model
+    torch.cuda.empty_cache()
+    if world == 1 and not args.no_extras:
+        try:
+            single = SingleCXREncoderDecoderModel(cfg, device=dev, seed=0)
+            if not args.eval_mode:
+                single.train()
+            r1 = tf_bench(args, rank, world, dev, single, 1, max(4, args.steps // 2), profile_gemm=False)
+            out["tf_single"] = {"metric": "tf_tokens_per_sec", "value": r1["tokens_per_s"], "unit": "tokens/s", "ms_per_step": r1["ms_per_step"],
+                                "workload": "cxrmate-single-tf teacher-forcing fwd/bwd + AdamW, batch 32 x 1 image (BASELINE.json configs[1])",
+                                "model_tflops_per_gpu": r1["step_gflop_per_gpu"] * 1e-3 / (r1["ms_per_step"] * 1e-3), "loss": r1["loss"]}
+            del single
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["tf_single"] = {"error": str(e)}
+    if not args.no_scst:
+        try:
+            out["scst"] = scst_bench(args, rank, world, dev, args.scst_steps)
+        except Exception as e:
+            if world > 1:
+                raise
             out["scst"] = {"metric": "scst_steps_per_sec", "value": None, "error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(T, V)
+            out["cpu_baseline"] = cpu_baseline(T, V, N)
         except Exception as e:                              # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:

@@ -516,9 +516,28 @@ __global__ __launch_bounds__(1024) void sample_topk_lds_kernel(const float* __re
     const long r = blockIdx.x;
     const float* x = logits + r * ld;
     const float invt = 1.0f / temperature;
-    for (int i = tid * 4; i < V; i += 4096) {
-        if (i + 4 <= V && ((size_t)(x + i) & 15) == 0) *reinterpret_cast<float4*>(row + i) = *reinterpret_cast<const float4*>(x + i);
-        else for (int j = i; j < V && j < i + 4; ++j) row[j] = x[j];
+    if ((V & 3) == 0 && ((size_t)x & 15) == 0 && V <= 8 * 4096) {
+        // wave-uniform fast path: the whole row as 8 UNCONDITIONAL 16-byte loads per lane, all in flight together (indices past the row re-read
+        // its last vector; a load guarded by a per-lane condition makes hipcc wait for each one before issuing the next: 8 dependent round trips)
+        float4 f[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            int i = (tid + it * 1024) * 4; i = i < V ? i : V - 4;
+            f[it] = *reinterpret_cast<const float4*>(x + i);
+        }
+        // (pin the loaded values: keeps hipcc from sinking each load into the guarded store below; a "memory" clobber here put f[] in scratch)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) asm volatile("" : "+v"(f[it].x), "+v"(f[it].y), "+v"(f[it].z), "+v"(f[it].w));
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int i = (tid + it * 1024) * 4;
+            if (i < V) *reinterpret_cast<float4*>(row + i) = f[it];
+        }
+    } else {
+        for (int i = tid * 4; i < V; i += 4096) {
+            if (i + 4 <= V && ((size_t)(x + i) & 15) == 0) *reinterpret_cast<float4*>(row + i) = *reinterpret_cast<const float4*>(x + i);
+            else for (int j = i; j < V && j < i + 4; ++j) row[j] = x[j];
+        }
     }
     __syncthreads();
     if (r >= n_sample) {

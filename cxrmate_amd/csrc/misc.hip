@@ -501,6 +501,116 @@ __global__ __launch_bounds__(64) void decode_step_inputs_kernel(const long* __re
     }
 }
 
+// The same input assembly FUSED with the BERT embeddings of the new token (TF5:bert:70-108: word + token-type + position gather, LayerNorm,
+// dropout): one wave per row, the row's ids are read once into registers, the embedding output goes straight to the decode activation layout
+// of cxr_dec_gemm_bf16. One launch per token instead of two.
+__global__ __launch_bounds__(64) void decode_step_embed_kernel(const long* __restrict__ ids, long ld, int rows, int strip, int cur,
+                                                               const long* __restrict__ special0, int n0, const long* __restrict__ special1, int n1,
+                                                               const long* __restrict__ sections, int half_rows, long mask_token_id,
+                                                               long* __restrict__ new_id, long* __restrict__ tt, long* __restrict__ pos,
+                                                               unsigned char* __restrict__ mask, long ldm, long* __restrict__ tt_hist,
+                                                               long* __restrict__ pos_hist, long ldh, const bf16_t* __restrict__ word,
+                                                               const bf16_t* __restrict__ type, const bf16_t* __restrict__ posw,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                               bf16_t* __restrict__ out, int out_mt, const uint32_t* __restrict__ drop_seed,
+                                                               uint32_t drop_site, uint32_t drop_thr16, float drop_inv) {
+    constexpr int C = 768, CH = 96, PER = 8;                 // up to 64 * PER = 512 tokens per row (max_position_embeddings)
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const long* row = ids + (long)r * ld + strip;
+    const int T = cur - strip;
+    long tok[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { const int t = j * 64 + lane; tok[j] = row[t < T ? t : T - 1]; }
+    const long* special = r < half_rows ? special0 : special1;
+    const int ns = r < half_rows ? n0 : n1;
+    long sp[4] = {special[0], special[ns > 1 ? 1 : 0], special[ns > 2 ? 2 : 0], special[ns > 3 ? 3 : 0]};
+    long v = sections[0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                           // separators searched in all but the last position, later separators win
+        int any = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) any |= (j * 64 + lane < T - 1) && (tok[j] == sp[i]);
+        if (i < ns && __any(any)) v = sections[i + 1];
+    }
+    int count = 0;
+    if (mask) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int t = j * 64 + lane;
+            const int m = t < T ? (tok[j] != mask_token_id) : 0;
+            if (t < T) mask[(long)r * ldm + t] = (unsigned char)m;
+            count += __popcll(__ballot(m));
+        }
+    }
+    const long last = row[T - 1];
+    const long p = mask ? (count > 0 ? count - 1 : 0) : (long)(T - 1);       // longitudinal: relu(cumsum(mask) - 1)[-1]; else the absolute position
+    if (lane == 0) {
+        new_id[r] = last;
+        tt[r] = v;
+        if (tt_hist) tt_hist[(long)r * ldh + cur] = v;
+        if (mask) {
+            pos[r] = p;
+            if (pos_hist) pos_hist[(long)r * ldh + cur] = p;
+        }
+    }
+    // ---- embeddings of the new token
+    const uint32_t dseed = drop_thr16 ? *drop_seed : 0u;
+    float x[2][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ch = lane + i * 64, chc = ch < CH ? ch : CH - 1;
+        float a[8], b[8], c[8];
+        unpack8(*reinterpret_cast<const uint4*>(word + last * C + chc * 8), a);
+        unpack8(*reinterpret_cast<const uint4*>(type + v * C + chc * 8), b);
+        unpack8(*reinterpret_cast<const uint4*>(posw + p * C + chc * 8), c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x[i][j] = ch < CH ? (a[j] + b[j]) + c[j] : 0.f; s += x[i][j]; }
+    }
+    const float mean = group_sum<64>(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = (lane + i * 64 < CH) ? x[i][j] - mean : 0.f; q += d * d; }
+    const float rstd = rsqrtf(group_sum<64>(q) * (1.0f / C) + eps);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < CH) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (x[i][j] - mean) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j];
+            if (drop_thr16) {                                  // embeddings dropout (TF5:bert:106): (sequence r, absolute position T-1)
+                const uint32_t key = dropout_row_key(dseed, drop_site, (uint32_t)r, (uint32_t)(T - 1));
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const uint32_t bits = dropout_pair_bits(key, (uint32_t)(ch * 8 + j) >> 1);
+                    o[j] = (bits & 0xffffu) >= drop_thr16 ? o[j] * drop_inv : 0.f;
+                    o[j + 1] = (bits >> 16) >= drop_thr16 ? o[j + 1] * drop_inv : 0.f;
+                }
+            }
+            *reinterpret_cast<uint4*>(out + (out_mt ? dal_off(r, ch * 8, out_mt) : (long)r * C + ch * 8)) = pack8(o);
+        }
+    }
+}
+
+extern "C" int cxr_decode_step_embed(const long* ids, long ld, int rows, int strip, int cur, const long* special0, int n0, const long* special1,
+                                     int n1, const long* sections, int half_rows, long mask_token_id, long* new_id, long* tt, long* pos,
+                                     void* mask, long ldm, long* tt_hist, long* pos_hist, long ldh, const void* word, const void* type,
+                                     const void* posw, const float* gamma, const float* beta, float eps, void* out, int out_dal, float drop_p,
+                                     const unsigned int* drop_seed, unsigned int drop_site, hipStream_t stream) {
+    if (rows <= 0 || cur - strip < 1 || cur - strip > 512 || !special0 || !special1 || !sections || !new_id || !tt || (mask && !pos)) return CXR_ERR_ARG;
+    if (n0 < 1 || n0 > 4 || n1 < 1 || n1 > 4 || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed) || (out_dal && rows > 64)) return CXR_ERR_ARG;
+    const int out_mt = out_dal ? (cdiv(rows, 16) == 3 ? 4 : cdiv(rows, 16)) : 0;
+    CXR_LAUNCH(decode_step_embed_kernel, dim3(rows), dim3(64), 0, stream, ids, ld, rows, strip, cur, special0, n0, special1, n1, sections, half_rows,
+                       mask_token_id, new_id, tt, pos, (unsigned char*)mask, ldm, tt_hist, pos_hist, ldh, (const bf16_t*)word, (const bf16_t*)type,
+                       (const bf16_t*)posw, gamma, beta, eps, (bf16_t*)out, out_mt, drop_seed, drop_site,
+                       drop_p > 0.f ? dropout_thr16(drop_p) : 0u, 1.0f / (1.0f - drop_p));
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
 extern "C" int cxr_decode_step_inputs(const long* ids, long ld, int rows, int strip, int cur, const long* special0, int n0, const long* special1,
                                       int n1, const long* sections, int half_rows, long mask_token_id, long* new_id, long* tt, long* pos,
                                       void* mask, long ldm, long* tt_hist, long* pos_hist, long ldh, hipStream_t stream) {

@@ -517,8 +517,7 @@ class BertEngine:
         e = p + "bert.embeddings."
         single = Tn == 1 and B <= 64          # one new token per row: weight-streaming GEMMs + single-query attention kernels
         lora_tr = self._lora_train(train)
-        fused = (single and D == 768 and cfg.intermediate_size == 3072 and self.fuse_decode_layernorm and cfg.add_cross_attention and enc is not None
-                 and cache.cross_ready and cfg.vocab_size % 2 == 0)
+        fused = single and self.fused_step_ok(cache, B, enc)
         h, _, _ = ops.bert_embed(ids_new, token_type_ids, position_ids, st.w16(e + "word_embeddings.weight"),
                                  st.w16(e + "token_type_embeddings.weight"), st.w16(e + "position_embeddings.weight"),
                                  st.f32(e + "LayerNorm.weight"), st.f32(e + "LayerNorm.bias"), cfg.layer_norm_eps, Tn, pos_offset=past,
@@ -665,6 +664,26 @@ class BertEngine:
         pack("lm_head", st.w16(p + "bert.embeddings.word_embeddings.weight"), st.f32(c + "bias"), c + "transform.LayerNorm")
         self._pack_key = key
         return pk
+
+    def fused_step_ok(self, cache, B, enc):
+        """One-token steps run on the decode-step kernels of csrc/decode_gemm.hip (instantiated for BERT-base widths) once the cross-attention
+        K/V exist."""
+        cfg = self.cfg
+        return (B <= 64 and cfg.hidden_size == 768 and cfg.intermediate_size == 3072 and self.fuse_decode_layernorm and cfg.add_cross_attention
+                and enc is not None and cache.cross_ready and cfg.vocab_size % 2 == 0)
+
+    def embed_tables(self):
+        """(word, token-type, position tables bf16, LayerNorm gamma, beta fp32, eps) of BertEmbeddings"""
+        st, e = self.s, self.p + "bert.embeddings."
+        return (st.w16(e + "word_embeddings.weight"), st.w16(e + "token_type_embeddings.weight"), st.w16(e + "position_embeddings.weight"),
+                st.f32(e + "LayerNorm.weight"), st.f32(e + "LayerNorm.bias"), self.cfg.layer_norm_eps)
+
+    def decode_embedded(self, cache, x0, B, enc_mask, attn_mask_full, train=None, seed=None):
+        """A cached one-token step whose embedding output x0 (decode activation layout) already exists (ops.decode_step_embed: the step-input
+        assembly and the embeddings are one launch). Same result as decode()."""
+        self.prepare()
+        ph, pa, seed = self._dropout_cfg(train, seed)
+        return self._decode_single_fused(cache, x0, B, enc_mask, attn_mask_full, cache.len, ph, pa, seed, self._lora_train(train))
 
     def refresh_decode_packs(self, train=None):
         """Bring the packed decode weights up to the current weight version / train mode (in place). Graph-replayed decode steps do not run

@@ -76,14 +76,17 @@ class DecodeSession:
             self.seed.copy_(m.next_dropout_seed())
         self.u_all.uniform_()                      # torch's CUDA generator: reproducible under torch.manual_seed
 
-    def step(self, cur, strip, mode):
-        """Append token `cur` (0-based column of self.ids). mode = (do_sample, special_token_ids, mask_token_id, top_k, temperature, eos, pad)."""
-        key = (cur, strip, mode)
-        hit = self.graphs.get(key)
+    def step(self, cur, strip, mode, n=1):
+        """Append tokens cur .. cur+n-1 (0-based columns of self.ids). mode = (kind, special_token_ids, mask_token_id, top_k, temperature, eos, pad,
+        train, top_p). The n cached steps are ONE hipGraph (a replay costs ~9 us of launch overhead whatever it holds: per token at n = 1, per
+        8 tokens at n = 8)."""
         prefill = self.cache.len == 0
         if prefill or not self.model.graph_decode:
-            self._run(cur, strip, mode, prefill)
+            for c in range(cur, cur + n):
+                self._run(c, strip, mode, prefill and c == cur)
             return
+        key = (cur, n, strip, mode)
+        hit = self.graphs.get(key)
         if hit is None:
             g = torch.cuda.CUDAGraph()
             if self.pool is None:
@@ -91,13 +94,14 @@ class DecodeSession:
             keep = self.cache.len
             torch.cuda.synchronize()
             with torch.cuda.graph(g, pool=self.pool):
-                self._run(cur, strip, mode, False)
-            self.cache.len = keep                      # capture does not execute: replay below performs the step
-            hit = (g, self.last_tt, self.last_pos)     # the step's token-type / position outputs live in the graph's pool
+                for c in range(cur, cur + n):
+                    self._run(c, strip, mode, False)
+            self.cache.len = keep                      # capture does not execute: replay below performs the steps
+            hit = (g, self.last_tt, self.last_pos)     # the last step's token-type / position outputs live in the session's history buffers
             self.graphs[key] = hit
         g, self.last_tt, self.last_pos = hit
         g.replay()
-        self.cache.len = cur - strip
+        self.cache.len = cur + n - 1 - strip
 
     def _run(self, cur, strip, mode, prefill):
         m = self.model
@@ -110,13 +114,22 @@ class DecodeSession:
             pair = isinstance(special, tuple) and special and isinstance(special[0], (tuple, list))
             sp0, sp1 = (special[0], special[1]) if pair else (special, special)
             longi = m.kind == "longitudinal"
-            ops.decode_step_inputs(self.ids, strip, cur, list(sp0), list(sp1), [0, 1, 0, 1] if longi else None, self.B // 2 if pair else self.B,
-                                   mask_token_id if longi else -1, self.new_id, self.tt1, self.pos1 if longi else None,
-                                   self.mask8 if longi else None, self.tt_hist, self.pos_hist if longi else None)
-            new, tt = self.new_id, self.tt1
-            pos = self.pos1 if longi else None
+            step_args = (self.ids, strip, cur, list(sp0), list(sp1), [0, 1, 0, 1] if longi else None, self.B // 2 if pair else self.B,
+                         mask_token_id if longi else -1, self.new_id, self.tt1, self.pos1 if longi else None,
+                         self.mask8 if longi else None, self.tt_hist, self.pos_hist if longi else None)
             mask = self.mask8[:, :cur - strip] if longi else None
-        logits = m._dec.decode(self.cache, new, self.enc16, self.enc_mask8, mask, tt, pos, train=train, seed=self.seed)
+            if m._dec.fused_step_ok(self.cache, self.B, self.enc16) and len(sp0) <= 4 and len(sp1) <= 4 and cur - strip <= 512:
+                # ... and the embeddings of the new token in the same launch, written in the decode kernels' activation layout
+                ph, _, _ = m._dec._dropout_cfg(train, self.seed)
+                x0 = ops.decode_step_embed(*step_args, *m._dec.embed_tables(), drop=(ph, self.seed, 1) if ph else None)
+                logits = m._dec.decode_embedded(self.cache, x0, self.B, self.enc_mask8, mask, train=train, seed=self.seed)
+                new = None
+            else:
+                ops.decode_step_inputs(*step_args)
+                new, tt = self.new_id, self.tt1
+                pos = self.pos1 if longi else None
+        if new is not None:
+            logits = m._dec.decode(self.cache, new, self.enc16, self.enc_mask8, mask, tt, pos, train=train, seed=self.seed)
         unf = self.unfinished if eos is not None else None
         eos_ = eos if eos is not None else -1
         n_smp = {"greedy": 0, "sample": self.B, "pair": self.B // 2}[kind]      # rows [0, n_smp) sample, the rest take the argmax
@@ -131,7 +144,7 @@ class DecodeSession:
             self.last_tt, self.last_pos = tt, pos
         else:                                                      # views of the history columns this step wrote (stable across graph replays)
             self.last_tt = self.tt_hist[:, cur:cur + 1]
-            self.last_pos = self.pos_hist[:, cur:cur + 1] if pos is not None else None
+            self.last_pos = self.pos_hist[:, cur:cur + 1] if m.kind == "longitudinal" else None
 
 
 class GenerationMixin:
@@ -295,10 +308,12 @@ class GenerationMixin:
             first_tt = first_pos = None
             poll = None                      # (pinned host word, event): "any row unfinished?" as of the PREVIOUS poll -- read without stalling the queue
             while cur < max_length:
-                ses.step(cur, strip, mode)
+                # the prefill step alone, then chunks of up to 8 cached steps per graph replay, aligned to the EOS polling period
+                n = 1 if cur == prompt_len else min(8 - (cur - prompt_len) % 8, max_length - cur)
+                ses.step(cur, strip, mode, n)
                 if rec is not None and cur == prompt_len:            # the prefill step's inputs cover the whole prompt
                     first_tt, first_pos = ses.last_tt.clone(), None if ses.last_pos is None else ses.last_pos.clone()
-                cur += 1
+                cur += n
                 if eos_token_id is not None and ((cur - prompt_len) % 8 == 0):
                     # EOS polling every 8 steps, one poll behind: the copy of this poll's flag is only waited for at the NEXT poll, so the host
                     # keeps enqueueing steps while the GPU works (a blocking .item() drained the queue 32 times per decode); the up to 16 steps of

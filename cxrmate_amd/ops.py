@@ -734,6 +734,21 @@ def decode_step_inputs(ids, strip, cur, special0, special1, sections, half_rows,
              mask.stride(0) if mask is not None else 0, _p(tt_hist), _p(pos_hist), tt_hist.stride(0) if tt_hist is not None else 0, _s())
 
 
+def decode_step_embed(ids, strip, cur, special0, special1, sections, half_rows, mask_token_id, new_id, tt, pos, mask, tt_hist, pos_hist, word, typ,
+                      posw, gamma, beta, eps, drop=None, out_dal=True):
+    """decode_step_inputs + the BERT embeddings of the new token in one launch -> embedding output bf16 (decode activation layout)."""
+    rows = ids.shape[0]
+    sp0, se = special_tensors(special0, sections, ids.device)
+    sp1, _ = special_tensors(special1, sections, ids.device)
+    out = torch.empty((dal_rows(rows) if out_dal else rows, word.shape[1]), device=ids.device, dtype=BF16)
+    LIB.call("cxr_decode_step_embed", _p(ids), ids.stride(0), rows, int(strip), int(cur), _p(sp0), len(special0), _p(sp1), len(special1), _p(se),
+             int(half_rows), int(mask_token_id if mask is not None else -1), _p(new_id), _p(tt), _p(pos), _p(mask),
+             mask.stride(0) if mask is not None else 0, _p(tt_hist), _p(pos_hist), tt_hist.stride(0) if tt_hist is not None else 0,
+             _p(word), _p(typ), _p(posw), _p(gamma), _p(beta), float(eps), _p(out), int(bool(out_dal)),
+             *((float(drop[0]), _p(drop[1]), int(drop[2])) if drop is not None and drop[0] > 0 else (0.0, None, 0)), _s())
+    return out
+
+
 def mask_position_ids(ids, mask_token_id):
     assert ids.dtype == torch.int64 and ids.stride(1) == 1
     B, T = ids.shape

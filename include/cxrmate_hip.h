@@ -319,6 +319,15 @@ int cxr_decode_step_inputs(const long* ids, long ld, int rows, int strip, int cu
                            const long* sections, int half_rows, long mask_token_id, long* new_id, long* tt, long* pos, void* mask, long ldm,
                            long* tt_hist, long* pos_hist, long ldh, hipStream_t stream);
 
+/* cxr_decode_step_inputs fused with the BERT embeddings of the new token (cxr_bert_embed_fwd for one position per row: word[new_id] + type[tt] +
+ * position[pos, or the absolute position when mask == NULL] -> LayerNorm -> dropout keyed by (row, absolute position)): `out` bf16 [rows, 768],
+ * in the decode activation layout when out_dal != 0. One launch per token instead of two; cur - strip <= 512, at most 4 separators per set. */
+int cxr_decode_step_embed(const long* ids, long ld, int rows, int strip, int cur, const long* special0, int n0, const long* special1, int n1,
+                          const long* sections, int half_rows, long mask_token_id, long* new_id, long* tt, long* pos, void* mask, long ldm,
+                          long* tt_hist, long* pos_hist, long ldh, const void* word, const void* type, const void* posw, const float* gamma,
+                          const float* beta, float eps, void* out, int out_dal, float drop_p, const unsigned int* drop_seed,
+                          unsigned int drop_site, hipStream_t stream);
+
 /* ---- reward (REF:tools/rewards/cxrbert.py:66-71 torch.nn.functional.cosine_similarity of the CLS projections) ---------------- */
 int cxr_cosine_rows_f32(const float* a, long lda, const float* b, long ldb, float* out, long R, int C, float eps, hipStream_t stream);
 
