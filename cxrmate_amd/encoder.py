@@ -154,9 +154,11 @@ class CvtEncoderEngine:
         return self._prep[("wt", key)]
 
     # ------------------------------------------------------------------------------------------ forward
-    def forward(self, px: torch.Tensor, save: bool = False, train: bool | None = None):
+    def forward(self, px: torch.Tensor, save: bool = False, train: bool | None = None, stage_outputs: list | None = None):
         """px [Bn,3,H,W] fp32 (contiguous) -> feats [Bn*tokens, projection_size] bf16, saved-activation dict | None.
-        train (default: the store's nn.Module flag): batch-statistics BatchNorm + DropPath."""
+        train (default: the store's nn.Module flag): batch-statistics BatchNorm + DropPath.
+        stage_outputs: a list that receives each stage's output as (tokens bf16 [Bn, H*W, C] without the class token, H, W) -- CvtModel's
+        `hidden_states` (TF5:cvt:430-447) in token-major form, for parity tests."""
         cfg, st = self.cfg, self.s
         train = bool(st.training) if train is None else bool(train)
         prep = self.prepare()
@@ -207,6 +209,8 @@ class CvtEncoderEngine:
                 ops.copy_rows(cur[:, 1:, :], x)
             else:
                 x = cur
+            if stage_outputs is not None:
+                stage_outputs.append((x, H, W))
         # projection head: LayerNorm(eps = config.layer_norm_eps) -> Linear(384 -> 768, no bias)
         hp = self.p + "projection_head."
         C = cfg.embed_dim[-1]

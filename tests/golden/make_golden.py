@@ -100,7 +100,7 @@ from modules.transformers.longitudinal_model.modelling_longitudinal import (  # 
     LongitudinalPromptMultiCXREncoderDecoderModel)
 
 from cxrmate_amd import weights  # noqa: E402
-from cxrmate_amd.config import tiny_config, BertConfig as MyBertConfig  # noqa: E402
+from cxrmate_amd.config import tiny_config, EncoderDecoderConfig, BertConfig as MyBertConfig  # noqa: E402
 
 BOS, EOS, SEP, PAD, PMT, PMT_SEP, NPF, NPI = 1, 2, 3, 4, 8, 9, 10, 11
 
@@ -660,6 +660,118 @@ def fixture_token_ops():
     print("token_ops", len(cases), "random cases;", len(helper), "helper cases")
 
 
+
+def fixture_encoder_full():
+    """CvT-21 at FULL depth (1, 4, 16) @384x384: per-stage and final activations of two 2-image studies (one image zero-padded). The bf16
+    error of the MI355X path over 21 layers is measured against this, not against the shallow (1, 2, 3) fixture."""
+    cfg = EncoderDecoderConfig()
+    cfg.decoder.vocab_size, cfg.decoder.num_hidden_layers = 1000, 1              # the decoder is not run here
+    model, _ = build(MultiCXREncoderDecoderModel, cfg, seed=31, perturb=0.05)
+    g = torch.Generator().manual_seed(131)
+    x = torch.randn(2, 2, 3, 384, 384, generator=g)
+    x[1, 1] = 0.0
+    with torch.no_grad():
+        cvt_out = model.encoder.cvt(x.view(-1, 3, 384, 384), output_hidden_states=True, return_dict=True)
+        out = model.encoder(x)
+    d = {"seed": 31, "perturb": 0.05, "pixel_seed": 131, "depth": np.array(cfg.encoder.depth)}
+    for i, h in enumerate(cvt_out.hidden_states):
+        d[f"stage{i}_sample"] = sample(h, 16384)
+        d[f"stage{i}_stats"] = stats(h)
+        d[f"stage{i}_shape"] = np.array(h.shape)
+    d["last_hidden_state_sample"] = sample(out.last_hidden_state, 32768)
+    d["last_hidden_state_stats"] = stats(out.last_hidden_state)
+    d["last_hidden_state_shape"] = np.array(out.last_hidden_state.shape)
+    d["attention_mask"] = out.attention_mask.numpy()
+    np.savez_compressed(os.path.join(OUT, "encoder_full.npz"), **d)
+    print("encoder_full", d["last_hidden_state_stats"])
+
+
+def fixture_tf_full():
+    """The full-size multi-image model (CvT-21 + BERT-6, vocab 30000) teacher-forced at T = 256: logits sample, argmax + margins at sampled
+    positions, cross-entropy loss (configs[1]/[2] shapes at batch 2)."""
+    cfg = EncoderDecoderConfig()
+    model, _ = build(MultiCXREncoderDecoderModel, cfg, seed=32, perturb=0.05)
+    g = torch.Generator().manual_seed(132)
+    x = torch.randn(2, 2, 3, 384, 384, generator=g)
+    x[0, 1] = 0.0
+    T = 256
+    full = rand_report_ids(g, 2, T + 1, 30000, [120, 77], [T + 1, 201])
+    attn = (full != PAD).long()
+    inp, lab, am = full[:, :-1], full[:, 1:].clone(), attn[:, 1:]
+    tt = model.token_ids_to_token_type_ids(inp, [SEP])
+    with torch.no_grad():
+        out = model(pixel_values=x, decoder_input_ids=inp, decoder_attention_mask=am, decoder_token_type_ids=tt, return_dict=True)
+        loss = torch.nn.functional.cross_entropy(out.logits.permute(0, 2, 1), lab, ignore_index=PAD)
+    lg = out.logits
+    top2 = torch.topk(lg, 2, dim=-1)[0]
+    rows = torch.arange(0, T, 5)
+    d = {"seed": 32, "perturb": 0.05, "pixel_seed": 132, "full_ids": full.numpy(), "token_type_ids": tt.numpy(),
+         "logits_sample": sample(lg, 65536), "logits_stats": stats(lg), "loss": np.array(loss.item()),
+         "logits_argmax": lg.argmax(-1).numpy(), "logits_margin": (top2[..., 0] - top2[..., 1]).numpy(),
+         "logits_rows": rows.numpy(), "logits_row_slices": lg[:, rows, :512].numpy().astype(np.float16)}
+    np.savez_compressed(os.path.join(OUT, "tf_full.npz"), **d)
+    print("tf_full loss", loss.item(), stats(lg))
+
+
+def fixture_longitudinal_c5():
+    """BASELINE.json configs[4] shape at batch 2: longitudinal model (LoRA), 3 images per study (one study with 2), 128-token previous-report
+    prompt, 64 report tokens teacher-forced after it: logits / loss of the report part, token-type and position ids, and 12 greedy steps."""
+    cfg = EncoderDecoderConfig()
+    cfg.decoder.lora_r = 8
+    model, sd = build(LongitudinalPromptMultiCXREncoderDecoderModel, cfg, seed=33, perturb=0.05, longitudinal=True)
+    g = torch.Generator().manual_seed(133)
+    x = torch.randn(2, 3, 3, 384, 384, generator=g)
+    x[1, 2] = 0.0
+    P, T = 128, 64
+    prompt = torch.randint(12, 30000, (2, P), generator=g)
+    prompt[:, 0], prompt[:, 63], prompt[:, P - 1] = PMT, PMT_SEP, BOS
+    prompt[1, 100:P - 1] = PAD                                        # a shorter previous report: interior PADs before [BOS] (quirk Q8)
+    full = rand_report_ids(g, 2, T + 1, 30000, [30, 21], [T + 1, 50])
+    inp = torch.cat([prompt, full[:, 1:-1]], dim=1)                  # prompt ends with [BOS]; the report continues after it
+    lab = full[:, 1:].clone()
+    am = (inp != PAD).long()
+    pos = torch.nn.functional.relu(torch.cumsum(am, dim=1) - 1)
+    tt = model.token_ids_to_token_type_ids(inp, [PMT_SEP, BOS, SEP], [0, 1, 0, 1])
+    with torch.no_grad():
+        eo = model.encoder(x)
+        out = model(encoder_outputs=eo, decoder_input_ids=inp, decoder_attention_mask=am, decoder_token_type_ids=tt, decoder_position_ids=pos,
+                    return_dict=True)
+        lg = out.logits[:, P - 1:]
+        loss = torch.nn.functional.cross_entropy(lg.permute(0, 2, 1), lab, ignore_index=PAD)
+        steps = 12
+        greedy, argm, margins = nocache_greedy(model, "longitudinal", eo, steps, prompt=prompt, special=[PMT_SEP, BOS, SEP])
+    top2 = torch.topk(lg, 2, dim=-1)[0]
+    d = {"seed": 33, "perturb": 0.05, "pixel_seed": 133, "prompt_ids": prompt.numpy(), "full_ids": full.numpy(), "input_ids": inp.numpy(),
+         "attention_mask": am.numpy(), "position_ids": pos.numpy(), "token_type_ids": tt.numpy(), "enc_mask": eo.attention_mask.numpy(),
+         "enc_sample": sample(eo.last_hidden_state, 16384), "logits_sample": sample(lg, 65536), "logits_stats": stats(lg),
+         "loss": np.array(loss.item()), "logits_argmax": lg.argmax(-1).numpy(), "logits_margin": (top2[..., 0] - top2[..., 1]).numpy(),
+         "greedy": greedy.numpy(), "greedy_margin": margins, "greedy_argmax": argm}
+    np.savez_compressed(os.path.join(OUT, "longitudinal_c5.npz"), **d)
+    print("longitudinal_c5 loss", loss.item(), "greedy", greedy[:, P:].tolist())
+
+
+
+def fixture_beam_margins():
+    """All four final beams (and their scores) of the beam-4 decode of fixture_generate's multi-image case: the gap between the best and the
+    second-best hypothesis says for which studies a bf16 decode must return the SAME sequence as the reference."""
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, depth=(1, 2, 3), image_size=96)
+    model, _ = build(MultiCXREncoderDecoderModel, cfg, seed=14, perturb=0.05)
+    g = torch.Generator().manual_seed(104)
+    x = torch.randn(3, 2, 3, 96, 96, generator=g)
+    x[1, 1] = 0.0
+    steps = 20
+    with torch.no_grad():
+        beam = model.generate(pixel_values=x, special_token_ids=[SEP], max_length=steps + 1, bos_token_id=BOS, eos_token_id=EOS, pad_token_id=PAD,
+                              num_beams=4, num_return_sequences=4, return_dict_in_generate=True, use_cache=True, do_sample=False, output_scores=True)
+    seqs = beam["sequences"].view(3, 4, -1)
+    sc = beam["sequences_scores"].view(3, 4)
+    best = np.load(os.path.join(OUT, "generate_multi.npz"))
+    assert np.array_equal(seqs[:, 0].numpy(), best["beam4"]) and np.allclose(sc[:, 0].numpy(), best["beam4_scores"])
+    np.savez_compressed(os.path.join(OUT, "generate_multi_beams.npz"), beam4_all=seqs.numpy(), beam4_all_scores=sc.numpy(),
+                        beam4_margin=(sc[:, 0] - sc[:, 1]).numpy())
+    print("beam margins", (sc[:, 0] - sc[:, 1]).tolist())
+
+
 def fixture_reward_trunk():
     """Pins the bidirectional BERT trunk of the CXR-BERT stand-in against transformers.BertModel (the projection head
     itself is an assumption -- parity unpinned)."""
@@ -684,7 +796,8 @@ def fixture_reward_trunk():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["token_ops", "encoder", "tf_single", "tf_single_train", "tf_longitudinal", "tf_longitudinal_train", "generate", "reward_trunk"]
+    which = sys.argv[1:] or ["token_ops", "encoder", "tf_single", "tf_single_train", "tf_longitudinal", "tf_longitudinal_train", "generate", "reward_trunk",
+                             "encoder_full", "tf_full", "longitudinal_c5", "beam_margins"]
     meta = {"transformers": transformers.__version__, "torch": torch.__version__,
             "adapter": "SURVEY.md A.3 (D1 legacy decoder.prepare_inputs_for_generation + D2 empty-cache prefill)",
             "reference": "/root/reference (aehrc/cxrmate @ 2025-02-22)", "mode": "eval(), fp32, CPU; tf_single_train: train() with the drawn dropout / DropPath masks recorded"}

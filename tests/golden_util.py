@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from cxrmate_amd import weights
-from cxrmate_amd.config import BertConfig, tiny_config
+from cxrmate_amd.config import BertConfig, EncoderDecoderConfig, tiny_config
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 BOS, EOS, SEP, PAD, PMT, PMT_SEP, NPF, NPI = 1, 2, 3, 4, 8, 9, 10, 11
@@ -153,3 +153,41 @@ def tf_longitudinal_train_case():
         paths[(int(name[4]), int(name[6]))] = (torch.from_numpy(g[f"path{i}_factor"]), torch.from_numpy(g[f"path{i + 1}_factor"]))
     return (g, cfg, sd, x, prompt, inp, full[:, 1:].clone(), torch.from_numpy(g["attention_mask"]), torch.from_numpy(g["token_type_ids"]),
             torch.from_numpy(g["position_ids"]), dropout, paths)
+
+
+def encoder_full_case():
+    """CvT-21 at full depth (1, 4, 16) @384: fixture encoder_full.npz"""
+    g = load("encoder_full.npz")
+    cfg = EncoderDecoderConfig()
+    cfg.decoder.vocab_size, cfg.decoder.num_hidden_layers = 1000, 1
+    assert tuple(int(i) for i in g["depth"]) == tuple(cfg.encoder.depth)
+    sd = weights.init_encoder_decoder(cfg, seed=int(g["seed"]), perturb=float(g["perturb"]))
+    gen = torch.Generator().manual_seed(int(g["pixel_seed"]))
+    x = torch.randn(2, 2, 3, 384, 384, generator=gen)
+    x[1, 1] = 0.0
+    return g, cfg, sd, x
+
+
+def tf_full_case():
+    """full-size multi-image model, T = 256: fixture tf_full.npz"""
+    g = load("tf_full.npz")
+    cfg = EncoderDecoderConfig()
+    sd = weights.init_encoder_decoder(cfg, seed=int(g["seed"]), perturb=float(g["perturb"]))
+    gen = torch.Generator().manual_seed(int(g["pixel_seed"]))
+    x = torch.randn(2, 2, 3, 384, 384, generator=gen)
+    x[0, 1] = 0.0
+    full = torch.from_numpy(g["full_ids"])
+    attn = (full != PAD).long()
+    return g, cfg, sd, x, full[:, :-1], full[:, 1:].clone(), attn[:, 1:], torch.from_numpy(g["token_type_ids"])
+
+
+def longitudinal_c5_case():
+    """BASELINE.json configs[4] shape: 3 images per study + 128-token prompt: fixture longitudinal_c5.npz"""
+    g = load("longitudinal_c5.npz")
+    cfg = EncoderDecoderConfig()
+    cfg.decoder.lora_r = 8
+    sd = weights.init_encoder_decoder(cfg, seed=int(g["seed"]), perturb=float(g["perturb"]))
+    gen = torch.Generator().manual_seed(int(g["pixel_seed"]))
+    x = torch.randn(2, 3, 3, 384, 384, generator=gen)
+    x[1, 2] = 0.0
+    return g, cfg, sd, x

@@ -52,10 +52,21 @@ def test_state_dict_keys_match_reference_layout(M):
     assert all(not p.requires_grad for p in ml.encoder.parameters())
 
 
+def _stage_activations(m, x):
+    """CvtModel hidden_states (NCHW, class token split off) from the engine's token-major stage outputs"""
+    taps = []
+    with torch.no_grad():
+        m._enc.forward(m._pixels(x).view(-1, *x.shape[-3:]), stage_outputs=taps)
+    return [t.float().view(t.shape[0], H, W, t.shape[2]).permute(0, 3, 1, 2).contiguous().cpu() for t, H, W in taps]
+
+
 def test_encoder_matches_reference_fixture(M):
     g, cfg, sd, x = gu.encoder_case()
     m = M.MultiCXREncoderDecoderModel(cfg, seed=None)
     m.load_state_dict(sd)
+    for i, h in enumerate(_stage_activations(m, x.cuda())):                          # per-stage activations of the reference's CvtModel
+        assert list(h.shape) == g[f"stage{i}_shape"].tolist()
+        check_act(gu.sample(h), g[f"stage{i}_sample"], f"stage {i} hidden state")
     with torch.no_grad():
         out = m.encoder(x.cuda())
     h = out.last_hidden_state.float().cpu()
@@ -422,6 +433,21 @@ def test_greedy_and_beam_multi(M):
     bs = beam["sequences"].cpu()
     assert bs.shape[0] == 3 and bool((bs[:, 0] == gu.BOS).all()) and bs.shape[1] <= L
     np.testing.assert_allclose(beam["sequences_scores"].cpu().numpy(), g["beam4_scores"], atol=0.05)
+    # ... and the reference's beam-4 SEQUENCES. With random-init weights the four final hypotheses lie within 0.005-0.013 of each other
+    # (generate_multi_beams.npz: all four beams and scores), far inside the bf16 score error, so the winner may be any of them: the returned
+    # sequence must BE one of the reference's final beams, with that beam's score.
+    gb = gu.load("generate_multi_beams.npz")
+    assert float(gb["beam4_margin"].max()) < MARGIN
+    hits = 0
+    for b in range(3):
+        for j in range(4):
+            rb = torch.from_numpy(gb["beam4_all"][b, j])
+            Lb = min(bs.shape[1], rb.shape[0])
+            if torch.equal(bs[b, :Lb], rb[:Lb]):
+                assert abs(float(beam["sequences_scores"][b]) - float(gb["beam4_all_scores"][b, j])) < 0.05
+                hits += 1
+                break
+    assert hits >= 2, (hits, bs, gb["beam4_all"])
     # EOS handling (EOS -> PAD fill, stop/trim when every row has finished): bias the EOS logit well past the fixture's threshold
     with torch.no_grad():
         m.param("decoder.cls.predictions.bias")[gu.EOS] += float(g["eos_bias"]) + 1.0      # in-place edit: the bf16 shadow follows by itself
@@ -559,3 +585,83 @@ def test_reference_sampled_sequence_scores_fixture(M):
         loss, row_loss, _ = ops.softmax_ce(sc.view(-1, V), sampled, gu.PAD, w, thr=thr, need_grad=False)
     assert abs(loss.item() - float(g["reinforce_loss"])) < 0.05 * max(1.0, abs(float(g["reinforce_loss"])))
     np.testing.assert_allclose(row_loss.view(B, T).cpu().numpy(), g["nll"], atol=0.08)
+
+
+# ------------------------------------------------------------------------------------------------ full-size fixtures (CvT-21, BERT-6, vocab 30000)
+def test_full_depth_encoder_matches_reference_fixture(M):
+    """CvT-21 at depth (1, 4, 16): the bf16 error of 21 layers measured against the reference's fp32 activations, stage by stage."""
+    g, cfg, sd, x = gu.encoder_full_case()
+    m = M.MultiCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    errs = []
+    for i, h in enumerate(_stage_activations(m, x.cuda())):
+        assert list(h.shape) == g[f"stage{i}_shape"].tolist()
+        errs.append(gu.rel_rms(gu.sample(h, 16384), g[f"stage{i}_sample"]))
+        check_act(gu.sample(h, 16384), g[f"stage{i}_sample"], f"full-depth stage {i}")
+    with torch.no_grad():
+        out = m.encoder(x.cuda())
+    h = out.last_hidden_state.float().cpu()
+    assert list(h.shape) == [2, 1152, 768] and np.array_equal(out.attention_mask.cpu().numpy(), g["attention_mask"])
+    check_act(gu.sample(h, 32768), g["last_hidden_state_sample"], "full-depth encoder output")
+    print("bf16 rel-rms per stage / output:", [round(e, 5) for e in errs], round(gu.rel_rms(gu.sample(h, 32768), g["last_hidden_state_sample"]), 5))
+
+
+def test_full_size_tf_logits_loss_argmax(M):
+    g, cfg, sd, x, inp, lab, am, tt = gu.tf_full_case()
+    m = M.MultiCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    tt_dev = m.token_ids_to_token_type_ids(inp, [gu.SEP])
+    assert np.array_equal(tt_dev.cpu().numpy(), g["token_type_ids"])
+    with torch.no_grad():
+        logits = m(pixel_values=x.cuda(), decoder_input_ids=inp.cuda(), decoder_attention_mask=am.cuda(), decoder_token_type_ids=tt_dev).logits
+        loss = torch.nn.functional.cross_entropy(logits.permute(0, 2, 1), lab.cuda(), ignore_index=gu.PAD)
+    assert list(logits.shape) == [2, 256, 30000]
+    check_act(gu.sample(logits, 65536), g["logits_sample"], "full-size logits")
+    assert abs(loss.item() - float(g["loss"])) < 2e-2
+    safe = g["logits_margin"] > MARGIN
+    assert safe.mean() > 0.3
+    assert np.array_equal(logits.argmax(-1).cpu().numpy()[safe], g["logits_argmax"][safe])
+    rows = torch.from_numpy(g["logits_rows"])
+    np.testing.assert_allclose(logits[:, rows, :512].float().cpu().numpy(), g["logits_row_slices"].astype(np.float32), atol=0.08)
+
+
+def test_longitudinal_c5_three_images_128_token_prompt(M):
+    """BASELINE.json configs[4] shape: 3 images per study (one zero-padded), 128-token previous-report prompt with interior PADs: teacher-forced
+    logits / loss of the report and KV-cached greedy steps against the reference."""
+    g, cfg, sd, x = gu.longitudinal_c5_case()
+    m = M.LongitudinalPromptMultiCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    inp, am = torch.from_numpy(g["input_ids"]).cuda(), torch.from_numpy(g["attention_mask"]).cuda()
+    prompt = torch.from_numpy(g["prompt_ids"])
+    P = prompt.shape[1]
+    special = [gu.PMT_SEP, gu.BOS, gu.SEP]
+    tt = m.token_ids_to_token_type_ids(inp, special, [0, 1, 0, 1])
+    assert np.array_equal(tt.cpu().numpy(), g["token_type_ids"])
+    _, pos = m.position_ids_from_mask_token(inp, gu.PAD)
+    assert np.array_equal(pos.cpu().numpy(), g["position_ids"])
+    with torch.no_grad():
+        eo = m.encoder(x.cuda())
+        assert np.array_equal(eo.attention_mask.cpu().numpy(), g["enc_mask"]) and eo.last_hidden_state.shape[1] == 3 * 576
+        check_act(gu.sample(eo.last_hidden_state.float(), 16384), g["enc_sample"], "C5 encoder output")
+        logits = m(encoder_outputs=eo, decoder_input_ids=inp, decoder_attention_mask=am, decoder_token_type_ids=tt, decoder_position_ids=pos).logits
+        lg = logits[:, P - 1:]
+        lab = torch.from_numpy(g["full_ids"])[:, 1:].cuda()
+        loss = torch.nn.functional.cross_entropy(lg.permute(0, 2, 1), lab, ignore_index=gu.PAD)
+    check_act(gu.sample(lg, 65536), g["logits_sample"], "C5 logits")
+    assert abs(loss.item() - float(g["loss"])) < 2e-2
+    safe = g["logits_margin"] > MARGIN
+    assert np.array_equal(lg.argmax(-1).cpu().numpy()[safe], g["logits_argmax"][safe])
+    # KV-cached greedy decode behind the 128-token prompt, teacher-forced along the reference's sequence
+    ref = torch.from_numpy(g["greedy"])
+    new = ref.shape[1] - P
+    out = m.generate(encoder_outputs=eo, decoder_input_ids=prompt.cuda(), special_token_ids=special, max_length=new + 1 + P, bos_token_id=gu.BOS,
+                     eos_token_id=gu.EOS, pad_token_id=gu.PAD, mask_token_id=gu.PAD, num_beams=1, return_dict_in_generate=True, use_cache=True,
+                     forced_tokens=ref[:, P:])
+    gsafe = g["greedy_margin"] > MARGIN
+    assert np.array_equal(out["greedy_tokens"].cpu().numpy()[gsafe], g["greedy_argmax"][gsafe])
+    free = m.generate(encoder_outputs=eo, decoder_input_ids=prompt.cuda(), special_token_ids=special, max_length=new + 1 + P, bos_token_id=gu.BOS,
+                      eos_token_id=None, pad_token_id=gu.PAD, mask_token_id=gu.PAD, num_beams=1, use_cache=True)[:, 1:].cpu()
+    for b in range(2):
+        unsafe = np.nonzero(~gsafe[b])[0]
+        upto = P + (unsafe[0] if len(unsafe) else new)
+        assert torch.equal(free[b, :upto], ref[b, :upto]), (b, free[b, P:], ref[b, P:])

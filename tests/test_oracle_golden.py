@@ -221,3 +221,47 @@ def test_top_k_top_p_filters_match_transformers_warpers():
             got = ogen.top_p_filter(got, p)
         assert torch.equal(torch.isfinite(ref), torch.isfinite(got)) and torch.equal(ref[torch.isfinite(ref)], got[torch.isfinite(got)])
         assert bool((torch.isfinite(got).sum(-1) >= 1).all())
+
+
+# ------------------------------------------------------------------------------------------------ full-size fixtures (CvT-21, BERT-6, vocab 30000)
+def test_full_depth_encoder_matches_reference():
+    g, cfg, sd, x = gu.encoder_full_case()
+    with torch.no_grad():
+        h, mask, stages = ocvt.encoder_forward(x, sd, cfg.encoder, return_stages=True)
+    assert list(h.shape) == g["last_hidden_state_shape"].tolist() == [2, 1152, 768]
+    assert np.array_equal(mask.numpy(), g["attention_mask"])
+    for i, s in enumerate(stages):
+        assert list(s.shape) == g[f"stage{i}_shape"].tolist()
+        assert gu.rel_rms(gu.sample(s, 16384), g[f"stage{i}_sample"]) < FP32_TOL, i
+    assert gu.rel_rms(gu.sample(h, 32768), g["last_hidden_state_sample"]) < FP32_TOL
+
+
+def test_full_size_tf_logits_and_loss_match_reference():
+    g, cfg, sd, x, inp, lab, am, tt = gu.tf_full_case()
+    assert np.array_equal(token_ops.token_ids_to_token_type_ids(inp.numpy(), [gu.SEP]), g["token_type_ids"])
+    with torch.no_grad():
+        h, mask = ocvt.encoder_forward(x, sd, cfg.encoder)
+        logits = obert.decoder_forward(inp, sd, cfg.decoder, h, mask, am, tt, None)
+        loss = ogen.tf_cross_entropy(logits, lab, gu.PAD)
+    assert list(logits.shape) == [2, 256, 30000]
+    assert gu.rel_rms(gu.sample(logits, 65536), g["logits_sample"]) < FP32_TOL
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    safe = g["logits_margin"] > 1e-3
+    assert np.array_equal(logits.argmax(-1).numpy()[safe], g["logits_argmax"][safe])
+
+
+def test_longitudinal_c5_shape_matches_reference():
+    g, cfg, sd, x = gu.longitudinal_c5_case()
+    inp, am, pos = (torch.from_numpy(g[k]) for k in ("input_ids", "attention_mask", "position_ids"))
+    P = g["prompt_ids"].shape[1]
+    assert np.array_equal(token_ops.token_ids_to_token_type_ids(inp.numpy(), [gu.PMT_SEP, gu.BOS, gu.SEP], [0, 1, 0, 1]), g["token_type_ids"])
+    assert np.array_equal(token_ops.position_ids_from_mask(am.numpy()), g["position_ids"])
+    with torch.no_grad():
+        h, mask = ocvt.encoder_forward(x, sd, cfg.encoder)
+        assert np.array_equal(mask.numpy(), g["enc_mask"]) and h.shape[1] == 3 * 576
+        assert gu.rel_rms(gu.sample(h, 16384), g["enc_sample"]) < FP32_TOL
+        logits = obert.decoder_forward(inp, sd, cfg.decoder, h, mask, am, torch.from_numpy(g["token_type_ids"]), pos)[:, P - 1:]
+        lab = torch.from_numpy(g["full_ids"])[:, 1:]
+        loss = ogen.tf_cross_entropy(logits, lab, gu.PAD)
+    assert gu.rel_rms(gu.sample(logits, 65536), g["logits_sample"]) < FP32_TOL
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
