@@ -165,6 +165,12 @@ def scst_bench(args, rank, world, dev, steps):
         model.sample_and_greedy(eo, prompt, [1, 3], [9, 1, 3], 4, args.new_tokens + 1 + prompt.shape[1], 1, None, 4)
         e1.record()
         torch.cuda.synchronize()
+    strings = None
+    if world == 1:
+        try:
+            strings = scst_string_round_trip(args, model, opt, images, prompt, special, dev, B)
+        except Exception as e:                                    # transformers / the fixture tokenizer missing: the main number stands
+            strings = {"error": str(e)}
     n_tok = args.new_tokens
     dec_ms = e0.elapsed_time(e1)
     t_ctx = prompt.shape[1] + n_tok / 2.0                          # mean self-attention context over the decode
@@ -178,13 +184,54 @@ def scst_bench(args, rank, world, dev, steps):
             "workload": "BASELINE.json configs[3] per-GPU shape: sample (top-k 50) + greedy baseline as one 32-row cached decode replayed from "
                         "hipGraphs, REINFORCE through one teacher-forced pass, AdamW on the 80.9 M decoder parameters",
             "mode": "eval" if args.eval_mode else "model.train(): batch-statistics BatchNorm in the frozen encoder, dropout 0.1 in both decodes and in "
-                    "the re-scoring pass (same seed)", "loss": float(out["loss"].item()),
+                    "the re-scoring pass (same seed)", "loss": float(out["loss"].item()), "string_round_trip": strings,
             "roofline": {"bound": "hbm", "kernel": "cached decode token-step (one hipGraph of ~54 kernels: dec_gemm_kernel x38, attn_decode_kernel x12, "
                          "embedding, step inputs, token selection), 32 rows", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_token_step": step_bytes,
                          "decode_ms_per_step": dec_ms, "us_per_token_step": dec_ms * 1e3 / n_tok,
                          "decode_share_of_step": dec_ms / (dt / steps * 1e3),
                          "profile": "profiles/r02_scst_decode_v1_kernel_stats.csv (rocprofv3 --kernel-trace of scripts/scst_decode_profile.py)"}}
+
+
+class _InVocabTokenizer:
+    """The synthetic byte-BPE tokenizer of tests/golden (400 entries, reference id layout) in front of a random-init model that emits ids up to
+    30000: ids are folded into the vocabulary before decoding so that every generated token becomes text."""
+
+    def __init__(self, tok):
+        self.tok, self.n = tok, len(tok)
+
+    def decode(self, ids, skip_special_tokens=True):
+        ids = [int(i) for i in ids]
+        return self.tok.decode([i if i < 12 else 12 + (i - 12) % (self.n - 12) for i in ids], skip_special_tokens=skip_special_tokens)
+
+
+def scst_string_round_trip(args, model, opt, images, prompt, special, dev, B, steps=3):
+    """The same SCST step with the reference's REAL reward path (scst/gt_prompt.py:90-91,120-128,192-197): generated ids -> findings /
+    impression strings (split_and_decode_sections + tokenizer.decode) -> CXR-BERT tokenizer -> two BERT-base forwards per reward call, through
+    reward.ReportReward on pinned host copies. Tokenizer: the synthetic byte-BPE of tests/golden (no real vocabulary offline)."""
+    import transformers
+    from cxrmate_amd.reward import CXRBERTReward, ReportReward
+    from cxrmate_amd.scst import scst_step
+    tok = transformers.PreTrainedTokenizerFast(tokenizer_file=os.path.join(ROOT, "tests", "golden", "tokenizer.json"), unk_token="[UNK]",
+                                               pad_token="[PAD]", cls_token="[BOS]", sep_token="[SEP]", mask_token="[MASK]", bos_token="[BOS]",
+                                               eos_token="[EOS]")
+    reward = CXRBERTReward(dev, tokenizer=tok, seed=1)
+    labels = [["The lungs are clear without focal consolidation. No pleural effusion or pneumothorax. No acute cardiopulmonary process."]] * B
+    rfn = ReportReward(model, _InVocabTokenizer(tok), reward, labels, 1, 3, 2)
+
+    def step():
+        return scst_step(model, opt, rfn, images, prompt, None, special, decoder_max_len=args.new_tokens + 1, reward_on_host=True)
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"ms_per_step": dt * 1e3, "steps_per_sec": 1.0 / dt, "steps": steps, "loss": float(out["loss"].item()),
+            "what": "scst_step(reward_on_host=True) with reward.ReportReward: async pinned copies of the sequences, strings decoded and re-tokenised "
+                    "on the host while the re-scoring forward runs, label embeddings cached; synthetic byte-BPE tokenizer (tests/golden/tokenizer.json)"}
 
 
 def tf_bench(args, rank, world, dev, model, n_images, steps, profile_gemm):

@@ -80,3 +80,20 @@ class CXRBERTReward:
     def reward_from_ids(self, pred_ids, pred_mask, label_ids, label_mask):
         """Tokenizer-free entry (synthetic benchmarks / parity tests)."""
         return ops.cosine_rows(self.embed_ids(pred_ids, pred_mask), self.embed_ids(label_ids, label_mask))
+
+
+class ReportReward:
+    """`reward_fn` for scst.scst_step(..., reward_on_host=True): the reference's string round trip inside an SCST step
+    (modules/lightning_modules/longitudinal/scst/gt_prompt.py:90-91,120-128,192-197): token ids -> findings / impression strings
+    (`split_and_decode_sections` with [bos, sep, eos], the previous-report prompt excluded) -> f"{findings} {impression}" -> CXR-BERT reward
+    against the study's labels. Works on PINNED HOST copies of the sequences (one asynchronous copy per decode, no per-row sync); the label
+    embeddings are computed once per batch (CXRBERTReward caches them per label tuple: the reference embeds them twice per step)."""
+
+    def __init__(self, model, tokenizer, reward: CXRBERTReward, labels, bos_token_id, sep_token_id, eos_token_id):
+        self.model, self.tokenizer, self.reward = model, tokenizer, reward
+        self.labels = labels                                  # [[f"{findings} {impression}"], ...] as the reference builds them (gt_prompt.py:90)
+        self.special = [bos_token_id, sep_token_id, eos_token_id]
+
+    def __call__(self, sequences_host):
+        _, findings, impression = self.model.split_and_decode_sections(sequences_host, self.special, self.tokenizer)
+        return self.reward.reward([f"{i} {j}" for i, j in zip(findings, impression)], self.labels)

@@ -21,10 +21,37 @@ import torch
 from . import dp, ops
 
 
+_SIDE = {}
+
+
+def _host_copies(tensors):
+    """Asynchronous device -> pinned-host copies on a side stream that waits only for what is queued so far (the decode): the main stream
+    goes on with the re-scoring forward while the copies land. -> (list of pinned CPU tensors, event to synchronise before reading them)."""
+    dev = tensors[0].device
+    side = _SIDE.get(dev)
+    if side is None:
+        side = _SIDE[dev] = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    outs = []
+    with torch.cuda.stream(side):
+        for t in tensors:
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            t.record_stream(side)
+            outs.append(h)
+        done = torch.cuda.Event()
+        done.record(side)
+    return outs, done
+
+
 def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, decoder_max_len, top_k=50, temperature=1.0,
-              fused_decode=True, top_p=1.0):
-    """special = dict(bos, eos, sep, pad, pmt_sep). reward_fn(sequences_without_prompt [B,L] int64) -> fp32 [B] given the caller's
-    labels (closure); decode/re-tokenise round trips live inside reward_fn so that benchmarks can swap them for synthetic ids.
+              fused_decode=True, top_p=1.0, reward_on_host=False):
+    """special = dict(bos, eos, sep, pad, pmt_sep). reward_fn -> fp32 [B] given the caller's labels (closure):
+      * reward_on_host=False: reward_fn(sequences_without_prompt [B,L] int64 on the device) -- benchmarks feed synthetic re-tokenised ids;
+      * reward_on_host=True: reward_fn(full sequences [B, P+L] int64 in PINNED HOST memory) -- the reference's real path (gt_prompt.py:192-197,
+        120-128: split_and_decode_sections -> strings -> CXR-BERT tokenizer), e.g. reward.ReportReward. The device -> host copies run on a side
+        stream and the teacher-forced re-scoring forward is queued BEFORE the rewards are needed, so the GPU works through it while the CPU
+        decodes and re-tokenises the reports.
     Returns dict(loss, reward, baseline, seq_len)."""
     bos, eos, sep, pad, pmt_sep = (special[k] for k in ("bos", "eos", "sep", "pad", "pmt_sep"))
     dev = model.device
@@ -48,14 +75,11 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         if bool(torch.all(base[:, 0] == bos)):
             base = base[:, 1:]
         sampled = seqs[:, P:].contiguous()
-        reward = reward_fn(sampled)
-        baseline = reward_fn(base[:, P:].contiguous())
-        adv = (reward - baseline).float().contiguous()
-        # data parallel: the sampled / greedy sequences and their rewards of ALL ranks (RCCL all-gather over xGMI, <= 64 KB per rank) for the
-        # global reward / baseline statistics the step reports; the advantage above stays per study, as in the reference (gt_prompt.py:129-132)
-        glob = dp.gather_scst_statistics(sampled, base[:, P:].contiguous(), reward, baseline, pad)
+        host = None
+        if reward_on_host:
+            host = _host_copies([seqs.contiguous(), base.contiguous()])
 
-        # ---- REINFORCE through one teacher-forced pass
+        # ---- REINFORCE through one teacher-forced pass: the forward needs no reward, so it is queued first
         opt.zero_grad()
         n_new = sampled.shape[1]
         tf_in = seqs[:, : P + n_new - 1].contiguous()
@@ -66,6 +90,19 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         enc_mask = eo.attention_mask.to(torch.uint8).contiguous()
         # train mode: the same dropout seed as the cached sampling decode -> the re-scored network IS the one that sampled
         logits, saved = model._dec.forward(tf_in, enc.contiguous(), enc_mask, mask, tt, pos, save=True, seed=rec.get("seed"))
+
+        if reward_on_host:
+            (seqs_h, base_h), done = host
+            done.synchronize()                                               # only the decode had to finish; the forward above keeps the GPU busy
+            reward = reward_fn(seqs_h)
+            baseline = reward_fn(base_h)
+        else:
+            reward = reward_fn(sampled)
+            baseline = reward_fn(base[:, P:].contiguous())
+        adv = (reward - baseline).float().contiguous()
+        # data parallel: the sampled / greedy sequences and their rewards of ALL ranks (RCCL all-gather over xGMI, <= 64 KB per rank) for the
+        # global reward / baseline statistics the step reports; the advantage above stays per study, as in the reference (gt_prompt.py:129-132)
+        glob = dp.gather_scst_statistics(sampled, base[:, P:].contiguous(), reward, baseline, pad)
         B, T, V = logits.shape
         sc = logits[:, P - 1:, :]                                            # scores of the n_new sampling steps
         if float(temperature) != 1.0:

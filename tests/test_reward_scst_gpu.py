@@ -216,3 +216,42 @@ def test_fused_sample_and_greedy_decode(cuda):
     out = scst_step(m, opt, lambda ids: ((ids % 5).float().mean(1) / 5.0), x.cuda(), prompt.cuda(), None,
                     dict(bos=gu.BOS, eos=gu.EOS, sep=gu.SEP, pad=gu.PAD, pmt_sep=gu.PMT_SEP), decoder_max_len=10, fused_decode=False)
     assert np.isfinite(out["loss"].item())
+
+
+def test_scst_step_through_real_strings(cuda):
+    """The reference's reward path inside scst_step (gt_prompt.py:90-91,120-128,192-197): ids -> findings / impression strings -> CXR-BERT
+    tokenizer -> reward, on pinned host copies taken while the re-scoring forward already runs. The rewards it reports equal ReportReward
+    applied to the sequences it returns; the label embeddings are computed once."""
+    import os
+    import transformers
+    from cxrmate_amd import modelling
+    from cxrmate_amd.reward import CXRBERTReward, ReportReward
+    from cxrmate_amd.scst import scst_step
+    from cxrmate_amd.training import FusedAdamW
+    g, cfg, sd, x, prompt = gu.generate_longitudinal_case()
+    m = modelling.LongitudinalPromptMultiCXREncoderDecoderModel(cfg, device=cuda, seed=None)
+    m.load_state_dict(sd)
+    for p in m.decoder.parameters():
+        p.requires_grad_(True)
+    opt = FusedAdamW(m, lr=1e-3)
+    tok = transformers.PreTrainedTokenizerFast(tokenizer_file=os.path.join(gu.GOLDEN, "tokenizer.json"), unk_token="[UNK]", pad_token="[PAD]",
+                                               cls_token="[BOS]", sep_token="[SEP]", mask_token="[MASK]", bos_token="[BOS]", eos_token="[EOS]")
+    rcfg = gu.BertConfig(vocab_size=600, num_hidden_layers=2, is_decoder=False, add_cross_attention=False, cls_projection_size=128)
+    reward = CXRBERTReward(cuda, tokenizer=tok, config=rcfg)
+    labels = [["The lungs are clear. No acute cardiopulmonary process."], ["Mild cardiomegaly is stable. Small left pleural effusion."]]
+    rfn = ReportReward(m, tok, reward, labels, gu.BOS, gu.SEP, gu.EOS)
+    n_label_embeds = []
+    orig = reward._encode
+    reward._encode = lambda texts: (n_label_embeds.append(len(texts)), orig(texts))[1]
+    special = dict(bos=gu.BOS, eos=gu.EOS, sep=gu.SEP, pad=gu.PAD, pmt_sep=gu.PMT_SEP)
+    torch.manual_seed(3)
+    out = scst_step(m, opt, rfn, x.cuda(), prompt.cuda(), None, special, decoder_max_len=10, reward_on_host=True)
+    torch.cuda.synchronize()
+    assert np.isfinite(out["loss"].item())
+    assert len(n_label_embeds) == 3                              # sampled predictions, labels (once), greedy predictions
+    P = prompt.shape[1]
+    full_s = torch.cat([prompt, out["sampled"].cpu()], 1)
+    want_r = rfn(full_s).float().cpu().numpy()
+    want_b = rfn(out["baseline_ids"].cpu()).float().cpu().numpy()
+    np.testing.assert_allclose(out["global"]["reward"].cpu().numpy(), want_r, atol=1e-5)
+    np.testing.assert_allclose(out["global"]["baseline"].cpu().numpy(), want_b, atol=1e-5)
