@@ -40,7 +40,30 @@ def chexbert_param_shapes(cfg: BertConfig):
 
 
 class CheXbert:
-    def __init__(self, device, tokenizer=None, config: BertConfig | None = None, state_dict=None, seed: int = 2):
+    def __init__(self, *args, device=None, tokenizer=None, config: BertConfig | None = None, state_dict=None, seed: int = 2, p: float = 0.1,
+                 ckpt_dir=None, bert_path=None, checkpoint_path=None):
+        """Two call forms:
+          * the reference's `CheXbert(ckpt_dir, bert_path, checkpoint_path, device, p=0.1)` (tools/chexbert.py:10): tokenizer from the LOCAL
+            directory `bert_path` (BertTokenizer files of bert-base-uncased), weights from `os.path.join(ckpt_dir, checkpoint_path)`
+            (`['model_state_dict']`, a missing file raises the reference's ValueError);
+          * `CheXbert(device, tokenizer=..., state_dict=...)` / `CheXbert(device)` (seeded random init) for tests and benchmarks."""
+        import os
+        if len(args) == 4:
+            ckpt_dir, bert_path, checkpoint_path, device = args
+        elif len(args) == 1:
+            device = args[0]
+        elif args:
+            raise TypeError("CheXbert(ckpt_dir, bert_path, checkpoint_path, device, p=0.1) or CheXbert(device, tokenizer=..., state_dict=...)")
+        if checkpoint_path is not None and state_dict is None:
+            ckpt_path = os.path.join(ckpt_dir, checkpoint_path)
+            if not os.path.isfile(ckpt_path):
+                raise ValueError(f'The CheXbert checkpoint does not exist at {ckpt_dir}, please download it from: '
+                                 'https://github.com/stanfordmlgroup/CheXbert#checkpoint-download.')
+            state_dict = torch.load(ckpt_path, map_location="cpu")["model_state_dict"]
+        if bert_path is not None and tokenizer is None:
+            import transformers
+            tokenizer = transformers.BertTokenizer.from_pretrained(bert_path, cache_dir=ckpt_dir)
+        self.ckpt_dir = ckpt_dir
         self.device = torch.device(device)
         self.config = config or chexbert_config()
         self.tokenizer = tokenizer

@@ -95,6 +95,42 @@ class EncoderDecoderConfig:
         return asdict(self)
 
 
+def _get(obj, name, default):
+    if isinstance(obj, dict):
+        return obj.get(name, default)
+    return getattr(obj, name, default)
+
+
+def from_hf_config(config) -> "EncoderDecoderConfig":
+    """An EncoderDecoderConfig from whatever the reference hands its model classes: an HF `VisionEncoderDecoderConfig` (duck-typed: anything
+    with `.encoder` / `.decoder` sub-configs, or their dicts), as built by the Lightning modules (reference modules/lightning_modules/
+    single.py:205-216: BertConfig(vocab_size, num_hidden_layers, type_vocab_size) + CvtWithProjectionHeadConfig(projection_size) on the
+    'microsoft/cvt-21-384-22k' defaults). Fields this build does not vary must hold the values it is instantiated for."""
+    if isinstance(config, EncoderDecoderConfig):
+        return config
+    enc, dec = _get(config, "encoder", None), _get(config, "decoder", None)
+    if enc is None or dec is None:
+        raise ValueError(f"Config: {config} has to be of type {EncoderDecoderConfig} (or an HF VisionEncoderDecoderConfig)")
+    ours_e, ours_d = CvtConfig(), BertConfig()
+    e = CvtConfig(**{f: (tuple(v) if isinstance(v, (list, tuple)) else v)
+                     for f in ("num_channels", "patch_sizes", "patch_stride", "patch_padding", "embed_dim", "num_heads", "depth", "mlp_ratio",
+                               "cls_token", "kernel_qkv", "padding_kv", "stride_kv", "padding_q", "stride_q", "initializer_range", "layer_norm_eps",
+                               "drop_path_rate", "projection_size")
+                     for v in [_get(enc, f, getattr(ours_e, f))]})
+    e.image_size = int(_get(enc, "image_size", ours_e.image_size) or ours_e.image_size)
+    d = BertConfig(**{f: _get(dec, f, getattr(ours_d, f))
+                      for f in ("vocab_size", "hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size", "max_position_embeddings",
+                                "type_vocab_size", "layer_norm_eps", "pad_token_id", "initializer_range", "hidden_dropout_prob",
+                                "attention_probs_dropout_prob")})
+    d.is_decoder = bool(_get(dec, "is_decoder", True))
+    d.add_cross_attention = bool(_get(dec, "add_cross_attention", True))
+    if _get(dec, "hidden_act", "gelu") != "gelu" or _get(dec, "position_embedding_type", "absolute") != "absolute":
+        raise ValueError("only BERT with GELU and absolute position embeddings is implemented (the reference's decoder)")
+    if d.hidden_size != 768 or d.num_attention_heads * 64 != d.hidden_size or any(c % 64 for c in e.embed_dim):
+        raise ValueError("the MI355X kernels are instantiated for head_dim 64 (CvT-13/21, BERT-base widths)")
+    return EncoderDecoderConfig(encoder=e, decoder=d)
+
+
 def reward_config() -> BertConfig:
     """CXR-BERT-specialized stand-in: BERT-base, vocab 30522, CLS projection 128 (assumption)."""
     return BertConfig(vocab_size=30522, num_hidden_layers=12, is_decoder=False, add_cross_attention=False,

@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import ops, weights
-from .config import EncoderDecoderConfig
+from .config import EncoderDecoderConfig, from_hf_config
 from .decoder import BertEngine
 from .encoder import CvtEncoderEngine
 from .generation import GenerationMixin
@@ -118,11 +118,15 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
     kind = "single"
     main_input_name = "pixel_values"
 
-    def __init__(self, config: Optional[EncoderDecoderConfig] = None, device="cuda", seed: Optional[int] = 0, perturb: float = 0.0):
-        if config is None:
+    def __init__(self, config=None, encoder=None, decoder=None, device="cuda", seed: Optional[int] = 0, perturb: float = 0.0):
+        """config: this build's EncoderDecoderConfig, or the HF `VisionEncoderDecoderConfig` the reference's Lightning modules construct
+        (modules/lightning_modules/single.py:205-216) -- duck-typed, no transformers import. `encoder` / `decoder` modules (the reference's
+        second constructor form, modelling_single.py:88-95) contribute their `.config`; their WEIGHTS arrive through load_state_dict()."""
+        if config is None and (encoder is None or decoder is None):
             raise ValueError("Either a configuration or an encoder and a decoder has to be provided.")
-        if not isinstance(config, EncoderDecoderConfig):
-            raise ValueError(f"Config: {config} has to be of type {EncoderDecoderConfig}")
+        if config is None:
+            config = {"encoder": encoder.config, "decoder": decoder.config}
+        config = from_hf_config(config)
         assert config.decoder.add_cross_attention, '"add_cross_attention" must be True for the given decoder'
         assert config.decoder.is_decoder, '"is_decoder" must be True for the given decoder'
         shapes = weights.encoder_decoder_param_shapes(config)
@@ -254,10 +258,14 @@ class LongitudinalPromptMultiCXREncoderDecoderModel(_CXREncoderDecoderBase):
     """Frozen encoder, LoRA (r=8, alpha=32) on decoder self-attention query/key (modelling_longitudinal.py:158-171)."""
     kind = "longitudinal"
 
-    def __init__(self, config=None, device="cuda", seed=0, perturb=0.0):
-        if config is not None and not config.decoder.lora_r:
-            config.decoder.lora_r = 8
-        super().__init__(config, device, seed, perturb)
+    def __init__(self, config=None, encoder=None, decoder=None, device="cuda", seed=0, perturb=0.0):
+        if config is not None:
+            config = from_hf_config(config)
+            if not config.decoder.lora_r:
+                config.decoder.lora_r = 8                         # peft LoraConfig(r=8, lora_alpha=32, lora_dropout=0.1) of modelling_longitudinal.py:163-170
+        super().__init__(config, encoder, decoder, device=device, seed=seed, perturb=perturb)
+        if not self.config.decoder.lora_r:
+            raise ValueError("the longitudinal model wraps the decoder's self-attention query / key in LoRA: pass a configuration")
         self.decoder.print_trainable_parameters()
 
     def _initially_trainable(self, key):

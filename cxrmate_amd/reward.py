@@ -18,10 +18,43 @@ from .decoder import BertEngine
 from .store import ParamStore
 
 
+def load_cxr_bert_checkpoint(path):
+    """(tokenizer, state_dict) of a LOCAL copy of `microsoft/BiomedVLP-CXR-BERT-specialized` (what the reference's AutoModel / AutoTokenizer
+    .from_pretrained(ckpt_name, cache_dir=...) pull from the Hub, tools/rewards/cxrbert.py:15-17). Expected files: the tokenizer files
+    (vocab.txt / tokenizer.json ...) and `model.safetensors` or `pytorch_model.bin` with the HF key names
+        bert.embeddings.{word,position,token_type}_embeddings.weight, bert.embeddings.LayerNorm.{weight,bias},
+        bert.encoder.layer.{0..11}.attention.self.{query,key,value}.{weight,bias}, ...attention.output.{dense,LayerNorm}.{weight,bias},
+        ...intermediate.dense.{weight,bias}, ...output.{dense,LayerNorm}.{weight,bias},
+        cls_projection_head.dense_to_hidden.{weight,bias}, cls_projection_head.LayerNorm.{weight,bias}, cls_projection_head.dense_to_output.{weight,bias}
+    (the MLM head `cls.predictions.*` is ignored: its output is discarded by the reference, quirk Q10). The projection-head layout is the
+    stand-in assumption of SURVEY.md 8c: a checkpoint whose head has other key names fails load_state_dict loudly."""
+    import os
+    import transformers
+    tok = transformers.AutoTokenizer.from_pretrained(path, trust_remote_code=False)
+    st = os.path.join(path, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        sd = load_file(st)
+    else:
+        sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
+    keep = {k: v.float() for k, v in sd.items() if (k.startswith("bert.") or k.startswith("cls_projection_head.")) and "position_ids" not in k
+            and not k.startswith("bert.pooler.")}
+    return tok, keep
+
+
 class CXRBERTReward:
-    def __init__(self, device, tokenizer=None, config: BertConfig | None = None, state_dict=None, seed: int = 1, max_cache: int = 64):
+    def __init__(self, device, tokenizer=None, config: BertConfig | None = None, state_dict=None, seed: int = 1, max_cache: int = 64,
+                 ckpt_dir: str | None = None):
+        """`CXRBERTReward(device)` is the reference's signature (tools/rewards/cxrbert.py:11). The weights / tokenizer come from, in order:
+        the `tokenizer=` / `state_dict=` arguments; a local checkpoint directory `ckpt_dir=` or $CXR_BERT_DIR (load_cxr_bert_checkpoint);
+        otherwise the seeded random-init stand-in without tokenizer (id-level entry points only: there is no Hub access here)."""
+        import os
         self.device = torch.device(device)
         self.config = config or reward_config()
+        ckpt_dir = ckpt_dir or os.environ.get("CXR_BERT_DIR")
+        if ckpt_dir and tokenizer is None and state_dict is None:
+            tokenizer, state_dict = load_cxr_bert_checkpoint(ckpt_dir)
+            self.config.vocab_size = int(state_dict["bert.embeddings.word_embeddings.weight"].shape[0])
         self.tokenizer = tokenizer
         self.model = ParamStore(weights.bert_param_shapes(self.config, prefix=""), {}, self.device, trainable=lambda k: False)
         self.model.load_state_dict(state_dict if state_dict is not None else weights.init_reward(self.config, seed=seed))

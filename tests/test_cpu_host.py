@@ -190,3 +190,36 @@ def test_cxr_bert_metric_host_logic(tmp_path):
     with pytest.raises(RuntimeError):
         m.compute(epoch=0)
     assert (tmp_path / "cxr_bert").is_dir()
+
+
+def test_model_constructor_accepts_the_reference_hf_config():
+    """The Lightning modules build the model as `SingleCXREncoderDecoderModel(config=VisionEncoderDecoderConfig...)` (reference
+    modules/lightning_modules/single.py:205-216): the drop-in class takes that object as is (duck-typed), and keeps the reference's errors."""
+    transformers = pytest.importorskip("transformers")
+    from cxrmate_amd import modelling
+    dec = transformers.BertConfig(vocab_size=128, num_hidden_layers=2, type_vocab_size=2)
+    dec.is_decoder, dec.add_cross_attention = True, True
+    enc = transformers.CvtConfig(depth=[1, 2, 3])                 # reference: CvtWithProjectionHeadConfig(projection_size=...) subclass of this
+    enc.projection_size = dec.hidden_size
+    hf = transformers.VisionEncoderDecoderConfig.from_encoder_decoder_configs(enc, dec)
+    m = modelling.MultiCXREncoderDecoderModel(config=hf, device="cpu", seed=0)
+    assert m.config.decoder.vocab_size == 128 and m.config.decoder.num_hidden_layers == 2 and tuple(m.config.encoder.depth) == (1, 2, 3)
+    assert m.config.encoder.embed_dim == (64, 192, 384) and m.config.encoder.drop_path_rate == (0.0, 0.0, 0.1)
+    assert sum(p.numel() for p in m.parameters()) == sum(p.numel() for p in modelling.MultiCXREncoderDecoderModel(
+        gu.tiny_config(vocab_size=128, decoder_layers=2, image_size=224), device="cpu", seed=0).parameters())
+    ml = modelling.LongitudinalPromptMultiCXREncoderDecoderModel(config=hf, device="cpu", seed=0)
+    assert sum(p.numel() for p in ml.parameters() if p.requires_grad) == 2 * 2 * 2 * 8 * 768
+    with pytest.raises(ValueError, match="Either a configuration or an encoder and a decoder has to be provided"):
+        modelling.SingleCXREncoderDecoderModel(device="cpu")
+    bad = gu.tiny_config(vocab_size=128, decoder_layers=2)
+    bad.decoder.add_cross_attention = False                      # (HF's from_encoder_decoder_configs forces the flag on: our own config class here)
+    with pytest.raises(AssertionError, match="add_cross_attention"):
+        modelling.SingleCXREncoderDecoderModel(config=bad, device="cpu", seed=0)
+
+
+def test_reward_and_chexbert_constructors_follow_the_reference_signatures(tmp_path):
+    from cxrmate_amd.chexbert import CheXbert
+    with pytest.raises(ValueError, match="The CheXbert checkpoint does not exist"):
+        CheXbert(str(tmp_path), str(tmp_path), "chexbert.pth", "cpu")           # tools/chexbert.py:10,34-35
+    with pytest.raises(TypeError):
+        CheXbert("a", "b", "cpu")
