@@ -193,6 +193,47 @@ def scst_bench(args, rank, world, dev, steps):
                          "profile": "profiles/r02_scst_decode_v1_kernel_stats.csv (rocprofv3 --kernel-trace of scripts/scst_decode_profile.py)"}}
 
 
+def beam_bench(args, dev, host_loop_too=True):
+    """BASELINE.json configs[2] (test-set generation, the reference's evaluation path): 8 studies x 2 images, beam 4, up to 256 tokens, no EOS
+    (all steps run: deterministic work). Device-side beam search: 32 beam-major rows on the cached-step kernels, the beams of a study sharing its
+    cross-attention K/V, bookkeeping + cache reorder as two launches per token, steps replayed from hipGraphs. The encoder forward is inside the
+    timed region, as in the reference's test_step."""
+    from cxrmate_amd.config import EncoderDecoderConfig
+    from cxrmate_amd.modelling import MultiCXREncoderDecoderModel
+    cfg = EncoderDecoderConfig()
+    B, N, L, nb = 8, 2, 256, 4
+    model = MultiCXREncoderDecoderModel(cfg, device=dev, seed=0)
+    model.eval()
+    g = torch.Generator().manual_seed(3000)
+    images = torch.randn(B, N, 3, 384, 384, generator=g).to(dev)
+
+    def run():
+        return model.generate(pixel_values=images, special_token_ids=[3], max_length=L, bos_token_id=1, eos_token_id=None, pad_token_id=4,
+                              num_beams=nb, return_dict_in_generate=True, use_cache=True, output_scores=True)
+
+    def clock(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            o = run()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps, o
+
+    run(); run()                                                   # captures the step graphs
+    dt, o = clock(3)
+    res = {"metric": "beam_generation_studies_per_sec", "value": B / dt, "unit": "studies/s", "ms_per_batch": dt * 1e3,
+           "generated_tokens_per_sec": B * (L - 1) / dt, "us_per_token_step": dt * 1e6 / (L - 1),
+           "workload": "BASELINE.json configs[2]: cxrmate-multi-tf generate(num_beams=4, max_length=256), 8 studies x 2 images per batch, encoder "
+                       "included, EOS disabled (255 steps always run)", "mean_sequence_score": float(o["sequences_scores"].mean())}
+    if host_loop_too:                                              # the library-style host loop on the same kernels (A/B: what device-side bookkeeping buys)
+        model.device_beam_search = False
+        run()
+        dt_h, _ = clock(1)
+        model.device_beam_search = True
+        res["host_loop_ms_per_batch"] = dt_h * 1e3
+    return res
+
+
 class _InVocabTokenizer:
     """The synthetic byte-BPE tokenizer of tests/golden (400 entries, reference id layout) in front of a random-init model that emits ids up to
     30000: ids are folded into the vocabulary before decoding so that every generated token becomes text."""
@@ -423,6 +464,11 @@ def main():
             if world > 1:
                 raise
             out["scst"] = {"metric": "scst_steps_per_sec", "value": None, "error": str(e)}
+    if world == 1 and not args.no_extras:
+        try:
+            out["beam_generation"] = beam_bench(args, dev)
+        except Exception as e:
+            out["beam_generation"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(T, V, N)

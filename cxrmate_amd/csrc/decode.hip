@@ -72,6 +72,276 @@ extern "C" int cxr_topk_rows(const float* x, long ld, long R, int n, int K, floa
     return CXR_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Device-side beam search (reference: generate(num_beams=4) -> TF5 generation/utils.py:3208-3560 `_beam_search`, do_sample=False,
+// early_stopping=False, one EOS id, num_return_sequences=1). One launch per decode step does what the host loop of the library does with
+// ~40 small tensor ops and two host synchronisations: log-softmax of the study's beams + running scores, the 2*beams best continuations,
+// the split into running / finished beams, the merge into the finished set, the improvement test, and the row indices the KV cache is
+// reordered by. Rows are BEAM-MAJOR (row = beam * B + study): the beams of a study then share its cross-attention K/V in the decode
+// attention kernel (G queries per K/V stream). State buffers are updated in place (every column of a study is owned by one thread);
+// the stop flags are double-buffered by step parity because workgroups of one launch read each other's flags of the previous step.
+// After the search has stopped (no study can improve, or every candidate hit the length limit) later launches leave the state alone,
+// which lets the host poll the flags asynchronously every few steps instead of synchronising per token.
+struct BeamArgs {
+    const float* logits; long ld;          // fp32 [beams*B, V], raw
+    long* running; long* sequences;        // int64 [beams, B, L]
+    float* run_scores; float* beam_scores; // fp32 [B, beams]
+    unsigned char* finished;               // [B, beams]
+    int* unsat; int* allhit;               // [2, B] each, indexed by step parity
+    long* beam_idx;                        // int64 [beams*B]: the cache rows of the new running beams
+    float* ws;                             // scan results: per (row, chunk) max, sum of exp, 2*beams best raw logits and their token ids
+    int B, nb, V, L, cur, max_length, par, nch;
+    long eos;
+    float div;                             // (cur + 1 - prompt_len) ^ length_penalty
+};
+constexpr int BEAM_CHUNK = 4096;           // vocabulary entries per scan workgroup (16 per thread, held in registers)
+
+__device__ __forceinline__ bool beam_stopped(const BeamArgs& a) {
+    const int* unsat_prev = a.unsat + (a.par ^ 1) * a.B; const int* hit_prev = a.allhit + (a.par ^ 1) * a.B;
+    int any_unsat = 0, all_hit = 1;
+    for (int i = 0; i < a.B; ++i) { any_unsat |= unsat_prev[i]; all_hit &= hit_prev[i]; }
+    return !(any_unsat && !all_hit);
+}
+
+// Scan: workgroup (chunk, row) reduces its slice of the row's logits to (max, sum exp(x - max)) and its K2 largest entries (descending, ties ->
+// lowest token id). Within a row the order of the raw logits IS the order of the log-probabilities, so the study's 2*beams best continuations
+// are among the per-row top 2*beams: the step kernel below only looks at beams * chunks * K2 candidates.
+template <int K2>
+__global__ __launch_bounds__(256) void beam_scan_kernel(const BeamArgs a) {
+    __shared__ float shv[4]; __shared__ int shi[4]; __shared__ float shs[4];
+    const int c = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
+    const int len = (a.V + a.nch - 1) / a.nch, lo = c * len, hi = min(a.V, lo + len);
+    const float* x = a.logits + (long)row * a.ld;
+    float v[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = lo + tid + 256 * j;
+        const float t = x[i < hi ? i : hi - 1];
+        v[j] = i < hi ? t : -INFINITY;
+        mx = fmaxf(mx, v[j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) shv[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(shv[0], shv[1]), fmaxf(shv[2], shv[3]));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sum += __expf(v[j] - mx);              // exp(-inf) = 0 for the padding
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((tid & 63) == 0) shs[tid >> 6] = sum;
+    __syncthreads();
+    float* out = a.ws + ((long)row * a.nch + c) * (2 + 2 * K2);
+    if (tid == 0) { out[0] = mx; out[1] = shs[0] + shs[1] + shs[2] + shs[3]; }
+    for (int k = 0; k < K2; ++k) {
+        float best = -INFINITY; int bj = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (v[j] > best) { best = v[j]; bj = j; }        // ascending j = ascending token id: first maximum wins
+        int bi = lo + tid + 256 * bj;
+        const int mine = bi;
+        if (!(best > -INFINITY)) bi = 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { shv[tid >> 6] = best; shi[tid >> 6] = bi; }
+        __syncthreads();
+        best = shv[0]; bi = shi[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) if (shv[w] > best || (shv[w] == best && shi[w] < bi)) { best = shv[w]; bi = shi[w]; }
+        if (bi == mine) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (j == bj) v[j] = -INFINITY;                // taken
+        }
+        if (tid == 0) { out[2 + k] = best; reinterpret_cast<int*>(out)[2 + K2 + k] = bi == 0x7fffffff ? lo : bi; }
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void beam_step_kernel(const BeamArgs a) {
+    constexpr int K2 = 2 * NB;
+    constexpr int MAXC = NB * 32 * K2;                                    // candidates: beams x chunks (<= 32) x K2
+    __shared__ float shv[4]; __shared__ int shi[4];
+    __shared__ float off[NB];
+    __shared__ float cand[MAXC]; __shared__ int cidx[MAXC];               // log-prob + running score, flat index beam * V + token
+    __shared__ float c_lp[K2]; __shared__ int c_idx[K2];
+    __shared__ int s_parent[NB], s_tok[NB], s_src[NB], s_stop;
+    __shared__ int c_beam[K2], c_tok[K2];
+    const int b = blockIdx.x, tid = threadIdx.x, B = a.B, V = a.V, nch = a.nch;
+    const int* unsat_prev = a.unsat + (a.par ^ 1) * B; const int* hit_prev = a.allhit + (a.par ^ 1) * B;
+    int* unsat_new = a.unsat + a.par * B; int* hit_new = a.allhit + a.par * B;
+    if (tid == 0) s_stop = beam_stopped(a);
+    __syncthreads();
+    if (s_stop) {                           // frozen: identity reorder, flags carried over
+        if (tid < NB) a.beam_idx[tid * B + b] = tid * B + b;
+        if (tid == 0) { unsat_new[b] = unsat_prev[b]; hit_new[b] = hit_prev[b]; }
+        return;
+    }
+    // ---- log-softmax offsets of the study's beams from the chunk partials: lp = x - (max + log(sum exp(x - max)) - running score)
+    if (tid < NB) {
+        const float* pr = a.ws + (long)(tid * B + b) * nch * (2 + 2 * K2);
+        float mx = -INFINITY;
+        for (int c = 0; c < nch; ++c) mx = fmaxf(mx, pr[c * (2 + 2 * K2)]);
+        float t = 0.f;
+        for (int c = 0; c < nch; ++c) t += pr[c * (2 + 2 * K2) + 1] * __expf(pr[c * (2 + 2 * K2)] - mx);
+        off[tid] = mx + __logf(t) - a.run_scores[b * NB + tid];
+    }
+    __syncthreads();
+    const int ncand = NB * nch * K2;
+    for (int i = tid; i < ncand; i += 256) {
+        const int g = i / (nch * K2), r = i % (nch * K2), c = r / K2, k = r % K2;
+        const float* pr = a.ws + ((long)(g * B + b) * nch + c) * (2 + 2 * K2);
+        cand[i] = pr[2 + k] - off[g];
+        cidx[i] = g * V + reinterpret_cast<const int*>(pr)[2 + K2 + k];
+    }
+    __syncthreads();
+    // ---- the 2*beams best continuations, descending, ties -> lowest flat index (beam * V + token)
+    float prev = INFINITY; int prev_i = -1;
+    for (int k = 0; k < K2; ++k) {
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int i = tid; i < ncand; i += 256) {
+            const float x = cand[i]; const int fi = cidx[i];
+            const bool ok = (x < prev) || (x == prev && fi > prev_i);
+            if (ok && (x > best || (x == best && fi < bi))) { best = x; bi = fi; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { shv[tid >> 6] = best; shi[tid >> 6] = bi; }
+        __syncthreads();
+        best = shv[0]; bi = shi[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) if (shv[w] > best || (shv[w] == best && shi[w] < bi)) { best = shv[w]; bi = shi[w]; }
+        prev = best; prev_i = bi;
+        if (tid == 0) { c_lp[k] = best; c_idx[k] = bi == 0x7fffffff ? 0 : bi; }       // (all-NaN rows: keep the indices in range)
+    }
+    __syncthreads();
+    // ---- bookkeeping of the step (a few dozen scalar operations)
+    if (tid == 0) {
+        const float NEG = -1.0e9f;
+        float run_lp[K2], fin_lp[K2]; bool hits[K2]; bool all_hits = true;
+        const bool unsat = unsat_prev[b] != 0;
+        for (int j = 0; j < K2; ++j) {
+            c_beam[j] = c_idx[j] / V; c_tok[j] = c_idx[j] % V;
+            hits[j] = (c_tok[j] == (int)a.eos) || (a.cur + 1 >= a.max_length);
+            all_hits = all_hits && hits[j];
+            run_lp[j] = c_lp[j] + (hits[j] ? NEG : -0.0f);
+            const bool just = hits[j] && j < NB;
+            fin_lp[j] = c_lp[j] / a.div;
+            fin_lp[j] = fin_lp[j] + (unsat ? -0.0f : NEG);
+            fin_lp[j] = fin_lp[j] + (just ? -0.0f : NEG);
+        }
+        // the beams that keep running: the `beams` best continuations that did not end (stable: lowest candidate first among ties)
+        unsigned taken = 0; float new_run[NB];
+        for (int i = 0; i < NB; ++i) {
+            int bj = -1;
+            for (int j = 0; j < K2; ++j) if (!((taken >> j) & 1) && (bj < 0 || run_lp[j] > run_lp[bj])) bj = j;
+            taken |= 1u << bj;
+            s_parent[i] = c_beam[bj]; s_tok[i] = c_tok[bj]; new_run[i] = run_lp[bj];
+        }
+        // finished set: the `beams` best of (held finished beams, continuations that ended among the first `beams` candidates)
+        float m_sc[NB + K2]; bool m_fin[NB + K2];
+        for (int i = 0; i < NB; ++i) { m_sc[i] = a.beam_scores[b * NB + i]; m_fin[i] = a.finished[b * NB + i] != 0; }
+        for (int j = 0; j < K2; ++j) { m_sc[NB + j] = fin_lp[j]; m_fin[NB + j] = hits[j] && j < NB; }
+        unsigned tk = 0; float nsc[NB]; bool nfin[NB];
+        for (int i = 0; i < NB; ++i) {
+            int bj = -1;
+            for (int j = 0; j < NB + K2; ++j) if (!((tk >> j) & 1) && (bj < 0 || m_sc[j] > m_sc[bj])) bj = j;
+            tk |= 1u << bj;
+            s_src[i] = bj; nsc[i] = m_sc[bj]; nfin[i] = m_fin[bj];
+        }
+        float mn = nsc[0];
+        for (int i = 1; i < NB; ++i) mn = fminf(mn, nsc[i]);
+        const float best_run = new_run[0] / a.div;      // the library divides by (cur - prompt)^lp AFTER its cur += 1: the same number
+        bool improve = false;
+        for (int i = 0; i < NB; ++i) improve = improve || (best_run > (nfin[i] ? mn : NEG));
+        for (int i = 0; i < NB; ++i) {
+            a.run_scores[b * NB + i] = new_run[i]; a.beam_scores[b * NB + i] = nsc[i]; a.finished[b * NB + i] = nfin[i] ? 1 : 0;
+            a.beam_idx[i * B + b] = (long)s_parent[i] * B + b;
+        }
+        unsat_new[b] = (unsat && improve) ? 1 : 0;
+        hit_new[b] = all_hits ? 1 : 0;
+    }
+    __syncthreads();
+    // ---- token rows: column t of every beam of the study is read, then written, by one thread (in place)
+    for (int t = tid; t <= a.cur; t += 256) {
+        long oldr[NB], olds[NB];
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            oldr[g] = a.running[((long)g * B + b) * a.L + t];
+            olds[g] = a.sequences[((long)g * B + b) * a.L + t];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            long r = 0, q = 0;
+            const int par = s_parent[i], src = s_src[i];
+            const int cb = src >= NB ? c_beam[src - NB] : 0;
+#pragma unroll
+            for (int g = 0; g < NB; ++g) {
+                if (g == par) r = oldr[g];
+                if (src < NB ? g == src : g == cb) q = src < NB ? olds[g] : oldr[g];
+            }
+            if (t == a.cur) { r = s_tok[i]; if (src >= NB) q = c_tok[src - NB]; }
+            a.running[((long)i * B + b) * a.L + t] = r;
+            a.sequences[((long)i * B + b) * a.L + t] = q;
+        }
+    }
+}
+// div = (cur + 1 - prompt_len) ** length_penalty, evaluated in double by the caller as the library evaluates the Python power, rounded to
+// fp32 as its tensor division does. ws: beams*B * ceil(V / 4096) * (2 + 4*beams) floats.
+extern "C" int cxr_beam_step(const float* logits, long ld, long* running, long* sequences, float* run_scores, float* beam_scores,
+                             unsigned char* finished, int* unsat, int* allhit, long* beam_idx, float* ws, int B, int nb, int V, int L, int cur,
+                             int max_length, long eos, float div, hipStream_t stream) {
+    if (B <= 0 || V <= 0 || cur < 0 || cur >= L || (nb != 1 && nb != 2 && nb != 3 && nb != 4 && nb != 5 && nb != 8) || (long)nb * V >= (1L << 31) || !ws)
+        return CXR_ERR_ARG;
+    const int nch = cdiv(V, BEAM_CHUNK);
+    if (nch > 32) return CXR_ERR_ARG;
+    BeamArgs a{logits, ld, running, sequences, run_scores, beam_scores, finished, unsat, allhit, beam_idx, ws, B, nb, V, L, cur, max_length, cur & 1,
+               nch, eos, div};
+    const dim3 sg(nch, nb * B);
+#define BEAM_CASE(NB_) case NB_: CXR_LAUNCH(beam_scan_kernel<2 * NB_>, sg, dim3(256), 0, stream, a);                       \
+                                 CXR_LAUNCH(beam_step_kernel<NB_>, dim3(B), dim3(256), 0, stream, a); break
+    switch (nb) { BEAM_CASE(1); BEAM_CASE(2); BEAM_CASE(3); BEAM_CASE(4); BEAM_CASE(5); default: BEAM_CASE(8); }
+#undef BEAM_CASE
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// The KV-cache reorder of a beam step for ALL layers in one launch: out[i][r, :rows, :] = in[i][idx[r], :rows, :] for up to 16 tensors of
+// one geometry (blockIdx.y = tensor).
+struct GatherMulti { const bf16_t* in[16]; bf16_t* out[16]; };
+__global__ __launch_bounds__(256) void gather_multi_kernel(const GatherMulti g, long bs, long rs, const long* __restrict__ idx, int B, int rows,
+                                                           int C) {
+    const bf16_t* in = g.in[blockIdx.y]; bf16_t* out = g.out[blockIdx.y];
+    const int cch = C / 8;
+    const long total = (long)B * rows * cch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i % cch) * 8;
+        const long t = i / cch;
+        const int r = (int)(t % rows), b = (int)(t / rows);
+        *reinterpret_cast<uint4*>(out + (long)b * bs + (long)r * rs + c8) = *reinterpret_cast<const uint4*>(in + idx[b] * bs + (long)r * rs + c8);
+    }
+}
+extern "C" int cxr_gather_batch_multi_bf16(const void* const* in, void* const* out, int n, long bs, long rs, const long* idx, int B, int rows,
+                                           int C, hipStream_t stream) {
+    if (n <= 0 || n > 16 || B <= 0 || rows <= 0 || (C % 8)) return CXR_ERR_ARG;
+    GatherMulti g;
+    for (int i = 0; i < 16; ++i) { g.in[i] = (const bf16_t*)in[i < n ? i : 0]; g.out[i] = (bf16_t*)out[i < n ? i : 0]; }
+    const long total = (long)B * rows * (C / 8);
+    const int gx = (int)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
+    CXR_LAUNCH(gather_multi_kernel, dim3(gx, n), dim3(256), 0, stream, g, bs, rs, idx, B, rows, C);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Skinny GEMM for autoregressive decode: C[M,N] = epi(A[M,K] . W[N,K]^T), M <= 64 (B*beams rows, one token each).
 // Weight-streaming regime (cdna_hip_programming.md section 5, "GEMV / M <= 16 decode weights"): every W element is read exactly once
@@ -651,13 +921,13 @@ __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const float* __r
     if (live) O[o_mt ? dal_off(r / H, (r % H) * 64 + d, o_mt) : (long)(r / H) * o_bs + (r % H) * 64 + d] = f2bf(n_ / d_);
 }
 
-// B query rows; K, V (and kpm) have B / kv_share rows: query rows b and b + B/kv_share read K/V row b (kv_share = 1 or 2).
+// B query rows; K, V (and kpm) have B / kv_share rows: query rows b and b + B/kv_share read K/V row b (kv_share = 1, 2 or 4: the beams of a study).
 extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V, void* O, const void* kpm, long q_bs, long k_bs, long k_rs,
                                     long v_bs, long v_rs, long o_bs, long kpm_bs, int B, int H, int Tk, float scale, int kv_share, float* ws,
                                     long kv_hs, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t, int wg_keys,
                                     int o_dal, int kpm_bits, hipStream_t stream) {
     if (B <= 0 || H <= 0 || Tk <= 0 || Tk > 8192 || (k_rs % 8) || (v_rs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8)) return CXR_ERR_ARG;
-    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed) || (kv_share != 1 && kv_share != 2) || (B % kv_share)) return CXR_ERR_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed) || (kv_share != 1 && kv_share != 2 && kv_share != 4) || (B % kv_share)) return CXR_ERR_ARG;
     if (k_rs <= 0 || v_rs <= 0 || (long)Tk * k_rs >= (1L << 31) || (long)Tk * v_rs >= (1L << 31)) return CXR_ERR_ARG;      // 32-bit in-range offsets
     if (kpm_bits && (!kpm || (kpm_bs % 4) || ((uintptr_t)kpm % 4))) return CXR_ERR_ARG;
     const int Bkv = B / kv_share;
@@ -667,6 +937,7 @@ extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V,
     // negative wg_keys (or no ws): the workgroup loops.
     const bool no_split = wg_keys < 0;
     if (no_split) wg_keys = -wg_keys;
+    if (kv_share == 4) wg_keys = (Tk % 576 == 0) ? 576 : 288;     // 4 beams of a study on one K/V stream: the register budget of the two smaller geometries
     if (wg_keys == 0) wg_keys = (Tk % 576 == 0) ? (Tk == 1152 ? 1152 : 576) : 256;       // whole studies of 1 / 2 images in one pass; more: 576-key splits
     if (wg_keys != 256 && wg_keys != 288 && wg_keys != 576 && wg_keys != 1152) return CXR_ERR_ARG;
     int nsplit = 1, chunk = Tk;
@@ -689,10 +960,14 @@ extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V,
 #define ATTN_DEC_M(G_, KU_, NG_) do { if (mask == 0) ATTN_DEC_L(G_, KU_, NG_, 0); else if (mask == 1) ATTN_DEC_L(G_, KU_, NG_, 1);          \
                                       else if (mask == 3) ATTN_DEC_L(G_, KU_, NG_, 3); else ATTN_DEC_L(G_, 8, 32, 2); } while (0)
 #define ATTN_DEC_G(KU_, NG_) do { if (kv_share == 2) ATTN_DEC_M(2, KU_, NG_); else ATTN_DEC_M(1, KU_, NG_); } while (0)
-    if (wg_keys == 256) ATTN_DEC_G(8, 32);
+#define ATTN_DEC_M4(KU_, NG_) do { if (mask == 0) ATTN_DEC_L(4, KU_, NG_, 0); else if (mask == 1) ATTN_DEC_L(4, KU_, NG_, 1);                \
+                                   else ATTN_DEC_L(4, KU_, NG_, 3); } while (0)
+    if (kv_share == 4) { if (wg_keys == 288) ATTN_DEC_M4(9, 32); else ATTN_DEC_M4(9, 64); }
+    else if (wg_keys == 256) ATTN_DEC_G(8, 32);
     else if (wg_keys == 288) ATTN_DEC_G(9, 32);
     else if (wg_keys == 576) ATTN_DEC_G(9, 64);
     else ATTN_DEC_G(9, 128);
+#undef ATTN_DEC_M4
 #undef ATTN_DEC_G
 #undef ATTN_DEC_M
 #undef ATTN_DEC_L

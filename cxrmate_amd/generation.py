@@ -54,6 +54,34 @@ class DecodeSession:
         self.graphs = {}
         self.pool = None
         self.version = -1
+        self.beam = None                                   # device-side beam-search state (beam_state)
+        self._cache_home = (list(self.cache.k), list(self.cache.v), list(self.cache.k2), list(self.cache.v2))
+
+    def beam_state(self, nb, pad):
+        """State of a device-side beam search over this session's rows (BEAM-MAJOR: row = beam * studies + study, so the beams of a study
+        share its cross-attention K/V): `self.ids` viewed [nb, B, Lmax] holds the running beams; finished beams, scores and the stop flags
+        live here (csrc/decode.hip beam_step_kernel)."""
+        dev, B = self.ids.device, self.B // nb
+        if self.beam is None or self.beam["nb"] != nb:
+            self.beam = dict(nb=nb, sequences=torch.zeros((nb, B, self.Lmax), dtype=torch.int64, device=dev),
+                             run_scores=torch.zeros((B, nb), dtype=torch.float32, device=dev),
+                             beam_scores=torch.zeros((B, nb), dtype=torch.float32, device=dev),
+                             finished=torch.zeros((B, nb), dtype=torch.uint8, device=dev),
+                             unsat=torch.zeros((2, B), dtype=torch.int32, device=dev), allhit=torch.zeros((2, B), dtype=torch.int32, device=dev),
+                             beam_idx=torch.zeros(self.B, dtype=torch.int64, device=dev),
+                             ws=ops.beam_ws(self.B, self.model.config.decoder.vocab_size, nb, dev))
+        st = self.beam
+        st["run_scores"].fill_(-1.0e9); st["run_scores"][:, 0] = 0.0            # only beam 0 of the identical start rows may continue
+        st["beam_scores"].fill_(-1.0e9); st["finished"].zero_()
+        st["unsat"].fill_(1); st["allhit"].zero_()
+        st["sequences"].copy_(self.ids.view(nb, B, self.Lmax))
+        return st
+
+    def _swap_caches(self, n=1):
+        c = self.cache
+        if n % 2:
+            c.k, c.k2 = c.k2, c.k
+            c.v, c.v2 = c.v2, c.v
 
     def reset(self, ids0, enc16, enc_mask8):
         m = self.model
@@ -72,6 +100,7 @@ class DecodeSession:
         self.cache.enc_bits = self.enc_bits
         self.cache.len = 0
         self.cache.cross_ready = False
+        self.cache.k, self.cache.v, self.cache.k2, self.cache.v2 = (list(t) for t in self._cache_home)      # beam search ping-pongs them
         if m.training:
             self.seed.copy_(m.next_dropout_seed())
         self.u_all.uniform_()                      # torch's CUDA generator: reproducible under torch.manual_seed
@@ -99,8 +128,13 @@ class DecodeSession:
             self.cache.len = keep                      # capture does not execute: replay below performs the steps
             hit = (g, self.last_tt, self.last_pos)     # the last step's token-type / position outputs live in the session's history buffers
             self.graphs[key] = hit
+            captured = True
+        else:
+            captured = False
         g, self.last_tt, self.last_pos = hit
         g.replay()
+        if mode[0] == "beam" and not captured:         # the capture pass already walked the ping-pong of the reordered caches
+            self._swap_caches(n)
         self.cache.len = cur + n - 1 - strip
 
     def _run(self, cur, strip, mode, prefill):
@@ -130,6 +164,16 @@ class DecodeSession:
                 pos = self.pos1 if longi else None
         if new is not None:
             logits = m._dec.decode(self.cache, new, self.enc16, self.enc_mask8, mask, tt, pos, train=train, seed=self.seed)
+        if kind == "beam":                                          # one launch: scoring, candidate search, bookkeeping; one more: cache reorder
+            nb, penalty, (prompt_len, max_length) = top_k, temperature, top_p
+            st, c = self.beam, self.cache
+            ops.beam_step(logits, self.ids.view(nb, self.B // nb, self.Lmax), st["sequences"], st["run_scores"], st["beam_scores"], st["finished"],
+                          st["unsat"], st["allhit"], st["beam_idx"], cur, max_length, -1 if eos is None else eos,
+                          float(cur + 1 - prompt_len) ** penalty, ws=st["ws"])
+            ops.gather_batch_multi(c.k + c.v, st["beam_idx"], c.len, c.k2 + c.v2)
+            self._swap_caches()
+            self.last_tt = self.last_pos = None
+            return
         unf = self.unfinished if eos is not None else None
         eos_ = eos if eos is not None else -1
         n_smp = {"greedy": 0, "sample": self.B, "pair": self.B // 2}[kind]      # rows [0, n_smp) sample, the rest take the argmax
@@ -149,6 +193,7 @@ class DecodeSession:
 
 class GenerationMixin:
     graph_decode = True      # replay single-token decode steps from hipGraphs (DecodeSession)
+    device_beam_search = True   # beam search with device-side bookkeeping (False: the host-loop restatement `_beam_search`, kept as an A/B check)
 
     def _session(self, B, S, Lmax, has_mask, share=1):
         cache = self.__dict__.setdefault("_decode_sessions", {})
@@ -221,8 +266,9 @@ class GenerationMixin:
             if do_sample:
                 raise NotImplementedError("beam sampling is not used by the reference")
             with torch.no_grad():
-                seqs, seq_scores = self._beam_search(ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, num_beams,
-                                                     bos_token_id, eos_token_id, pad_token_id, length_penalty)
+                search = self._beam_search_session if (self.device_beam_search and num_beams in (2, 3, 4, 5, 8)) else self._beam_search
+                seqs, seq_scores = search(ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, num_beams,
+                                          bos_token_id, eos_token_id, pad_token_id, length_penalty)
             if return_dict_in_generate:
                 return ModelOutput(sequences=seqs, sequences_scores=seq_scores if output_scores else None)
             return seqs
@@ -407,6 +453,49 @@ class GenerationMixin:
         return tuple(sc[:, t, :] for t in range(sc.shape[1]))
 
     # ------------------------------------------------------------------------------------------ beam search
+    def _beam_search_session(self, ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, num_beams, bos, eos, pad, length_penalty):
+        """Beam search (TF5 generation/utils.py:3208-3560, do_sample=False, early_stopping=False, num_return_sequences=1) over a DecodeSession:
+        beams*B rows decoded by the cached-step kernels (the beams of a study share its cross-attention K/V: ONE copy of the encoder rows, as in
+        the SCST sample+greedy batch), the whole per-step bookkeeping in one kernel launch (ops.beam_step), the cache reorder in another, the
+        steps replayed from hipGraphs eight at a time, and the stop condition polled asynchronously every 8 steps (the stopped state is frozen
+        on the device, so overshoot steps change nothing). The host loop `_beam_search` does the same with ~40 tensor ops and two
+        synchronisations per token."""
+        B, prompt_len = ids.shape
+        nb = num_beams
+        pad = 0 if pad is None else pad
+        strip = 1 if (self.kind == "longitudinal" and bool(torch.all(ids[:, 0] == bos))) else 0
+        with torch.no_grad():
+            ses = self._session(B * nb, enc16.shape[1], max_length, enc_mask8 is not None, share=nb)
+            ses.reset(ids.repeat(nb, 1), enc16, enc_mask8)
+            ses.ids[:, prompt_len:] = pad
+            st = ses.beam_state(nb, pad)
+            mode = ("beam", tuple(special_token_ids), mask_token_id, nb, float(length_penalty), eos, pad, bool(self.training), (prompt_len, max_length))
+            cur = prompt_len
+            poll = None
+            while cur < max_length:
+                n = 1 if cur == prompt_len else min(8 - (cur - prompt_len) % 8, max_length - cur)
+                ses.step(cur, strip, mode, n)
+                cur += n
+                if (cur - prompt_len) % 8 == 0 and cur < max_length:
+                    if poll is not None:
+                        poll[1].synchronize()
+                        if int(poll[0][0]) == 0:
+                            break
+                    par = (cur - 1) & 1                                     # flags of the last executed step (column cur - 1)
+                    going = ((st["unsat"][par].max() > 0) & (st["allhit"][par].min() == 0)).to(torch.int32).reshape(1)
+                    ses.poll_host.copy_(going, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    poll = (ses.poll_host, ev)
+            out = st["sequences"][0].clone()
+            scores = st["beam_scores"][:, 0].clone()
+        if eos is None:
+            return out, scores
+        gen = out[:, prompt_len:]
+        is_eos = gen == eos
+        lens = torch.where(is_eos.any(1), is_eos.int().argmax(1) + 1, torch.full((B,), gen.shape[1], device=out.device))
+        return out[:, : prompt_len + int(lens.max())], scores
+
     def _beam_search(self, ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, num_beams, bos, eos, pad, length_penalty):
         """TF5 generation/utils.py:3208-3560 with do_sample=False, early_stopping=False, one EOS id, num_return_sequences=1."""
         dev = ids.device
@@ -446,7 +535,7 @@ class GenerationMixin:
             beam_of = topk_idx // V
             topk_seq = gather(running, beam_of)
             topk_seq[:, :, cur] = topk_idx % V
-            hits = (topk_seq[:, :, cur] == eos) | (cur + 1 >= max_length)
+            hits = (topk_seq[:, :, cur] == (-1 if eos is None else eos)) | (cur + 1 >= max_length)
             run_lp = topk_lp + hits.float() * -1.0e9
             nxt = torch.topk(run_lp, k=nb)[1]
             running, run_scores = gather(topk_seq, nxt), gather(run_lp, nxt)
@@ -467,6 +556,8 @@ class GenerationMixin:
             if not (bool(unsat.any()) and not bool(hits.all())):
                 break
         out = sequences[:, 0, :]
+        if eos is None:
+            return out, beam_scores[:, 0]
         gen = out[:, prompt_len:]
         is_eos = gen == eos
         lens = torch.where(is_eos.any(1), is_eos.int().argmax(1) + 1, torch.full((B,), gen.shape[1], device=dev))

@@ -875,6 +875,32 @@ def gather_batch(src, idx, rows, dst):
     return dst
 
 
+def gather_batch_multi(srcs, idx, rows, dsts):
+    """dsts[i][b, :rows] = srcs[i][idx[b], :rows] for up to 16 [B, Tmax, C] bf16 caches of one geometry, one launch."""
+    n = len(srcs)
+    B, _, C = dsts[0].shape
+    pin = (_ct.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    pout = (_ct.c_void_p * n)(*[d.data_ptr() for d in dsts])
+    LIB.call("cxr_gather_batch_multi_bf16", pin, pout, n, dsts[0].stride(0), dsts[0].stride(1), _p(idx), B, rows, C, _s())
+
+
+def beam_ws(rows, V, nb, device):
+    """Scan workspace of beam_step for `rows` = beams * studies rows over a vocabulary of V."""
+    return torch.empty(rows * ((V + 4095) // 4096) * (2 + 4 * nb), dtype=torch.float32, device=device)
+
+
+def beam_step(logits, running, sequences, run_scores, beam_scores, finished, unsat, allhit, beam_idx, cur, max_length, eos, div, ws=None):
+    """One device-side beam-search step (csrc/decode.hip beam_scan_kernel + beam_step_kernel; include/cxrmate_hip.h cxr_beam_step). Beam-major rows."""
+    nb, B, L = running.shape
+    R, V = logits.shape
+    assert R == nb * B and logits.dtype == torch.float32 and running.is_contiguous() and sequences.is_contiguous()
+    if ws is None:
+        ws = beam_ws(R, V, nb, logits.device)
+    assert ws.numel() >= R * ((V + 4095) // 4096) * (2 + 4 * nb)
+    LIB.call("cxr_beam_step", _p(logits), logits.stride(0), _p(running), _p(sequences), _p(run_scores), _p(beam_scores), _p(finished), _p(unsat),
+             _p(allhit), _p(beam_idx), _p(ws), B, nb, V, L, int(cur), int(max_length), int(eos), float(div), _s())
+
+
 def topk_rows(x, k):
     """x fp32 [R, n] -> (values [R,k], indices [R,k]) in descending order."""
     R, n = x.shape
@@ -935,7 +961,7 @@ def attention_decode(q, k, v, heads, scale, kpm=None, out=None, drop=None, head_
     b and b + B/2 share K/V row b."""
     B = q.shape[0]
     share = B // k.shape[0]
-    assert k.shape[0] * share == B and share in (1, 2)
+    assert k.shape[0] * share == B and share in (1, 2, 4)
     if head_major:                         # k, v [Bkv, H, Tk, 64] contiguous: every (b, h) K/V stream is one contiguous block
         Tk = k.shape[2]
         k_bs, k_rs, v_bs, v_rs, hs = k.stride(0), k.stride(2), v.stride(0), v.stride(2), k.stride(1)

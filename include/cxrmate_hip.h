@@ -300,6 +300,20 @@ int cxr_dec_from_dal_bf16(const void* x, int M, int K, void* out, long ldo, hipS
 int cxr_pack_mask_bits(const void* kpm, long kpm_bs, int B, int T, unsigned int* out, int words, hipStream_t stream);
                        /* key-padding bytes [B,T] (1 = attend) -> uint32 [B][words], bit k%32 of word k/32 */
 int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, long* inds, hipStream_t stream);
+/* One beam-search step of all studies in one launch (TF5:gen:3208-3560 `_beam_search`, do_sample=False, early_stopping=False, one EOS id):
+ * log-softmax + running scores, the 2*beams best continuations, running / finished split, merge into the finished set, improvement test,
+ * cache-reorder indices. Rows are beam-major (row = beam * B + study). logits fp32 [beams*B, V] raw; running / sequences int64 [beams,B,L];
+ * run_scores / beam_scores fp32 [B,beams]; finished u8 [B,beams]; unsat / allhit int32 [2,B] (double-buffered by the parity of `cur`; initial
+ * state: unsat = 1, allhit = 0 in both halves); beam_idx int64 [beams*B] out. div = (cur + 1 - prompt_len) ** length_penalty. Once no study
+ * can improve (or all candidates hit max_length) later launches leave the state unchanged and emit the identity reorder. Two kernels: a scan
+ * over (vocabulary chunk, row) workgroups -> ws (beams*B * ceil(V/4096) * (2 + 4*beams) floats), then one workgroup per study. */
+int cxr_beam_step(const float* logits, long ld, long* running, long* sequences, float* run_scores, float* beam_scores, unsigned char* finished,
+                  int* unsat, int* allhit, long* beam_idx, float* ws, int B, int nb, int V, int L, int cur, int max_length, long eos, float div,
+                  hipStream_t stream);
+/* out[i][r, :rows, :] = in[i][idx[r], :rows, :] for n <= 16 tensors [B, *, C] of one geometry (host arrays of device pointers): the KV-cache
+ * reorder of a beam step for all layers in one launch (TF5:gen:3468-3478) */
+int cxr_gather_batch_multi_bf16(const void* const* in, void* const* out, int n, long bs, long rs, const long* idx, int B, int rows, int C,
+                                hipStream_t stream);
 
 /* ---- input pipeline tail (next-row f3): ToTensor + Normalize + pad_sequence of the reference collate (REF:modules/lightning_modules/
  * single.py:248-262, multi.py:155-164). src: packed uint8 HWC images of all studies; first_image int64 [B+1] (prefix sums of images per

@@ -1101,3 +1101,85 @@ def test_top_p_threshold_and_sampling(ops):
         probs = torch.softmax(want[0][support.cpu()], -1)
         freq = torch.stack([(draws == i).float().mean() for i in support]).cpu()
         assert (freq - probs).abs().max().item() < 0.04
+
+
+def _beam_step_host(logits, st, cur, prompt_len, max_length, eos, penalty):
+    """One step of the library's beam search (TF5 generation/utils.py:3380-3520, do_sample=False, early_stopping=False) on study-major torch
+    tensors: the checker of the device-side kernel. st: running / sequences [B,nb,L], run_scores / beam_scores [B,nb], finished [B,nb] bool,
+    unsat [B,1] bool. Returns (new state, beam_idx [B,nb] parent beam, hits [B,2nb])."""
+    B, nb, L = st["running"].shape
+    V = logits.shape[-1]
+    lp = torch.log_softmax(logits.float().view(B, nb, V), -1) + st["run_scores"][:, :, None]
+    topk_lp, topk_idx = torch.topk(lp.view(B, nb * V), 2 * nb)
+    beam_of, tok = topk_idx // V, topk_idx % V
+    g = lambda t, i: torch.gather(t, 1, i.view(*i.shape, *([1] * (t.dim() - 2))).expand(-1, -1, *t.shape[2:]))
+    topk_seq = g(st["running"], beam_of).clone()
+    topk_seq[:, :, cur] = tok
+    hits = (tok == eos) | (cur + 1 >= max_length)
+    run_lp = topk_lp + hits.float() * -1.0e9
+    nxt = torch.topk(run_lp, nb)[1]
+    just = hits & (torch.arange(2 * nb, device=logits.device) < nb)[None]
+    fin_lp = topk_lp / ((cur + 1 - prompt_len) ** penalty) + (~st["unsat"]).float() * -1.0e9 + (~just).float() * -1.0e9
+    m_seq, m_sc, m_fin = torch.cat((st["sequences"], topk_seq), 1), torch.cat((st["beam_scores"], fin_lp), 1), torch.cat((st["finished"], just), 1)
+    best = torch.topk(m_sc, nb)[1]
+    new = dict(running=g(topk_seq, nxt), run_scores=g(run_lp, nxt), sequences=g(m_seq, best), beam_scores=g(m_sc, best), finished=g(m_fin, best))
+    best_run = new["run_scores"][:, :1] / ((cur + 1 - prompt_len) ** penalty)
+    worst = torch.where(new["finished"], new["beam_scores"].min(1, keepdim=True)[0], torch.full_like(new["beam_scores"], -1.0e9))
+    new["unsat"] = st["unsat"] & torch.any(best_run > worst, -1, keepdim=True)
+    return new, g(beam_of, nxt), hits
+
+
+@pytest.mark.parametrize("nb,penalty,V", [(4, 2.0, 600), (2, 1.0, 9001), (3, 0.7, 600), (4, 2.0, 30000)])
+def test_beam_step_kernel_follows_the_library_step(ops, nb, penalty, V):
+    """Device-side beam search bookkeeping (cxr_beam_step) against the library's step restated with torch ops, over a whole search with EOS hits,
+    the length limit, and the frozen state after the stop condition."""
+    torch.manual_seed(5)
+    B, L, P, eos, pad = 3, 14, 2, 7, 0
+    dev = "cuda"
+    run0 = torch.full((B, nb, L), pad, dtype=torch.int64, device=dev)
+    run0[:, :, :P] = torch.randint(8, V, (B, 1, P), device=dev)
+    st = dict(running=run0.clone(), sequences=run0.clone(), run_scores=torch.zeros((B, nb), device=dev), beam_scores=torch.full((B, nb), -1.0e9, device=dev),
+              finished=torch.zeros((B, nb), dtype=torch.bool, device=dev), unsat=torch.ones((B, 1), dtype=torch.bool, device=dev))
+    st["run_scores"][:, 1:] = -1.0e9
+    d_run = run0.permute(1, 0, 2).contiguous(); d_seq = d_run.clone()
+    d_rs, d_bs = st["run_scores"].clone(), st["beam_scores"].clone()
+    d_fin = torch.zeros((B, nb), dtype=torch.uint8, device=dev)
+    d_unsat = torch.ones((2, B), dtype=torch.int32, device=dev); d_hit = torch.zeros((2, B), dtype=torch.int32, device=dev)
+    d_idx = torch.zeros(nb * B, dtype=torch.int64, device=dev)
+    stopped = False
+    for cur in range(P, L):
+        logits = torch.randn((B, nb, V), device=dev) * 3.0
+        logits[:, :, eos] += 4.0 + 0.5 * (cur - P) + math.log(V / 600.0) * 3.0     # EOS becomes likely after a few steps
+        bm = logits.permute(1, 0, 2).reshape(nb * B, V).contiguous()      # beam-major rows
+        before = (d_run.clone(), d_seq.clone(), d_rs.clone(), d_bs.clone(), d_fin.clone())
+        ops.beam_step(bm, d_run, d_seq, d_rs, d_bs, d_fin, d_unsat, d_hit, d_idx, cur, L, eos, float(cur + 1 - P) ** penalty)
+        if stopped:                                                        # frozen: nothing moves, identity reorder
+            for a, b in zip(before, (d_run, d_seq, d_rs, d_bs, d_fin)):
+                assert torch.equal(a, b)
+            assert torch.equal(d_idx, torch.arange(nb * B, device=dev))
+            continue
+        st, parent, hits = _beam_step_host(logits, st, cur, P, L, eos, penalty)
+        ok = hits.sum(1) <= nb            # more ended continuations than that: the running set is a tie at -1e9 (the search is over for the study)
+        assert torch.equal(d_run.permute(1, 0, 2)[ok], st["running"][ok]), cur
+        torch.testing.assert_close(d_rs, st["run_scores"], atol=2e-4, rtol=1e-6)
+        assert torch.equal((d_idx.view(nb, B).t() // B)[ok], parent[ok]) and torch.equal(d_idx.view(nb, B).t() % B, torch.arange(B, device=dev)[:, None].expand(B, nb))
+        st["running"] = d_run.permute(1, 0, 2).clone()                           # (carry the device's tie winners forward)
+        assert torch.equal(d_fin.bool(), st["finished"]), cur
+        fin = st["finished"]
+        torch.testing.assert_close(d_bs[fin], st["beam_scores"][fin], atol=2e-4, rtol=1e-6)
+        assert torch.equal(d_seq.permute(1, 0, 2)[fin], st["sequences"][fin]), cur         # (slots still at -1e9 hold arbitrary tie winners)
+        assert torch.equal(d_unsat[cur & 1].bool(), st["unsat"][:, 0]), cur
+        assert torch.equal(d_hit[cur & 1].bool(), hits.all(1)), cur
+        stopped = not (bool(st["unsat"].any()) and not bool(hits.all()))
+    assert stopped and bool(st["finished"][:, 0].all())
+
+
+def test_gather_batch_multi_equals_single_gathers(ops):
+    torch.manual_seed(6)
+    B, T, C, rows = 12, 40, 768, 23
+    srcs = [torch.randn((B, T, C), device="cuda").to(BF) for _ in range(12)]
+    idx = torch.randint(0, B, (B,), device="cuda")
+    outs = [torch.zeros_like(s) for s in srcs]
+    ops.gather_batch_multi(srcs, idx, rows, outs)
+    for s, o in zip(srcs, outs):
+        assert torch.equal(o[:, :rows], s[idx][:, :rows]) and float(o[:, rows:].abs().max()) == 0.0

@@ -665,3 +665,76 @@ def test_longitudinal_c5_three_images_128_token_prompt(M):
         unsafe = np.nonzero(~gsafe[b])[0]
         upto = P + (unsafe[0] if len(unsafe) else new)
         assert torch.equal(free[b, :upto], ref[b, :upto]), (b, free[b, P:], ref[b, P:])
+
+
+def _same_beams(a, b, pad):
+    """Equal sequences after right-padding to one width."""
+    L = max(a.shape[1], b.shape[1])
+    pa = torch.full((a.shape[0], L), pad, dtype=a.dtype); pa[:, :a.shape[1]] = a
+    pb = torch.full((b.shape[0], L), pad, dtype=b.dtype); pb[:, :b.shape[1]] = b
+    return torch.equal(pa, pb)
+
+
+@pytest.mark.parametrize("beams", [4, 2])
+def test_device_beam_search_equals_host_loop(M, beams):
+    """generate(num_beams>1): the device-side search (beam-major rows sharing the cross K/V, bookkeeping kernel, graph-replayed steps, polled stop)
+    returns what the host-loop restatement of the library's `_beam_search` returns -- multi-image model and prompted longitudinal model, free
+    running and with an EOS that ends hypotheses early, twice (the second run replays the captured graphs)."""
+    g, cfg, sd, x = gu.generate_multi_case()
+    m = M.MultiCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    L = 24
+    eo = m.encoder(x.cuda())
+
+    def run(model, device_side, **kw):
+        model.device_beam_search = device_side
+        o = model.generate(encoder_outputs=eo_, bos_token_id=gu.BOS, eos_token_id=gu.EOS, pad_token_id=gu.PAD, num_beams=beams,
+                           return_dict_in_generate=True, use_cache=True, output_scores=True, **kw)
+        return o["sequences"].cpu(), o["sequences_scores"].cpu()
+
+    eo_ = eo
+    for bias in (0.0, float(g["eos_bias"]) - 1.0):
+        with torch.no_grad():
+            m.param("decoder.cls.predictions.bias")[gu.EOS] += bias
+        kw = dict(special_token_ids=[gu.SEP], max_length=L)
+        hs, hsc = run(m, False, **kw)
+        for _ in range(2):
+            ds, dsc = run(m, True, **kw)
+            torch.testing.assert_close(dsc, hsc, atol=2e-2, rtol=0)
+            assert _same_beams(ds, hs, gu.PAD), (bias, ds, hs)
+    # prompted longitudinal model: BOS stripped per step, position ids from the mask, prompt of several tokens
+    g2, cfg2, sd2, x2, prompt = gu.generate_longitudinal_case()
+    m2 = M.LongitudinalPromptMultiCXREncoderDecoderModel(cfg2, seed=None)
+    m2.load_state_dict(sd2)
+    eo_ = m2.encoder(x2.cuda())
+    kw = dict(decoder_input_ids=prompt.cuda(), special_token_ids=[gu.PMT_SEP, gu.BOS, gu.SEP], max_length=prompt.shape[1] + 14, mask_token_id=gu.PAD)
+    hs, hsc = run(m2, False, **kw)
+    for _ in range(2):
+        ds, dsc = run(m2, True, **kw)
+        torch.testing.assert_close(dsc, hsc, atol=2e-2, rtol=0)
+        assert _same_beams(ds, hs, gu.PAD), (ds, hs)
+
+
+def test_device_beam_search_full_size_fused_steps(M):
+    """BERT-base widths: the cached beam steps run on the fused decode-step kernels (decode activation layout, 4 beams per cross K/V stream in
+    the attention kernel). Random-init hypotheses lie within the bf16 error of each other, so the comparison with the host loop (whose steps run
+    the generic kernels) is on the scores, plus well-formedness and replay determinism."""
+    from cxrmate_amd.config import EncoderDecoderConfig
+    cfg = EncoderDecoderConfig()
+    m = M.MultiCXREncoderDecoderModel(cfg, device="cuda", seed=3)
+    m.eval()
+    x = torch.randn(2, 2, 3, 384, 384, generator=torch.Generator().manual_seed(11)).cuda()
+    eo = m.encoder(x)
+    kw = dict(encoder_outputs=eo, special_token_ids=[gu.SEP], max_length=20, bos_token_id=gu.BOS, eos_token_id=gu.EOS, pad_token_id=gu.PAD, num_beams=4,
+              return_dict_in_generate=True, use_cache=True, output_scores=True)
+    m.device_beam_search = False
+    h = m.generate(**kw)
+    m.device_beam_search = True
+    d1 = m.generate(**kw)
+    d2 = m.generate(**kw)
+    assert torch.equal(d1["sequences"], d2["sequences"]) and torch.equal(d1["sequences_scores"], d2["sequences_scores"])
+    torch.testing.assert_close(d1["sequences_scores"], h["sequences_scores"], atol=0.05, rtol=0)
+    s = d1["sequences"]
+    assert s.shape[0] == 2 and bool((s[:, 0] == gu.BOS).all()) and s.shape[1] <= 20 and int(s.max()) < cfg.decoder.vocab_size
+    ses = [v for k, v in m._decode_sessions.items() if k[-1] == 4]
+    assert ses and any(k[0] == "beam" for s_ in ses for (_, _, _, k) in s_.graphs)          # the steps were replayed from captured graphs
