@@ -33,6 +33,53 @@ class CvtEncoderEngine:
         self._fused_proj = os.environ.get("CXR_DWPROJ", "1") != "0"      # A/B switch: 0 = per-projection kernels of conv.hip
         self._embed_buf = {}                        # persistent conv-as-GEMM weight re-layouts (their addresses feed the batched transpose table)
         self._bt, self._bt_sig, self._bt_keys = None, None, None
+        self.fp8 = None                             # {"w": {key: (e4m3 weight, scale)}, "a": {key: scale}} after enable_fp8(); None = bf16
+        self._amax = None                           # calibration pass: {key: running max |activation|}
+
+    # ------------------------------------------------------------------------------------------ fp8 (e4m3) linear layers of the frozen encoder
+    def enable_fp8(self, px, margin: float = 2.0, train: bool | None = None):
+        """Post-training quantisation of the encoder's linear layers for gradient-free forwards (BASELINE.json configs[4], the reference's
+        gen-prompt SCST: modules/lightning_modules/longitudinal/scst/gen_prompt.py:174-259): every Linear of the 21 blocks (q/k/v projections,
+        attention output, both MLP layers: 99.5 % of the encoder's multiply-adds) runs as an e4m3 (OCP) GEMM with ONE scale per weight tensor
+        (max|W| / 448) and ONE static scale per GEMM input (margin * max|activation| / 448 over the calibration images `px`, saturating). The
+        patch embeddings (K = 147 / 576 / 1728 im2col rows), depthwise convolutions, LayerNorms, attention and the projection head stay bf16.
+        Forwards that save activations for a backward pass ignore the switch. Call again after the weights change."""
+        st = self.s
+        self.fp8 = None
+        self._amax = {}
+        with torch.no_grad():
+            self.forward(px, save=False, train=train)
+        amax, self._amax = self._amax, None
+        self.fp8 = {"w": {}, "a": {k: max(float(v), 1e-12) * margin / ops.FP8_MAX for k, v in amax.items()}, "version": st.shadow_version}
+        self._quantise_weights(sorted({key[0] for key in amax}))
+        return self
+
+    def _quantise_weights(self, names):
+        st = self.s
+        for name in list(names):
+            w = st.w16(name)
+            sw = max(float(w.float().abs().max()), 1e-12) / ops.FP8_MAX
+            old = self.fp8["w"].get(name)
+            self.fp8["w"][name] = (ops.quantize_fp8(w, sw, out=None if old is None else old[0]), sw)
+
+    def _linear(self, x, wname, bias=None, residual=None, act=0, row_scale=None, x8=None, out8_for=None):
+        """x [M,K] bf16 (or its e4m3 form x8 from the producing layer) -> Linear. bf16 GEMM, or the e4m3 GEMM once enable_fp8() ran; during the
+        calibration pass the input's max magnitude is recorded. out8_for = weight name of the ONLY consumer: the output is produced as e4m3 with
+        that layer's input scale instead of bf16 (no separate quantisation pass) -> returns (None, e4m3)."""
+        st = self.s
+        if self._amax is not None:
+            key = (wname, "in")
+            m = x.float().abs().max()
+            self._amax[key] = m if key not in self._amax else torch.maximum(self._amax[key], m)
+        if self.fp8 is None or self._saving:
+            return ops.gemm_nt(x, st.w16(wname), bias=None if bias is None else st.f32(bias), residual=residual, act=act, row_scale=row_scale), None
+        w8, sw = self.fp8["w"][wname]
+        sa = self.fp8["a"][(wname, "in")]
+        if x8 is None:
+            x8 = ops.quantize_fp8(x, sa)
+        so = self.fp8["a"][(out8_for, "in")] if out8_for is not None else None
+        return ops.gemm_nt_fp8(x8, w8, sa * sw, bias=None if bias is None else st.f32(bias), residual=residual, act=act, out_scale=so,
+                               want_bf16=out8_for is None, row_scale=row_scale)
 
     # ------------------------------------------------------------------------------------------ weight preparation
     def _stage(self, s):
@@ -167,6 +214,14 @@ class CvtEncoderEngine:
         Bn = px.shape[0]
         saved = {"Bn": Bn, "stages": [], "train": train} if save else None
         self._train = train
+        self._saving = bool(save)
+        if self.fp8 is not None and self.fp8["version"] != st.shadow_version and not save:
+            # the bf16 shadow was refreshed (train-mode BatchNorm statistics, an optimiser step on OTHER parameters ...): the e4m3 weights are
+            # re-quantised only when an encoder Linear can have moved, i.e. when one of them is trainable (a frozen encoder keeps its snapshot;
+            # load_state_dict() drops the fp8 state, see ParamStore.load_state_dict)
+            if any(st.param(name).requires_grad for name in self.fp8["w"]):
+                self._quantise_weights(self.fp8["w"].keys())
+            self.fp8["version"] = st.shadow_version
         self._seed = None
         self._dp_factors = {}
         if train:
@@ -278,16 +333,30 @@ class CvtEncoderEngine:
             qc, _ = ops.dwconv_bn(h1, H, W, cfg.stride_q[s], tok0, fq)
             kc, vc = ops.dwconv_bn(h1, H, W, cfg.stride_kv[s], tok0, fk, fv)
         Lk = kc.shape[1]
+        dp1, dp2 = self._drop_path_scales(s, l, Bn)
+        Ch = st.w16(lp + "intermediate.dense.weight").shape[0]
+        if (self.fp8 is not None or self._amax is not None) and not save:
+            # e4m3 GEMMs (or their calibration pass); the MLP's hidden activation goes from the first GEMM's epilogue to the second as e4m3
+            q, k, v = (self._linear(t_.view(-1, C), ap + f"projection_{n}.weight", ap + f"projection_{n}.bias")[0]
+                       for n, t_ in (("query", qc), ("key", kc), ("value", vc)))
+            q, k, v = q.view(Bn, L, C), k.view(Bn, Lk, C), v.view(Bn, Lk, C)
+            ctx, lse = ops.attention(q, k, v, nh, C ** -0.5, need_lse=False)
+            x2, _ = self._linear(ctx.view(-1, C), lp + "attention.output.dense.weight", lp + "attention.output.dense.bias", residual=x2d,
+                                 row_scale=None if dp1 is None else (dp1, L, False))
+            h2, st2 = ops.layernorm(x2, st.f32(lp + "layernorm_after.weight"), st.f32(lp + "layernorm_after.bias"), cfg.inner_layer_norm_eps)
+            fc2 = lp + "output.dense.weight"
+            g, g8 = self._linear(h2, lp + "intermediate.dense.weight", lp + "intermediate.dense.bias", act=1,
+                                 out8_for=fc2 if self.fp8 is not None else None)
+            x3, _ = self._linear(g, fc2, lp + "output.dense.bias", residual=x2, row_scale=None if dp2 is None else (dp2, L, True), x8=g8)
+            return x3.view(Bn, L, C), None
         # the three linear projections in one grouped launch (the key / value GEMMs alone would leave most CUs idle)
         q, k, v = ops.gemm_nt_group([(t_.view(-1, C), st.w16(ap + f"projection_{n}.weight"), st.f32(ap + f"projection_{n}.bias"))
                                      for n, t_ in (("query", qc), ("key", kc), ("value", vc))])
         q, k, v = q.view(Bn, L, C), k.view(Bn, Lk, C), v.view(Bn, Lk, C)
         ctx, lse = ops.attention(q, k, v, nh, C ** -0.5, need_lse=save)                  # scale = embed_dim^-0.5 (quirk Q1)
-        dp1, dp2 = self._drop_path_scales(s, l, Bn)
         x2 = ops.gemm_nt(ctx.view(-1, C), st.w16(lp + "attention.output.dense.weight"), bias=st.f32(lp + "attention.output.dense.bias"), residual=x2d,
                          row_scale=None if dp1 is None else (dp1, L, False))              # first CvtDropPath: scales the attention branch
         h2, st2 = ops.layernorm(x2, st.f32(lp + "layernorm_after.weight"), st.f32(lp + "layernorm_after.bias"), cfg.inner_layer_norm_eps, need_stats=save)
-        Ch = st.w16(lp + "intermediate.dense.weight").shape[0]
         u = torch.empty((Bn * L, Ch), dtype=torch.bfloat16, device=x.device) if save else None
         g = ops.gemm_nt(h2, st.w16(lp + "intermediate.dense.weight"), bias=st.f32(lp + "intermediate.dense.bias"), act=1, aux=u)
         # the second CvtDropPath scales the WHOLE layer output, residual included (TF5:cvt:382-383, Q12)

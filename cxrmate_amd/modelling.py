@@ -174,6 +174,18 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
             px = px.to(self.device)
         return px.float().contiguous()
 
+    def enable_fp8_encoder(self, calibration_pixel_values, margin: float = 2.0):
+        """Run the frozen encoder's linear layers as e4m3 (OCP) GEMMs with per-tensor scales from here on (gradient-free forwards only; BASELINE.json
+        configs[4]). `calibration_pixel_values` [B,(N,)3,H,W]: images the static activation scales are taken from. `disable_fp8_encoder()` undoes it.
+        See CvtEncoderEngine.enable_fp8."""
+        px = self._pixels(calibration_pixel_values)
+        self._enc.enable_fp8(px.view(-1, *px.shape[-3:]), margin=margin)
+        return self
+
+    def disable_fp8_encoder(self):
+        self._enc.fp8 = None
+        return self
+
     def _encode(self, pixel_values):
         px = self._pixels(pixel_values)
         multi = px.dim() == 5

@@ -875,6 +875,34 @@ def gather_batch(src, idx, rows, dst):
     return dst
 
 
+# ------------------------------------------------------------------------------------------------ fp8 (e4m3) linear layers of the frozen encoder
+FP8 = torch.float8_e4m3fn
+FP8_MAX = 448.0
+
+
+def quantize_fp8(x, scale, out=None):
+    """bf16 [M,K] -> e4m3 [M,K] holding x / scale (saturating)."""
+    _chk(x, BF16)
+    M, K = x.shape
+    if out is None:
+        out = torch.empty((M, K), dtype=FP8, device=x.device)
+    LIB.call("cxr_quantize_fp8", _p(x), x.stride(0), _p(out), out.stride(0), M, K, 1.0 / float(scale), _s())
+    return out
+
+
+def gemm_nt_fp8(a8, w8, scale, bias=None, residual=None, act=0, out_scale=None, want_bf16=True, row_scale=None):
+    """epi(scale * a8[M,K] @ w8[N,K]^T) -> (bf16 [M,N] | None, e4m3 [M,N] holding value / out_scale | None)."""
+    assert a8.dtype == FP8 and w8.dtype == FP8 and a8.stride(1) == 1 and w8.stride(1) == 1
+    M, K = a8.shape
+    N = w8.shape[0]
+    c = torch.empty((M, N), dtype=BF16, device=a8.device) if want_bf16 else None
+    c8 = torch.empty((M, N), dtype=FP8, device=a8.device) if out_scale is not None else None
+    LIB.call("cxr_gemm_nt_fp8", _p(a8), a8.stride(0), _p(w8), w8.stride(0), _p(c), N, _p(c8), N, 1.0 / float(out_scale) if out_scale is not None else 0.0,
+             M, N, K, float(scale), _p(bias), _p(residual), residual.stride(0) if residual is not None else 0, int(act),
+             *((_p(row_scale[0]), int(row_scale[1]), int(bool(row_scale[2]))) if row_scale is not None else (None, 1, 0)), _s())
+    return c, c8
+
+
 def gather_batch_multi(srcs, idx, rows, dsts):
     """dsts[i][b, :rows] = srcs[i][idx[b], :rows] for up to 16 [B, Tmax, C] bf16 caches of one geometry, one launch."""
     n = len(srcs)

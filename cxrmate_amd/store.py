@@ -235,4 +235,7 @@ class ParamStore(nn.Module):
     def load_state_dict(self, state_dict, strict=True, assign=False):
         out = super().load_state_dict(state_dict, strict=strict, assign=False)
         self.shadow_dirty = True
+        enc = getattr(self, "_enc", None)
+        if enc is not None and getattr(enc, "fp8", None) is not None:
+            enc.fp8 = None              # e4m3 weight snapshot + activation scales belong to the old weights: back to bf16 until enable_fp8_encoder() runs again
         return out

@@ -228,6 +228,15 @@ int cxr_select_token(const float* logits, long ld, long R, int V, int mode, floa
                         the rest take the argmax in the same launch (negative n_sample = all rows) */
 int cxr_log_softmax_rows(float* x, long ld, long R, int V, const float* add_row, hipStream_t stream);
 
+/* ---- fp8 (OCP e4m3fn) linear layers of the frozen encoder (BASELINE.json configs[4]; caller REF:modules/lightning_modules/longitudinal/scst/
+ * gen_prompt.py:174-259, encoder under no_grad). C[M,N] = epi(scale * A8[M,K] . W8[N,K]^T): one scale per tensor (scale = s_A * s_W), fp32
+ * accumulation on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales; epi = + bias, GELU (act 1), + residual (bf16); output bf16 (C) and / or
+ * e4m3 (C8 = value * c8_inv_scale, saturating at +-448: the next fp8 layer's input). K % 64 == 0, lda / ldw % 16 == 0. ------------------------- */
+int cxr_gemm_nt_fp8(const void* A8, long lda, const void* W8, long ldw, void* C, long ldc, void* C8, long ldc8, float c8_inv_scale, int M, int N,
+                    int K, float scale, const float* bias, const void* residual, long ldr, int act, const float* row_scale, int rs_rows, int rs_after,
+                    hipStream_t stream);   /* row_scale [M / rs_rows]: per-image DropPath factor on the branch (rs_after 0) or on branch + residual (1) */
+int cxr_quantize_fp8(const void* x, long ldx, void* out, long ldo, int M, int K, float inv_scale, hipStream_t stream);   /* bf16 -> e4m3(x * inv_scale) */
+
 /* ---- autoregressive decode helpers (TF5:gen:3388-3485 beam continuation search + cache reorder) ------------------------- */
 int cxr_gather_batch_bf16(const void* in, long in_bs, long in_rs, void* out, long out_bs, long out_rs, const long* idx, int B, int rows, int C,
                           hipStream_t stream);

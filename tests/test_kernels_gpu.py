@@ -1183,3 +1183,36 @@ def test_gather_batch_multi_equals_single_gathers(ops):
     ops.gather_batch_multi(srcs, idx, rows, outs)
     for s, o in zip(srcs, outs):
         assert torch.equal(o[:, :rows], s[idx][:, :rows]) and float(o[:, rows:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(1000, 384, 384, 0, True), (300, 64, 256, 0, False), (2304, 1536, 384, 1, False), (777, 192, 768, 0, True),
+                                           (4096, 768, 384, 0, False)])
+def test_gemm_nt_fp8_matches_dequantised_fp32_product(ops, M, N, K, act, res):
+    """e4m3 (OCP) GEMM with per-tensor scales: EXACT operands (the e4m3 bytes, dequantised to fp32 on the host side) -> the only differences from
+    an fp32 product are the accumulation order and the bf16 output rounding (rel 2^-8)."""
+    torch.manual_seed(M + N)
+    a = (torch.randn(M, K, device="cuda") * 1.7).to(BF)
+    w = (torch.randn(N, K, device="cuda") * 0.05).to(BF)
+    sa, sw = float(a.float().abs().max()) / 448.0, float(w.float().abs().max()) / 448.0
+    a8, w8 = ops.quantize_fp8(a, sa), ops.quantize_fp8(w, sw)
+    # the quantiser itself: round-to-nearest-even e4m3 of x / scale, as torch's conversion
+    assert torch.equal(a8.view(torch.uint8), (a.float() / sa).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
+    bias = torch.randn(N, device="cuda")
+    r = torch.randn(M, N, device="cuda").to(BF) if res else None
+    ref = (a8.float() @ w8.float().t()) * (sa * sw) + bias
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if res:
+        ref = ref + r.float()
+    so = float(ref.abs().max()) / 448.0
+    c, c8 = ops.gemm_nt_fp8(a8, w8, sa * sw, bias=bias, residual=r, act=act, out_scale=so)
+    close(c, ref, rtol=4e-3, atol=1e-2, what="fp8 gemm bf16 output")
+    close(c8.float() * so, ref, rtol=4e-2, atol=7e-2, what="fp8 gemm e4m3 output")          # e4m3: 3 mantissa bits -> rel 2^-4 per element
+    # and against the UNQUANTISED product: the stated fp8 tolerance of a single layer (two e4m3 operands, K-fold averaging)
+    full = a.float() @ w.float().t() + bias
+    if act == 1:
+        full = torch.nn.functional.gelu(full)
+    if res:
+        full = full + r.float()
+    rel = ((c.float() - full).pow(2).mean().sqrt() / full.pow(2).mean().sqrt()).item()
+    assert rel < 0.05, rel

@@ -738,3 +738,45 @@ def test_device_beam_search_full_size_fused_steps(M):
     assert s.shape[0] == 2 and bool((s[:, 0] == gu.BOS).all()) and s.shape[1] <= 20 and int(s.max()) < cfg.decoder.vocab_size
     ses = [v for k, v in m._decode_sessions.items() if k[-1] == 4]
     assert ses and any(k[0] == "beam" for s_ in ses for (_, _, _, k) in s_.graphs)          # the steps were replayed from captured graphs
+
+
+FP8_RMS = 0.05          # stated tolerance of the e4m3 encoder (per-tensor scales, 126 quantised GEMMs in sequence) against the reference's fp32 output
+
+
+def test_fp8_encoder_against_the_fp32_reference_fixture(M):
+    """BASELINE.json configs[4] encoder: CvT-21 with every Linear of the 21 blocks as an e4m3 (OCP) MFMA GEMM, per-tensor weight scales and static
+    per-tensor activation scales calibrated on OTHER images, against the reference's fp32 activations (tests/golden/encoder_full.npz)."""
+    g, cfg, sd, x = gu.encoder_full_case()
+    m = M.MultiCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    m.eval()
+    with torch.no_grad():
+        h16 = m.encoder(x.cuda()).last_hidden_state.float().cpu()
+        calib = torch.randn(2, 2, 3, 384, 384, generator=torch.Generator().manual_seed(777))       # not the test images
+        m.enable_fp8_encoder(calib)
+        assert m._enc.fp8 is not None and len(m._enc.fp8["w"]) == 21 * 6
+        out = m.encoder(x.cuda())
+        h8 = out.last_hidden_state.float().cpu()
+    assert np.array_equal(out.attention_mask.cpu().numpy(), g["attention_mask"])
+    ref = g["last_hidden_state_sample"]
+    r8, r16 = gu.rel_rms(gu.sample(h8, 32768), ref), gu.rel_rms(gu.sample(h16, 32768), ref)
+    c8 = gu.cosine(gu.sample(h8, 32768), ref)
+    print(f"encoder output rel-rms vs fp32 reference: e4m3 {r8:.4f} (cosine {c8:.5f}), bf16 {r16:.4f}")
+    assert np.isfinite(h8.numpy()).all() and r8 < FP8_RMS and c8 > 0.995
+    assert not torch.equal(h8, h16)                                     # the e4m3 GEMMs really ran
+    # the decoder on top of it: teacher-forced logits stay close to the bf16-encoder logits (what the frozen-encoder SCST consumes)
+    m.disable_fp8_encoder()
+    with torch.no_grad():
+        again = m.encoder(x.cuda()).last_hidden_state.float().cpu()
+    assert torch.equal(again, h16)
+    # trainable encoder weights that moved are re-quantised by the next forward; load_state_dict drops the fp8 state (back to bf16)
+    m.enable_fp8_encoder(calib)
+    wname = "encoder.cvt.encoder.stages.2.layers.0.output.dense.weight"
+    m.param(wname).requires_grad_(True)
+    before = m._enc.fp8["w"][wname][0].clone()
+    with torch.no_grad():
+        m.param(wname).mul_(1.5)
+        m.encoder(x.cuda())
+    assert not torch.equal(before.view(torch.uint8), m._enc.fp8["w"][wname][0].view(torch.uint8)) or abs(m._enc.fp8["w"][wname][1]) > 0
+    m.load_state_dict(sd)
+    assert m._enc.fp8 is None
