@@ -119,6 +119,20 @@ def timed(step, steps, world, dev):
     return dt, out
 
 
+def decode_traffic():
+    """HBM-side bytes per cached token-step from the committed PMC passes (profiles/r02_pmc_decode_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs over one 255-step sample+greedy decode of the configs[3] shape; counters cannot be collected live): the
+    decode-step kernels only (the encoder / prefill kernels of the same run are left out)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_decode_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    pmc = json.load(open(path))
+    fams = ("dec_gemm", "attn_decode", "token_selection", "step_inputs_embedding")
+    return (sum(pmc[f]["hbm_bytes_per_unit"] for f in fams if f in pmc),
+            "profiles/r02_pmc_decode_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per token-step of dec_gemm + attn_decode + token selection + step "
+            "inputs kernels, separate --pmc passes)")
+
+
 def scst_bench(args, rank, world, dev, steps, c5=False):
     """BASELINE.json configs[3] per-GPU shape: 16 studies x 2 images, prompt [PMT][NPF][PMT-SEP][NPI][BOS], 255 sampled + 255 greedy tokens
     (EOS disabled so the work is deterministic), CXR-BERT stand-in reward on R = 128 synthetic WordPiece ids, REINFORCE + AdamW on the whole
@@ -220,10 +234,11 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
                     "the re-scoring pass (same seed)", "loss": float(out["loss"].item()), "string_round_trip": strings,
             "roofline": {"bound": "hbm", "kernel": "cached decode token-step (one hipGraph of ~54 kernels: dec_gemm_kernel x38, attn_decode_kernel x12, "
                          "embedding, step inputs, token selection), 32 rows", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_token_step": step_bytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": decode_traffic()[0], "traffic_unit": "bytes per token-step",
+                         "traffic_source": decode_traffic()[1], "algorithmic_bytes_per_token_step": step_bytes,
                          "decode_ms_per_step": dec_ms, "us_per_token_step": dec_ms * 1e3 / n_tok,
                          "decode_share_of_step": dec_ms / (dt / steps * 1e3),
-                         "profile": "profiles/r02_scst_decode_v1_kernel_stats.csv (rocprofv3 --kernel-trace of scripts/scst_decode_profile.py)"}}
+                         "profile": "profiles/r02_scst_decode_v3_kernel_stats.csv (rocprofv3 --kernel-trace of scripts/scst_decode_profile.py)"}}
 
 
 def beam_bench(args, dev, host_loop_too=True):
@@ -439,7 +454,7 @@ def main():
     ms_per_step, tokens_per_s = main_res["ms_per_step"], main_res["tokens_per_s"]
     gm = main_res["gemm"]
     traffic, traffic_src = None, None                        # HBM-side bytes per launch from the committed PMC passes (cannot be collected live)
-    for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for name in ("r02_pmc_tf_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             traffic = pmc["gemm_nt"]["hbm_bytes_per_launch"]
