@@ -127,6 +127,9 @@ class ReportReward:
         self.labels = labels                                  # [[f"{findings} {impression}"], ...] as the reference builds them (gt_prompt.py:90)
         self.special = [bos_token_id, sep_token_id, eos_token_id]
 
+        self.last_sections = None                             # (findings, impression) strings of the most recent call
+
     def __call__(self, sequences_host):
         _, findings, impression = self.model.split_and_decode_sections(sequences_host, self.special, self.tokenizer)
+        self.last_sections = (findings, impression)
         return self.reward.reward([f"{i} {j}" for i, j in zip(findings, impression)], self.labels)

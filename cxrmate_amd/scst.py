@@ -126,3 +126,25 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         seq_len = (glob["sampled"] != pad).sum(-1).float().mean()
     return {"loss": loss, "reward": glob["reward"].mean(), "baseline": glob["baseline"].mean(), "seq_len": seq_len, "sampled": sampled,
             "baseline_ids": base, "global": glob}
+
+
+def scst_generated_prompt_step(model, opt, reward, tokenizer, images, previous_findings, previous_impression, findings, impression,
+                               decoder_max_len, top_k=50, top_p=1.0, temperature=1.0):
+    """SCST step of the GENERATED-prompt model -- the engine-side analogue of SCSTGeneratedPrompt.scst_step (reference
+    modules/lightning_modules/longitudinal/scst/gen_prompt.py:174-259, BASELINE.json configs[4]): the prompt is tokenised from the previous
+    study's GENERATED findings / impression strings (`tokenize_prompt(..., add_bos_token_id=True)`, :186-192), the step is the gt-prompt SCST
+    step with the reward taken through real strings, and the greedy baseline's decoded sections are returned for the caller to write back
+    into its history (:243-246: they become the next study's prompt). The reference runs this at mbatch_size == 1 (:38) because consecutive
+    studies of a patient depend on each other; any batch of INDEPENDENT studies works here.
+    reward: reward.CXRBERTReward with a tokenizer. Returns scst_step's dict + "baseline_findings" / "baseline_impression" (lists of str)."""
+    from .reward import ReportReward
+    prompt = model.tokenize_prompt(previous_findings, previous_impression, tokenizer, decoder_max_len, add_bos_token_id=True)
+    add = tokenizer.convert_tokens_to_ids("[PMT-SEP]")      # (the reference indexes additional_special_tokens_ids; same id, and this spelling survives transformers 5)
+    special = dict(bos=tokenizer.bos_token_id, eos=tokenizer.eos_token_id, sep=tokenizer.sep_token_id, pad=tokenizer.pad_token_id, pmt_sep=add)
+    labels = [[f"{i} {j}"] for i, j in zip(findings, impression)]                                   # :198
+    rfn = ReportReward(model, tokenizer, reward, labels, tokenizer.bos_token_id, tokenizer.sep_token_id, tokenizer.eos_token_id)
+    out = scst_step(model, opt, rfn, images, prompt["input_ids"], None, special, decoder_max_len, top_k=top_k, top_p=top_p, temperature=temperature,
+                    reward_on_host=True)
+    out["baseline_findings"], out["baseline_impression"] = rfn.last_sections                         # the second reward call decoded the greedy rows
+    out["prompt_ids"] = prompt["input_ids"]
+    return out

@@ -255,3 +255,46 @@ def test_scst_step_through_real_strings(cuda):
     want_b = rfn(out["baseline_ids"].cpu()).float().cpu().numpy()
     np.testing.assert_allclose(out["global"]["reward"].cpu().numpy(), want_r, atol=1e-5)
     np.testing.assert_allclose(out["global"]["baseline"].cpu().numpy(), want_b, atol=1e-5)
+
+
+def test_scst_generated_prompt_steps_chain_through_the_written_back_report(cuda):
+    """SCSTGeneratedPrompt.scst_step (reference scst/gen_prompt.py:174-259, configs[4]'s caller) at its mbatch_size of 1: three consecutive
+    studies of one patient -- the prompt of each step is tokenised from the PREVIOUS step's greedy report strings (written back :243-246), the
+    first from the no-previous-study tokens. Checks the prompt ids the step fed, that the returned strings are the decoded greedy rows, and that
+    the model trains."""
+    import os
+    import transformers
+    from cxrmate_amd import modelling
+    from cxrmate_amd.reward import CXRBERTReward
+    from cxrmate_amd.scst import scst_generated_prompt_step
+    from cxrmate_amd.training import FusedAdamW
+    g, cfg, sd, x, _ = gu.generate_longitudinal_case()
+    m = modelling.LongitudinalPromptMultiCXREncoderDecoderModel(cfg, device=cuda, seed=None)
+    m.load_state_dict(sd)
+    m.train()
+    for p in m.decoder.parameters():
+        p.requires_grad_(True)
+    opt = FusedAdamW(m, lr=1e-3)
+    tok = transformers.PreTrainedTokenizerFast(tokenizer_file=os.path.join(gu.GOLDEN, "tokenizer.json"), unk_token="[UNK]", pad_token="[PAD]",
+                                               cls_token="[BOS]", sep_token="[SEP]", mask_token="[MASK]", bos_token="[BOS]", eos_token="[EOS]")
+    rcfg = gu.BertConfig(vocab_size=600, num_hidden_layers=2, is_decoder=False, add_cross_attention=False, cls_projection_size=128)
+    reward = CXRBERTReward(cuda, tokenizer=tok, config=rcfg)
+    prev_f, prev_i = [None], [None]                               # first study of the patient: [NPF] / [NPI]
+    w0 = m.param("decoder.base_model.model.bert.encoder.layer.0.output.dense.weight").detach().clone()
+    torch.manual_seed(5)
+    for study in range(3):
+        images = x[study % 2:study % 2 + 1].cuda()                # one study (2 images) per step
+        out = scst_generated_prompt_step(m, opt, reward, tok, images, prev_f, prev_i, ["The lungs are clear."], ["No acute process."],
+                                         decoder_max_len=12)
+        torch.cuda.synchronize()
+        assert np.isfinite(out["loss"].item())
+        want_prompt = m.tokenize_prompt(prev_f, prev_i, tok, 12, add_bos_token_id=True)["input_ids"]
+        assert torch.equal(out["prompt_ids"], want_prompt)
+        if study == 0:
+            assert out["prompt_ids"].cpu().tolist() == [[gu.PMT, gu.NPF, gu.PMT_SEP, gu.NPI, gu.BOS]]
+        base = out["baseline_ids"].cpu()
+        _, f, i = m.split_and_decode_sections(base, [gu.BOS, gu.SEP, gu.EOS], tok)
+        assert out["baseline_findings"] == f and out["baseline_impression"] == i and len(f) == 1
+        assert base.shape[1] <= out["prompt_ids"].shape[1] + 12
+        prev_f, prev_i = out["baseline_findings"], out["baseline_impression"]          # written back: the next study's prompt
+    assert not torch.equal(w0, m.param("decoder.base_model.model.bert.encoder.layer.0.output.dense.weight").detach())
