@@ -2,6 +2,9 @@
 // greedy argmax (lowest index wins ties, like torch.argmax), and top-k multinomial sampling. One 256-thread block per logits row
 // (V = 30000 fp32 = 120 KB: first pass from HBM, later passes from L2).
 #include "common.h"
+#ifndef CXR_STAMP
+#define CXR_STAMP(i)            /* scripts/lab defines it to record s_memrealtime per wave; nothing in the product build */
+#endif
 
 __device__ __forceinline__ float block_max(float v, float* sh) {
     v = group_max<64>(v);
@@ -516,10 +519,13 @@ __global__ __launch_bounds__(1024) void sample_topk_lds_kernel(const float* __re
     const long r = blockIdx.x;
     const float* x = logits + r * ld;
     const float invt = 1.0f / temperature;
-    if ((V & 3) == 0 && ((size_t)x & 15) == 0 && V <= 8 * 4096) {
-        // wave-uniform fast path: the whole row as 8 UNCONDITIONAL 16-byte loads per lane, all in flight together (indices past the row re-read
-        // its last vector; a load guarded by a per-lane condition makes hipcc wait for each one before issuing the next: 8 dependent round trips)
-        float4 f[8];
+    CXR_STAMP(0);
+    // the row as 8 UNCONDITIONAL 16-byte loads per lane, all in flight together (indices past the row re-read its last vector; a load guarded by
+    // a per-lane condition makes hipcc wait for each one before issuing the next: 8 dependent round trips). The values stay in registers for
+    // the candidate-filter path below (its passes over the row read registers, not LDS); the LDS copy serves the general path.
+    const bool vec_row = (V & 3) == 0 && ((size_t)x & 15) == 0 && V <= 8 * 4096;       // wave-uniform
+    float4 f[8];
+    if (vec_row) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             int i = (tid + it * 1024) * 4; i = i < V ? i : V - 4;
@@ -528,24 +534,45 @@ __global__ __launch_bounds__(1024) void sample_topk_lds_kernel(const float* __re
         // (pin the loaded values: keeps hipcc from sinking each load into the guarded store below; a "memory" clobber here put f[] in scratch)
 #pragma unroll
         for (int it = 0; it < 8; ++it) asm volatile("" : "+v"(f[it].x), "+v"(f[it].y), "+v"(f[it].z), "+v"(f[it].w));
+        CXR_STAMP(1);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int i = (tid + it * 1024) * 4;
-            if (i < V) *reinterpret_cast<float4*>(row + i) = f[it];
-        }
+        for (int it = 0; it < 8; ++it)
+            if ((tid + it * 1024) * 4 >= V) f[it] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);      // past the row: never a maximum / candidate
+        // (the LDS copy of the row is written only if the general path below is taken: ROW_TO_LDS)
     } else {
         for (int i = tid * 4; i < V; i += 4096) {
             if (i + 4 <= V && ((size_t)(x + i) & 15) == 0) *reinterpret_cast<float4*>(row + i) = *reinterpret_cast<const float4*>(x + i);
             else for (int j = i; j < V && j < i + 4; ++j) row[j] = x[j];
         }
     }
-    __syncthreads();
+#define ROW_TO_LDS()                                                                                          \
+    do {                                                                                                      \
+        if (vec_row) {                                                                                        \
+            _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                \
+                const int i = (tid + it * 1024) * 4;                                                          \
+                if (i < V) *reinterpret_cast<float4*>(row + i) = f[it];                                       \
+            }                                                                                                 \
+        }                                                                                                     \
+        __syncthreads();                                                                                      \
+    } while (0)
     if (r >= n_sample) {
         // argmax row in the same launch (the greedy half of an SCST decode batch): first maximal index, like torch.argmax
         __shared__ float gbest[16];
         __shared__ int gidx[16];
         float best = -INFINITY; int bi = 0x7fffffff;
-        for (int v = tid; v < V; v += 1024) { const float a = row[v]; if (a > best) { best = a; bi = v; } }     // ascending v: first maximum per thread
+        if (vec_row) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {                        // ascending index: first maximum per thread
+                const int v = (tid + it * 1024) * 4;
+                if (f[it].x > best) { best = f[it].x; bi = v; }
+                if (f[it].y > best) { best = f[it].y; bi = v + 1; }
+                if (f[it].z > best) { best = f[it].z; bi = v + 2; }
+                if (f[it].w > best) { best = f[it].w; bi = v + 3; }
+            }
+        } else {
+            __syncthreads();
+            for (int v = tid; v < V; v += 1024) { const float a = row[v]; if (a > best) { best = a; bi = v; } }     // ascending v: first maximum per thread
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
@@ -569,79 +596,131 @@ __global__ __launch_bounds__(1024) void sample_topk_lds_kernel(const float* __re
     //   L = k-th largest of 256 group maxima (a lower bound of the k-th largest element: those are k distinct elements >= L), so every
     //   kept entry is among the few elements >= L; the exact threshold, the softmax and the inverse-CDF walk then run on that short list.
     constexpr int CAND = 1024;
-    __shared__ float gmax[256];
+    __shared__ __attribute__((aligned(16))) unsigned gkey[256];
     __shared__ float cval[CAND];
     __shared__ int cidx[CAND];
     __shared__ float sval[CAND];
     __shared__ int sidx[CAND];
-    __shared__ int ncand, nkept;
+    __shared__ int ncand;
     __shared__ float thr_s;
-    if (top_k > 0 && top_k <= 256 && top_k < V) {
+    __shared__ unsigned lkey;
+    if (top_k > 0 && top_k <= 256 && top_k < V && vec_row) {
         float lm = -INFINITY;
-        for (int v = tid; v < V; v += 1024) lm = fmaxf(lm, row[v]);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) lm = fmaxf(lm, fmaxf(fmaxf(f[it].x, f[it].y), fmaxf(f[it].z, f[it].w)));
+        const float own_max = lm;
         lm = fmaxf(lm, __shfl_xor(lm, 1, 64));
         lm = fmaxf(lm, __shfl_xor(lm, 2, 64));
-        if ((tid & 3) == 0) gmax[tid >> 2] = lm;
-        if (tid == 0) { ncand = 0; nkept = 0; thr_s = -INFINITY; pick = -1; }
+        // group maxima as DISTINCT ordered keys: the order-preserving integer image of the value with its low 8 bits replaced by 255 - group
+        // (ties -> lower group first). Dropping 8 mantissa bits only lowers the bound L a little (a few more candidates).
+        if ((tid & 3) == 0) gkey[tid >> 2] = (f2ord(lm) & 0xffffff00u) | (255u - (unsigned)(tid >> 2));
+        if (tid == 0) { ncand = 0; thr_s = -INFINITY; lkey = 0u; pick = -1; }
+        CXR_STAMP(2);
         __syncthreads();
-        if (tid < 256) {                                           // rank of my group maximum (descending, ties by lower index first)
-            const float mine = gmax[tid];
+        {
+            // rank of every group key (number of larger keys): 4 lanes per group, each compares against a quarter of the 256 keys with 16-byte LDS
+            // reads, one compare + one add-with-carry per key (a one-thread-per-group loop of 256 dependent 4-byte reads took 7 us: one LDS latency
+            // per iteration; value + index comparisons on all 1024 threads 3.5 us: the CU's VALU rate)
+            const int grp = tid >> 2, part = tid & 3;
+            const unsigned mine = gkey[grp];
             int rank = 0;
-            for (int j = 0; j < 256; ++j) { const float o = gmax[j]; rank += (o > mine) || (o == mine && j < tid); }
-            if (rank == top_k - 1) thr_s = mine;
+#pragma unroll
+            for (int j4 = 0; j4 < 16; ++j4) {
+                const uint4 o = *reinterpret_cast<const uint4*>(&gkey[(part * 16 + j4) * 4]);
+                rank += o.x > mine; rank += o.y > mine; rank += o.z > mine; rank += o.w > mine;
+            }
+            rank += __shfl_xor(rank, 1, 64);
+            rank += __shfl_xor(rank, 2, 64);
+            if (part == 0 && rank == top_k - 1) lkey = mine & 0xffffff00u;
         }
         __syncthreads();
-        const float L = thr_s;
-        for (int v = tid; v < V; v += 1024) {
-            const float a = row[v];
-            if (a >= L) { const int i = atomicAdd(&ncand, 1); if (i < CAND) { cval[i] = a; cidx[i] = v; } }
+        CXR_STAMP(3);
+        float L = ord2f(lkey);                                     // <= the value of top_k distinct elements: every kept entry is >= L
+        if (!(L == L)) L = -INFINITY;                              // (fewer than top_k groups hold data: the truncated key of -inf decodes to a NaN)
+        {
+            // candidates straight from the registers, compacted with ONE LDS atomic per wave (a same-address atomic per candidate serialised:
+            // ~100 x 40 cycles)
+            uint32_t m = 0u;
+            if (own_max >= L) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it)
+                    if ((tid + it * 1024) * 4 < V)                 // (vectors past the row were set to -inf: not candidates even when L is -inf)
+                        m |= ((f[it].x >= L ? 1u : 0u) | (f[it].y >= L ? 2u : 0u) | (f[it].z >= L ? 4u : 0u) | (f[it].w >= L ? 8u : 0u)) << (it * 4);
+            }
+            const int cnt = __popc(m);
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+            const int total = __shfl(incl, 63, 64);
+            int base = 0;
+            if (lane == 63 && total) base = atomicAdd(&ncand, total);
+            base = __shfl(base, 63, 64);
+            int off = base + incl - cnt;
+            if (m) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int v = (tid + it * 1024) * 4;
+                    const float a4[4] = {f[it].x, f[it].y, f[it].z, f[it].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if ((m >> (it * 4 + q)) & 1u) { if (off < CAND) { cval[off] = a4[q]; cidx[off] = v + q; } ++off; }
+                }
+            }
         }
         __syncthreads();
+        CXR_STAMP(4);
         const int nc = ncand;
         if (nc <= CAND) {
-            if (tid < nc) {                                        // the k-th largest VALUE among the candidates (entries equal to it are all kept)
-                const float a = cval[tid];
-                int gt = 0, ge = 0;
-                for (int j = 0; j < nc; ++j) { const float o = cval[j]; gt += o > a; ge += o >= a; }
-                if (gt < top_k && top_k <= ge) thr_s = a;          // every thread holding that value writes the same number
+            // one pass per candidate (8 lanes split the comparisons): its rank by value -> the k-th largest VALUE (entries equal to it are all
+            // kept), and its position by vocabulary index -> the candidate list in torch.multinomial's category order
+            for (int c0 = 0; c0 < nc; c0 += 128) {
+                const int c = c0 + (tid >> 3), part = tid & 7;
+                const float a = c < nc ? cval[c] : 0.f;
+                const int myi = c < nc ? cidx[c] : 0;
+                int gt = 0, ge = 0, pos = 0;
+                for (int j = part; j < nc; j += 8) { const float o = cval[j]; gt += o > a; ge += o >= a; pos += cidx[j] < myi; }
+                gt += __shfl_xor(gt, 1, 64); ge += __shfl_xor(ge, 1, 64); pos += __shfl_xor(pos, 1, 64);
+                gt += __shfl_xor(gt, 2, 64); ge += __shfl_xor(ge, 2, 64); pos += __shfl_xor(pos, 2, 64);
+                gt += __shfl_xor(gt, 4, 64); ge += __shfl_xor(ge, 4, 64); pos += __shfl_xor(pos, 4, 64);
+                if (c < nc && part == 0) {
+                    sval[pos] = a; sidx[pos] = myi;
+                    if (gt < top_k && top_k <= ge) thr_s = a;      // every candidate holding that value writes the same number
+                }
             }
             __syncthreads();
+            CXR_STAMP(5);
             float t = thr_s;
             if (top_p < 1.0f) {                                    // TopPLogitsWarper on the top-k set (uniform branch)
                 __shared__ unsigned tmin;
                 t = topp_threshold_from_list(cval, cidx, nc, t, top_p, invt, &tmin);
             }
-            if (tid < nc && cval[tid] >= t) {                      // kept entries, sorted by vocabulary index (torch.multinomial's category order)
-                const int myi = cidx[tid];
-                int pos = 0;
-                for (int j = 0; j < nc; ++j) pos += (cval[j] >= t) && (cidx[j] < myi);
-                sval[pos] = cval[tid]; sidx[pos] = myi;
-                atomicAdd(&nkept, 1);
-            }
-            __syncthreads();
-            if (wave == 0) {
-                const int nk = nkept;
+            CXR_STAMP(6);
+            if (wave == 0) {                                       // softmax over the kept entries (value >= t) + inverse-CDF walk in index order
                 float mx = -INFINITY;
-                for (int i = lane; i < nk; i += 64) mx = fmaxf(mx, sval[i] * invt);
+                int last = -1;
+                for (int i = lane; i < nc; i += 64) if (sval[i] >= t) { mx = fmaxf(mx, sval[i] * invt); last = i; }
                 mx = group_max<64>(mx);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
                 float tot = 0.f;
-                for (int i = lane; i < nk; i += 64) tot += __expf(sval[i] * invt - mx);
+                for (int i = lane; i < nc; i += 64) tot += sval[i] >= t ? __expf(sval[i] * invt - mx) : 0.f;
                 tot = group_sum<64>(tot);
                 const float target = u[r] * tot;
                 float carry = 0.f;
                 int found = -1;
-                for (int i0 = 0; i0 < nk && found < 0; i0 += 64) {
+                for (int i0 = 0; i0 < nc && found < 0; i0 += 64) {
                     const int i = i0 + lane;
-                    const float e = i < nk ? __expf(sval[i] * invt - mx) : 0.f;
+                    const bool kept = i < nc && sval[i] >= t;
+                    const float e = kept ? __expf(sval[i] * invt - mx) : 0.f;
                     float incl = e;
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) { const float y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
-                    const bool hit = i < nk && target < carry + incl;
+                    const bool hit = kept && target < carry + incl;
                     const unsigned long long bal = __ballot(hit);
                     if (bal) found = i0 + __ffsll((long long)bal) - 1;
                     carry += __shfl(incl, 63, 64);
                 }
-                if (found < 0) found = nk - 1;                      // numerical edge (u ~ 1): the last kept entry
+                if (found < 0) found = last;                        // numerical edge (u ~ 1): the last kept entry
                 if (lane == 0) {
                     long tok = sidx[found];
                     if (unfinished) {
@@ -651,11 +730,14 @@ __global__ __launch_bounds__(1024) void sample_topk_lds_kernel(const float* __re
                     }
                     next[r * next_stride] = tok;
                 }
+                CXR_STAMP(7);
             }
             return;
         }
         __syncthreads();                                           // pathological ties (more than CAND elements >= L): general path below
     }
+    ROW_TO_LDS();                                                  // general path: every pass below reads the row from LDS
+#undef ROW_TO_LDS
     // exact k-th largest (radix select on the order-preserving integer image)
     float t = -INFINITY;
     if (top_k > 0 && top_k < V) {

@@ -104,7 +104,9 @@ class wgrad_overlap:
 
     def __enter__(self):
         if wgrad_overlap._stream is None and os.environ.get("CXR_WGRAD_OVERLAP", "1") != "0":      # 0: A/B switch, everything on one stream
-            wgrad_overlap._stream = torch.cuda.Stream()
+            # CXR_WGRAD_PRIORITY: stream priority of the weight-gradient stream (default: torch's default = lowest; negative = higher)
+            prio = int(os.environ.get("CXR_WGRAD_PRIORITY", "0"))
+            wgrad_overlap._stream = torch.cuda.Stream(priority=prio)
         self.prev, ops.WGRAD_STREAM = ops.WGRAD_STREAM, wgrad_overlap._stream
         return self
 

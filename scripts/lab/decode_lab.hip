@@ -82,6 +82,7 @@ static const char* g_filter = nullptr;
 // time a chain of `reps` dependent launches replayed from a graph; print us / launch and the stamp profile of the LAST launch
 static const int g_order_default[8] = {0, 1, 2, 3, 4, 5, -1, -1};
 static const int g_order_gemm[8] = {0, 6, 7, 1, 2, 3, 4, 5};
+static const int g_order_sample[8] = {0, 1, 2, 3, 4, 5, 6, 7};
 static void bench(const char* name, int reps, const std::function<void(int, hipStream_t)>& fn, int nblocks_for_stamps = 0, int nwaves = 4, int nstamps = 6, const int* order = g_order_default) {
     if (g_filter && !strstr(name, g_filter)) return;
     hipStream_t s; HC(hipStreamCreate(&s));
@@ -363,7 +364,7 @@ int main(int argc, char** argv) {
         float* u = df32(M, 0.49f, 0.5f);
         long* nxt = dalloc<long>(M);
         bench("select_token: 16 sampled (top-k 50) + 16 argmax rows", 32, [&](int i, hipStream_t s) {
-            RC(cxr_select_token(logits, V, M, V, 1, 1.0f, 50, 1.0f, u, nxt, 1, nullptr, -1, 0, nullptr, 16, s)); });
+            RC(cxr_select_token(logits, V, M, V, 1, 1.0f, 50, 1.0f, u, nxt, 1, nullptr, -1, 0, nullptr, 16, s)); }, 16, 16, 8, g_order_sample);
         bench("select_token: 32 argmax rows", 32, [&](int i, hipStream_t s) {
             RC(cxr_select_token(logits, V, M, V, 0, 1.0f, 0, 1.0f, nullptr, nxt, 1, nullptr, -1, 0, nullptr, -1, s)); });
     }
