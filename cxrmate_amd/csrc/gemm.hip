@@ -458,6 +458,9 @@ struct GemmTnArgs {
     int R, I, J;
     int splits, tiles_j, rt_per_split;
     float alpha;
+    float* ws;          // deterministic split-K: split s leaves its partial tile in ws[s][I_pad][J_pad] (plain stores) and partial bias sums in
+    float* wsb;         // wsb[s][I_pad]; gemm_tn_reduce_kernel adds them to C / dbias in split order. NULL: fp32 atomics straight into C / dbias
+    int mode;           // 0 atomics, 1 one split: this workgroup owns its tile -> plain read-modify-write of C, 2 partials to ws
     int debug;          // tuning aid (CXR_TN_DEBUG): 1 skip epilogue atomics, 2 skip MFMA, 4 skip LDS-DMA refills, 8 skip fragment reads
 };
 
@@ -617,11 +620,24 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
         __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0): own writes landed (each wave reads back only its own tile)
         const int j = tj * 128 + wj * 64 + lane;
         const int ibase = ti * 128 + wi * 64 + half * PASS_ROWS;
-        if (j < g.J) {
+        if (g.mode == 2) {                                         // partial tile of this split: whole 256-B rows, plain stores
+            const int Jp = g.tiles_j * 128, Ip = (tiles / g.tiles_j) * 128;
+            float* wrow = g.ws + ((long)split * Ip + ibase) * Jp + tj * 128 + wj * 64 + lane;
 #pragma unroll 8
-            for (int row = 0; row < PASS_ROWS; ++row) {
-                const int i = ibase + row;
-                if (i < g.I) atomicAdd(g.C + (long)i * g.ldc + j, wtile[row * 64 + lane]);
+            for (int row = 0; row < PASS_ROWS; ++row) wrow[(long)row * Jp] = wtile[row * 64 + lane];
+        } else if (j < g.J) {
+            if (g.mode == 1) {                                     // the only split: this workgroup owns the tile
+#pragma unroll 8
+                for (int row = 0; row < PASS_ROWS; ++row) {
+                    const int i = ibase + row;
+                    if (i < g.I) g.C[(long)i * g.ldc + j] += wtile[row * 64 + lane];
+                }
+            } else {
+#pragma unroll 8
+                for (int row = 0; row < PASS_ROWS; ++row) {
+                    const int i = ibase + row;
+                    if (i < g.I) atomicAdd(g.C + (long)i * g.ldc + j, wtile[row * 64 + lane]);
+                }
             }
         }
         if (half + 1 < 64 / PASS_ROWS) __builtin_amdgcn_s_waitcnt(0xC07F);          // the next pass overwrites the rows just read
@@ -632,13 +648,56 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = ti * 128 + wi * 64 + it * 16 + fq * 4 + r;
-                if (i < g.I) atomicAdd(g.dbias + i, accb[it][r]);
+                if (g.mode == 2) g.wsb[(long)split * ((tiles / g.tiles_j) * 128) + i] = accb[it][r];
+                else if (i < g.I) {
+                    if (g.mode == 1) g.dbias[i] += accb[it][r];
+                    else atomicAdd(g.dbias + i, accb[it][r]);
+                }
             }
     }
 }
 
+// C[i][j] += sum of the splits' partial tiles, dbias likewise, in a FIXED order: SL lanes share one group of 4 columns, lane l sums the splits
+// congruent to l (ascending), a butterfly over the SL lanes finishes (small outputs have up to 176 splits: one thread walking them serially is a
+// chain of 176 dependent loads).
+template <int SL>
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ wsb, float* __restrict__ C, long ldc,
+                                                             float* __restrict__ dbias, int I, int J, int Ip, int Jp, int splits) {
+    const int j4 = J / 4;
+    const long total = (long)I * j4;
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) / SL;
+    const int sl = threadIdx.x % SL;
+    if (e < total) {
+        const int i = (int)(e / j4), j = (int)(e % j4) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s2 = sl; s2 < splits; s2 += SL) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + ((long)s2 * Ip + i) * Jp + j);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+#pragma unroll
+        for (int o = 1; o < SL; o <<= 1) {
+            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64); acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+        }
+        if (sl == 0) {
+            float* c = C + (long)i * ldc + j;
+            if ((ldc & 3) == 0 && ((size_t)C & 15) == 0) {
+                float4 o = *reinterpret_cast<float4*>(c);
+                o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+                *reinterpret_cast<float4*>(c) = o;
+            } else { c[0] += acc.x; c[1] += acc.y; c[2] += acc.z; c[3] += acc.w; }
+        }
+    } else if (dbias && e - total < I) {
+        const int i = (int)(e - total);
+        float acc = 0.f;
+        for (int s2 = sl; s2 < splits; s2 += SL) acc += wsb[(long)s2 * Ip + i];
+#pragma unroll
+        for (int o = 1; o < SL; o <<= 1) acc += __shfl_xor(acc, o, 64);
+        if (sl == 0) dbias[i] += acc;
+    }
+}
+
 extern "C" int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* dbias, int R, int I, int J,
-                                float alpha, hipStream_t stream) {
+                                float alpha, float* ws, long ws_floats, hipStream_t stream) {
     if (R <= 0 || I <= 0 || J <= 0 || (I % 8) || (J % 8) || (ldp % 8) || (ldq % 8)) return CXR_ERR_ARG;
     GemmTnArgs g;
     g.P = (const bf16_t*)P; g.ldp = ldp; g.Q = (const bf16_t*)Q; g.ldq = ldq; g.C = C; g.ldc = ldc; g.dbias = dbias;
@@ -660,10 +719,27 @@ extern "C" int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq
     if (splits < 1) splits = 1;
     g.rt_per_split = cdiv(nrt, splits);
     g.splits = cdiv(nrt, g.rt_per_split);
+    // accumulation: one split -> atomics (each element receives exactly one add per launch: order-free); several splits -> partial tiles into the
+    // caller's workspace + one reduce launch that adds them in a fixed order (deterministic; measured at the same speed as 64 KB of fp32 atomics
+    // per workgroup, scripts/tn_micro.py with CXR_TN_ATOMICS=1); no / too small a workspace: atomics
+    const int Ip = tiles_i * 128, Jp = g.tiles_j * 128;
+    const long need = (long)g.splits * Ip * Jp + (long)g.splits * Ip;
+    static int det = -1;
+    if (det < 0) { const char* e = getenv("CXR_TN_ATOMICS"); det = (e && atoi(e)) ? 0 : 1; }
+    g.ws = nullptr; g.wsb = nullptr;
+    g.mode = 0;                                            // one split: every element gets exactly ONE atomic add per launch -- deterministic as it is
+    if (det && g.splits > 1 && ws && ws_floats >= need && (J % 4) == 0) { g.mode = 2; g.ws = ws; g.wsb = ws + (long)g.splits * Ip * Jp; }
     static int stages = -1;                                // CXR_TN_STAGES = 2 | 4 (LDS 32 | 64 KB per workgroup)
     if (stages < 0) { const char* e = getenv("CXR_TN_STAGES"); stages = e ? atoi(e) : 4; }
     if (stages == 2) CXR_LAUNCH(gemm_tn_kernel<2>, dim3(tiles * g.splits), dim3(256), 0, stream, g);
     else             CXR_LAUNCH(gemm_tn_kernel<4>, dim3(tiles * g.splits), dim3(256), 0, stream, g);
+    if (g.mode == 2) {
+        const long total = (long)I * (J / 4) + (dbias ? I : 0);
+        const int sl = g.splits <= 8 ? 1 : (g.splits <= 32 ? 4 : 16);
+#define TN_RED(SL_) CXR_LAUNCH(gemm_tn_reduce_kernel<SL_>, dim3((unsigned)cdiv(total * SL_, 256)), dim3(256), 0, stream, g.ws, g.wsb, C, ldc, dbias, I, J, Ip, Jp, g.splits)
+        if (sl == 1) TN_RED(1); else if (sl == 4) TN_RED(4); else TN_RED(16);
+#undef TN_RED
+    }
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

@@ -155,6 +155,16 @@ def colsum_into(x, out):
     LIB.call("cxr_colsum_bf16", _p(x), x.stride(0), _p(out), x.shape[0], x.shape[1], _s())
 
 
+_TN_WS = {}             # raw stream handle -> fp32 scratch of the deterministic split-K weight-gradient GEMM (launches of one stream are serial)
+
+
+def _tn_ws(stream, device):
+    ws = _TN_WS.get(stream)
+    if ws is None or ws.device != device:
+        ws = _TN_WS[stream] = torch.empty(8 << 20, dtype=torch.float32, device=device)
+    return ws
+
+
 def gemm_tn(p, q, out, dbias=None, alpha=1.0):
     """out[I,J] (fp32) += alpha * p[R,I]^T @ q[R,J];  dbias[I] += colsum(p). p, q bf16 row-major (row stride free)."""
     _chk(p, BF16); _chk(q, BF16)
@@ -166,7 +176,10 @@ def gemm_tn(p, q, out, dbias=None, alpha=1.0):
         pstream = WGRAD_STREAM if _SIDE_RAW is not None else None           # the stream the kernel is launched on
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(pstream)
-    LIB.call("cxr_gemm_tn_bf16", _p(p), p.stride(0), _p(q), q.stride(0), _p(out), out.stride(0), _p(dbias), R, I, J, float(alpha), _s())
+    stream = _s()
+    ws = _tn_ws(stream, p.device)
+    LIB.call("cxr_gemm_tn_bf16", _p(p), p.stride(0), _p(q), q.stride(0), _p(out), out.stride(0), _p(dbias), R, I, J, float(alpha), _p(ws), ws.numel(),
+             stream)
     if prof is not None:
         e1.record(pstream)
         prof.append((2.0 * R * I * J, e0, e1, ("tn", I, J, R), 2.0 * R * (I + J) + 4.0 * I * J))

@@ -43,9 +43,11 @@ typedef struct cxr_gemm_nt_desc {
 } cxr_gemm_nt_desc;
 int cxr_gemm_nt_group_bf16(const cxr_gemm_nt_desc* d, int n, hipStream_t stream);
 /* weight gradient: C[I,J] += alpha * sum_r P[r,I] Q[r,J]  (dW += dY^T X), dbias[I] += colsum(P); token dimension split across
- * workgroups, fp32 atomic accumulation into the gradient buffer. Requires I%8==0, J%8==0. */
+ * workgroups. Deterministic accumulation: one split = the workgroup owns its tile; several splits = partial tiles into `ws` (fp32, the caller's
+ * scratch: 8 M floats cover every shape of this model; must not be shared by launches on different streams) + a reduce launch in split order.
+ * ws NULL / too small (or CXR_TN_ATOMICS=1): fp32 atomics into C. Requires I%8==0, J%8==0. Nothing else may accumulate into C concurrently. */
 int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* dbias, int R, int I, int J, float alpha,
-                     hipStream_t stream);
+                     float* ws, long ws_floats, hipStream_t stream);
 int cxr_gemm_set_regstage(int on);   /* debug: 1 = stage operands through registers instead of LDS-DMA */
 int cxr_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int C, hipStream_t stream);
 int cxr_transpose_batched_bf16(const long* table, int n, long total_tiles, hipStream_t stream);   /* n transposes in one launch; table (device)

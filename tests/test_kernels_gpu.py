@@ -128,6 +128,22 @@ def test_gemm_tn_exact_integers(ops):
     assert torch.equal(out.cpu(), (p.float().t() @ q.float()).cpu())
 
 
+@pytest.mark.parametrize("R,I,J", [(8192, 768, 768), (5000, 384, 1536), (3001, 200, 72), (36928, 384, 384)])
+def test_gemm_tn_is_deterministic(ops, R, I, J):
+    """Weight-gradient GEMM: the token dimension is split over workgroups; partial tiles are reduced in split order (no float atomics), so two
+    launches on the same operands give the same bits -- also into a strided view of a wider gradient matrix and with the bias gradient."""
+    p, q = dev(rnd(R, I, seed=11).to(BF)), dev(rnd(R, J, seed=12).to(BF))
+    wide = [torch.zeros(I, J + 24, device="cuda") for _ in range(2)]
+    dbs = [torch.zeros(I, device="cuda") for _ in range(2)]
+    for w, d in zip(wide, dbs):
+        ops.gemm_tn(p, q, w[:, 8:8 + J], dbias=d)
+        ops.gemm_tn(p, q, w[:, 8:8 + J], dbias=d, alpha=0.25)          # accumulates
+    assert torch.equal(wide[0], wide[1]) and torch.equal(dbs[0], dbs[1])
+    assert float(wide[0][:, :8].abs().max()) == 0.0 and float(wide[0][:, 8 + J:].abs().max()) == 0.0
+    close(wide[0][:, 8:8 + J], 1.25 * (p.float().t() @ q.float()), rtol=1e-2, atol=1e-2, what="deterministic gemm_tn")
+    close(dbs[0], 2.0 * p.float().sum(0), rtol=1e-2, atol=1e-2, what="deterministic gemm_tn dbias")
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def ref_attention(q, k, v, heads, scale, kpm=None, causal=False, shift=0, drop=None):
     B, Tq, D = q.shape
