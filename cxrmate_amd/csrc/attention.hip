@@ -66,6 +66,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     const bf16_t* kbase = a.K + (long)b * a.k_bs + head * 64;
     const bf16_t* vbase = a.V + (long)b * a.v_bs + head * 64;
     uint4 kreg0, kreg1, vreg0, vreg1;
+    unsigned char mbyte = 0;
+    const unsigned char* mrow = a.kpm ? a.kpm + (long)b * a.kpm_bs : reinterpret_cast<const unsigned char*>(kbase);       // stand-in: any valid address
     const int srow0 = tid >> 3, srow1 = (256 + tid) >> 3, sc = tid & 7;     // staging slots of this thread
 #define ATT_GLOAD(tile)                                                                              \
     do {                                                                                             \
@@ -75,6 +77,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         kreg1 = *reinterpret_cast<const uint4*>(kbase + (long)key1_ * a.k_rs + sc * 8);              \
         vreg0 = *reinterpret_cast<const uint4*>(vbase + (long)key0_ * a.v_rs + sc * 8);              \
         vreg1 = *reinterpret_cast<const uint4*>(vbase + (long)key1_ * a.v_rs + sc * 8);              \
+        {   /* key-padding byte of this thread's key of the tile, prefetched WITH the tile. Unconditional (stand-in address without a mask): */ \
+            /* guarded, hipcc branches around the load and waits vmcnt(0) behind it -- one exposed L2 round trip per tile of a masked call    */ \
+            const int kk_ = (tile) * 64 + (tid & 63);                                                \
+            mbyte = mrow[a.kpm ? (kk_ < a.Tk ? kk_ : a.Tk - 1) : 0];                                 \
+        }                                                                                            \
     } while (0)
 
     f32x16_t o[2];
@@ -92,9 +99,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         *reinterpret_cast<uint4*>(Vs + srow1 * VS_STRIDE + sc * 8) = vreg1;
         if (tid < 64) {
             const int key = tile * 64 + tid;
-            unsigned char code = 0;                        // 0 = beyond Tk, 1 = masked, 2 = attend
-            if (key < a.Tk) code = (a.kpm == nullptr || a.kpm[(long)b * a.kpm_bs + key]) ? 2 : 1;
-            Ms[tid] = code;
+            Ms[tid] = key < a.Tk ? ((a.kpm == nullptr || mbyte) ? 2 : 1) : 0;      // 0 = beyond Tk, 1 = masked, 2 = attend
         }
         __syncthreads();
         if (tile + 1 < ntiles) ATT_GLOAD(tile + 1);            // in flight during this tile's math (T14 split)

@@ -86,10 +86,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdArgs
         q1 = *reinterpret_cast<const uint4*>(qbase + (long)r1_ * a.q_rs + sc * 8);                          \
         d0 = *reinterpret_cast<const uint4*>(dbase + (long)r0_ * a.o_rs + sc * 8);                          \
         d1 = *reinterpret_cast<const uint4*>(dbase + (long)r1_ * a.o_rs + sc * 8);                          \
-        if (tid < 128) {                                                                                    \
+        {   /* UNCONDITIONAL load (pointer select + clamped index): a load guarded by a per-lane condition makes hipcc branch around it and  */ \
+            /* park s_waitcnt vmcnt(0) behind the branch -- which also waited for the tile prefetch just issued, in every iteration           */ \
+            /* the value is only TOUCHED at the top of the next iteration: arithmetic on it here makes the wave wait for the prefetch now */ \
             const int qq_ = (tile) * 64 + (tid & 63);                                                       \
-            if (tid < 64) lsev = qq_ < a.Tq ? lbase[qq_] * 1.4426950408889634f : INFINITY;                  \
-            else          lsev = qq_ < a.Tq ? ebase[qq_] : 0.f;                                             \
+            lsev = (tid < 64 ? lbase : ebase)[qq_ < a.Tq ? qq_ : a.Tq - 1];                                 \
         }                                                                                                   \
     } while (0)
 
@@ -98,13 +99,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdArgs
     for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
 
     if (tile0 < ntiles) BWD_GLOAD_Q(tile0);
+    // the K / V fragments (loaded above, loop-invariant) are "used" here so that their wait sits BEFORE the loop: hipcc's wait-count pass otherwise
+    // keeps an s_waitcnt vmcnt(0) in front of their first use INSIDE the loop (the back edge merges to "possibly pending"), where it also waits
+    // for the tile prefetch issued a few instructions earlier -- every iteration exposed the whole global-load latency
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" :: "v"(kf[s]), "v"(vf[s]));
     for (int tile = tile0; tile < ntiles; ++tile) {
         __syncthreads();
         *reinterpret_cast<uint4*>(Qr + srow0 * RS + sc * 8) = q0; *reinterpret_cast<uint4*>(Qr + srow1 * RS + sc * 8) = q1;
         *reinterpret_cast<uint4*>(Qt + srow0 * TS + sc * 8) = q0; *reinterpret_cast<uint4*>(Qt + srow1 * TS + sc * 8) = q1;
         *reinterpret_cast<uint4*>(Dr + srow0 * RS + sc * 8) = d0; *reinterpret_cast<uint4*>(Dr + srow1 * RS + sc * 8) = d1;
         *reinterpret_cast<uint4*>(Dt + srow0 * TS + sc * 8) = d0; *reinterpret_cast<uint4*>(Dt + srow1 * TS + sc * 8) = d1;
-        if (tid < 64) Ls[tid] = lsev; else if (tid < 128) Es[tid - 64] = lsev;
+        const bool inq = tile * 64 + (tid & 63) < a.Tq;
+        if (tid < 64) Ls[tid] = inq ? lsev * 1.4426950408889634f : INFINITY;
+        else if (tid < 128) Es[tid - 64] = inq ? lsev : 0.f;
         else if (a.drop_thr16 && tid < 192)
             Rk[tid - 128] = dropout_row_key(drop_seed, a.drop_site, (uint32_t)(b * a.H + head), (uint32_t)(tile * 64 + tid - 128 + a.drop_t0));
         __syncthreads();
@@ -257,6 +265,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwdArgs a
     const bf16_t* vbase = a.V + (long)b * a.v_bs + head * 64;
     const int srow0 = tid >> 3, srow1 = (256 + tid) >> 3, sc = tid & 7;
     uint4 k0, k1, v0, v1;
+    unsigned char mbyte = 0;
+    const unsigned char* mrow = a.kpm ? a.kpm + (long)b * a.kpm_bs : reinterpret_cast<const unsigned char*>(kbase);       // stand-in: any valid address
 #define BWD_GLOAD_KV(tile)                                                                           \
     do {                                                                                             \
         int r0_ = (tile) * 64 + srow0; r0_ = r0_ < a.Tk ? r0_ : a.Tk - 1;                            \
@@ -265,6 +275,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwdArgs a
         k1 = *reinterpret_cast<const uint4*>(kbase + (long)r1_ * a.k_rs + sc * 8);                   \
         v0 = *reinterpret_cast<const uint4*>(vbase + (long)r0_ * a.v_rs + sc * 8);                   \
         v1 = *reinterpret_cast<const uint4*>(vbase + (long)r1_ * a.v_rs + sc * 8);                   \
+        {   /* key-padding byte of this thread's key of the tile, prefetched WITH the tile (unconditional: stand-in address without a mask) */ \
+            const int kk_ = (tile) * 64 + (tid & 63);                                                \
+            mbyte = mrow[a.kpm ? (kk_ < a.Tk ? kk_ : a.Tk - 1) : 0];                                 \
+        }                                                                                            \
     } while (0)
 
     f32x16_t dq[2];
@@ -279,9 +293,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwdArgs a
         *reinterpret_cast<uint4*>(Vr + srow0 * RS + sc * 8) = v0; *reinterpret_cast<uint4*>(Vr + srow1 * RS + sc * 8) = v1;
         if (tid < 64) {
             const int kk = tile * 64 + tid;
-            unsigned char code = 0;
-            if (kk < a.Tk) code = (a.kpm == nullptr || a.kpm[(long)b * a.kpm_bs + kk]) ? 2 : 1;
-            Ms[tid] = code;
+            Ms[tid] = kk < a.Tk ? ((a.kpm == nullptr || mbyte) ? 2 : 1) : 0;      // 0 = beyond Tk, 1 = masked, 2 = attend
         }
         __syncthreads();
         if (tile + 1 < ntiles) BWD_GLOAD_KV(tile + 1);
