@@ -188,6 +188,83 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs& g, const int bid, c
             }
         __syncthreads();
         constexpr int CPRW = WCOLS / 8;                          // 8-column chunks per sub-tile row
+        if ((g.N & 7) == 0 && !(g.act == 2 && g.residual)) {
+            // Every global READ of the epilogue (residual, saved pre-activation, DropPath factor) is issued up front for all CPRW passes,
+            // unconditionally (clamped rows / columns), and only the stores are guarded: with the loads inside the per-lane `m < M && n < N`
+            // guard hipcc branches around each and waits vmcnt(0) behind it -- CPRW dependent memory round trips per tile.
+            uint4 rop[CPRW];                                     // residual OR saved pre-activation (never both on this path: register budget)
+            float rsc[CPRW];
+            const bool rd_aux = g.act == 2;
+            const bf16_t* opp = rd_aux ? g.aux : g.residual;
+            const long ldop = rd_aux ? g.ldaux : g.ldr;
+#pragma unroll
+            for (int it = 0; it < CPRW; ++it) {
+                const int c = it * 64 + lane;
+                const int row = c / CPRW, cc = c % CPRW;
+                int m = tm * BM + wm * 64 + row, n = tn * BN + wn * WCOLS + cc * 8;
+                m = m < g.M ? m : g.M - 1; n = n < g.N ? n : g.N - 8;
+                if (opp) rop[it] = *reinterpret_cast<const uint4*>(opp + (long)m * ldop + n);
+                if (g.row_scale) rsc[it] = g.row_scale[(unsigned)m / (unsigned)g.rs_rows];
+            }
+#pragma unroll
+            for (int it = 0; it < CPRW; ++it) {
+                const int c = it * 64 + lane;
+                const int row = c / CPRW, cc = c % CPRW;
+                const int m = tm * BM + wm * 64 + row;
+                const int n = tn * BN + wn * WCOLS + cc * 8;
+                const bool ok = m < g.M && n < g.N;
+                const int sw = row & (WCOLS / 4 - 1);
+                const float4 lo = *reinterpret_cast<const float4*>(stg + row * WCOLS + (((2 * cc) ^ sw) << 2));
+                const float4 hi = *reinterpret_cast<const float4*>(stg + row * WCOLS + (((2 * cc + 1) ^ sw) << 2));
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                if (g.act == 1) {
+                    if (g.aux && ok) *reinterpret_cast<uint4*>(g.aux + (long)m * g.ldaux + n) = pack8(v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+                } else if (rd_aux) {
+                    float a8[8];
+                    unpack8(rop[it], a8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(a8[j]);
+                }
+                if (g.drop_thr16) {
+                    const uint32_t dkey = dropout_row_key(dseed, g.drop_site, (uint32_t)(m / g.drop_rows_per_b), (uint32_t)(g.drop_t0 + m % g.drop_rows_per_b));
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const uint32_t bits = dropout_pair_bits(dkey, (uint32_t)(n + j) >> 1);
+                        v[j] = (bits & 0xffffu) >= g.drop_thr16 ? v[j] * g.drop_inv : 0.f;
+                        v[j + 1] = (bits >> 16) >= g.drop_thr16 ? v[j + 1] * g.drop_inv : 0.f;
+                    }
+                }
+                const float rscale = g.row_scale ? rsc[it] : 1.0f;
+                if (g.row_scale && !g.rs_after) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= rscale;
+                }
+                if (g.residual) {
+                    float a8[8];
+                    unpack8(rop[it], a8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += a8[j];
+                }
+                if (g.row_scale && g.rs_after) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= rscale;
+                }
+                if (g.out_f32) {
+                    float* cp = reinterpret_cast<float*>(g.C) + (long)(ok ? m : 0) * g.ldc + (ok ? n : 0);
+                    float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+                    if (g.accumulate && ok) {
+                        const float4 p0 = *reinterpret_cast<const float4*>(cp), p1 = *reinterpret_cast<const float4*>(cp + 4);
+                        o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w; o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
+                    }
+                    if (ok) { *reinterpret_cast<float4*>(cp) = o0; *reinterpret_cast<float4*>(cp + 4) = o1; }
+                } else if (ok) {
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = pack8(v);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < CPRW; ++it) {
             const int c = it * 64 + lane;

@@ -105,13 +105,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
     for (long base = (long)blockIdx.x * rows_per_block; base < rows; base += (long)gridDim.x * rows_per_block) {
         uint4 xr[U][L::CPL], dr[U][L::CPL], ar[U][L::CPL];
         long row[U];
-        float mean[U], rstd[U];
+        float mean[U], rstd[U], rsf[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             row[u] = base + u * 4 * L::RPW + wave * L::RPW + grp;
             const bool live = row[u] < rows;
             const long rc = live ? row[u] : rows - 1;
             mean[u] = stats[2 * rc]; rstd[u] = stats[2 * rc + 1];
+            // the DropPath factor of the row, fetched WITH the row (unconditional, stand-in address when unused): loaded where it is used, after
+            // the dx store, it was a dependent round trip (load + s_waitcnt vmcnt(0)) per row in the middle of the loop
+            rsf[u] = (dd.row_scale ? dd.row_scale : stats)[dd.row_scale ? (uint32_t)rc / (uint32_t)dd.rows_per_b : 0u];      // (32-bit division: rows < 2^31)
 #pragma unroll
             for (int i = 0; i < L::CPL; ++i) {
                 const int ch = sub + i * L::LPR;
@@ -163,11 +166,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
                     *reinterpret_cast<uint4*>(dx + row[u] * lddx + ch * 8) = pack8(o);
                     if (dd.dx2) {
                         if (dd.row_scale) {
-                            const float f = dd.row_scale[row[u] / dd.rows_per_b];
+                            const float f = rsf[u];
 #pragma unroll
                             for (int j = 0; j < 8; ++j) o[j] *= f;
                         } else {
-                            const uint32_t key = dropout_row_key(dseed, dd.site, (uint32_t)(row[u] / dd.rows_per_b), (uint32_t)(dd.t0 + (int)(row[u] % dd.rows_per_b)));
+                            const uint32_t rq = (uint32_t)row[u] / (uint32_t)dd.rows_per_b;          // (32-bit: a 64-bit division is ~150 VALU instructions)
+                            const uint32_t key = dropout_row_key(dseed, dd.site, rq, (uint32_t)(dd.t0 + (int)((uint32_t)row[u] - rq * (uint32_t)dd.rows_per_b)));
 #pragma unroll
                             for (int j = 0; j < 8; j += 2) {
                                 const uint32_t bits = dropout_pair_bits(key, (uint32_t)(ch * 8 + j) >> 1);
