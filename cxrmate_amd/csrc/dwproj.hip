@@ -55,22 +55,25 @@ __device__ __forceinline__ Dw3Blk dw3_block(const Dw3Geo& g) {
 __device__ __forceinline__ void dw3_stage(uint4* tile, const bf16_t* __restrict__ src, long rs, int H, int W, int iy0, int rows, int ix0, int cols) {
     const int total = rows * cols * 8;
     for (int s0 = threadIdx.x; s0 < total; s0 += DW3_THREADS * 4) {
+        // UNCONDITIONAL loads (coordinates clamped into the map, the zero padding applied by a select afterwards): guarded by the per-lane
+        // "inside the map" test, hipcc branches around every load and waits vmcnt(0) behind it -- the four loads became four dependent round trips
         uint4 v[4];
+        bool ok[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int s = s0 + u * DW3_THREADS;
-            v[u] = make_uint4(0, 0, 0, 0);
-            if (s < total) {
-                const int ch = s & 7, pix = s >> 3;
-                const int rr = pix / cols, cc = pix - rr * cols;
-                const int iy = iy0 + rr, ix = ix0 + cc;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v[u] = *reinterpret_cast<const uint4*>(src + (long)(iy * W + ix) * rs + ch * 8);
-            }
+            const int sc = s < total ? s : 0;
+            const int ch = sc & 7, pix = sc >> 3;
+            const int rr = pix / cols, cc = pix - rr * cols;
+            const int iy = iy0 + rr, ix = ix0 + cc;
+            ok[u] = s < total && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int iyc = iy < 0 ? 0 : (iy < H ? iy : H - 1), ixc = ix < 0 ? 0 : (ix < W ? ix : W - 1);
+            v[u] = *reinterpret_cast<const uint4*>(src + (long)(iyc * W + ixc) * rs + ch * 8);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int s = s0 + u * DW3_THREADS;
-            if (s < total) tile[s] = v[u];
+            if (s < total) tile[s] = ok[u] ? v[u] : make_uint4(0, 0, 0, 0);
         }
     }
 }
@@ -117,10 +120,10 @@ __device__ __forceinline__ void dw3_stage_taps(float (*wl)[12][64], const Dw3Geo
     for (int i = threadIdx.x; i < g.nproj * rows * 64; i += DW3_THREADS) {
         const int q = i / (rows * 64), r = (i / 64) % rows, c = i % 64;
         const Dw3P& P = q == 0 ? p0 : (q == 1 ? p1 : p2);
-        float v = 0.f;
-        if (r < 9) v = P.taps[r * g.C + slice * 64 + c];
-        else if (P.aux) v = P.aux[(r - 9) * g.C + slice * 64 + c];
-        wl[q][r][c] = v;
+        // (unconditional load through a selected pointer: see dw3_stage)
+        const float* sp = r < 9 ? P.taps + r * g.C : (P.aux ? P.aux + (r - 9) * g.C : P.taps);
+        const float v = sp[slice * 64 + c];
+        wl[q][r][c] = (r < 9 || P.aux) ? v : 0.f;
     }
 }
 
