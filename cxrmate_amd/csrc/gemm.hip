@@ -173,17 +173,22 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs& g, const int bid, c
     if (LDS_EPI_FITS && g.lds_epilogue) {
         __syncthreads();                                         // every wave has finished reading the last K step's fragments
         float* stg = reinterpret_cast<float*>(lds) + wave * (64 * WCOLS);
+        // the lane's bias values: NTL unconditional loads (clamped column) issued together -- per (mt, nt) and guarded by `n0 < N` they were
+        // 4 * NTL branch + load + s_waitcnt vmcnt(0) sequences in front of the LDS writes
+        float4 bv[NTL];
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) {
+            const int n0 = tn * BN + wn * WCOLS + (nt * 4 + fq) * 4;
+            bv[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.bias) bv[nt] = *reinterpret_cast<const float4*>(g.bias + (n0 < g.N ? n0 : g.N - 4));      // (uniform branch; N % 4 == 0)
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt) {
                 const int row = mt * 16 + fr, c4 = nt * 4 + fq;
-                float4 v = make_float4(acc[nt][mt][0] * g.alpha, acc[nt][mt][1] * g.alpha, acc[nt][mt][2] * g.alpha, acc[nt][mt][3] * g.alpha);
-                const int n0 = tn * BN + wn * WCOLS + c4 * 4;
-                if (g.bias && n0 < g.N) {
-                    const float4 b = *reinterpret_cast<const float4*>(g.bias + n0);
-                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-                }
+                float4 v = make_float4(acc[nt][mt][0] * g.alpha + bv[nt].x, acc[nt][mt][1] * g.alpha + bv[nt].y, acc[nt][mt][2] * g.alpha + bv[nt].z,
+                                       acc[nt][mt][3] * g.alpha + bv[nt].w);
                 *reinterpret_cast<float4*>(stg + row * WCOLS + ((c4 ^ (row & (WCOLS / 4 - 1))) << 2)) = v;
             }
         __syncthreads();

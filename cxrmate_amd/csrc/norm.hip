@@ -24,23 +24,41 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % L::LPR, grp = lane / L::LPR;
     const long rows_per_block = 4 * L::RPW * U;
+    // gamma / beta of this lane's chunks: once per kernel (they were re-loaded per row inside the loop)
+    float gg[L::CPL][8], bb[L::CPL][8];
+#pragma unroll
+    for (int i = 0; i < L::CPL; ++i) {
+        const int ch = sub + i * L::LPR, cc = ch < L::CH ? ch : 0;
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + cc * 8), g1 = *reinterpret_cast<const float4*>(gamma + cc * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(beta + cc * 8), b1 = *reinterpret_cast<const float4*>(beta + cc * 8 + 4);
+        gg[i][0] = g0.x; gg[i][1] = g0.y; gg[i][2] = g0.z; gg[i][3] = g0.w; gg[i][4] = g1.x; gg[i][5] = g1.y; gg[i][6] = g1.z; gg[i][7] = g1.w;
+        bb[i][0] = b0.x; bb[i][1] = b0.y; bb[i][2] = b0.z; bb[i][3] = b0.w; bb[i][4] = b1.x; bb[i][5] = b1.y; bb[i][6] = b1.z; bb[i][7] = b1.w;
+    }
     for (long base = (long)blockIdx.x * rows_per_block; base < rows; base += (long)gridDim.x * rows_per_block) {
         float v[U][L::CPL][8];
         long row[U];
+        // UNCONDITIONAL loads (row / chunk clamped, dead lanes zeroed by a select): behind the per-lane `row < rows && ch < CH` guard hipcc
+        // branched around every load and waited vmcnt(0) after it -- U * CPL dependent round trips instead of U * CPL loads in flight
+        uint4 raw[U][L::CPL];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             row[u] = base + u * 4 * L::RPW + wave * L::RPW + grp;
+            const long rc = row[u] < rows ? row[u] : rows - 1;
 #pragma unroll
             for (int i = 0; i < L::CPL; ++i) {
-                const int ch = sub + i * L::LPR;
-                if (row[u] < rows && ch < L::CH) {
-                    unpack8(*reinterpret_cast<const uint4*>(x + row[u] * ldx + ch * 8), v[u][i]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[u][i][j] = 0.f;
-                }
+                const int ch = sub + i * L::LPR, cc = ch < L::CH ? ch : 0;
+                raw[u][i] = *reinterpret_cast<const uint4*>(x + rc * ldx + cc * 8);
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < L::CPL; ++i) {
+                unpack8(raw[u][i], v[u][i]);
+                const bool on = row[u] < rows && sub + i * L::LPR < L::CH;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[u][i][j] = on ? v[u][i][j] : 0.f;
+            }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float s = 0.f;
@@ -63,13 +81,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
             for (int i = 0; i < L::CPL; ++i) {
                 const int ch = sub + i * L::LPR;
                 if (ch < L::CH) {
-                    const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch * 8), g1 = *reinterpret_cast<const float4*>(gamma + ch * 8 + 4);
-                    const float4 b0 = *reinterpret_cast<const float4*>(beta + ch * 8), b1 = *reinterpret_cast<const float4*>(beta + ch * 8 + 4);
-                    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-                    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
                     float o[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (v[u][i][j] - mean) * rstd * gg[j] + bb[j];
+                    for (int j = 0; j < 8; ++j) o[j] = (v[u][i][j] - mean) * rstd * gg[i][j] + bb[i][j];
                     *reinterpret_cast<uint4*>(y + row[u] * ldy + ch * 8) = pack8(o);
                 }
             }
