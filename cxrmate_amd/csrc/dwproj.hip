@@ -277,10 +277,22 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_bwd_stats_kernel(const Dw3
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         int oy0;
         const int npo = dw3_band_outputs(g, P, k.band_i, oy0);
+        // the gradient rows are prefetched two iterations ahead (unconditional, index clamped): loaded where it is used, every iteration of
+        // this loop was one exposed global round trip
+        const bf16_t* ybase = yb + (long)(g.tok0 + oy0 * P.Wo) * P.y_rs;
+        const int last = npo > 0 ? npo - 1 : 0;
+        uint4 dq0 = make_uint4(0, 0, 0, 0), dq1 = dq0;
+        if (npo > 0) {                                             // (block-uniform: a band past the last output row reads nothing)
+            dq0 = *reinterpret_cast<const uint4*>(ybase + (long)min(k.pl, last) * P.y_rs);
+            dq1 = *reinterpret_cast<const uint4*>(ybase + (long)min(k.pl + DW3_PL, last) * P.y_rs);
+        }
         for (int o = k.pl; o < npo; o += DW3_PL) {
             const int oyl = o / P.Wo, ox = o - oyl * P.Wo;
             float d[8], c[8];
-            unpack8(*reinterpret_cast<const uint4*>(yb + (long)(g.tok0 + (oy0 + oyl) * P.Wo + ox) * P.y_rs), d);
+            const uint4 dcur = dq0;
+            dq0 = dq1;
+            dq1 = *reinterpret_cast<const uint4*>(ybase + (long)min(o + 2 * DW3_PL, last) * P.y_rs);
+            unpack8(dcur, d);
             dw3_conv(dw3_tile, (oyl * P.stride * pitch + ox * P.stride) * 8 + k.ch, pitch8, w, c);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { acc[j] += d[j]; acc[8 + j] = fmaf(d[j], c[j], acc[8 + j]); }
@@ -313,12 +325,23 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_dc_taps_kernel(const Dw3Ge
         for (int i = 0; i < 80; ++i) G[i] = 0.f;
         int oy0;
         const int npo = dw3_band_outputs(g, P, k.band_i, oy0);
+        // (gradient rows prefetched two iterations ahead, as in dw3_bwd_stats_kernel; every pixel is read and rewritten by its own iteration only)
+        bf16_t* ybase = yb + (long)(g.tok0 + oy0 * P.Wo) * P.y_rs;
+        const int last = npo > 0 ? npo - 1 : 0;
+        uint4 dq0 = make_uint4(0, 0, 0, 0), dq1 = dq0;
+        if (npo > 0) {                                             // (block-uniform: a band past the last output row reads nothing)
+            dq0 = *reinterpret_cast<const uint4*>(ybase + (long)min(k.pl, last) * P.y_rs);
+            dq1 = *reinterpret_cast<const uint4*>(ybase + (long)min(k.pl + DW3_PL, last) * P.y_rs);
+        }
         for (int o = k.pl; o < npo; o += DW3_PL) {
             const int oyl = o / P.Wo, ox = o - oyl * P.Wo;
             const int base = (oyl * P.stride * pitch + ox * P.stride) * 8 + k.ch;
-            bf16_t* dp = yb + (long)(g.tok0 + (oy0 + oyl) * P.Wo + ox) * P.y_rs;
+            bf16_t* dp = ybase + (long)o * P.y_rs;
             float d[8];
-            unpack8(*reinterpret_cast<const uint4*>(dp), d);
+            const uint4 dcur = dq0;
+            dq0 = dq1;
+            dq1 = *reinterpret_cast<const uint4*>(ybase + (long)min(o + 2 * DW3_PL, last) * P.y_rs);
+            unpack8(dcur, d);
             float f[9][8];                                       // the 3 x 3 input window, unpacked ONCE for the conv and the tap sums
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
