@@ -114,6 +114,28 @@ class _DecoderModule(_Node):
 
 
 # ---------------------------------------------------------------------------------------------------- models
+class _CrossEntropyFn(torch.autograd.Function):
+    """`CrossEntropyLoss()(logits.reshape(-1, V), labels.reshape(-1))` of the reference's forward(labels=...) on the fused loss kernel
+    (csrc/loss.hip: log-softmax + nll + d(logits) in one pass over the vocabulary row; ignore_index = -100, mean over the counted labels)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        V = logits.shape[-1]
+        flat = logits.detach().reshape(-1, V)
+        flat = flat if flat.stride(1) == 1 else flat.contiguous()
+        lab = labels.reshape(-1).to(torch.int64).contiguous()
+        w = ops.ce_weights(lab, -100, mode=0)
+        loss, _, dl = ops.softmax_ce(flat, lab, -100, w, need_grad=True)
+        ctx.save_for_backward(dl)
+        ctx.shape = logits.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return (dl.float() * g).view(ctx.shape), None
+
+
 class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
     kind = "single"
     main_input_name = "pixel_values"
@@ -225,7 +247,7 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
                                  kwargs_decoder.get("position_ids"), embeds=decoder_inputs_embeds)
         loss = None
         if labels is not None:
-            loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1))
+            loss = _CrossEntropyFn.apply(logits, labels.to(logits.device))    # CrossEntropyLoss(): mean over labels != -100 (reference :239-241)
         out = ModelOutput(loss=loss, logits=logits, past_key_values=None, encoder_last_hidden_state=enc)
         if return_dict is False:
             return out.to_tuple()

@@ -780,3 +780,31 @@ def test_fp8_encoder_against_the_fp32_reference_fixture(M):
     assert not torch.equal(before.view(torch.uint8), m._enc.fp8["w"][wname][0].view(torch.uint8)) or abs(m._enc.fp8["w"][wname][1]) > 0
     m.load_state_dict(sd)
     assert m._enc.fp8 is None
+
+
+def test_forward_with_labels_matches_torch_cross_entropy(M):
+    """forward(labels=...) (reference modelling_single.py:205-210: CrossEntropyLoss() over the flattened logits, ignore_index -100): the loss and the
+    gradient that reaches the parameters equal torch's cross entropy applied to the same logits."""
+    g, cfg, sd, x = gu.generate_multi_case()
+    m = M.MultiCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    for p in m.parameters():
+        p.requires_grad_(True)
+    torch.manual_seed(0)
+    ids = torch.randint(5, cfg.decoder.vocab_size, (3, 9), device="cuda")
+    labels = ids.roll(-1, 1).clone()
+    labels[:, -1] = -100
+    labels[1, 3:] = -100
+    tt = m.token_ids_to_token_type_ids(ids, [gu.SEP])
+    out = m(pixel_values=x.cuda(), decoder_input_ids=ids, decoder_token_type_ids=tt, labels=labels)
+    ref = torch.nn.functional.cross_entropy(out.logits.detach().float().reshape(-1, cfg.decoder.vocab_size), labels.reshape(-1))
+    assert abs(float(out.loss.detach()) - float(ref)) < 2e-3
+    name = "decoder.cls.predictions.bias"
+    m.zero_grad()
+    out.loss.backward()
+    g1 = m.param(name).grad.detach().clone()
+    m.zero_grad()
+    out2 = m(pixel_values=x.cuda(), decoder_input_ids=ids, decoder_token_type_ids=tt)
+    torch.nn.functional.cross_entropy(out2.logits.float().reshape(-1, cfg.decoder.vocab_size), labels.reshape(-1)).backward()
+    g2 = m.param(name).grad.detach()
+    assert gu.rel_rms(g1.cpu().numpy(), g2.cpu().numpy()) < 2e-2
