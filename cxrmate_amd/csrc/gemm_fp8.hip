@@ -140,6 +140,17 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const Fp8Args g) {
         const int cr = lane / CPR, cc = (lane % CPR) * 8;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            // residual chunks and DropPath factors of this half's passes: issued up front, unconditional (clamped row / column) -- inside the
+            // per-lane `m < M && n < N` guard below every one of them would be a branch + load + s_waitcnt vmcnt(0)
+            uint4 rres[32 / RPI];
+            float rsv[32 / RPI];
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int mc = min(m0 + wm * 64 + i * 32 + it * RPI + cr, g.M - 1), nc = min(n0 + wn * WCOLS + cc, g.N - 8);
+                rres[it] = make_uint4(0, 0, 0, 0);
+                if (g.residual) rres[it] = *reinterpret_cast<const uint4*>(g.residual + (long)mc * g.ldr + nc);      // (uniform branch)
+                rsv[it] = g.row_scale ? g.row_scale[(unsigned)mc / (unsigned)g.rs_rows] : 1.f;
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -156,14 +167,14 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const Fp8Args g) {
                 const float4 lo = *reinterpret_cast<const float4*>(&T[rr * WCOLS + cc]), hi = *reinterpret_cast<const float4*>(&T[rr * WCOLS + cc + 4]);
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 if (m < g.M && n < g.N) {
-                    const float rs = g.row_scale ? g.row_scale[m / g.rs_rows] : 1.f;
+                    const float rs = rsv[it];
                     if (!g.rs_after) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] *= rs;
                     }
                     if (g.residual) {
                         float r[8];
-                        unpack8(*reinterpret_cast<const uint4*>(g.residual + (long)m * g.ldr + n), r);
+                        unpack8(rres[it], r);
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] += r[q];
                     }
