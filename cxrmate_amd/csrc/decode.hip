@@ -891,6 +891,188 @@ extern "C" int cxr_pack_mask_bits(const void* kpm, long kpm_bs, int B, int T, un
     return CXR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Cross-attention of a cached decode step on the matrix cores. The cross K/V of a study are static for a whole decode and shared by all of its
+// rows (sample + greedy: 2, beams: 4), so V is ALSO kept transposed per head (VT [Bkv, H*64, Tk], written once at prefill): then both products of
+// a 32-key block are MFMAs whose operands are single 16-byte loads per lane straight from HBM, with no data movement in between:
+//   S^T[keys x queries] = K . Q^T   A = K rows (16 keys x 32 dims per instruction), B = Q^T (dims x 16 query columns, G of them real)
+//   O[queries x dims]   = P . V     A = P (the S^T accumulators ARE this fragment when a block's two 16-key tiles interleave the keys
+//                                       {8g + r} / {8g + 4 + r}: lane (query, g) then owns keys 8g .. 8g+7 in order), B = VT rows
+// Up to 16 query rows cost what one costs. One workgroup = (study, head), 12 waves, wave w owns key blocks w, w+12, w+24 (Tk <= 1152 = a 2-image
+// study), all 24 loads of a wave in flight before the first MFMA; softmax over the whole key range with two workgroup reductions (max, then sum and
+// numerators); probabilities enter P.V as bf16 (as in the teacher-forced kernels). The VALU kernel above spends 4.8 us per (study, head) on the
+// dot products / softmax and 3.8 us merging 16 wave states; this one has ~60 MFMAs and two LDS reductions.
+struct AttnXArgs {
+    const bf16_t* Q; const bf16_t* Kp; const bf16_t* Vp; bf16_t* O; const uint32_t* mbits; const uint32_t* drop_seed;
+    long q_bs, o_bs, mb_bs;                         // mb_bs in 32-bit words
+    int H, Tk, Bkv, G, drop_t, o_mt;
+    float scale_log2e, drop_inv; uint32_t drop_site, drop_thr16, has_mask;
+};
+
+// Fragment-ordered copies of a study's cross-attention K and V (written once at prefill, like the packed decode weights): block = 32 keys of one
+// head. Kp[(b*H + h)*nblk + blk][t][ks][lane][8] = K[key = blk*32 + 8*(m>>2) + 4*t + (m&3)][h*64 + ks*32 + 8*g + j] (m = lane & 15, g = lane >> 4):
+// the A fragments of the block's two interleaved 16-key tiles; Vp[(b*H + h)*nblk + blk][dt][lane][8] = V[key = blk*32 + 8*g + j][h*64 + dt*16 + m]:
+// the B fragments of P.V. Every fragment is 1 KB contiguous: the decode kernel's loads are 16 bytes per lane, fully coalesced, and can be
+// non-temporal (a row-major K gives the MFMA operand layout 64-byte pieces, which only merge through L1 -- i.e. not with streaming loads, and
+// plain loads push the decoder weights out of the Infinity Cache: measured +15 us per token-step on the GEMMs that follow).
+__global__ __launch_bounds__(256) void pack_cross_kv_kernel(const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, long kv_bs, long kv_rs,
+                                                            bf16_t* __restrict__ Kp, bf16_t* __restrict__ Vp, int H, int nblk) {
+    __shared__ __attribute__((aligned(16))) bf16_t ks_[32][64 + 8], vs_[32][64 + 8];
+    const int blk = blockIdx.x % nblk, bh = blockIdx.x / nblk, h = bh % H, b = bh / H;
+    const int tid = threadIdx.x;
+    {
+        const int r = tid >> 3, c = (tid & 7) * 8;                                                   // 32 rows x 8 chunks of 16 bytes
+        const long off = (long)b * kv_bs + (long)(blk * 32 + r) * kv_rs + h * 64 + c;
+        *reinterpret_cast<uint4*>(&ks_[r][c]) = *reinterpret_cast<const uint4*>(K + off);
+        *reinterpret_cast<uint4*>(&vs_[r][c]) = *reinterpret_cast<const uint4*>(V + off);
+    }
+    __syncthreads();
+    const int lane = tid & 63, f = tid >> 6, m = lane & 15, g = lane >> 4;                          // fragment f of 4, lane of 64
+    {
+        const int t = f >> 1, ksx = f & 1;
+        const int key = 8 * (m >> 2) + 4 * t + (m & 3);
+        *reinterpret_cast<uint4*>(Kp + (((long)blockIdx.x * 4 + f) * 64 + lane) * 8) = *reinterpret_cast<const uint4*>(&ks_[key][ksx * 32 + g * 8]);
+    }
+    {
+        const int dt = f;
+        s16x8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (short)vs_[8 * g + j][dt * 16 + m];
+        *reinterpret_cast<s16x8_t*>(Vp + (((long)blockIdx.x * 4 + f) * 64 + lane) * 8) = o;
+    }
+}
+extern "C" int cxr_pack_cross_kv_bf16(const void* K, const void* V, long kv_bs, long kv_rs, void* Kp, void* Vp, int Bkv, int H, int Tk, hipStream_t stream) {
+    if (Bkv <= 0 || H <= 0 || Tk <= 0 || (Tk % 32) || (kv_rs % 8) || (kv_bs % 8)) return CXR_ERR_ARG;
+    CXR_LAUNCH(pack_cross_kv_kernel, dim3((unsigned)(Bkv * H * (Tk / 32))), dim3(256), 0, stream, (const bf16_t*)K, (const bf16_t*)V, kv_bs, kv_rs, (bf16_t*)Kp,
+               (bf16_t*)Vp, H, Tk / 32);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+template <int MAXB>
+__global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a) {
+    __shared__ float wmax[12][16], wsum[12][16];
+    __shared__ float wo[12][4][64];                  // per-wave numerators of up to 4 query rows... (G <= 4 here; see the entry point)
+    asm volatile("" :: "s"(a.Q), "s"(a.Kp), "s"(a.Vp), "s"(a.mbits), "s"(a.drop_seed), "s"(a.q_bs), "s"(a.mb_bs), "s"(a.H), "s"(a.Tk), "s"(a.Bkv), "s"(a.G));
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
+    const int qi = lane & 15, g4 = lane >> 4;
+    const int nblk = a.Tk >> 5;
+    const bf16_t* kp = a.Kp + (long)blockIdx.x * nblk * 2048 + lane * 8;                // 4 fragments of 64 x 8 elements per block
+    const bf16_t* vp = a.Vp + (long)blockIdx.x * nblk * 2048 + lane * 8;
+    // ---- every load of the wave first: K fragments (2 tiles x 2 k-steps) and V fragments (4 dim tiles) of its blocks, 1 KB contiguous each
+    bf16x8_t kf[MAXB][2][2], vf[MAXB][4];
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        int blk = wave + 12 * i; blk = blk < nblk ? blk : nblk - 1;                       // (blocks past the range re-read the last one; masked below)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) kf[i][t][ks] = __builtin_bit_cast(bf16x8_t, nt_load16(kp + ((long)blk * 4 + t * 2 + ks) * 512));
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vf[i][dt] = __builtin_bit_cast(bf16x8_t, nt_load16(vp + ((long)blk * 4 + dt) * 512));
+    }
+    // queries (B operand: column qi = query row b + qi * Bkv; columns >= G are zero), mask words, seed
+    const int qrow = b + (qi < a.G ? qi : 0) * a.Bkv;
+    bf16x8_t qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        uint4 qv = *reinterpret_cast<const uint4*>(a.Q + (long)qrow * a.q_bs + h * 64 + ks * 32 + g4 * 8);
+        if (qi >= a.G) qv = make_uint4(0, 0, 0, 0);
+        qf[ks] = __builtin_bit_cast(bf16x8_t, qv);
+    }
+    uint32_t mw[MAXB];
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        int blk = wave + 12 * i; blk = blk < nblk ? blk : nblk - 1;
+        mw[i] = (a.has_mask ? a.mbits + (long)b * a.mb_bs : a.drop_seed)[a.has_mask ? blk : 0];
+    }
+    const uint32_t dseed = a.drop_seed[vzero];
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- scores (exp2 domain), masked
+    f32x4_t sc[MAXB][2];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const bool live = wave + 12 * i < nblk;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i][t][0], qf[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i][t][1], qf[1], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kin = 8 * g4 + 4 * t + r;                                          // key inside the block
+                const bool ok = !a.has_mask || ((mw[i] >> kin) & 1u);
+                const float v = live ? (ok ? acc[r] * a.scale_log2e : -1.0e30f) : -3.0e38f;  // masked: finite sentinel; past the range: p = 0
+                acc[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            sc[i][t] = acc;
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (g4 == 0) wmax[wave][qi] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 12; ++w) mx = fmaxf(mx, wmax[w][qi]);
+    // ---- probabilities, dropout (train mode), P . V
+    const uint32_t dkey = dropout_row_key(dseed, a.drop_site, (uint32_t)(qrow * a.H + h), (uint32_t)a.drop_t);
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int blk = wave + 12 * i;
+        float p[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(sc[i][t][r] - mx);
+                lsum += e;
+                p[4 * t + r] = e;
+            }
+        if (a.drop_thr16) {
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {                                                 // keys 8 g4 + j, + j + 1: one hash word per pair
+                const uint32_t bits = dropout_pair_bits(dkey, (uint32_t)(blk * 32 + 8 * g4 + j) >> 1);
+                p[j] = (bits & 0xffffu) >= a.drop_thr16 ? p[j] * a.drop_inv : 0.f;
+                p[j + 1] = (bits >> 16) >= a.drop_thr16 ? p[j + 1] * a.drop_inv : 0.f;
+            }
+        }
+        s16x8_t pv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv[j] = (short)f2bf(p[j]);
+        const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pv);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf[i][dt], o[dt], 0, 0, 0);
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (g4 == 0) wsum[wave][qi] = lsum;
+    // numerators: C layout of o[dt] = (query row 4 g4 + r, dim dt * 16 + qi): the G <= 4 real queries sit in lane group g4 == 0
+    if (g4 == 0) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wo[wave][r][dt * 16 + qi] = o[dt][r];
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * a.G; e += 768) {
+        const int g = e >> 6, d = e & 63;
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 12; ++w) { num += wo[w][g][d]; den += wsum[w][g]; }
+        const int row = b + g * a.Bkv;
+        a.O[a.o_mt ? dal_off(row, h * 64 + d, a.o_mt) : (long)row * a.o_bs + h * 64 + d] = f2bf(num / den);
+    }
+}
+
 // O[b,h,:] from the nsplit (<= 8) partial states of attn_decode_kernel: one 64-lane wave per (query row, head). All partial states are
 // requested up front (unused slots re-read slot 0), so the launch costs one memory round trip.
 __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const float* __restrict__ ws, bf16_t* __restrict__ O, long o_bs, int H, int nsplit, int rows,
@@ -973,6 +1155,32 @@ extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V,
 #undef ATTN_DEC_L
 #undef ATTN_DEC
     if (nsplit > 1) CXR_LAUNCH(attn_decode_merge_kernel, dim3(cdiv(B * H, 4)), dim3(256), 0, stream, ws, (bf16_t*)O, o_bs, H, nsplit, B * H, a.o_mt);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// Cross-attention decode step on the matrix cores (attn_cross_mfma_kernel). Q [B rows, H*64] bf16 (row stride q_bs); Kp / Vp = fragment-ordered K / V of
+// the Bkv studies (cxr_pack_cross_kv_bf16, Bkv*Tk*H*64 elements each); kpm_bits uint32 [Bkv][mb_words] or NULL; O as in cxr_attn_decode_bf16
+// (o_dal: decode activation layout). kv_share = B / Bkv query rows per K/V stream, <= 4. Tk % 32 == 0, Tk <= 1152.
+extern "C" int cxr_attn_cross_mfma_bf16(const void* Q, const void* Kp, const void* Vp, void* O, const unsigned int* kpm_bits, long q_bs, long o_bs,
+                                        long mb_words, int B, int H, int Tk, float scale, int kv_share, float drop_p, const unsigned int* drop_seed,
+                                        unsigned int drop_site, int drop_t, int o_dal, hipStream_t stream) {
+    if (B <= 0 || H <= 0 || Tk <= 0 || (Tk % 32) || Tk > 1152 || kv_share < 1 || kv_share > 4 || (B % kv_share) || (q_bs % 8) || ((uintptr_t)Kp % 16) ||
+        ((uintptr_t)Vp % 16) || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed) || (o_dal && B > 64))
+        return CXR_ERR_ARG;
+    AttnXArgs a;
+    a.Q = (const bf16_t*)Q; a.Kp = (const bf16_t*)Kp; a.Vp = (const bf16_t*)Vp; a.O = (bf16_t*)O; a.mbits = kpm_bits;
+    a.drop_seed = drop_seed ? drop_seed : (const uint32_t*)Kp;
+    a.q_bs = q_bs; a.o_bs = o_bs; a.mb_bs = mb_words;
+    a.H = H; a.Tk = Tk; a.Bkv = B / kv_share; a.G = kv_share; a.drop_t = drop_t;
+    a.o_mt = o_dal ? (cdiv(B, 16) == 3 ? 4 : cdiv(B, 16)) : 0;
+    a.scale_log2e = scale * 1.4426950408889634f; a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_site = drop_site;
+    a.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u; a.has_mask = kpm_bits ? 1u : 0u;
+    const dim3 grid(a.Bkv * H);
+    const int nblk = Tk / 32;
+    if (nblk <= 12) CXR_LAUNCH(attn_cross_mfma_kernel<1>, grid, dim3(768), 0, stream, a);
+    else if (nblk <= 24) CXR_LAUNCH(attn_cross_mfma_kernel<2>, grid, dim3(768), 0, stream, a);
+    else CXR_LAUNCH(attn_cross_mfma_kernel<3>, grid, dim3(768), 0, stream, a);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

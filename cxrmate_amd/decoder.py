@@ -30,6 +30,7 @@ _CROSS_KV_FUSED = os.environ.get("CXR_CROSS_KV_FUSED", "1") != "0"      # A/B sw
 _LORA_IN_KERNEL = os.environ.get("CXR_LORA_IN_KERNEL", "1") != "0"        # A/B switch: 0 = separate LoRA down-projection launch per decode layer
 _SELF_QKV_FUSED = os.environ.get("CXR_SELF_QKV_FUSED", "1") != "0"      # A/B switch: 0 = separate query / key / value GEMMs
 _CROSS_WG_KEYS = int(os.environ.get("CXR_CROSS_WG_KEYS", "0"))          # cached cross-attention geometry (ops.attention_decode wg_keys)
+_CROSS_MFMA = os.environ.get("CXR_CROSS_MFMA", "1") != "0"              # A/B switch: 0 = VALU decode kernel for the cached cross-attention
 
 
 def _site(layer, k):
@@ -48,6 +49,7 @@ class KVCache:
         self.v2 = [torch.empty((B, Tmax, D), dtype=BF16, device=device) for _ in range(layers)]
         self.ck = [None] * layers
         self.cv = [None] * layers
+        self.cpk = [None] * layers       # fragment-ordered cross-attention (K, V) of the studies (ops.pack_cross_kv): the MFMA cross-attention of the cached steps
         self.cross_ready = False         # ck/cv may be pre-allocated static buffers (graph replay): filled at prefill
         self.enc_bits = None             # optional: the encoder key-padding mask as bit words (ops.pack_mask_bits), read by the cached steps
         self.len = 0
@@ -578,6 +580,11 @@ class BertEngine:
                     ovb = cache.cv[l].view(Be * S, D) if cache.cv[l] is not None else None
                     cache.ck[l] = ops.gemm_nt(enc.reshape(Be * S, D), ck, bias=cbk, out=okb).view(Be, S, D)
                     cache.cv[l] = ops.gemm_nt(enc.reshape(Be * S, D), cv, bias=cbv, out=ovb).view(Be, S, D)
+                    if _CROSS_MFMA and ops.attention_cross_mfma_ok(B, Be, S):      # the cached steps read fragment-ordered copies (one launch per decode and layer)
+                        keep = cache.cpk[l] if (cache.cpk[l] is not None and cache.cpk[l][0].numel() == Be * S * D) else None
+                        cache.cpk[l] = ops.pack_cross_kv(cache.ck[l], cache.cv[l], nh, out=keep)
+                    else:
+                        cache.cpk[l] = None
                 cq, cbq = self._lin(lp + "crossattention.self.query"); co, cbo = self._lin(lp + "crossattention.output.dense")
                 q2 = lin(h1, cq, bias=cbq).view(B, Tn, D)
                 if single:
@@ -731,8 +738,13 @@ class BertEngine:
             cur, cur_st, cur_ln = a1, st1, lp + "attention.output.LayerNorm"
             q2 = torch.empty((B, D), dtype=BF16, device=dev)
             ops.dec_gemm(cur, B, D, [prob((l, "cq"), D, q2)], stats=cur_st, eps=eps)
-            ctx2 = ops.attention_decode(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask, drop=(pa, seed, _site(l, 2), past),
-                                        wg_keys=_CROSS_WG_KEYS, out_dal=True, kpm_bits=cache.enc_bits if enc_mask is not None else None)
+            if cache.cpk[l] is not None and (enc_mask is None or cache.enc_bits is not None):
+                # matrix-core kernel on the fragment-ordered K / V copies (Tk <= 1152, <= 4 rows per study)
+                ctx2 = ops.attention_cross_mfma(q2, cache.cpk[l], cache.ck[l].shape[0], cache.ck[l].shape[1], nh, scale,
+                                                kpm_bits=cache.enc_bits if enc_mask is not None else None, drop=(pa, seed, _site(l, 2), past), out_dal=True)
+            else:
+                ctx2 = ops.attention_decode(q2, cache.ck[l], cache.cv[l], nh, scale, kpm=enc_mask, drop=(pa, seed, _site(l, 2), past),
+                                            wg_keys=_CROSS_WG_KEYS, out_dal=True, kpm_bits=cache.enc_bits if enc_mask is not None else None)
             (a2,), st2 = ops.dec_gemm(ctx2, B, D, [prob((l, "cout"), D)], out_stats=True, drop=drop(_site(l, 3)), **res_kw())
             cur, cur_st, cur_ln = a2, st2, lp + "crossattention.output.LayerNorm"
             (f,), _ = ops.dec_gemm(cur, B, D, [prob((l, "ffn1"), F)], act=1, stats=cur_st, eps=eps)

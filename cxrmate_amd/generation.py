@@ -38,6 +38,8 @@ class DecodeSession:
         L = model.config.decoder.num_hidden_layers
         self.cache.ck = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
         self.cache.cv = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
+        if ops.attention_cross_mfma_ok(rows, B, S):             # static fragment-ordered K / V copies (captured by the step graphs)
+            self.cache.cpk = [(torch.empty(B * S * D, dtype=torch.bfloat16, device=dev), torch.empty(B * S * D, dtype=torch.bfloat16, device=dev)) for _ in range(L)]
         self.seed = torch.zeros(1, dtype=torch.int32, device=dev)     # dropout seed of the running decode (train mode); graphs read it
         # uniforms of every sampling step of a decode, drawn by ONE torch call in reset(): a torch.rand inside a captured step costs three extra
         # tiny launches per replay (the generator's seed / offset refresh in front of the graph + the fill kernel itself)

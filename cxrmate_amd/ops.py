@@ -1026,6 +1026,32 @@ def attention_decode(q, k, v, heads, scale, kpm=None, out=None, drop=None, head_
     return out
 
 
+def pack_cross_kv(k, v, heads, out=None):
+    """k, v [Bkv, Tk, H*64] bf16 (equal strides) -> (Kp, Vp): fragment-ordered copies for attention_cross_mfma (one launch, once per decode)."""
+    Bkv, Tk, D = k.shape
+    assert v.shape == k.shape and k.stride() == v.stride() and k.stride(2) == 1 and Tk % 32 == 0 and D == heads * 64
+    kp, vp = out if out is not None else (torch.empty(Bkv * Tk * D, device=k.device, dtype=BF16), torch.empty(Bkv * Tk * D, device=k.device, dtype=BF16))
+    LIB.call("cxr_pack_cross_kv_bf16", _p(k), _p(v), k.stride(0), k.stride(1), _p(kp), _p(vp), Bkv, heads, Tk, _s())
+    return kp, vp
+
+
+def attention_cross_mfma_ok(B, Bkv, Tk):
+    return Tk % 32 == 0 and Tk <= 1152 and B % Bkv == 0 and B // Bkv <= 4
+
+
+def attention_cross_mfma(q, packed, Bkv, Tk, heads, scale, kpm_bits=None, out=None, drop=None, out_dal=False):
+    """Cross-attention of a cached decode step on the matrix cores (csrc/decode.hip attn_cross_mfma_kernel): q [B, H*64]; packed = pack_cross_kv(k, v)
+    of the Bkv studies; kpm_bits uint32 [Bkv, words] | None. Query rows b + g*Bkv share K/V row b. -> [B, H*64] (or DAL)."""
+    B = q.shape[0]
+    D = heads * 64
+    assert attention_cross_mfma_ok(B, Bkv, Tk) and packed[0].numel() == Bkv * Tk * D
+    if out is None:
+        out = torch.empty((dal_rows(B) if out_dal else B, D), device=q.device, dtype=BF16)
+    LIB.call("cxr_attn_cross_mfma_bf16", _p(q), _p(packed[0]), _p(packed[1]), _p(out), _p(kpm_bits), q.stride(0), out.stride(0),
+             kpm_bits.stride(0) if kpm_bits is not None else 0, B, heads, Tk, float(scale), B // Bkv, *_drop_args(drop), int(bool(out_dal)), _s())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ decode-step linear layers (csrc/decode_gemm.hip)
 def dal_rows(M):
     """rows of the buffer that holds M rows in the decode activation layout (16-row tiles; 3 tiles are stored as 4)"""

@@ -1232,3 +1232,39 @@ def test_gemm_nt_fp8_matches_dequantised_fp32_product(ops, M, N, K, act, res):
         full = full + r.float()
     rel = ((c.float() - full).pow(2).mean().sqrt() / full.pow(2).mean().sqrt()).item()
     assert rel < 0.05, rel
+
+
+@pytest.mark.parametrize("Bkv,share,Tk,masked,drop", [(3, 2, 1152, True, 0.0), (2, 4, 576, False, 0.0), (5, 1, 1152, True, 0.1), (2, 2, 320, True, 0.1), (16, 2, 1152, True, 0.1)])
+def test_attention_cross_mfma_matches_the_valu_decode_kernel(ops, Bkv, share, Tk, masked, drop):
+    """Cached cross-attention on the matrix cores (attn_cross_mfma_kernel, fragment-ordered K / V copies) against the VALU decode kernel and an fp32 reference:
+    shared K/V rows, key-padding bit mask, the same train-mode dropout hash (probabilities enter P.V as bf16 here: tolerance of that rounding)."""
+    torch.manual_seed(Bkv * 7 + Tk)
+    H, D, B = 12, 768, Bkv * share
+    q = (torch.randn(B, D, device="cuda") * 0.7).to(BF)
+    k = (torch.randn(Bkv, Tk, D, device="cuda") * 0.7).to(BF)
+    v = torch.randn(Bkv, Tk, D, device="cuda").to(BF)
+    kpm = None
+    if masked:
+        kpm = torch.ones(Bkv, Tk, dtype=torch.uint8, device="cuda")
+        kpm[0, Tk // 2:] = 0
+        kpm[-1, 5:37] = 0
+    bits = ops.pack_mask_bits(kpm) if masked else None
+    seed = torch.tensor([1234], dtype=torch.int32, device="cuda")
+    dr = (drop, seed, 21, 9) if drop > 0 else None
+    wide = torch.randn(Bkv, Tk, 2 * D + 64, device="cuda").to(BF)                    # K / V as column blocks of a wider buffer (strided rows)
+    wide[:, :, :D] = k; wide[:, :, D + 64:] = v
+    pk = ops.pack_cross_kv(wide[:, :, :D], wide[:, :, D + 64:], H)
+    ref = ops.attention_decode(q, k, v, H, 0.125, kpm=kpm, drop=dr)
+    out = ops.attention_cross_mfma(q, pk, Bkv, Tk, H, 0.125, kpm_bits=bits, drop=dr)
+    close(out, ref, rtol=1e-2, atol=2e-2, what="cross-attention mfma vs valu kernel")
+    if drop == 0:
+        kk, vv = k.float().repeat(share, 1, 1), v.float().repeat(share, 1, 1)                      # query row b + g*Bkv <-> K/V row b
+        qh, kh, vh = q.float().view(B, H, 1, 64), kk.view(B, Tk, H, 64).transpose(1, 2), vv.view(B, Tk, H, 64).transpose(1, 2)
+        s = (qh @ kh.transpose(2, 3)) * 0.125
+        if masked:
+            s = s.masked_fill(~kpm.bool().repeat(share, 1).view(B, 1, 1, Tk), torch.finfo(torch.float32).min)
+        full = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, D)
+        close(out, full, rtol=1e-2, atol=2e-2, what="cross-attention mfma vs fp32")
+    # decode activation layout output == row-major output re-laid out
+    dal = ops.attention_cross_mfma(q, pk, Bkv, Tk, H, 0.125, kpm_bits=bits, drop=dr, out_dal=True)
+    assert torch.equal(ops.dec_from_dal(dal, B, D), out)
