@@ -905,7 +905,8 @@ extern "C" int cxr_pack_mask_bits(const void* kpm, long kpm_bs, int B, int T, un
 struct AttnXArgs {
     const bf16_t* Q; const bf16_t* Kp; const bf16_t* Vp; bf16_t* O; const uint32_t* mbits; const uint32_t* drop_seed;
     long q_bs, o_bs, mb_bs;                         // mb_bs in 32-bit words
-    int H, Tk, Bkv, G, drop_t, o_mt;
+    float* ws;                                      // nsplit > 1: partial states (max, denominator, numerator[64]) per (row, head, split) for attn_decode_merge_kernel
+    int H, Tk, Bkv, G, drop_t, o_mt, nsplit, bps;   // bps = key blocks per split (<= 36)
     float scale_log2e, drop_inv; uint32_t drop_site, drop_thr16, has_mask;
 };
 
@@ -951,17 +952,19 @@ extern "C" int cxr_pack_cross_kv_bf16(const void* K, const void* V, long kv_bs, 
 
 template <int MAXB>
 __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a) {
-    __shared__ float wmax[12][16], wsum[12][16];
+    __shared__ float wmax[12][16], wsum[12][16], wmax_all[16];
     __shared__ float wo[12][4][64];                  // per-wave numerators of up to 4 query rows... (G <= 4 here; see the entry point)
     asm volatile("" :: "s"(a.Q), "s"(a.Kp), "s"(a.Vp), "s"(a.mbits), "s"(a.drop_seed), "s"(a.q_bs), "s"(a.mb_bs), "s"(a.H), "s"(a.Tk), "s"(a.Bkv), "s"(a.G));
     int vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
+    const int split = blockIdx.x % a.nsplit, bh = blockIdx.x / a.nsplit;
+    const int h = bh % a.H, b = bh / a.H;
     const int qi = lane & 15, g4 = lane >> 4;
-    const int nblk = a.Tk >> 5;
-    const bf16_t* kp = a.Kp + (long)blockIdx.x * nblk * 2048 + lane * 8;                // 4 fragments of 64 x 8 elements per block
-    const bf16_t* vp = a.Vp + (long)blockIdx.x * nblk * 2048 + lane * 8;
+    const int nblk_all = a.Tk >> 5, blk0 = split * a.bps;
+    const int nblk = min(a.bps, nblk_all - blk0);                                        // this workgroup's blocks: blk0 .. blk0 + nblk
+    const bf16_t* kp = a.Kp + ((long)bh * nblk_all + blk0) * 2048 + lane * 8;            // 4 fragments of 64 x 8 elements per block
+    const bf16_t* vp = a.Vp + ((long)bh * nblk_all + blk0) * 2048 + lane * 8;
     // ---- every load of the wave first: K fragments (2 tiles x 2 k-steps) and V fragments (4 dim tiles) of its blocks, 1 KB contiguous each
     bf16x8_t kf[MAXB][2][2], vf[MAXB][4];
 #pragma unroll
@@ -987,7 +990,7 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) {
         int blk = wave + 12 * i; blk = blk < nblk ? blk : nblk - 1;
-        mw[i] = (a.has_mask ? a.mbits + (long)b * a.mb_bs : a.drop_seed)[a.has_mask ? blk : 0];
+        mw[i] = (a.has_mask ? a.mbits + (long)b * a.mb_bs : a.drop_seed)[a.has_mask ? blk0 + blk : 0];
     }
     const uint32_t dseed = a.drop_seed[vzero];
     __builtin_amdgcn_sched_barrier(0);
@@ -1019,6 +1022,7 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < 12; ++w) mx = fmaxf(mx, wmax[w][qi]);
+    if (wave == 0 && g4 == 0) wmax_all[qi] = mx;                                         // (read after the next barrier by the split epilogue)
     // ---- probabilities, dropout (train mode), P . V
     const uint32_t dkey = dropout_row_key(dseed, a.drop_site, (uint32_t)(qrow * a.H + h), (uint32_t)a.drop_t);
     f32x4_t o[4];
@@ -1027,7 +1031,7 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
     float lsum = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) {
-        const int blk = wave + 12 * i;
+        const int blk = blk0 + wave + 12 * i;
         float p[8];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -1069,7 +1073,12 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
 #pragma unroll
         for (int w = 0; w < 12; ++w) { num += wo[w][g][d]; den += wsum[w][g]; }
         const int row = b + g * a.Bkv;
-        a.O[a.o_mt ? dal_off(row, h * 64 + d, a.o_mt) : (long)row * a.o_bs + h * 64 + d] = f2bf(num / den);
+        if (a.nsplit == 1) a.O[a.o_mt ? dal_off(row, h * 64 + d, a.o_mt) : (long)row * a.o_bs + h * 64 + d] = f2bf(num / den);
+        else {
+            float* w = a.ws + ((((long)row * a.H + h) * a.nsplit) + split) * 66;
+            w[2 + d] = num;
+            if (d == 0) { w[0] = wmax_all[g]; w[1] = den; }
+        }
     }
 }
 
@@ -1161,11 +1170,11 @@ extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V,
 
 // Cross-attention decode step on the matrix cores (attn_cross_mfma_kernel). Q [B rows, H*64] bf16 (row stride q_bs); Kp / Vp = fragment-ordered K / V of
 // the Bkv studies (cxr_pack_cross_kv_bf16, Bkv*Tk*H*64 elements each); kpm_bits uint32 [Bkv][mb_words] or NULL; O as in cxr_attn_decode_bf16
-// (o_dal: decode activation layout). kv_share = B / Bkv query rows per K/V stream, <= 4. Tk % 32 == 0, Tk <= 1152.
+// (o_dal: decode activation layout). kv_share = B / Bkv query rows per K/V stream, <= 4. Tk % 32 == 0; Tk > 1152 needs ws (B*H*8*66 floats).
 extern "C" int cxr_attn_cross_mfma_bf16(const void* Q, const void* Kp, const void* Vp, void* O, const unsigned int* kpm_bits, long q_bs, long o_bs,
                                         long mb_words, int B, int H, int Tk, float scale, int kv_share, float drop_p, const unsigned int* drop_seed,
-                                        unsigned int drop_site, int drop_t, int o_dal, hipStream_t stream) {
-    if (B <= 0 || H <= 0 || Tk <= 0 || (Tk % 32) || Tk > 1152 || kv_share < 1 || kv_share > 4 || (B % kv_share) || (q_bs % 8) || ((uintptr_t)Kp % 16) ||
+                                        unsigned int drop_site, int drop_t, int o_dal, float* ws, hipStream_t stream) {
+    if (B <= 0 || H <= 0 || Tk <= 0 || (Tk % 32) || Tk > 8 * 1152 || (Tk > 1152 && !ws) || kv_share < 1 || kv_share > 4 || (B % kv_share) || (q_bs % 8) || ((uintptr_t)Kp % 16) ||
         ((uintptr_t)Vp % 16) || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed) || (o_dal && B > 64))
         return CXR_ERR_ARG;
     AttnXArgs a;
@@ -1176,11 +1185,15 @@ extern "C" int cxr_attn_cross_mfma_bf16(const void* Q, const void* Kp, const voi
     a.o_mt = o_dal ? (cdiv(B, 16) == 3 ? 4 : cdiv(B, 16)) : 0;
     a.scale_log2e = scale * 1.4426950408889634f; a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_site = drop_site;
     a.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u; a.has_mask = kpm_bits ? 1u : 0u;
-    const dim3 grid(a.Bkv * H);
-    const int nblk = Tk / 32;
-    if (nblk <= 12) CXR_LAUNCH(attn_cross_mfma_kernel<1>, grid, dim3(768), 0, stream, a);
-    else if (nblk <= 24) CXR_LAUNCH(attn_cross_mfma_kernel<2>, grid, dim3(768), 0, stream, a);
+    // more than 36 key blocks (1152 keys) per study: the blocks are split over nsplit workgroups per (study, head), partial states -> ws
+    // (B*H*nsplit*66 floats) -> attn_decode_merge_kernel
+    const int nblk_all = Tk / 32;
+    a.nsplit = cdiv(nblk_all, 36); a.bps = cdiv(nblk_all, a.nsplit); a.ws = ws;
+    const dim3 grid(a.Bkv * H * a.nsplit);
+    if (a.bps <= 12) CXR_LAUNCH(attn_cross_mfma_kernel<1>, grid, dim3(768), 0, stream, a);
+    else if (a.bps <= 24) CXR_LAUNCH(attn_cross_mfma_kernel<2>, grid, dim3(768), 0, stream, a);
     else CXR_LAUNCH(attn_cross_mfma_kernel<3>, grid, dim3(768), 0, stream, a);
+    if (a.nsplit > 1) CXR_LAUNCH(attn_decode_merge_kernel, dim3(cdiv(B * H, 4)), dim3(256), 0, stream, ws, (bf16_t*)O, o_bs, H, a.nsplit, B * H, a.o_mt);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

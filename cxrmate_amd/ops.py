@@ -1036,7 +1036,7 @@ def pack_cross_kv(k, v, heads, out=None):
 
 
 def attention_cross_mfma_ok(B, Bkv, Tk):
-    return Tk % 32 == 0 and Tk <= 1152 and B % Bkv == 0 and B // Bkv <= 4
+    return Tk % 32 == 0 and Tk <= 8 * 1152 and B % Bkv == 0 and B // Bkv <= 4
 
 
 def attention_cross_mfma(q, packed, Bkv, Tk, heads, scale, kpm_bits=None, out=None, drop=None, out_dal=False):
@@ -1047,8 +1047,12 @@ def attention_cross_mfma(q, packed, Bkv, Tk, heads, scale, kpm_bits=None, out=No
     assert attention_cross_mfma_ok(B, Bkv, Tk) and packed[0].numel() == Bkv * Tk * D
     if out is None:
         out = torch.empty((dal_rows(B) if out_dal else B, D), device=q.device, dtype=BF16)
+    key = ("attn_decode_ws", _s(), B * heads, q.device)
+    ws = _DW_WS.get(key)
+    if ws is None:
+        ws = _DW_WS[key] = torch.empty(B * heads * 8 * 66, device=q.device, dtype=torch.float32)
     LIB.call("cxr_attn_cross_mfma_bf16", _p(q), _p(packed[0]), _p(packed[1]), _p(out), _p(kpm_bits), q.stride(0), out.stride(0),
-             kpm_bits.stride(0) if kpm_bits is not None else 0, B, heads, Tk, float(scale), B // Bkv, *_drop_args(drop), int(bool(out_dal)), _s())
+             kpm_bits.stride(0) if kpm_bits is not None else 0, B, heads, Tk, float(scale), B // Bkv, *_drop_args(drop), int(bool(out_dal)), _p(ws), _s())
     return out
 
 

@@ -311,11 +311,11 @@ int cxr_dec_from_dal_bf16(const void* x, int M, int K, void* out, long ldo, hipS
 /* cross-attention of a cached decode step on the matrix cores. Kp / Vp: fragment-ordered copies of the studies' cross K / V (cxr_pack_cross_kv_bf16,
  * once per decode: K, V [Bkv, Tk, H*64] with batch / row strides kv_bs / kv_rs -> Bkv*Tk*H*64 elements each, 1 KB per MFMA fragment);
  * kpm_bits uint32 [Bkv][mb_words] (cxr_pack_mask_bits) or NULL; kv_share = B / Bkv <= 4 query rows per K/V stream (rows b + g*Bkv); Tk % 32 == 0,
- * Tk <= 1152; output as cxr_attn_decode_bf16 (same dropout hash; probabilities enter P.V as bf16) */
+ * Tk <= 9216; output as cxr_attn_decode_bf16 (same dropout hash; probabilities enter P.V as bf16) */
 int cxr_pack_cross_kv_bf16(const void* K, const void* V, long kv_bs, long kv_rs, void* Kp, void* Vp, int Bkv, int H, int Tk, hipStream_t stream);
 int cxr_attn_cross_mfma_bf16(const void* Q, const void* Kp, const void* Vp, void* O, const unsigned int* kpm_bits, long q_bs, long o_bs, long mb_words,
                              int B, int H, int Tk, float scale, int kv_share, float drop_p, const unsigned int* drop_seed, unsigned int drop_site,
-                             int drop_t, int o_dal, hipStream_t stream);
+                             int drop_t, int o_dal, float* ws, hipStream_t stream);   /* ws (B*H*8*66 floats): needed for Tk > 1152 (key range split + merge) */
 int cxr_pack_mask_bits(const void* kpm, long kpm_bs, int B, int T, unsigned int* out, int words, hipStream_t stream);
                        /* key-padding bytes [B,T] (1 = attend) -> uint32 [B][words], bit k%32 of word k/32 */
 int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, long* inds, hipStream_t stream);

@@ -1234,7 +1234,8 @@ def test_gemm_nt_fp8_matches_dequantised_fp32_product(ops, M, N, K, act, res):
     assert rel < 0.05, rel
 
 
-@pytest.mark.parametrize("Bkv,share,Tk,masked,drop", [(3, 2, 1152, True, 0.0), (2, 4, 576, False, 0.0), (5, 1, 1152, True, 0.1), (2, 2, 320, True, 0.1), (16, 2, 1152, True, 0.1)])
+@pytest.mark.parametrize("Bkv,share,Tk,masked,drop", [(3, 2, 1152, True, 0.0), (2, 4, 576, False, 0.0), (5, 1, 1152, True, 0.1), (2, 2, 320, True, 0.1), (16, 2, 1152, True, 0.1),
+                                                       (3, 2, 1728, True, 0.1), (2, 4, 2880, True, 0.0)])
 def test_attention_cross_mfma_matches_the_valu_decode_kernel(ops, Bkv, share, Tk, masked, drop):
     """Cached cross-attention on the matrix cores (attn_cross_mfma_kernel, fragment-ordered K / V copies) against the VALU decode kernel and an fp32 reference:
     shared K/V rows, key-padding bit mask, the same train-mode dropout hash (probabilities enter P.V as bf16 here: tolerance of that rounding)."""
