@@ -232,13 +232,13 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
                         "hipGraphs, REINFORCE through one teacher-forced pass, AdamW on the 80.9 M decoder parameters",
             "mode": "eval" if args.eval_mode else "model.train(): batch-statistics BatchNorm in the frozen encoder, dropout 0.1 in both decodes and in "
                     "the re-scoring pass (same seed)", "loss": float(out["loss"].item()), "string_round_trip": strings,
-            "roofline": {"bound": "hbm", "kernel": "cached decode token-step (one hipGraph of ~54 kernels: dec_gemm_kernel x38, attn_decode_kernel x12, "
+            "roofline": {"bound": "hbm", "kernel": "cached decode token-step (one hipGraph of ~54 kernels: dec_gemm_kernel x38, attn_cross_mfma_kernel x6, attn_decode_kernel x6, "
                          "embedding, step inputs, token selection), 32 rows", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": decode_traffic()[0], "traffic_unit": "bytes per token-step",
                          "traffic_source": decode_traffic()[1], "algorithmic_bytes_per_token_step": step_bytes,
                          "decode_ms_per_step": dec_ms, "us_per_token_step": dec_ms * 1e3 / n_tok,
                          "decode_share_of_step": dec_ms / (dt / steps * 1e3),
-                         "profile": "profiles/r02_scst_decode_v3_kernel_stats.csv (rocprofv3 --kernel-trace of scripts/scst_decode_profile.py)"}}
+                         "profile": "profiles/r02_scst_decode_v4_kernel_stats.csv (rocprofv3 --kernel-trace of scripts/scst_decode_profile.py)"}}
 
 
 def beam_bench(args, dev, host_loop_too=True):
