@@ -167,6 +167,49 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
     def _initially_trainable(self, key):
         return True
 
+    # -------------------------------------------------------------------------------------- checkpoints (HF directory layout)
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, device="cuda", **kwargs):
+        """The reference's `Model.from_pretrained(ckpt_dir)` for a LOCAL checkpoint directory in the HF layout: `config.json` (a
+        VisionEncoderDecoderConfig: `encoder` / `decoder` sub-dicts) + `model.safetensors` or `pytorch_model.bin` with the HF state-dict key names.
+        There is no Hub access from this process: a model id that is not a directory raises. Constructed in eval mode, like transformers."""
+        import json
+        import os
+        path = str(pretrained_model_name_or_path)
+        if not os.path.isdir(path):
+            raise OSError(f"{path} is not a local directory (this build never contacts the Hugging Face Hub; download the checkpoint first)")
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = json.load(f)
+        model = cls(config=cfg, device=device, seed=None, **kwargs)
+        st = os.path.join(path, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
+        for alias, canon in weights.tied_aliases(model.config.decoder).items():       # transformers writes tied tensors once (LM projection = word embeddings)
+            if alias not in sd and canon in sd:
+                sd[alias] = sd[canon]
+        model.load_state_dict(sd)
+        model.eval()
+        return model
+
+    def save_pretrained(self, save_directory, safe_serialization: bool = True):
+        """`config.json` + weights in the HF directory layout (what from_pretrained reads; the state-dict keys are the reference's)."""
+        import dataclasses
+        import json
+        import os
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = {"model_type": "vision-encoder-decoder", "encoder": dataclasses.asdict(self.config.encoder), "decoder": dataclasses.asdict(self.config.decoder)}
+        with open(os.path.join(save_directory, "config.json"), "w") as f:
+            json.dump(cfg, f, indent=1)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(save_directory, "model.safetensors"))
+        else:
+            torch.save(sd, os.path.join(save_directory, "pytorch_model.bin"))
+
     # -------------------------------------------------------------------------------------- gradient plumbing
     def enable_direct_grads(self):
         """p.grad are views of the flat gradient buffer (no autograd copies); pair with FusedAdamW."""

@@ -808,3 +808,30 @@ def test_forward_with_labels_matches_torch_cross_entropy(M):
     torch.nn.functional.cross_entropy(out2.logits.float().reshape(-1, cfg.decoder.vocab_size), labels.reshape(-1)).backward()
     g2 = m.param(name).grad.detach()
     assert gu.rel_rms(g1.cpu().numpy(), g2.cpu().numpy()) < 2e-2
+
+
+def test_save_pretrained_from_pretrained_round_trip(M, tmp_path):
+    """HF directory layout (config.json + model.safetensors with the reference's key names): a saved model comes back through from_pretrained with
+    identical logits -- also when the tied LM-projection keys are missing from the file (transformers writes tied tensors once) -- and a model id
+    that is not a local directory is refused (no Hub access)."""
+    g, cfg, sd, x = gu.generate_multi_case()
+    m = M.MultiCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    ids = torch.randint(5, cfg.decoder.vocab_size, (3, 7), device="cuda")
+    tt = m.token_ids_to_token_type_ids(ids, [gu.SEP])
+    with torch.no_grad():
+        ref = m(pixel_values=x.cuda(), decoder_input_ids=ids, decoder_token_type_ids=tt).logits
+    d = str(tmp_path / "ckpt")
+    m.save_pretrained(d)
+    from safetensors.torch import load_file, save_file
+    import os
+    f = os.path.join(d, "model.safetensors")
+    st = {k: v for k, v in load_file(f).items() if "cls.predictions.decoder" not in k}
+    save_file(st, f)
+    m2 = M.MultiCXREncoderDecoderModel.from_pretrained(d)
+    assert not m2.training and m2.config.encoder.depth == cfg.encoder.depth and m2.config.decoder.vocab_size == cfg.decoder.vocab_size
+    with torch.no_grad():
+        out = m2(pixel_values=x.cuda(), decoder_input_ids=ids, decoder_token_type_ids=tt).logits
+    assert torch.equal(out, ref)
+    with pytest.raises(OSError):
+        M.MultiCXREncoderDecoderModel.from_pretrained("aehrc/cxrmate-multi-tf")
