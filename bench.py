@@ -180,11 +180,26 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
     label_ids = torch.randint(1000, 30000, (B, 128), generator=g).to(dev)
     ones = torch.ones(B, 128, dtype=torch.int64, device=dev)
 
-    def reward_fn(ids):                                           # ids [B, L] -> synthetic "re-tokenised" R=128 WordPiece ids
-        pred = torch.zeros(B, 128, dtype=torch.int64, device=dev)
+    def retok(ids):                                               # ids [B, L] -> synthetic "re-tokenised" R=128 WordPiece ids
+        pred = torch.zeros(ids.shape[0], 128, dtype=torch.int64, device=dev)
         n = min(128, ids.shape[1])
         pred[:, :n] = ids[:, :n] % 30522
-        return reward.reward_from_ids(pred, ones, label_ids, ones)
+        return pred
+
+    label_emb = {}
+
+    def reward_fn(ids):
+        return reward.reward_from_ids(retok(ids), ones, label_ids, ones)
+
+    def reward_pair(a, b):                                        # sampled + greedy rows as ONE 2B-row CXR-BERT forward, labels embedded once
+        from cxrmate_amd import ops
+        if "e" not in label_emb:
+            label_emb["e"] = reward.embed_ids(label_ids, ones)
+        pe = reward.embed_ids(torch.cat([retok(a), retok(b)], 0), torch.cat([ones, ones], 0))
+        r = ops.cosine_rows(pe, torch.cat([label_emb["e"], label_emb["e"]], 0))
+        return r[:B], r[B:]
+
+    reward_fn.pair = reward_pair
 
     special = dict(bos=1, eos=None, sep=3, pad=4, pmt_sep=9)
 
@@ -227,7 +242,7 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
             "steps_per_sec_per_gpu": steps / dt, "steps": steps, "ms_per_step": dt / steps * 1e3, "studies_per_sec": world * B * steps / dt,
             "new_tokens_sampled_and_greedy": n_tok,
             "reward": "CXR-BERT stand-in (BERT-base + CLS projection head: architecture assumed, PARITY UNPINNED -- SURVEY.md 8c), R = 128 SYNTHETIC "
-                      "ids in place of the decode -> re-tokenise string round trip, 4 forwards per step (labels cached)",
+                      "ids in place of the decode -> re-tokenise string round trip, ONE 32-row forward per step (sampled + greedy together, labels cached)",
             "workload": "BASELINE.json configs[3] per-GPU shape: sample (top-k 50) + greedy baseline as one 32-row cached decode replayed from "
                         "hipGraphs, REINFORCE through one teacher-forced pass, AdamW on the 80.9 M decoder parameters",
             "mode": "eval" if args.eval_mode else "model.train(): batch-statistics BatchNorm in the frozen encoder, dropout 0.1 in both decodes and in "

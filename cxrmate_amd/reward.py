@@ -129,6 +129,16 @@ class ReportReward:
 
         self.last_sections = None                             # (findings, impression) strings of the most recent call
 
+    def pair(self, sampled_host, greedy_host):
+        """(reward of the sampled rows, reward of the greedy rows) from ONE tokenizer call and ONE 2B-row CXR-BERT forward; `last_sections` holds the
+        greedy rows' sections afterwards (what the generated-prompt caller writes back)."""
+        _, fs, is_ = self.model.split_and_decode_sections(sampled_host, self.special, self.tokenizer)
+        _, fg, ig = self.model.split_and_decode_sections(greedy_host, self.special, self.tokenizer)
+        self.last_sections = (fg, ig)
+        both = self.reward.reward([f"{i} {j}" for i, j in zip(list(fs) + list(fg), list(is_) + list(ig))], self.labels + self.labels)
+        B = len(fs)
+        return both[:B], both[B:]
+
     def __call__(self, sequences_host):
         _, findings, impression = self.model.split_and_decode_sections(sequences_host, self.special, self.tokenizer)
         self.last_sections = (findings, impression)

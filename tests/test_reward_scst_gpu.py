@@ -248,13 +248,13 @@ def test_scst_step_through_real_strings(cuda):
     out = scst_step(m, opt, rfn, x.cuda(), prompt.cuda(), None, special, decoder_max_len=10, reward_on_host=True)
     torch.cuda.synchronize()
     assert np.isfinite(out["loss"].item())
-    assert len(n_label_embeds) == 3                              # sampled predictions, labels (once), greedy predictions
+    assert n_label_embeds == [4, 4]                              # ONE pass for sampled + greedy predictions (2 x 2 studies), the labels embedded once
     P = prompt.shape[1]
     full_s = torch.cat([prompt, out["sampled"].cpu()], 1)
     want_r = rfn(full_s).float().cpu().numpy()
     want_b = rfn(out["baseline_ids"].cpu()).float().cpu().numpy()
-    np.testing.assert_allclose(out["global"]["reward"].cpu().numpy(), want_r, atol=1e-5)
-    np.testing.assert_allclose(out["global"]["baseline"].cpu().numpy(), want_b, atol=1e-5)
+    np.testing.assert_allclose(out["global"]["reward"].cpu().numpy(), want_r, atol=2e-3)       # (one 4-row pass vs two 2-row passes: other padding)
+    np.testing.assert_allclose(out["global"]["baseline"].cpu().numpy(), want_b, atol=2e-3)
 
 
 def test_scst_generated_prompt_steps_chain_through_the_written_back_report(cuda):
