@@ -119,8 +119,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdArgs
         if (tile + 1 < ntiles) BWD_GLOAD_Q(tile + 1);
 
         const int g = lane >> 4, li = lane & 15;
+        // wave-uniform skips (the staging and the barriers above are still shared): a wave whose 32 keys lie past Tk (Tk = 145: three of the eight
+        // waves of a (image, head)) and the second 32-query half of a tile that lies past Tq (Tq = 577: half of the tenth tile) do no math
+        if (kb0 + wave * 32 >= a.Tk) continue;
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
+            if (qs == 1 && tile * 64 + 32 >= a.Tq) continue;
             f32x16_t S, dP;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
@@ -299,8 +303,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwdArgs a
         if (tile + 1 < ntiles) BWD_GLOAD_KV(tile + 1);
 
         const int g = lane >> 4, li = lane & 15;
+        if (qb0 + wave * 32 >= a.Tq) continue;                     // (wave-uniform: no query of this wave exists; staging and barriers above are shared)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
+            if (kt == 1 && tile * 64 + 32 >= a.Tk) continue;        // (the second 32-key half of the last tile lies past Tk)
             f32x16_t S, dP;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
