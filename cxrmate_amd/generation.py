@@ -268,7 +268,7 @@ class GenerationMixin:
             if do_sample:
                 raise NotImplementedError("beam sampling is not used by the reference")
             with torch.no_grad():
-                search = self._beam_search_session if (self.device_beam_search and num_beams in (2, 3, 4, 5, 8)) else self._beam_search
+                search = self._beam_search_session if (self.device_beam_search and num_beams in (2, 4)) else self._beam_search
                 seqs, seq_scores = search(ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, num_beams,
                                           bos_token_id, eos_token_id, pad_token_id, length_penalty)
             if return_dict_in_generate:

@@ -835,3 +835,15 @@ def test_save_pretrained_from_pretrained_round_trip(M, tmp_path):
     assert torch.equal(out, ref)
     with pytest.raises(OSError):
         M.MultiCXREncoderDecoderModel.from_pretrained("aehrc/cxrmate-multi-tf")
+
+
+def test_beam_counts_without_a_shared_kv_kernel_fall_back_to_the_host_loop(M):
+    """The device-side search shares a study's cross K/V between its beams through the 2- and 4-row attention kernels; other beam counts run the
+    host-loop restatement (same decode kernels, replicated K/V) and return a well-formed result."""
+    g, cfg, sd, x = gu.generate_multi_case()
+    m = M.MultiCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    out = m.generate(pixel_values=x.cuda(), special_token_ids=[gu.SEP], max_length=14, bos_token_id=gu.BOS, eos_token_id=gu.EOS, pad_token_id=gu.PAD,
+                     num_beams=3, return_dict_in_generate=True, use_cache=True, output_scores=True)
+    s = out["sequences"].cpu()
+    assert s.shape[0] == 3 and bool((s[:, 0] == gu.BOS).all()) and s.shape[1] <= 14 and bool(torch.isfinite(out["sequences_scores"]).all())
