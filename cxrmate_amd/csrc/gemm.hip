@@ -9,34 +9,10 @@
 // accesses for bias / residual / store. 1-D grid with an XCD-aware (bijective) tile remap so the 8 private L2s
 // each see a contiguous run of N-tiles sharing one A panel.
 #include "common.h"
+#include "gemm_args.h"
 #include "../../include/cxrmate_hip.h"
 #include <stdlib.h>
 
-struct GemmArgs {
-    const bf16_t* A; long lda;
-    const bf16_t* W; long ldw;
-    void* C; long ldc;
-    const float* bias;            // [N] or null
-    const bf16_t* residual; long ldr;   // [M,N] or null, added after the activation
-    bf16_t* aux; long ldaux;      // act==1 && aux: pre-activation is stored here; act==2: pre-activation is read from here
-    int M, N, K;
-    float alpha;
-    int act;                      // 0 none, 1 GELU(erf), 2 multiply by GELU'(aux)  (backward of 1)
-    int out_f32;                  // 0: C is bf16, 1: C is f32
-    int accumulate;               // out_f32 only: C += result
-    // train-mode regularisers folded into the epilogue (after the activation): element dropout by the counter-based hash of common.h
-    // (row m = sequence m / drop_rows_per_b at position drop_t0 + m % drop_rows_per_b), or a per-image DropPath factor row_scale[m / rs_rows];
-    // rs_after != 0 applies the row scale AFTER the residual (CvT's second DropPath scales the whole layer output, quirk Q12)
-    const uint32_t* drop_seed; uint32_t drop_site, drop_thr16; float drop_inv; int drop_rows_per_b, drop_t0;
-    const float* row_scale; int rs_rows, rs_after;
-    int lds_epilogue;             // 1: every memory-facing epilogue access is 16-byte aligned -> the tile goes through LDS and is written in full rows
-};
-
-template <int BK> struct Swz;
-template <> struct Swz<32> { static __device__ __forceinline__ int f(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; } };
-template <> struct Swz<64> { static __device__ __forceinline__ int f(int row) { return (row >> 1) & 7; } };
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // NST = number of LDS stages. NST == 2: one tile in flight behind the math (vmcnt(0) + __syncthreads per K step).
 // NST >= 3 (LDS-DMA only): NST-1 tiles in flight across raw s_barriers with a COUNTED vmcnt, so that the HBM/L2 latency of the
@@ -423,6 +399,9 @@ __global__ __launch_bounds__(256) void gemm_nt_group_kernel(const GemmGroupArgs 
 }
 
 static int g_gemm_regstage = 0;     // debugging aid: 1 = stage through registers instead of LDS-DMA
+static int g_gemm_exclusive = 1;    // 1: NT GEMM launches may use the persistent kernels (gemm_ws.hip / gemm_pk.hip)
+
+extern "C" int cxr_gemm_set_exclusive(int on) { g_gemm_exclusive = on != 0; return CXR_OK; }
 
 extern "C" int cxr_gemm_set_regstage(int on) { g_gemm_regstage = on; return CXR_OK; }
 
@@ -468,6 +447,13 @@ extern "C" int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw
     GemmArgs g;
     const int rc = gemm_nt_fill(g, d);
     if (rc) return rc;
+    // Persistent one-workgroup-per-CU kernels (144 KB of LDS each) for the shapes they win on -- only while the launching stream has the GPU to
+    // itself (cxr_gemm_set_exclusive): beside the weight-gradient stream's kernels their workgroups cannot be co-resident and the static work
+    // partition waits for the last CU to free up.
+    if (g_gemm_exclusive) {
+        if (gemm_ws_launch(g, stream)) { CXR_LAUNCH_CHECK(); return CXR_OK; }   // K = 384, N >= 768: W resident in registers (gemm_ws.hip)
+        if (gemm_pk_launch(g, stream)) { CXR_LAUNCH_CHECK(); return CXR_OK; }   // tall / very wide problems: persistent 256-row tiles (gemm_pk.hip)
+    }
     static int force_bk = -1, stages = -1;     // tuning aids: CXR_GEMM_BK=32|64, CXR_GEMM_STAGES=2|3|4
     if (force_bk < 0) { const char* e = getenv("CXR_GEMM_BK"); force_bk = e ? atoi(e) : 0; }
     if (stages < 0) { const char* e = getenv("CXR_GEMM_STAGES"); stages = e ? atoi(e) : 2; }

@@ -369,6 +369,7 @@ class BertEngine:
         lora_tr = bool(saved.get("lora_tr"))
         self._prepare_transposes(lora_tr)
         ops.wgrad_join()                                                # transposed weights (side stream) are ready
+        ops.wgrad_begin()                                               # from here on weight-gradient kernels run beside the main stream
         st.ensure_grads()
         B, T = saved["B"], saved["T"]
         R, D, nh = B * T, cfg.hidden_size, cfg.num_attention_heads

@@ -373,6 +373,7 @@ class CvtEncoderEngine:
         on_stage_done(s): called when every gradient launch of stage s (and of the later stages and the projection head) has been issued --
         data parallelism starts the all-reduce of that stage's parameters while the earlier stages are still in backward."""
         cfg, st = self.cfg, self.s
+        ops.wgrad_begin()
         prep = self.prepare()
         self._prepare_transposes()
         ops.wgrad_wait(self._wt_event)                                  # transposed weights are ready (NOT a join: the decoder's weight-gradient backlog keeps running)

@@ -246,6 +246,26 @@ def wgrad_join():
     if WGRAD_STREAM is not None:
         torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
     _side_launch._pending.clear()
+    gemm_exclusive(True)                                   # nothing runs beside the main stream any more
+
+
+_GEMM_EXCLUSIVE = True
+
+
+def gemm_exclusive(on: bool):
+    """on: NT GEMM launches may use the persistent one-workgroup-per-CU kernels (csrc/gemm_ws.hip, gemm_pk.hip: 144 KB of LDS each). The backward
+    passes turn it off while weight-gradient kernels run beside the main stream (wgrad_begin) -- such a workgroup cannot share a CU with them
+    and the kernels' static work partition would wait for the last CU to free up (measured: 43.9 -> 45.8 ms per step)."""
+    global _GEMM_EXCLUSIVE
+    if bool(on) != _GEMM_EXCLUSIVE:
+        _GEMM_EXCLUSIVE = bool(on)
+        LIB.call("cxr_gemm_set_exclusive", int(bool(on)))
+
+
+def wgrad_begin():
+    """Start of a backward pass: from here on weight-gradient kernels may be running on the side stream (until wgrad_join)."""
+    if WGRAD_STREAM is not None:
+        gemm_exclusive(False)
 
 
 def wgrad_mark():

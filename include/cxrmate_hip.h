@@ -49,6 +49,19 @@ int cxr_gemm_nt_group_bf16(const cxr_gemm_nt_desc* d, int n, hipStream_t stream)
 int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* dbias, int R, int I, int J, float alpha,
                      float* ws, long ws_floats, hipStream_t stream);
 int cxr_gemm_set_regstage(int on);   /* debug: 1 = stage operands through registers instead of LDS-DMA */
+/* on != 0 (default): cxr_gemm_nt_bf16 may pick the persistent one-workgroup-per-CU kernels (csrc/gemm_ws.hip, csrc/gemm_pk.hip). The training
+ * step turns it off while its weight-gradient stream runs kernels beside the main stream (their workgroups cannot share a CU with a 144 KB one). */
+int cxr_gemm_set_exclusive(int on);
+/* cxr_gemm_nt_bf16 sends tall problems (M >= min_rows, K%64==0, N%8==0, 16-byte aligned rows) to the persistent 256-row-tile kernel of
+ * csrc/gemm_pk.hip (same results bit for bit). Tuning / A-B aid: enabled 0|1, bn 0 (automatic) | 128 | 256 | 1000 + i = tile configuration, wgs =
+ * workgroups of a launch (0 = fill the chip); a negative argument keeps the current value. */
+int cxr_gemm_pk_config(int enabled, int bn, int min_rows, int wgs);
+int cxr_gemm_pk_stamps(void* out, long bytes);   /* timing experiments: copies the in-kernel s_memtime stamps of the last stamped launch to HOST memory */
+/* K = 384, N % 384 == 0 problems (the channel-width products of CvT stage 3) go to the W-stationary kernel of csrc/gemm_ws.hip (weights resident in
+ * registers, A row blocks streamed through LDS; same results bit for bit). Tuning / A-B aid: enabled 0|1, bm 0 (automatic) | 32 | 64 rows per block,
+ * wgs = workgroups of a launch, dbg = timing-experiment bits; a negative argument keeps the current value. */
+int cxr_gemm_ws_config(int enabled, int bm, int min_rows, int wgs, int dbg);
+int cxr_gemm_ws_stamps(void* out, long bytes);   /* timing experiments: in-kernel s_memtime stamps of the last stamped launch -> HOST memory */
 int cxr_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int C, hipStream_t stream);
 int cxr_transpose_batched_bf16(const long* table, int n, long total_tiles, hipStream_t stream);   /* n transposes in one launch; table (device)
                                    int64 [n][8] = {in, out, ld_in, ld_out, R, C, first_tile, tiles_x}, 64x64 tiles numbered row-major per matrix */

@@ -6,15 +6,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from cxrmate_amd import ops
 from cxrmate_amd.config import EncoderDecoderConfig
-from cxrmate_amd.modelling import SingleCXREncoderDecoderModel
+from cxrmate_amd.modelling import MultiCXREncoderDecoderModel, SingleCXREncoderDecoderModel
 from cxrmate_amd.training import FusedAdamW, tf_train_step
 
-ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--images", type=int, default=2); a = ap.parse_args()
 cfg = EncoderDecoderConfig()
-m = SingleCXREncoderDecoderModel(cfg, device="cuda", seed=0)
+m = (MultiCXREncoderDecoderModel if a.images > 1 else SingleCXREncoderDecoderModel)(cfg, device="cuda", seed=0)
 m.train()
 opt = FusedAdamW(m, lr=5e-5)
-px, inp, am, lab = bench.synth_batch(a.batch, 256, 30000, "cuda", 1)
+px, inp, am, lab = bench.synth_batch(a.batch, 256, 30000, "cuda", 1, a.images)
 tt = m.token_ids_to_token_type_ids(inp, [3])
 for _ in range(2):
     tf_train_step(m, opt, px, inp, am, tt, lab, 4)

@@ -41,6 +41,102 @@ def close(a, b, rtol=2e-2, atol=2e-2, what=""):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+class _gemm_route:
+    """Force the NT GEMM onto one kernel family for a block of calls: 'tiled' (gemm_nt_kernel), ('pk', config index) (csrc/gemm_pk.hip),
+    'ws' (csrc/gemm_ws.hip, every K = 384 / N % 384 == 0 shape)."""
+
+    def __init__(self, route):
+        self.route = route
+
+    def __enter__(self):
+        from cxrmate_amd._lib import LIB
+        r = self.route
+        if r == "tiled":
+            LIB.call("cxr_gemm_set_exclusive", 0)
+        elif r == "ws":
+            LIB.call("cxr_gemm_set_exclusive", 1)
+            LIB.call("cxr_gemm_ws_config", 1, 1, 1, -1, 0)
+            LIB.call("cxr_gemm_pk_config", 0, -1, -1, -1)
+        else:
+            LIB.call("cxr_gemm_set_exclusive", 1)
+            LIB.call("cxr_gemm_ws_config", 0, -1, -1, -1, -1)
+            LIB.call("cxr_gemm_pk_config", 1, 1000 + r[1], 1, -1)
+        return self
+
+    def __exit__(self, *exc):
+        from cxrmate_amd._lib import LIB
+        LIB.call("cxr_gemm_set_exclusive", 1)
+        LIB.call("cxr_gemm_ws_config", 1, 0, 2048, -1, 0)
+        LIB.call("cxr_gemm_pk_config", 1, 0, 2048, 0)
+        return False
+
+
+def _gemm_variants(M, N, seed):
+    bias = dev(rnd(N, seed=seed + 1))
+    res = dev(rnd(M, N, seed=seed + 2).to(BF))
+    rs = dev(torch.rand(max(1, (M + 576) // 577)) * 2)
+    dseed = torch.tensor([4321], dtype=torch.int32, device="cuda")
+    return {"plain": dict(), "bias": dict(bias=bias), "bias+residual": dict(bias=bias, residual=res), "gelu+saved": dict(bias=bias, act=1, aux="new"),
+            "gelu": dict(bias=bias, act=1), "gelu'": dict(act=2, aux=res), "droppath after": dict(bias=bias, residual=res, row_scale=(rs, 577, True)),
+            "droppath before": dict(bias=bias, residual=res, row_scale=(rs, 577, False)), "alpha": dict(alpha=0.37, bias=bias),
+            "f32": dict(bias=bias, out_f32=True), "dropout+residual": dict(bias=bias, residual=res, drop=(0.1, dseed, 7, 256, 3))}
+
+
+def _run_variant(ops, a, w, kw):
+    kw = dict(kw)
+    aux = None
+    if kw.get("aux") == "new":
+        aux = kw["aux"] = torch.zeros(a.shape[0], w.shape[0], device="cuda", dtype=BF)
+    return ops.gemm_nt(a, w, **kw), aux
+
+
+@pytest.mark.parametrize("route", [("pk", 0), ("pk", 1), ("pk", 2), ("pk", 3), ("pk", 4), ("pk", 5)])
+@pytest.mark.parametrize("M,N,K", [(36928, 384, 384), (4000, 392, 128), (2049, 64, 64), (5000, 1000, 192), (300, 384, 1536), (70, 136, 64), (3000, 30000, 128)])
+def test_gemm_persistent_kernel_is_bit_identical_to_the_tiled_kernel(ops, route, M, N, K):
+    """csrc/gemm_pk.hip (every built tile configuration; ragged row / column tails, row strides != K, every epilogue) against gemm_nt_kernel: same
+    MFMA orientation and K order -> the same bits; and against fp32 torch on the plain product."""
+    a = dev(rnd(M + 3, K + 8, seed=M).to(BF))[:M, :K]
+    w = dev((rnd(N, K, seed=N) * 0.1).to(BF))
+    for name, kw in _gemm_variants(M, N, M + N).items():
+        with _gemm_route("tiled"):
+            ref, ref_aux = _run_variant(ops, a, w, kw)
+        with _gemm_route(route):
+            out, out_aux = _run_variant(ops, a, w, kw)
+        assert torch.equal(ref, out), f"{route} {M}x{N}x{K} {name}: {int((ref != out).sum())} elements differ"
+        assert ref_aux is None or torch.equal(ref_aux, out_aux), f"{route} {M}x{N}x{K} {name}: saved pre-activation differs"
+        if name == "plain":
+            close(out, a.float() @ w.float().t(), rtol=1e-2, atol=1e-2, what=f"{route} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N", [(36928, 384), (9280, 384), (36928, 1536), (1000, 384), (70, 768), (4999, 1536)])
+def test_gemm_w_stationary_kernel_is_bit_identical_to_the_tiled_kernel(ops, M, N):
+    """csrc/gemm_ws.hip (K = 384: weights resident in registers, A / second-operand blocks through the LDS ring, anti-phased wave groups) against
+    gemm_nt_kernel on every epilogue it takes; other shapes / epilogues must fall through to the tiled kernels unchanged."""
+    K = 384
+    a = dev(rnd(M + 3, K + 8, seed=M).to(BF))[:M, :K]
+    w = dev((rnd(N, K, seed=N) * 0.1).to(BF))
+    for name, kw in _gemm_variants(M, N, M + N).items():
+        with _gemm_route("tiled"):
+            ref, ref_aux = _run_variant(ops, a, w, kw)
+        with _gemm_route("ws"):
+            out, out_aux = _run_variant(ops, a, w, kw)
+        assert torch.equal(ref, out), f"ws {M}x{N} {name}: {int((ref != out).sum())} elements differ"
+        assert ref_aux is None or torch.equal(ref_aux, out_aux), f"ws {M}x{N} {name}: saved pre-activation differs"
+        if name == "plain":
+            close(out, a.float() @ w.float().t(), rtol=1e-2, atol=1e-2, what=f"ws {M}x{N}")
+
+
+def test_gemm_persistent_asymmetric_identity(ops):
+    # A = I with an asymmetric W through the W-row deal of the persistent kernels: a permuted column would show exactly
+    n = 384
+    a = dev(torch.eye(n).repeat(8, 1).to(BF))                     # [3072, 384]: every row block sees the identity
+    w = dev((torch.arange(n * n).reshape(n, n) % 251 - 125).float().to(BF))
+    for route in (("pk", 0), ("pk", 1), "ws"):
+        with _gemm_route(route):
+            out = ops.gemm_nt(a, w)
+        assert torch.equal(out.float().cpu(), w.float().t().repeat(8, 1).cpu()), route
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 192, 192), (577, 384, 1536), (1000, 30000 // 8 * 4, 768), (64, 64, 32),
                                    (9216, 64, 192), (17, 768, 3072), (256, 128, 96)])
 @pytest.mark.parametrize("regstage", [0, 1])
