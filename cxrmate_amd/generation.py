@@ -154,7 +154,8 @@ class DecodeSession:
                          mask_token_id if longi else -1, self.new_id, self.tt1, self.pos1 if longi else None,
                          self.mask8 if longi else None, self.tt_hist, self.pos_hist if longi else None)
             mask = self.mask8[:, :cur - strip] if longi else None
-            if m._dec.fused_step_ok(self.cache, self.B, self.enc16) and len(sp0) <= 4 and len(sp1) <= 4 and cur - strip <= 512:
+            if (m._dec.fused_step_ok(self.cache, self.B, self.enc16) and len(sp0) <= 4 and len(sp1) <= 4
+                    and cur - strip <= min(512, m.config.decoder.max_position_embeddings)):      # (the kernel indexes the position table with cur - strip - 1)
                 # ... and the embeddings of the new token in the same launch, written in the decode kernels' activation layout
                 ph, _, _ = m._dec._dropout_cfg(train, self.seed)
                 x0 = ops.decode_step_embed(*step_args, *m._dec.embed_tables(), drop=(ph, self.seed, 1) if ph else None)
@@ -268,7 +269,9 @@ class GenerationMixin:
             if do_sample:
                 raise NotImplementedError("beam sampling is not used by the reference")
             with torch.no_grad():
-                search = self._beam_search_session if (self.device_beam_search and num_beams in (2, 4)) else self._beam_search
+                # device-side search: beam counts with a shared-K/V attention kernel, and a cache the one-launch reorder can address (16 tensors = 8 layers)
+                on_device = self.device_beam_search and num_beams in (2, 4) and 2 * self.config.decoder.num_hidden_layers <= 16
+                search = self._beam_search_session if on_device else self._beam_search
                 seqs, seq_scores = search(ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, num_beams,
                                           bos_token_id, eos_token_id, pad_token_id, length_penalty)
             if return_dict_in_generate:

@@ -136,6 +136,12 @@ class _CrossEntropyFn(torch.autograd.Function):
         return (dl.float() * g).view(ctx.shape), None
 
 
+def _is_bookkeeping_key(k: str) -> bool:
+    """State-dict entries that are not weights: older transformers checkpoints persist `...embeddings.position_ids` (an arange buffer) and
+    `num_batches_tracked` counters are kept by this build in one place of its own."""
+    return k.endswith(".position_ids") or k.endswith("token_type_ids_buffer")
+
+
 class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
     kind = "single"
     main_input_name = "pixel_values"
@@ -163,6 +169,31 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
         self.direct_grads = False
         if seed is not None:
             self.load_state_dict(weights.init_encoder_decoder(config, seed=seed, perturb=perturb))
+        # Second constructor form of the reference (modelling_single.py:88-95; lightning_modules/single.py:218-221 builds the model from
+        # `CvtWithProjectionHead.from_pretrained(...)` + a fresh decoder): the passed modules' WEIGHTS are the model's weights.
+        for prefix, mod in (("encoder.", encoder), ("decoder.", decoder)):
+            self._adopt_module_weights(prefix, mod)
+
+    def _adopt_module_weights(self, prefix, mod):
+        """Copy `mod.state_dict()` in under `prefix` (strict: every parameter / buffer of that half must be there, nothing else may be, apart
+        from the non-parameter bookkeeping keys HF checkpoints carry). Modules without tensors (a bare object holding `.config`) are ignored."""
+        sd_fn = getattr(mod, "state_dict", None)
+        if mod is None or sd_fn is None:
+            return
+        sd = {k: v for k, v in sd_fn().items() if torch.is_tensor(v) and not _is_bookkeeping_key(k)}
+        if not sd:
+            return
+        own = {k for k in self.state_dict().keys() if k.startswith(prefix)}
+        given = {prefix + k for k in sd}
+        for alias, canon in weights.tied_aliases(self.config.decoder).items():      # a tied tensor may be stored once
+            if alias in own and alias not in given and canon in given:
+                sd[alias[len(prefix):]] = sd[canon[len(prefix):]]
+                given.add(alias)
+        missing, unexpected = sorted(own - given), sorted(given - own)
+        if missing or unexpected:
+            raise RuntimeError(f"{type(mod).__name__} passed as `{prefix[:-1]}=` does not match this model's {prefix[:-1]}: "
+                               f"missing keys {missing[:5]}{'...' if len(missing) > 5 else ''}, unexpected keys {unexpected[:5]}{'...' if len(unexpected) > 5 else ''}")
+        self.load_state_dict({prefix + k: v for k, v in sd.items()}, strict=False)
 
     def _initially_trainable(self, key):
         return True
@@ -190,6 +221,7 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
         for alias, canon in weights.tied_aliases(model.config.decoder).items():       # transformers writes tied tensors once (LM projection = word embeddings)
             if alias not in sd and canon in sd:
                 sd[alias] = sd[canon]
+        sd = {k: v for k, v in sd.items() if not _is_bookkeeping_key(k)}              # e.g. `decoder.bert.embeddings.position_ids` of older pytorch_model.bin files
         model.load_state_dict(sd)
         model.eval()
         return model
@@ -200,7 +232,9 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
         import json
         import os
         os.makedirs(save_directory, exist_ok=True)
-        cfg = {"model_type": "vision-encoder-decoder", "encoder": dataclasses.asdict(self.config.encoder), "decoder": dataclasses.asdict(self.config.decoder)}
+        # sub-configurations carry their `model_type` so that transformers' AutoConfig can read the directory too
+        cfg = {"model_type": "vision-encoder-decoder", "encoder": dict(dataclasses.asdict(self.config.encoder), model_type="cvt"),
+               "decoder": dict(dataclasses.asdict(self.config.decoder), model_type="bert")}
         with open(os.path.join(save_directory, "config.json"), "w") as f:
             json.dump(cfg, f, indent=1)
         sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}

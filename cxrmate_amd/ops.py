@@ -155,14 +155,36 @@ def colsum_into(x, out):
     LIB.call("cxr_colsum_bf16", _p(x), x.stride(0), _p(out), x.shape[0], x.shape[1], _s())
 
 
-_TN_WS = {}             # raw stream handle -> fp32 scratch of the deterministic split-K weight-gradient GEMM (launches of one stream are serial)
+_TN_WS = {}             # (device index, raw stream handle) -> fp32 scratch of the deterministic split-K weight-gradient GEMM (launches of one
+                        # stream are serial); 8 M floats cover every shape of this model: an output beyond it (splits * I_pad * J_pad floats, more than
+                        # 192 splits) falls back to fp32 atomics inside cxr_gemm_tn_bf16 -- reported once per shape, never silent
+_TN_WS_FLOATS = 8 << 20
+_TN_FALLBACK_SEEN = set()
 
 
 def _tn_ws(stream, device):
-    ws = _TN_WS.get(stream)
-    if ws is None or ws.device != device:
-        ws = _TN_WS[stream] = torch.empty(8 << 20, dtype=torch.float32, device=device)
+    key = (device.index, stream)
+    ws = _TN_WS.get(key)
+    if ws is None:
+        ws = _TN_WS[key] = torch.empty(_TN_WS_FLOATS, dtype=torch.float32, device=device)
     return ws
+
+
+def _tn_note_fallback(R, I, J):
+    """Mirror of the split choice in cxr_gemm_tn_bf16 (csrc/gemm.hip): warn when a shape cannot use the deterministic partial-tile path."""
+    import os
+    import warnings
+    tiles = -(-I // 128) * -(-J // 128)
+    nrt = -(-R // 32)
+    target = int(os.environ.get("CXR_TN_WGS", "176") or 176)
+    splits = max(1, min(-(-target // tiles), max(1, nrt // 8)))
+    rt = -(-nrt // splits)
+    splits = -(-nrt // rt)
+    need = splits * (-(-I // 128) * 128) * (-(-J // 128) * 128 + 1)
+    if splits > 1 and (need > _TN_WS_FLOATS or splits > 192) and (I, J) not in _TN_FALLBACK_SEEN:
+        _TN_FALLBACK_SEEN.add((I, J))
+        warnings.warn(f"weight-gradient GEMM {I}x{J} over {R} rows: {splits} splits need {need} scratch floats (> {_TN_WS_FLOATS}) -> fp32 atomics, "
+                      "the sum order (last bits of the gradient) is not reproducible for this shape")
 
 
 def gemm_tn(p, q, out, dbias=None, alpha=1.0):
@@ -178,6 +200,8 @@ def gemm_tn(p, q, out, dbias=None, alpha=1.0):
         e0.record(pstream)
     stream = _s()
     ws = _tn_ws(stream, p.device)
+    if (I, J) not in _TN_FALLBACK_SEEN and I * J > (1 << 20):
+        _tn_note_fallback(R, I, J)
     LIB.call("cxr_gemm_tn_bf16", _p(p), p.stride(0), _p(q), q.stride(0), _p(out), out.stride(0), _p(dbias), R, I, J, float(alpha), _p(ws), ws.numel(),
              stream)
     if prof is not None:

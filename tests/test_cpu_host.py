@@ -217,6 +217,58 @@ def test_model_constructor_accepts_the_reference_hf_config():
         modelling.SingleCXREncoderDecoderModel(config=bad, device="cpu", seed=0)
 
 
+def test_model_constructor_adopts_the_weights_of_passed_encoder_and_decoder_modules(tmp_path):
+    """Second constructor form of the reference (modelling_single.py:88-95), as its warm-start path uses it (lightning_modules/single.py:218-221:
+    `SingleCXREncoderDecoderModel(encoder=CvtWithProjectionHead.from_pretrained(...), decoder=...)`): the modules' weights ARE the model's.
+    Here the two halves are transformers' own BertLMHeadModel and a CvtModel + projection head assembled like the reference's wrapper."""
+    transformers = pytest.importorskip("transformers")
+    import torch
+    from torch import nn
+    from cxrmate_amd import modelling
+    dec_cfg = transformers.BertConfig(vocab_size=128, num_hidden_layers=2, type_vocab_size=2)
+    dec_cfg.is_decoder, dec_cfg.add_cross_attention = True, True
+    enc_cfg = transformers.CvtConfig(depth=[1, 2, 3])
+    enc_cfg.projection_size = dec_cfg.hidden_size
+
+    class Head(nn.Module):                                        # reference modelling_single.py:25-40
+        def __init__(self):
+            super().__init__()
+            self.layer_norm = nn.LayerNorm(384, eps=enc_cfg.layer_norm_eps)
+            self.projection = nn.Linear(384, dec_cfg.hidden_size, bias=False)
+
+    class Enc(nn.Module):                                         # reference modelling_single.py:43-51
+        def __init__(self):
+            super().__init__()
+            self.config = enc_cfg
+            self.cvt = transformers.CvtModel(enc_cfg, add_pooling_layer=False)
+            self.projection_head = Head()
+
+    torch.manual_seed(11)
+    enc, dec = Enc(), transformers.BertLMHeadModel(dec_cfg)
+    m = modelling.SingleCXREncoderDecoderModel(encoder=enc, decoder=dec, device="cpu", seed=0)
+    sd = m.state_dict()
+    for k, v in enc.state_dict().items():
+        assert torch.equal(sd["encoder." + k].cpu(), v), k
+    for k, v in dec.state_dict().items():
+        if not k.endswith("position_ids"):
+            assert torch.equal(sd["decoder." + k].cpu(), v), k
+    # a half that does not fit is an error, not a silently random-initialised model
+    other = transformers.BertLMHeadModel(transformers.BertConfig(vocab_size=128, num_hidden_layers=2, type_vocab_size=2, is_decoder=True))
+    other.config.add_cross_attention = True                       # claims cross-attention but has no such weights
+    with pytest.raises(RuntimeError, match="does not match this model's decoder"):
+        modelling.SingleCXREncoderDecoderModel(encoder=enc, decoder=other, device="cpu", seed=0)
+    # HF-layout round trip: sub-configs carry their model_type, stale bookkeeping keys of older checkpoints are dropped on load
+    m.save_pretrained(tmp_path / "ckpt", safe_serialization=False)
+    import json
+    cfg = json.load(open(tmp_path / "ckpt" / "config.json"))
+    assert cfg["encoder"]["model_type"] == "cvt" and cfg["decoder"]["model_type"] == "bert"
+    raw = torch.load(tmp_path / "ckpt" / "pytorch_model.bin")
+    raw["decoder.bert.embeddings.position_ids"] = torch.arange(512).unsqueeze(0)
+    torch.save(raw, tmp_path / "ckpt" / "pytorch_model.bin")
+    m2 = modelling.SingleCXREncoderDecoderModel.from_pretrained(tmp_path / "ckpt", device="cpu")
+    assert all(torch.equal(v, m2.state_dict()[k]) for k, v in sd.items())
+
+
 def test_reward_and_chexbert_constructors_follow_the_reference_signatures(tmp_path):
     from cxrmate_amd.chexbert import CheXbert
     with pytest.raises(ValueError, match="The CheXbert checkpoint does not exist"):
