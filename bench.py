@@ -411,6 +411,111 @@ def forward_only(args, dev, model, n_images):
                     + ("model.train()" if model.training else "model.eval()") + ", algorithmic FLOPs (2 x MAC) / HIP-event time"}
 
 
+def tf_dropin(args, dev, n_images, steps=6):
+    """What a reference caller gets from the drop-in boundary: the call sequence of the reference's TF training_step (modules/lightning_modules/
+    single.py:449-475, multi.py:182-210) against cxrmate_amd's model class, with torch doing what the caller does itself -- fp32 `.logits` out
+    of the model, `F.cross_entropy(logits.permute(0, 2, 1), labels, ignore_index=pad)`, `loss.backward()` through the autograd bridges,
+    `torch.optim.AdamW(model.parameters())` (single.py:426-431). Same workload as the headline number."""
+    from cxrmate_amd.config import EncoderDecoderConfig
+    from cxrmate_amd.modelling import MultiCXREncoderDecoderModel, SingleCXREncoderDecoderModel
+    cfg = EncoderDecoderConfig()
+    B, T, V = args.batch, args.seq_len, cfg.decoder.vocab_size
+    model = (MultiCXREncoderDecoderModel if n_images > 1 else SingleCXREncoderDecoderModel)(cfg, device=dev, seed=0)
+    if not args.eval_mode:
+        model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-5)
+    px, inp, am, lab = synth_batch(B, T, V, dev, 1000, n_images)
+
+    def step():
+        tt = model.token_ids_to_token_type_ids(inp, [3])                       # single.py:458-461
+        y_hat = model(pixel_values=px, decoder_input_ids=inp, decoder_attention_mask=am, decoder_token_type_ids=tt, return_dict=True).logits
+        loss = torch.nn.functional.cross_entropy(y_hat.permute([0, 2, 1]), lab, ignore_index=4)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(3):
+        step()
+    dt, loss = timed(step, steps, 1, dev)
+    return {"ms_per_step": dt / steps * 1e3, "tokens_per_s": B * T * steps / dt, "steps": steps, "loss": float(loss.item()),
+            "what": "reference TF caller sequence on the drop-in classes: model(...).logits (fp32 [B,T,30000], autograd bridges) -> "
+                    "F.cross_entropy(logits.permute(0,2,1), labels, ignore_index=pad) -> loss.backward() -> torch.optim.AdamW.step(), "
+                    f"{B} studies x {n_images} images, T = {T}, " + ("model.eval()" if args.eval_mode else "model.train()")}
+
+
+def scst_dropin(args, dev, steps=3):
+    """The reference's SCST caller sequence (modules/lightning_modules/longitudinal/scst/gt_prompt.py:62-142, sample :144-209, reinforce_loss
+    :211-246) against the drop-in classes at the configs[3] per-GPU shape: tokenize_prompt -> encoder -> generate.__wrapped__(do_sample,
+    output_scores) -> torch.stack(scores, -1) -> split_and_decode_sections -> reward(strings) -> greedy generate -> strings -> reward ->
+    log_softmax / nll_loss over the [B, V, T] stack -> backward -> torch.optim.AdamW. Synthetic byte-BPE tokenizer (tests/golden); EOS
+    disabled so that all 255 steps run, as in the fused `scst` number."""
+    import transformers
+    from cxrmate_amd.config import EncoderDecoderConfig
+    from cxrmate_amd.modelling import LongitudinalPromptMultiCXREncoderDecoderModel
+    from cxrmate_amd.reward import CXRBERTReward
+    cfg = EncoderDecoderConfig()
+    B, N = 16, 2
+    model = LongitudinalPromptMultiCXREncoderDecoderModel(cfg, device=dev, seed=0)
+    if not args.eval_mode:
+        model.train()
+    for p in model.encoder.parameters():
+        p.requires_grad = False                                                  # scst/gt_prompt.py:34-40
+    for p in model.decoder.parameters():
+        p.requires_grad = True
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=5e-6)
+    tok = transformers.PreTrainedTokenizerFast(tokenizer_file=os.path.join(ROOT, "tests", "golden", "tokenizer.json"), unk_token="[UNK]",
+                                               pad_token="[PAD]", cls_token="[BOS]", sep_token="[SEP]", mask_token="[MASK]", bos_token="[BOS]",
+                                               eos_token="[EOS]", additional_special_tokens=["[PMT]", "[PMT-SEP]", "[NPF]", "[NPI]"])
+    dec_tok = _InVocabTokenizer(tok)
+    reward_model = CXRBERTReward(dev, tokenizer=tok, seed=1)
+    images = torch.randn(B, N, 3, 384, 384, generator=torch.Generator().manual_seed(2000)).to(dev)
+    batch = {"previous_findings": [None] * B, "previous_impression": [None] * B,
+             "findings": ["The lungs are clear without focal consolidation. No pleural effusion or pneumothorax."] * B,
+             "impression": ["No acute cardiopulmonary process."] * B}
+    bos, eos, sep, pad = tok.bos_token_id, None, tok.sep_token_id, tok.pad_token_id
+    pmt_sep = tok.convert_tokens_to_ids("[PMT-SEP]")
+    max_len = args.new_tokens + 1
+
+    def step():
+        prompt = model.tokenize_prompt(batch["previous_findings"], batch["previous_impression"], tok, max_len, add_bos_token_id=True)
+        ids = prompt["input_ids"].to(dev)
+        encoder_outputs = model.encoder(images)
+        sample = model.generate.__wrapped__(model, input_ids=ids, special_token_ids=[bos, sep], encoder_outputs=encoder_outputs, bos_token_id=bos,
+                                            eos_token_id=eos, pad_token_id=pad, mask_token_id=pad, return_dict_in_generate=True, do_sample=True,
+                                            num_beams=1, use_cache=True, output_scores=True, top_p=1.0, top_k=50, temperature=1.0,
+                                            max_new_tokens=max_len - 1)
+        if torch.all(sample["sequences"][:, 0] == 1):
+            sample["sequences"] = sample["sequences"][:, 1:]
+        logits = torch.stack(sample["scores"], dim=-1)
+        _, f, i = model.split_and_decode_sections(sample["sequences"], [bos, sep, tok.eos_token_id], dec_tok)
+        sampled = sample["sequences"][:, ids.shape[1]:]
+        labels = [[f"{a} {b}"] for a, b in zip(batch["findings"], batch["impression"])]
+        reward = reward_model([f"{a} {b}" for a, b in zip(f, i)], labels).to(dev)
+        base = model.generate(encoder_outputs=encoder_outputs, decoder_input_ids=ids, special_token_ids=[pmt_sep, bos, sep], max_length=max_len + ids.shape[1],
+                              bos_token_id=bos, eos_token_id=eos, pad_token_id=pad, mask_token_id=pad, num_beams=1, return_dict_in_generate=True,
+                              use_cache=True)["sequences"]
+        if torch.all(base[:, 0] == 1):
+            base = base[:, 1:]
+        _, bf, bi = model.split_and_decode_sections(base, [bos, sep, tok.eos_token_id], dec_tok)
+        baseline = reward_model([f"{a} {b}" for a, b in zip(bf, bi)], labels).to(dev)
+        adv = reward - baseline
+        loss = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(logits, dim=1), sampled, ignore_index=pad, reduction="none")
+        loss = (loss.sum(dim=-1) * adv).mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(2):
+        step()
+    dt, loss = timed(step, steps, 1, dev)
+    return {"ms_per_step": dt / steps * 1e3, "steps_per_sec": steps / dt, "steps": steps, "loss": float(loss.item()),
+            "what": "reference SCST caller sequence (scst/gt_prompt.py:62-246) on the drop-in classes: tokenize_prompt, encoder, generate.__wrapped__("
+                    "do_sample=True, output_scores=True, top_k=50), torch.stack(scores, -1) [16, 30000, 255] fp32, split_and_decode_sections + string reward "
+                    "twice, greedy generate, log_softmax / nll_loss, backward, torch.optim.AdamW on the decoder; 16 studies x 2 images, 255 new tokens"}
+
+
 def spawn_ranks(n):
     """`--gpus N` without a torchrun environment: start N fresh ranks of this script (one per GPU) BEFORE this process touches the GPU, relay
     rank 0's output, exit with the worst return code."""
@@ -441,6 +546,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scst", action="store_true", help="skip the SCST measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip tf_single and forward_only")
+    ap.add_argument("--no-dropin", action="store_true", help="skip tf_dropin / scst_dropin (the reference callers' call sequences on the drop-in classes)")
     ap.add_argument("--scst-steps", type=int, default=10)
     ap.add_argument("--graph", action="store_true", help="replay the TF step from hipGraphs (3 segments)")
     ap.add_argument("--eval-mode", action="store_true", help="run the steps under model.eval() (running-statistics BatchNorm, no dropout)")
@@ -520,6 +626,13 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             out["tf_single"] = {"error": str(e)}
+    if world == 1 and not args.no_extras and not args.no_dropin:
+        try:
+            out["tf_dropin"] = tf_dropin(args, dev, N)
+            out["tf_dropin"]["vs_fused_step"] = out["tf_dropin"]["ms_per_step"] / ms_per_step
+        except Exception as e:
+            out["tf_dropin"] = {"error": str(e)}
+        torch.cuda.empty_cache()
     if not args.no_scst:
         try:
             out["scst"] = scst_bench(args, rank, world, dev, args.scst_steps)
@@ -527,6 +640,14 @@ def main():
             if world > 1:
                 raise
             out["scst"] = {"metric": "scst_steps_per_sec", "value": None, "error": str(e)}
+    if world == 1 and not args.no_extras and not args.no_scst and not args.no_dropin:
+        try:
+            out["scst_dropin"] = scst_dropin(args, dev)
+            if out["scst"].get("ms_per_step"):
+                out["scst_dropin"]["vs_fused_step"] = out["scst_dropin"]["ms_per_step"] / out["scst"]["ms_per_step"]
+        except Exception as e:
+            out["scst_dropin"] = {"error": str(e)}
+        torch.cuda.empty_cache()
     if world == 1 and not args.no_extras and not args.no_scst:
         try:
             out["scst_c5"] = scst_bench(args, rank, world, dev, max(3, args.scst_steps // 2), c5=True)

@@ -50,6 +50,96 @@ class ModelOutput(dict):
         return tuple(v for v in self.values() if v is not None)
 
 
+# ---------------------------------------------------------------------------------------------------- what the callers do with logits / scores
+class BoundaryTensor(torch.Tensor):
+    """`.logits` of forward() and the per-step `scores` of generate.__wrapped__() as the reference's callers receive them: ordinary fp32 tensors
+    in every respect, except that the three torch calls those callers make on them are recognised and served without the [B, V, T] detour:
+
+      * TF step (reference modules/lightning_modules/single.py:467-469): `F.cross_entropy(logits.permute([0, 2, 1]), labels, ignore_index=pad)`
+        -- torch runs its "spatial" softmax over the strided class dimension (39 + 26 ms forward + backward for [32, 30000, 256] on MI355X);
+        here the permuted view remembers its [B, T, V] base and the loss runs on the fused loss kernel (csrc/loss.hip, one pass per vocabulary row).
+      * SCST step (scst/gt_prompt.py:189,230-235): `torch.stack(sample['scores'], dim=-1)` then `log_softmax(logits, dim=1)` then `nll_loss`:
+        the stack of ALL steps of one generate call, in order, is the permuted view of the tensor they were unbound from (no copy), and the
+        log-softmax over dim 1 of such a view is a row softmax of the contiguous base.
+    Anything else falls through to torch with plain tensors (results are never BoundaryTensors), so no other code path changes behaviour."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        handler = _BOUNDARY_HANDLERS.get(func)
+        if handler is not None:
+            out = handler(*args, **kwargs)
+            if out is not NotImplemented:
+                return out
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+
+def _as_boundary(tensor, **meta):
+    b = tensor.as_subclass(BoundaryTensor)
+    b._cxr = meta
+    return b
+
+
+def _meta(t):
+    return getattr(t, "_cxr", None) if isinstance(t, BoundaryTensor) else None
+
+
+def _plain(t):
+    return t.as_subclass(torch.Tensor) if isinstance(t, BoundaryTensor) else t
+
+
+def _h_permute(x, *dims, **kw):
+    m = _meta(x)
+    if "dims" in kw:
+        dims = (kw["dims"],)
+    d = tuple(dims[0]) if len(dims) == 1 and isinstance(dims[0], (list, tuple)) else tuple(dims)
+    if m is None or m.get("kind") != "btv" or d not in ((0, 2, 1), (0, -1, 1), (0, -1, -2), (0, 2, -2)):
+        return NotImplemented
+    return _as_boundary(_plain(x).permute(0, 2, 1), kind="bvt", base=_plain(x))
+
+
+def _h_transpose(x, d0, d1):
+    m = _meta(x)
+    if m is None or m.get("kind") != "btv" or {d0 % 3, d1 % 3} != {1, 2}:
+        return NotImplemented
+    return _as_boundary(_plain(x).permute(0, 2, 1), kind="bvt", base=_plain(x))
+
+
+def _h_cross_entropy(input, target, weight=None, size_average=None, ignore_index=-100, reduce=None, reduction="mean", label_smoothing=0.0):
+    m = _meta(input)
+    if (m is None or m.get("kind") != "bvt" or weight is not None or size_average is not None or reduce is not None or reduction != "mean"
+            or label_smoothing != 0.0 or not torch.is_tensor(target) or target.dtype != torch.int64 or tuple(target.shape) != tuple(m["base"].shape[:2])):
+        return NotImplemented
+    return _CrossEntropyFn.apply(m["base"], _plain(target).to(m["base"].device), int(ignore_index))
+
+
+def _h_stack(tensors, dim=0, out=None):
+    if out is not None or dim not in (-1, 2) or not tensors:
+        return NotImplemented
+    metas = [_meta(t) for t in tensors]
+    m0 = metas[0]
+    if m0 is None or m0.get("kind") != "step" or len(tensors) != m0["base"].shape[1]:
+        return NotImplemented
+    if any(m is None or m.get("kind") != "step" or m["base"] is not m0["base"] or m["t"] != i for i, m in enumerate(metas)):
+        return NotImplemented
+    return _as_boundary(m0["base"].permute(0, 2, 1), kind="bvt", base=m0["base"])
+
+
+def _h_log_softmax(input, dim=None, _stacklevel=3, dtype=None):
+    m = _meta(input)
+    if m is None or m.get("kind") != "bvt" or dim not in (1, -2) or dtype is not None:
+        return NotImplemented
+    return torch.log_softmax(m["base"], dim=-1).permute(0, 2, 1)
+
+
+_BOUNDARY_HANDLERS = {
+    torch.Tensor.permute: _h_permute, torch.permute: _h_permute, torch.Tensor.transpose: _h_transpose, torch.transpose: _h_transpose,
+    torch.nn.functional.cross_entropy: _h_cross_entropy, torch.stack: _h_stack,
+    torch.nn.functional.log_softmax: _h_log_softmax, torch.log_softmax: _h_log_softmax, torch.Tensor.log_softmax: _h_log_softmax,
+}
+
+
 # ---------------------------------------------------------------------------------------------------- autograd bridges
 class _EncodeFn(torch.autograd.Function):
     @staticmethod
@@ -60,10 +150,13 @@ class _EncodeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dfeats):
+        from .training import wgrad_overlap
         model = ctx.model
         if not model.direct_grads:
             model.zero_grads_prefix("encoder.")
-        model._enc.backward(ctx.saved, dfeats.contiguous())
+        with wgrad_overlap():                                              # weight-gradient GEMMs beside the dX chain, as in the fused step
+            model._enc.backward(ctx.saved, dfeats.contiguous())
+            ops.wgrad_join()                                               # ... complete before autograd reads them
         ctx.saved = None
         return (None, None) + model._collect_grads("encoder.", ctx.nparams)
 
@@ -85,7 +178,10 @@ class _DecodeFn(torch.autograd.Function):
         B, T, V = dlogits.shape
         d16 = dlogits.reshape(B * T, V)
         d16 = ops.cast_to_bf16(d16.contiguous()) if d16.dtype == torch.float32 else d16.contiguous()
-        denc = model._dec.backward(ctx.saved, dlogits=d16, need_denc=ctx.need_denc)
+        from .training import wgrad_overlap
+        with wgrad_overlap():
+            denc = model._dec.backward(ctx.saved, dlogits=d16, need_denc=ctx.need_denc)
+            ops.wgrad_join()
         d_emb = None
         if ctx.embeds_like is not None:
             d_emb = ctx.saved["d_embeds"].view(ctx.embeds_like.shape).to(ctx.embeds_like.dtype)
@@ -119,13 +215,13 @@ class _CrossEntropyFn(torch.autograd.Function):
     (csrc/loss.hip: log-softmax + nll + d(logits) in one pass over the vocabulary row; ignore_index = -100, mean over the counted labels)."""
 
     @staticmethod
-    def forward(ctx, logits, labels):
+    def forward(ctx, logits, labels, ignore_index=-100):
         V = logits.shape[-1]
         flat = logits.detach().reshape(-1, V)
         flat = flat if flat.stride(1) == 1 else flat.contiguous()
         lab = labels.reshape(-1).to(torch.int64).contiguous()
-        w = ops.ce_weights(lab, -100, mode=0)
-        loss, _, dl = ops.softmax_ce(flat, lab, -100, w, need_grad=True)
+        w = ops.ce_weights(lab, ignore_index, mode=0)
+        loss, _, dl = ops.softmax_ce(flat, lab, ignore_index, w, need_grad=True)
         ctx.save_for_backward(dl)
         ctx.shape = logits.shape
         return loss.reshape(())
@@ -133,7 +229,7 @@ class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        return (dl.float() * g).view(ctx.shape), None
+        return (dl.float() * g).view(ctx.shape), None, None
 
 
 def _is_bookkeeping_key(k: str) -> bool:
@@ -262,9 +358,17 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
         return [(k, p) for k, p in self._params.items() if k.startswith(prefix) and p.requires_grad]
 
     def _collect_grads(self, prefix, n):
+        """Gradients handed to autograd for the trainable parameters under `prefix`: views of ONE copy of the flat gradient range they span
+        (a clone per parameter was ~400 copy launches per backward)."""
         if self.direct_grads:
             return (None,) * n
-        return tuple(self.grad(k).clone() for k, _ in self._grad_params(prefix))
+        keys = [k for k, _ in self._grad_params(prefix)]
+        if not keys:
+            return ()
+        lo = min(self._offsets[k] for k in keys)
+        hi = max(self._offsets[k] + self._numel(k) for k in keys)
+        snap = self.gflat[lo:hi].clone()
+        return tuple(snap[self._offsets[k] - lo: self._offsets[k] - lo + self._numel(k)].view(self._params[k].shape) for k in keys)
 
     # -------------------------------------------------------------------------------------- encoder
     def _pixels(self, pixel_values):
@@ -324,7 +428,9 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
                                  kwargs_decoder.get("position_ids"), embeds=decoder_inputs_embeds)
         loss = None
         if labels is not None:
-            loss = _CrossEntropyFn.apply(logits, labels.to(logits.device))    # CrossEntropyLoss(): mean over labels != -100 (reference :239-241)
+            loss = _CrossEntropyFn.apply(logits, labels.to(logits.device), -100)    # CrossEntropyLoss(): mean over labels != -100 (reference :239-241)
+        if logits.dim() == 3:
+            logits = _as_boundary(logits, kind="btv")                       # see BoundaryTensor: the callers' permute + F.cross_entropy stays on the fused loss kernel
         out = ModelOutput(loss=loss, logits=logits, past_key_values=None, encoder_last_hidden_state=enc)
         if return_dict is False:
             return out.to_tuple()

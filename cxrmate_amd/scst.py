@@ -126,8 +126,10 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
             opt.reducer.wait()
         opt.step(gscale=1.0 / world)
         seq_len = (glob["sampled"] != pad).sum(-1).float().mean()
+    # dropout_seed / encoder_seed: the device words the counter-based dropout / DropPath hashes of this step were keyed with (None in eval
+    # mode) -- cxr_dropout_mask materialises the masks from them (parity tests hand them to the CPU oracle)
     return {"loss": loss, "reward": glob["reward"].mean(), "baseline": glob["baseline"].mean(), "seq_len": seq_len, "sampled": sampled,
-            "baseline_ids": base, "global": glob}
+            "baseline_ids": base, "global": glob, "dropout_seed": rec.get("seed"), "encoder_seed": getattr(model._enc, "_seed", None)}
 
 
 def scst_generated_prompt_step(model, opt, reward, tokenizer, images, previous_findings, previous_impression, findings, impression,

@@ -39,11 +39,16 @@ def step_inputs(kind, input_ids, special_token_ids, mask_token_id=None, bos_toke
     return ids, torch.ones_like(ids), tt, None
 
 
-def top_k_filter(scores, top_k):
-    """TopKLogitsWarper (TF5 logits_process.py): entries below the k-th largest become -inf (ties at the k-th kept)."""
+def top_k_filter(scores, top_k, keep=None):
+    """TopKLogitsWarper (TF5 logits_process.py): entries below the k-th largest become -inf (ties at the k-th kept).
+    keep (int64, scores.shape[:-1]): token per row that stays finite whatever its rank -- for checking a bf16 implementation whose sampled token
+    sat at the edge of ITS top-k and falls just outside the fp32 one (the filtered distributions then differ by that one boundary entry)."""
     top_k = min(top_k, scores.shape[-1])
     kth = torch.topk(scores, top_k)[0][..., -1, None]
-    return scores.masked_fill(scores < kth, float("-inf"))
+    drop = scores < kth
+    if keep is not None:
+        drop = drop.scatter(-1, keep.clamp(min=0)[..., None], False)
+    return scores.masked_fill(drop, float("-inf"))
 
 
 def top_p_filter(scores, top_p, min_tokens_to_keep=1):

@@ -83,6 +83,39 @@ def generate_multi_case():
     return g, cfg, sd, x
 
 
+SHARPEN_KEYS = ("decoder.cls.predictions.transform.LayerNorm.weight", "decoder.cls.predictions.transform.LayerNorm.bias")
+
+
+def sharpened_state(cfg, seed, perturb, sharpen):
+    """Seeded weights with the LM head's final LayerNorm scaled by `sharpen` (the generator of the robust generate fixtures does the same)."""
+    sd = weights.init_encoder_decoder(cfg, seed=seed, perturb=perturb)
+    for k in SHARPEN_KEYS:
+        sd[k] = sd[k] * sharpen
+    return sd
+
+
+def generate_single_case():
+    g = load("generate_single.npz")
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, image_size=96)
+    sd = sharpened_state(cfg, int(g["seed"]), float(g["perturb"]), float(g["sharpen"]))
+    x = torch.randn(3, 3, 96, 96, generator=torch.Generator().manual_seed(int(g["pixel_seed"])))
+    return g, cfg, sd, x
+
+
+def beam_safe_case(name):
+    """-> (cfg, state dict, pixels, EOS bias, length_penalty, reference hypotheses [3,4,T], scores [3,4]) or None when the generator found no
+    robust case of that kind."""
+    g = load("generate_beam_safe.npz")
+    if f"{name}_seed" not in g.files:
+        return None
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, image_size=96)
+    seed = int(g[f"{name}_seed"])
+    sd = sharpened_state(cfg, seed, float(g["perturb"]), float(g["sharpen"]))
+    x = torch.randn(3, 2, 3, 96, 96, generator=torch.Generator().manual_seed(int(g[f"{name}_pixel_seed"])))
+    x[1, 1] = 0.0
+    return cfg, sd, x, float(g[f"{name}_eos_bias"]), float(g[f"{name}_length_penalty"]), g[f"{name}_all"], g[f"{name}_all_scores"], int(g["steps"])
+
+
 def generate_longitudinal_case():
     g = load("generate_longitudinal.npz")
     cfg = tiny_config(vocab_size=1000, decoder_layers=2, image_size=96, lora_r=8)

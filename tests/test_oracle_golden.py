@@ -168,6 +168,48 @@ def test_greedy_and_beam_multi():
         np.testing.assert_allclose(score.numpy(), g["beam4_eos_scores"], atol=1e-4)
 
 
+def test_single_image_generate_and_noise_robust_beam_fixtures():
+    """generate_single.npz (reference SingleCXREncoderDecoderModel: greedy with cache == no-cache, beam-4) and generate_beam_safe.npz (multi-image
+    beam-4 with length penalties; every case survived bf16-sized logit noise in the generator): the oracle's greedy / beam search reproduce them."""
+    g, cfg, sd, x = gu.generate_single_case()
+    with torch.no_grad():
+        h, _ = ocvt.encoder_forward(x, sd, cfg.encoder)
+
+        def fn(ids, am, tt, pos):
+            hh = h if ids.shape[0] == h.shape[0] else h.repeat_interleave(ids.shape[0] // h.shape[0], 0)
+            return obert.decoder_forward(ids, sd, cfg.decoder, hh, None, None, tt, pos)       # single-image model: no encoder mask (modelling_single.py:176)
+
+        L = g["greedy"].shape[1]
+        seq, argm, margin = ogen.greedy(fn, "single", 3, [gu.SEP], gu.BOS, gu.EOS, gu.PAD, L, return_margins=True)
+        assert np.array_equal(seq.numpy(), g["greedy"])
+        np.testing.assert_allclose(margin, g["greedy_margin"], atol=2e-3)
+        beam, score = ogen.beam_search(fn, "single", 3, 4, [gu.SEP], gu.BOS, gu.EOS, gu.PAD, L)
+        assert np.array_equal(beam.numpy(), g["beam4_all"][:, 0, : beam.shape[1]])
+        np.testing.assert_allclose(score.numpy(), g["beam4_all_scores"][:, 0], atol=2e-4)
+    found = 0
+    for case in ("plain", "lp2", "lp05", "eos"):
+        c = gu.beam_safe_case(case)
+        if c is None:
+            continue
+        found += 1
+        cfg, sd, x, eos_bias, lp, ref_all, ref_scores, steps = c
+        sd = dict(sd)
+        if eos_bias:
+            sd["decoder.cls.predictions.bias"] = sd["decoder.cls.predictions.bias"].clone()
+            sd["decoder.cls.predictions.bias"][gu.EOS] += eos_bias
+        with torch.no_grad():
+            h, emask = ocvt.encoder_forward(x, sd, cfg.encoder)
+
+            def fn2(ids, am, tt, pos):
+                r = ids.shape[0] // h.shape[0]
+                return obert.decoder_forward(ids, sd, cfg.decoder, h.repeat_interleave(r, 0), emask.repeat_interleave(r, 0), None, tt, pos)
+
+            beam, score = ogen.beam_search(fn2, "multi", 3, 4, [gu.SEP], gu.BOS, gu.EOS, gu.PAD, steps + 1, length_penalty=lp)
+        assert np.array_equal(beam.numpy(), ref_all[:, 0, : beam.shape[1]]), case
+        np.testing.assert_allclose(score.numpy(), ref_scores[:, 0], atol=2e-4, err_msg=case)
+    assert found >= 3
+
+
 def test_prompted_greedy_scores_and_reinforce():
     g, cfg, sd, x, prompt = gu.generate_longitudinal_case()
     with torch.no_grad():
