@@ -524,9 +524,15 @@ def spawn_ranks(n):
     port = s.getsockname()[1]
     s.close()
     procs = []
+    cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if len(cores) >= 2 * n and "CXR_CPU_AFFINITY" not in os.environ:
+            # every rank needs ~17 ms of host time per 43 ms step (Python + ctypes launches): its own slice of the host cores, so that eight
+            # ranks do not migrate over each other's caches (applied by the child before it touches the GPU, see main())
+            per = len(cores) // n
+            env["CXR_CPU_AFFINITY"] = ",".join(str(c) for c in cores[r * per:(r + 1) * per])
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
@@ -555,6 +561,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
 
+    aff = os.environ.get("CXR_CPU_AFFINITY")
+    if aff and hasattr(os, "sched_setaffinity"):
+        try:
+            os.sched_setaffinity(0, {int(c) for c in aff.split(",") if c != ""})
+        except (OSError, ValueError):
+            pass
     from cxrmate_amd import dp
     rank, local, world = dp.init_from_env()
     if world != args.gpus:

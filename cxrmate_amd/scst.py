@@ -104,7 +104,7 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         adv = (reward - baseline).float().contiguous()
         # data parallel: the sampled / greedy sequences and their rewards of ALL ranks (RCCL all-gather over xGMI, <= 64 KB per rank) for the
         # global reward / baseline statistics the step reports; the advantage above stays per study, as in the reference (gt_prompt.py:129-132)
-        glob = dp.gather_scst_statistics(sampled, base[:, P:].contiguous(), reward, baseline, pad)
+        glob = dp.gather_scst_statistics(sampled, base[:, P:].contiguous(), reward, baseline, pad, max_sampled=decoder_max_len, max_greedy=decoder_max_len)
         B, T, V = logits.shape
         sc = logits[:, P - 1:, :]                                            # scores of the n_new sampling steps
         if float(temperature) != 1.0:
@@ -121,7 +121,7 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
             model._dec.backward(saved, dlogits=full.view(B * T, -1), need_denc=False)
             ops.wgrad_join()
         world = dp.world_size()
-        if world > 1:
+        if dp.active():
             opt.reducer.reduce_range(0, model._param_total)
             opt.reducer.wait()
         opt.step(gscale=1.0 / world)

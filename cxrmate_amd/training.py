@@ -57,10 +57,11 @@ class FusedAdamW:
 
 
 # ---------------------------------------------------------------------------------------------------- step phases
-def _phase_fwd_loss_decbwd(model, opt, px, ids, am, tt, lab, pad_token_id, pos, logits_slice_from, join=True):
+def _phase_fwd_loss_decbwd(model, opt, px, ids, am, tt, lab, pad_token_id, pos, logits_slice_from, join=True, zero=True):
     """zero grads -> encoder fwd -> decoder fwd -> fused CE (loss + dlogits) -> decoder bwd. Returns (loss, esaved, denc)."""
     dev = model.device
-    opt.zero_grad()
+    if zero:
+        opt.zero_grad()
     px = model._pixels(px)
     multi = px.dim() == 5
     flat = px.view(-1, *px.shape[-3:]) if multi else px
@@ -116,36 +117,46 @@ class wgrad_overlap:
 
 
 def tf_train_step(model, opt: FusedAdamW, pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids, label_ids,
-                  pad_token_id, decoder_position_ids=None, logits_slice_from: int = 0):
-    """One teacher-forcing optimisation step (eager launches); returns the (detached, device) loss tensor [1]."""
+                  pad_token_id, decoder_position_ids=None, logits_slice_from: int = 0, accumulate=None):
+    """One teacher-forcing optimisation step (eager launches); returns the (detached, device) loss tensor [1].
+    accumulate = (j, k): micro-batch j of k of one optimiser step -- gradient accumulation as the reference trains (config/train/single_tf.yaml:16-17:
+    mbatch_size 8, accumulated_mbatch_size 32; under DDP Lightning wraps the first k - 1 micro-steps in `no_sync()`): micro-step 0 zeroes the
+    gradient buffer, every micro-step adds its gradients, ONLY the last one all-reduces (once per optimiser step, not once per micro-batch) and
+    runs AdamW on the mean over ranks and micro-batches (gscale = 1 / (world * k))."""
     with wgrad_overlap():
         return _tf_train_step(model, opt, pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids, label_ids,
-                              pad_token_id, decoder_position_ids, logits_slice_from)
+                              pad_token_id, decoder_position_ids, logits_slice_from, accumulate)
 
 
 def _tf_train_step(model, opt, pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids, label_ids, pad_token_id,
-                   decoder_position_ids, logits_slice_from):
+                   decoder_position_ids, logits_slice_from, accumulate=None):
+    j, k = accumulate if accumulate is not None else (0, 1)
+    assert 0 <= j < k
     # eager launches: the main stream goes straight from the decoder backward into the encoder backward; the decoder's weight-gradient
     # kernels still queued on the side stream keep running beside it (one join at the end of the step)
     loss, esaved, denc = _phase_fwd_loss_decbwd(model, opt, pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids,
-                                                label_ids, pad_token_id, decoder_position_ids, logits_slice_from, join=False)
-    world = dp.world_size()
+                                                label_ids, pad_token_id, decoder_position_ids, logits_slice_from, join=False, zero=j == 0)
+    if j + 1 < k:                                                # no_sync micro-step: gradients stay local, no optimiser step
+        _phase_encbwd(model, esaved, denc, None)
+        return loss
+    world = dp.world_size() if dp.active() else 1
+    sync = dp.active()
     enc_trainable = esaved is not None
-    if world > 1 and enc_trainable:
+    if sync and enc_trainable:
         # decoder parameters sit after the encoder's in the flat buffer: reduce them while the encoder backward runs (the reducer's stream
         # waits for the weight-gradient stream, the main stream does not)
         opt.reducer.reduce_range(opt.split, model._param_total, after=ops.WGRAD_STREAM)
     early = None
-    if world > 1 and enc_trainable and opt.enc_tail:
+    if sync and enc_trainable and opt.enc_tail:
         # ... and the last encoder stage + projection head (93 % of the encoder's parameters) while the first stages are still in backward
         def early(s):
             if s == opt.enc_last_stage:
                 opt.reducer.reduce_range(opt.enc_tail, opt.split, after=ops.WGRAD_STREAM)
     _phase_encbwd(model, esaved, denc, early)
-    if world > 1:
+    if sync:
         opt.reducer.reduce_range(0, opt.split if enc_trainable else model._param_total)      # whatever has not been started yet
         opt.reducer.wait()
-    opt.step(gscale=1.0 / world)
+    opt.step(gscale=1.0 / (world * k))
     return loss
 
 
@@ -158,7 +169,8 @@ class GraphedTFStep:
         dev = model.device
         self.static = [t.detach().to(dev).clone() if t is not None else None
                        for t in (pixel_values, decoder_input_ids, decoder_attention_mask, decoder_token_type_ids, label_ids, decoder_position_ids)]
-        self.world = dp.world_size()
+        self.world = dp.world_size() if dp.active() else 1
+        self.sync = dp.active()
         px, ids, am, tt, lab, pos = self.static
         if model.training and model.static_dropout_seed is None:
             # captured kernels read the dropout seed from this device word; each replay advances it (store.next_dropout_seed)
@@ -191,10 +203,10 @@ class GraphedTFStep:
         if model.training:
             model._enc._bn_version += 1       # the replay moves the BatchNorm running statistics: eval-mode folds must be re-derived
         self.g1.replay()
-        if self.world > 1 and self.enc_trainable:
+        if self.sync and self.enc_trainable:
             opt.reducer.reduce_range(opt.split, model._param_total)
         self.g2.replay()
-        if self.world > 1:
+        if self.sync:
             opt.reducer.reduce_range(0, opt.split if self.enc_trainable else model._param_total)
             opt.reducer.wait()
         self.g3.replay()

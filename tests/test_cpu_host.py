@@ -144,7 +144,15 @@ def _dp_worker(rank, world, path, q):
     # SCST statistics: ragged sampled / greedy lengths per rank, rewards in rank order
     st = dp.gather_scst_statistics(torch.full((2, 4 + rank), 10 + rank, dtype=torch.int64), torch.full((2, 6 - rank), 20 + rank, dtype=torch.int64),
                                    torch.tensor([0.1, 0.2]) + rank, torch.tensor([0.3, 0.4]) + rank, pad_token_id=4)
-    gathered = (gathered, st)
+    # ... and with the caller's decode limits as fixed widths: ONE collective, no length exchange
+    st_fixed = dp.gather_scst_statistics(torch.full((2, 4 + rank), 10 + rank, dtype=torch.int64), torch.full((2, 6 - rank), 20 + rank, dtype=torch.int64),
+                                         torch.tensor([0.1, 0.2]) + rank, torch.tensor([0.3, 0.4]) + rank, pad_token_id=4, max_sampled=7, max_greedy=8)
+    # bf16 on the wire: same sums up to bf16 rounding of the summands and of the sum
+    flat16 = mine.clone()
+    red16 = dp.GradReducer(flat16, [(0, 300), (400, 1000)], max_bucket_elems=128, cuts=[500], comm_dtype=torch.bfloat16)
+    red16.reduce_range(0, 1000)
+    red16.wait()
+    gathered = (gathered, st, st_fixed, flat16)
     q.put((rank, mine, flat, gathered, mean))
     dist.destroy_process_group()
 
@@ -162,9 +170,17 @@ def test_gradient_allreduce_and_sequence_allgather_gloo_world2():
         for p in procs:
             p.join(60)
             assert p.exitcode == 0
-    (_, m0, f0, (g0, st0), mean0), (_, m1, f1, (g1, st1), _) = res
+    (_, m0, f0, (g0, st0, sf0, h0), mean0), (_, m1, f1, (g1, st1, sf1, h1), _) = res
     for k in st0:
-        assert torch.equal(st0[k], st1[k])                                  # every rank holds the same global view
+        assert torch.equal(st0[k], st1[k]) and torch.equal(sf0[k], sf1[k])  # every rank holds the same global view
+    assert sf0["sampled"].shape == (4, 7) and sf0["greedy"].shape == (4, 8)
+    assert torch.equal(sf0["sampled"][:, :5], st0["sampled"]) and bool((sf0["sampled"][:, 5:] == 4).all())
+    assert torch.equal(sf0["greedy"][:, :6], st0["greedy"]) and torch.equal(sf0["reward"], st0["reward"]) and torch.equal(sf0["baseline"], st0["baseline"])
+    tot = m0 + m1
+    assert torch.equal(h0[:300], h1[:300]) and torch.equal(h0[400:], h1[400:])
+    for lo, hi in ((0, 300), (400, 1000)):
+        err = (h0[lo:hi] - tot[lo:hi]).pow(2).mean().sqrt() / tot[lo:hi].pow(2).mean().sqrt()
+        assert float(err) < 6e-3, float(err)                               # stated tolerance of the bf16 wire format at 2 ranks
     assert st0["sampled"].shape == (4, 5) and st0["sampled"][0].tolist() == [10, 10, 10, 10, 4] and st0["sampled"][3].tolist() == [11] * 5
     assert st0["greedy"].shape == (4, 6) and st0["greedy"][2].tolist() == [21] * 5 + [4]
     assert torch.allclose(st0["reward"], torch.tensor([0.1, 0.2, 1.1, 1.2])) and torch.allclose(st0["baseline"], torch.tensor([0.3, 0.4, 1.3, 1.4]))

@@ -137,3 +137,130 @@ def test_dp2_scst_step_train_mode_replicas_and_global_statistics():
     assert gs0.shape[0] == 4 and np.array_equal(gs0[:2, :s0.shape[1]], s0) and np.array_equal(gs0[2:, :s1.shape[1]], s1)
     assert abs(r0 - float(gr0.mean())) < 1e-6
     assert not np.array_equal(s0, s1)                                   # different studies / random streams per rank
+
+
+def test_gradient_accumulation_equals_one_step_on_the_concatenated_batch():
+    """tf_train_step(accumulate=(j, k)): k micro-steps (reference config/train/single_tf.yaml:16-17: mbatch_size 8 of accumulated_mbatch_size 32;
+    DDP `no_sync` on the first k - 1) == ONE step on the concatenated batch. Eval-mode BatchNorm / no dropout so that the two computations are the
+    same function of the data (batch statistics are per micro-batch in the reference too)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cxrmate_amd import modelling
+    from cxrmate_amd.training import FusedAdamW, tf_train_step
+    cfg = gu.tiny_config(vocab_size=1000, decoder_layers=2, image_size=96)
+    g = torch.Generator().manual_seed(9)
+    px = torch.randn(4, 3, 96, 96, generator=g).cuda()
+    ids = torch.randint(12, 1000, (4, 17), generator=g)
+    ids[:, 0] = 1
+    inp, lab = ids[:, :-1].cuda(), ids[:, 1:].cuda()
+    names = ["decoder.bert.encoder.layer.1.output.dense.weight", "encoder.cvt.encoder.stages.2.layers.0.intermediate.dense.weight",
+             "decoder.bert.embeddings.word_embeddings.weight"]
+
+    def run(k):
+        m = modelling.SingleCXREncoderDecoderModel(cfg, device="cuda:0", seed=21, perturb=0.05)
+        opt = FusedAdamW(m, lr=1e-3)
+        tt = m.token_ids_to_token_type_ids(inp, [3])
+        per = 4 // k
+        losses = []
+        for j in range(k):
+            sl = slice(j * per, (j + 1) * per)
+            before = m.f32(names[0]).clone()
+            losses.append(float(tf_train_step(m, opt, px[sl], inp[sl], torch.ones_like(inp[sl]), tt[sl], lab[sl], pad_token_id=4, accumulate=(j, k)).item()))
+            if j + 1 < k:
+                assert torch.equal(before, m.f32(names[0]))          # no optimiser step inside the accumulation window
+        torch.cuda.synchronize()
+        return np.mean(losses), {n: m.f32(n).cpu().clone() for n in names}, int(opt.t)
+
+    l1, w1, t1 = run(1)
+    l2, w2, t2 = run(2)
+    l4, w4, t4 = run(4)
+    assert t1 == t2 == t4 == 1
+    assert abs(l1 - l2) < 2e-3 and abs(l1 - l4) < 2e-3
+    for n in names:
+        # AdamW's first step moves every weight by lr * sign-like(g): compare the UPDATES (equal up to the summation order of the gradients)
+        torch.testing.assert_close(w2[n], w1[n], atol=2e-4, rtol=0)
+        torch.testing.assert_close(w4[n], w1[n], atol=2e-4, rtol=0)
+
+
+def _nccl_worker(path, q):
+    import torch.distributed as dist
+    from cxrmate_amd import dp, modelling
+    from cxrmate_amd.scst import scst_step
+    from cxrmate_amd.training import FusedAdamW, tf_train_step
+    os.environ["CXR_DP_FORCE"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"file://{path}", rank=0, world_size=1)
+    try:
+        assert dp.active() and dp.world_size() == 1
+        cfg = gu.tiny_config(vocab_size=1000, decoder_layers=2, image_size=96)
+        g = torch.Generator().manual_seed(5)
+        px = torch.randn(2, 3, 96, 96, generator=g).cuda()
+        ids = torch.randint(12, 1000, (2, 17), generator=g)
+        ids[:, 0] = 1
+        inp, lab = ids[:, :-1].cuda(), ids[:, 1:].cuda()
+        out = {}
+        for wire in (None, torch.bfloat16):
+            m = modelling.SingleCXREncoderDecoderModel(cfg, device="cuda:0", seed=21, perturb=0.05)
+            opt = FusedAdamW(m, lr=1e-3)
+            opt.reducer.comm_dtype = wire
+            calls = []
+            real = dist.all_reduce
+
+            def spy(t, *a, **k):
+                calls.append((t.dtype, t.numel()))
+                return real(t, *a, **k)
+
+            dist.all_reduce = spy
+            try:
+                tt = m.token_ids_to_token_type_ids(inp, [3])
+                loss = tf_train_step(m, opt, px, inp, torch.ones_like(inp), tt, lab, pad_token_id=4)
+                torch.cuda.synchronize()
+            finally:
+                dist.all_reduce = real
+            out[str(wire)] = (float(loss.item()), m.f32("decoder.bert.encoder.layer.1.output.dense.weight").cpu().numpy(), calls)
+        # SCST statistics gather (one all_gather_into_tensor over RCCL)
+        st = dp.gather_scst_statistics(torch.full((2, 4), 10, dtype=torch.int64, device="cuda"), torch.full((2, 6), 20, dtype=torch.int64, device="cuda"),
+                                       torch.tensor([0.1, 0.2], device="cuda"), torch.tensor([0.3, 0.4], device="cuda"), 4, max_sampled=5, max_greedy=6)
+        torch.cuda.synchronize()
+        q.put(("ok", out, {k: v.cpu().numpy() for k, v in st.items()}))
+    except Exception as e:                                       # pragma: no cover
+        import traceback
+        q.put(("error", traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_executes_the_reducer_and_the_gather_at_world_1():
+    """backend='nccl' (= RCCL on ROCm) with ONE rank and CXR_DP_FORCE=1: the training step's gradient all-reduces (async work handles on the
+    reducer's private stream, fp32 and bf16 wire format) and the SCST gather run through RCCL on the hardware. Sums over one rank are the identity,
+    so the step must equal the collective-free step. (No multi-GPU box is available to this build: this is the RCCL code path, not a scaling number.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    from cxrmate_amd import modelling
+    from cxrmate_amd.training import FusedAdamW, tf_train_step
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as d:
+        p = ctx.Process(target=_nccl_worker, args=(os.path.join(d, "rdzv"), q))
+        p.start()
+        status, out, st = q.get(timeout=600)
+        p.join(120)
+    assert status == "ok", out
+    cfg = gu.tiny_config(vocab_size=1000, decoder_layers=2, image_size=96)
+    g = torch.Generator().manual_seed(5)
+    px = torch.randn(2, 3, 96, 96, generator=g).cuda()
+    ids = torch.randint(12, 1000, (2, 17), generator=g)
+    ids[:, 0] = 1
+    inp, lab = ids[:, :-1].cuda(), ids[:, 1:].cuda()
+    m = modelling.SingleCXREncoderDecoderModel(cfg, device="cuda:0", seed=21, perturb=0.05)
+    opt = FusedAdamW(m, lr=1e-3)
+    loss = tf_train_step(m, opt, px, inp, torch.ones_like(inp), m.token_ids_to_token_type_ids(inp, [3]), lab, pad_token_id=4)
+    ref = m.f32("decoder.bert.encoder.layer.1.output.dense.weight").cpu().numpy()
+    l32, w32, c32 = out["None"]
+    l16, w16, c16 = out["torch.bfloat16"]
+    assert c32 and all(dt == torch.float32 for dt, _ in c32) and sum(n for _, n in c32) == sum(b - a for a, b in opt.reducer.buckets)
+    assert c16 and all(dt == torch.bfloat16 for dt, _ in c16)
+    assert abs(l32 - float(loss.item())) < 1e-6 and np.array_equal(w32, ref)        # fp32 wire at one rank: bit-identical step
+    assert abs(l16 - float(loss.item())) < 1e-6 and np.abs(w16 - ref).max() < 2.5e-3   # bf16 wire: AdamW's first step is lr-sized (1e-3) whatever the gradient's last bits
+    assert st["sampled"].shape == (2, 5) and st["greedy"].shape == (2, 6) and np.allclose(st["reward"], [0.1, 0.2]) and np.allclose(st["baseline"], [0.3, 0.4])
