@@ -319,6 +319,11 @@ def linear_bwd_input(dy, w_t, **kw):
 
 
 # ------------------------------------------------------------------------------------------------ attention
+def attention_config(fwd=0, bwd=0):
+    """kernel generation of attention / attention_bwd (1 = rounds 1-2, 2 = round 3; 0 keeps the setting): A/B measurements and parity tests"""
+    LIB.call("cxr_attn_config", int(fwd), int(bwd))
+
+
 def attention(q, k, v, heads, scale, kpm=None, causal=False, causal_shift=None, need_lse=False, out=None, drop=None):
     """q [B,Tq,H*64], k/v [B,Tk,H*64] bf16 (last dim contiguous; batch/row strides free). -> out [B,Tq,H*64], lse [B,H,Tq] | None"""
     B, Tq, D = q.shape

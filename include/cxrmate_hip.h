@@ -82,6 +82,9 @@ int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, const void* O
                       long o_rs, long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal, int causal_shift, float drop_p,
                       const unsigned int* drop_seed, unsigned int drop_site, int drop_t0, long dkv_bs, long dkv_rs, long dq_bs, long dq_rs, hipStream_t stream);
                       /* dkv_rs != 0 / dq_rs != 0: dK, dV / dQ are written with these batch / row strides (elements) instead of contiguously */
+/* kernel generation behind the two entry points above (A/B measurements, parity tests): forward 1 = 32 query rows per wave, two barriers per tile
+ * (rounds 1-2); 2 = 64 rows per wave, double-buffered tiles, one barrier (round 3, default). Backward likewise. Any other value keeps the setting. */
+int cxr_attn_config(int fwd_version, int bwd_version);
 
 /* ---- train-mode dropout / DropPath (TF5:bert:106,298,464; TF5:cvt:297-316) ---------------------------------------------------
  * out = resid + f * y with f = keep(seed, site, b, t, col)/(1-p) per element (b = row / rows_per_b, t = t0 + row % rows_per_b), or
