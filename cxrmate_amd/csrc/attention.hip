@@ -495,8 +495,9 @@ static void attn_fwd2_launch(const AttnArgs& a, hipStream_t stream) {
     else { CXR_LAUNCH((attn_fwd2_kernel<NW, 0>), grid, block, 0, stream, a); }
 }
 
-static int g_attn_fwd_version = 2;
-int g_attn_bwd_version = 1;
+static int env_version(const char* name) { const char* e = getenv(name); return (e && e[0] == '1') ? 1 : 2; }
+static int g_attn_fwd_version = env_version("CXR_ATT_FWD");        // lab switches: CXR_ATT_FWD=1 / CXR_ATT_BWD=1 start with the round-2 kernels
+int g_attn_bwd_version = env_version("CXR_ATT_BWD");
 // A/B switch (tests, micro-benchmarks): forward 1 = attn_fwd_kernel (32 rows per wave), 2 = attn_fwd2_kernel; backward likewise (attention_bwd.hip)
 extern "C" int cxr_attn_config(int fwd_version, int bwd_version) {
     if (fwd_version == 1 || fwd_version == 2) g_attn_fwd_version = fwd_version;

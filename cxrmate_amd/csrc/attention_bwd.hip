@@ -6,6 +6,7 @@
 // Tiles that are consumed both row-wise (ds_read_b128) and column-wise (ds_read_b64_tr_b16) are kept as two LDS images
 // (144-B rows / 192-B rows) so both read patterns are bank-conflict free.
 #include "common.h"
+#include <stdlib.h>
 
 struct AttnBwdArgs {
     const bf16_t* Q; const bf16_t* K; const bf16_t* V; const bf16_t* dO; const bf16_t* O;
@@ -374,6 +375,253 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwdArgs a
     }
 }
 
+// ---- round 3: the dQ kernel in the structure of attn_fwd2_kernel (attention.hip): 64 query rows per wave (every K / V fragment read from LDS
+// feeds two MFMAs, two independent softmax-backward chains per wave), K / V tiles double-buffered with ONE barrier per tile, straight-line
+// 32-key step for tiles without masking, no math for tiles whose keys are all masked or causally invisible to the wave (exact: p = 0 there).
+constexpr int Q2_KR = 64 * RS * 2, Q2_KT = 64 * TS * 2, Q2_BUF = 2 * Q2_KR + Q2_KT;        // row image of K, transposed-read image of K, row image of V
+
+template <bool MASKED, bool DROP>
+__device__ __forceinline__ void dq2_step(const AttnBwdArgs& a, const bf16_t* Kr, const bf16_t* Kt, const bf16_t* Vr, const unsigned char* Mc, const int kt,
+                                         const int kv0, const bf16x8_t (&qf)[2][4], const bf16x8_t (&dof)[2][4], f32x16_t (&dq)[2][2],
+                                         const float (&lse2)[2], const float (&dl)[2], const uint32_t (&drop_key)[2], const int row0, const int lane) {
+    const int ql = lane & 31, hh = lane >> 5, g = lane >> 4, li = lane & 15;
+    f32x16_t S[2], dP[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { S[0][i] = 0.f; S[1][i] = 0.f; dP[0][i] = 0.f; dP[1][i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const bf16x8_t ka = *reinterpret_cast<const bf16x8_t*>(Kr + (kt * 32 + ql) * RS + s * 16 + hh * 8);
+        const bf16x8_t va = *reinterpret_cast<const bf16x8_t*>(Vr + (kt * 32 + ql) * RS + s * 16 + hh * 8);
+        S[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[0][s], S[0], 0, 0, 0);
+        S[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[1][s], S[1], 0, 0, 0);
+        dP[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[0][s], dP[0], 0, 0, 0);
+        dP[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[1][s], dP[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        if (DROP) {                                                 // dP <- keep/(1-p) * dP before the softmax backward
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int kloc = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const uint32_t bits = dropout_pair_bits(drop_key[x], (uint32_t)(kv0 + kloc) >> 1);
+                dP[x][r] = (bits & 0xffffu) >= a.drop_thr16 ? dP[x][r] * a.drop_inv : 0.f;
+                dP[x][r + 1] = (bits >> 16) >= a.drop_thr16 ? dP[x][r + 1] * a.drop_inv : 0.f;
+            }
+        }
+        if (!MASKED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(S[x][r], a.scale_log2e, -lse2[x]));
+                dP[x][r] = p * (dP[x][r] - dl[x]);                  // softmax scale applied once to the dQ accumulators
+            }
+        } else {
+            const int qrow = row0 + x * 32 + ql;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kloc = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                bool ok = Mc[kloc] == 2;
+                if (a.causal) ok = ok && (kv0 + kloc <= qrow + a.causal_shift);
+                const float p = ok ? __builtin_amdgcn_exp2f(fmaf(S[x][r], a.scale_log2e, -lse2[x])) : 0.f;
+                dP[x][r] = p * (dP[x][r] - dl[x]);
+            }
+        }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8_t ds0 = pack_frag(dP[0], s2), ds1 = pack_frag(dP[1], s2);
+        const int kb = kt * 32 + s2 * 16 + 4 * hh + (li >> 2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int col = dt * 32 + 16 * (g & 1) + 4 * (li & 3);
+            const bf16x8_t ktf = trp(Kt + kb * TS + col, Kt + (kb + 8) * TS + col);
+            dq[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, ds0, dq[0][dt], 0, 0, 0);
+            dq[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, ds1, dq[1][dt], 0, 0, 0);
+        }
+    }
+}
+
+// MODE 0: no key-padding mask, not causal, no dropout; 1: masks; 2: masks + dropout (as attn_fwd2_kernel)
+template <int NW, int MODE>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq2_kernel(const AttnBwdArgs a) {
+    constexpr int NT = NW * 64, CH = 512 / NT;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * Q2_BUF + 128 + 16];
+    unsigned char* Ms = smem + 2 * Q2_BUF;
+    int* Mf = reinterpret_cast<int*>(smem + 2 * Q2_BUF + 128);     // per buffer: bit 0 = every key of the tile attends, bit 1 = none does
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int qb0 = blockIdx.x * (NW * 64);
+    const int ql = lane & 31, hh = lane >> 5;
+    const int row0 = qb0 + wave * 64;
+    const bool wave_on = row0 < a.Tq;
+
+    bf16x8_t qf[2][4], dof[2][4];
+    float lse2[2], dl[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int qrow = row0 + x * 32 + ql;
+        const int qc = qrow < a.Tq ? qrow : a.Tq - 1;
+        const bf16_t* qp = a.Q + (long)b * a.q_bs + (long)qc * a.q_rs + head * 64 + hh * 8;
+        const bf16_t* dp = a.dO + (long)b * a.o_bs + (long)qc * a.o_rs + head * 64 + hh * 8;
+        const bf16_t* op = a.O + (long)b * a.o_bs + (long)qc * a.o_rs + head * 64 + hh * 8;
+        uint4 ov[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[x][s] = *reinterpret_cast<const bf16x8_t*>(qp + s * 16);
+            dof[x][s] = *reinterpret_cast<const bf16x8_t*>(dp + s * 16);
+            ov[s] = *reinterpret_cast<const uint4*>(op + s * 16);
+        }
+        lse2[x] = a.LSE[((long)b * a.H + head) * a.Tq + qc] * 1.4426950408889634f;
+        // delta = rowsum(dO * O) of this lane's query row (the lane pair hh = 0 / 1 holds the row between them); left in a.delta for the dK/dV kernel
+        float part = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float of[8], df[8];
+            unpack8(ov[s], of);
+            unpack8(__builtin_bit_cast(uint4, dof[x][s]), df);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part = fmaf(of[j], df[j], part);
+        }
+        dl[x] = part + __shfl_xor(part, 32, 64);
+        if (hh == 0 && qrow < a.Tq) a.delta[((long)b * a.H + head) * a.Tq + qrow] = dl[x];
+    }
+    uint32_t drop_key[2] = {0u, 0u};
+    if (MODE == 2) {
+        drop_key[0] = dropout_row_key(*a.drop_seed, a.drop_site, (uint32_t)(b * a.H + head), (uint32_t)(row0 + ql + a.drop_t0));
+        drop_key[1] = dropout_row_key(*a.drop_seed, a.drop_site, (uint32_t)(b * a.H + head), (uint32_t)(row0 + 32 + ql + a.drop_t0));
+    }
+
+    int ntiles = (a.Tk + 63) >> 6;
+    if (MODE != 0 && a.causal) {
+        const int last = qb0 + NW * 64 - 1 + a.causal_shift;
+        const int lim = last < 0 ? 0 : (last >> 6) + 1;
+        ntiles = lim < ntiles ? lim : ntiles;
+    }
+    const int nloop = MODE == 0 ? (a.Tk >> 6) : ntiles;            // MODE 0: the full tiles; the ragged one (if any) follows the loop
+    const bf16_t* kbase = a.K + (long)b * a.k_bs + head * 64;
+    const bf16_t* vbase = a.V + (long)b * a.v_bs + head * 64;
+    const unsigned char* mrow = (MODE != 0 && a.kpm) ? a.kpm + (long)b * a.kpm_bs : reinterpret_cast<const unsigned char*>(kbase);
+    uint4 kreg_0, kreg_1, kreg_2, kreg_3, vreg_0, vreg_1, vreg_2, vreg_3;      // (named scalars: as arrays hipcc keeps them in scratch memory)
+    unsigned char mbyte = 0;
+#define Q2_GL1(c, tile)                                                                              \
+    if (c < CH) {                                                                                    \
+        const int i_ = c * NT + tid;                                                                 \
+        int key_ = (tile) * 64 + (i_ >> 3); key_ = key_ < a.Tk ? key_ : a.Tk - 1;                    \
+        kreg_##c = *reinterpret_cast<const uint4*>(kbase + (long)key_ * a.k_rs + (i_ & 7) * 8);      \
+        vreg_##c = *reinterpret_cast<const uint4*>(vbase + (long)key_ * a.v_rs + (i_ & 7) * 8);      \
+    }
+#define Q2_GLOAD(tile)                                                                               \
+    do {                                                                                             \
+        Q2_GL1(0, tile) Q2_GL1(1, tile) Q2_GL1(2, tile) Q2_GL1(3, tile)                              \
+        if (MODE != 0) {                                                                             \
+            const int kk_ = (tile) * 64 + (tid & 63);                                                \
+            mbyte = mrow[a.kpm ? (kk_ < a.Tk ? kk_ : a.Tk - 1) : 0];                                 \
+        }                                                                                            \
+    } while (0)
+#define Q2_LW1(c, kr_, kt_, vr_)                                                                     \
+    if (c < CH) {                                                                                    \
+        const int i_ = c * NT + tid;                                                                 \
+        *reinterpret_cast<uint4*>(kr_ + (i_ >> 3) * RS + (i_ & 7) * 8) = kreg_##c;                   \
+        *reinterpret_cast<uint4*>(kt_ + (i_ >> 3) * TS + (i_ & 7) * 8) = kreg_##c;                   \
+        *reinterpret_cast<uint4*>(vr_ + (i_ >> 3) * RS + (i_ & 7) * 8) = vreg_##c;                   \
+    }
+#define Q2_LWRITE(tile, buf)                                                                         \
+    do {                                                                                             \
+        bf16_t* kr_ = reinterpret_cast<bf16_t*>(smem + (buf) * Q2_BUF);                              \
+        bf16_t* kt_ = reinterpret_cast<bf16_t*>(smem + (buf) * Q2_BUF + Q2_KR);                      \
+        bf16_t* vr_ = reinterpret_cast<bf16_t*>(smem + (buf) * Q2_BUF + Q2_KR + Q2_KT);              \
+        Q2_LW1(0, kr_, kt_, vr_) Q2_LW1(1, kr_, kt_, vr_) Q2_LW1(2, kr_, kt_, vr_) Q2_LW1(3, kr_, kt_, vr_) \
+        if (tid < 64) {                                                                              \
+            const int key_ = (tile) * 64 + tid;        /* 0 = beyond Tk, 1 = masked, 2 = attend */   \
+            const int code_ = key_ < a.Tk ? ((MODE == 0 || a.kpm == nullptr || mbyte) ? 2 : 1) : 0;  \
+            Ms[(buf) * 64 + tid] = code_;                                                            \
+            if (MODE != 0) {                           /* (tid < 64 is the whole wave 0) */          \
+                const unsigned long long live_ = __ballot(code_ == 2);                               \
+                if (tid == 0) Mf[buf] = (live_ == ~0ull ? 1 : 0) | (live_ == 0ull ? 2 : 0);          \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
+
+    f32x16_t dq[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dq[x][0][i] = 0.f; dq[x][1][i] = 0.f; }
+
+    if (ntiles > 0) { Q2_GLOAD(0); Q2_LWRITE(0, 0); }
+    if (ntiles > 1) Q2_GLOAD(1);
+    __syncthreads();
+    for (int tile = 0; tile < nloop; ++tile) {
+        const int cur = tile & 1;
+        const bf16_t* Kr = reinterpret_cast<const bf16_t*>(smem + cur * Q2_BUF);
+        const bf16_t* Kt = reinterpret_cast<const bf16_t*>(smem + cur * Q2_BUF + Q2_KR);
+        const bf16_t* Vr = reinterpret_cast<const bf16_t*>(smem + cur * Q2_BUF + Q2_KR + Q2_KT);
+        int how = wave_on ? (MODE == 0 ? 1 : 2) : 0;               // 0 = skip, 1 = straight-line step, 2 = masked step (wave-uniform)
+        if (MODE != 0 && wave_on) {
+            const int fl = __builtin_amdgcn_readfirstlane(Mf[cur]);
+            const int kv0 = tile * 64;
+            if ((fl & 2) || (a.causal && kv0 > row0 + 63 + a.causal_shift)) how = 0;
+            else if ((fl & 1) && (!a.causal || kv0 + 63 <= row0 + a.causal_shift)) how = 1;
+        }
+        if (how == 1) dq2_step<false, MODE == 2>(a, Kr, Kt, Vr, Ms + cur * 64, 0, tile * 64, qf, dof, dq, lse2, dl, drop_key, row0, lane);
+        else if (MODE != 0 && how == 2) dq2_step<true, MODE == 2>(a, Kr, Kt, Vr, Ms + cur * 64, 0, tile * 64, qf, dof, dq, lse2, dl, drop_key, row0, lane);
+        if (tile + 1 < ntiles) {
+            Q2_LWRITE(tile + 1, cur ^ 1);
+            if (tile + 2 < ntiles) Q2_GLOAD(tile + 2);
+        }
+        if (how == 1) dq2_step<false, MODE == 2>(a, Kr, Kt, Vr, Ms + cur * 64, 1, tile * 64, qf, dof, dq, lse2, dl, drop_key, row0, lane);
+        else if (MODE != 0 && how == 2) dq2_step<true, MODE == 2>(a, Kr, Kt, Vr, Ms + cur * 64, 1, tile * 64, qf, dof, dq, lse2, dl, drop_key, row0, lane);
+        __syncthreads();
+    }
+    if (MODE == 0 && nloop < ntiles) {                             // ragged last tile: keys beyond Tk are dead
+        const int cur = nloop & 1;
+        const bf16_t* Kr = reinterpret_cast<const bf16_t*>(smem + cur * Q2_BUF);
+        const bf16_t* Kt = reinterpret_cast<const bf16_t*>(smem + cur * Q2_BUF + Q2_KR);
+        const bf16_t* Vr = reinterpret_cast<const bf16_t*>(smem + cur * Q2_BUF + Q2_KR + Q2_KT);
+        if (wave_on) {
+            dq2_step<true, false>(a, Kr, Kt, Vr, Ms + cur * 64, 0, nloop * 64, qf, dof, dq, lse2, dl, drop_key, row0, lane);
+            if (nloop * 64 + 32 < a.Tk) dq2_step<true, false>(a, Kr, Kt, Vr, Ms + cur * 64, 1, nloop * 64, qf, dof, dq, lse2, dl, drop_key, row0, lane);
+        }
+        __syncthreads();
+    }
+#undef Q2_GL1
+#undef Q2_GLOAD
+#undef Q2_LW1
+#undef Q2_LWRITE
+
+    bf16_t* Ot = reinterpret_cast<bf16_t*>(smem) + wave * (32 * 64);
+    if (wave_on) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int r0 = row0 + x * 32;
+            const int valid = a.Tq - r0 < 32 ? a.Tq - r0 : 32;
+            if (valid > 0) {                                       // wave-uniform
+                if (x) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        uint2 pk;
+                        pk.x = pack2bf(dq[x][dt][4 * rg] * a.scale, dq[x][dt][4 * rg + 1] * a.scale);
+                        pk.y = pack2bf(dq[x][dt][4 * rg + 2] * a.scale, dq[x][dt][4 * rg + 3] * a.scale);
+                        TILE_PUT(Ot, lane, dt, rg, pk);
+                    }
+                tile_rows_store(Ot, lane, a.dQ + (long)b * a.dq_bs + (long)r0 * a.dq_rs + head * 64, a.dq_rs, valid);
+            }
+        }
+    }
+}
+
+// Only the unmasked form is launched: with masks / dropout the kernel needs more than 256 registers (100 - 140 bytes of scratch per lane) and
+// measured 4 - 17 % SLOWER than attn_bwd_dq_kernel on the decoder's shapes, 3 - 8 % faster on the CvT stages (scripts/attn_micro.py).
+template <int NW>
+static void attn_bwd_dq2_launch(const AttnBwdArgs& a, hipStream_t stream) {
+    const dim3 grid(cdiv(a.Tq, NW * 64), a.H, a.B), block(NW * 64);
+    CXR_LAUNCH((attn_bwd_dq2_kernel<NW, 0>), grid, block, 0, stream, a);
+}
+
+extern int g_attn_bwd_version;      // attention.hip (cxr_attn_config)
+
 // dQ [B,Tq,H*64] and dK / dV [B,Tk,H*64] are written contiguously (dq_rs == 0, dkv_rs == 0) or with batch / row strides (the self-attention
 // gradients of a layer as the three column blocks of one [B*T, 3*D] matrix; the
 // decoder writes the cross-attention dK / dV of all layers into one [B*S, layers*2*D] matrix: one dX and one dW GEMM for all of them).
@@ -396,7 +644,12 @@ extern "C" int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, co
     a.causal = causal; a.causal_shift = causal_shift;
     a.drop_seed = drop_seed; a.drop_site = drop_site; a.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u;
     a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_t0 = drop_t0;
-    CXR_LAUNCH(attn_bwd_dq_kernel, dim3(cdiv(Tq, 128), H, B), dim3(256), 0, stream, a);          // also writes delta = rowsum(dO * O)
+    // the dQ kernel also writes delta = rowsum(dO * O)
+    if (g_attn_bwd_version == 2 && !a.kpm && !a.causal && !a.drop_thr16 && Tq > 1024) {      // (Tq 577: equal within noise)
+        attn_bwd_dq2_launch<4>(a, stream);
+    } else {
+        CXR_LAUNCH(attn_bwd_dq_kernel, dim3(cdiv(Tq, 128), H, B), dim3(256), 0, stream, a);
+    }
     CXR_LAUNCH(attn_bwd_dkdv_kernel, dim3(cdiv(Tk, 128), H, B), dim3(256), 0, stream, a);
     CXR_LAUNCH_CHECK();
     return CXR_OK;

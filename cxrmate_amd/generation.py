@@ -124,7 +124,7 @@ class DecodeSession:
                 self.pool = torch.cuda.graph_pool_handle()
             keep = self.cache.len
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, pool=self.pool):
+            with ops.graph_capture(g, pool=self.pool):
                 for c in range(cur, cur + n):
                     self._run(c, strip, mode, False)
             self.cache.len = keep                      # capture does not execute: replay below performs the steps

@@ -4,6 +4,9 @@ from __future__ import annotations
 
 import ctypes as _ct
 
+import contextlib
+import gc
+
 import torch
 
 from ._lib import LIB, CxrError
@@ -319,6 +322,23 @@ def linear_bwd_input(dy, w_t, **kw):
 
 
 # ------------------------------------------------------------------------------------------------ attention
+@contextlib.contextmanager
+def graph_capture(graph, pool=None):
+    """torch.cuda.graph with Python's cyclic garbage collector held off for the duration of the capture. A collection that starts INSIDE a capture
+    (thousands of ctypes launches allocate enough objects to trigger one) destroys whatever garbage earlier work left behind -- old CUDAGraph
+    objects, tensors with cross-stream uses -- and their destructors issue HIP calls that are illegal while a stream is capturing in global mode:
+    the process aborts (seen in the GPU test suite: 'Fatal Python error: Aborted ... Garbage-collecting' under _DecodeSession.step).
+    torch.cuda.graph itself collects once BEFORE the capture begins; nothing new becomes collectable garbage that matters during it."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, pool=pool):
+            yield
+    finally:
+        if was:
+            gc.enable()
+
+
 def attention_config(fwd=0, bwd=0):
     """kernel generation of attention / attention_bwd (1 = rounds 1-2, 2 = round 3; 0 keeps the setting): A/B measurements and parity tests"""
     LIB.call("cxr_attn_config", int(fwd), int(bwd))

@@ -185,11 +185,11 @@ class GraphedTFStep:
         pool = torch.cuda.graph_pool_handle()
         self.g1, self.g2, self.g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with wgrad_overlap():
-            with torch.cuda.graph(self.g1, pool=pool):
+            with ops.graph_capture(self.g1, pool=pool):
                 self.loss, self._esaved, self._denc = _phase_fwd_loss_decbwd(model, opt, px, ids, am, tt, lab, pad_token_id, pos, 0)
-            with torch.cuda.graph(self.g2, pool=pool):
+            with ops.graph_capture(self.g2, pool=pool):
                 _phase_encbwd(model, self._esaved, self._denc)
-        with torch.cuda.graph(self.g3, pool=pool):
+        with ops.graph_capture(self.g3, pool=pool):
             opt.step(gscale=1.0 / self.world)
         self.enc_trainable = self._esaved is not None
 

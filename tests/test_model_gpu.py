@@ -967,6 +967,33 @@ def test_single_image_model_generate_matches_the_reference(M):
     m.device_beam_search = True
 
 
+def test_graph_capture_survives_a_garbage_collection_inside_it(M):
+    """A cyclic-GC run that STARTS inside a hipGraph capture used to destroy the previous session's graphs there (HIP calls that are illegal while
+    a stream captures in global mode: the process aborted, depending on how many Python objects earlier tests had allocated). ops.graph_capture holds
+    the collector off; here every allocation would trigger a collection (threshold 1) while garbage with CUDA graphs is waiting."""
+    import gc
+    g, cfg, sd, x = gu.generate_single_case()
+    ref = torch.from_numpy(g["greedy"])
+    kw = dict(pixel_values=x.cuda(), special_token_ids=[gu.SEP], max_length=ref.shape[1], bos_token_id=gu.BOS, eos_token_id=gu.EOS,
+              pad_token_id=gu.PAD, return_dict_in_generate=True, use_cache=True, num_beams=1)
+    old = M.SingleCXREncoderDecoderModel(cfg, seed=None)
+    old.load_state_dict(sd)
+    assert torch.equal(old.generate(**kw)["sequences"].cpu(), ref)          # its session holds captured step graphs
+    cycle = [old]
+    cycle.append(cycle)                                                         # reachable only through a reference cycle once the names are dropped
+    del old, cycle
+    m = M.SingleCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    thr = gc.get_threshold()
+    gc.set_threshold(1)
+    try:
+        out = m.generate(**kw)["sequences"].cpu()
+    finally:
+        gc.set_threshold(*thr)
+    assert torch.equal(out, ref)
+    assert gc.isenabled()
+
+
 @pytest.mark.parametrize("case", ["plain", "lp2", "lp05", "eos"])
 def test_device_beam_search_equals_the_reference_on_every_row(M, case):
     """generate_beam_safe.npz: beam-4 decodes of the multi-image model whose every decision survives bf16-sized logit noise (checked by noise
