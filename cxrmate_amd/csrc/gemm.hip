@@ -725,6 +725,211 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
     }
 }
 
+// ---- round 3: 256 x 256 output blocks (weight gradients with both dimensions > 128) -------------------------------------------------------------
+// gemm_tn_kernel moves 16 KB through LDS per 1 MFLOP step (64 FLOP / byte) and keeps at most 48 KB in flight per CU against ~2 us of loaded
+// memory latency: its step takes ~2000 cycles for 256 cycles of MFMA work (8 % of peak, in-step profile). Here a workgroup owns up to 256 x 256
+// outputs (eight waves x 128 x 64: 128 accumulator registers per lane, two waves per SIMD; four waves x 128 x 128 need all 256 accumulator
+// registers and hipcc then spills accumulators around the loop's back edge), i.e. 128 FLOP per staged byte and half as many partial tiles per launch; a step stages (NI + NJ) sub-images of [32 tokens][128 columns] in the layout of gemm_tn_kernel (same swizzle, same
+// transposing reads), three stages deep = 96 KB, which still leaves a co-resident main-stream workgroup its 64 KB. Blocks at the edge of an output
+// whose width is 128 (mod 256) are 128 wide (NI / NJ = 1): 384 x 384 is covered by a 256x256, a 256x128, a 128x256 and a 128x128 block.
+// tn_frag_issue with the address split into a per-lane constant and the 16-column MFMA tile index t16 (0..7) of the sub-image: the swizzled
+// chunk index (2*t16 + (p >> 1)) ^ (gsw(row) << 1) is lane_off's chunk bits XOR (t16 << 1) (gsw(row + 4) == gsw(row): the second read is the
+// first + 4 rows = offset:1024) -- one v_xad per fragment instead of two precomputed addresses per fragment and stage (96 registers)
+__device__ __forceinline__ void tn2_frag_issue(const unsigned lane_off, const unsigned tile_base, const int t16, s16x4_t& lo, s16x4_t& hi) {
+    const unsigned a = (lane_off ^ ((unsigned)t16 << 5)) + tile_base;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(a));
+}
+
+template <int NI, int NJ>
+__device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char* lds, const int bi, const int bj, const int split) {
+    constexpr int BR = 32, TILE = BR * 256, NST = 3, LPS = NI + NJ, STAGE = (NI + NJ) * TILE;
+    constexpr int MI = 4 * NI, MJ = 2 * NJ;                        // 16 x 16 MFMA tiles of a wave: (64 NI) x (32 NJ) outputs
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 8 waves: 2 (I) x 4 (J)
+    const int wi = wave & 1, wj = wave >> 1;
+    const int nrt = (g.R + BR - 1) / BR;
+    const int rt0 = split * g.rt_per_split;
+    const int rt1 = min(nrt, rt0 + g.rt_per_split);
+    const int nt = rt1 - rt0;
+    if (nt <= 0) return;
+
+    // staging slot of a sub-image: slot = tid -> row = tid >> 4, physical chunk = tid & 15, logical chunk = physical ^ (gsw(row) << 1)
+    const int srow = tid >> 4;
+    const int scol = ((tid & 15) ^ (tn_gsw(srow) << 1)) * 8;
+    const bf16_t* zr = reinterpret_cast<const bf16_t*>(g_tn_zero_row) + (tid & 15) * 8;
+    auto stage = [&](int st, int rt) {
+        unsigned char* base = lds + st * STAGE + wave * 1024;
+        const long r = (long)rt * BR + srow;
+        const bool ok = r < g.R;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            int c = bi * 256 + u * 128 + scol; if (c >= g.I) c = 0;
+            const bf16_t* sp = ok ? g.P + r * g.ldp + c : zr;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                             (__attribute__((address_space(3))) void*)(base + u * TILE), 16, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < NJ; ++u) {
+            int c = bj * 256 + u * 128 + scol; if (c >= g.J) c = 0;
+            const bf16_t* sq = ok ? g.Q + r * g.ldq + c : zr;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sq,
+                                             (__attribute__((address_space(3))) void*)(base + (NI + u) * TILE), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[MI][MJ];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < MJ; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // bias gradient = column sums of P: the 8 tokens a lane holds of its column, added with v_dot2c_f32_bf16 against (1, 1) -- one fp32 register
+    // per 16-column tile (the all-ones MFMA of gemm_tn_kernel needs four)
+    const bool do_bias = g.dbias != nullptr && bj == 0 && wj == 0;
+    float accb[MI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a) accb[a] = 0.f;
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t one2 = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);
+    // this wave's columns inside the block's sub-images
+    const int sub_i = NI == 2 ? wi : 0, cb_i = NI == 2 ? 0 : wi * 64;
+    const int sub_j = NJ == 2 ? (wj >> 1) : 0, cb_j = NJ == 2 ? (wj & 1) * 64 : wj * 32;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    unsigned lane_off;                                              // this lane's part of every fragment address (tn2_frag_issue)
+    {
+        const int g4 = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+        const int r0 = 8 * g4 + q;
+        lane_off = r0 * 256 + ((((tn_gsw(r0) << 1) | (p >> 1)) << 4)) + (p & 1) * 8;
+    }
+
+#pragma unroll
+    for (int s2 = 0; s2 < NST - 1; ++s2)
+        if (s2 < nt) stage(s2, rt0 + s2);
+    for (int kt = 0; kt < nt; ++kt) {
+        const int ahead = nt - 1 - kt;
+        if (ahead >= NST - 2) wait_vmcnt<LPS * (NST - 2)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NST - 1 < nt) stage((kt + NST - 1) % NST, rt0 + kt + NST - 1);
+        const unsigned tp = lds_base + (kt % NST) * STAGE + sub_i * TILE;      // wave-uniform
+        const unsigned tq = lds_base + (kt % NST) * STAGE + (NI + sub_j) * TILE;
+        s16x4_t alo[MI], ahi[MI], blo[MJ], bhi[MJ];
+#pragma unroll
+        for (int t = 0; t < MI; ++t) tn2_frag_issue(lane_off, tp, (cb_i >> 4) + t, alo[t], ahi[t]);
+#pragma unroll
+        for (int t = 0; t < MJ; ++t) tn2_frag_issue(lane_off, tq, (cb_j >> 4) + t, blo[t], bhi[t]);
+        // the B fragments arrive in issue order (LDS returns in order): column j of the MFMA grid starts as soon as its fragment is there,
+        // the reads of the later columns land behind the MFMAs of the earlier ones
+        bf16x8_t fa[MI];
+#pragma unroll
+        for (int j2 = 0; j2 < MJ; ++j2) {
+            if (MJ - 1 - j2 == 3) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            else if (MJ - 1 - j2 == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            else if (MJ - 1 - j2 == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (j2 == 0) {
+#pragma unroll
+                for (int t = 0; t < MI; ++t) fa[t] = tn_frag_join(alo[t], ahi[t]);
+                if (do_bias) {
+#pragma unroll
+                    for (int i2 = 0; i2 < MI; ++i2) {
+                        const uint4 w = __builtin_bit_cast(uint4, fa[i2]);
+                        accb[i2] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.x), one2, accb[i2], false);
+                        accb[i2] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.y), one2, accb[i2], false);
+                        accb[i2] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.z), one2, accb[i2], false);
+                        accb[i2] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.w), one2, accb[i2], false);
+                    }
+                }
+            }
+            const bf16x8_t fb = tn_frag_join(blo[j2], bhi[j2]);
+#pragma unroll
+            for (int i2 = 0; i2 < MI; ++i2) acc[i2][j2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i2], fb, acc[i2][j2], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // epilogue: the waves park 32 rows of their sub-tile at a time in the (idle) staging LDS and hand them out as runs of whole 128 / 256-byte
+    // row pieces per wave-instruction, as gemm_tn_kernel does
+    const int fr = lane & 15, fq = lane >> 4;
+    __syncthreads();
+    constexpr int WCOLS = 16 * MJ;                                 // columns of a wave's sub-tile (64 or 32)
+    constexpr int RPI = 64 / WCOLS;                                // rows per store instruction (1 or 2)
+    float* wtile = reinterpret_cast<float*>(lds) + wave * (32 * WCOLS);
+    const int Jp = g.tiles_j * 128;
+    const int Ipad = ((g.I + 127) / 128) * 128;
+    const int i_wave = bi * 256 + (NI == 2 ? wi * 128 : wi * 64);
+    const int j_wave = bj * 256 + (NJ == 2 ? wj * 64 : wj * 32);
+    const int lrow = lane / WCOLS, lcol = lane % WCOLS;
+    const int j = j_wave + lcol;
+#pragma unroll
+    for (int pass = 0; pass < MI / 2; ++pass) {                     // 32 rows = two 16-row MFMA tiles per pass
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int jt = 0; jt < MJ; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    wtile[(it * 16 + fq * 4 + r) * WCOLS + jt * 16 + fr] = acc[pass * 2 + it][jt][r] * g.alpha;
+        __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0): own writes landed (each wave reads back only its own tile)
+        const int ibase = i_wave + pass * 32 + lrow;
+        if (g.mode == 2) {                                         // partial tile of this split: plain stores (padded workspace: no bounds)
+            float* wrow = g.ws + ((long)split * Ipad + ibase) * Jp + j;
+#pragma unroll 8
+            for (int row = 0; row < 32; row += RPI) wrow[(long)row * Jp] = wtile[row * WCOLS + lane];
+        } else if (j < g.J) {
+            if (g.mode == 1) {                                     // the only split: this workgroup owns the tile
+#pragma unroll 8
+                for (int row = 0; row < 32; row += RPI) {
+                    const int i = ibase + row;
+                    if (i < g.I) g.C[(long)i * g.ldc + j] += wtile[row * WCOLS + lane];
+                }
+            } else {
+#pragma unroll 8
+                for (int row = 0; row < 32; row += RPI) {
+                    const int i = ibase + row;
+                    if (i < g.I) atomicAdd(g.C + (long)i * g.ldc + j, wtile[row * WCOLS + lane]);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                        // the next pass overwrites the rows just read
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (do_bias) {                                                  // (wave-uniform) lane l of the A fragment holds column l & 15, tokens 8 * (l >> 4) ..
+#pragma unroll
+        for (int it = 0; it < MI; ++it) {
+            float v = accb[it];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int i = i_wave + it * 16 + fr;
+            if (fq == 0) {
+                if (g.mode == 2) g.wsb[(long)split * Ipad + i] = v;
+                else if (i < g.I) {
+                    if (g.mode == 1) g.dbias[i] += v;
+                    else atomicAdd(g.dbias + i, v);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(const GemmTnArgs g, const int blocks_j) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * 4 * 32 * 256];      // 3 stages x (2 + 2) sub-images = 96 KB
+    int swz;
+    {   // split-major work list cut into 8 contiguous runs, one per XCD (as gemm_tn_kernel)
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int blocks = gridDim.x / g.splits;
+    const int split = swz / blocks, blk = swz % blocks;
+    const int bi = blk / blocks_j, bj = blk % blocks_j;
+    const int ni = g.I - bi * 256 > 128 ? 2 : 1, nj = g.J - bj * 256 > 128 ? 2 : 1;      // block-uniform
+    if (ni == 2 && nj == 2) gemm_tn2_body<2, 2>(g, lds, bi, bj, split);
+    else if (ni == 2) gemm_tn2_body<2, 1>(g, lds, bi, bj, split);
+    else if (nj == 2) gemm_tn2_body<1, 2>(g, lds, bi, bj, split);
+    else gemm_tn2_body<1, 1>(g, lds, bi, bj, split);
+}
+
 // C[i][j] += sum of the splits' partial tiles, dbias likewise, in a FIXED order: SL lanes share one group of 4 columns, lane l sums the splits
 // congruent to l (ascending), a butterfly over the SL lanes finishes (small outputs have up to 176 splits: one thread walking them serially is a
 // chain of 176 dependent loads).
@@ -773,6 +978,47 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
     }
 }
 
+// Launch plan of a weight-gradient GEMM (shared by cxr_gemm_tn_bf16 and cxr_gemm_tn_plan)
+struct TnPlan { bool big; int tiles_i, tiles_j, blocks_j, wgs_per_split, splits, rt_per_split; long need; };
+static TnPlan tn_plan(int R, int I, int J) {
+    TnPlan p;
+    p.tiles_i = cdiv(I, 128); p.tiles_j = cdiv(J, 128);
+    const int nrt = cdiv(R, 32);
+    static int tn2 = -1, target_wgs = -1, target_big = -1;
+    if (tn2 < 0) { const char* e = getenv("CXR_TN2"); tn2 = (e && e[0] == '0') ? 0 : 1; }       // CXR_TN2=0: every shape through gemm_tn_kernel (A/B)
+    // Workgroups a launch aims for. These kernels run on the weight-gradient stream BESIDE the critical dX / attention kernels and every
+    // workgroup holds 64 KB of LDS (half a CU's co-residency): ~0.7 workgroups per CU leaves the main stream its slots and halves the
+    // atomic traffic (one 64 KB fp32 tile per split). Measured on the training step: 448 -> 32.5 ms, 320 -> 31.7, 224 -> 31.3, 176 -> 31.0,
+    // 128 -> 31.5 (same box); alone, a single launch is up to 1.4x faster at 320. CXR_TN_WGS overrides.
+    if (target_wgs < 0) { const char* e = getenv("CXR_TN_WGS"); target_wgs = e ? atoi(e) : 176; if (target_wgs < 1) target_wgs = 176; }
+    if (target_big < 0) { const char* e = getenv("CXR_TN2_WGS"); target_big = e ? atoi(e) : 128; if (target_big < 1) target_big = 128; }
+    // 256 x 256 blocks (gemm_tn2_kernel) when both dimensions exceed 128 AND a workgroup gets a long enough token run: its prologue and its
+    // 256-KB partial tile only pay off from ~24 steps of 32 tokens per workgroup (scripts/tn_micro.py: 8192 x 768 x 768 is 1.35x SLOWER with it,
+    // 36864 x 768 x 768 1.5x faster)
+    p.blocks_j = cdiv(J, 256);
+    const int blocks = cdiv(I, 256) * p.blocks_j;
+    p.big = tn2 && I > 128 && J > 128 && (long)blocks * nrt >= 4096;
+    p.wgs_per_split = p.big ? blocks : p.tiles_i * p.tiles_j;
+    int splits = cdiv(p.big ? target_big : target_wgs, p.wgs_per_split);
+    const int max_splits = nrt / 8 > 0 ? nrt / 8 : 1;      // at least 256 tokens per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.rt_per_split = cdiv(nrt, splits);
+    p.splits = cdiv(nrt, p.rt_per_split);
+    const long Ip = p.tiles_i * 128, Jp = p.tiles_j * 128;
+    p.need = (long)p.splits * Ip * Jp + (long)p.splits * Ip;
+    return p;
+}
+
+// what a launch on this shape will do: *splits token splits, *ws_floats floats of scratch for the deterministic (partial tiles + ordered sum) path
+extern "C" int cxr_gemm_tn_plan(int R, int I, int J, int* splits, long* ws_floats) {
+    if (R <= 0 || I <= 0 || J <= 0) return CXR_ERR_ARG;
+    const TnPlan p = tn_plan(R, I, J);
+    if (splits) *splits = p.splits;
+    if (ws_floats) *ws_floats = p.splits > 1 ? p.need : 0;
+    return CXR_OK;
+}
+
 extern "C" int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* dbias, int R, int I, int J,
                                 float alpha, float* ws, long ws_floats, hipStream_t stream) {
     if (R <= 0 || I <= 0 || J <= 0 || (I % 8) || (J % 8) || (ldp % 8) || (ldq % 8)) return CXR_ERR_ARG;
@@ -780,27 +1026,15 @@ extern "C" int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq
     g.P = (const bf16_t*)P; g.ldp = ldp; g.Q = (const bf16_t*)Q; g.ldq = ldq; g.C = C; g.ldc = ldc; g.dbias = dbias;
     g.R = R; g.I = I; g.J = J; g.alpha = alpha;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CXR_TN_DEBUG"); dbg = e ? atoi(e) : 0; } g.debug = dbg; }
-    const int tiles_i = cdiv(I, 128);
-    g.tiles_j = cdiv(J, 128);
-    const int tiles = tiles_i * g.tiles_j;
-    const int nrt = cdiv(R, 32);
-    // Workgroups a launch aims for. These kernels run on the weight-gradient stream BESIDE the critical dX / attention kernels and every
-    // workgroup holds 64 KB of LDS (half a CU's co-residency): ~0.7 workgroups per CU leaves the main stream its slots and halves the
-    // atomic traffic (one 64 KB fp32 tile per split). Measured on the training step: 448 -> 32.5 ms, 320 -> 31.7, 224 -> 31.3, 176 -> 31.0,
-    // 128 -> 31.5 (same box); alone, a single launch is up to 1.4x faster at 320. CXR_TN_WGS overrides.
-    static int target_wgs = -1;
-    if (target_wgs < 0) { const char* e = getenv("CXR_TN_WGS"); target_wgs = e ? atoi(e) : 176; if (target_wgs < 1) target_wgs = 176; }
-    int splits = cdiv(target_wgs, tiles);
-    const int max_splits = nrt / 8 > 0 ? nrt / 8 : 1;      // at least 256 tokens per split
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    g.rt_per_split = cdiv(nrt, splits);
-    g.splits = cdiv(nrt, g.rt_per_split);
+    const TnPlan pl = tn_plan(R, I, J);
+    const bool big = pl.big;
+    const int tiles_i = pl.tiles_i, blocks_j = pl.blocks_j, tiles = pl.wgs_per_split;
+    g.tiles_j = pl.tiles_j; g.rt_per_split = pl.rt_per_split; g.splits = pl.splits;
     // accumulation: one split -> atomics (each element receives exactly one add per launch: order-free); several splits -> partial tiles into the
     // caller's workspace + one reduce launch that adds them in a fixed order (deterministic; measured at the same speed as 64 KB of fp32 atomics
     // per workgroup, scripts/tn_micro.py with CXR_TN_ATOMICS=1); no / too small a workspace: atomics
     const int Ip = tiles_i * 128, Jp = g.tiles_j * 128;
-    const long need = (long)g.splits * Ip * Jp + (long)g.splits * Ip;
+    const long need = pl.need;
     static int det = -1;
     if (det < 0) { const char* e = getenv("CXR_TN_ATOMICS"); det = (e && atoi(e)) ? 0 : 1; }
     g.ws = nullptr; g.wsb = nullptr;
@@ -808,8 +1042,9 @@ extern "C" int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq
     if (det && g.splits > 1 && g.splits <= 192 && ws && ws_floats >= need && (J % 4) == 0) { g.mode = 2; g.ws = ws; g.wsb = ws + (long)g.splits * Ip * Jp; }
     static int stages = -1;                                // CXR_TN_STAGES = 2 | 4 (LDS 32 | 64 KB per workgroup)
     if (stages < 0) { const char* e = getenv("CXR_TN_STAGES"); stages = e ? atoi(e) : 4; }
-    if (stages == 2) CXR_LAUNCH(gemm_tn_kernel<2>, dim3(tiles * g.splits), dim3(256), 0, stream, g);
-    else             CXR_LAUNCH(gemm_tn_kernel<4>, dim3(tiles * g.splits), dim3(256), 0, stream, g);
+    if (big)              CXR_LAUNCH(gemm_tn2_kernel, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
+    else if (stages == 2) CXR_LAUNCH(gemm_tn_kernel<2>, dim3(tiles * g.splits), dim3(256), 0, stream, g);
+    else                  CXR_LAUNCH(gemm_tn_kernel<4>, dim3(tiles * g.splits), dim3(256), 0, stream, g);
     if (g.mode == 2) {
         const long total = (long)I * (J / 4) + (dbias ? I : 0);
         const int sl = g.splits <= 12 ? 1 : (g.splits <= 48 ? 4 : 16);      // 12 partials per lane at most (splits <= 176 + 1)

@@ -159,9 +159,9 @@ def colsum_into(x, out):
 
 
 _TN_WS = {}             # (device index, raw stream handle) -> fp32 scratch of the deterministic split-K weight-gradient GEMM (launches of one
-                        # stream are serial); 8 M floats cover every shape of this model: an output beyond it (splits * I_pad * J_pad floats, more than
+                        # stream are serial); 16 M floats (64 MB) cover every shape of this model: an output beyond it (splits * I_pad * J_pad floats, more than
                         # 192 splits) falls back to fp32 atomics inside cxr_gemm_tn_bf16 -- reported once per shape, never silent
-_TN_WS_FLOATS = 8 << 20
+_TN_WS_FLOATS = 16 << 20
 _TN_FALLBACK_SEEN = set()
 
 
@@ -174,20 +174,14 @@ def _tn_ws(stream, device):
 
 
 def _tn_note_fallback(R, I, J):
-    """Mirror of the split choice in cxr_gemm_tn_bf16 (csrc/gemm.hip): warn when a shape cannot use the deterministic partial-tile path."""
-    import os
+    """Warn when a shape cannot use the deterministic partial-tile path (the launch plan comes from the library: cxr_gemm_tn_plan)."""
     import warnings
-    tiles = -(-I // 128) * -(-J // 128)
-    nrt = -(-R // 32)
-    target = int(os.environ.get("CXR_TN_WGS", "176") or 176)
-    splits = max(1, min(-(-target // tiles), max(1, nrt // 8)))
-    rt = -(-nrt // splits)
-    splits = -(-nrt // rt)
-    need = splits * (-(-I // 128) * 128) * (-(-J // 128) * 128 + 1)
-    if splits > 1 and (need > _TN_WS_FLOATS or splits > 192) and (I, J) not in _TN_FALLBACK_SEEN:
+    splits, need = _ct.c_int(0), _ct.c_long(0)
+    LIB.call("cxr_gemm_tn_plan", int(R), int(I), int(J), _ct.byref(splits), _ct.byref(need))
+    if splits.value > 1 and (need.value > _TN_WS_FLOATS or splits.value > 192) and (I, J) not in _TN_FALLBACK_SEEN:
         _TN_FALLBACK_SEEN.add((I, J))
-        warnings.warn(f"weight-gradient GEMM {I}x{J} over {R} rows: {splits} splits need {need} scratch floats (> {_TN_WS_FLOATS}) -> fp32 atomics, "
-                      "the sum order (last bits of the gradient) is not reproducible for this shape")
+        warnings.warn(f"weight-gradient GEMM {I}x{J} over {R} rows: {splits.value} splits need {need.value} scratch floats (> {_TN_WS_FLOATS}) -> fp32 "
+                      "atomics, the sum order (last bits of the gradient) is not reproducible for this shape")
 
 
 def gemm_tn(p, q, out, dbias=None, alpha=1.0):

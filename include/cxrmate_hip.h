@@ -48,6 +48,8 @@ int cxr_gemm_nt_group_bf16(const cxr_gemm_nt_desc* d, int n, hipStream_t stream)
  * ws NULL / too small (or CXR_TN_ATOMICS=1): fp32 atomics into C. Requires I%8==0, J%8==0. Nothing else may accumulate into C concurrently. */
 int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* dbias, int R, int I, int J, float alpha,
                      float* ws, long ws_floats, hipStream_t stream);
+/* launch plan of cxr_gemm_tn_bf16 for a shape: token splits and the scratch floats its deterministic path needs (0 with one split) */
+int cxr_gemm_tn_plan(int R, int I, int J, int* splits, long* ws_floats);
 int cxr_gemm_set_regstage(int on);   /* debug: 1 = stage operands through registers instead of LDS-DMA */
 /* on != 0 (default): cxr_gemm_nt_bf16 may pick the persistent one-workgroup-per-CU kernels (csrc/gemm_ws.hip, csrc/gemm_pk.hip). The training
  * step turns it off while its weight-gradient stream runs kernels beside the main stream (their workgroups cannot share a CU with a 144 KB one). */
