@@ -22,6 +22,7 @@ struct AttnArgs {
     int causal, causal_shift;          // key j visible to query i iff j <= i + causal_shift
     // dropout on the attention probabilities (TF5 modeling_bert.py:131, train mode): P*keep/(1-p) feeds P.V, the softmax sums do not change
     const uint32_t* drop_seed; uint32_t drop_site, drop_thr16; float drop_inv; int drop_t0;      // drop_thr16 == 0: off
+    unsigned char* O8; long o8_bs, o8_rs; float o8_inv;      // attn_fwd2_kernel only: e4m3 output (value * o8_inv) for a consumer that is an e4m3 GEMM; O may be null then
 };
 
 constexpr int KS_STRIDE = 72;          // bf16 elements per K row in LDS (144 B)
@@ -478,7 +479,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd2_kernel(const AttnArgs a)
                         pk.y = pack2bf(o[x][dt][4 * rg + 2] * inv, o[x][dt][4 * rg + 3] * inv);
                         TILE_PUT(Ot, lane, dt, rg, pk);
                     }
-                tile_rows_store(Ot, lane, a.O + (long)b * a.o_bs + (long)r0 * a.o_rs + head * 64, a.o_rs, valid);
+                if (a.O) tile_rows_store(Ot, lane, a.O + (long)b * a.o_bs + (long)r0 * a.o_rs + head * 64, a.o_rs, valid);
+                if (a.O8) tile_rows_store_q8(Ot, lane, a.O8 + (long)b * a.o8_bs + (long)r0 * a.o8_rs + head * 64, a.o8_rs, valid, a.o8_inv);
             }
             const int qrow = r0 + ql;
             if (a.LSE && hh == 0 && qrow < a.Tq)
@@ -505,13 +507,17 @@ extern "C" int cxr_attn_config(int fwd_version, int bwd_version) {
     return CXR_OK;
 }
 
-extern "C" int cxr_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, float* LSE, const void* kpm,
-                                 long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs, long o_rs,
-                                 long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal, int causal_shift,
-                                 float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t0, hipStream_t stream) {
-    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return CXR_ERR_ARG;
-    if ((q_rs % 8) || (k_rs % 8) || (v_rs % 8) || (o_rs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 8) || (((size_t)O) % 16)) return CXR_ERR_ARG;
+static int attn_fwd_launch(const void* Q, const void* K, const void* V, void* O, float* LSE, const void* kpm,
+                           long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs, long o_rs,
+                           long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal, int causal_shift,
+                           float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t0,
+                           void* O8, long o8_bs, long o8_rs, float o8_inv, hipStream_t stream) {
+    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed) || (!O && !O8)) return CXR_ERR_ARG;
+    if ((q_rs % 8) || (k_rs % 8) || (v_rs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8)) return CXR_ERR_ARG;
+    if (O && ((o_rs % 8) || (o_bs % 8) || (((size_t)O) % 16))) return CXR_ERR_ARG;
+    if (O8 && ((o8_rs % 8) || (o8_bs % 8) || (((size_t)O8) % 8) || !(o8_inv > 0.f))) return CXR_ERR_ARG;
     AttnArgs a;
+    a.O8 = (unsigned char*)O8; a.o8_bs = o8_bs; a.o8_rs = o8_rs; a.o8_inv = o8_inv;
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.O = (bf16_t*)O; a.LSE = LSE;
     a.kpm = (const unsigned char*)kpm;
     a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_rs = o_rs;
@@ -519,7 +525,7 @@ extern "C" int cxr_attn_fwd_bf16(const void* Q, const void* K, const void* V, vo
     a.scale_log2e = scale * 1.4426950408889634f; a.causal = causal; a.causal_shift = causal_shift;
     a.drop_seed = drop_seed; a.drop_site = drop_site; a.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u;
     a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_t0 = drop_t0;
-    if (g_attn_fwd_version == 2) {
+    if (g_attn_fwd_version == 2 || O8) {
         static const int force_nw = getenv("CXR_ATT_NW") ? atoi(getenv("CXR_ATT_NW")) : 0;      // lab switch
         if (force_nw ? force_nw == 4 : Tq > 128) attn_fwd2_launch<4>(a, stream);
         else attn_fwd2_launch<2>(a, stream);
@@ -528,4 +534,22 @@ extern "C" int cxr_attn_fwd_bf16(const void* Q, const void* K, const void* V, vo
     }
     CXR_LAUNCH_CHECK();
     return CXR_OK;
+}
+
+extern "C" int cxr_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, float* LSE, const void* kpm,
+                                 long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs, long o_rs,
+                                 long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal, int causal_shift,
+                                 float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t0, hipStream_t stream) {
+    if (!O) return CXR_ERR_ARG;
+    return attn_fwd_launch(Q, K, V, O, LSE, kpm, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, kpm_bs, B, H, Tq, Tk, scale, causal, causal_shift,
+                           drop_p, drop_seed, drop_site, drop_t0, nullptr, 0, 0, 0.f, stream);
+}
+
+// the same attention with the context written as e4m3 (value * inv_scale, saturating; element (b,t,h,d) at O8 + b*o8_bs + t*o8_rs + h*64 + d bytes)
+// for a consumer that is an e4m3 GEMM: the bf16-rounded context is what gets quantised, exactly as a separate pass over a bf16 output would
+extern "C" int cxr_attn_fwd_q8_bf16(const void* Q, const void* K, const void* V, void* O8, long o8_bs, long o8_rs, float inv_scale, const void* kpm,
+                                    long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long kpm_bs, int B, int H, int Tq, int Tk,
+                                    float scale, int causal, int causal_shift, hipStream_t stream) {
+    return attn_fwd_launch(Q, K, V, nullptr, nullptr, kpm, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, 0, 0, kpm_bs, B, H, Tq, Tk, scale, causal, causal_shift,
+                           0.f, nullptr, 0, 0, O8, o8_bs, o8_rs, inv_scale, stream);
 }

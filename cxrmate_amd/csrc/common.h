@@ -69,6 +69,24 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return v;
 }
 
+// ---- e4m3 (OCP fp8) outputs: value * inverse scale, saturating at +-448; used by the fp8 GEMM and by every producer that hands its output
+// straight to an e4m3 GEMM (LayerNorm, depthwise projections, attention: no separate quantisation pass)
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+}
+__device__ __forceinline__ uint8_t to_fp8(float a) {
+    a = fminf(fmaxf(a, -448.f), 448.f);
+    return (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(a, 0.f, 0, false) & 0xff);
+}
+__device__ __forceinline__ uint2 pack8_fp8(const float (&f)[8], float inv) {
+    return make_uint2(pack_fp8x4(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv), pack_fp8x4(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv));
+}
+
 // GELU(x) = x * Phi(x) with Phi(x) ~= sigmoid(x * (a1 + a3 x^2 + a5 x^4)), minimax-fitted to the exact (erf) GELU that torch.nn.GELU() /
 // ACT2FN["gelu"] compute: max |error| 2.5e-5 on the value and 1.1e-4 on the derivative (the derivative below is the exact derivative
 // of this function, so forward and backward stay consistent). 9 instructions (one v_exp, one v_rcp) instead of ~40 for libm erff: the
@@ -128,6 +146,23 @@ __device__ __forceinline__ void tile_rows_store(const bf16_t* tile, int lane, bf
         const uint2 lo = *reinterpret_cast<const uint2*>(tile + r * 64 + (((2 * cc) ^ (r & 15)) << 2));
         const uint2 hi = *reinterpret_cast<const uint2*>(tile + r * 64 + (((2 * cc + 1) ^ (r & 15)) << 2));
         if (r < rows_valid) *reinterpret_cast<uint4*>(gbase + (long)r * row_stride + cc * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+}
+
+// the same tile written as e4m3 rows (value * inv, saturating): 8 bytes per lane, one 64-byte head row per 8 lanes
+__device__ __forceinline__ void tile_rows_store_q8(const bf16_t* tile, int lane, unsigned char* gbase, long row_stride, int rows_valid, float inv) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = it * 64 + lane;
+        const int r = c >> 3, cc = c & 7;
+        const uint2 lo = *reinterpret_cast<const uint2*>(tile + r * 64 + (((2 * cc) ^ (r & 15)) << 2));
+        const uint2 hi = *reinterpret_cast<const uint2*>(tile + r * 64 + (((2 * cc + 1) ^ (r & 15)) << 2));
+        float f[8];
+        unpack8(make_uint4(lo.x, lo.y, hi.x, hi.y), f);
+        if (r < rows_valid) *reinterpret_cast<uint2*>(gbase + (long)r * row_stride + cc * 8) = pack8_fp8(f, inv);
     }
 }
 

@@ -34,6 +34,7 @@ struct Dw3P {                                      // one projection, device vie
     const float* taps; const float* aux;           // [9][C] taps; aux = shift [C] (apply) or coef [3][C] (dc; may be null)
     bf16_t* y; long y_bs, y_rs;
     int stride, Ho, Wo;
+    float inv8;                                    // apply only: > 0 -> y is an e4m3 matrix (strides in bytes) holding output * inv8
 };
 struct Dw3Blk { int b, band_i, slice, ch, pl, c0; };
 
@@ -236,9 +237,14 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_apply_kernel(const Dw3Geo 
     for (int q = 0; q < g.nproj; ++q) {
         const Dw3P P = q == 0 ? p0 : (q == 1 ? p1 : p2);
         bf16_t* yb = P.y + (long)k.b * P.y_bs + k.c0;
+        unsigned char* yb8 = reinterpret_cast<unsigned char*>(P.y) + (long)k.b * P.y_bs + k.c0;      // (e4m3 output: same element strides, 1-byte elements)
+        const bool q8 = P.inv8 > 0.f;
         if (g.tok0 && k.band_i == 0 && threadIdx.x < 8) {
-            for (int t = 0; t < g.tok0; ++t)
-                *reinterpret_cast<uint4*>(yb + (long)t * P.y_rs) = *reinterpret_cast<const uint4*>(xb + (long)t * g.x_rs + k.ch * 8);
+            for (int t = 0; t < g.tok0; ++t) {
+                const uint4 cls = *reinterpret_cast<const uint4*>(xb + (long)t * g.x_rs + k.ch * 8);
+                if (q8) { float f[8]; unpack8(cls, f); *reinterpret_cast<uint2*>(yb8 + (long)t * P.y_rs) = pack8_fp8(f, P.inv8); }
+                else *reinterpret_cast<uint4*>(yb + (long)t * P.y_rs) = cls;
+            }
         }
         float w[9][8], sh[8];
         dw3_load_taps(P.taps, g.C, k.c0, w);
@@ -251,7 +257,8 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_apply_kernel(const Dw3Geo 
             dw3_conv(dw3_tile, (oyl * P.stride * pitch + ox * P.stride) * 8 + k.ch, pitch8, w, c);
 #pragma unroll
             for (int j = 0; j < 8; ++j) c[j] += sh[j];
-            *reinterpret_cast<uint4*>(yb + (long)(g.tok0 + (oy0 + oyl) * P.Wo + ox) * P.y_rs) = pack8(c);
+            if (q8) *reinterpret_cast<uint2*>(yb8 + (long)(g.tok0 + (oy0 + oyl) * P.Wo + ox) * P.y_rs) = pack8_fp8(c, P.inv8);
+            else *reinterpret_cast<uint4*>(yb + (long)(g.tok0 + (oy0 + oyl) * P.Wo + ox) * P.y_rs) = pack8(c);
         }
     }
 }
@@ -616,7 +623,7 @@ static int dw3_plan(Dw3Plan& pl, const void* x, long x_bs, long x_rs, int Bn, in
     for (int q = 0; q < 3; ++q) {
         const cxr_dwproj& s = projs[q < nproj ? q : 0];
         Dw3P& d = pl.p[q];
-        d.taps = s.taps; d.aux = nullptr; d.y = (bf16_t*)s.y; d.y_bs = s.y_bs; d.y_rs = s.y_rs; d.stride = s.stride;
+        d.taps = s.taps; d.aux = nullptr; d.y = (bf16_t*)s.y; d.y_bs = s.y_bs; d.y_rs = s.y_rs; d.stride = s.stride; d.inv8 = 0.f;
         d.Ho = (H + 2 - 3) / s.stride + 1; d.Wo = (W + 2 - 3) / s.stride + 1;
         if (!s.taps) return CXR_ERR_ARG;
     }
@@ -650,6 +657,23 @@ extern "C" int cxr_dwproj_apply_bf16(const void* x, long x_bs, long x_rs, int Bn
     if (rc) return rc;
     if (!dw3_y_ok(projs, nproj) || (((size_t)x) % 16)) return CXR_ERR_ARG;
     for (int q = 0; q < nproj; ++q) { if (!projs[q].shift) return CXR_ERR_ARG; pl.p[q].aux = projs[q].shift; }
+    { static bool big = false; dw3_allow_big_lds(dw3_apply_kernel, big); }
+    CXR_LAUNCH(dw3_apply_kernel, dim3(pl.grid), dim3(DW3_THREADS), pl.lds, stream, pl.g, pl.p[0], pl.p[1], pl.p[2]);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// the same pass with e4m3 outputs for consumers that are e4m3 GEMMs: projs[q].y is a 1-byte matrix (y_bs / y_rs in bytes), value * inv_scale[q]
+extern "C" int cxr_dwproj_apply_q8(const void* x, long x_bs, long x_rs, int Bn, int C, int H, int W, int tok0, const cxr_dwproj* projs, int nproj,
+                                   const float* inv_scale, hipStream_t stream) {
+    Dw3Plan pl;
+    const int rc = dw3_plan(pl, x, x_bs, x_rs, Bn, C, H, W, tok0, projs, nproj, false, 0);
+    if (rc) return rc;
+    if (!inv_scale || (((size_t)x) % 16)) return CXR_ERR_ARG;
+    for (int q = 0; q < nproj; ++q) {
+        if (!projs[q].shift || !projs[q].y || (projs[q].y_rs % 8) || (projs[q].y_bs % 8) || (((size_t)projs[q].y) % 8) || !(inv_scale[q] > 0.f)) return CXR_ERR_ARG;
+        pl.p[q].aux = projs[q].shift; pl.p[q].inv8 = inv_scale[q];
+    }
     { static bool big = false; dw3_allow_big_lds(dw3_apply_kernel, big); }
     CXR_LAUNCH(dw3_apply_kernel, dim3(pl.grid), dim3(DW3_THREADS), pl.lds, stream, pl.g, pl.p[0], pl.p[1], pl.p[2]);
     CXR_LAUNCH_CHECK();

@@ -34,18 +34,7 @@ struct Fp8Args {
 
 constexpr int LDSROW = 80;               // 64 k-bytes + 16 of padding: the 16-byte fragment reads of a wave spread over all banks
 
-__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
-    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
-    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
-    int w = 0;
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-    return (uint32_t)w;
-}
-__device__ __forceinline__ uint8_t to_fp8(float a) {
-    a = fminf(fmaxf(a, -448.f), 448.f);
-    return (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(a, 0.f, 0, false) & 0xff);
-}
+// (pack_fp8x4 / to_fp8: common.h)
 
 template <int BN>
 __global__ __launch_bounds__(256) void gemm_fp8_kernel(const Fp8Args g) {

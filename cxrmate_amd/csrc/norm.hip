@@ -16,10 +16,12 @@ template <int C, bool LN_TRI = false> struct LNCfg {
 
 // U rows per row-group per iteration: all loads of the U rows are issued before the first reduction, so every lane keeps U (forward)
 // or 2-3 U (backward) 16-byte loads in flight -- at 8 waves per CU a single row per iteration leaves the kernel latency-bound (~2 TB/s).
-template <int C, int U>
+// Q8: the output goes out as e4m3 (y8 = value * inv8, saturating) for a consumer that is an e4m3 GEMM; y (bf16) is then optional
+template <int C, int U, bool Q8 = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ y, long ldy,
-                                                            float* __restrict__ stats, long rows, float eps) {
+                                                            float* __restrict__ stats, long rows, float eps,
+                                                            unsigned char* __restrict__ y8 = nullptr, long ldy8 = 0, float inv8 = 0.f) {
     using L = LNCfg<C, true>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % L::LPR, grp = lane / L::LPR;
@@ -84,7 +86,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
                     float o[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = (v[u][i][j] - mean) * rstd * gg[i][j] + bb[i][j];
-                    *reinterpret_cast<uint4*>(y + row[u] * ldy + ch * 8) = pack8(o);
+                    if (!Q8 || y) *reinterpret_cast<uint4*>(y + row[u] * ldy + ch * 8) = pack8(o);
+                    if (Q8) *reinterpret_cast<uint2*>(y8 + row[u] * ldy8 + ch * 8) = pack8_fp8(o, inv8);
                 }
             }
             if (stats && sub == 0) { stats[2 * row[u]] = mean; stats[2 * row[u] + 1] = rstd; }
@@ -277,6 +280,26 @@ extern "C" int cxr_layernorm_fwd_bf16(const void* x, long ldx, const float* gamm
     if (rows <= 0 || (ldx % 8) || (ldy % 8)) return CXR_ERR_ARG;
     const int grid = ln_grid(rows, C, (C == 64 || C == 128) ? 4 : 2, true);
     LN_DISPATCH(C, layernorm_fwd_kernel, 4, 4, 2, 2, 2, (const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, stats, rows, eps);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// LayerNorm whose consumer is an e4m3 GEMM: y8[rows, C] = e4m3(LN(x) * inv_scale); y (bf16) may be null
+extern "C" int cxr_layernorm_q8_bf16(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, void* y8, long ldy8,
+                                     float inv_scale, float* stats, long rows, int C, float eps, hipStream_t stream) {
+    if (rows <= 0 || (ldx % 8) || (y && (ldy % 8)) || !y8 || (ldy8 % 8) || (((size_t)y8) % 8)) return CXR_ERR_ARG;
+    const int grid = ln_grid(rows, C, (C == 64 || C == 128) ? 4 : 2, true);
+#define LN_Q8(C_, U_) CXR_LAUNCH((layernorm_fwd_kernel<C_, U_, true>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, \
+                                 stats, rows, eps, (unsigned char*)y8, ldy8, inv_scale)
+    switch (C) {
+        case 64: LN_Q8(64, 4); break;
+        case 128: LN_Q8(128, 4); break;
+        case 192: LN_Q8(192, 2); break;
+        case 384: LN_Q8(384, 2); break;
+        case 768: LN_Q8(768, 2); break;
+        default: return CXR_ERR_ARG;
+    }
+#undef LN_Q8
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

@@ -34,6 +34,7 @@ class CvtEncoderEngine:
         self._embed_buf = {}                        # persistent conv-as-GEMM weight re-layouts (their addresses feed the batched transpose table)
         self._bt, self._bt_sig, self._bt_keys = None, None, None
         self.fp8 = None                             # {"w": {key: (e4m3 weight, scale)}, "a": {key: scale}} after enable_fp8(); None = bf16
+        self._q8_fused = os.environ.get("CXR_FP8_FUSED", "1") != "0"      # A/B switch: 0 = separate bf16 -> e4m3 passes in front of the e4m3 GEMMs
         self._amax = None                           # calibration pass: {key: running max |activation|}
 
     # ------------------------------------------------------------------------------------------ fp8 (e4m3) linear layers of the frozen encoder
@@ -313,6 +314,7 @@ class CvtEncoderEngine:
         h1, st1 = ops.layernorm(x2d, st.f32(lp + "layernorm_before.weight"), st.f32(lp + "layernorm_before.bias"), cfg.inner_layer_norm_eps, need_stats=save)
         h1 = h1.view(Bn, L, C)
         bn = None
+        qc8 = kc8 = vc8 = None
         names = ("query", "key", "value")
         strides = (cfg.stride_q[s], cfg.stride_kv[s], cfg.stride_kv[s])
         if self._fused_proj and C % 64 == 0:
@@ -322,7 +324,13 @@ class CvtEncoderEngine:
                 bn = {n: (f["mean"], f["rstd"], f["count"]) for n, f in zip(names, folds)}
             else:
                 folds = [dict(stride=sd, taps=f[0], shift=f[1]) for sd, f in zip(strides, (self._fold_eval(s, l, n) for n in names))]
-            qc, kc, vc = ops.dwproj_apply(h1, H, W, tok0, folds)
+            if self.fp8 is not None and self._q8_fused and not save:
+                # frozen e4m3 encoder: the three projections leave the pass as e4m3 with the input scales of the Linear layers that consume them
+                qc8, kc8, vc8 = (t_.view(-1, C) for t_ in ops.dwproj_apply_q8(h1, H, W, tok0, folds, [self.fp8["a"][(ap + f"projection_{n}.weight", "in")] for n in names]))
+                qc = kc = vc = None
+                Lk_q8 = kc8.shape[0] // Bn
+            else:
+                qc, kc, vc = ops.dwproj_apply(h1, H, W, tok0, folds)
         else:
             if self._train:
                 (fq,), bn = self._fold_train(h1, H, W, cfg.stride_q[s], tok0, s, l, ("query",))
@@ -332,21 +340,29 @@ class CvtEncoderEngine:
                 fq, fk, fv = (self._fold_eval(s, l, n) for n in names)
             qc, _ = ops.dwconv_bn(h1, H, W, cfg.stride_q[s], tok0, fq)
             kc, vc = ops.dwconv_bn(h1, H, W, cfg.stride_kv[s], tok0, fk, fv)
-        Lk = kc.shape[1]
+        Lk = kc.shape[1] if kc is not None else Lk_q8
         dp1, dp2 = self._drop_path_scales(s, l, Bn)
         Ch = st.w16(lp + "intermediate.dense.weight").shape[0]
         if (self.fp8 is not None or self._amax is not None) and not save:
             # e4m3 GEMMs (or their calibration pass); the MLP's hidden activation goes from the first GEMM's epilogue to the second as e4m3
-            q, k, v = (self._linear(t_.view(-1, C), ap + f"projection_{n}.weight", ap + f"projection_{n}.bias")[0]
-                       for n, t_ in (("query", qc), ("key", kc), ("value", vc)))
+            fused8 = self.fp8 is not None and self._q8_fused
+            q, k, v = (self._linear(None if t_ is None else t_.view(-1, C), ap + f"projection_{n}.weight", ap + f"projection_{n}.bias", x8=t8)[0]
+                       for n, t_, t8 in (("query", qc, qc8), ("key", kc, kc8), ("value", vc, vc8)))
             q, k, v = q.view(Bn, L, C), k.view(Bn, Lk, C), v.view(Bn, Lk, C)
-            ctx, lse = ops.attention(q, k, v, nh, C ** -0.5, need_lse=False)
-            x2, _ = self._linear(ctx.view(-1, C), lp + "attention.output.dense.weight", lp + "attention.output.dense.bias", residual=x2d,
-                                 row_scale=None if dp1 is None else (dp1, L, False))
-            h2, st2 = ops.layernorm(x2, st.f32(lp + "layernorm_after.weight"), st.f32(lp + "layernorm_after.bias"), cfg.inner_layer_norm_eps)
+            wo = lp + "attention.output.dense.weight"
+            if fused8:      # the context leaves the attention kernel as e4m3 with the output projection's input scale
+                ctx, ctx8 = None, ops.attention_q8(q, k, v, nh, C ** -0.5, self.fp8["a"][(wo, "in")]).view(-1, C)
+            else:
+                ctx, ctx8 = ops.attention(q, k, v, nh, C ** -0.5, need_lse=False)[0].view(-1, C), None
+            x2, _ = self._linear(ctx, wo, lp + "attention.output.dense.bias", residual=x2d, row_scale=None if dp1 is None else (dp1, L, False), x8=ctx8)
+            fc1 = lp + "intermediate.dense.weight"
+            if fused8:      # ... and so does the second LayerNorm (bf16 copy not needed: the residual of the MLP is x2)
+                h2, h28 = None, ops.layernorm_q8(x2, st.f32(lp + "layernorm_after.weight"), st.f32(lp + "layernorm_after.bias"), cfg.inner_layer_norm_eps,
+                                                 self.fp8["a"][(fc1, "in")])
+            else:
+                h2, h28 = ops.layernorm(x2, st.f32(lp + "layernorm_after.weight"), st.f32(lp + "layernorm_after.bias"), cfg.inner_layer_norm_eps)[0], None
             fc2 = lp + "output.dense.weight"
-            g, g8 = self._linear(h2, lp + "intermediate.dense.weight", lp + "intermediate.dense.bias", act=1,
-                                 out8_for=fc2 if self.fp8 is not None else None)
+            g, g8 = self._linear(h2, fc1, lp + "intermediate.dense.bias", act=1, out8_for=fc2 if self.fp8 is not None else None, x8=h28)
             x3, _ = self._linear(g, fc2, lp + "output.dense.bias", residual=x2, row_scale=None if dp2 is None else (dp2, L, True), x8=g8)
             return x3.view(Bn, L, C), None
         # the three linear projections in one grouped launch (the key / value GEMMs alone would leave most CUs idle)

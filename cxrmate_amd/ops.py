@@ -283,9 +283,12 @@ def gemm_exclusive(on: bool):
         LIB.call("cxr_gemm_set_exclusive", int(bool(on)))
 
 
+_EXCL_ALWAYS = __import__("os").environ.get("CXR_GEMM_EXCL_ALWAYS") == "1"      # lab switch: persistent GEMM kernels also beside the weight-gradient stream
+
+
 def wgrad_begin():
     """Start of a backward pass: from here on weight-gradient kernels may be running on the side stream (until wgrad_join)."""
-    if WGRAD_STREAM is not None:
+    if WGRAD_STREAM is not None and not _EXCL_ALWAYS:
         gemm_exclusive(False)
 
 
@@ -356,6 +359,21 @@ def attention(q, k, v, heads, scale, kpm=None, causal=False, causal_shift=None, 
              v.stride(0), v.stride(1), out.stride(0), out.stride(1), kpm.stride(0) if kpm is not None else 0, B, heads, Tq, Tk,
              float(scale), int(causal), int(causal_shift), *_drop_args(drop), _s())
     return out, lse
+
+
+def attention_q8(q, k, v, heads, scale, out_scale, kpm=None, causal=False, causal_shift=None):
+    """attention whose only consumer is an e4m3 GEMM with input scale `out_scale`: -> e4m3 [B, Tq, D] holding bf16(context) / out_scale."""
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    for t in (q, k, v):
+        assert t.dtype == BF16 and t.stride(2) == 1
+    out8 = torch.empty((B, Tq, D), device=q.device, dtype=FP8)
+    if causal_shift is None:
+        causal_shift = Tk - Tq
+    LIB.call("cxr_attn_fwd_q8_bf16", _p(q), _p(k), _p(v), _p(out8), out8.stride(0), out8.stride(1), 1.0 / float(out_scale), _p(kpm), q.stride(0), q.stride(1),
+             k.stride(0), k.stride(1), v.stride(0), v.stride(1), kpm.stride(0) if kpm is not None else 0, B, heads, Tq, Tk, float(scale), int(causal),
+             int(causal_shift), _s())
+    return out8
 
 
 def _drop_args(drop):
@@ -449,6 +467,17 @@ def layernorm(x, gamma, beta, eps, need_stats=False, out=None):
     stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32) if need_stats else None
     LIB.call("cxr_layernorm_fwd_bf16", _p(x), x.stride(0), _p(gamma), _p(beta), _p(out), out.stride(0), _p(stats), rows, C, float(eps), _s())
     return out, stats
+
+
+def layernorm_q8(x, gamma, beta, eps, scale):
+    """LayerNorm whose only consumer is an e4m3 GEMM with input scale `scale`: x [rows, C] bf16 -> e4m3 [rows, C] holding LN(x) / scale (no bf16
+    output, no separate quantisation pass)."""
+    _chk(x, BF16)
+    rows, C = x.shape
+    out8 = torch.empty((rows, C), device=x.device, dtype=FP8)
+    LIB.call("cxr_layernorm_q8_bf16", _p(x), x.stride(0), _p(gamma), _p(beta), None, 0, _p(out8), out8.stride(0), 1.0 / float(scale), None, rows, C,
+             float(eps), _s())
+    return out8
 
 
 def layernorm_bwd(x, dy, gamma, stats, dgamma, dbeta, add=None, out=None, drop=None, row_scale=None):
@@ -681,7 +710,7 @@ def _dwproj_array(projs):
                 setattr(d, k, _p(t))
         y = p.get("y")
         if y is not None:
-            assert y.dtype == BF16 and y.stride(2) == 1
+            assert y.dtype in (BF16, FP8) and y.stride(2) == 1
             d.y, d.y_bs, d.y_rs = _p(y), y.stride(0), y.stride(1)
     return arr
 
@@ -701,6 +730,19 @@ def dwproj_apply(x, H, W, tok0, projs):
         ys.append(torch.empty((Bn, tok0 + Ho * Wo, C), device=x.device, dtype=BF16))
     arr = _dwproj_array([dict(p, y=y) for p, y in zip(projs, ys)])
     LIB.call("cxr_dwproj_apply_bf16", _p(x), x.stride(0), x.stride(1), Bn, C, H, W, int(tok0), _ct.addressof(arr), len(projs), _s())
+    return ys
+
+
+def dwproj_apply_q8(x, H, W, tok0, projs, scales):
+    """dwproj_apply with e4m3 outputs y / scales[q] (the consumers are e4m3 GEMMs with these input scales)."""
+    Bn, C = _dwproj_geo(x, H, W, tok0)
+    ys = []
+    for p in projs:
+        Ho, Wo = (H - 1) // p["stride"] + 1, (W - 1) // p["stride"] + 1
+        ys.append(torch.empty((Bn, tok0 + Ho * Wo, C), device=x.device, dtype=FP8))
+    arr = _dwproj_array([dict(p, y=y) for p, y in zip(projs, ys)])
+    inv = (_ct.c_float * len(projs))(*[1.0 / float(s_) for s_ in scales])
+    LIB.call("cxr_dwproj_apply_q8", _p(x), x.stride(0), x.stride(1), Bn, C, H, W, int(tok0), _ct.addressof(arr), len(projs), inv, _s())
     return ys
 
 

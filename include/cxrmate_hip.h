@@ -78,6 +78,11 @@ int cxr_colsum_bf16(const void* in, long ld, float* out, int R, int C, hipStream
 int cxr_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, float* LSE, const void* kpm, long q_bs, long q_rs, long k_bs,
                       long k_rs, long v_bs, long v_rs, long o_bs, long o_rs, long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal,
                       int causal_shift, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t0, hipStream_t stream);
+/* forward with the context written as e4m3 (value * inv_scale, saturating; strides in bytes) for a consumer that is an e4m3 GEMM: no bf16 output,
+ * no separate quantisation pass (frozen encoder, BASELINE.json configs[4]) */
+int cxr_attn_fwd_q8_bf16(const void* Q, const void* K, const void* V, void* O8, long o8_bs, long o8_rs, float inv_scale, const void* kpm, long q_bs,
+                         long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long kpm_bs, int B, int H, int Tq, int Tk, float scale, int causal,
+                         int causal_shift, hipStream_t stream);
 /* backward: dQ,dK,dV (contiguous [B,T,H*64]) from dO with P recomputed from (Q,K,LSE); delta[B,H,Tq] = rowsum(dO*O) is scratch */
 int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* delta, void* dQ,
                       void* dK, void* dV, const void* kpm, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
@@ -116,7 +121,10 @@ int cxr_lora_outer_bf16(const void* a, long lda, long M, int K, const float* t, 
 
 /* ---- LayerNorm (TF5:cvt:79,363-364; REF:modelling_single.py:29; TF5:bert:103,292,350,478) ------------------------------- */
 int cxr_layernorm_fwd_bf16(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* stats, long rows, int C,
-                           float eps, hipStream_t stream);           /* stats[rows][2] = (mean, rstd), optional */
+                           float eps, hipStream_t stream);
+/* LayerNorm whose consumer is an e4m3 GEMM: y8[rows, C] (row stride ldy8 bytes) = e4m3(LN(x) * inv_scale), saturating; y (bf16) may be NULL */
+int cxr_layernorm_q8_bf16(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, void* y8, long ldy8, float inv_scale,
+                          float* stats, long rows, int C, float eps, hipStream_t stream);           /* stats[rows][2] = (mean, rstd), optional */
 int cxr_layernorm_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, const float* gamma, const float* stats, const void* add,
                            long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, float* workspace, long rows, int C, void* dx2,
                            long lddx2, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_rows_per_b, int drop_t0,
@@ -204,6 +212,10 @@ typedef struct cxr_dwproj {
 int cxr_dwproj_ws_floats(int Bn, int C, int H, int W);      /* returns the element count (> 0) or a negative error */
 int cxr_dwproj_apply_bf16(const void* x, long x_bs, long x_rs, int Bn, int C, int H, int W, int tok0, const cxr_dwproj* projs, int nproj,
                           hipStream_t stream);
+/* cxr_dwproj_apply_bf16 for consumers that are e4m3 GEMMs (frozen encoder, BASELINE.json configs[4]): projs[q].y is an e4m3 matrix (y_bs / y_rs in
+ * bytes) that receives output * inv_scale[q], saturating -- no separate quantisation pass */
+int cxr_dwproj_apply_q8(const void* x, long x_bs, long x_rs, int Bn, int C, int H, int W, int tok0, const cxr_dwproj* projs, int nproj,
+                        const float* inv_scale, hipStream_t stream);
 int cxr_dwproj_bn_train_stats_bf16(const void* x, long x_bs, long x_rs, int Bn, int C, int H, int W, int tok0, float eps, float momentum,
                                    const cxr_dwproj* projs, int nproj, float* ws, hipStream_t stream);
 int cxr_dwproj_bn_train_bwd_stats_bf16(const void* x, long x_bs, long x_rs, int Bn, int C, int H, int W, int tok0, const cxr_dwproj* projs, int nproj,
