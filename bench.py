@@ -119,18 +119,20 @@ def timed(step, steps, world, dev):
     return dt, out
 
 
-def decode_traffic():
-    """HBM-side bytes per cached token-step from the committed PMC passes (profiles/r02_pmc_decode_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate runs over one 255-step sample+greedy decode of the configs[3] shape; counters cannot be collected live): the
-    decode-step kernels only (the encoder / prefill kernels of the same run are left out)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_decode_hbm_traffic.json")
-    if not os.path.exists(path):
-        return None, None
-    pmc = json.load(open(path))
-    fams = ("dec_gemm", "attn_decode", "token_selection", "step_inputs_embedding")
-    return (sum(pmc[f]["hbm_bytes_per_unit"] for f in fams if f in pmc),
-            "profiles/r02_pmc_decode_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per token-step of dec_gemm + attn_decode + token selection + step "
-            "inputs kernels, separate --pmc passes)")
+def decode_traffic(c5=False):
+    """HBM-side bytes per cached token-step from the committed PMC passes (profiles/r03_pmc_decode[_c5]_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs over one sample+greedy decode of the configs[3] / configs[4] shape, kernels launched one by one -- counters cannot
+    be collected live, and hipGraph replays under --pmc take tens of minutes): the decode-step kernels only (the encoder / prefill kernels of the
+    same run are left out)."""
+    for name in (("r03_pmc_decode_c5_hbm_traffic.json",) if c5 else ("r03_pmc_decode_hbm_traffic.json", "r02_pmc_decode_hbm_traffic.json")):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        if os.path.exists(path):
+            pmc = json.load(open(path))
+            fams = ("dec_gemm", "attn_decode", "token_selection", "step_inputs_embedding")
+            return (sum(pmc[f]["hbm_bytes_per_unit"] for f in fams if f in pmc),
+                    f"profiles/{name} (FETCH_SIZE x2 + WRITE_SIZE per token-step of dec_gemm + attn_decode + token selection + step inputs kernels, "
+                    "separate --pmc passes)")
+    return None, None
 
 
 def scst_bench(args, rank, world, dev, steps, c5=False):
@@ -237,7 +239,9 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
                             "(OCP) MFMA linear layers (static per-tensor scales), sample + greedy as one 32-row cached decode, REINFORCE + AdamW; "
                             "the reference runs this path at batch 1 (scst/gen_prompt.py:38), the batch here is the C4 batch",
                 "roofline": {"bound": "hbm", "kernel": "cached decode token-step, 32 rows, 1728 encoder keys", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_token_step": step_bytes}}
+                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": decode_traffic(True)[0], "traffic_unit": "bytes per token-step",
+                             "traffic_source": decode_traffic(True)[1], "algorithmic_bytes_per_token_step": step_bytes,
+                             "profile": "profiles/r03_scst_c5_decode_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/scst_c5_decode_profile.py)"}}
     return {"metric": "scst_steps_per_sec", "value": world * steps / dt, "unit": "steps/s (16 studies x 2 images per GPU per step; all GPUs)",
             "steps_per_sec_per_gpu": steps / dt, "steps": steps, "ms_per_step": dt / steps * 1e3, "studies_per_sec": world * B * steps / dt,
             "new_tokens_sampled_and_greedy": n_tok,
@@ -253,7 +257,7 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
                          "traffic_source": decode_traffic()[1], "algorithmic_bytes_per_token_step": step_bytes,
                          "decode_ms_per_step": dec_ms, "us_per_token_step": dec_ms * 1e3 / n_tok,
                          "decode_share_of_step": dec_ms / (dt / steps * 1e3),
-                         "profile": "profiles/r02_scst_decode_v4_kernel_stats.csv (rocprofv3 --kernel-trace of scripts/scst_decode_profile.py)"}}
+                         "profile": "profiles/r03_scst_decode_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/scst_decode_profile.py)"}}
 
 
 def beam_bench(args, dev, host_loop_too=True):
@@ -587,11 +591,11 @@ def main():
     ms_per_step, tokens_per_s = main_res["ms_per_step"], main_res["tokens_per_s"]
     gm = main_res["gemm"]
     traffic, traffic_src = None, None                        # HBM-side bytes per launch from the committed PMC passes (cannot be collected live)
-    for name in ("r02_pmc_tf_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for name in ("r03_pmc_tf_hbm_traffic.json", "r02_pmc_tf_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             traffic = pmc["gemm_nt"]["hbm_bytes_per_launch"]
-            traffic_src = f"profiles/{name} (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes" + ("" if name.startswith("r02") else "; collected on configs[1] in round 1") + ")"
+            traffic_src = f"profiles/{name} (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes" + ("" if not name.startswith("r01") else "; collected on configs[1] in round 1") + ")"
             break
         except Exception:
             pass
@@ -608,13 +612,14 @@ def main():
                    "rccl_ranks": world, "launch": "hipGraph replay (3 segments, RCCL between)" if args.graph else "eager, weight-gradient kernels on a side stream",
                    "mode": mode, "loss": main_res["loss"], "tokens_per_sec_per_gpu": tokens_per_s / world,
                    "model_tflops_per_gpu": main_res["step_gflop_per_gpu"] * 1e-3 / (ms_per_step * 1e-3)},
-        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (all tile variants; v_mfma_f32_16x16x32_bf16), timed while the weight-gradient "
-                               "stream runs beside it, as in the timed region", "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": "NT GEMM family (gemm_nt_kernel tile variants, gemm_nt_group_kernel, and in the forward pass the persistent "
+                               "gemm_nt_pk_kernel / gemm_ws384_kernel; v_mfma_f32_16x16x32_bf16), timed while the weight-gradient stream runs beside it, "
+                               "as in the timed region", "achieved": achieved,
                      "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TF, "traffic": traffic,
                      "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "algorithmic_bytes_per_launch": gm["nt_bytes"] / max(1, gm["nt_n"]),
                      "launches_per_step": gm["nt_n"], "avg_launch_us": gm["nt_ms"] * 1e3 / max(1, gm["nt_n"]),
                      "avg_launch_gflop": gm["nt_flops"] / max(1, gm["nt_n"]) * 1e-9, "gemm_share_of_step": gm["nt_ms"] / ms_per_step,
-                     "weight_grad_kernel": {"kernel": "gemm_tn_kernel", "launches_per_step": gm["tn_n"],
+                     "weight_grad_kernel": {"kernel": "gemm_tn_kernel (128x128 tiles) / gemm_tn2_kernel (256x256 blocks, long token runs)", "launches_per_step": gm["tn_n"],
                                             "achieved": gm["tn_flops"] / (gm["tn_ms"] * 1e-3) / 1e12 if gm["tn_ms"] else None,
                                             "avg_launch_us": gm["tn_ms"] * 1e3 / max(1, gm["tn_n"])}},
     }

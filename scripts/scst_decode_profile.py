@@ -9,6 +9,8 @@ dev = torch.device("cuda")
 m = LongitudinalPromptMultiCXREncoderDecoderModel(EncoderDecoderConfig(), device=dev, seed=0).train()
 images = torch.randn(16, 2, 3, 384, 384, device=dev)
 prompt = torch.tensor([[8, 10, 9, 11, 1]] * 16, device=dev)
+if os.environ.get("CXR_PROFILE_EAGER") == "1":      # counter (--pmc) passes: the same kernels launched one by one (hipGraph replays under --pmc take tens of minutes)
+    m.graph_decode = False
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 with torch.no_grad():
     eo = m.encoder(images)
