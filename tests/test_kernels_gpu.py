@@ -282,6 +282,53 @@ def test_attention_fwd(ops, B, H, Tq, Tk, causal, masked):
     close(lse, ref_lse, rtol=1e-3, atol=1e-3, what="lse")
 
 
+@pytest.mark.parametrize("B,H,Tq,Tk,causal,masked", [(2, 1, 1300, 200, False, False), (1, 3, 577, 145, False, False), (2, 2, 300, 300, True, True),
+                                                     (2, 12, 70, 1152, False, True), (1, 2, 100, 33, False, False), (2, 1, 2100, 64, False, False)])
+def test_attention_kernel_generations_agree(ops, B, H, Tq, Tk, causal, masked):
+    """cxr_attn_config: the round-3 kernels (64 query rows per wave, one barrier per tile, skipped masked tiles; dQ kernel for unmasked Tq > 1024)
+    against the rounds 1-2 kernels on the same inputs: context within one bf16 step of each other (the online softmax advances in 32-key steps
+    instead of 64), LSE to fp32 rounding, dQ of the unmasked long calls BIT-identical (same arithmetic, other tiling), everything equally close to
+    the fp32 reference. A whole image's keys masked (second half of row 0) exercises the skipped tiles."""
+    D = H * 64
+    q, k, v = dev(rnd(B, Tq, D).to(BF)), dev(rnd(B, Tk, D, seed=1).to(BF)), dev(rnd(B, Tk, D, seed=2).to(BF))
+    do = dev(rnd(B, Tq, D, seed=3).to(BF))
+    kpm = None
+    if masked:
+        kpm = torch.ones(B, Tk, dtype=torch.uint8)
+        kpm[0, Tk // 2:] = 0
+        kpm[-1, 3:7] = 0
+        kpm = kpm.cuda()
+    res = {}
+    try:
+        for ver in (1, 2):
+            ops.attention_config(ver, ver)
+            out, lse = ops.attention(q, k, v, H, 0.125, kpm=kpm, causal=causal, need_lse=True)
+            res[ver] = (out, lse) + tuple(ops.attention_bwd(q, k, v, res[1][0] if ver == 2 else out, do, res[1][1] if ver == 2 else lse, H, 0.125, kpm=kpm,
+                                                            causal=causal))
+    finally:
+        ops.attention_config(2, 2)
+    ref, ref_lse = ref_attention(q, k, v, H, 0.125, kpm, causal, Tk - Tq)
+    for ver in (1, 2):
+        close(res[ver][0], ref, rtol=2e-2, atol=2e-2, what=f"attn out v{ver}")
+        close(res[ver][1], ref_lse, rtol=1e-3, atol=1e-3, what=f"lse v{ver}")
+    close(res[2][0], res[1][0].float(), rtol=1e-2, atol=1e-2, what="context v2 vs v1")
+    close(res[2][1], res[1][1], rtol=1e-5, atol=1e-5, what="lse v2 vs v1")
+    for i, name in ((2, "dq"), (3, "dk"), (4, "dv")):
+        assert torch.equal(res[2][i], res[1][i]), name          # same O / LSE in: the dK/dV kernel is shared, the dQ kernels do the same arithmetic
+
+
+def test_attention_e4m3_context_equals_quantised_bf16_context(ops):
+    """cxr_attn_fwd_q8_bf16 (frozen e4m3 encoder): the context written as e4m3 by the attention kernel == cxr_quantize_fp8 of its bf16 context."""
+    B, H, Tq, Tk = 2, 3, 577, 145
+    D = H * 64
+    q, k, v = dev(rnd(B, Tq, D).to(BF)), dev(rnd(B, Tk, D, seed=1).to(BF)), dev(rnd(B, Tk, D, seed=2).to(BF))
+    out, _ = ops.attention(q, k, v, H, 0.125)
+    scale = float(out.float().abs().max()) / 300.0
+    want = ops.quantize_fp8(out.view(-1, D), scale)
+    got = ops.attention_q8(q, k, v, H, 0.125, scale).view(-1, D)
+    assert torch.equal(got.view(torch.uint8), want.view(torch.uint8))
+
+
 def test_attention_exact_integers(ops):
     # one-hot keys/queries: softmax is (almost) a hard selection, V integers -> catches any key/lane permutation in P.V
     B, H, T = 1, 1, 128
@@ -963,6 +1010,42 @@ def test_dwproj_fused_eval(ops, Bn, C, H, W, tok0):
     # the per-projection kernels of conv.hip compute the same thing
     yq, _ = ops.dwconv_bn(x, H, W, 1, tok0, folds[0])
     close(ys[0], yq, rtol=1e-3, atol=1e-2, what="dwproj vs dwconv q")
+
+
+def _fp8_values(t8):
+    """e4m3 bytes -> fp32 values (torch's own cast)"""
+    return t8.float()
+
+
+@pytest.mark.parametrize("Bn,C,H,W,tok0", [(2, 64, 12, 12, 0), (2, 384, 6, 6, 1)])
+def test_dwproj_and_layernorm_e4m3_outputs(ops, Bn, C, H, W, tok0):
+    """Producers of the frozen e4m3 encoder (BASELINE.json configs[4]): cxr_dwproj_apply_q8 and cxr_layernorm_q8_bf16 write e4m3(value / scale)
+    directly. They quantise the fp32 value (the separate pass quantised the bf16-rounded one): equal to quantising the bf16 output up to one e4m3
+    step, and the dequantised result stays as close to the fp32 reference as the e4m3 grid allows (relative step 2^-3 at worst, 2^-4 typical)."""
+    strides = (1, 2, 2)
+    x = dev((rnd(Bn, tok0 + H * W, C) + 0.2).to(BF))
+    par = _dwproj_params(C)
+    folds = [ops.bn_fold(p["w"], p["g"], p["b"], p["rm"], p["rv"], 1e-5) for p in par]
+    projs = [dict(stride=st, taps=f[0], shift=f[1]) for st, f in zip(strides, folds)]
+    ys = ops.dwproj_apply(x, H, W, tok0, projs)
+    scales = [float(y.float().abs().max()) / 400.0 for y in ys]
+    y8 = ops.dwproj_apply_q8(x, H, W, tok0, projs, scales)
+    for y, q8, sc in zip(ys, y8, scales):
+        assert q8.shape == y.shape and q8.dtype == ops.FP8
+        want = ops.quantize_fp8(y.reshape(-1, C), sc).view(y.shape)
+        a, b = _fp8_values(q8) * sc, _fp8_values(want) * sc
+        assert float((a - b).abs().max()) <= 0.13 * float(y.float().abs().max())          # at most one e4m3 step apart (fp32 vs bf16 rounding at a tie)
+        assert float(((a - b) != 0).float().mean()) < 0.05                                   # ... and almost never
+        assert bool(((a - y.float()).abs() <= 0.0635 * y.float().abs() + sc * 2.0 ** -9).all())          # e4m3 rounding: 2^-4 relative, 2^-10 * scale near zero
+    g, b_ = dev(rnd(C, seed=5) * 0.1 + 1.0), dev(rnd(C, seed=6) * 0.1)
+    x2 = x.view(-1, C)
+    y, _ = ops.layernorm(x2, g, b_, 1e-5)
+    sc = float(y.float().abs().max()) / 400.0
+    q8 = ops.layernorm_q8(x2, g, b_, 1e-5, sc)
+    want = ops.quantize_fp8(y, sc)
+    a, b = _fp8_values(q8) * sc, _fp8_values(want) * sc
+    assert float(((a - b) != 0).float().mean()) < 0.05
+    assert bool(((a - y.float()).abs() <= 0.0635 * y.float().abs() + sc * 2.0 ** -9).all())
 
 
 @pytest.mark.parametrize("Bn,C,H,W,tok0", DWPROJ_SHAPES)
