@@ -339,8 +339,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd2_kernel(const AttnArgs a)
     int* Mf = reinterpret_cast<int*>(smem + 2 * A2_BUF + 128);     // per buffer: bit 0 = every key of the tile attends, bit 1 = none does
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int qb0 = blockIdx.x * (NW * 64);
+    int bx, head, b;
+    xcd_block_remap(bx, head, b);                                  // the query blocks of one (image, head) run on ONE XCD: its K / V stay in that L2
+    const int qb0 = bx * (NW * 64);
     const int ql = lane & 31, hh = lane >> 5;
     const int row0 = qb0 + wave * 64;                              // first query row of this wave
     const bool wave_on = row0 < a.Tq;                              // wave-uniform: a wave without queries only stages tiles and meets the barriers

@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdArgs
     __shared__ __attribute__((aligned(16))) bf16_t Os[4][32 * 64];    // per-wave tile for the row-contiguous dK / dV stores
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int kb0 = blockIdx.x * 128;
+    int bx, head, b;
+    xcd_block_remap(bx, head, b);                                  // the key blocks of one (image, head) run on ONE XCD: its Q / dO stream stays in that L2
+    const int kb0 = bx * 128;
     const uint32_t drop_seed = a.drop_thr16 ? *a.drop_seed : 0u;
     const int kl = lane & 31, hh = lane >> 5;
     const int key = kb0 + wave * 32 + kl;
@@ -227,8 +228,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwdArgs a
     __shared__ __attribute__((aligned(16))) bf16_t Os[4][32 * 64];    // per-wave tile for the row-contiguous dQ store
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int qb0 = blockIdx.x * 128;
+    int bx, head, b;
+    xcd_block_remap(bx, head, b);
+    const int qb0 = bx * 128;
     const int ql = lane & 31, hh = lane >> 5;
     const int qrow = qb0 + wave * 32 + ql;
     const int qc = qrow < a.Tq ? qrow : a.Tq - 1;
@@ -449,8 +451,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq2_kernel(const AttnBwdA
     int* Mf = reinterpret_cast<int*>(smem + 2 * Q2_BUF + 128);     // per buffer: bit 0 = every key of the tile attends, bit 1 = none does
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int qb0 = blockIdx.x * (NW * 64);
+    int bx, head, b;
+    xcd_block_remap(bx, head, b);
+    const int qb0 = bx * (NW * 64);
     const int ql = lane & 31, hh = lane >> 5;
     const int row0 = qb0 + wave * 64;
     const bool wave_on = row0 < a.Tq;

@@ -166,6 +166,21 @@ __device__ __forceinline__ void tile_rows_store_q8(const bf16_t* tile, int lane,
     }
 }
 
+// XCD-aware workgroup order for 3-D grids whose x index walks the blocks that SHARE operands (the query blocks of one (image, head) all stream
+// that head's K / V; its key blocks all stream its Q / dO): hardware deals workgroups round-robin over the 8 XCDs in linear order, so neighbours in
+// x land on 8 different L2s and every L2 ends up holding the operands of every image in flight (PMC: 2-3x the unique bytes fetched from the fabric).
+// The linear id is remapped (bijectively, remainder included) so that each XCD runs a CONTIGUOUS run of the linear order.
+__device__ __forceinline__ void xcd_block_remap(int& bx, int& by, int& bz) {
+    const int nx = gridDim.x, ny = gridDim.y, n = nx * ny * gridDim.z;
+    const int L = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const int xcd = L & 7, q = n >> 3, r = n & 7;
+    const int Lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    bx = Lp % nx;
+    const int t = Lp / nx;
+    by = t % ny;
+    bz = t / ny;
+}
+
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {     // butterfly over W lanes (W power of two <= 64)
 #pragma unroll
