@@ -662,6 +662,9 @@ def main():
             out["scst_dropin"] = scst_dropin(args, dev)
             if out["scst"].get("ms_per_step"):
                 out["scst_dropin"]["vs_fused_step"] = out["scst_dropin"]["ms_per_step"] / out["scst"]["ms_per_step"]
+                srt = out["scst"].get("string_round_trip") or {}
+                if srt.get("ms_per_step"):      # the like-for-like twin: the fused step WITH the decode -> re-tokenise string round trip the callers do
+                    out["scst_dropin"]["vs_fused_string_round_trip_step"] = out["scst_dropin"]["ms_per_step"] / srt["ms_per_step"]
         except Exception as e:
             out["scst_dropin"] = {"error": str(e)}
         torch.cuda.empty_cache()
