@@ -615,6 +615,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq2_kernel(const AttnBwdA
     }
 }
 
+// (Measured and removed in round 3: a dK / dV kernel with 64 keys per wave -- every Q / dO fragment feeding two MFMAs, dK / dV of both key blocks in
+// 128 accumulator registers, double-buffered tiles, one barrier per tile, ~480 registers = one wave per SIMD. Bit-identical to attn_bwd_dkdv_kernel and
+// 8-30 % SLOWER (stage 1 backward 1479 -> 1843 us, stage 2 364 -> 491, stage 3 94 -> 103): with a single wave per SIMD nothing runs under the
+// S / dP -> exp -> pack -> dV / dK dependency chain; two waves per SIMD need <= 256 registers, which 64 keys per wave cannot meet.)
 // Only the unmasked form is launched: with masks / dropout the kernel needs more than 256 registers (100 - 140 bytes of scratch per lane) and
 // measured 4 - 17 % SLOWER than attn_bwd_dq_kernel on the decoder's shapes, 3 - 8 % faster on the CvT stages (scripts/attn_micro.py).
 template <int NW>
