@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] += av[j];
                     }
-                    *reinterpret_cast<uint4*>(dx + row[u] * lddx + ch * 8) = pack8(o);
+                    if (dx) *reinterpret_cast<uint4*>(dx + row[u] * lddx + ch * 8) = pack8(o);      // (dx may be null when only the scaled copy dx2 is wanted)
                     if (dd.dx2) {
                         if (dd.row_scale) {
                             const float f = rsf[u];
@@ -314,7 +314,7 @@ extern "C" int cxr_layernorm_bwd_bf16(const void* x, long ldx, const void* dy, l
                                       const void* add, long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, float* workspace,
                                       long rows, int C, void* dx2, long lddx2, float drop_p, const unsigned int* drop_seed, unsigned int drop_site,
                                       int drop_rows_per_b, int drop_t0, const float* row_scale, hipStream_t stream) {
-    if (rows <= 0 || (ldx % 8) || (lddy % 8) || (lddx % 8) || (add && (ldadd % 8)) || (dgamma && (!workspace || !dbeta))) return CXR_ERR_ARG;
+    if (rows <= 0 || (ldx % 8) || (lddy % 8) || (lddx % 8) || (add && (ldadd % 8)) || (dgamma && (!workspace || !dbeta)) || (!dx && !dx2)) return CXR_ERR_ARG;
     if (dx2 && ((lddx2 % 8) || drop_rows_per_b <= 0 || (!row_scale && (drop_p <= 0.f || drop_p >= 1.f || !drop_seed)))) return CXR_ERR_ARG;
     LnBwdDrop dd;
     dd.dx2 = (bf16_t*)dx2; dd.lddx2 = lddx2; dd.seed = drop_seed; dd.site = drop_site; dd.thr16 = (dx2 && !row_scale) ? dropout_thr16(drop_p) : 0u;

@@ -413,7 +413,10 @@ class CvtEncoderEngine:
                 ops.copy_rows(dx, full[:, 1:, :])
                 dx = full
             for l in reversed(range(cfg.depth[s])):
-                dx = self._layer_bwd(dx, ss["layers"][l], s, l, H, W, tok0, prep)
+                # the layer below scales its incoming gradient by ITS second DropPath factor first thing: let this layer's last kernel write it scaled
+                below = ss["layers"][l - 1]["dp"][1] if l > 0 else None
+                dx = self._layer_bwd(dx, ss["layers"][l], s, l, H, W, tok0, prep, prescaled=l + 1 < cfg.depth[s] and ss["layers"][l]["dp"][1] is not None,
+                                     out_scale=below)
             if tok0:
                 ops.sum_row0_into(dx, st.grad(sp + "cls_token").view(-1))
                 dsp = torch.empty((Bn, H * W, C), dtype=torch.bfloat16, device=dx.device)
@@ -439,7 +442,9 @@ class CvtEncoderEngine:
                 on_stage_done(s)
         return None
 
-    def _layer_bwd(self, dy, sv, s, l, H, W, tok0, prep):
+    def _layer_bwd(self, dy, sv, s, l, H, W, tok0, prep, prescaled=False, out_scale=None):
+        """prescaled: dy already carries this layer's second DropPath factor (the layer above wrote it so). out_scale: per-image factors the returned
+        gradient is multiplied with (the second DropPath of the layer below), applied by the last LayerNorm-backward kernel instead of a separate pass."""
         cfg, st = self.cfg, self.s
         lp = self._stage(s) + f"layers.{l}."
         ap = lp + "attention.attention."
@@ -449,7 +454,7 @@ class CvtEncoderEngine:
         g = st.grad
         # MLP:  x3 = droppath2(x2 + W2 gelu(W1 h2 + b1) + b2)
         dp1, dp2 = sv["dp"]
-        if dp2 is not None:
+        if dp2 is not None and not prescaled:
             dy2 = ops.dropout_add(dy2, None, 0.0, None, 0, L, row_scale=dp2)
         ops.linear_bwd_weight(dy2, sv["g"], g(lp + "output.dense.weight"), g(lp + "output.dense.bias"))
         du = ops.gemm_nt(dy2, self._wt(lp + "output.dense.weight"), act=2, aux=sv["u"])
@@ -523,6 +528,10 @@ class CvtEncoderEngine:
                 dh1 = ops.dwproj_dx([dict(stride=sd, taps=wf, y=d) for d, wf, sd in projs], Bn, C, H, W, tok0)
             else:
                 dh1 = ops.dwconv_bn_bwd_dx(projs, Bn, C, H, W, tok0)
-        dx = ops.layernorm_bwd(sv["x"].view(-1, C), dh1.view(-1, C), st.f32(lp + "layernorm_before.weight"), sv["st1"],
-                               g(lp + "layernorm_before.weight"), g(lp + "layernorm_before.bias"), add=dx2)
+        if out_scale is not None:
+            _, dx = ops.layernorm_bwd(sv["x"].view(-1, C), dh1.view(-1, C), st.f32(lp + "layernorm_before.weight"), sv["st1"],
+                                      g(lp + "layernorm_before.weight"), g(lp + "layernorm_before.bias"), add=dx2, row_scale=(out_scale, L), main=False)
+        else:
+            dx = ops.layernorm_bwd(sv["x"].view(-1, C), dh1.view(-1, C), st.f32(lp + "layernorm_before.weight"), sv["st1"],
+                                   g(lp + "layernorm_before.weight"), g(lp + "layernorm_before.bias"), add=dx2)
         return dx.view(Bn, L, C)

@@ -480,12 +480,13 @@ def layernorm_q8(x, gamma, beta, eps, scale):
     return out8
 
 
-def layernorm_bwd(x, dy, gamma, stats, dgamma, dbeta, add=None, out=None, drop=None, row_scale=None):
+def layernorm_bwd(x, dy, gamma, stats, dgamma, dbeta, add=None, out=None, drop=None, row_scale=None, main=True):
     """-> dx, or (dx, dx2) with dx2 = f * dx when drop = (p, seed, site, rows_per_b, t0) (dropout mask re-applied) or row_scale =
-    (scale fp32 [rows / rows_per_b], rows_per_b) (DropPath factor) is given."""
+    (scale fp32 [rows / rows_per_b], rows_per_b) (DropPath factor) is given. main=False (with drop / row_scale): only dx2 is written -> (None, dx2)."""
     _chk(x, BF16); _chk(dy, BF16)
     rows, C = x.shape
-    if out is None:
+    assert main or drop is not None or row_scale is not None
+    if out is None and main:
         out = torch.empty((rows, C), device=x.device, dtype=BF16)
     second = drop is not None or row_scale is not None
     out2 = torch.empty((rows, C), device=x.device, dtype=BF16) if second else None
@@ -495,7 +496,7 @@ def layernorm_bwd(x, dy, gamma, stats, dgamma, dbeta, add=None, out=None, drop=N
         ws = torch.empty((nb, 2, C), device=x.device, dtype=torch.float32)
     side = WGRAD_STREAM is not None and dgamma is not None       # row sum of the (dgamma, dbeta) partials off the critical path
     LIB.call("cxr_layernorm_bwd_bf16", _p(x), x.stride(0), _p(dy), dy.stride(0), _p(gamma), _p(stats), _p(add),
-             add.stride(0) if add is not None else 0, _p(out), out.stride(0), None if side else _p(dgamma), None if side else _p(dbeta), _p(ws), rows, C, _p(out2),
+             add.stride(0) if add is not None else 0, _p(out), out.stride(0) if out is not None else C, None if side else _p(dgamma), None if side else _p(dbeta), _p(ws), rows, C, _p(out2),
              out2.stride(0) if second else 0, float(drop[0]) if drop is not None else 0.0, _p(drop[1]) if drop is not None else None,
              int(drop[2]) if drop is not None else 0, int(drop[3]) if drop is not None else (int(row_scale[1]) if row_scale is not None else 1),
              int(drop[4]) if drop is not None else 0, _p(row_scale[0]) if row_scale is not None else None, _s())
