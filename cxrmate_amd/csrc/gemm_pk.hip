@@ -28,7 +28,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
-struct PkSched { int tiles_n, teams, slots, rg_total; int dbg; };      // dbg (timing experiments only): 1 no epilogue, 2 no epilogue stores, 4 stamps, 8 (host) every workgroup
+struct PkSched { int tiles_n, teams, slots, rg_total; int dbg; int slot_major; };      // dbg (timing experiments only): 1 no epilogue, 2 no epilogue stores, 4 stamps, 8 (host) every workgroup
                                                                         // covers all N tiles of its own rows, 16 odd workgroups walk their M tiles backwards
 
 // One configuration of the kernel: BM x BN tile, BK-deep ring stages (NST of them), WM x WN waves (wave tile (BM / WM) x 64), OCC workgroups
@@ -94,7 +94,10 @@ __global__ __launch_bounds__(C::THREADS, (C::OCC * C::WM * C::WN + 3) / 4) void 
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int team = L / sc.slots, slot = L % sc.slots;
+    // team-major (default): a team's workgroups (one per N tile) are neighbours in L, i.e. share an XCD and its L2 copy of the team's A rows.
+    // slot-major (W far larger than an L2: the 30000-column LM head): the teams that work on the SAME N tiles are neighbours instead, so an XCD holds
+    // few W tiles at a time and every one of them is fetched once per XCD, not once per workgroup and row tile (PMC: 2.2 GB -> see DESIGN.md section 6)
+    const int team = sc.slot_major ? L % sc.teams : L / sc.slots, slot = sc.slot_major ? L / sc.teams : L % sc.slots;
     const int rg0 = (int)((long)team * sc.rg_total / sc.teams), rg1 = (int)((long)(team + 1) * sc.rg_total / sc.teams);
     const int m_begin = rg0 * 16, m_end = min(g.M, rg1 * 16);
     const int mtiles = (m_end - m_begin + C::BM - 1) / C::BM;
@@ -441,6 +444,7 @@ static void pk_launch_cfg(const GemmArgs& g, int wgs, int dbg, hipStream_t strea
     if (wgs <= 0) wgs = 256 * C::OCC;
     PkSched sc;
     sc.dbg = dbg;
+    sc.slot_major = 0;
     sc.tiles_n = cdiv(g.N, C::BN);
     sc.rg_total = cdiv(g.M, 16);
     if (dbg & 8) {
@@ -448,6 +452,13 @@ static void pk_launch_cfg(const GemmArgs& g, int wgs, int dbg, hipStream_t strea
         sc.teams = wgs;
         const int max_teams = cdiv(g.M, 64);
         if (sc.teams > max_teams) sc.teams = max_teams;
+    } else if (!(dbg & 32) && (long)g.N * g.K * 2 > (16L << 20) && g.M >= 8 * C::BM && wgs >= 64 && sc.tiles_n * 8 >= wgs) {
+        // weights far beyond the 4-MB L2s (LM head: 46 MB): 8 row teams x (wgs / 8 rounded down to a divisor-friendly count) column slots, slot-major
+        sc.slot_major = 1;
+        sc.teams = 8;
+        sc.slots = wgs / 8;
+        const int per = cdiv(sc.tiles_n, sc.slots);               // N tiles per slot; fewer slots with the same count leave less imbalance
+        sc.slots = cdiv(sc.tiles_n, per);
     } else if (sc.tiles_n <= wgs) {
         sc.slots = sc.tiles_n;
         sc.teams = wgs / sc.tiles_n;
