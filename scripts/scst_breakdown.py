@@ -27,7 +27,13 @@ def T(name, fn, n=3):
     for _ in range(n):
         out = fn()
     torch.cuda.synchronize()
-    print(f"{name:44s} {(time.perf_counter() - t) / n * 1e3:8.2f} ms")
+    wall = (time.perf_counter() - t) / n * 1e3
+    t = time.perf_counter()                  # host enqueue time alone (no wait): equal to the wall time = the phase is launch-bound
+    for _ in range(n):
+        out = fn()
+    host = (time.perf_counter() - t) / n * 1e3
+    torch.cuda.synchronize()
+    print(f"{name:50s} {wall:8.2f} ms   (host enqueue {host:6.2f} ms)")
     return out
 
 with torch.no_grad():
