@@ -35,6 +35,9 @@ struct Dw3P {                                      // one projection, device vie
     bf16_t* y; long y_bs, y_rs;
     int stride, Ho, Wo;
     float inv8;                                    // apply only: > 0 -> y is an e4m3 matrix (strides in bytes) holding output * inv8
+    // backward statistics only: the projection's FORWARD output (saved for the Linear layer's weight gradient anyway) and its BatchNorm parameters:
+    // c = mean + (yf - beta) / (gamma * rstd) replaces the recomputed convolution wherever |gamma * rstd| is not tiny
+    const bf16_t* yf; long yf_bs, yf_rs; const float* gm; const float* bt; const float* mn; const float* rs;
 };
 struct Dw3Blk { int b, band_i, slice, ch, pl, c0; };
 
@@ -264,21 +267,42 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_apply_kernel(const Dw3Geo 
 }
 
 // ------------------------------------------------------------------------------------------------------------------ backward statistics
-// ws row of [nproj][2][C]: (sum dy, sum dy*c), c recomputed from the staged activation and the raw taps
+// ws row of [nproj][2][C]: (sum dy, sum dy*c). c is the projection's raw convolution output: recomputed from the staged activation and the raw taps, or --
+// when the caller hands over the projection's forward output yf = (c - mean) * gamma * rstd + beta (bf16, saved for the weight gradient of the Linear layer
+// that follows) and |gamma * rstd| >= 1e-3 for all 64 channels of the slice -- recovered as c = mean + (yf - beta) / (gamma * rstd): the pass is then a plain
+// streaming reduction over (dy, yf) without the LDS tile, the 9 window reads and the 108 VALU instructions of the convolution per 8 outputs. The bf16
+// rounding of yf perturbs c by <= 2^-9 |yf - beta| / |gamma * rstd| per element, which averages out in the two sums (tests: same tolerances as before).
 __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_bwd_stats_kernel(const Dw3Geo g, const Dw3P p0, const Dw3P p1, const Dw3P p2, float* __restrict__ ws) {
     __shared__ float red[DW3_RED_SMALL];
     extern __shared__ uint4 dw3_tile[];
     const Dw3Blk k = dw3_block(g);
     const int pitch = g.W + 2, pitch8 = pitch * 8;
-    dw3_stage(dw3_tile, g.x + (long)k.b * g.x_bs + (long)g.tok0 * g.x_rs + k.slice * 64, g.x_rs, g.H, g.W, k.band_i * g.band - 1, g.band + 2, -1, pitch);
-    __syncthreads();
+    // which projections can take c from their forward output (workgroup-uniform: one decision per 64-channel slice)
+    bool from_y[3] = {false, false, false};
+    bool need_tile = false;
+#pragma unroll 1
+    for (int q = 0; q < g.nproj; ++q) {
+        const Dw3P& P = q == 0 ? p0 : (q == 1 ? p1 : p2);
+        int safe = 0;
+        if (P.yf) {                                                 // (kernel-argument uniform)
+            float gm[8], rs[8];
+            dw3_load8(P.gm + k.c0, gm); dw3_load8(P.rs + k.c0, rs);
+            safe = 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) safe &= fabsf(gm[j] * rs[j]) >= 1e-3f ? 1 : 0;
+        }
+        from_y[q] = __syncthreads_and(safe) != 0;
+        need_tile = need_tile || !from_y[q];
+    }
+    if (need_tile) {
+        dw3_stage(dw3_tile, g.x + (long)k.b * g.x_bs + (long)g.tok0 * g.x_rs + k.slice * 64, g.x_rs, g.H, g.W, k.band_i * g.band - 1, g.band + 2, -1, pitch);
+        __syncthreads();
+    }
     float* row = ws + (long)(k.b * g.nbands + k.band_i) * g.nproj * 2 * g.C;
 #pragma unroll 1
     for (int q = 0; q < g.nproj; ++q) {
         const Dw3P P = q == 0 ? p0 : (q == 1 ? p1 : p2);
         const bf16_t* yb = P.y + (long)k.b * P.y_bs + k.c0;
-        float w[9][8];
-        dw3_load_taps(P.taps, g.C, k.c0, w);
         float acc[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -288,21 +312,55 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_bwd_stats_kernel(const Dw3
         // this loop was one exposed global round trip
         const bf16_t* ybase = yb + (long)(g.tok0 + oy0 * P.Wo) * P.y_rs;
         const int last = npo > 0 ? npo - 1 : 0;
-        uint4 dq0 = make_uint4(0, 0, 0, 0), dq1 = dq0;
-        if (npo > 0) {                                             // (block-uniform: a band past the last output row reads nothing)
-            dq0 = *reinterpret_cast<const uint4*>(ybase + (long)min(k.pl, last) * P.y_rs);
-            dq1 = *reinterpret_cast<const uint4*>(ybase + (long)min(k.pl + DW3_PL, last) * P.y_rs);
-        }
-        for (int o = k.pl; o < npo; o += DW3_PL) {
-            const int oyl = o / P.Wo, ox = o - oyl * P.Wo;
-            float d[8], c[8];
-            const uint4 dcur = dq0;
-            dq0 = dq1;
-            dq1 = *reinterpret_cast<const uint4*>(ybase + (long)min(o + 2 * DW3_PL, last) * P.y_rs);
-            unpack8(dcur, d);
-            dw3_conv(dw3_tile, (oyl * P.stride * pitch + ox * P.stride) * 8 + k.ch, pitch8, w, c);
+        if (from_y[q]) {
+            float k0[8], k1[8];                                     // c = yf * k0 + k1
+            {
+                float gm[8], rs[8], bt[8], mn[8];
+                dw3_load8(P.gm + k.c0, gm); dw3_load8(P.rs + k.c0, rs); dw3_load8(P.bt + k.c0, bt); dw3_load8(P.mn + k.c0, mn);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { acc[j] += d[j]; acc[8 + j] = fmaf(d[j], c[j], acc[8 + j]); }
+                for (int j = 0; j < 8; ++j) { k0[j] = 1.0f / (gm[j] * rs[j]); k1[j] = mn[j] - bt[j] * k0[j]; }
+            }
+            const bf16_t* fbase = P.yf + (long)k.b * P.yf_bs + k.c0 + (long)(g.tok0 + oy0 * P.Wo) * P.yf_rs;
+            uint4 dq[4], fq[4];                                     // four outputs in flight per thread (8 independent 16-byte loads)
+            for (int o0 = k.pl; o0 < npo; o0 += 4 * DW3_PL) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int o = min(o0 + u * DW3_PL, last);
+                    dq[u] = ld_stream16(ybase + (long)o * P.y_rs);
+                    fq[u] = ld_stream16(fbase + (long)o * P.yf_rs);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool on = o0 + u * DW3_PL < npo;
+                    float d[8], f[8];
+                    unpack8(dq[u], d); unpack8(fq[u], f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float dj = on ? d[j] : 0.f;
+                        acc[j] += dj;
+                        acc[8 + j] = fmaf(dj, fmaf(f[j], k0[j], k1[j]), acc[8 + j]);
+                    }
+                }
+            }
+        } else {
+            float w[9][8];
+            dw3_load_taps(P.taps, g.C, k.c0, w);
+            uint4 dq0 = make_uint4(0, 0, 0, 0), dq1 = dq0;
+            if (npo > 0) {                                             // (block-uniform: a band past the last output row reads nothing)
+                dq0 = *reinterpret_cast<const uint4*>(ybase + (long)min(k.pl, last) * P.y_rs);
+                dq1 = *reinterpret_cast<const uint4*>(ybase + (long)min(k.pl + DW3_PL, last) * P.y_rs);
+            }
+            for (int o = k.pl; o < npo; o += DW3_PL) {
+                const int oyl = o / P.Wo, ox = o - oyl * P.Wo;
+                float d[8], c[8];
+                const uint4 dcur = dq0;
+                dq0 = dq1;
+                dq1 = *reinterpret_cast<const uint4*>(ybase + (long)min(o + 2 * DW3_PL, last) * P.y_rs);
+                unpack8(dcur, d);
+                dw3_conv(dw3_tile, (oyl * P.stride * pitch + ox * P.stride) * 8 + k.ch, pitch8, w, c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { acc[j] += d[j]; acc[8 + j] = fmaf(d[j], c[j], acc[8 + j]); }
+            }
         }
         dw3_reduce_small<16>(acc, red, row + (long)q * 2 * g.C, g.C, k.slice);
     }
@@ -624,6 +682,7 @@ static int dw3_plan(Dw3Plan& pl, const void* x, long x_bs, long x_rs, int Bn, in
         const cxr_dwproj& s = projs[q < nproj ? q : 0];
         Dw3P& d = pl.p[q];
         d.taps = s.taps; d.aux = nullptr; d.y = (bf16_t*)s.y; d.y_bs = s.y_bs; d.y_rs = s.y_rs; d.stride = s.stride; d.inv8 = 0.f;
+        d.yf = nullptr; d.yf_bs = d.yf_rs = 0; d.gm = d.bt = d.mn = d.rs = nullptr;
         d.Ho = (H + 2 - 3) / s.stride + 1; d.Wo = (W + 2 - 3) / s.stride + 1;
         if (!s.taps) return CXR_ERR_ARG;
     }
@@ -710,6 +769,11 @@ extern "C" int cxr_dwproj_bn_train_bwd_stats_bf16(const void* x, long x_bs, long
         const cxr_dwproj& s = projs[q < nproj ? q : 0];
         if (!s.gamma || !s.mean || !s.rstd || !s.dgamma || !s.dbeta || !s.coef) return CXR_ERR_ARG;
         f[q] = Dw3Coef{s.gamma, s.mean, s.rstd, s.dgamma, s.dbeta, s.coef, (float)((long)Bn * pl.p[q].Ho * pl.p[q].Wo)};
+        if (q < nproj && s.yf && s.beta) {                          // forward output handed over: c from it instead of the recomputed convolution
+            if ((s.yf_rs % 8) || (s.yf_bs % 8) || (((size_t)s.yf) % 16)) return CXR_ERR_ARG;
+            pl.p[q].yf = (const bf16_t*)s.yf; pl.p[q].yf_bs = s.yf_bs; pl.p[q].yf_rs = s.yf_rs;
+            pl.p[q].gm = s.gamma; pl.p[q].bt = s.beta; pl.p[q].mn = s.mean; pl.p[q].rs = s.rstd;
+        }
     }
     { static bool big = false; dw3_allow_big_lds(dw3_bwd_stats_kernel, big); }
     CXR_LAUNCH(dw3_bwd_stats_kernel, dim3(pl.grid), dim3(DW3_THREADS), pl.lds, stream, pl.g, pl.p[0], pl.p[1], pl.p[2], ws);

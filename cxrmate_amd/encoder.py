@@ -34,6 +34,7 @@ class CvtEncoderEngine:
         self._embed_buf = {}                        # persistent conv-as-GEMM weight re-layouts (their addresses feed the batched transpose table)
         self._bt, self._bt_sig, self._bt_keys = None, None, None
         self.fp8 = None                             # {"w": {key: (e4m3 weight, scale)}, "a": {key: scale}} after enable_fp8(); None = bf16
+        self._bwd_stats_from_y = os.environ.get("CXR_DW3_STATS_FROM_Y", "1") != "0"      # A/B switch: 0 = backward BatchNorm statistics recompute the convolution
         self._q8_fused = os.environ.get("CXR_FP8_FUSED", "1") != "0"      # A/B switch: 0 = separate bf16 -> e4m3 passes in front of the e4m3 GEMMs
         self._amax = None                           # calibration pass: {key: running max |activation|}
 
@@ -485,7 +486,8 @@ class CvtEncoderEngine:
             for n, b in zip(names, base):
                 cp = self._conv_prefix(s, l, n)
                 mean, rstd, _ = sv["bn"][n]
-                bp.append(dict(stride=b["stride"], taps=b["taps"], y=dcs[n], gamma=b["gamma"], mean=mean, rstd=rstd,
+                bp.append(dict(stride=b["stride"], taps=b["taps"], y=dcs[n], gamma=b["gamma"], mean=mean, rstd=rstd, beta=b["beta"],
+                               yf=sv[{"query": "qc", "key": "kc", "value": "vc"}[n]] if self._bwd_stats_from_y else None,
                                dgamma=g(cp + "normalization.weight"), dbeta=g(cp + "normalization.bias"), dw=g(cp + "convolution.weight").view(C, 9)))
             coefs = ops.dwproj_bn_train_bwd_stats(h1, H, W, tok0, bp)
             for b, cf in zip(bp, coefs):

@@ -681,7 +681,8 @@ class DwProj(_ct.Structure):
     _fields_ = [("stride", _ct.c_int), ("taps", _ct.c_void_p), ("shift", _ct.c_void_p), ("y", _ct.c_void_p), ("y_bs", _ct.c_long), ("y_rs", _ct.c_long),
                 ("w", _ct.c_void_p), ("gamma", _ct.c_void_p), ("beta", _ct.c_void_p), ("run_mean", _ct.c_void_p), ("run_var", _ct.c_void_p),
                 ("mean", _ct.c_void_p), ("rstd", _ct.c_void_p), ("taps_out", _ct.c_void_p), ("shift_out", _ct.c_void_p),
-                ("dgamma", _ct.c_void_p), ("dbeta", _ct.c_void_p), ("coef", _ct.c_void_p), ("GS", _ct.c_void_p), ("dw", _ct.c_void_p)]
+                ("dgamma", _ct.c_void_p), ("dbeta", _ct.c_void_p), ("coef", _ct.c_void_p), ("GS", _ct.c_void_p), ("dw", _ct.c_void_p),
+                ("yf", _ct.c_void_p), ("yf_bs", _ct.c_long), ("yf_rs", _ct.c_long)]
 
 
 _DWP_PTRS = ("taps", "shift", "w", "gamma", "beta", "run_mean", "run_var", "mean", "rstd", "taps_out", "shift_out", "dgamma", "dbeta", "coef", "GS", "dw")
@@ -713,6 +714,10 @@ def _dwproj_array(projs):
         if y is not None:
             assert y.dtype in (BF16, FP8) and y.stride(2) == 1
             d.y, d.y_bs, d.y_rs = _p(y), y.stride(0), y.stride(1)
+        yf = p.get("yf")
+        if yf is not None:
+            assert yf.dtype == BF16 and yf.stride(2) == 1
+            d.yf, d.yf_bs, d.yf_rs = _p(yf), yf.stride(0), yf.stride(1)
     return arr
 
 
@@ -766,7 +771,8 @@ def dwproj_bn_train_stats(x, H, W, tok0, eps, momentum, projs):
 
 
 def dwproj_bn_train_bwd_stats(x, H, W, tok0, projs):
-    """projs: [{stride, taps (raw), y = dL/d(BN out), gamma, mean, rstd, dgamma, dbeta (accumulated)}] -> coef list ([3,C] each: a, kb, kc)."""
+    """projs: [{stride, taps (raw), y = dL/d(BN out), gamma, mean, rstd, dgamma, dbeta (accumulated)[, yf = the projection's forward output, beta]}]
+    -> coef list ([3,C] each: a, kb, kc). With yf + beta the pass streams (dy, yf) instead of recomputing the convolution (see csrc/dwproj.hip)."""
     Bn, C = _dwproj_geo(x, H, W, tok0)
     coefs = torch.empty((len(projs), 3, C), device=x.device, dtype=torch.float32)
     arr = _dwproj_array([dict(p, coef=coefs[i]) for i, p in enumerate(projs)])

@@ -208,6 +208,9 @@ typedef struct cxr_dwproj {
     float* mean; float* rstd; float* taps_out; float* shift_out;
     float* dgamma; float* dbeta; float* coef;
     float* GS; float* dw;
+    const void* yf; long yf_bs, yf_rs;   /* bn_train_bwd_stats only, optional (with beta): the projection's FORWARD output [Bn, tok0 + Ho*Wo, C] bf16 -- the raw
+                                            convolution output is then recovered from it (c = mean + (yf - beta) / (gamma * rstd)) instead of recomputed,
+                                            per 64-channel slice wherever |gamma * rstd| >= 1e-3 */
 } cxr_dwproj;
 int cxr_dwproj_ws_floats(int Bn, int C, int H, int W);      /* returns the element count (> 0) or a negative error */
 int cxr_dwproj_apply_bf16(const void* x, long x_bs, long x_rs, int Bn, int C, int H, int W, int tok0, const cxr_dwproj* projs, int nproj,

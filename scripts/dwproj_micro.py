@@ -18,7 +18,7 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-for Bn, C, H, tok0 in [(32, 64, 96, 0), (32, 192, 48, 0), (32, 384, 24, 1)]:
+for Bn, C, H, tok0 in [(64, 64, 96, 0), (64, 192, 48, 0), (64, 384, 24, 1)]:
     W = H
     x = (torch.randn(Bn, tok0 + H * W, C, device="cuda") + 0.2).to(BF)
     strides = (1, 2, 2)
@@ -36,7 +36,8 @@ for Bn, C, H, tok0 in [(32, 64, 96, 0), (32, 192, 48, 0), (32, 384, 24, 1)]:
     xp = [dict(stride=s, taps=r, y=d) for s, r, d in zip(strides, raws, dys)]
     mb = x.numel() * 2 / 1e6
     t = dict(stats=timeit(lambda: ops.dwproj_bn_train_stats(x, H, W, tok0, 1e-5, 0.1, sp)), apply=timeit(lambda: ops.dwproj_apply(x, H, W, tok0, st)),
-             bwd_stats=timeit(lambda: ops.dwproj_bn_train_bwd_stats(x, H, W, tok0, bp)), dc_taps=timeit(lambda: ops.dwproj_dc_taps_(x, H, W, tok0, cp)),
+             bwd_stats=timeit(lambda: ops.dwproj_bn_train_bwd_stats(x, H, W, tok0, bp)),
+             bwd_stats_y=timeit(lambda: ops.dwproj_bn_train_bwd_stats(x, H, W, tok0, [dict(b_, beta=p_["b"], yf=y_) for b_, p_, y_ in zip(bp, par, ys)])), dc_taps=timeit(lambda: ops.dwproj_dc_taps_(x, H, W, tok0, cp)),
              dx=timeit(lambda: ops.dwproj_dx(xp, Bn, C, H, W, tok0)))
     # per-projection path of conv.hip (what the encoder used before)
     op = [dict(wt=r, w=p["w"], g=p["g"], b=p["b"], run_mean=p["rm"], run_var=p["rv"]) for r, p in zip(raws, par)]
@@ -54,6 +55,6 @@ for Bn, C, H, tok0 in [(32, 64, 96, 0), (32, 192, 48, 0), (32, 384, 24, 1)]:
             ops.tap_grad_accum(G2, dw[i])
         ops.dwconv_bn_bwd_dx([(d, r, s) for d, r, s in zip(dys, raws, strides)], Bn, C, H, W, tok0)
     t_old_f, t_old_b = timeit(old_fwd), timeit(old_bwd)
-    new_f, new_b = t["stats"] + t["apply"], t["bwd_stats"] + t["dc_taps"] + t["dx"]
+    new_f, new_b = t["stats"] + t["apply"], t["bwd_stats_y"] + t["dc_taps"] + t["dx"]
     print(f"Bn={Bn} C={C} H=W={H}  x={mb:.1f} MB | " + "  ".join(f"{k} {v:6.1f}us" for k, v in t.items()) +
           f" | fwd new {new_f:6.1f} old {t_old_f:6.1f}  bwd new {new_b:6.1f} old {t_old_b:6.1f} us")

@@ -1082,6 +1082,25 @@ def test_dwproj_fused_train(ops, Bn, C, H, W, tok0):
     dw = [torch.zeros(C, 9, device="cuda") for _ in par]
     coefs = ops.dwproj_bn_train_bwd_stats(x, H, W, tok0, [dict(stride=s_, taps=r, y=d, gamma=p["g"], mean=t["mean"], rstd=t["rstd"], dgamma=a, dbeta=b)
                                                           for s_, r, d, p, t, a, b in zip(strides, raws, dys, par, st, dg, db)])
+    # the same statistics from the projections' FORWARD outputs (yf + beta handed over: c recovered from the bf16 output instead of the recomputed
+    # convolution); one projection gets a channel with gamma = 0, whose 64-channel slice must fall back to the convolution
+    dg_y = [torch.zeros(C, device="cuda") for _ in par]
+    db_y = [torch.zeros(C, device="cuda") for _ in par]
+    coefs_y = ops.dwproj_bn_train_bwd_stats(x, H, W, tok0, [dict(stride=s_, taps=r, y=d, gamma=p["g"], beta=p["b"], mean=t["mean"], rstd=t["rstd"], dgamma=a, dbeta=b, yf=y)
+                                                            for s_, r, d, p, t, a, b, y in zip(strides, raws, dys, par, st, dg_y, db_y, ys)])
+    for i in range(len(par)):
+        close(dg_y[i], dg[i], rtol=5e-3, atol=5e-3, what=f"dgamma from the forward output {i}")
+        assert torch.equal(db_y[i], db[i]) or float((db_y[i] - db[i]).abs().max()) <= 1e-3 * float(db[i].abs().max())
+        close(coefs_y[i], coefs[i], rtol=5e-3, atol=5e-3, what=f"dc coefficients from the forward output {i}")
+    g0 = par[0]["g"].clone(); g0[5] = 0.0
+    y0 = ops.dwproj_apply(x, H, W, tok0, [dict(stride=strides[0], taps=ops.bn_fold(par[0]["w"], g0, par[0]["b"], st[0]["mean"], 1.0 / st[0]["rstd"] ** 2 - 1e-5, 1e-5)[0],
+                                               shift=ops.bn_fold(par[0]["w"], g0, par[0]["b"], st[0]["mean"], 1.0 / st[0]["rstd"] ** 2 - 1e-5, 1e-5)[1])])[0]
+    dz, dz_y = [torch.zeros(C, device="cuda") for _ in range(2)], [torch.zeros(C, device="cuda") for _ in range(2)]
+    base = dict(stride=strides[0], taps=raws[0], y=dys[0], gamma=g0, mean=st[0]["mean"], rstd=st[0]["rstd"])
+    cz = ops.dwproj_bn_train_bwd_stats(x, H, W, tok0, [dict(base, dgamma=dz[0], dbeta=dz[1])])
+    cz_y = ops.dwproj_bn_train_bwd_stats(x, H, W, tok0, [dict(base, beta=par[0]["b"], yf=y0, dgamma=dz_y[0], dbeta=dz_y[1])])
+    close(dz_y[0], dz[0], rtol=5e-3, atol=5e-3, what="dgamma with a zero gamma channel")
+    assert torch.equal(dz_y[0][:64], dz[0][:64]) and torch.equal(cz_y[0][:, :64], cz[0][:, :64])      # the slice with the zero gamma took the convolution path
     GS = ops.dwproj_dc_taps_(x, H, W, tok0, [dict(stride=s_, taps=r, y=d, coef=cf, dw=w_) for s_, r, d, cf, w_ in zip(strides, raws, dys, coefs, dw)], need_GS=True)
     for i, lv in enumerate(leaves):
         if tok0:
