@@ -443,9 +443,11 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_dc_taps_kernel(const Dw3Ge
 }
 
 // ------------------------------------------------------------------------------------------------------------------ input gradient
+// w0: the taps of projection 0 in REGISTERS when it has stride 1 (the query projection: 9 of the ~13.5 taps a pixel gathers) -- from LDS each tap costs two
+// ds_read_b128 per pixel on top of the data read; the stride-2 projections' taps (1-4 per pixel and projection) stay in LDS
 template <int py, int px>
 __device__ __forceinline__ void dw3_dx_class(const Dw3Geo& g, const Dw3P& p0, const Dw3P& p1, const Dw3P& p2, const uint4* dw3_tile, const float (*wl)[12][64],
-                                             int toff1, int toff2, int nrow, int ch, bf16_t* drow) {
+                                             int toff1, int toff2, int nrow, int ch, bf16_t* drow, const float (&w0)[9][8], const bool w0_regs) {
     const int wave = threadIdx.x >> 6, lpl = (threadIdx.x & 63) >> 3;
     const int nr = (nrow - py + 1) >> 1, nc = (g.W - px + 1) >> 1;
     const int n = nr * nc;
@@ -455,8 +457,20 @@ __device__ __forceinline__ void dw3_dx_class(const Dw3Geo& g, const Dw3P& p0, co
         const int ry = idx / nc, rx = idx - ry * nc;
         const int iyl = 2 * ry + py, ix = 2 * rx + px;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (w0_regs) {                                              // projection 0, stride 1, taps in registers (block-uniform)
+            const int cols8 = (g.W + 2) * 8;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    float f[8];
+                    unpack8(dw3_tile[(iyl + 2 - ky) * cols8 + (ix + 2 - kx) * 8 + ch], f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(f[j], w0[ky * 3 + kx][j], acc[j]);
+                }
+        }
 #pragma unroll 1
-        for (int q = 0; q < g.nproj; ++q) {
+        for (int q = w0_regs ? 1 : 0; q < g.nproj; ++q) {
             const int stride = q == 0 ? p0.stride : (q == 1 ? p1.stride : p2.stride);
             const float* wq = &wl[q][0][ch * 8];
             const uint4* tile = dw3_tile + (q == 0 ? 0 : (q == 1 ? toff1 : toff2));
@@ -533,10 +547,14 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_dx_kernel(const Dw3Geo g, 
     // compiled in (no per-lane predication: 2.25 taps per pixel on average instead of 9 masked ones); every wave serves all four classes, taking
     // every 4th group of 8 pixels with a class-dependent rotation so the waves stay balanced.
     bf16_t* drow = db + (long)(g.tok0 + k.band_i * g.band * g.W) * g.x_rs;
-    dw3_dx_class<0, 0>(g, p0, p1, p2, dw3_tile, wl, toff1, toff2, nrow, k.ch, drow);
-    dw3_dx_class<0, 1>(g, p0, p1, p2, dw3_tile, wl, toff1, toff2, nrow, k.ch, drow);
-    dw3_dx_class<1, 0>(g, p0, p1, p2, dw3_tile, wl, toff1, toff2, nrow, k.ch, drow);
-    dw3_dx_class<1, 1>(g, p0, p1, p2, dw3_tile, wl, toff1, toff2, nrow, k.ch, drow);
+    float w0[9][8];
+    const bool w0_regs = p0.stride == 1;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dw3_load8(&wl[0][t][k.ch * 8], w0[t]);
+    dw3_dx_class<0, 0>(g, p0, p1, p2, dw3_tile, wl, toff1, toff2, nrow, k.ch, drow, w0, w0_regs);
+    dw3_dx_class<0, 1>(g, p0, p1, p2, dw3_tile, wl, toff1, toff2, nrow, k.ch, drow, w0, w0_regs);
+    dw3_dx_class<1, 0>(g, p0, p1, p2, dw3_tile, wl, toff1, toff2, nrow, k.ch, drow, w0, w0_regs);
+    dw3_dx_class<1, 1>(g, p0, p1, p2, dw3_tile, wl, toff1, toff2, nrow, k.ch, drow, w0, w0_regs);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ row reductions
