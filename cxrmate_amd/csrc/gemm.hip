@@ -991,7 +991,8 @@ static TnPlan tn_plan(int R, int I, int J) {
     // atomic traffic (one 64 KB fp32 tile per split). Measured on the training step: 448 -> 32.5 ms, 320 -> 31.7, 224 -> 31.3, 176 -> 31.0,
     // 128 -> 31.5 (same box); alone, a single launch is up to 1.4x faster at 320. CXR_TN_WGS overrides.
     if (target_wgs < 0) { const char* e = getenv("CXR_TN_WGS"); target_wgs = e ? atoi(e) : 176; if (target_wgs < 1) target_wgs = 176; }
-    if (target_big < 0) { const char* e = getenv("CXR_TN2_WGS"); target_big = e ? atoi(e) : 128; if (target_big < 1) target_big = 128; }
+    if (target_big < 0) { const char* e = getenv("CXR_TN2_WGS"); target_big = e ? atoi(e) : 96; if (target_big < 1) target_big = 96; }
+    // (gemm_tn2_kernel aims for 96 workgroups: same-box alternation on the training step, 80 / 96 / 112 / 128 / 160 -> 42.2 / 41.85 / 42.3 / 42.4 / 42.8 ms)
     // 256 x 256 blocks (gemm_tn2_kernel) when both dimensions exceed 128 AND a workgroup gets a long enough token run: its prologue and its
     // 256-KB partial tile only pay off from ~24 steps of 32 tokens per workgroup (scripts/tn_micro.py: 8192 x 768 x 768 is 1.35x SLOWER with it,
     // 36864 x 768 x 768 1.5x faster)
