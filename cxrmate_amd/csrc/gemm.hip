@@ -998,7 +998,9 @@ static TnPlan tn_plan(int R, int I, int J) {
     // 36864 x 768 x 768 1.5x faster)
     p.blocks_j = cdiv(J, 256);
     const int blocks = cdiv(I, 256) * p.blocks_j;
-    p.big = tn2 && I > 128 && J > 128 && (long)blocks * nrt >= 4096;
+    static long min_steps = -1;                            // CXR_TN2_MIN: blocks x 32-token steps from which the 256 x 256 blocks are used
+    if (min_steps < 0) { const char* e = getenv("CXR_TN2_MIN"); min_steps = e ? atol(e) : 4096; }
+    p.big = tn2 && I > 128 && J > 128 && (long)blocks * nrt >= min_steps;
     p.wgs_per_split = p.big ? blocks : p.tiles_i * p.tiles_j;
     int splits = cdiv(p.big ? target_big : target_wgs, p.wgs_per_split);
     const int max_splits = nrt / 8 > 0 ? nrt / 8 : 1;      // at least 256 tokens per split
