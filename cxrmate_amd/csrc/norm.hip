@@ -3,6 +3,7 @@
 // HBM-bound: 16-byte vector loads, a row is owned by a group of LPR lanes of one wave (wave-shuffle reductions),
 // several rows per wave when C is small (C=64 -> 8 rows per wave) so that every lane issues a full 16-byte access.
 #include "common.h"
+#include <stdlib.h>
 
 template <int C, bool LN_TRI = false> struct LNCfg {
     static constexpr int CH = C / 8;                                    // 16-byte chunks per row
@@ -307,7 +308,9 @@ extern "C" int cxr_layernorm_q8_bf16(const void* x, long ldx, const float* gamma
 // workspace: fp32 [cxr_layernorm_bwd_grid(rows, C)][2][C] (may be null when dgamma/dbeta are not wanted)
 extern "C" int cxr_layernorm_bwd_grid(long rows, int C) {
     int grid = ln_grid(rows, C, C == 192 ? 4 : (C == 768 ? 1 : 2), false);
-    return grid < 512 ? grid : 512;
+    static int cap = -1;                                   // CXR_LN_BWD_GRID: workgroup cap of the grid-stride loop (lab switch)
+    if (cap < 0) { const char* e = getenv("CXR_LN_BWD_GRID"); cap = e ? atoi(e) : 512; if (cap < 64) cap = 512; }
+    return grid < cap ? grid : cap;
 }
 
 extern "C" int cxr_layernorm_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, const float* gamma, const float* stats,

@@ -17,7 +17,7 @@ def timeit(fn, n=30):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-for rows, C in [(18464, 384), (8192, 768), (73728, 192), (294912, 64)]:
+for rows, C in [(36928, 384), (8192, 768), (147456, 192), (589824, 64)]:
     nb = 12
     xs = [torch.randn(rows, C, device="cuda").to(BF) for _ in range(nb)]
     dys = [torch.randn(rows, C, device="cuda").to(BF) for _ in range(nb)]
