@@ -420,10 +420,11 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
         enc_mask = encoder_outputs.get("attention_mask") if isinstance(encoder_outputs, dict) else None
         if self.kind == "single":
             enc_mask = None                                                  # modelling_single.py:176
-        if past_key_values is not None:
-            raise NotImplementedError("external past_key_values are not part of the accelerated path (generate() owns the KV cache)")
         if (decoder_input_ids is None) == (decoder_inputs_embeds is None):
             raise ValueError("You have to specify exactly one of decoder_input_ids or decoder_inputs_embeds")
+        if past_key_values is not None or use_cache:
+            return self._forward_cached(decoder_input_ids, enc, enc_mask, decoder_attention_mask, kwargs_decoder, past_key_values, labels,
+                                        decoder_inputs_embeds, return_dict)
         logits = self._decode_tf(decoder_input_ids, enc, enc_mask, decoder_attention_mask, kwargs_decoder.get("token_type_ids"),
                                  kwargs_decoder.get("position_ids"), embeds=decoder_inputs_embeds)
         loss = None
@@ -435,6 +436,31 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
         if return_dict is False:
             return out.to_tuple()
         return out
+
+    def _forward_cached(self, ids, enc, enc_mask, attn_mask, kwargs_decoder, past, labels, embeds, return_dict):
+        """forward(..., use_cache=True[, past_key_values=]) for callers that run their own decoding loop (transformers' generate does exactly this through
+        prepare_inputs_for_generation, modelling_longitudinal.py:251-295): `past_key_values` is the engine's own KV cache object (opaque: hand back what the
+        previous call returned), decoder_input_ids holds the NEW tokens only (the whole prompt in the first call), decoder_attention_mask the full mask
+        [B, past + new]. Gradient-free (the cached kernels have no backward) and -- unlike the library -- only the LAST position's logits come back
+        ([B, 1, V]): every decoding loop reads `logits[:, -1]`."""
+        if labels is not None or embeds is not None:
+            raise NotImplementedError("use_cache / past_key_values: decoder_input_ids only, no labels (the cached path is the decoding path)")
+        if torch.is_grad_enabled() and any(p.requires_grad for _, p in self._grad_params("decoder.")):
+            raise RuntimeError("use_cache / past_key_values needs torch.no_grad(): the cached decode kernels have no backward")
+        dev = self.device
+        ids = self._i64(ids, dev)
+        B, Tn = ids.shape
+        enc16 = (enc if enc.dtype == torch.bfloat16 else ops.cast_to_bf16(enc.float().contiguous())).contiguous()
+        cache = past
+        if cache is None:
+            cache = self._dec.new_cache(B, int(self.config.decoder.max_position_embeddings), dev)
+        if cache.len + Tn > cache.Tmax:
+            raise ValueError(f"cache holds {cache.len} positions, {Tn} more exceed max_position_embeddings = {cache.Tmax}")
+        seed = self.next_dropout_seed() if self.training else None
+        logits = self._dec.decode(cache, ids, enc16, self._u8(enc_mask, dev), self._u8(attn_mask, dev), self._i64(kwargs_decoder.get("token_type_ids"), dev),
+                                  self._i64(kwargs_decoder.get("position_ids"), dev), train=self.training, seed=seed)
+        out = ModelOutput(loss=None, logits=logits.view(B, 1, -1), past_key_values=cache, encoder_last_hidden_state=enc)
+        return out.to_tuple() if return_dict is False else out
 
     @staticmethod
     def _u8(mask, device):

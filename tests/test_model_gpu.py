@@ -955,6 +955,22 @@ def test_single_image_model_generate_matches_the_reference(M):
             lg = m(encoder_outputs=eo, decoder_input_ids=ids, decoder_token_type_ids=m.token_ids_to_token_type_ids(ids, [gu.SEP])).logits[:, -1]
             ids = torch.cat([ids, lg.argmax(-1, keepdim=True)], 1)
     assert torch.equal(ids.cpu(), ref)
+    # the same loop with the engine's KV cache handed back and forth through forward(use_cache=True, past_key_values=...): a caller that owns its decoding
+    # loop (what transformers' generate does through prepare_inputs_for_generation) -- new tokens only, last-position logits [B, 1, V]
+    ids, past = torch.full((3, 1), gu.BOS, dtype=torch.int64, device="cuda"), None
+    with torch.no_grad():
+        for _ in range(L - 1):
+            tt = m.token_ids_to_token_type_ids(ids, [gu.SEP])
+            fed, tt_new = (ids, tt) if past is None else (ids[:, -1:], tt[:, -1:])
+            out = m(encoder_outputs=eo, decoder_input_ids=fed, decoder_token_type_ids=tt_new, past_key_values=past, use_cache=True)
+            assert out.logits.shape[:2] == (3, 1)
+            past = out.past_key_values
+            ids = torch.cat([ids, out.logits[:, -1].argmax(-1, keepdim=True)], 1)
+    assert past.len == L - 1 and torch.equal(ids.cpu(), ref)
+    with pytest.raises(RuntimeError):                            # the cached kernels have no backward
+        for p_ in m.decoder.parameters():
+            p_.requires_grad_(True)
+        m(encoder_outputs=eo, decoder_input_ids=ids, decoder_token_type_ids=m.token_ids_to_token_type_ids(ids, [gu.SEP]), use_cache=True)
     # beam-4: device-side search and the host loop, both equal to the reference's best hypothesis and score on every row
     rb, rs = torch.from_numpy(g["beam4_all"][:, 0]), g["beam4_all_scores"]
     gap = rs[:, 0] - rs[:, 1]
