@@ -733,8 +733,10 @@ class BertEngine:
             # q / k / v in one launch; k and v land in their KV-cache rows
             ops.dec_gemm(cur, B, D, [prob((l, "query"), D, q, lq), prob((l, "key"), D, cache.k[l][:, past, :], lk),
                                      prob((l, "value"), D, cache.v[l][:, past, :])], stats=cur_st, eps=eps, **lora_kw)
+            # more than 256 cached tokens (configs[4]: a 128-token prompt): the workgroup loops over 256-key passes instead of splitting the range over
+            # workgroups + a merge launch (4.8 us per layer; the looping pass costs ~2)
             ctx = ops.attention_decode(q, cache.k[l][:, :past + 1, :], cache.v[l][:, :past + 1, :], nh, scale, kpm=attn_mask_full,
-                                       drop=(pa, seed, _site(l, 0), past), wg_keys=256, out_dal=True)
+                                       drop=(pa, seed, _site(l, 0), past), wg_keys=256 if past + 1 <= 256 else -256, out_dal=True)
             (a1,), st1 = ops.dec_gemm(ctx, B, D, [prob((l, "attn_out"), D)], out_stats=True, drop=drop(_site(l, 1)), **res_kw())
             cur, cur_st, cur_ln = a1, st1, lp + "attention.output.LayerNorm"
             q2 = torch.empty((B, D), dtype=BF16, device=dev)
