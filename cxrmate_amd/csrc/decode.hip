@@ -950,7 +950,11 @@ extern "C" int cxr_pack_cross_kv_bf16(const void* K, const void* V, long kv_bs, 
     return CXR_OK;
 }
 
-template <int MAXB>
+// PHASED (MAXB = 5: up to 60 key blocks = 1920 keys in ONE workgroup, e.g. the 1728 keys of a 3-image study): the V fragments are requested after the
+// scores are computed instead of up front -- K and V fragments of 5 blocks per wave do not fit the 170 registers of a 12-wave workgroup together. The
+// V round trip then sits behind the score phase of the same wave, but other workgroups of the launch are in their K phase meanwhile (the launch as a
+// whole stays at the HBM rate), and the split + partial states + merge launch of the > 36-block case is gone.
+template <int MAXB, bool PHASED = false>
 __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a) {
     __shared__ float wmax[12][16], wsum[12][16], wmax_all[16];
     __shared__ float wo[12][4][64];                  // per-wave numerators of up to 4 query rows... (G <= 4 here; see the entry point)
@@ -974,8 +978,10 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) kf[i][t][ks] = __builtin_bit_cast(bf16x8_t, nt_load16(kp + ((long)blk * 4 + t * 2 + ks) * 512));
+        if (!PHASED) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) vf[i][dt] = __builtin_bit_cast(bf16x8_t, nt_load16(vp + ((long)blk * 4 + dt) * 512));
+            for (int dt = 0; dt < 4; ++dt) vf[i][dt] = __builtin_bit_cast(bf16x8_t, nt_load16(vp + ((long)blk * 4 + dt) * 512));
+        }
     }
     // queries (B operand: column qi = query row b + qi * Bkv; columns >= G are zero), mask words, seed
     const int qrow = b + (qi < a.G ? qi : 0) * a.Bkv;
@@ -1014,6 +1020,14 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
                 mx = fmaxf(mx, v);
             }
             sc[i][t] = acc;
+        }
+    }
+    if (PHASED) {                                                                         // the K fragments are dead: their registers take the V fragments
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) {
+            int blk = wave + 12 * i; blk = blk < nblk ? blk : nblk - 1;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) vf[i][dt] = __builtin_bit_cast(bf16x8_t, nt_load16(vp + ((long)blk * 4 + dt) * 512));
         }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -1174,7 +1188,7 @@ extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V,
 extern "C" int cxr_attn_cross_mfma_bf16(const void* Q, const void* Kp, const void* Vp, void* O, const unsigned int* kpm_bits, long q_bs, long o_bs,
                                         long mb_words, int B, int H, int Tk, float scale, int kv_share, float drop_p, const unsigned int* drop_seed,
                                         unsigned int drop_site, int drop_t, int o_dal, float* ws, hipStream_t stream) {
-    if (B <= 0 || H <= 0 || Tk <= 0 || (Tk % 32) || Tk > 8 * 1152 || (Tk > 1152 && !ws) || kv_share < 1 || kv_share > 4 || (B % kv_share) || (q_bs % 8) || ((uintptr_t)Kp % 16) ||
+    if (B <= 0 || H <= 0 || Tk <= 0 || (Tk % 32) || Tk > 8 * 1152 || (Tk > 1920 && !ws) || kv_share < 1 || kv_share > 4 || (B % kv_share) || (q_bs % 8) || ((uintptr_t)Kp % 16) ||
         ((uintptr_t)Vp % 16) || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed) || (o_dal && B > 64))
         return CXR_ERR_ARG;
     AttnXArgs a;
@@ -1189,6 +1203,14 @@ extern "C" int cxr_attn_cross_mfma_bf16(const void* Q, const void* Kp, const voi
     // (B*H*nsplit*66 floats) -> attn_decode_merge_kernel
     const int nblk_all = Tk / 32;
     a.nsplit = cdiv(nblk_all, 36); a.bps = cdiv(nblk_all, a.nsplit); a.ws = ws;
+    static int phased = -1;                                       // CXR_CROSS_PHASED=0: 37..60 blocks split + merge as before (A/B)
+    if (phased < 0) { const char* e = getenv("CXR_CROSS_PHASED"); phased = (e && e[0] == '0') ? 0 : 1; }
+    if (phased && nblk_all > 36 && nblk_all <= 60) {              // one workgroup per (study, head), K phase then V phase: no partial states, no merge launch
+        a.nsplit = 1; a.bps = nblk_all;
+        CXR_LAUNCH((attn_cross_mfma_kernel<5, true>), dim3(a.Bkv * H), dim3(768), 0, stream, a);
+        CXR_LAUNCH_CHECK();
+        return CXR_OK;
+    }
     const dim3 grid(a.Bkv * H * a.nsplit);
     if (a.bps <= 12) CXR_LAUNCH(attn_cross_mfma_kernel<1>, grid, dim3(768), 0, stream, a);
     else if (a.bps <= 24) CXR_LAUNCH(attn_cross_mfma_kernel<2>, grid, dim3(768), 0, stream, a);
