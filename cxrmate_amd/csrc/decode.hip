@@ -1147,6 +1147,13 @@ extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V,
     if (wg_keys != 256 && wg_keys != 288 && wg_keys != 576 && wg_keys != 1152) return CXR_ERR_ARG;
     int nsplit = 1, chunk = Tk;
     if (ws && Tk > wg_keys && cdiv(Tk, wg_keys) <= 8 && !no_split) { nsplit = cdiv(Tk, wg_keys); chunk = wg_keys; }
+    // a workgroup that LOOPS over passes keeps its running softmax state next to the 2 * KU loads in flight: the widest geometry of each sharing
+    // degree (1152 keys = 1024 threads = 128 registers; 576 keys with 4 rows per stream) then spills 200-456 bytes per lane -- looping launches
+    // step down to the next geometry (576 / 288 keys per pass), which fits
+    if (chunk > wg_keys) {
+        if (kv_share == 4 && wg_keys == 576) wg_keys = 288;
+        else if (kv_share != 4 && wg_keys == 1152) wg_keys = 576;
+    }
     const bool loop = chunk > wg_keys;
     AttnDecArgs a;
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.O = (bf16_t*)O;
@@ -1161,7 +1168,8 @@ extern "C" int cxr_attn_decode_bf16(const void* Q, const void* K, const void* V,
     const int mask = !kpm ? 0 : (kpm_bits ? 3 : ((wg_keys == 256 && (kpm_bs % 8) == 0 && ((uintptr_t)kpm % 8) == 0 && (nsplit == 1 || (chunk % 8) == 0)) ? 2 : 1));
     const dim3 grid(Bkv * H * nsplit);
 #define ATTN_DEC(G_, KU_, NG_, MK_, L_) CXR_LAUNCH((attn_decode_kernel<G_, KU_, NG_, MK_, L_>), grid, dim3(NG_ * 8), 0, stream, a)
-#define ATTN_DEC_L(G_, KU_, NG_, MK_) do { if (loop) ATTN_DEC(G_, KU_, NG_, MK_, true); else ATTN_DEC(G_, KU_, NG_, MK_, false); } while (0)
+#define ATTN_DEC_L(G_, KU_, NG_, MK_) do { if (loop && !((NG_) == 128 || ((G_) == 4 && (NG_) == 64))) ATTN_DEC(G_, KU_, (((NG_) == 128 || ((G_) == 4 && (NG_) == 64)) ? 32 : (NG_)), MK_, true); \
+                                           else ATTN_DEC(G_, KU_, NG_, MK_, false); } while (0)      /* (the widest geometries never loop: see above) */
 #define ATTN_DEC_M(G_, KU_, NG_) do { if (mask == 0) ATTN_DEC_L(G_, KU_, NG_, 0); else if (mask == 1) ATTN_DEC_L(G_, KU_, NG_, 1);          \
                                       else if (mask == 3) ATTN_DEC_L(G_, KU_, NG_, 3); else ATTN_DEC_L(G_, 8, 32, 2); } while (0)
 #define ATTN_DEC_G(KU_, NG_) do { if (kv_share == 2) ATTN_DEC_M(2, KU_, NG_); else ATTN_DEC_M(1, KU_, NG_); } while (0)

@@ -403,14 +403,15 @@ extern "C" int cxr_dec_gemm_bf16(const cxr_dec_gemm_desc* d, hipStream_t stream)
     if (g.K != 768 && g.K != 3072) return CXR_ERR_ARG;            // instantiated reductions: BERT-base hidden / intermediate size
     if (g.K == 3072 && (any_lora || nc != 1)) return CXR_ERR_ARG;
     const bool fits = (long)cdiv(nmax, 16 * nc) * d->nprob * mtl <= 256;                          // one workgroup per CU after the split
-    const int mt = (d->mt_hint > 0 ? d->mt_hint == 1 : (fits && mtl > 1)) ? 1 : mtl;               // tiles per workgroup
+    int mt = (d->mt_hint > 0 ? d->mt_hint == 1 : (fits && mtl > 1)) ? 1 : mtl;                     // tiles per workgroup
+    if (g.K == 3072 && mt == 4) mt = 2;                            // (16 waves x 4 row tiles x 6 k-steps need 96 registers of A fragments alone: 128-register cap, spills)
     const dim3 grid(cdiv(nmax, 16 * nc), d->nprob, mtl / mt);
 #define DG(MT_, NW_, KB_, NC_, L_) CXR_LAUNCH((dec_gemm_kernel<MT_, NW_, KB_, NC_, L_>), grid, dim3(NW_ * 64), 0, stream, g)
-#define DGM(MT_) do {                                                                                              \
-        if (g.K == 3072) DG(MT_, 16, 6, 1, false);                                                                  \
+#define DGM(MT_, MT3072_) do {                                                                                     \
+        if (g.K == 3072) DG(MT3072_, 16, 6, 1, false);                                                              \
         else if (any_lora) DG(MT_, 8, 3, 1, true); else if (nc == 4) DG(MT_, 8, 3, 4, false); else DG(MT_, 8, 3, 1, false); \
     } while (0)
-    if (mt == 1) DGM(1); else if (mt == 2) DGM(2); else DGM(4);
+    if (mt == 1) DGM(1, 1); else if (mt == 2) DGM(2, 2); else DGM(4, 2);
 #undef DGM
 #undef DG
     CXR_LAUNCH_CHECK();
