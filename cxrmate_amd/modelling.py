@@ -13,6 +13,7 @@ state-dict key names. There is no PyTorch fallback for the math: every op goes t
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Optional
 
@@ -152,12 +153,18 @@ class _EncodeFn(torch.autograd.Function):
     def backward(ctx, dfeats):
         from .training import wgrad_overlap
         model = ctx.model
-        if not model.direct_grads:
+        bound = model._grads_bindable("encoder.")
+        if not model.direct_grads and bound != "accumulate":
             model.zero_grads_prefix("encoder.")
         with wgrad_overlap():                                              # weight-gradient GEMMs beside the dX chain, as in the fused step
             model._enc.backward(ctx.saved, dfeats.contiguous())
-            ops.wgrad_join()                                               # ... complete before autograd reads them
+            if not bound:
+                ops.wgrad_join()                                           # ... complete before autograd reads them
+            else:
+                model._queue_backward_join()
         ctx.saved = None
+        if bound:
+            return (None, None) + model._bind_grads("encoder.", ctx.nparams)
         return (None, None) + model._collect_grads("encoder.", ctx.nparams)
 
 
@@ -173,7 +180,8 @@ class _DecodeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         model = ctx.model
-        if not model.direct_grads:
+        bound = model._grads_bindable("decoder.")
+        if not model.direct_grads and bound != "accumulate":
             model.zero_grads_prefix("decoder.")
         B, T, V = dlogits.shape
         d16 = dlogits.reshape(B * T, V)
@@ -181,11 +189,16 @@ class _DecodeFn(torch.autograd.Function):
         from .training import wgrad_overlap
         with wgrad_overlap():
             denc = model._dec.backward(ctx.saved, dlogits=d16, need_denc=ctx.need_denc)
-            ops.wgrad_join()
+            if not bound:
+                ops.wgrad_join()
+            else:
+                model._queue_backward_join()                               # the decoder's weight gradients keep running under the encoder backward
         d_emb = None
         if ctx.embeds_like is not None:
             d_emb = ctx.saved["d_embeds"].view(ctx.embeds_like.shape).to(ctx.embeds_like.dtype)
         ctx.saved = None
+        if bound:
+            return (None, denc, None, None, None, None, None, None, d_emb) + model._bind_grads("decoder.", ctx.nparams)
         return (None, denc, None, None, None, None, None, None, d_emb) + model._collect_grads("decoder.", ctx.nparams)
 
 
@@ -356,6 +369,51 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
 
     def _grad_params(self, prefix):
         return [(k, p) for k, p in self._params.items() if k.startswith(prefix) and p.requires_grad]
+
+    def _grads_bindable(self, prefix):
+        """The autograd bridges may hand the gradients of the parameters under `prefix` over by BINDING `p.grad` to views of the flat gradient buffer
+        (no clone of the range, no AccumulateGrad copy per parameter, and the weight-gradient stream is joined once, when the whole backward pass is
+        over, instead of at the end of every bridge). Two states allow it: every trainable parameter's .grad is None -- what `optimizer.zero_grad()`
+        (set_to_none=True: torch's and Lightning's default) leaves behind: the range is zeroed and filled -- or every .grad already IS such a view
+        (zero_grad(set_to_none=False), or gradient accumulation over several backward calls): the engine adds into the buffer, which is what autograd
+        would do. Returns 'fresh' / 'accumulate' / None. In any other state the gradients go through autograd as before, after .grad tensors that
+        alias the flat buffer have been detached from it (the bridge is about to overwrite that buffer)."""
+        if self.direct_grads or os.environ.get("CXR_BIND_GRADS", "1") == "0":
+            return None
+        ps = self._grad_params(prefix)
+        if not ps:
+            return None
+        if all(p.grad is None for _, p in ps):
+            return "fresh"
+        lo, hi = self.gflat.data_ptr(), self.gflat.data_ptr() + self.gflat.numel() * 4
+        own = [p.grad is not None and lo <= p.grad.data_ptr() < hi for _, p in ps]
+        if all(own):
+            return "accumulate"
+        for (_, p), o in zip(ps, own):
+            if o:
+                p.grad = p.grad.clone()
+        return None
+
+    def _bind_grads(self, prefix, n):
+        for k, p in self._grad_params(prefix):
+            o = self._offsets[k]
+            p.grad = self.gflat[o: o + self._numel(k)].view(p.shape)
+        return (None,) * n
+
+    def _queue_backward_join(self):
+        """One join of the weight-gradient stream at the end of the running backward pass (autograd final callback)."""
+        if self.__dict__.get("_join_queued"):
+            return
+        from .training import wgrad_overlap
+        side, cur = wgrad_overlap._stream, torch.cuda.current_stream(self.device)
+        self.__dict__["_join_queued"] = True
+
+        def done():
+            self.__dict__["_join_queued"] = False
+            with torch.cuda.stream(cur):
+                ops.wgrad_join(side)
+
+        torch.autograd.Variable._execution_engine.queue_callback(done)
 
     def _collect_grads(self, prefix, n):
         """Gradients handed to autograd for the trainable parameters under `prefix`: views of ONE copy of the flat gradient range they span

@@ -263,9 +263,11 @@ class _side_launch:
         return False
 
 
-def wgrad_join():
-    if WGRAD_STREAM is not None:
-        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+def wgrad_join(stream=None):
+    """stream: the weight-gradient stream to join when called outside the wgrad_overlap context that launched on it (deferred joins)"""
+    stream = WGRAD_STREAM if stream is None else stream
+    if stream is not None:
+        torch.cuda.current_stream().wait_stream(stream)
     _side_launch._pending.clear()
     gemm_exclusive(True)                                   # nothing runs beside the main stream any more
 

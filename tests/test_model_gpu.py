@@ -158,6 +158,58 @@ def test_torch_optimizer_updates_reach_the_kernels(M):
     assert torch.equal(m.w16(key), m.f32(key).to(torch.bfloat16))                      # shadow == master after the refresh
 
 
+def test_autograd_bridges_bind_gradients_with_torch_semantics(M, monkeypatch):
+    """The bridges hand parameter gradients over as views of the flat gradient buffer when nothing foreign has to be accumulated into
+    (modelling._grads_bindable). Against the plain path (CXR_BIND_GRADS=0: gradients returned through autograd) on the same eval-mode model:
+    one backward after zero_grad(set_to_none=True); two backward calls without zeroing (accumulation: 2x); zero_grad(set_to_none=False) in between;
+    and foreign .grad tensors (the aliasing ones are detached first, autograd accumulates)."""
+    g, cfg, sd, x, inp, lab, am, tt = gu.tf_single_case()
+    ttd = None
+
+    def grads(bind, script):
+        monkeypatch.setenv("CXR_BIND_GRADS", "1" if bind else "0")
+        m = M.SingleCXREncoderDecoderModel(cfg, seed=None)
+        m.load_state_dict(sd)
+        kw = dict(pixel_values=x.cuda(), decoder_input_ids=inp.cuda(), decoder_attention_mask=am.cuda(),
+                  decoder_token_type_ids=m.token_ids_to_token_type_ids(inp, [gu.SEP]), return_dict=True)
+        ps = list(m.parameters())
+
+        def backward():
+            torch.nn.functional.cross_entropy(m(**kw).logits.permute(0, 2, 1), lab.cuda(), ignore_index=gu.PAD).backward()
+
+        script(backward, ps)
+        torch.cuda.synchronize()
+        return [p.grad.detach().float().clone() for p in ps]
+
+    def once(backward, ps):
+        backward()
+
+    def twice(backward, ps):
+        backward(); backward()
+
+    def zero_in_place(backward, ps):
+        backward()
+        for p in ps:
+            p.grad.zero_()                                       # optimizer.zero_grad(set_to_none=False)
+        backward()
+
+    def foreign(backward, ps):
+        backward()
+        for i, p in enumerate(ps):
+            if i % 2:
+                p.grad = torch.ones_like(p)                      # somebody else's tensors in half of the slots
+        backward()
+
+    ref1 = grads(False, once)
+    for name, script, scale in (("fresh", once, 1.0), ("accumulate", twice, 2.0), ("zeroed in place", zero_in_place, 1.0)):
+        got = grads(True, script)
+        for a, b in zip(got, ref1):
+            assert torch.allclose(a, scale * b, rtol=2e-3, atol=2e-5 * max(1.0, float(b.abs().max()))), name
+    got, ref = grads(True, foreign), grads(False, foreign)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-5 * max(1.0, float(b.abs().max()))), ("foreign", i)
+
+
 def test_graphed_tf_step_leaves_no_stale_weight_copies(M):
     """After K replays of GraphedTFStep every weight-derived buffer the engines cache per weight version (BN folds, tap re-layouts, LoRA merges,
     transposed copies, packed decode weights, decode sessions) must describe the CURRENT weights: forward and generate of the stepped model ==
