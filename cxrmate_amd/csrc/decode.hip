@@ -908,6 +908,9 @@ struct AttnXArgs {
     float* ws;                                      // nsplit > 1: partial states (max, denominator, numerator[64]) per (row, head, split) for attn_decode_merge_kernel
     int H, Tk, Bkv, G, drop_t, o_mt, nsplit, bps;   // bps = key blocks per split (<= 36)
     float scale_log2e, drop_inv; uint32_t drop_site, drop_thr16, has_mask;
+    // QPROJ: the query projection q = LN(x) Wq^T + b computed by the workgroup itself (x raw in the decode activation layout, LayerNorm folded into the
+    // packed weights, row statistics from the producer's partials: the operands of cxr_dec_gemm_bf16) -- Q is unused then
+    const bf16_t* xA; const float* xstats; const bf16_t* qWp; const float2* qbc; int x_mtl, x_M, x_tiles; float x_eps;
 };
 
 // Fragment-ordered copies of a study's cross-attention K and V (written once at prefill, like the packed decode weights): block = 32 keys of one
@@ -954,8 +957,18 @@ extern "C" int cxr_pack_cross_kv_bf16(const void* K, const void* V, long kv_bs, 
 // scores are computed instead of up front -- K and V fragments of 5 blocks per wave do not fit the 170 registers of a 12-wave workgroup together. The
 // V round trip then sits behind the score phase of the same wave, but other workgroups of the launch are in their K phase meanwhile (the launch as a
 // whole stays at the HBM rate), and the split + partial states + merge launch of the > 36-block case is gone.
-template <int MAXB, bool PHASED = false>
+// QPROJ (G <= 2 query rows per study, K = 768): the cross-attention QUERY projection of the cached step runs inside this kernel. Every (study, head)
+// workgroup needs only its head's 64 query columns of its G rows: 12 waves split K (2 k-steps of 32 each) over the 4 x 16 output columns, with the
+// packed weights as the A operand and the activation fragments as the B operand (both are laid out as either), partial sums meet in LDS, the folded
+// LayerNorm is applied as in dec_gemm_kernel (Chan combination of the producer's 48 partial statistics by one wave per row). The weight fragments are
+// requested together with the K fragments, so the K stream is not delayed; the separate 4.7-us query launch of every layer is gone. V is requested
+// after the projection (as in PHASED): K + V + the projection's operands do not fit 170 registers.
+template <int MAXB, bool PHASED = false, bool QPROJ = false>
 __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a) {
+    constexpr bool VLATE = PHASED || QPROJ;
+    __shared__ float qred[QPROJ ? 12 : 1][2][64];
+    __shared__ float q_mean[2], q_rstd[2];
+    __shared__ __attribute__((aligned(16))) bf16_t q_s[2][64];
     __shared__ float wmax[12][16], wsum[12][16], wmax_all[16];
     __shared__ float wo[12][4][64];                  // per-wave numerators of up to 4 query rows... (G <= 4 here; see the entry point)
     asm volatile("" :: "s"(a.Q), "s"(a.Kp), "s"(a.Vp), "s"(a.mbits), "s"(a.drop_seed), "s"(a.q_bs), "s"(a.mb_bs), "s"(a.H), "s"(a.Tk), "s"(a.Bkv), "s"(a.G));
@@ -978,7 +991,7 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) kf[i][t][ks] = __builtin_bit_cast(bf16x8_t, nt_load16(kp + ((long)blk * 4 + t * 2 + ks) * 512));
-        if (!PHASED) {
+        if (!VLATE) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) vf[i][dt] = __builtin_bit_cast(bf16x8_t, nt_load16(vp + ((long)blk * 4 + dt) * 512));
         }
@@ -986,11 +999,80 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
     // queries (B operand: column qi = query row b + qi * Bkv; columns >= G are zero), mask words, seed
     const int qrow = b + (qi < a.G ? qi : 0) * a.Bkv;
     bf16x8_t qf[2];
+    if (QPROJ) {
+        // ---- q[g][64 h + d] for the G (<= 2) rows m_g = b + g * Bkv. D'[d][m] = sum_k W'[64 h + d][k] * x[m][k]: A = packed weight fragment (16 columns d),
+        // B = activation fragment of row m_g's 16-row tile; this wave's k-steps are 2 * wave, 2 * wave + 1 of the 24
+        const int m1 = a.G > 1 ? b + a.Bkv : b;
+        const int mg[2] = {b, m1};
+        bf16x8_t wq[4][2], xf[2][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        uint4 qv = *reinterpret_cast<const uint4*>(a.Q + (long)qrow * a.q_bs + h * 64 + ks * 32 + g4 * 8);
-        if (qi >= a.G) qv = make_uint4(0, 0, 0, 0);
-        qf[ks] = __builtin_bit_cast(bf16x8_t, qv);
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+                wq[jj][ss] = *reinterpret_cast<const bf16x8_t*>(a.qWp + ((long)((4 * h + jj) * 24 + 2 * wave + ss) * 64 + lane) * 8);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+                xf[g][ss] = *reinterpret_cast<const bf16x8_t*>(a.xA + ((long)((2 * wave + ss) * a.x_mtl + (mg[g] >> 4)) * 64 + lane) * 8);
+        // partial row statistics of the two rows: wave g combines row g's (<= 64) 16-column partials
+        float2 pst = make_float2(0.f, 0.f);
+        const int myg = wave < 2 ? wave : 0;
+        {
+            const int tile = lane < a.x_tiles ? lane : 0;
+            pst = *reinterpret_cast<const float2*>(a.xstats + ((long)tile * a.x_M + mg[myg]) * 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4_t qa[4][2];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                qa[jj][g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) qa[jj][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[jj][ss], xf[g][ss], qa[jj][g], 0, 0, 0);
+            }
+        // D' element (row d = 16 jj + 4 (lane >> 4) + r, column lane & 15): keep column m_g & 15
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if ((lane & 15) == (mg[g] & 15)) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) qred[wave][g][16 * jj + 4 * (lane >> 4) + r] = qa[jj][g][r];
+            }
+        }
+        if (wave < 2) {                                             // Chan et al., as in dec_gemm_kernel: n_i = 16 per partial
+            const bool on = lane < a.x_tiles;
+            const float ntot = 16.0f * (float)a.x_tiles;
+            const float mean = group_sum<64>(on ? pst.x : 0.f) / ntot;
+            const float dlt = pst.x * (1.0f / 16.0f) - mean;
+            const float Qs = group_sum<64>(on ? pst.y + 16.0f * dlt * dlt : 0.f);
+            if (lane == 0) { q_mean[wave] = mean; q_rstd[wave] = rsqrtf(Qs / ntot + a.x_eps); }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int g = tid >> 6, d = tid & 63;
+            float raw = 0.f;
+#pragma unroll
+            for (int w = 0; w < 12; ++w) raw += qred[w][g][d];
+            const float2 bcv = a.qbc[h * 64 + d];                  // (bias', column sum of W')
+            q_s[g][d] = f2bf(q_rstd[g] * (raw - q_mean[g] * bcv.y) + bcv.x);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 qv = *reinterpret_cast<const uint4*>(&q_s[qi < 2 ? qi : 0][ks * 32 + g4 * 8]);
+            if (qi >= a.G) qv = make_uint4(0, 0, 0, 0);
+            qf[ks] = __builtin_bit_cast(bf16x8_t, qv);
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 qv = *reinterpret_cast<const uint4*>(a.Q + (long)qrow * a.q_bs + h * 64 + ks * 32 + g4 * 8);
+            if (qi >= a.G) qv = make_uint4(0, 0, 0, 0);
+            qf[ks] = __builtin_bit_cast(bf16x8_t, qv);
+        }
     }
     uint32_t mw[MAXB];
 #pragma unroll
@@ -1022,7 +1104,7 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
             sc[i][t] = acc;
         }
     }
-    if (PHASED) {                                                                         // the K fragments are dead: their registers take the V fragments
+    if (VLATE) {                                                                          // the K fragments are dead: their registers take the V fragments
 #pragma unroll
         for (int i = 0; i < MAXB; ++i) {
             int blk = wave + 12 * i; blk = blk < nblk ? blk : nblk - 1;
@@ -1207,6 +1289,7 @@ extern "C" int cxr_attn_cross_mfma_bf16(const void* Q, const void* Kp, const voi
     a.o_mt = o_dal ? (cdiv(B, 16) == 3 ? 4 : cdiv(B, 16)) : 0;
     a.scale_log2e = scale * 1.4426950408889634f; a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_site = drop_site;
     a.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u; a.has_mask = kpm_bits ? 1u : 0u;
+    a.xA = nullptr; a.xstats = nullptr; a.qWp = nullptr; a.qbc = nullptr; a.x_mtl = a.x_M = a.x_tiles = 0; a.x_eps = 0.f;
     // more than 36 key blocks (1152 keys) per study: the blocks are split over nsplit workgroups per (study, head), partial states -> ws
     // (B*H*nsplit*66 floats) -> attn_decode_merge_kernel
     const int nblk_all = Tk / 32;
@@ -1224,6 +1307,38 @@ extern "C" int cxr_attn_cross_mfma_bf16(const void* Q, const void* Kp, const voi
     else if (a.bps <= 24) CXR_LAUNCH(attn_cross_mfma_kernel<2>, grid, dim3(768), 0, stream, a);
     else CXR_LAUNCH(attn_cross_mfma_kernel<3>, grid, dim3(768), 0, stream, a);
     if (a.nsplit > 1) CXR_LAUNCH(attn_decode_merge_kernel, dim3(cdiv(B * H, 4)), dim3(256), 0, stream, ws, (bf16_t*)O, o_bs, H, a.nsplit, B * H, a.o_mt);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// The same step with the cross-attention QUERY projection inside the kernel (attn_cross_mfma_kernel<.., QPROJ>): xA = the raw hidden rows [x_M rows, 768]
+// in the decode activation layout (x_mtl 16-row tiles), xstats = their producer's partial row statistics fp32 [x_tiles][x_M][2], qWp / qbc = the query
+// Linear packed by cxr_dec_pack_weight_bf16 with the LayerNorm folded in. Requires H * 64 == 768, kv_share <= 2, Tk <= 1920 (one workgroup per
+// (study, head)). Replaces one cxr_dec_gemm_bf16 launch + cxr_attn_cross_mfma_bf16 per layer and token-step.
+extern "C" int cxr_attn_cross_mfma_q_bf16(const void* xA, int x_mtl, int x_M, const float* xstats, int x_tiles, float x_eps, const void* qWp, const float* qbc,
+                                          const void* Kp, const void* Vp, void* O, const unsigned int* kpm_bits, long o_bs, long mb_words, int B, int H, int Tk,
+                                          float scale, int kv_share, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t, int o_dal,
+                                          hipStream_t stream) {
+    if (B <= 0 || H * 64 != 768 || Tk <= 0 || (Tk % 32) || Tk > 1920 || kv_share < 1 || kv_share > 2 || (B % kv_share) || ((uintptr_t)Kp % 16) || ((uintptr_t)Vp % 16) ||
+        drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed) || (o_dal && B > 64) || !xA || !xstats || !qWp || !qbc || x_tiles <= 0 || x_tiles > 64 ||
+        x_M < B || x_mtl < (B + 15) / 16 || ((uintptr_t)xA % 16) || ((uintptr_t)qWp % 16))
+        return CXR_ERR_ARG;
+    AttnXArgs a;
+    a.Q = (const bf16_t*)Kp; a.Kp = (const bf16_t*)Kp; a.Vp = (const bf16_t*)Vp; a.O = (bf16_t*)O; a.mbits = kpm_bits;
+    a.drop_seed = drop_seed ? drop_seed : (const uint32_t*)Kp;
+    a.q_bs = 0; a.o_bs = o_bs; a.mb_bs = mb_words;
+    a.H = H; a.Tk = Tk; a.Bkv = B / kv_share; a.G = kv_share; a.drop_t = drop_t;
+    a.o_mt = o_dal ? (cdiv(B, 16) == 3 ? 4 : cdiv(B, 16)) : 0;
+    a.scale_log2e = scale * 1.4426950408889634f; a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_site = drop_site;
+    a.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u; a.has_mask = kpm_bits ? 1u : 0u;
+    a.xA = (const bf16_t*)xA; a.xstats = xstats; a.qWp = (const bf16_t*)qWp; a.qbc = (const float2*)qbc; a.x_mtl = x_mtl; a.x_M = x_M; a.x_tiles = x_tiles; a.x_eps = x_eps;
+    const int nblk_all = Tk / 32;
+    a.nsplit = 1; a.bps = nblk_all; a.ws = nullptr;
+    const dim3 grid(a.Bkv * H);
+    if (nblk_all <= 12) CXR_LAUNCH((attn_cross_mfma_kernel<1, false, true>), grid, dim3(768), 0, stream, a);
+    else if (nblk_all <= 24) CXR_LAUNCH((attn_cross_mfma_kernel<2, false, true>), grid, dim3(768), 0, stream, a);
+    else if (nblk_all <= 36) CXR_LAUNCH((attn_cross_mfma_kernel<3, false, true>), grid, dim3(768), 0, stream, a);
+    else CXR_LAUNCH((attn_cross_mfma_kernel<5, true, true>), grid, dim3(768), 0, stream, a);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

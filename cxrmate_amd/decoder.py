@@ -30,6 +30,7 @@ _CROSS_KV_FUSED = os.environ.get("CXR_CROSS_KV_FUSED", "1") != "0"      # A/B sw
 _LORA_IN_KERNEL = os.environ.get("CXR_LORA_IN_KERNEL", "1") != "0"        # A/B switch: 0 = separate LoRA down-projection launch per decode layer
 _SELF_QKV_FUSED = os.environ.get("CXR_SELF_QKV_FUSED", "1") != "0"      # A/B switch: 0 = separate query / key / value GEMMs
 _CROSS_WG_KEYS = int(os.environ.get("CXR_CROSS_WG_KEYS", "0"))          # cached cross-attention geometry (ops.attention_decode wg_keys)
+_CROSS_Q_FUSED = os.environ.get("CXR_CROSS_Q_FUSED", "1") != "0"      # A/B switch: 0 = separate query GEMM launch in front of the cached cross-attention
 _CROSS_MFMA = os.environ.get("CXR_CROSS_MFMA", "1") != "0"              # A/B switch: 0 = VALU decode kernel for the cached cross-attention
 
 
@@ -739,6 +740,19 @@ class BertEngine:
                                        drop=(pa, seed, _site(l, 0), past), wg_keys=256 if past + 1 <= 256 else -256, out_dal=True)
             (a1,), st1 = ops.dec_gemm(ctx, B, D, [prob((l, "attn_out"), D)], out_stats=True, drop=drop(_site(l, 1)), **res_kw())
             cur, cur_st, cur_ln = a1, st1, lp + "attention.output.LayerNorm"
+            Bkv, Tk = cache.ck[l].shape[0], cache.ck[l].shape[1]
+            if (_CROSS_Q_FUSED and cache.cpk[l] is not None and (enc_mask is None or cache.enc_bits is not None) and D == 768 and B // Bkv <= 2
+                    and Tk <= 1920 and cur_st is not None and cur_ln is not None):
+                # the query projection runs inside the cross-attention kernel (one launch instead of two per layer: csrc/decode.hip QPROJ)
+                wp, bc = pk[(l, "cq")]
+                ctx2 = ops.attention_cross_mfma_q(cur, B, cur_st, eps, wp, bc, cache.cpk[l], Bkv, Tk, nh, scale,
+                                                  kpm_bits=cache.enc_bits if enc_mask is not None else None, drop=(pa, seed, _site(l, 2), past), out_dal=True)
+                (a2,), st2 = ops.dec_gemm(ctx2, B, D, [prob((l, "cout"), D)], out_stats=True, drop=drop(_site(l, 3)), **res_kw())
+                cur, cur_st, cur_ln = a2, st2, lp + "crossattention.output.LayerNorm"
+                (f,), _ = ops.dec_gemm(cur, B, D, [prob((l, "ffn1"), F)], act=1, stats=cur_st, eps=eps)
+                (a3,), st3 = ops.dec_gemm(f, B, F, [prob((l, "ffn2"), D)], out_stats=True, drop=drop(_site(l, 4)), **res_kw())
+                cur, cur_st, cur_ln = a3, st3, lp + "output.LayerNorm"
+                continue
             q2 = torch.empty((B, D), dtype=BF16, device=dev)
             ops.dec_gemm(cur, B, D, [prob((l, "cq"), D, q2)], stats=cur_st, eps=eps)
             if cache.cpk[l] is not None and (enc_mask is None or cache.enc_bits is not None):

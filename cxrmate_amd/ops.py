@@ -1170,6 +1170,19 @@ def attention_cross_mfma(q, packed, Bkv, Tk, heads, scale, kpm_bits=None, out=No
     return out
 
 
+def attention_cross_mfma_q(x_dal, M, stats, eps, wp, bc, packed, Bkv, Tk, heads, scale, kpm_bits=None, out=None, drop=None, out_dal=True):
+    """attention_cross_mfma with the query projection inside the kernel: x_dal = raw hidden rows (decode activation layout, M rows x 768), stats = its
+    producer's partial row statistics [tiles, M, 2], (wp, bc) = the packed query Linear with the LayerNorm folded in (dec_pack_weight)."""
+    D = heads * 64
+    assert D == 768 and M % Bkv == 0 and M // Bkv <= 2 and Tk % 32 == 0 and Tk <= 1920 and packed[0].numel() == Bkv * Tk * D
+    if out is None:
+        out = torch.empty((dal_rows(M) if out_dal else M, D), device=x_dal.device, dtype=BF16)
+    LIB.call("cxr_attn_cross_mfma_q_bf16", _p(x_dal), x_dal.shape[0] // 16, M, _p(stats), stats.shape[0], float(eps), _p(wp), _p(bc), _p(packed[0]), _p(packed[1]),
+             _p(out), _p(kpm_bits), out.stride(0), kpm_bits.stride(0) if kpm_bits is not None else 0, M, heads, Tk, float(scale), M // Bkv, *_drop_args(drop),
+             int(bool(out_dal)), _s())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ decode-step linear layers (csrc/decode_gemm.hip)
 def dal_rows(M):
     """rows of the buffer that holds M rows in the decode activation layout (16-row tiles; 3 tiles are stored as 4)"""

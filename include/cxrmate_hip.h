@@ -348,7 +348,15 @@ int cxr_dec_from_dal_bf16(const void* x, int M, int K, void* out, long ldo, hipS
 int cxr_pack_cross_kv_bf16(const void* K, const void* V, long kv_bs, long kv_rs, void* Kp, void* Vp, int Bkv, int H, int Tk, hipStream_t stream);
 int cxr_attn_cross_mfma_bf16(const void* Q, const void* Kp, const void* Vp, void* O, const unsigned int* kpm_bits, long q_bs, long o_bs, long mb_words,
                              int B, int H, int Tk, float scale, int kv_share, float drop_p, const unsigned int* drop_seed, unsigned int drop_site,
-                             int drop_t, int o_dal, float* ws, hipStream_t stream);   /* ws (B*H*8*66 floats): needed for Tk > 1152 (key range split + merge) */
+                             int drop_t, int o_dal, float* ws, hipStream_t stream);
+/* cxr_attn_cross_mfma_bf16 with the cross-attention QUERY projection inside the kernel: xA = the raw hidden rows [x_M, 768] in the decode activation
+ * layout (x_mtl 16-row tiles), xstats = the producer's partial row statistics fp32 [x_tiles][x_M][2] (as cxr_dec_gemm_bf16 publishes them), qWp / qbc =
+ * the query Linear packed by cxr_dec_pack_weight_bf16 with the LayerNorm folded in. H * 64 == 768, kv_share <= 2, Tk <= 1920. One launch instead of
+ * cxr_dec_gemm_bf16 (query) + cxr_attn_cross_mfma_bf16 per layer and token-step. */
+int cxr_attn_cross_mfma_q_bf16(const void* xA, int x_mtl, int x_M, const float* xstats, int x_tiles, float x_eps, const void* qWp, const float* qbc,
+                               const void* Kp, const void* Vp, void* O, const unsigned int* kpm_bits, long o_bs, long mb_words, int B, int H, int Tk,
+                               float scale, int kv_share, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t, int o_dal,
+                               hipStream_t stream);   /* ws (B*H*8*66 floats): needed for Tk > 1152 (key range split + merge) */
 int cxr_pack_mask_bits(const void* kpm, long kpm_bs, int B, int T, unsigned int* out, int words, hipStream_t stream);
                        /* key-padding bytes [B,T] (1 = attend) -> uint32 [B][words], bit k%32 of word k/32 */
 int cxr_topk_rows(const float* x, long ld, long R, int n, int K, float* vals, long* inds, hipStream_t stream);

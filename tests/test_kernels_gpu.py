@@ -1467,3 +1467,52 @@ def test_attention_cross_mfma_matches_the_valu_decode_kernel(ops, Bkv, share, Tk
     # decode activation layout output == row-major output re-laid out
     dal = ops.attention_cross_mfma(q, pk, Bkv, Tk, H, 0.125, kpm_bits=bits, drop=dr, out_dal=True)
     assert torch.equal(ops.dec_from_dal(dal, B, D), out)
+
+
+@pytest.mark.parametrize("Bkv,share,Tk,masked,drop", [(16, 2, 1152, False, 0.0), (16, 2, 1152, True, 0.1), (1, 1, 1152, False, 0.0), (3, 2, 320, True, 0.0), (5, 1, 576, True, 0.1),
+                                                       (16, 2, 1728, True, 0.0), (2, 2, 1920, True, 0.1), (32, 2, 1152, True, 0.0)])
+def test_attention_cross_mfma_with_the_query_projection_inside(ops, Bkv, share, Tk, masked, drop):
+    """cxr_attn_cross_mfma_q_bf16 (query Linear with the LayerNorm folded in computed per (study, head) inside the cross-attention kernel) against the two
+    launches it replaces (cxr_dec_gemm_bf16 for q, then cxr_attn_cross_mfma_bf16) and against fp32 LayerNorm -> Linear -> attention."""
+    torch.manual_seed(Bkv * 11 + Tk)
+    H, D, B = 12, 768, Bkv * share
+    raw = ((torch.randn(B, D, device="cuda") * 1.5 + 0.3)).to(BF)
+    w, bias = (torch.randn(D, D, device="cuda") * 0.04).to(BF), torch.randn(D, device="cuda") * 0.1
+    g, b = 1 + 0.1 * torch.randn(D, device="cuda"), 0.1 * torch.randn(D, device="cuda")
+    k = (torch.randn(Bkv, Tk, D, device="cuda") * 0.7).to(BF)
+    v = torch.randn(Bkv, Tk, D, device="cuda").to(BF)
+    kpm = None
+    if masked:
+        kpm = torch.ones(Bkv, Tk, dtype=torch.uint8, device="cuda")
+        kpm[0, Tk // 2:] = 0
+        kpm[-1, 5:37] = 0
+    bits = ops.pack_mask_bits(kpm) if masked else None
+    seed = torch.tensor([4321], dtype=torch.int32, device="cuda")
+    dr = (drop, seed, 23, 5) if drop > 0 else None
+    pk = ops.pack_cross_kv(k, v, H)
+    x_dal, st = _dal(ops, raw)
+    wf, bcf = ops.dec_pack_weight(w, g, b, bias)
+    q = torch.empty(B, D, dtype=BF, device="cuda")
+    ops.dec_gemm(x_dal, B, D, [dict(wp=wf, bc=bcf, N=D, fold=True, out=q)], stats=st, eps=1e-12)
+    two = ops.attention_cross_mfma(q, pk, Bkv, Tk, H, 0.125, kpm_bits=bits, drop=dr)
+    for out_dal in (True, False):
+        one = ops.attention_cross_mfma_q(x_dal, B, st, 1e-12, wf, bcf, pk, Bkv, Tk, H, 0.125, kpm_bits=bits, drop=dr, out_dal=out_dal)
+        got = ops.dec_from_dal(one, B, D) if out_dal else one
+        close(got, two, rtol=1e-2, atol=2e-2, what=f"fused query projection vs two launches (dal={out_dal})")
+    if drop == 0:
+        qf = torch.nn.functional.layer_norm(raw.float(), (D,), g, b, 1e-12) @ w.float().t() + bias
+        kk, vv = k.float().repeat(share, 1, 1), v.float().repeat(share, 1, 1)
+        qh, kh, vh = qf.view(B, H, 1, 64), kk.view(B, Tk, H, 64).transpose(1, 2), vv.view(B, Tk, H, 64).transpose(1, 2)
+        s_ = (qh @ kh.transpose(2, 3)) * 0.125
+        if masked:
+            s_ = s_.masked_fill(~kpm.bool().repeat(share, 1).view(B, 1, 1, Tk), torch.finfo(torch.float32).min)
+        full = (torch.softmax(s_, -1) @ vh).transpose(1, 2).reshape(B, D)
+        close(got, full, rtol=2e-2, atol=3e-2, what="fused query projection vs fp32")
+    # statistics split over several producer tiles (the layout a dec_gemm with out_stats publishes) give the same result
+    (y,), yst = ops.dec_gemm(x_dal, B, D, [dict(wp=wf, bc=bcf, N=D, fold=True)], stats=st, eps=1e-12, out_stats=True)
+    assert yst.shape[0] > 1
+    q2 = torch.empty(B, D, dtype=BF, device="cuda")
+    ops.dec_gemm(y, B, D, [dict(wp=wf, bc=bcf, N=D, fold=True, out=q2)], stats=yst, eps=1e-12)
+    two2 = ops.attention_cross_mfma(q2, pk, Bkv, Tk, H, 0.125, kpm_bits=bits, drop=dr)
+    one2 = ops.attention_cross_mfma_q(y, B, yst, 1e-12, wf, bcf, pk, Bkv, Tk, H, 0.125, kpm_bits=bits, drop=dr, out_dal=False)
+    close(one2, two2, rtol=1e-2, atol=2e-2, what="fused query projection, multi-tile statistics")
