@@ -251,7 +251,7 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
                         "hipGraphs, REINFORCE through one teacher-forced pass, AdamW on the 80.9 M decoder parameters",
             "mode": "eval" if args.eval_mode else "model.train(): batch-statistics BatchNorm in the frozen encoder, dropout 0.1 in both decodes and in "
                     "the re-scoring pass (same seed)", "loss": float(out["loss"].item()), "string_round_trip": strings,
-            "roofline": {"bound": "hbm", "kernel": "cached decode token-step (one hipGraph of ~54 kernels: dec_gemm_kernel x38, attn_cross_mfma_kernel x6, attn_decode_kernel x6, "
+            "roofline": {"bound": "hbm", "kernel": "cached decode token-step (one hipGraph of ~48 kernels: dec_gemm_kernel x32, attn_cross_mfma_kernel (query projection inside) x6, attn_decode_kernel x6, "
                          "embedding, step inputs, token selection), 32 rows", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": decode_traffic()[0], "traffic_unit": "bytes per token-step",
                          "traffic_source": decode_traffic()[1], "algorithmic_bytes_per_token_step": step_bytes,
@@ -566,6 +566,13 @@ def main():
         return spawn_ranks(args.gpus)
 
     aff = os.environ.get("CXR_CPU_AFFINITY")
+    if not aff and int(os.environ.get("WORLD_SIZE", "1")) > 1 and hasattr(os, "sched_getaffinity"):
+        # launched by torch.distributed.run (the driver's N > 1 command): the same per-rank slice of the host cores spawn_ranks hands out
+        cores, nloc = sorted(os.sched_getaffinity(0)), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]))
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        if len(cores) >= 2 * nloc and lr < nloc:
+            per = len(cores) // nloc
+            aff = ",".join(str(c) for c in cores[lr * per:(lr + 1) * per])
     if aff and hasattr(os, "sched_setaffinity"):
         try:
             os.sched_setaffinity(0, {int(c) for c in aff.split(",") if c != ""})
