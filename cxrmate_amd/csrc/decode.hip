@@ -1004,17 +1004,20 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
         // B = activation fragment of row m_g's 16-row tile; this wave's k-steps are 2 * wave, 2 * wave + 1 of the 24
         const int m1 = a.G > 1 ? b + a.Bkv : b;
         const int mg[2] = {b, m1};
-        bf16x8_t wq[4][2], xf[2][2];
+        // ONE B operand for both rows: output column 0 = row m_0, column 1 = row m_1 (every lane fetches the 16 bytes of "its" row straight from the
+        // decode activation layout; columns >= 2 repeat row m_0 and are dropped) -- half the MFMAs, accumulators and LDS partials of a fragment per row
+        bf16x8_t wq[4][2], xf[2];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss)
                 wq[jj][ss] = *reinterpret_cast<const bf16x8_t*>(a.qWp + ((long)((4 * h + jj) * 24 + 2 * wave + ss) * 64 + lane) * 8);
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
+        {
+            const int mrow = mg[(lane & 15) == 1 ? 1 : 0];
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss)
-                xf[g][ss] = *reinterpret_cast<const bf16x8_t*>(a.xA + ((long)((2 * wave + ss) * a.x_mtl + (mg[g] >> 4)) * 64 + lane) * 8);
+                xf[ss] = *reinterpret_cast<const bf16x8_t*>(a.xA + ((long)((2 * wave + ss) * a.x_mtl + (mrow >> 4)) * 64 + (lane & 48) + (mrow & 15)) * 8);
+        }
         // partial row statistics of the two rows: wave g combines row g's (<= 64) 16-column partials
         float2 pst = make_float2(0.f, 0.f);
         const int myg = wave < 2 ? wave : 0;
@@ -1023,24 +1026,19 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
             pst = *reinterpret_cast<const float2*>(a.xstats + ((long)tile * a.x_M + mg[myg]) * 2);
         }
         __builtin_amdgcn_sched_barrier(0);
-        f32x4_t qa[4][2];
+        f32x4_t qa[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < 4; ++jj) {
+            qa[jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                qa[jj][g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int ss = 0; ss < 2; ++ss) qa[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[jj][ss], xf[ss], qa[jj], 0, 0, 0);
+        }
+        // D' element (row d = 16 jj + 4 (lane >> 4) + r, column lane & 15): columns 0 / 1 are the two query rows
+        if ((lane & 15) < 2) {
 #pragma unroll
-                for (int ss = 0; ss < 2; ++ss) qa[jj][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[jj][ss], xf[g][ss], qa[jj][g], 0, 0, 0);
-            }
-        // D' element (row d = 16 jj + 4 (lane >> 4) + r, column lane & 15): keep column m_g & 15
+            for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            if ((lane & 15) == (mg[g] & 15)) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) qred[wave][g][16 * jj + 4 * (lane >> 4) + r] = qa[jj][g][r];
-            }
+                for (int r = 0; r < 4; ++r) qred[wave][lane & 15][16 * jj + 4 * (lane >> 4) + r] = qa[jj][r];
         }
         if (wave < 2) {                                             // Chan et al., as in dec_gemm_kernel: n_i = 16 per partial
             const bool on = lane < a.x_tiles;
