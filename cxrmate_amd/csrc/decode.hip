@@ -957,7 +957,7 @@ extern "C" int cxr_pack_cross_kv_bf16(const void* K, const void* V, long kv_bs, 
 // scores are computed instead of up front -- K and V fragments of 5 blocks per wave do not fit the 170 registers of a 12-wave workgroup together. The
 // V round trip then sits behind the score phase of the same wave, but other workgroups of the launch are in their K phase meanwhile (the launch as a
 // whole stays at the HBM rate), and the split + partial states + merge launch of the > 36-block case is gone.
-// QPROJ (G <= 2 query rows per study, K = 768): the cross-attention QUERY projection of the cached step runs inside this kernel. Every (study, head)
+// QPROJ (G <= 4 query rows per study, K = 768): the cross-attention QUERY projection of the cached step runs inside this kernel. Every (study, head)
 // workgroup needs only its head's 64 query columns of its G rows: 12 waves split K (2 k-steps of 32 each) over the 4 x 16 output columns, with the
 // packed weights as the A operand and the activation fragments as the B operand (both are laid out as either), partial sums meet in LDS, the folded
 // LayerNorm is applied as in dec_gemm_kernel (Chan combination of the producer's 48 partial statistics by one wave per row). The weight fragments are
@@ -966,9 +966,9 @@ extern "C" int cxr_pack_cross_kv_bf16(const void* K, const void* V, long kv_bs, 
 template <int MAXB, bool PHASED = false, bool QPROJ = false>
 __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a) {
     constexpr bool VLATE = PHASED || QPROJ;
-    __shared__ float qred[QPROJ ? 12 : 1][2][64];
-    __shared__ float q_mean[2], q_rstd[2];
-    __shared__ __attribute__((aligned(16))) bf16_t q_s[2][64];
+    __shared__ float qred[QPROJ ? 12 : 1][4][64];
+    __shared__ float q_mean[4], q_rstd[4];
+    __shared__ __attribute__((aligned(16))) bf16_t q_s[4][64];
     __shared__ float wmax[12][16], wsum[12][16], wmax_all[16];
     __shared__ float wo[12][4][64];                  // per-wave numerators of up to 4 query rows... (G <= 4 here; see the entry point)
     asm volatile("" :: "s"(a.Q), "s"(a.Kp), "s"(a.Vp), "s"(a.mbits), "s"(a.drop_seed), "s"(a.q_bs), "s"(a.mb_bs), "s"(a.H), "s"(a.Tk), "s"(a.Bkv), "s"(a.G));
@@ -1000,12 +1000,10 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
     const int qrow = b + (qi < a.G ? qi : 0) * a.Bkv;
     bf16x8_t qf[2];
     if (QPROJ) {
-        // ---- q[g][64 h + d] for the G (<= 2) rows m_g = b + g * Bkv. D'[d][m] = sum_k W'[64 h + d][k] * x[m][k]: A = packed weight fragment (16 columns d),
+        // ---- q[g][64 h + d] for the G (<= 4) rows m_g = b + g * Bkv. D'[d][m] = sum_k W'[64 h + d][k] * x[m][k]: A = packed weight fragment (16 columns d),
         // B = activation fragment of row m_g's 16-row tile; this wave's k-steps are 2 * wave, 2 * wave + 1 of the 24
-        const int m1 = a.G > 1 ? b + a.Bkv : b;
-        const int mg[2] = {b, m1};
-        // ONE B operand for both rows: output column 0 = row m_0, column 1 = row m_1 (every lane fetches the 16 bytes of "its" row straight from the
-        // decode activation layout; columns >= 2 repeat row m_0 and are dropped) -- half the MFMAs, accumulators and LDS partials of a fragment per row
+        // ONE B operand for all G rows: output column g = row m_g (every lane fetches the 16 bytes of "its" row straight from the decode activation
+        // layout; columns >= G repeat row m_0 and are dropped) -- a fragment per row would cost G times the MFMAs, accumulators and LDS partials
         bf16x8_t wq[4][2], xf[2];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
@@ -1013,17 +1011,18 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
             for (int ss = 0; ss < 2; ++ss)
                 wq[jj][ss] = *reinterpret_cast<const bf16x8_t*>(a.qWp + ((long)((4 * h + jj) * 24 + 2 * wave + ss) * 64 + lane) * 8);
         {
-            const int mrow = mg[(lane & 15) == 1 ? 1 : 0];
+            const int gl = lane & 15;
+            const int mrow = b + (gl < a.G ? gl : 0) * a.Bkv;
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss)
                 xf[ss] = *reinterpret_cast<const bf16x8_t*>(a.xA + ((long)((2 * wave + ss) * a.x_mtl + (mrow >> 4)) * 64 + (lane & 48) + (mrow & 15)) * 8);
         }
-        // partial row statistics of the two rows: wave g combines row g's (<= 64) 16-column partials
+        // partial row statistics of the G rows: wave g combines row g's (<= 64) 16-column partials
         float2 pst = make_float2(0.f, 0.f);
-        const int myg = wave < 2 ? wave : 0;
         {
+            const int myg = wave < a.G ? wave : 0;
             const int tile = lane < a.x_tiles ? lane : 0;
-            pst = *reinterpret_cast<const float2*>(a.xstats + ((long)tile * a.x_M + mg[myg]) * 2);
+            pst = *reinterpret_cast<const float2*>(a.xstats + ((long)tile * a.x_M + b + myg * a.Bkv) * 2);
         }
         __builtin_amdgcn_sched_barrier(0);
         f32x4_t qa[4];
@@ -1033,14 +1032,14 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) qa[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[jj][ss], xf[ss], qa[jj], 0, 0, 0);
         }
-        // D' element (row d = 16 jj + 4 (lane >> 4) + r, column lane & 15): columns 0 / 1 are the two query rows
-        if ((lane & 15) < 2) {
+        // D' element (row d = 16 jj + 4 (lane >> 4) + r, column lane & 15): columns 0 .. G - 1 are the query rows
+        if ((lane & 15) < 4) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) qred[wave][lane & 15][16 * jj + 4 * (lane >> 4) + r] = qa[jj][r];
         }
-        if (wave < 2) {                                             // Chan et al., as in dec_gemm_kernel: n_i = 16 per partial
+        if (wave < 4) {                                             // Chan et al., as in dec_gemm_kernel: n_i = 16 per partial
             const bool on = lane < a.x_tiles;
             const float ntot = 16.0f * (float)a.x_tiles;
             const float mean = group_sum<64>(on ? pst.x : 0.f) / ntot;
@@ -1049,7 +1048,7 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
             if (lane == 0) { q_mean[wave] = mean; q_rstd[wave] = rsqrtf(Qs / ntot + a.x_eps); }
         }
         __syncthreads();
-        if (tid < 128) {
+        if (tid < 256) {
             const int g = tid >> 6, d = tid & 63;
             float raw = 0.f;
 #pragma unroll
@@ -1060,7 +1059,7 @@ __global__ __launch_bounds__(768) void attn_cross_mfma_kernel(const AttnXArgs a)
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint4 qv = *reinterpret_cast<const uint4*>(&q_s[qi < 2 ? qi : 0][ks * 32 + g4 * 8]);
+            uint4 qv = *reinterpret_cast<const uint4*>(&q_s[qi < 4 ? qi : 0][ks * 32 + g4 * 8]);
             if (qi >= a.G) qv = make_uint4(0, 0, 0, 0);
             qf[ks] = __builtin_bit_cast(bf16x8_t, qv);
         }
@@ -1311,13 +1310,13 @@ extern "C" int cxr_attn_cross_mfma_bf16(const void* Q, const void* Kp, const voi
 
 // The same step with the cross-attention QUERY projection inside the kernel (attn_cross_mfma_kernel<.., QPROJ>): xA = the raw hidden rows [x_M rows, 768]
 // in the decode activation layout (x_mtl 16-row tiles), xstats = their producer's partial row statistics fp32 [x_tiles][x_M][2], qWp / qbc = the query
-// Linear packed by cxr_dec_pack_weight_bf16 with the LayerNorm folded in. Requires H * 64 == 768, kv_share <= 2, Tk <= 1920 (one workgroup per
+// Linear packed by cxr_dec_pack_weight_bf16 with the LayerNorm folded in. Requires H * 64 == 768, kv_share <= 4, Tk <= 1920 (one workgroup per
 // (study, head)). Replaces one cxr_dec_gemm_bf16 launch + cxr_attn_cross_mfma_bf16 per layer and token-step.
 extern "C" int cxr_attn_cross_mfma_q_bf16(const void* xA, int x_mtl, int x_M, const float* xstats, int x_tiles, float x_eps, const void* qWp, const float* qbc,
                                           const void* Kp, const void* Vp, void* O, const unsigned int* kpm_bits, long o_bs, long mb_words, int B, int H, int Tk,
                                           float scale, int kv_share, float drop_p, const unsigned int* drop_seed, unsigned int drop_site, int drop_t, int o_dal,
                                           hipStream_t stream) {
-    if (B <= 0 || H * 64 != 768 || Tk <= 0 || (Tk % 32) || Tk > 1920 || kv_share < 1 || kv_share > 2 || (B % kv_share) || ((uintptr_t)Kp % 16) || ((uintptr_t)Vp % 16) ||
+    if (B <= 0 || H * 64 != 768 || Tk <= 0 || (Tk % 32) || Tk > 1920 || kv_share < 1 || kv_share > 4 || (B % kv_share) || ((uintptr_t)Kp % 16) || ((uintptr_t)Vp % 16) ||
         drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed) || (o_dal && B > 64) || !xA || !xstats || !qWp || !qbc || x_tiles <= 0 || x_tiles > 64 ||
         x_M < B || x_mtl < (B + 15) / 16 || ((uintptr_t)xA % 16) || ((uintptr_t)qWp % 16))
         return CXR_ERR_ARG;

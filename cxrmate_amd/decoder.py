@@ -741,7 +741,7 @@ class BertEngine:
             (a1,), st1 = ops.dec_gemm(ctx, B, D, [prob((l, "attn_out"), D)], out_stats=True, drop=drop(_site(l, 1)), **res_kw())
             cur, cur_st, cur_ln = a1, st1, lp + "attention.output.LayerNorm"
             Bkv, Tk = cache.ck[l].shape[0], cache.ck[l].shape[1]
-            if (_CROSS_Q_FUSED and cache.cpk[l] is not None and (enc_mask is None or cache.enc_bits is not None) and D == 768 and nh * 64 == D and B // Bkv <= 2
+            if (_CROSS_Q_FUSED and cache.cpk[l] is not None and (enc_mask is None or cache.enc_bits is not None) and D == 768 and nh * 64 == D and B // Bkv <= 4
                     and Tk <= 1920 and Tk % 32 == 0 and B <= 64 and cur_st is not None and cur_ln is not None):
                 # the query projection runs inside the cross-attention kernel (one launch instead of two per layer: csrc/decode.hip QPROJ)
                 wp, bc = pk[(l, "cq")]

@@ -1174,7 +1174,7 @@ def attention_cross_mfma_q(x_dal, M, stats, eps, wp, bc, packed, Bkv, Tk, heads,
     """attention_cross_mfma with the query projection inside the kernel: x_dal = raw hidden rows (decode activation layout, M rows x 768), stats = its
     producer's partial row statistics [tiles, M, 2], (wp, bc) = the packed query Linear with the LayerNorm folded in (dec_pack_weight)."""
     D = heads * 64
-    assert D == 768 and M % Bkv == 0 and M // Bkv <= 2 and Tk % 32 == 0 and Tk <= 1920 and packed[0].numel() == Bkv * Tk * D
+    assert D == 768 and M % Bkv == 0 and M // Bkv <= 4 and Tk % 32 == 0 and Tk <= 1920 and packed[0].numel() == Bkv * Tk * D
     if out is None:
         out = torch.empty((dal_rows(M) if out_dal else M, D), device=x_dal.device, dtype=BF16)
     LIB.call("cxr_attn_cross_mfma_q_bf16", _p(x_dal), x_dal.shape[0] // 16, M, _p(stats), stats.shape[0], float(eps), _p(wp), _p(bc), _p(packed[0]), _p(packed[1]),

@@ -351,7 +351,7 @@ int cxr_attn_cross_mfma_bf16(const void* Q, const void* Kp, const void* Vp, void
                              int drop_t, int o_dal, float* ws, hipStream_t stream);
 /* cxr_attn_cross_mfma_bf16 with the cross-attention QUERY projection inside the kernel: xA = the raw hidden rows [x_M, 768] in the decode activation
  * layout (x_mtl 16-row tiles), xstats = the producer's partial row statistics fp32 [x_tiles][x_M][2] (as cxr_dec_gemm_bf16 publishes them), qWp / qbc =
- * the query Linear packed by cxr_dec_pack_weight_bf16 with the LayerNorm folded in. H * 64 == 768, kv_share <= 2, Tk <= 1920. One launch instead of
+ * the query Linear packed by cxr_dec_pack_weight_bf16 with the LayerNorm folded in. H * 64 == 768, kv_share <= 4, Tk <= 1920. One launch instead of
  * cxr_dec_gemm_bf16 (query) + cxr_attn_cross_mfma_bf16 per layer and token-step. */
 int cxr_attn_cross_mfma_q_bf16(const void* xA, int x_mtl, int x_M, const float* xstats, int x_tiles, float x_eps, const void* qWp, const float* qbc,
                                const void* Kp, const void* Vp, void* O, const unsigned int* kpm_bits, long o_bs, long mb_words, int B, int H, int Tk,

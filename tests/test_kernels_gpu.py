@@ -1470,7 +1470,8 @@ def test_attention_cross_mfma_matches_the_valu_decode_kernel(ops, Bkv, share, Tk
 
 
 @pytest.mark.parametrize("Bkv,share,Tk,masked,drop", [(16, 2, 1152, False, 0.0), (16, 2, 1152, True, 0.1), (1, 1, 1152, False, 0.0), (3, 2, 320, True, 0.0), (5, 1, 576, True, 0.1),
-                                                       (16, 2, 1728, True, 0.0), (2, 2, 1920, True, 0.1), (32, 2, 1152, True, 0.0)])
+                                                       (16, 2, 1728, True, 0.0), (2, 2, 1920, True, 0.1), (32, 2, 1152, True, 0.0), (8, 4, 1152, True, 0.0), (3, 3, 576, False, 0.1),
+                                                       (5, 4, 1728, True, 0.1)])
 def test_attention_cross_mfma_with_the_query_projection_inside(ops, Bkv, share, Tk, masked, drop):
     """cxr_attn_cross_mfma_q_bf16 (query Linear with the LayerNorm folded in computed per (study, head) inside the cross-attention kernel) against the two
     launches it replaces (cxr_dec_gemm_bf16 for q, then cxr_attn_cross_mfma_bf16) and against fp32 LayerNorm -> Linear -> attention."""
