@@ -52,3 +52,30 @@ for it in range(25):
     if e > 2e-3 or eb > 2e-3 or not torch.equal(out, out2) or not torch.equal(db, db2):
         bad += 1; print("BAD tn", R, I, J, e, eb, torch.equal(out, out2))
 print("tn fuzz done, bad =", bad)
+bad = 0
+for it in range(60):
+    G = random.choice([1, 2, 3, 4]); Bkv = random.choice([1, 2, 5, 8, 16]); Tk = 32 * random.choice([1, 2, 7, 12, 13, 24, 25, 36, 37, 54, 60])
+    if Bkv * G > 64: continue
+    B, H, D = Bkv * G, 12, 768
+    raw = (torch.randn(B, D, device="cuda") * random.choice([0.5, 2.0]) + random.choice([0.0, 0.5])).to(BF)
+    w, bias = (torch.randn(D, D, device="cuda") * 0.04).to(BF), torch.randn(D, device="cuda") * 0.1
+    g_, b_ = 1 + 0.1 * torch.randn(D, device="cuda"), 0.1 * torch.randn(D, device="cuda")
+    k = (torch.randn(Bkv, Tk, D, device="cuda") * 0.7).to(BF); v = torch.randn(Bkv, Tk, D, device="cuda").to(BF)
+    kpm = None
+    if random.random() < 0.6:
+        kpm = (torch.rand(Bkv, Tk, device="cuda") < 0.7).to(torch.uint8); kpm[:, 0] = 1
+    bits = ops.pack_mask_bits(kpm) if kpm is not None else None
+    pk = ops.pack_cross_kv(k, v, H)
+    x_dal, st = ops.dec_to_dal(raw, want_stats=True)
+    wf, bcf = ops.dec_pack_weight(w, g_, b_, bias)
+    one = ops.attention_cross_mfma_q(x_dal, B, st, 1e-12, wf, bcf, pk, Bkv, Tk, H, 0.125, kpm_bits=bits, out_dal=False)
+    qf = torch.nn.functional.layer_norm(raw.float(), (D,), g_, b_, 1e-12) @ w.float().t() + bias
+    kk, vv = k.float().repeat(G, 1, 1), v.float().repeat(G, 1, 1)
+    qh, kh, vh = qf.view(B, H, 1, 64), kk.view(B, Tk, H, 64).transpose(1, 2), vv.view(B, Tk, H, 64).transpose(1, 2)
+    s_ = (qh @ kh.transpose(2, 3)) * 0.125
+    if kpm is not None: s_ = s_.masked_fill(~kpm.bool().repeat(G, 1).view(B, 1, 1, Tk), torch.finfo(torch.float32).min)
+    full = (torch.softmax(s_, -1) @ vh).transpose(1, 2).reshape(B, D)
+    e = (one.float() - full).abs().max().item() / max(full.abs().max().item(), 0.05)
+    if e > 4e-2 or not torch.isfinite(one.float()).all():
+        bad += 1; print("BAD cross-q", G, Bkv, Tk, kpm is not None, e)
+print("fused cross-attention fuzz done, bad =", bad)
