@@ -427,12 +427,12 @@ static int gemm_nt_fill(GemmArgs& g, const cxr_gemm_nt_desc& d) {
     return CXR_OK;
 }
 
-// tile shape: narrow (128x64) when the last N tile would be mostly empty (N = 64, 192) or when 128x128 tiling gives fewer than ~1.5 tiles per CU
+// tile shape: narrow (128x64) when the last N tile would be mostly empty (N = 64, 192) or when 128x128 tiling gives at most one tile per CU
 static bool gemm_nt_narrow(int N, long tiles128) {
     static int force_bn = -1;         // tuning aid: CXR_GEMM_BN=64|128
     if (force_bn < 0) { const char* e = getenv("CXR_GEMM_BN"); force_bn = e ? atoi(e) : 0; }
     bool bn64 = (N % 128) != 0 && (N % 128) <= 64 && N < 1024;      // (a ragged last tile of a wide N -- the 30000-column LM head -- is 1 tile in 235)
-    if (tiles128 < 160) bn64 = true;
+    if (tiles128 <= 256) bn64 = true;           // at most one 128-wide tile per CU: twice as many half-width workgroups finish ~15 % sooner (scripts/gemm_bn_threshold.py)
     if (force_bn == 64) bn64 = true; else if (force_bn == 128) bn64 = false;
     return bn64;
 }

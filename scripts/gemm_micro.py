@@ -5,6 +5,8 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cxrmate_amd import ops
 BF = torch.bfloat16
+if os.environ.get("GEMM_MICRO_NOEXCL") == "1":
+    ops.gemm_exclusive(False)      # the tile kernels only, as in the backward passes (no persistent one-workgroup-per-CU kernels)
 shapes = [(4096, 4096, 4096, 0), (8192, 8192, 8192, 0),
           (36928, 384, 384, 0), (36928, 384, 384, 1), (36928, 1536, 384, 2), (36928, 1536, 384, 3), (36928, 384, 1536, 1), (9280, 384, 384, 0),
           (147456, 192, 192, 0), (147456, 768, 192, 2), (147456, 192, 768, 1), (589824, 64, 64, 0), (589824, 256, 64, 2), (589824, 64, 256, 1),
