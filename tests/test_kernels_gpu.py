@@ -736,6 +736,16 @@ def test_im2col_pixels_matches_conv(ops):
     ref = torch.nn.functional.conv2d(px, w.to(BF).float(), stride=4, padding=2)
     ref = ref.flatten(2).transpose(1, 2).reshape(-1, 64)
     close(out, ref, what="patch conv 7x7")
+    # the col matrix itself, bit for bit (bf16 of the gathered pixel, zero padding): the row-staged kernel, odd widths (scalar staging), other
+    # kernel sizes / strides, and a geometry too large for LDS staging (the gather kernel)
+    for (Bn, Cin, H, W, ks, st, pad, kpad) in ((2, 3, 384, 384, 7, 4, 2, 192), (3, 3, 50, 37, 7, 4, 2, 152), (2, 4, 33, 64, 3, 2, 1, 40), (1, 2, 20, 24, 5, 1, 2, 56),
+                                                (1, 16, 40, 1024, 7, 4, 2, 784)):
+        px = dev(rnd(Bn, Cin, H, W, seed=H + W))
+        col, Ho, Wo = ops.im2col_pixels(px, ks, st, pad, kpad)
+        un = torch.nn.functional.unfold(px, ks, padding=pad, stride=st).transpose(1, 2).reshape(-1, Cin * ks * ks)      # k = c*KS*KS + ky*KS + kx
+        assert (Ho, Wo) == ((H + 2 * pad - ks) // st + 1, (W + 2 * pad - ks) // st + 1)
+        assert torch.equal(col[:, :Cin * ks * ks], un.to(BF)), (Bn, Cin, H, W, ks, st, pad)
+        assert float(col[:, Cin * ks * ks:].float().abs().sum()) == 0
 
 
 def test_im2col_tokens_and_col2im(ops):
