@@ -25,7 +25,7 @@ def _p(t):
 _DEV_INDEX = None
 
 
-_SIDE_RAW = None        # raw handle of the weight-gradient stream while a _side_launch block is open (see below)
+_SIDE_RAW = None        # raw handle of the weight-gradient stream while wgrad_flush issues collected launches (see below)
 
 
 def _s():
@@ -221,6 +221,7 @@ class _on_wgrad_stream:
     def __enter__(self):
         self.side = WGRAD_STREAM
         if self.side is not None:
+            wgrad_flush()                                  # (launches collected by _side_defer come first on the side stream)
             self.side.wait_stream(torch.cuda.current_stream())
             self.ctx = torch.cuda.stream(self.side)
             self.ctx.__enter__()
@@ -235,40 +236,53 @@ class _on_wgrad_stream:
         return False
 
 
-class _side_launch:
-    """Light variant of _on_wgrad_stream for blocks that only issue C-ABI launches and allocate nothing: the launches get the side stream's raw
-    handle (no torch stream switch), ordering is one event record + wait, and the operands are kept alive until the next wgrad_join() instead
-    of record_stream (after the join nothing on the side stream can still read them). The torch context manager cost ~25 us of host time per
-    weight-gradient launch -- 250 of them per step, in the backward pass where the GPU waits for the host."""
-    _pending = []
+_WGRAD_BATCH = max(1, int(__import__("os").environ.get("CXR_WGRAD_BATCH", "4")))
+_SIDE_DEFERRED = []     # launches waiting for the next fork point (closures issuing C-ABI launches on the side stream)
+_SIDE_PENDING = []      # their operands, kept alive until the next wgrad_join()
 
-    def __init__(self, *tensors):
-        self.tensors = tensors
 
-    def __enter__(self):
-        global _SIDE_RAW
-        self.side = WGRAD_STREAM
-        if self.side is not None:
-            ev = torch.cuda.Event()
-            ev.record()                                    # main stream position: the operands are complete
-            self.side.wait_event(ev)
-            _SIDE_RAW = self.side.cuda_stream
-        return self
+def _side_defer(fn, *tensors):
+    """Issue `fn` (C-ABI launches only, nothing allocated) on the weight-gradient stream. Ordering against the main stream costs an event record
+    on the MAIN stream -- a barrier packet that keeps the next main-stream kernel from starting under the tail of the previous one: ~9 us each,
+    145 of them = 1.3 ms of a 41-ms step when every weight-gradient launch had its own. The launches are therefore collected and issued in
+    batches of CXR_WGRAD_BATCH behind ONE event (wgrad_flush); every synchronisation with the side stream flushes first. Operands are kept alive
+    until the next wgrad_join() instead of record_stream (after the join nothing on the side stream can still read them); as before, nothing may
+    overwrite an operand in place before that join -- the side stream runs arbitrarily far behind the main stream."""
+    if WGRAD_STREAM is None:
+        fn()
+        return
+    _SIDE_DEFERRED.append(fn)
+    _SIDE_PENDING.append(tensors)
+    if len(_SIDE_DEFERRED) >= _WGRAD_BATCH:
+        wgrad_flush()
 
-    def __exit__(self, *exc):
-        global _SIDE_RAW
-        if self.side is not None:
-            _SIDE_RAW = None
-            _side_launch._pending.append(self.tensors)
-        return False
+
+def wgrad_flush():
+    """Issue the collected weight-gradient launches: one event on the main stream (their operands are complete), the side stream waits for it."""
+    global _SIDE_RAW
+    if not _SIDE_DEFERRED:
+        return
+    side = WGRAD_STREAM
+    assert side is not None, "deferred weight-gradient launches outlived their stream (wgrad_overlap exits through wgrad_flush)"
+    ev = torch.cuda.Event()
+    ev.record()
+    side.wait_event(ev)
+    _SIDE_RAW = side.cuda_stream
+    try:
+        for fn in _SIDE_DEFERRED:
+            fn()
+    finally:
+        _SIDE_RAW = None
+        _SIDE_DEFERRED.clear()
 
 
 def wgrad_join(stream=None):
     """stream: the weight-gradient stream to join when called outside the wgrad_overlap context that launched on it (deferred joins)"""
+    wgrad_flush()
     stream = WGRAD_STREAM if stream is None else stream
     if stream is not None:
         torch.cuda.current_stream().wait_stream(stream)
-    _side_launch._pending.clear()
+    _SIDE_PENDING.clear()
     gemm_exclusive(True)                                   # nothing runs beside the main stream any more
 
 
@@ -299,6 +313,7 @@ def wgrad_mark():
     (the W^T transposes of a forward pass) instead of joining the whole weight-gradient backlog."""
     if WGRAD_STREAM is None:
         return None
+    wgrad_flush()
     ev = torch.cuda.Event()
     ev.record(WGRAD_STREAM)
     return ev
@@ -311,8 +326,7 @@ def wgrad_wait(ev):
 
 def linear_bwd_weight(dy, x, dw, db=None):
     """dw[N,K] += dy[M,N]^T @ x[M,K]; db[N] += colsum(dy)   (one split-K TN kernel; no transposes)."""
-    with _side_launch(dy, x, dw, db):
-        gemm_tn(dy, x, dw, dbias=db)
+    _side_defer(lambda: gemm_tn(dy, x, dw, dbias=db), dy, x, dw, db)
 
 
 def linear_bwd_input(dy, w_t, **kw):
@@ -503,8 +517,7 @@ def layernorm_bwd(x, dy, gamma, stats, dgamma, dbeta, add=None, out=None, drop=N
              int(drop[2]) if drop is not None else 0, int(drop[3]) if drop is not None else (int(row_scale[1]) if row_scale is not None else 1),
              int(drop[4]) if drop is not None else 0, _p(row_scale[0]) if row_scale is not None else None, _s())
     if side:
-        with _side_launch(ws, dgamma, dbeta):
-            LIB.call("cxr_layernorm_bwd_reduce", _p(ws), rows, C, _p(dgamma), _p(dbeta), _s())
+        _side_defer(lambda: LIB.call("cxr_layernorm_bwd_reduce", _p(ws), rows, C, _p(dgamma), _p(dbeta), _s()), ws, dgamma, dbeta)
     return (out, out2) if second else out
 
 
@@ -820,9 +833,9 @@ def bert_embed(ids, tt, pid, word, typ, posw, gamma, beta, eps, T, pos_offset=0,
 
 
 def bert_embed_bwd(dsum, ids, tt, pid, dword, dtype_, dpos, T, pos_offset, padding_idx):
-    with _side_launch(dsum, ids, tt, pid):                       # embedding-table gradients only feed the optimiser: weight-gradient stream
-        LIB.call("cxr_bert_embed_bwd", _p(dsum), _p(ids), _p(tt), _p(pid), _p(dword), _p(dtype_), _p(dpos), ids.numel(), T, pos_offset,
-                 int(padding_idx), dsum.shape[1], _s())
+    # embedding-table gradients only feed the optimiser: weight-gradient stream
+    _side_defer(lambda: LIB.call("cxr_bert_embed_bwd", _p(dsum), _p(ids), _p(tt), _p(pid), _p(dword), _p(dtype_), _p(dpos), ids.numel(), T, pos_offset,
+                                 int(padding_idx), dsum.shape[1], _s()), dsum, ids, tt, pid, dword, dtype_, dpos)
 
 
 _SPECIAL_CACHE = {}

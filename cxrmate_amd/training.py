@@ -108,10 +108,12 @@ class wgrad_overlap:
             # CXR_WGRAD_PRIORITY: stream priority of the weight-gradient stream (default: torch's default = lowest; negative = higher)
             prio = int(os.environ.get("CXR_WGRAD_PRIORITY", "0"))
             wgrad_overlap._stream = torch.cuda.Stream(priority=prio)
+        ops.wgrad_flush()
         self.prev, ops.WGRAD_STREAM = ops.WGRAD_STREAM, wgrad_overlap._stream
         return self
 
     def __exit__(self, *exc):
+        ops.wgrad_flush()                                   # launches still collected for this stream are issued on it
         ops.WGRAD_STREAM = self.prev
         return False
 
@@ -145,12 +147,14 @@ def _tf_train_step(model, opt, pixel_values, decoder_input_ids, decoder_attentio
     if sync and enc_trainable:
         # decoder parameters sit after the encoder's in the flat buffer: reduce them while the encoder backward runs (the reducer's stream
         # waits for the weight-gradient stream, the main stream does not)
+        ops.wgrad_flush()
         opt.reducer.reduce_range(opt.split, model._param_total, after=ops.WGRAD_STREAM)
     early = None
     if sync and enc_trainable and opt.enc_tail:
         # ... and the last encoder stage + projection head (93 % of the encoder's parameters) while the first stages are still in backward
         def early(s):
             if s == opt.enc_last_stage:
+                ops.wgrad_flush()
                 opt.reducer.reduce_range(opt.enc_tail, opt.split, after=ops.WGRAD_STREAM)
     _phase_encbwd(model, esaved, denc, early)
     if sync:

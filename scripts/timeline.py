@@ -39,3 +39,19 @@ for g in sorted(gaps, reverse=True)[:12]:
     print(f"   {g[0]/1e3:8.1f} us after {g[1]:40s} before {g[2]}")
 hist = collections.Counter(min(int(g[0] / 1000), 20) for g in gaps)
 print("gap histogram (us: count):", dict(sorted(hist.items())))
+# tail of the weight-gradient queue: side-queue work that runs after the main queue's last backward kernel (the optimiser waits for both)
+if len(byq) >= 2:
+    qs = sorted(byq.items(), key=lambda kv: -len(kv[1]))
+    mainq, sideq = qs[0][1], qs[1][1]
+    side_end = max(r['e'] for r in sideq)
+    before = [r for r in mainq if r['e'] <= side_end and not r['Kernel_Name'].startswith('adamw')]
+    after = [r for r in mainq if r['s'] >= side_end]
+    last_main = max((r['e'] for r in before), default=t0)
+    print(f"side-queue end - last main-queue kernel end before it: {(side_end - last_main) / 1e3:.1f} us; first main kernel after the side queue ends: "
+          f"{after[0]['Kernel_Name'][:40] if after else None} at +{(after[0]['s'] - side_end) / 1e3 if after else 0:.1f} us")
+    # side-queue idle time inside the backward window (from its first kernel to its last)
+    s0 = min(r['s'] for r in sideq)
+    busy = sum(r['e'] - r['s'] for r in sideq)
+    print(f"side queue: window {(side_end - s0) / 1e6:.3f} ms, busy {busy / 1e6:.3f} ms")
+    tailk = sorted(sideq, key=lambda r: r['e'])[-6:]
+    for r in tailk: print(f"   side tail: {r['Kernel_Name'][:50]:50s} start +{(r['s'] - last_main) / 1e3:8.1f} us  dur {(r['e'] - r['s']) / 1e3:7.1f} us")
