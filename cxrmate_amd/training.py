@@ -46,14 +46,21 @@ class FusedAdamW:
         for lo, hi in self.ranges:
             self.model.gflat[lo:hi].zero_()
 
-    def step(self, gscale: float = 1.0):
+    def step(self, gscale: float = 1.0, lo_bound: int = None, hi_bound: int = None, begin: bool = True, finish: bool = True):
+        """lo_bound / hi_bound: only the part of the flat buffer in [lo_bound, hi_bound) -- a step may be issued in two pieces (begin=True on the first:
+        the step counter advances once; finish=True on the last), e.g. the decoder's parameters as soon as their gradients are complete."""
         mo = self.model
-        ops.increment_(self.t_dev)
+        if begin:
+            ops.increment_(self.t_dev)
         for lo, hi in self.ranges:
-            ops.adamw_step(mo.flat32[lo:hi], mo.gflat[lo:hi], self.m[lo:hi], self.v[lo:hi], mo.flat16[lo:hi], self.lr, self.betas[0],
-                           self.betas[1], self.eps, self.wd, 0, gscale, step_dev=self.t_dev)
-        mo.shadow_dirty = False
-        mo.shadow_version += 1              # engines re-derive their per-version weight re-layouts (BN fold, LoRA merge)
+            lo = lo if lo_bound is None else max(lo, lo_bound)
+            hi = hi if hi_bound is None else min(hi, hi_bound)
+            if lo < hi:
+                ops.adamw_step(mo.flat32[lo:hi], mo.gflat[lo:hi], self.m[lo:hi], self.v[lo:hi], mo.flat16[lo:hi], self.lr, self.betas[0],
+                               self.betas[1], self.eps, self.wd, 0, gscale, step_dev=self.t_dev)
+        if finish:
+            mo.shadow_dirty = False
+            mo.shadow_version += 1          # engines re-derive their per-version weight re-layouts (BN fold, LoRA merge)
 
 
 # ---------------------------------------------------------------------------------------------------- step phases
@@ -96,6 +103,7 @@ def _phase_encbwd(model, esaved, denc, on_stage_done=None):
     ops.wgrad_join()
 
 
+_EARLY_DEC_ADAMW = os.environ.get("CXR_EARLY_DEC_ADAMW", "1") != "0"      # A/B switch: 0 = one AdamW launch at the end of the step
 _BF16_LOGITS = os.environ.get("CXR_BF16_LOGITS", "1") != "0"      # training step: bf16 logits as under the reference's autocast (0: fp32)
 
 
@@ -156,11 +164,25 @@ def _tf_train_step(model, opt, pixel_values, decoder_input_ids, decoder_attentio
             if s == opt.enc_last_stage:
                 ops.wgrad_flush()
                 opt.reducer.reduce_range(opt.enc_tail, opt.split, after=ops.WGRAD_STREAM)
+    gscale = 1.0 / (world * k)
+    side = ops.WGRAD_STREAM
+    dec_early = _EARLY_DEC_ADAMW and not sync and enc_trainable and side is not None
+    if dec_early:
+        # one rank: the decoder's gradients are final once its weight-gradient kernels are through -- its 81 M parameters (0.43 ms of AdamW at the
+        # HBM rate) are updated on the weight-gradient stream, behind those kernels, while the main stream runs the encoder backward. Nothing
+        # reads decoder weights before the next forward; the join at the end of the encoder backward orders the update before it.
+        ops.wgrad_flush()
+        side.wait_stream(torch.cuda.current_stream())              # every decoder dX kernel (they read the weights) is in front of the update
+        with torch.cuda.stream(side):
+            opt.step(gscale=gscale, lo_bound=opt.split, begin=True, finish=False)
     _phase_encbwd(model, esaved, denc, early)
     if sync:
         opt.reducer.reduce_range(0, opt.split if enc_trainable else model._param_total)      # whatever has not been started yet
         opt.reducer.wait()
-    opt.step(gscale=1.0 / (world * k))
+    if dec_early:
+        opt.step(gscale=gscale, hi_bound=opt.split, begin=False, finish=True)
+    else:
+        opt.step(gscale=gscale)
     return loss
 
 
