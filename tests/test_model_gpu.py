@@ -244,14 +244,16 @@ def test_graphed_tf_step_leaves_no_stale_weight_copies(M):
     np.testing.assert_allclose(res[True], res[False], rtol=2e-2)
 
 
-def test_training_step_gradients_do_not_depend_on_stream_overlap(M):
+def test_training_step_gradients_do_not_depend_on_stream_overlap(M, monkeypatch):
     """The eager training step puts every weight-gradient kernel (and the embedding-table / LayerNorm parameter sums) on a side stream and joins
     it once per step: the gradients it leaves in the flat buffer must equal those of the same step issued on ONE stream (fp32 atomics reorder,
     nothing else), and the bf16-logits loss must match the fp32-logits loss."""
     from cxrmate_amd import ops, training
     g, cfg, sd, x, inp, lab, am, tt = gu.tf_single_case()
     res = {}
-    for overlap in (True, False):
+    # overlap = the number of weight-gradient launches issued behind one fork event (ops._side_defer; 1000: only the joins flush), 0 = one stream
+    for overlap in (4, 1, 1000, 0):
+        monkeypatch.setattr(ops, "_WGRAD_BATCH", max(overlap, 1))
         m = M.SingleCXREncoderDecoderModel(cfg, seed=None)
         m.load_state_dict(sd)
         opt = training.FusedAdamW(m, lr=0.0)
@@ -268,11 +270,37 @@ def test_training_step_gradients_do_not_depend_on_stream_overlap(M):
                 training._phase_encbwd(m, esaved, denc)
             torch.cuda.synchronize()
             res.setdefault(overlap, []).append((float(loss.item()), m.gflat.clone()))
-    (l0, g0) = res[False][0]
-    for l1, g1 in res[True] + res[False][1:]:
+            assert not ops._SIDE_DEFERRED and not ops._SIDE_PENDING                    # every step ends flushed and joined
+    (l0, g0) = res[0][0]
+    for l1, g1 in res[4] + res[1] + res[1000] + res[0][1:]:
         assert abs(l1 - l0) < 1e-5
         err = float((g1 - g0).norm() / g0.norm())
         assert err < 2e-4, err
+
+
+def test_early_decoder_adamw_equals_the_single_update(M, monkeypatch):
+    """On one rank tf_train_step updates the decoder's parameters on the weight-gradient stream while the encoder backward runs and the encoder's at
+    the end (training._EARLY_DEC_ADAMW); the step counter advances once. Same parameters, moments and losses as one AdamW launch at the end of the
+    step, bit for bit where the gradient kernels are deterministic (the loss trajectory otherwise)."""
+    from cxrmate_amd import training
+    g, cfg, sd, x, inp, lab, am, tt = gu.tf_single_case()
+    out = {}
+    for early in (True, False):
+        monkeypatch.setattr(training, "_EARLY_DEC_ADAMW", early)
+        m = M.SingleCXREncoderDecoderModel(cfg, seed=None)
+        m.load_state_dict(sd)
+        m.eval()                                                    # no dropout seeds: the two runs see the same network
+        opt = training.FusedAdamW(m, lr=1e-3)
+        ttd = m.token_ids_to_token_type_ids(inp, [gu.SEP])
+        losses = [float(training.tf_train_step(m, opt, x.cuda(), inp.cuda(), am.cuda(), ttd, lab.cuda(), gu.PAD)) for _ in range(3)]
+        torch.cuda.synchronize()
+        out[early] = (losses, m.flat32.clone(), opt.m.clone(), opt.v.clone(), opt.t)
+    assert out[True][4] == out[False][4] == 3
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-4)
+    assert out[True][0][-1] < out[True][0][0]
+    for a, b in zip(out[True][1:4], out[False][1:4]):
+        err = float((a - b).norm() / b.norm())
+        assert err < 1e-4, err
 
 
 def _hash_masks(m, cfg, B, T, S, enc_seed, dec_seed, Bn):
