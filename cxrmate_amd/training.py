@@ -68,7 +68,15 @@ def _phase_fwd_loss_decbwd(model, opt, px, ids, am, tt, lab, pad_token_id, pos, 
     """zero grads -> encoder fwd -> decoder fwd -> fused CE (loss + dlogits) -> decoder bwd. Returns (loss, esaved, denc)."""
     dev = model.device
     if zero:
-        opt.zero_grad()
+        side = ops.WGRAD_STREAM
+        if side is not None and _ZERO_ON_SIDE:
+            # the gradient buffer is not touched before the decoder backward, which starts by joining the weight-gradient stream: the five fill
+            # kernels (0.1 ms) run there, under the forward pass
+            side.wait_stream(torch.cuda.current_stream())          # the previous optimiser step has read the gradients
+            with torch.cuda.stream(side):
+                opt.zero_grad()
+        else:
+            opt.zero_grad()
     px = model._pixels(px)
     multi = px.dim() == 5
     flat = px.view(-1, *px.shape[-3:]) if multi else px
@@ -103,6 +111,7 @@ def _phase_encbwd(model, esaved, denc, on_stage_done=None):
     ops.wgrad_join()
 
 
+_ZERO_ON_SIDE = os.environ.get("CXR_ZERO_ON_SIDE", "1") != "0"              # A/B switch: 0 = gradient zeroing on the main stream
 _EARLY_DEC_ADAMW = os.environ.get("CXR_EARLY_DEC_ADAMW", "1") != "0"      # A/B switch: 0 = one AdamW launch at the end of the step
 _BF16_LOGITS = os.environ.get("CXR_BF16_LOGITS", "1") != "0"      # training step: bf16 logits as under the reference's autocast (0: fp32)
 
