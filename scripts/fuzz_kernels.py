@@ -2,7 +2,7 @@
 import os, sys, torch, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cxrmate_amd import ops
-torch.manual_seed(0); random.seed(0)
+_SEED = int(os.environ.get("FUZZ_SEED", "0")); torch.manual_seed(_SEED); random.seed(_SEED)
 BF = torch.bfloat16
 def ref_attn(q, k, v, H, scale, kpm, causal, shift):
     B, Tq, D = q.shape; Tk = k.shape[1]
