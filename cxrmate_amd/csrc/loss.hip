@@ -68,11 +68,9 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
 // BF16IN: the logits are bf16 (what the LM head produces under the reference's bf16 autocast; the softmax still runs in fp32): half the bytes of
 // the largest tensor of a training step, written by the LM-head GEMM and read here.
 template <bool BF16IN>
-__global__ __launch_bounds__(1024) void softmax_ce_reg_kernel(const void* __restrict__ logits, long ld, const long* __restrict__ labels,
-                                                              long ignore_index, const float* __restrict__ thr, const float* __restrict__ row_w,
-                                                              float* __restrict__ row_loss, bf16_t* __restrict__ dlogits, long lddl, int V) {
-    __shared__ float sh[16];
-    __shared__ float xl;
+__device__ __forceinline__ void softmax_ce_reg_body(const void* __restrict__ logits, long ld, const long* __restrict__ labels,
+                                                    long ignore_index, const float* __restrict__ thr, const float* __restrict__ row_w,
+                                                    float* __restrict__ row_loss, bf16_t* __restrict__ dlogits, long lddl, int V, float* sh, float& xl) {
     const long r = blockIdx.x;
     const float* x = reinterpret_cast<const float*>(logits) + r * ld;
     const bf16_t* x16 = reinterpret_cast<const bf16_t*>(logits) + r * ld;
@@ -171,13 +169,112 @@ __global__ __launch_bounds__(1024) void softmax_ce_reg_kernel(const void* __rest
     }
 }
 
+template <bool BF16IN>
+__global__ __launch_bounds__(1024) void softmax_ce_reg_kernel(const void* __restrict__ logits, long ld, const long* __restrict__ labels,
+                                                                              long ignore_index, const float* __restrict__ thr,
+                                                                              const float* __restrict__ row_w, float* __restrict__ row_loss,
+                                                                              bf16_t* __restrict__ dlogits, long lddl, int V) {
+    __shared__ float sh[16];
+    __shared__ float xl;
+    softmax_ce_reg_body<BF16IN>(logits, ld, labels, ignore_index, thr, row_w, row_loss, dlogits, lddl, V, sh, xl);
+}
+
+// bf16 rows of a multiple of 8 columns (the training step's 30000-column logits): the row stays PACKED in registers (4 x 16 bytes per thread) and the
+// exponentials are recomputed for the gradient instead of kept as fp32 -- 64 registers = 8 waves per SIMD, so TWO 1024-thread workgroups share a CU and
+// one's load / store phase runs under the other's reductions (the fp32-resident version: 72 registers, one workgroup per CU). All four loads are
+// unconditional (chunks past the row re-read its last one and are masked) and in flight together. Same arithmetic as softmax_ce_reg_kernel<true>.
+__global__ __launch_bounds__(1024, 8) void softmax_ce_bf16row_kernel(const bf16_t* __restrict__ logits, long ld, const long* __restrict__ labels,
+                                                                     long ignore_index, const float* __restrict__ thr, const float* __restrict__ row_w,
+                                                                     float* __restrict__ row_loss, bf16_t* __restrict__ dlogits, long lddl, int V) {
+    __shared__ float sh[16];
+    __shared__ float xl;
+    const long r = blockIdx.x;
+    const bf16_t* x16 = logits + r * ld;
+    const long label = labels[r];
+    const int tid = threadIdx.x;
+    if (label == ignore_index) {
+        if (row_loss && tid == 0) row_loss[r] = 0.f;
+        if (dlogits) for (int v = tid * 8; v < (int)lddl; v += 8192)
+            *reinterpret_cast<uint4*>(dlogits + r * lddl + v) = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const float t = thr ? thr[r] : -INFINITY;
+    uint4 raw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = tid * 8 + 8192 * i;
+        raw[i] = *reinterpret_cast<const uint4*>(x16 + (v < V ? v : V - 8));
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (tid * 8 + 8192 * i >= V) continue;
+        float f[8];
+        unpack8(raw[i], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (f[j] >= t) mx = fmaxf(mx, f[j]);
+    }
+    mx = group_max<64>(mx);
+    if ((tid & 63) == 0) sh[tid >> 6] = mx;
+    __syncthreads();
+    mx = sh[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, sh[w]);
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = tid * 8 + 8192 * i;
+        if (v >= V) continue;
+        float f[8], e[8];
+        unpack8(raw[i], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            e[j] = f[j] >= t ? __expf(f[j] - mx) : 0.f;
+            if (v + j == (int)label) xl = f[j];
+        }
+        s += (e[0] + e[1]) + (e[2] + e[3]);                              // (the summation order of softmax_ce_reg_kernel: bit-identical results)
+        s += (e[4] + e[5]) + (e[6] + e[7]);
+    }
+    s = group_sum<64>(s);
+    if ((tid & 63) == 0) sh[tid >> 6] = s;
+    __syncthreads();
+    s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += sh[w];
+    if (row_loss && tid == 0) row_loss[r] = mx + __logf(s) - xl;
+    if (dlogits) {
+        const float w = row_w[r], inv = 1.0f / s;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = tid * 8 + 8192 * i;
+            if (v >= (int)lddl) continue;                                   // columns [V, lddl) are zero padding (K of the next GEMM)
+            float f[8], o[8];
+            unpack8(raw[i], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float gv = (f[j] >= t ? __expf(f[j] - mx) : 0.f) * inv;
+                if (v + j == (int)label) gv -= 1.0f;
+                o[j] = v < V ? gv * w : 0.f;
+            }
+            *reinterpret_cast<uint4*>(dlogits + r * lddl + v) = pack8(o);
+        }
+    }
+}
+
 extern "C" int cxr_softmax_ce(const void* logits, long ld, const long* labels, long ignore_index, const float* thr, const float* row_w,
                               float* row_loss, void* dlogits, long lddl, long R, int V, int logits_bf16, hipStream_t stream) {
     if (R <= 0 || V <= 0 || (dlogits && (!row_w || (lddl % 8)))) return CXR_ERR_ARG;
     if (logits_bf16) {
         if (V > 32768 || lddl > 32768 || (ld % 8) || (((size_t)logits) % 16)) return CXR_ERR_ARG;
-        CXR_LAUNCH((softmax_ce_reg_kernel<true>), dim3((unsigned)R), dim3(1024), 0, stream, logits, ld, labels, ignore_index, thr, row_w, row_loss,
-                           (bf16_t*)dlogits, lddl, V);
+        static int row_on = -1;                                    // CXR_CE_BF16ROW=0: the fp32-resident kernel (A/B)
+        if (row_on < 0) { const char* e = getenv("CXR_CE_BF16ROW"); row_on = (e && e[0] == '0') ? 0 : 1; }
+        if (row_on && (V & 7) == 0 && V >= 8)
+            CXR_LAUNCH(softmax_ce_bf16row_kernel, dim3((unsigned)R), dim3(1024), 0, stream, (const bf16_t*)logits, ld, labels, ignore_index, thr, row_w,
+                       row_loss, (bf16_t*)dlogits, lddl, V);
+        else
+            CXR_LAUNCH((softmax_ce_reg_kernel<true>), dim3((unsigned)R), dim3(1024), 0, stream, logits, ld, labels, ignore_index, thr, row_w, row_loss,
+                       (bf16_t*)dlogits, lddl, V);
     } else if (V <= 32768 && lddl <= 32768 && (ld % 4) == 0 && (((size_t)logits) % 16) == 0)
         CXR_LAUNCH((softmax_ce_reg_kernel<false>), dim3((unsigned)R), dim3(1024), 0, stream, logits, ld, labels, ignore_index, thr, row_w, row_loss,
                            (bf16_t*)dlogits, lddl, V);
