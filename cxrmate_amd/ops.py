@@ -276,6 +276,12 @@ def wgrad_flush():
         _SIDE_DEFERRED.clear()
 
 
+def wgrad_discard():
+    """Drop collected launches without issuing them (error path of training.wgrad_overlap)."""
+    _SIDE_DEFERRED.clear()
+    _SIDE_PENDING.clear()
+
+
 def wgrad_join(stream=None):
     """stream: the weight-gradient stream to join when called outside the wgrad_overlap context that launched on it (deferred joins)"""
     wgrad_flush()

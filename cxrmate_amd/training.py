@@ -130,8 +130,13 @@ class wgrad_overlap:
         return self
 
     def __exit__(self, *exc):
-        ops.wgrad_flush()                                   # launches still collected for this stream are issued on it
-        ops.WGRAD_STREAM = self.prev
+        try:
+            if exc[0] is None:
+                ops.wgrad_flush()                           # launches still collected for this stream are issued on it
+            else:
+                ops.wgrad_discard()                         # the step failed: nothing of it is launched later by an unrelated step
+        finally:
+            ops.WGRAD_STREAM = self.prev
         return False
 
 

@@ -291,3 +291,20 @@ def test_reward_and_chexbert_constructors_follow_the_reference_signatures(tmp_pa
         CheXbert(str(tmp_path), str(tmp_path), "chexbert.pth", "cpu")           # tools/chexbert.py:10,34-35
     with pytest.raises(TypeError):
         CheXbert("a", "b", "cpu")
+
+
+def test_failed_step_leaves_no_deferred_weight_gradient_launches(monkeypatch):
+    """training.wgrad_overlap collects weight-gradient launches (ops._side_defer) and issues them in batches; a step that raises must not leave
+    launches behind for the next step to issue, and the stream selection is restored."""
+    from cxrmate_amd import ops, training
+    monkeypatch.setenv("CXR_WGRAD_OVERLAP", "0")                    # no GPU here: the context runs without a side stream
+    ran = []
+    ops._side_defer(lambda: ran.append(1))                            # no side stream: runs inline
+    assert ran == [1] and not ops._SIDE_DEFERRED
+    prev = ops.WGRAD_STREAM
+    with pytest.raises(ValueError):
+        with training.wgrad_overlap():
+            ops._SIDE_DEFERRED.append(lambda: ran.append(2))          # (as if collected for a side stream)
+            ops._SIDE_PENDING.append(())
+            raise ValueError("step failed")
+    assert ran == [1] and not ops._SIDE_DEFERRED and not ops._SIDE_PENDING and ops.WGRAD_STREAM is prev
