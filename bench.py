@@ -427,7 +427,11 @@ def tf_dropin(args, dev, n_images, steps=6):
     model = (MultiCXREncoderDecoderModel if n_images > 1 else SingleCXREncoderDecoderModel)(cfg, device=dev, seed=0)
     if not args.eval_mode:
         model.train()
-    opt = torch.optim.AdamW(model.parameters(), lr=5e-5)
+    # configure_optimizers (single.py:426-431) with the optimiser class this build offers for it: torch.optim.AdamW's interface on the fused kernel
+    # (cxrmate_amd/optim.py); CXR_DROPIN_TORCH_ADAMW=1 keeps torch's own class (its foreach kernels cost ~3.5 ms per step on 112 M parameters)
+    from cxrmate_amd.optim import AdamW as FusedTorchAdamW
+    torch_adamw = os.environ.get("CXR_DROPIN_TORCH_ADAMW") == "1"
+    opt = (torch.optim.AdamW if torch_adamw else FusedTorchAdamW)(model.parameters(), lr=5e-5)
     px, inp, am, lab = synth_batch(B, T, V, dev, 1000, n_images)
 
     def step():
@@ -443,8 +447,9 @@ def tf_dropin(args, dev, n_images, steps=6):
         step()
     dt, loss = timed(step, steps, 1, dev)
     return {"ms_per_step": dt / steps * 1e3, "tokens_per_s": B * T * steps / dt, "steps": steps, "loss": float(loss.item()),
+            "optimizer": "torch.optim.AdamW" if torch_adamw else "cxrmate_amd.optim.AdamW (torch.optim.Optimizer subclass on the fused kernel)",
             "what": "reference TF caller sequence on the drop-in classes: model(...).logits (fp32 [B,T,30000], autograd bridges) -> "
-                    "F.cross_entropy(logits.permute(0,2,1), labels, ignore_index=pad) -> loss.backward() -> torch.optim.AdamW.step(), "
+                    "F.cross_entropy(logits.permute(0,2,1), labels, ignore_index=pad) -> loss.backward() -> optimizer.step(), "
                     f"{B} studies x {n_images} images, T = {T}, " + ("model.eval()" if args.eval_mode else "model.train()")}
 
 
@@ -467,7 +472,9 @@ def scst_dropin(args, dev, steps=3):
         p.requires_grad = False                                                  # scst/gt_prompt.py:34-40
     for p in model.decoder.parameters():
         p.requires_grad = True
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=5e-6)
+    from cxrmate_amd.optim import AdamW as FusedTorchAdamW
+    torch_adamw = os.environ.get("CXR_DROPIN_TORCH_ADAMW") == "1"
+    opt = (torch.optim.AdamW if torch_adamw else FusedTorchAdamW)([p for p in model.parameters() if p.requires_grad], lr=5e-6)
     tok = transformers.PreTrainedTokenizerFast(tokenizer_file=os.path.join(ROOT, "tests", "golden", "tokenizer.json"), unk_token="[UNK]",
                                                pad_token="[PAD]", cls_token="[BOS]", sep_token="[SEP]", mask_token="[MASK]", bos_token="[BOS]",
                                                eos_token="[EOS]", additional_special_tokens=["[PMT]", "[PMT-SEP]", "[NPF]", "[NPI]"])
@@ -517,7 +524,8 @@ def scst_dropin(args, dev, steps=3):
     return {"ms_per_step": dt / steps * 1e3, "steps_per_sec": steps / dt, "steps": steps, "loss": float(loss.item()),
             "what": "reference SCST caller sequence (scst/gt_prompt.py:62-246) on the drop-in classes: tokenize_prompt, encoder, generate.__wrapped__("
                     "do_sample=True, output_scores=True, top_k=50), torch.stack(scores, -1) [16, 30000, 255] fp32, split_and_decode_sections + string reward "
-                    "twice, greedy generate, log_softmax / nll_loss, backward, torch.optim.AdamW on the decoder; 16 studies x 2 images, 255 new tokens"}
+                    "twice, greedy generate, log_softmax / nll_loss, backward, optimizer.step() on the decoder; 16 studies x 2 images, 255 new tokens",
+            "optimizer": "torch.optim.AdamW" if torch_adamw else "cxrmate_amd.optim.AdamW (torch.optim.Optimizer subclass on the fused kernel)"}
 
 
 def spawn_ranks(n):

@@ -40,7 +40,11 @@ __device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& x, int s) {
 }
 
 // (delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d] is produced by attn_bwd_dq_kernel, which runs first)
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdArgs a) {
+// NW = waves (32 keys each) per workgroup: 4, or 5 when a 160-key block covers ALL keys of an (image, head) -- CvT stage 3 has 145: as two 128-key
+// workgroups the second one staged every Q / dO tile again for 17 keys (one live wave out of four).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_kernel(const AttnBwdArgs a) {
+    constexpr int NT = NW * 64;
     __shared__ __attribute__((aligned(16))) bf16_t Qr[64 * RS];
     __shared__ __attribute__((aligned(16))) bf16_t Qt[64 * TS];
     __shared__ __attribute__((aligned(16))) bf16_t Dr[64 * RS];
@@ -48,12 +52,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdArgs
     __shared__ __attribute__((aligned(16))) float Ls[64];
     __shared__ __attribute__((aligned(16))) float Es[64];
     __shared__ __attribute__((aligned(16))) uint32_t Rk[64];          // dropout row keys of the tile's queries
-    __shared__ __attribute__((aligned(16))) bf16_t Os[4][32 * 64];    // per-wave tile for the row-contiguous dK / dV stores
+    __shared__ __attribute__((aligned(16))) bf16_t Os[NW][32 * 64];   // per-wave tile for the row-contiguous dK / dV stores
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx, head, b;
     xcd_block_remap(bx, head, b);                                  // the key blocks of one (image, head) run on ONE XCD: its Q / dO stream stays in that L2
-    const int kb0 = bx * 128;
+    const int kb0 = bx * (NW * 32);
     const uint32_t drop_seed = a.drop_thr16 ? *a.drop_seed : 0u;
     const int kl = lane & 31, hh = lane >> 5;
     const int key = kb0 + wave * 32 + kl;
@@ -77,7 +81,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdArgs
     const bf16_t* dbase = a.dO + (long)b * a.o_bs + head * 64;
     const float* lbase = a.LSE + ((long)b * a.H + head) * a.Tq;
     const float* ebase = a.delta + ((long)b * a.H + head) * a.Tq;
-    const int srow0 = tid >> 3, srow1 = (256 + tid) >> 3, sc = tid & 7;
+    // 512 16-byte pieces per 64 x 64 tile: thread t stages piece t and piece NT + t (the second one exists for t < 512 - NT; its load is
+    // unconditional on a clamped index, only the LDS write is predicated)
+    const int pc1 = NT + tid < 512 ? NT + tid : 511;
+    const bool two = NT + tid < 512;
+    const int srow0 = tid >> 3, srow1 = pc1 >> 3, sc = tid & 7, sc1 = pc1 & 7;
     uint4 q0, q1, d0, d1;
     float lsev = 0.f;
 #define BWD_GLOAD_Q(tile)                                                                                   \
@@ -85,9 +93,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdArgs
         int r0_ = (tile) * 64 + srow0; r0_ = r0_ < a.Tq ? r0_ : a.Tq - 1;                                   \
         int r1_ = (tile) * 64 + srow1; r1_ = r1_ < a.Tq ? r1_ : a.Tq - 1;                                   \
         q0 = *reinterpret_cast<const uint4*>(qbase + (long)r0_ * a.q_rs + sc * 8);                          \
-        q1 = *reinterpret_cast<const uint4*>(qbase + (long)r1_ * a.q_rs + sc * 8);                          \
+        q1 = *reinterpret_cast<const uint4*>(qbase + (long)r1_ * a.q_rs + sc1 * 8);                         \
         d0 = *reinterpret_cast<const uint4*>(dbase + (long)r0_ * a.o_rs + sc * 8);                          \
-        d1 = *reinterpret_cast<const uint4*>(dbase + (long)r1_ * a.o_rs + sc * 8);                          \
+        d1 = *reinterpret_cast<const uint4*>(dbase + (long)r1_ * a.o_rs + sc1 * 8);                         \
         {   /* UNCONDITIONAL load (pointer select + clamped index): a load guarded by a per-lane condition makes hipcc branch around it and  */ \
             /* park s_waitcnt vmcnt(0) behind the branch -- which also waited for the tile prefetch just issued, in every iteration           */ \
             /* the value is only TOUCHED at the top of the next iteration: arithmetic on it here makes the wave wait for the prefetch now */ \
@@ -108,10 +116,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdArgs
     for (int s = 0; s < 4; ++s) asm volatile("" :: "v"(kf[s]), "v"(vf[s]));
     for (int tile = tile0; tile < ntiles; ++tile) {
         __syncthreads();
-        *reinterpret_cast<uint4*>(Qr + srow0 * RS + sc * 8) = q0; *reinterpret_cast<uint4*>(Qr + srow1 * RS + sc * 8) = q1;
-        *reinterpret_cast<uint4*>(Qt + srow0 * TS + sc * 8) = q0; *reinterpret_cast<uint4*>(Qt + srow1 * TS + sc * 8) = q1;
-        *reinterpret_cast<uint4*>(Dr + srow0 * RS + sc * 8) = d0; *reinterpret_cast<uint4*>(Dr + srow1 * RS + sc * 8) = d1;
-        *reinterpret_cast<uint4*>(Dt + srow0 * TS + sc * 8) = d0; *reinterpret_cast<uint4*>(Dt + srow1 * TS + sc * 8) = d1;
+        *reinterpret_cast<uint4*>(Qr + srow0 * RS + sc * 8) = q0; *reinterpret_cast<uint4*>(Qt + srow0 * TS + sc * 8) = q0;
+        *reinterpret_cast<uint4*>(Dr + srow0 * RS + sc * 8) = d0; *reinterpret_cast<uint4*>(Dt + srow0 * TS + sc * 8) = d0;
+        if (NT == 256 || two) {
+            *reinterpret_cast<uint4*>(Qr + srow1 * RS + sc1 * 8) = q1; *reinterpret_cast<uint4*>(Qt + srow1 * TS + sc1 * 8) = q1;
+            *reinterpret_cast<uint4*>(Dr + srow1 * RS + sc1 * 8) = d1; *reinterpret_cast<uint4*>(Dt + srow1 * TS + sc1 * 8) = d1;
+        }
         const bool inq = tile * 64 + (tid & 63) < a.Tq;
         if (tid < 64) Ls[tid] = inq ? lsev * 1.4426950408889634f : INFINITY;
         else if (tid < 128) Es[tid - 64] = inq ? lsev : 0.f;
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdArgs
                 dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[s], dP, 0, 0, 0);
             }
             // rows of this accumulator: q = 32*qs + 8*(r>>2) + 4*hh + (r&3): four consecutive queries per register quad -> float4 LDS reads
-            const bool fast = (a.kpm == nullptr) && !a.causal && (kb0 + 128 <= a.Tk);       // block-uniform
+            const bool fast = (a.kpm == nullptr) && !a.causal && (kb0 + NW * 32 <= a.Tk);       // block-uniform
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int qb4 = qs * 32 + 8 * g4 + 4 * hh;
@@ -615,6 +625,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq2_kernel(const AttnBwdA
     }
 }
 
+// (Measured and removed in round 4: the dK / dV kernel with 5 / 6 / 8 waves of 32 keys sharing ONE double-buffered Q / dO tile stream -- half the LDS
+// staging writes per wave, one barrier per tile instead of two, no nearly empty second workgroup at Tk = 145; 88 KB of LDS = one workgroup per CU.
+// Bit-identical and SLOWER on every shape: stage 1 backward 1478 -> 1646 us (dQ + dK/dV), stage 2 364 -> 436, stage 3 94 -> 106, decoder self 59 -> 67,
+// cross 216 -> 256; TF step +1.0 ms on the same box. Two independent 4-wave workgroups per CU overlap one another's staging and math phases; eight
+// waves behind one barrier stage together and compute together, and the matrix pipe idles through every staging phase.)
 // (Measured and removed in round 3: a dK / dV kernel with 64 keys per wave -- every Q / dO fragment feeding two MFMAs, dK / dV of both key blocks in
 // 128 accumulator registers, double-buffered tiles, one barrier per tile, ~480 registers = one wave per SIMD. Bit-identical to attn_bwd_dkdv_kernel and
 // 8-30 % SLOWER (stage 1 backward 1479 -> 1843 us, stage 2 364 -> 491, stage 3 94 -> 103): with a single wave per SIMD nothing runs under the
@@ -657,7 +672,12 @@ extern "C" int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, co
     } else {
         CXR_LAUNCH(attn_bwd_dq_kernel, dim3(cdiv(Tq, 128), H, B), dim3(256), 0, stream, a);
     }
-    CXR_LAUNCH(attn_bwd_dkdv_kernel, dim3(cdiv(Tk, 128), H, B), dim3(256), 0, stream, a);
+    // (NW = 5, one 160-key workgroup per (image, head) at Tk = 145: measured SLOWER, 95 -> 104 us per CvT stage-3 call -- 384 workgroups of 5 waves fill
+    // the chip worse than 768 of 4, of which every second one retires almost at once. CXR_ATTN_DKDV_NW5=1 selects it for A/B.)
+    static int nw5 = -1;
+    if (nw5 < 0) { const char* e = getenv("CXR_ATTN_DKDV_NW5"); nw5 = (e && atoi(e)) ? 1 : 0; }
+    if (nw5 && Tk > 128 && Tk <= 160) CXR_LAUNCH(attn_bwd_dkdv_kernel<5>, dim3(1, H, B), dim3(320), 0, stream, a);
+    else                              CXR_LAUNCH(attn_bwd_dkdv_kernel<4>, dim3(cdiv(Tk, 128), H, B), dim3(256), 0, stream, a);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

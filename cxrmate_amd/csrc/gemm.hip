@@ -12,6 +12,7 @@
 #include "gemm_args.h"
 #include "../../include/cxrmate_hip.h"
 #include <stdlib.h>
+#include <string.h>
 
 
 // NST = number of LDS stages. NST == 2: one tile in flight behind the math (vmcnt(0) + __syncthreads per K step).
@@ -741,13 +742,18 @@ __device__ __forceinline__ void tn2_frag_issue(const unsigned lane_off, const un
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(a));
 }
 
-template <int NI, int NJ>
-__device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char* lds, const int bi, const int bj, const int split) {
+// WI = waves along I (8 / WI along J); i0 / j0 = first output row / column of the block. (NI, NJ, WI) = (3, 1, 4) is round 4's 384 x 128 block: the
+// CvT stage-3 gradients (384 x 384, 384 x 1536, 1536 x 384) are covered by EQUAL blocks -- as 256-blocks they were a mix of 256 x 256, 256 x 128
+// and 128 x 128 blocks with 4 : 2 : 1 work per workgroup, and the launch waited for the big ones.
+template <int NI, int NJ, int WI = 2>
+__device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char* lds, const int i0, const int j0, const bool bias_block, const int split) {
     constexpr int BR = 32, TILE = BR * 256, NST = 3, LPS = NI + NJ, STAGE = (NI + NJ) * TILE;
-    constexpr int MI = 4 * NI, MJ = 2 * NJ;                        // 16 x 16 MFMA tiles of a wave: (64 NI) x (32 NJ) outputs
+    constexpr int WJ = 8 / WI;
+    constexpr int MI = NI * 8 / WI, MJ = NJ * 8 / WJ;              // 16 x 16 MFMA tiles of a wave: (128 NI / WI) x (128 NJ / WJ) outputs
+    static_assert((NI * 8) % WI == 0 && (NJ * 8) % WJ == 0 && MI % 2 == 0 && MJ >= 1 && MJ <= 4, "wave grid");
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 8 waves: 2 (I) x 4 (J)
-    const int wi = wave & 1, wj = wave >> 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 8 waves: WI (I) x WJ (J)
+    const int wi = wave % WI, wj = wave / WI;
     const int nrt = (g.R + BR - 1) / BR;
     const int rt0 = split * g.rt_per_split;
     const int rt1 = min(nrt, rt0 + g.rt_per_split);
@@ -764,14 +770,14 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char
         const bool ok = r < g.R;
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
-            int c = bi * 256 + u * 128 + scol; if (c >= g.I) c = 0;
+            int c = i0 + u * 128 + scol; if (c >= g.I) c = 0;
             const bf16_t* sp = ok ? g.P + r * g.ldp + c : zr;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
                                              (__attribute__((address_space(3))) void*)(base + u * TILE), 16, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < NJ; ++u) {
-            int c = bj * 256 + u * 128 + scol; if (c >= g.J) c = 0;
+            int c = j0 + u * 128 + scol; if (c >= g.J) c = 0;
             const bf16_t* sq = ok ? g.Q + r * g.ldq + c : zr;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sq,
                                              (__attribute__((address_space(3))) void*)(base + (NI + u) * TILE), 16, 0, 0);
@@ -785,15 +791,14 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char
         for (int b = 0; b < MJ; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // bias gradient = column sums of P: the 8 tokens a lane holds of its column, added with v_dot2c_f32_bf16 against (1, 1) -- one fp32 register
     // per 16-column tile (the all-ones MFMA of gemm_tn_kernel needs four)
-    const bool do_bias = g.dbias != nullptr && bj == 0 && wj == 0;
+    const bool do_bias = g.dbias != nullptr && bias_block && wj == 0;
     float accb[MI];
 #pragma unroll
     for (int a = 0; a < MI; ++a) accb[a] = 0.f;
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     const bf16x2_t one2 = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);
-    // this wave's columns inside the block's sub-images
-    const int sub_i = NI == 2 ? wi : 0, cb_i = NI == 2 ? 0 : wi * 64;
-    const int sub_j = NJ == 2 ? (wj >> 1) : 0, cb_j = NJ == 2 ? (wj & 1) * 64 : wj * 32;
+    // this wave's first 16-column MFMA tile inside the block (tile r16 lives in sub-image r16 >> 3, at 16-column index r16 & 7: wave-uniform)
+    const int ri0 = wi * MI, rj0 = wj * MJ;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     unsigned lane_off;                                              // this lane's part of every fragment address (tn2_frag_issue)
     {
@@ -811,13 +816,13 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (kt + NST - 1 < nt) stage((kt + NST - 1) % NST, rt0 + kt + NST - 1);
-        const unsigned tp = lds_base + (kt % NST) * STAGE + sub_i * TILE;      // wave-uniform
-        const unsigned tq = lds_base + (kt % NST) * STAGE + (NI + sub_j) * TILE;
+        const unsigned tp = lds_base + (kt % NST) * STAGE;                      // wave-uniform
+        const unsigned tq = tp + NI * TILE;
         s16x4_t alo[MI], ahi[MI], blo[MJ], bhi[MJ];
 #pragma unroll
-        for (int t = 0; t < MI; ++t) tn2_frag_issue(lane_off, tp, (cb_i >> 4) + t, alo[t], ahi[t]);
+        for (int t = 0; t < MI; ++t) tn2_frag_issue(lane_off, tp + ((ri0 + t) >> 3) * TILE, (ri0 + t) & 7, alo[t], ahi[t]);
 #pragma unroll
-        for (int t = 0; t < MJ; ++t) tn2_frag_issue(lane_off, tq, (cb_j >> 4) + t, blo[t], bhi[t]);
+        for (int t = 0; t < MJ; ++t) tn2_frag_issue(lane_off, tq + ((rj0 + t) >> 3) * TILE, (rj0 + t) & 7, blo[t], bhi[t]);
         // the B fragments arrive in issue order (LDS returns in order): column j of the MFMA grid starts as soon as its fragment is there,
         // the reads of the later columns land behind the MFMAs of the earlier ones
         bf16x8_t fa[MI];
@@ -857,8 +862,8 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char
     float* wtile = reinterpret_cast<float*>(lds) + wave * (32 * WCOLS);
     const int Jp = g.tiles_j * 128;
     const int Ipad = ((g.I + 127) / 128) * 128;
-    const int i_wave = bi * 256 + (NI == 2 ? wi * 128 : wi * 64);
-    const int j_wave = bj * 256 + (NJ == 2 ? wj * 64 : wj * 32);
+    const int i_wave = i0 + ri0 * 16;
+    const int j_wave = j0 + rj0 * 16;
     const int lrow = lane / WCOLS, lcol = lane % WCOLS;
     const int j = j_wave + lcol;
 #pragma unroll
@@ -924,10 +929,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(const GemmTnArgs g, co
     const int split = swz / blocks, blk = swz % blocks;
     const int bi = blk / blocks_j, bj = blk % blocks_j;
     const int ni = g.I - bi * 256 > 128 ? 2 : 1, nj = g.J - bj * 256 > 128 ? 2 : 1;      // block-uniform
-    if (ni == 2 && nj == 2) gemm_tn2_body<2, 2>(g, lds, bi, bj, split);
-    else if (ni == 2) gemm_tn2_body<2, 1>(g, lds, bi, bj, split);
-    else if (nj == 2) gemm_tn2_body<1, 2>(g, lds, bi, bj, split);
-    else gemm_tn2_body<1, 1>(g, lds, bi, bj, split);
+    if (ni == 2 && nj == 2) gemm_tn2_body<2, 2>(g, lds, bi * 256, bj * 256, bj == 0, split);
+    else if (ni == 2) gemm_tn2_body<2, 1>(g, lds, bi * 256, bj * 256, bj == 0, split);
+    else if (nj == 2) gemm_tn2_body<1, 2>(g, lds, bi * 256, bj * 256, bj == 0, split);
+    else gemm_tn2_body<1, 1>(g, lds, bi * 256, bj * 256, bj == 0, split);
+}
+
+// 384 x 128 blocks (I a multiple of 384): see gemm_tn2_body
+__global__ __launch_bounds__(512, 2) void gemm_tn3_kernel(const GemmTnArgs g, const int blocks_j) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * 4 * 32 * 256];      // 3 stages x (3 + 1) sub-images = 96 KB
+    int swz;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int blocks = gridDim.x / g.splits;
+    const int split = swz / blocks, blk = swz % blocks;
+    const int bi = blk / blocks_j, bj = blk % blocks_j;
+    gemm_tn2_body<3, 1, 4>(g, lds, bi * 384, bj * 128, bj == 0, split);
 }
 
 // C[i][j] += sum of the splits' partial tiles, dbias likewise, in a FIXED order: SL lanes share one group of 4 columns, lane l sums the splits
@@ -978,8 +998,63 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
     }
 }
 
+// ---- round 4: ONE reduce launch for many weight gradients ------------------------------------------------------------------------------------------
+// A training step has ~170 weight-gradient GEMMs with several token splits; each used to be followed by its own gemm_tn_reduce_kernel launch (3.7 ms
+// of weight-gradient-stream time per step: 20-30 us apiece for 0.6-20 MB of partial tiles, because a small launch in the shadow of the main stream's
+// kernels gets few CUs and the stream then waits for it). cxr_gemm_tn_partial_bf16 only leaves the partial tiles behind (each GEMM in scratch of its
+// own) and describes the pending sum; cxr_gemm_tn_reduce_batch adds up to TN_BATCH of them per launch, every output element still summed over its
+// splits in the same fixed order by the same lane grouping as gemm_tn_reduce_kernel (bit-identical results).
+constexpr int TN_BATCH = 40;
+struct TnRedItem { const float* ws; const float* wsb; float* C; float* dbias; long ldc; int I, J, Ip, Jp, splits, sl; unsigned block0, pad; };
+struct TnRedBatch { TnRedItem d[TN_BATCH]; int n; };
+
+__global__ __launch_bounds__(256) void gemm_tn_reduce_batch_kernel(const TnRedBatch bt) {
+    int k = 0;                                                     // (block-uniform) the last item whose first block is <= this block
+    for (int i = 1; i < bt.n; ++i) k = blockIdx.x >= bt.d[i].block0 ? i : k;
+    const TnRedItem& it = bt.d[k];
+    const float* __restrict__ ws = it.ws; const float* __restrict__ wsb = it.wsb; float* __restrict__ C = it.C; float* __restrict__ dbias = it.dbias;
+    const long ldc = it.ldc;
+    const int I = it.I, J = it.J, Ip = it.Ip, Jp = it.Jp, splits = it.splits, SL = it.sl;
+    const int j4 = J / 4;
+    const long total = (long)I * j4;
+    const long e = ((long)(blockIdx.x - it.block0) * 256 + threadIdx.x) / SL;
+    const int sl = threadIdx.x % SL;
+    if (e < total) {
+        const int i = (int)(e / j4), j = (int)(e % j4) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v[12];                                              // ALL partials of the lane loaded before the first add (as gemm_tn_reduce_kernel)
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int s2 = sl + q * SL;
+            v[q] = *reinterpret_cast<const float4*>(ws + ((long)(s2 < splits ? s2 : splits - 1) * Ip + i) * Jp + j);
+        }
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const bool on = sl + q * SL < splits;
+            acc.x += on ? v[q].x : 0.f; acc.y += on ? v[q].y : 0.f; acc.z += on ? v[q].z : 0.f; acc.w += on ? v[q].w : 0.f;
+        }
+        for (int o = 1; o < SL; o <<= 1) {
+            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64); acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+        }
+        if (sl == 0) {
+            float* c = C + (long)i * ldc + j;
+            if ((ldc & 3) == 0 && ((size_t)C & 15) == 0) {
+                float4 o = *reinterpret_cast<float4*>(c);
+                o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+                *reinterpret_cast<float4*>(c) = o;
+            } else { c[0] += acc.x; c[1] += acc.y; c[2] += acc.z; c[3] += acc.w; }
+        }
+    } else if (dbias && e - total < I) {
+        const int i = (int)(e - total);
+        float acc = 0.f;
+        for (int s2 = sl; s2 < splits; s2 += SL) acc += wsb[(long)s2 * Ip + i];
+        for (int o = 1; o < SL; o <<= 1) acc += __shfl_xor(acc, o, 64);
+        if (sl == 0) dbias[i] += acc;
+    }
+}
+
 // Launch plan of a weight-gradient GEMM (shared by cxr_gemm_tn_bf16 and cxr_gemm_tn_plan)
-struct TnPlan { bool big; int tiles_i, tiles_j, blocks_j, wgs_per_split, splits, rt_per_split; long need; };
+struct TnPlan { bool big; bool b384; int tiles_i, tiles_j, blocks_j, wgs_per_split, splits, rt_per_split; long need; };
 static TnPlan tn_plan(int R, int I, int J) {
     TnPlan p;
     p.tiles_i = cdiv(I, 128); p.tiles_j = cdiv(J, 128);
@@ -1001,7 +1076,16 @@ static TnPlan tn_plan(int R, int I, int J) {
     static long min_steps = -1;                            // CXR_TN2_MIN: blocks x 32-token steps from which the 256 x 256 blocks are used
     if (min_steps < 0) { const char* e = getenv("CXR_TN2_MIN"); min_steps = e ? atol(e) : 4096; }
     p.big = tn2 && I > 128 && J > 128 && (long)blocks * nrt >= min_steps;
-    p.wgs_per_split = p.big ? blocks : p.tiles_i * p.tiles_j;
+    // 384 x 128 blocks where 256-blocks would be of unequal size (a dimension that is 128 mod 256) and I is a multiple of 384: CvT stage 3
+    static int tn3 = -1;
+    // Default OFF: alone the equal blocks are 15-25 % faster (384 x 384 x 36928: 56 -> 42 us, 1536 x 384: 136 -> 117, 384 x 1536: 133 -> 115,
+    // profiles/r04_tn_micro_blocks384.txt), but beside the main stream the training step gets 0.2-0.4 ms SLOWER with them (same-box alternation, two
+    // boxes, 64 / 96 / 128 workgroups per launch: profiles/r04_ab_wgrad_stream.txt) -- a faster weight-gradient kernel takes more of the shared
+    // LDS-DMA / L2 bandwidth from the dX GEMMs while it runs, and the weight-gradient stream was not the critical path. CXR_TN3=1 turns them on.
+    if (tn3 < 0) { const char* e = getenv("CXR_TN3"); tn3 = (e && e[0] == '1') ? 1 : 0; }
+    p.b384 = p.big && tn3 && (I % 384) == 0 && ((I % 256) != 0 || (J % 256) != 0);
+    if (p.b384) p.blocks_j = cdiv(J, 128);
+    p.wgs_per_split = p.b384 ? (I / 384) * p.blocks_j : (p.big ? blocks : p.tiles_i * p.tiles_j);
     int splits = cdiv(p.big ? target_big : target_wgs, p.wgs_per_split);
     const int max_splits = nrt / 8 > 0 ? nrt / 8 : 1;      // at least 256 tokens per split
     if (splits > max_splits) splits = max_splits;
@@ -1022,9 +1106,14 @@ extern "C" int cxr_gemm_tn_plan(int R, int I, int J, int* splits, long* ws_float
     return CXR_OK;
 }
 
-extern "C" int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* dbias, int R, int I, int J,
-                                float alpha, float* ws, long ws_floats, hipStream_t stream) {
+static int tn_sl(int splits) { return splits <= 12 ? 1 : (splits <= 48 ? 4 : 16); }      // 12 partials per lane at most (splits <= 176 + 1)
+
+// pending != null: the partial tiles are left in `ws` and *pending describes the sum still to be added to C / dbias (splits == 0: nothing is pending --
+// one split, or no usable scratch: the launch accumulated by itself)
+static int tn_launch(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* dbias, int R, int I, int J, float alpha, float* ws,
+                     long ws_floats, cxr_tn_pending* pending, hipStream_t stream) {
     if (R <= 0 || I <= 0 || J <= 0 || (I % 8) || (J % 8) || (ldp % 8) || (ldq % 8)) return CXR_ERR_ARG;
+    if (pending) memset(pending, 0, sizeof(*pending));
     GemmTnArgs g;
     g.P = (const bf16_t*)P; g.ldp = ldp; g.Q = (const bf16_t*)Q; g.ldq = ldq; g.C = C; g.ldc = ldc; g.dbias = dbias;
     g.R = R; g.I = I; g.J = J; g.alpha = alpha;
@@ -1034,8 +1123,8 @@ extern "C" int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq
     const int tiles_i = pl.tiles_i, blocks_j = pl.blocks_j, tiles = pl.wgs_per_split;
     g.tiles_j = pl.tiles_j; g.rt_per_split = pl.rt_per_split; g.splits = pl.splits;
     // accumulation: one split -> atomics (each element receives exactly one add per launch: order-free); several splits -> partial tiles into the
-    // caller's workspace + one reduce launch that adds them in a fixed order (deterministic; measured at the same speed as 64 KB of fp32 atomics
-    // per workgroup, scripts/tn_micro.py with CXR_TN_ATOMICS=1); no / too small a workspace: atomics
+    // caller's workspace + a reduce that adds them in a fixed order (deterministic; measured at the same speed as 64 KB of fp32 atomics per workgroup,
+    // scripts/tn_micro.py with CXR_TN_ATOMICS=1); no / too small a workspace: atomics
     const int Ip = tiles_i * 128, Jp = g.tiles_j * 128;
     const long need = pl.need;
     static int det = -1;
@@ -1045,15 +1134,54 @@ extern "C" int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq
     if (det && g.splits > 1 && g.splits <= 192 && ws && ws_floats >= need && (J % 4) == 0) { g.mode = 2; g.ws = ws; g.wsb = ws + (long)g.splits * Ip * Jp; }
     static int stages = -1;                                // CXR_TN_STAGES = 2 | 4 (LDS 32 | 64 KB per workgroup)
     if (stages < 0) { const char* e = getenv("CXR_TN_STAGES"); stages = e ? atoi(e) : 4; }
-    if (big)              CXR_LAUNCH(gemm_tn2_kernel, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
+    if (pl.b384)          CXR_LAUNCH(gemm_tn3_kernel, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
+    else if (big)         CXR_LAUNCH(gemm_tn2_kernel, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
     else if (stages == 2) CXR_LAUNCH(gemm_tn_kernel<2>, dim3(tiles * g.splits), dim3(256), 0, stream, g);
     else                  CXR_LAUNCH(gemm_tn_kernel<4>, dim3(tiles * g.splits), dim3(256), 0, stream, g);
-    if (g.mode == 2) {
+    if (g.mode == 2 && pending) {
+        pending->ws = g.ws; pending->wsb = g.wsb; pending->C = C; pending->dbias = dbias; pending->ldc = ldc;
+        pending->I = I; pending->J = J; pending->Ip = Ip; pending->Jp = Jp; pending->splits = g.splits;
+    } else if (g.mode == 2) {
         const long total = (long)I * (J / 4) + (dbias ? I : 0);
-        const int sl = g.splits <= 12 ? 1 : (g.splits <= 48 ? 4 : 16);      // 12 partials per lane at most (splits <= 176 + 1)
+        const int sl = tn_sl(g.splits);
 #define TN_RED(SL_) CXR_LAUNCH(gemm_tn_reduce_kernel<SL_>, dim3((unsigned)cdiv(total * SL_, 256)), dim3(256), 0, stream, g.ws, g.wsb, C, ldc, dbias, I, J, Ip, Jp, g.splits)
         if (sl == 1) TN_RED(1); else if (sl == 4) TN_RED(4); else TN_RED(16);
 #undef TN_RED
+    }
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+extern "C" int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* dbias, int R, int I, int J,
+                                float alpha, float* ws, long ws_floats, hipStream_t stream) {
+    return tn_launch(P, ldp, Q, ldq, C, ldc, dbias, R, I, J, alpha, ws, ws_floats, nullptr, stream);
+}
+
+extern "C" int cxr_gemm_tn_partial_bf16(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* dbias, int R, int I, int J,
+                                        float alpha, float* ws, long ws_floats, cxr_tn_pending* pending, hipStream_t stream) {
+    if (!pending) return CXR_ERR_ARG;
+    return tn_launch(P, ldp, Q, ldq, C, ldc, dbias, R, I, J, alpha, ws, ws_floats, pending, stream);
+}
+
+extern "C" int cxr_gemm_tn_reduce_batch(const cxr_tn_pending* pending, int n, hipStream_t stream) {
+    if (n < 0 || (n > 0 && !pending)) return CXR_ERR_ARG;
+    int i = 0;
+    while (i < n) {
+        TnRedBatch bt;
+        bt.n = 0;
+        unsigned blocks = 0;
+        for (; i < n && bt.n < TN_BATCH; ++i) {
+            const cxr_tn_pending& p = pending[i];
+            if (p.splits <= 1) continue;                           // nothing pending for this one
+            if (!p.ws || !p.C || p.I <= 0 || p.J <= 0 || (p.J % 4) || p.splits > 192 || (p.dbias && !p.wsb)) return CXR_ERR_ARG;
+            TnRedItem& it = bt.d[bt.n++];
+            it.ws = p.ws; it.wsb = p.wsb; it.C = p.C; it.dbias = p.dbias; it.ldc = p.ldc;
+            it.I = p.I; it.J = p.J; it.Ip = p.Ip; it.Jp = p.Jp; it.splits = p.splits; it.sl = tn_sl(p.splits);
+            it.block0 = blocks; it.pad = 0;
+            const long total = (long)p.I * (p.J / 4) + (p.dbias ? p.I : 0);
+            blocks += (unsigned)cdiv(total * it.sl, 256);
+        }
+        if (bt.n) CXR_LAUNCH(gemm_tn_reduce_batch_kernel, dim3(blocks), dim3(256), 0, stream, bt);
     }
     CXR_LAUNCH_CHECK();
     return CXR_OK;

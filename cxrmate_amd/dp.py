@@ -84,6 +84,7 @@ class GradReducer:
         self._pending = []
         self._started = set()
         self._stream = torch.cuda.Stream() if flat.is_cuda else None
+        self.log = None              # a list: receives (lo, hi) of every collective in launch order (every rank must issue the same sequence)
 
     def reduce_range(self, lo: int, hi: int, async_op: bool = True, after=None):
         """Start reducing every bucket inside [lo, hi). Safe to call while later kernels write OTHER ranges. after: an extra stream whose
@@ -100,6 +101,8 @@ class GradReducer:
             torch.cuda.current_stream().wait_stream(after)          # no private stream (gloo on device tensors): the collective runs on the current one
         def launch():
             for a, b in todo:
+                if self.log is not None:
+                    self.log.append((a, b))
                 if self.comm_dtype is None:
                     self._pending.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=async_op))
                 else:

@@ -286,14 +286,19 @@ class GenerationMixin:
         # greedy call over the SAME encoder outputs and prompt. A cached decode step costs the same for 16 and for 32 rows (it streams the
         # decoder weights), so the sampling call decodes the greedy rows too -- with the arguments the greedy call of the PREVIOUS step used --
         # and the greedy call that follows, if it asks for exactly that, gets the finished rows (`speculative_baseline = False` switches it off).
-        spec_key = (enc.data_ptr(), tuple(enc.shape), None if prompt is None else (prompt.data_ptr(), prompt._version, tuple(prompt.shape)),
-                    getattr(self, "shadow_version", 0), bool(self.training))
+        # the speculative result is tied to the very tensor OBJECTS of the sampling call (held alive here, so the allocator cannot hand their
+        # addresses to another batch), their in-place version counters, and the weights' state: FusedAdamW moves shadow_version, torch.optim's
+        # in-place updates move the version counter the parameter views share with the flat master buffer
+        spec_objs = (enc, prompt, enc_mask)
+        spec_ver = (enc._version, None if prompt is None else prompt._version, None if enc_mask is None else enc_mask._version,
+                    getattr(self, "shadow_version", 0), self.flat32._version, bool(self.training))
         if plain and not do_sample and prompt is not None:
             want = (tuple(special_token_ids), mask_token_id, int(max_length), bos_token_id, eos_token_id, pad_token_id)
             hit = getattr(self, "_spec_result", None)
             self._spec_result = None
             self._spec_pattern = want                            # what the next sampling call may decode along
-            if hit is not None and hit[0] == spec_key and hit[1] == want and getattr(self, "speculative_baseline", True):
+            if (hit is not None and all(a is b for a, b in zip(hit[0], spec_objs)) and hit[3] == spec_ver and hit[1] == want
+                    and getattr(self, "speculative_baseline", True)):
                 return ModelOutput(sequences=hit[2], scores=None) if return_dict_in_generate else hit[2]
         pattern = getattr(self, "_spec_pattern", None)
         if (plain and do_sample and output_scores and prompt is not None and pattern is not None and getattr(self, "speculative_baseline", True)
@@ -301,7 +306,7 @@ class GenerationMixin:
             with torch.no_grad():
                 ids, base, rec = self.sample_and_greedy(encoder_outputs, prompt, list(special_token_ids), list(pattern[0]), mask_token_id, int(max_length),
                                                         bos_token_id, eos_token_id, pad_token_id, top_k=top_k, temperature=temperature, top_p=top_p)
-            self._spec_result = (spec_key, pattern, base)
+            self._spec_result = (spec_objs, pattern, base, spec_ver)
         elif forced_tokens is None and not return_margins:
             ids = self._generate_session(ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, bos_token_id, eos_token_id,
                                          pad_token_id, do_sample, top_k, temperature, rec if ((output_scores and do_sample) or record_inputs) else None,

@@ -72,6 +72,8 @@ class BoundaryTensor(torch.Tensor):
             out = handler(*args, **kwargs)
             if out is not NotImplemented:
                 return out
+        if func not in _METADATA_ONLY:
+            args, kwargs = _materialise_pending(args), _materialise_pending(kwargs)
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **kwargs)
 
@@ -128,23 +130,78 @@ def _h_stack(tensors, dim=0, out=None):
 
 
 def _h_log_softmax(input, dim=None, _stacklevel=3, dtype=None):
+    """log_softmax over dim 1 of the [B, V, T] stack: PENDING. The SCST caller feeds it straight into nll_loss(reduction='none')
+    (scst/gt_prompt.py:230-235), which the fused loss kernel serves from the scores themselves (one pass per vocabulary row, no [B, V, T]
+    log-probability tensor, no dense one-hot gradient); the tensor handed back carries the scores' shape / dtype / device, and ANY other use of it
+    computes the log-softmax first (BoundaryTensor.__torch_function__ -> _materialise_pending), so it behaves as the real result everywhere."""
     m = _meta(input)
-    if m is None or m.get("kind") != "bvt" or dim not in (1, -2) or dtype is not None:
+    if m is None or m.get("kind") != "bvt" or dim not in (1, -2) or dtype is not None or m["base"].dtype != torch.float32:
         return NotImplemented
-    return torch.log_softmax(m["base"], dim=-1).permute(0, 2, 1)
+    return _as_boundary(m["base"].permute(0, 2, 1), kind="pending_logp", base=m["base"])
+
+
+def _h_nll_loss(input, target, weight=None, size_average=None, ignore_index=-100, reduce=None, reduction="mean"):
+    m = _meta(input)
+    if (m is None or m.get("kind") != "pending_logp" or weight is not None or size_average is not None or reduce is not None or reduction != "none"
+            or not torch.is_tensor(target) or target.dtype != torch.int64 or tuple(target.shape) != tuple(m["base"].shape[:2])):
+        return NotImplemented
+    return _RowNllFn.apply(m["base"], _plain(target).to(m["base"].device), int(ignore_index))
+
+
+def _materialise_pending(obj):
+    """Replace every pending log-softmax in a (nested) argument structure by the computed one."""
+    if isinstance(obj, BoundaryTensor):
+        m = getattr(obj, "_cxr", None)
+        if m is not None and m.get("kind") == "pending_logp":
+            return torch.log_softmax(m["base"], dim=-1).permute(0, 2, 1)
+        return obj
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_materialise_pending(o) for o in obj)
+    if isinstance(obj, dict):
+        return {k: _materialise_pending(v) for k, v in obj.items()}
+    return obj
+
+
+class _RowNllFn(torch.autograd.Function):
+    """nll_loss(log_softmax(scores, vocabulary), target, ignore_index, reduction='none') -> [B, T] on the fused loss kernel (csrc/loss.hip): forward
+    = one pass per row (log-sum-exp minus the target's score; -inf entries of the top-k filtered scores carry zero probability as in torch);
+    backward = the same pass weighted by the incoming per-row gradient, emitting d(scores) = g * (softmax - onehot) directly."""
+
+    @staticmethod
+    def forward(ctx, scores, target, ignore_index):
+        B, T, V = scores.shape
+        flat = scores.detach().reshape(B * T, V)
+        lab = target.reshape(-1).contiguous()
+        ones = torch.ones((B * T,), dtype=torch.float32, device=scores.device)
+        _, rows, _ = ops.softmax_ce(flat, lab, ignore_index, ones, need_grad=False)
+        ctx.save_for_backward(flat, lab)
+        ctx.ignore_index, ctx.shape = ignore_index, (B, T, V)
+        return rows.view(B, T)
+
+    @staticmethod
+    def backward(ctx, g):
+        flat, lab = ctx.saved_tensors
+        w = g.reshape(-1).float().contiguous()
+        _, _, dl = ops.softmax_ce(flat, lab, ctx.ignore_index, w, need_grad=True)       # rows with an ignored label get a zero gradient row
+        return dl.view(ctx.shape), None, None
 
 
 _BOUNDARY_HANDLERS = {
     torch.Tensor.permute: _h_permute, torch.permute: _h_permute, torch.Tensor.transpose: _h_transpose, torch.transpose: _h_transpose,
     torch.nn.functional.cross_entropy: _h_cross_entropy, torch.stack: _h_stack,
     torch.nn.functional.log_softmax: _h_log_softmax, torch.log_softmax: _h_log_softmax, torch.Tensor.log_softmax: _h_log_softmax,
+    torch.nn.functional.nll_loss: _h_nll_loss,
 }
+# attribute reads that are the same for a pending log-softmax and for its scores: answered without computing anything
+_METADATA_ONLY = {getattr(torch.Tensor, a).__get__ for a in ("shape", "dtype", "device", "ndim", "is_cuda", "requires_grad", "layout")} | {
+    torch.Tensor.size, torch.Tensor.dim, torch.Tensor.numel, torch.Tensor.stride, torch.Tensor.is_contiguous, torch.Tensor.is_floating_point}
 
 
 # ---------------------------------------------------------------------------------------------------- autograd bridges
 class _EncodeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, px, *params):
+        model._settle_owed_join()
         feats, saved = model._enc.forward(px, save=True)
         ctx.model, ctx.saved, ctx.nparams = model, saved, len(params)
         return feats
@@ -171,6 +228,7 @@ class _EncodeFn(torch.autograd.Function):
 class _DecodeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, enc, enc_mask, ids, attn_mask, tt, pos, seed, embeds, *params):
+        model._settle_owed_join()
         logits, saved = model._dec.forward(ids, enc, enc_mask, attn_mask, tt, pos, save=True, seed=seed, inputs_embeds=embeds)
         ctx.model, ctx.saved, ctx.nparams = model, saved, len(params)
         ctx.need_denc = enc is not None and enc.requires_grad
@@ -383,14 +441,30 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
         ps = self._grad_params(prefix)
         if not ps:
             return None
+        # Binding skips autograd's AccumulateGrad nodes, so it is only allowed where that cannot be observed: no tensor hook / post-accumulate hook
+        # on any parameter, and no torch.distributed process group (DistributedDataParallel's reducer hangs its hooks on the AccumulateGrad nodes
+        # themselves, where they cannot be seen from here: under a process group the gradients always take the autograd route; this build's own
+        # data-parallel path -- training.tf_train_step / dp.GradReducer -- uses direct_grads and never reaches this point).
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            return self._unbind_grads(ps)
+        if any(getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None) for _, p in ps):
+            return self._unbind_grads(ps)
         if all(p.grad is None for _, p in ps):
             return "fresh"
         lo, hi = self.gflat.data_ptr(), self.gflat.data_ptr() + self.gflat.numel() * 4
         own = [p.grad is not None and lo <= p.grad.data_ptr() < hi for _, p in ps]
         if all(own):
             return "accumulate"
-        for (_, p), o in zip(ps, own):
-            if o:
+        return self._unbind_grads(ps)
+
+    def _unbind_grads(self, ps):
+        """The gradients of `ps` go through autograd: .grad tensors that alias the flat gradient buffer are detached from it first (the bridge is
+        about to overwrite that buffer, and autograd would otherwise accumulate into the very memory it is handed). -> None"""
+        if self.gflat is None:
+            return None
+        lo, hi = self.gflat.data_ptr(), self.gflat.data_ptr() + self.gflat.numel() * 4
+        for _, p in ps:
+            if p.grad is not None and lo <= p.grad.data_ptr() < hi:
                 p.grad = p.grad.clone()
         return None
 
@@ -414,6 +488,15 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
                 ops.wgrad_join(side)
 
         torch.autograd.Variable._execution_engine.queue_callback(done)
+
+    def _settle_owed_join(self):
+        """A backward pass that RAISED never runs its final callbacks (the autograd engine skips them on an exception), so the join queued by
+        _queue_backward_join() is still owed and the flag would keep every later backward pass from queueing its own: a new forward pass joins the
+        weight-gradient stream itself and clears the flag (nothing to do in the normal case)."""
+        if self.__dict__.get("_join_queued"):
+            from .training import wgrad_overlap
+            self.__dict__["_join_queued"] = False
+            ops.wgrad_join(wgrad_overlap._stream)
 
     def _collect_grads(self, prefix, n):
         """Gradients handed to autograd for the trainable parameters under `prefix`: views of ONE copy of the flat gradient range they span
@@ -448,6 +531,7 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
         return self
 
     def _encode(self, pixel_values):
+        self._spec_result = None                       # a new encoder pass: no greedy baseline decoded along an earlier batch can be asked for any more
         px = self._pixels(pixel_values)
         multi = px.dim() == 5
         flat = px.view(-1, *px.shape[-3:]) if multi else px
@@ -480,7 +564,7 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
             enc_mask = None                                                  # modelling_single.py:176
         if (decoder_input_ids is None) == (decoder_inputs_embeds is None):
             raise ValueError("You have to specify exactly one of decoder_input_ids or decoder_inputs_embeds")
-        if past_key_values is not None or use_cache:
+        if past_key_values is not None:
             return self._forward_cached(decoder_input_ids, enc, enc_mask, decoder_attention_mask, kwargs_decoder, past_key_values, labels,
                                         decoder_inputs_embeds, return_dict)
         logits = self._decode_tf(decoder_input_ids, enc, enc_mask, decoder_attention_mask, kwargs_decoder.get("token_type_ids"),
@@ -490,21 +574,30 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
             loss = _CrossEntropyFn.apply(logits, labels.to(logits.device), -100)    # CrossEntropyLoss(): mean over labels != -100 (reference :239-241)
         if logits.dim() == 3:
             logits = _as_boundary(logits, kind="btv")                       # see BoundaryTensor: the callers' permute + F.cross_entropy stays on the fused loss kernel
-        out = ModelOutput(loss=loss, logits=logits, past_key_values=None, encoder_last_hidden_state=enc)
+        past = None
+        if use_cache and decoder_input_ids is not None and not torch.is_grad_enabled():
+            # use_cache=True WITHOUT a cache, the library's contract (TF5 models/bert/modeling_bert.py:851-905): logits for EVERY fed position (the
+            # teacher-forced pass above) plus a cache filled with those positions, which the next call hands back with its new tokens only. The
+            # cache is built by the cached-step kernels' prefill over the same inputs (its last-position logits are not needed). Under autograd no
+            # cache is returned (the cached kernels have no backward): the call is then an ordinary teacher-forced pass, as in training.
+            past = self._forward_cached(decoder_input_ids, enc, enc_mask, decoder_attention_mask, kwargs_decoder, None, None, None, True).past_key_values
+        out = ModelOutput(loss=loss, logits=logits, past_key_values=past, encoder_last_hidden_state=enc)
         if return_dict is False:
             return out.to_tuple()
         return out
 
     def _forward_cached(self, ids, enc, enc_mask, attn_mask, kwargs_decoder, past, labels, embeds, return_dict):
-        """forward(..., use_cache=True[, past_key_values=]) for callers that run their own decoding loop (transformers' generate does exactly this through
+        """forward(..., past_key_values=cache) for callers that run their own decoding loop (transformers' generate does exactly this through
         prepare_inputs_for_generation, modelling_longitudinal.py:251-295): `past_key_values` is the engine's own KV cache object (opaque: hand back what the
-        previous call returned), decoder_input_ids holds the NEW tokens only (the whole prompt in the first call), decoder_attention_mask the full mask
-        [B, past + new]. Gradient-free (the cached kernels have no backward) and -- unlike the library -- only the LAST position's logits come back
-        ([B, 1, V]): every decoding loop reads `logits[:, -1]`."""
+        previous call returned), decoder_input_ids holds the NEW token of every row, decoder_attention_mask the full mask [B, past + new]. Gradient-free
+        (the cached kernels have no backward). Logits come back for the fed position, [B, 1, V], as from the library; feeding several new tokens on top
+        of a non-empty cache (chunked prefill) is not something the reference's callers do and is refused rather than answered with one position."""
         if labels is not None or embeds is not None:
-            raise NotImplementedError("use_cache / past_key_values: decoder_input_ids only, no labels (the cached path is the decoding path)")
+            raise NotImplementedError("past_key_values: decoder_input_ids only, no labels (the cached path is the decoding path)")
         if torch.is_grad_enabled() and any(p.requires_grad for _, p in self._grad_params("decoder.")):
-            raise RuntimeError("use_cache / past_key_values needs torch.no_grad(): the cached decode kernels have no backward")
+            raise RuntimeError("past_key_values needs torch.no_grad(): the cached decode kernels have no backward")
+        if past is not None and past.len > 0 and ids.shape[1] != 1:
+            raise NotImplementedError("past_key_values with more than one new token per row: only the last position's logits would come back")
         dev = self.device
         ids = self._i64(ids, dev)
         B, Tn = ids.shape

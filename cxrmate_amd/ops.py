@@ -184,8 +184,58 @@ def _tn_note_fallback(R, I, J):
                       "atomics, the sum order (last bits of the gradient) is not reproducible for this shape")
 
 
+class _TnPending(_ct.Structure):
+    """cxr_tn_pending (include/cxrmate_hip.h): a weight gradient whose sum over the token splits is still to be added to C / dbias"""
+    _fields_ = [("ws", _ct.c_void_p), ("wsb", _ct.c_void_p), ("C", _ct.c_void_p), ("dbias", _ct.c_void_p), ("ldc", _ct.c_long),
+                ("I", _ct.c_int), ("J", _ct.c_int), ("Ip", _ct.c_int), ("Jp", _ct.c_int), ("splits", _ct.c_int), ("reserved", _ct.c_int)]
+
+
+# Deferred split sums of the weight-gradient stream (CXR_TN_DEFER=0: every GEMM followed by its own reduce launch, as before round 4). Each deferred
+# GEMM gets scratch of its own from a bump allocator over a few large buffers (288 GB of HBM: the ~2 GB of partial tiles a step leaves behind are not a
+# constraint); wgrad_reduce() adds all pending sums with one launch per 40 and hands the scratch back.
+_TN_DEFER = __import__("os").environ.get("CXR_TN_DEFER", "1") != "0"
+_TN_CHUNK = 64 << 20                                       # floats per arena buffer (256 MB)
+_TN_DEFER_FLOATS = int(__import__("os").environ.get("CXR_TN_DEFER_MB", "64")) << 18      # pending partial tiles that trigger a reduce launch (MB -> floats)
+_TN_ARENA = {}                                            # device index -> [buffers, index of the current one, floats used in it]
+_TN_PENDING = []                                          # (_TnPending, tensors kept alive)
+
+
+def _tn_arena_alloc(device, n):
+    ar = _TN_ARENA.get(device.index)
+    if ar is None:
+        ar = _TN_ARENA[device.index] = [[], 0, 0]
+    bufs = ar[0]
+    n = (n + 63) // 64 * 64
+    while True:
+        if ar[1] < len(bufs) and ar[2] + n <= bufs[ar[1]].numel():
+            out = bufs[ar[1]][ar[2]: ar[2] + n]
+            ar[2] += n
+            return out
+        if ar[1] < len(bufs):
+            ar[1] += 1
+            ar[2] = 0
+            continue
+        bufs.append(torch.empty(max(n, _TN_CHUNK), dtype=torch.float32, device=device))
+
+
+def wgrad_reduce(side=None):
+    """Add every pending split sum of the weight-gradient stream to its gradient (one launch per 40 sums, on that stream, behind the GEMMs that left
+    the partial tiles). Called at every point where something may READ a weight gradient: the joins, the fork points of the gradient all-reduce and of
+    the early optimiser update, other side-stream work that consumes a GEMM's result, the end of a wgrad_overlap context."""
+    if not _TN_PENDING:
+        return
+    side = WGRAD_STREAM if side is None else side
+    assert side is not None, "pending weight-gradient sums outlived their stream"
+    arr = (_TnPending * len(_TN_PENDING))(*[d for d, _ in _TN_PENDING])
+    LIB.call("cxr_gemm_tn_reduce_batch", _ct.addressof(arr), len(_TN_PENDING), side.cuda_stream)
+    _TN_PENDING.clear()
+    for ar in _TN_ARENA.values():
+        ar[1] = ar[2] = 0                                  # the same stream orders the next GEMM's partial tiles behind this reduce
+
+
 def gemm_tn(p, q, out, dbias=None, alpha=1.0):
-    """out[I,J] (fp32) += alpha * p[R,I]^T @ q[R,J];  dbias[I] += colsum(p). p, q bf16 row-major (row stride free)."""
+    """out[I,J] (fp32) += alpha * p[R,I]^T @ q[R,J];  dbias[I] += colsum(p). p, q bf16 row-major (row stride free). Issued from the weight-gradient
+    stream's deferred launches (wgrad_flush) the sum over the token splits stays pending until wgrad_reduce()."""
     _chk(p, BF16); _chk(q, BF16)
     R, I = p.shape
     R2, J = q.shape
@@ -196,11 +246,26 @@ def gemm_tn(p, q, out, dbias=None, alpha=1.0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(pstream)
     stream = _s()
-    ws = _tn_ws(stream, p.device)
-    if (I, J) not in _TN_FALLBACK_SEEN and I * J > (1 << 20):
-        _tn_note_fallback(R, I, J)
-    LIB.call("cxr_gemm_tn_bf16", _p(p), p.stride(0), _p(q), q.stride(0), _p(out), out.stride(0), _p(dbias), R, I, J, float(alpha), _p(ws), ws.numel(),
-             stream)
+    if _TN_DEFER and _SIDE_RAW is not None and WGRAD_STREAM is not None:
+        splits, need = _ct.c_int(0), _ct.c_long(0)
+        LIB.call("cxr_gemm_tn_plan", int(R), int(I), int(J), _ct.byref(splits), _ct.byref(need))
+        ws = _tn_arena_alloc(p.device, need.value) if (splits.value > 1 and need.value > 0) else None
+        pend = _TnPending()
+        LIB.call("cxr_gemm_tn_partial_bf16", _p(p), p.stride(0), _p(q), q.stride(0), _p(out), out.stride(0), _p(dbias), R, I, J, float(alpha), _p(ws),
+                 0 if ws is None else ws.numel(), _ct.byref(pend), stream)
+        if pend.splits > 1:
+            _TN_PENDING.append((pend, (out, dbias)))
+            # ... but not for long: the partial tiles should still be in the 256-MB Infinity Cache when the reduce reads them (with every sum of a
+            # step pending, ~2 GB of partial tiles went out to HBM and came back: the step got 0.16 ms SLOWER than with one reduce launch per GEMM)
+            ar = _TN_ARENA[p.device.index]
+            if len(_TN_PENDING) >= 40 or ar[1] > 0 or ar[2] >= _TN_DEFER_FLOATS:
+                wgrad_reduce()
+    else:
+        ws = _tn_ws(stream, p.device)
+        if (I, J) not in _TN_FALLBACK_SEEN and I * J > (1 << 20):
+            _tn_note_fallback(R, I, J)
+        LIB.call("cxr_gemm_tn_bf16", _p(p), p.stride(0), _p(q), q.stride(0), _p(out), out.stride(0), _p(dbias), R, I, J, float(alpha), _p(ws), ws.numel(),
+                 stream)
     if prof is not None:
         e1.record(pstream)
         prof.append((2.0 * R * I * J, e0, e1, ("tn", I, J, R), 2.0 * R * (I + J) + 4.0 * I * J))
@@ -222,6 +287,7 @@ class _on_wgrad_stream:
         self.side = WGRAD_STREAM
         if self.side is not None:
             wgrad_flush()                                  # (launches collected by _side_defer come first on the side stream)
+            wgrad_reduce()                                 # (... and what follows on that stream may read a weight gradient)
             self.side.wait_stream(torch.cuda.current_stream())
             self.ctx = torch.cuda.stream(self.side)
             self.ctx.__enter__()
@@ -280,12 +346,16 @@ def wgrad_discard():
     """Drop collected launches without issuing them (error path of training.wgrad_overlap)."""
     _SIDE_DEFERRED.clear()
     _SIDE_PENDING.clear()
+    _TN_PENDING.clear()
+    for ar in _TN_ARENA.values():
+        ar[1] = ar[2] = 0
 
 
 def wgrad_join(stream=None):
     """stream: the weight-gradient stream to join when called outside the wgrad_overlap context that launched on it (deferred joins)"""
     wgrad_flush()
     stream = WGRAD_STREAM if stream is None else stream
+    wgrad_reduce(stream)
     if stream is not None:
         torch.cuda.current_stream().wait_stream(stream)
     _SIDE_PENDING.clear()
@@ -320,6 +390,7 @@ def wgrad_mark():
     if WGRAD_STREAM is None:
         return None
     wgrad_flush()
+    wgrad_reduce()
     ev = torch.cuda.Event()
     ev.record(WGRAD_STREAM)
     return ev
@@ -330,8 +401,13 @@ def wgrad_wait(ev):
         torch.cuda.current_stream().wait_event(ev)
 
 
+_WGRAD_SKIP = __import__("os").environ.get("CXR_WGRAD_SKIP") == "1"       # TIMING EXPERIMENT ONLY (wrong gradients): no weight-gradient GEMM is launched
+
+
 def linear_bwd_weight(dy, x, dw, db=None):
     """dw[N,K] += dy[M,N]^T @ x[M,K]; db[N] += colsum(dy)   (one split-K TN kernel; no transposes)."""
+    if _WGRAD_SKIP:
+        return
     _side_defer(lambda: gemm_tn(dy, x, dw, dbias=db), dy, x, dw, db)
 
 

@@ -8,6 +8,7 @@ torch optimiser keep working, while the fused AdamW kernel (ops.adamw_step) upda
 """
 from __future__ import annotations
 
+import weakref
 from collections import OrderedDict
 from typing import Dict, Tuple
 
@@ -105,6 +106,7 @@ class ParamStore(nn.Module):
                 if p is None:
                     p = nn.Parameter(v, requires_grad=bool(self._trainable(k)))
                     self._params[k] = p
+                    p._cxr_store, p._cxr_key = weakref.ref(self), k       # lets optim.AdamW find the flat buffers behind a bare parameter list
                 else:
                     p.data = v
                 self._register(k, p, buffer=False)

@@ -31,12 +31,24 @@ class FusedAdamW:
         self.v = torch.zeros_like(model.flat32)
         self.t_dev = torch.zeros((), dtype=torch.int32, device=model.device)       # step counter lives on the device (graph replay)
         self.split = model._offsets[next(k for k in model._offsets if k.startswith("decoder."))]
-        # flat-buffer offset where the parameters of the LAST encoder stage begin (CvT-21: 29 of the encoder's 31 M parameters sit behind it, followed
-        # by the projection head): their gradients are complete when that stage's backward is, long before the first stages finish
-        last = max((int(k.split(".")[4]) for k in model._offsets if k.startswith("encoder.cvt.encoder.stages.")), default=None)
-        self.enc_tail = None if last is None else min(o for k, o in model._offsets.items() if k.startswith(f"encoder.cvt.encoder.stages.{last}."))
+        # flat-buffer offsets where the parameters of each encoder stage begin (storage order: stage 0, 1, 2, projection head, then the decoder): the
+        # gradients of stage s are complete when that stage's backward is, so data parallelism reduces the encoder range stage by stage under the
+        # backward of the earlier stages -- what Lightning's DDP buckets do for the reference (config/train/single_tf.yaml:8). CvT-21: stage 2 + head
+        # hold 29 of the encoder's 31 M parameters; stage 1 (1.8 M) goes under stage 0's backward, stage 0 (0.06 M) is the only range left for the end.
+        stages = sorted({int(k.split(".")[4]) for k in model._offsets if k.startswith("encoder.cvt.encoder.stages.")})
+        self.stage_start = {s_: min(o for k, o in model._offsets.items() if k.startswith(f"encoder.cvt.encoder.stages.{s_}.") and o < model._param_total)
+                            for s_ in stages}
+        last = stages[-1] if stages else None
+        self.enc_tail = None if last is None else self.stage_start[last]
         self.enc_last_stage = last
-        self.reducer = dp.GradReducer(model.gflat, self.ranges, cuts=[self.split] + ([self.enc_tail] if self.enc_tail else []))
+        self.reducer = dp.GradReducer(model.gflat, self.ranges, cuts=[self.split] + [o for o in self.stage_start.values() if o > 0])
+
+    def stage_range(self, s):
+        """[lo, hi) of the flat buffer holding the parameters of encoder stage s (the last stage's range includes the projection head)."""
+        starts = sorted(self.stage_start.values())
+        lo = self.stage_start[s]
+        later = [o for o in starts if o > lo]
+        return lo, (later[0] if later else self.split)
 
     @property
     def t(self):
@@ -133,6 +145,7 @@ class wgrad_overlap:
         try:
             if exc[0] is None:
                 ops.wgrad_flush()                           # launches still collected for this stream are issued on it
+                ops.wgrad_reduce()                          # ... and the split sums they left pending are added (one launch)
             else:
                 ops.wgrad_discard()                         # the step failed: nothing of it is launched later by an unrelated step
         finally:
@@ -170,14 +183,17 @@ def _tf_train_step(model, opt, pixel_values, decoder_input_ids, decoder_attentio
         # decoder parameters sit after the encoder's in the flat buffer: reduce them while the encoder backward runs (the reducer's stream
         # waits for the weight-gradient stream, the main stream does not)
         ops.wgrad_flush()
+        ops.wgrad_reduce()
         opt.reducer.reduce_range(opt.split, model._param_total, after=ops.WGRAD_STREAM)
     early = None
     if sync and enc_trainable and opt.enc_tail:
-        # ... and the last encoder stage + projection head (93 % of the encoder's parameters) while the first stages are still in backward
+        # ... and every encoder stage as soon as its backward is through (the last stage + projection head first: 93 % of the encoder's parameters),
+        # while the earlier stages are still in backward; stage 0 is picked up by the closing reduce_range below
         def early(s):
-            if s == opt.enc_last_stage:
+            if s != min(opt.stage_start):
                 ops.wgrad_flush()
-                opt.reducer.reduce_range(opt.enc_tail, opt.split, after=ops.WGRAD_STREAM)
+                ops.wgrad_reduce()
+                opt.reducer.reduce_range(*opt.stage_range(s), after=ops.WGRAD_STREAM)
     gscale = 1.0 / (world * k)
     side = ops.WGRAD_STREAM
     dec_early = _EARLY_DEC_ADAMW and not sync and enc_trainable and side is not None
@@ -186,6 +202,7 @@ def _tf_train_step(model, opt, pixel_values, decoder_input_ids, decoder_attentio
         # HBM rate) are updated on the weight-gradient stream, behind those kernels, while the main stream runs the encoder backward. Nothing
         # reads decoder weights before the next forward; the join at the end of the encoder backward orders the update before it.
         ops.wgrad_flush()
+        ops.wgrad_reduce()                                         # the decoder's pending split sums: ONE launch, in front of the update
         side.wait_stream(torch.cuda.current_stream())              # every decoder dX kernel (they read the weights) is in front of the update
         with torch.cuda.stream(side):
             opt.step(gscale=gscale, lo_bound=opt.split, begin=True, finish=False)

@@ -48,6 +48,18 @@ int cxr_gemm_nt_group_bf16(const cxr_gemm_nt_desc* d, int n, hipStream_t stream)
  * ws NULL / too small (or CXR_TN_ATOMICS=1): fp32 atomics into C. Requires I%8==0, J%8==0. Nothing else may accumulate into C concurrently. */
 int cxr_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* dbias, int R, int I, int J, float alpha,
                      float* ws, long ws_floats, hipStream_t stream);
+/* The same product with the sum over the token splits DEFERRED: the launch leaves its partial tiles in `ws` (which must then stay untouched and
+ * belong to this product alone until the reduce) and fills *pending (HOST struct); cxr_gemm_tn_reduce_batch adds any number of pending sums to
+ * their C / dbias in ONE launch per 40 of them, in the fixed split order of cxr_gemm_tn_bf16 (bit-identical results). pending->splits == 0: nothing
+ * is pending (one split, or no usable scratch: the launch accumulated by itself). A training step has ~170 of these sums; as single launches they
+ * cost 3.7 ms of weight-gradient-stream time. Replaces what torch does for the reference's Linear / Conv2d weight gradients inside loss.backward()
+ * (reference modules/lightning_modules/single.py:449-475 training_step -> Lightning's backward). */
+typedef struct cxr_tn_pending {
+    const float* ws; const float* wsb; float* C; float* dbias; long ldc; int I, J, Ip, Jp, splits, reserved;
+} cxr_tn_pending;
+int cxr_gemm_tn_partial_bf16(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* dbias, int R, int I, int J, float alpha,
+                             float* ws, long ws_floats, cxr_tn_pending* pending, hipStream_t stream);
+int cxr_gemm_tn_reduce_batch(const cxr_tn_pending* pending, int n, hipStream_t stream);
 /* launch plan of cxr_gemm_tn_bf16 for a shape: token splits and the scratch floats its deterministic path needs (0 with one split) */
 int cxr_gemm_tn_plan(int R, int I, int J, int* splits, long* ws_floats);
 int cxr_gemm_set_regstage(int on);   /* debug: 1 = stage operands through registers instead of LDS-DMA */

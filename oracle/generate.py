@@ -99,8 +99,10 @@ def greedy(logits_fn, kind, batch_size, special_token_ids, bos_token_id, eos_tok
 
 
 def beam_search(logits_fn, kind, batch_size, num_beams, special_token_ids, bos_token_id, eos_token_id, pad_token_id,
-                max_length, prompt_ids=None, mask_token_id=None, length_penalty=1.0):
-    """TF5:gen:3208-3560 with do_sample=False, early_stopping=False, num_return_sequences=1, one EOS id."""
+                max_length, prompt_ids=None, mask_token_id=None, length_penalty=1.0, return_all=False, trace=None):
+    """TF5:gen:3208-3560 with do_sample=False, early_stopping=False, one EOS id; num_return_sequences=1, or =num_beams with `return_all`
+    (-> sequences [B, nb, T], scores [B, nb]). `trace` (a list) receives one dict per step: the running beams the step started from, the parent
+    beam and token of each new running beam, the finished set after the step, and the smallest gap inside the step's two top-k selections."""
     ids = prepare_decoder_input_ids(prompt_ids, batch_size, bos_token_id)
     ids = ids.repeat_interleave(num_beams, dim=0)                              # _expand_inputs_for_generation
     cur_len = prompt_len = ids.shape[1]
@@ -145,6 +147,15 @@ def beam_search(logits_fn, kind, batch_size, num_beams, special_token_ids, bos_t
         m_fin = torch.cat((finished, just), dim=1)
         best = torch.topk(m_sc, k=num_beams)[1]
         sequences, beam_scores, finished = gather(m_seq, best), gather(m_sc, best), gather(m_fin, best)
+        if trace is not None:
+            srt = torch.sort(logp.view(batch_size, -1), descending=True)[0][:, : keep + 1]
+            live = m_sc > -1.0e8
+            msrt = torch.sort(torch.where(live, m_sc, torch.full_like(m_sc, float("inf"))), dim=1)[0]      # live merged scores ascending, dead = +inf
+            mgap = torch.where(torch.isfinite(msrt[:, 1:]), msrt[:, 1:] - msrt[:, :-1], torch.full_like(msrt[:, 1:], float("inf")))
+            trace.append(dict(running_in=flat.view(batch_size, num_beams, cur_len).clone(), parent=gather(beam_of, nxt).clone(),
+                              token=running[:, :, cur_len].clone(), running_scores=running_scores.clone(), sequences=sequences.clone(),
+                              beam_scores=beam_scores.clone(), finished=finished.clone(),
+                              min_gap=float(min((srt[:, :-1] - srt[:, 1:]).min(), mgap.min()))))
         cur_len += 1
         # early-stop heuristic (:3008-3052) with early_stopping=False
         best_run = running_scores[:, :1] / ((cur_len - prompt_len) ** length_penalty)
@@ -152,14 +163,16 @@ def beam_search(logits_fn, kind, batch_size, num_beams, special_token_ids, bos_t
         unsat = unsat & torch.any(best_run > worst_fin, dim=-1, keepdim=True)
         if not (bool(unsat.any()) and not bool(hits.all())):
             break
-    out = sequences[:, 0, :]
+    out = sequences if return_all else sequences[:, :1, :]
     # trim to the longest generated hypothesis, as HF does through beam_indices (:3515-3519)
-    lens = torch.full((batch_size,), prompt_len, dtype=torch.long)
-    for b in range(batch_size):
-        row = out[b, prompt_len:]
-        eos = (row == eos_token_id).nonzero()
-        lens[b] = prompt_len + (int(eos[0]) + 1 if len(eos) else row.shape[0])
-    return out[:, : int(lens.max())], beam_scores[:, 0]
+    longest = prompt_len
+    for row in out.reshape(-1, out.shape[-1]):
+        gen = row[prompt_len:]
+        eos = (gen == eos_token_id).nonzero()
+        longest = max(longest, prompt_len + (int(eos[0]) + 1 if len(eos) else gen.shape[0]))
+    if return_all:
+        return out[:, :, :longest], beam_scores
+    return out[:, 0, :longest], beam_scores[:, 0]
 
 
 def reinforce_loss(logits, sampled_token_ids, reward, pad_token_id):

@@ -26,6 +26,7 @@ sys.path.insert(0, "/root/reference")
 warnings.filterwarnings("ignore")
 os.environ.setdefault("TRANSFORMERS_OFFLINE", "1")
 OUT = os.path.dirname(os.path.abspath(__file__))
+COMMITTED = OUT          # where the committed fixtures live (OUT moves to a scratch directory under --verify)
 
 
 # ------------------------------------------------------------------------------------------------ peft stand-in
@@ -144,11 +145,23 @@ def install_generate_adapter(model, ref_cls, longitudinal):
 
 
 SHARPEN_KEYS = ("decoder.cls.predictions.transform.LayerNorm.weight", "decoder.cls.predictions.transform.LayerNorm.bias")
+CROSS_OUT_KEY = "crossattention.output.dense."
 
 
-def build(ref_cls, cfg, seed, perturb, longitudinal=False, sharpen=1.0):
+def distinct_study_pixels(pixel_seed, img_off, size=96):
+    """Three 2-image studies that differ in contrast and brightness (study b: x * (1 + off * b) + off * b), study 1 with a zero-padded image."""
+    x = torch.randn(3, 2, 3, size, size, generator=torch.Generator().manual_seed(pixel_seed))
+    for b in range(3):
+        x[b] = x[b] * (1.0 + img_off * b) + img_off * b
+    x[1, 1] = 0.0
+    return x
+
+
+def build(ref_cls, cfg, seed, perturb, longitudinal=False, sharpen=1.0, cross_gain=1.0):
     """sharpen: factor on the LM head's final LayerNorm (weight and bias), i.e. on every logit: random-init logits have a standard deviation
-    of ~0.55 and beam hypotheses that differ by ~0.01 in score; x 16 makes the distribution as peaked as a trained model's."""
+    of ~0.55 and beam hypotheses that differ by ~0.01 in score; x 16 makes the distribution as peaked as a trained model's.
+    cross_gain: factor on every decoder layer's cross-attention output projection (weight and bias): with random weights the image contributes
+    almost nothing to a post-LayerNorm residual stream and a sharpened head then picks the SAME hypothesis for every study; x 8 lets the image decide."""
     dec = transformers.BertConfig(vocab_size=cfg.decoder.vocab_size, num_hidden_layers=cfg.decoder.num_hidden_layers,
                                   type_vocab_size=2)
     dec.is_decoder = True
@@ -160,6 +173,10 @@ def build(ref_cls, cfg, seed, perturb, longitudinal=False, sharpen=1.0):
     if sharpen != 1.0:
         for k in SHARPEN_KEYS:
             sd[k] = sd[k] * sharpen
+    if cross_gain != 1.0:
+        for k in list(sd):
+            if CROSS_OUT_KEY in k:
+                sd[k] = sd[k] * cross_gain
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected
     assert all("lora_dropout" in m or "position_ids" in m or "token_type_ids" in m for m in missing), missing
@@ -796,9 +813,12 @@ class _LogitNoise:
         self.h.remove()
 
 
-def _robust_beam_case(model, kw, trials=6, rel=0.02):
-    """-> (all hypotheses [B, nb, T], scores [B, nb]) of a beam search when `trials` noisy repetitions return the same best sequences and final scores
-    that move by less than 40 % of the gap to the runner-up; None otherwise."""
+def _robust_beam_case(model, kw, trials=6, rel=0.02, min_rel_gap=0.15):
+    """-> (all hypotheses [B, nb, T], scores [B, nb], tolerance) of a beam search when `trials` noisy repetitions return the same best sequences and
+    final scores that move by less than the tolerance; None otherwise. tolerance = 0.4 x the smallest gap between a row's best hypothesis and its
+    runner-up: a score within it identifies the hypothesis; the ROW is identified by the sequence itself (callers require the rows' best hypotheses
+    to be pairwise different sequences -- random-init scores of different studies can lie within 0.002 of each other, far inside the bf16 score
+    error, so a tolerance below every row-to-row distance exists only for lucky seeds; `row_dist` is recorded with each case)."""
     with torch.no_grad():
         clean = model.generate(**kw)
     nb = kw["num_beams"]
@@ -806,8 +826,9 @@ def _robust_beam_case(model, kw, trials=6, rel=0.02):
     B = sc.shape[0]
     seqs = seqs.view(B, nb, -1)
     gap = sc[:, 0] - sc[:, 1]
-    if float((gap / sc[:, 0].abs()).min()) < 0.15:                # the runner-up is at least 15 % worse (noise moves a score by ~5 %)
+    if float((gap / sc[:, 0].abs()).min()) < min_rel_gap:
         return None
+    tol = 0.4 * float(gap.min())
     for t in range(trials):
         noise = _LogitNoise(model, rel, 1000 + t)
         try:
@@ -816,96 +837,204 @@ def _robust_beam_case(model, kw, trials=6, rel=0.02):
         finally:
             noise.remove()
         ns, nsc = n["sequences"].view(B, nb, -1), n["sequences_scores"].view(B, nb)
-        if ns.shape != seqs.shape or not torch.equal(ns[:, 0], seqs[:, 0]) or bool(((nsc[:, 0] - sc[:, 0]).abs() > 0.4 * gap).any()):
+        # sequences must survive the full noise (2 x the measured bf16 logit error); the score may move by the tolerance at the measured error itself
+        # (the score error is linear in the noise amplitude: 0.6 = 0.012 / 0.02)
+        if ns.shape != seqs.shape or not torch.equal(ns[:, 0], seqs[:, 0]) or bool((0.6 * (nsc[:, 0] - sc[:, 0]).abs() > tol).any()):
             return None
-    return seqs, sc
+    return seqs, sc, tol
+
+
+def _pinned(file, key, env):
+    """Seed recorded in the committed fixture `file` (so that a re-run rebuilds the SAME case instead of searching again), unless `env` asks for a
+    fresh search (`env`=search) or names a seed."""
+    want = os.environ.get(env, "")
+    if want == "search":
+        return None
+    if want:
+        return int(want)
+    path = os.path.join(COMMITTED, file)
+    if os.path.exists(path):
+        old = np.load(path)
+        if key in old.files:
+            return int(old[key])
+    return None
+
+
+def _generate_single_case(seed, steps=16):
+    """Everything generate_single.npz holds for model seed `seed` (clean runs of the reference only)."""
+    cfg = tiny_config(vocab_size=1000, decoder_layers=2, depth=(1, 2, 3), image_size=96)
+    model, _ = build(SingleCXREncoderDecoderModel, cfg, seed=seed, perturb=0.05, sharpen=16.0)
+    g = torch.Generator().manual_seed(seed + 1000)
+    x = torch.randn(3, 3, 96, 96, generator=g)
+    with torch.no_grad():
+        eo = model.encoder(x)
+        seq_nc, argm, margins = nocache_greedy(model, "single", eo, steps, special=[SEP])
+        logit_std = float(model(encoder_outputs=eo, decoder_input_ids=seq_nc[:, :-1], decoder_token_type_ids=model.token_ids_to_token_type_ids(seq_nc[:, :-1], [SEP]),
+                                return_dict=True).logits.std())
+    gkw = dict(pixel_values=x, special_token_ids=[SEP], max_length=steps + 1, bos_token_id=BOS, eos_token_id=EOS, pad_token_id=PAD,
+               return_dict_in_generate=True, use_cache=True, do_sample=False)
+    with torch.no_grad():
+        seq_gen = model.generate(num_beams=1, **gkw)["sequences"]
+        beam = model.generate(num_beams=4, num_return_sequences=4, output_scores=True, **gkw)
+    assert torch.equal(seq_nc, seq_gen), (seq_nc, seq_gen)
+    d = dict(seed=seed, perturb=0.05, sharpen=16.0, pixel_seed=seed + 1000, steps=steps, greedy=seq_gen.numpy(), greedy_argmax=argm, greedy_margin=margins,
+             logit_std=logit_std, beam4_all=beam["sequences"].view(3, 4, -1).numpy(), beam4_all_scores=beam["sequences_scores"].view(3, 4).numpy())
+    return model, dict(num_beams=4, num_return_sequences=4, output_scores=True, **gkw), d
 
 
 def fixture_generate_single():
     """BASELINE.json configs[0] / C1: the SINGLE-image model's generate (modelling_single.py:217-249: no encoder mask in the cached step), greedy with
     cache == no-cache (per-step top-1 / top-2 margins recorded: bit-exact comparison wherever the margin exceeds the bf16 logit error), and beam-4.
-    Seeds are searched until the beam search survives bf16-sized logit noise, so the MI355X path must reproduce its sequences AND scores on every row."""
-    cfg = tiny_config(vocab_size=1000, decoder_layers=2, depth=(1, 2, 3), image_size=96)
-    steps = 16
-    for seed in range(40, 200):
-        model, _ = build(SingleCXREncoderDecoderModel, cfg, seed=seed, perturb=0.05, sharpen=16.0)
-        g = torch.Generator().manual_seed(seed + 1000)
-        x = torch.randn(3, 3, 96, 96, generator=g)
+    The model seed is the one recorded in the committed file (GEN_SINGLE_SEED=search looks for a new one: seeds are tried until the beam search
+    survives bf16-sized logit noise); the stored arrays are clean runs of the reference for that seed, so a re-run reproduces the file."""
+    seed = _pinned("generate_single.npz", "seed", "GEN_SINGLE_SEED")
+    if seed is None:
+        for seed in range(40, 200):
+            model, kw, d = _generate_single_case(seed)
+            if _robust_beam_case(model, kw) is not None:
+                break
+        else:
+            raise SystemExit("no robust single-image generate case found")
+    else:
+        _, _, d = _generate_single_case(seed)
+    np.savez_compressed(os.path.join(OUT, "generate_single.npz"), **d)
+    sc = d["beam4_all_scores"]
+    print("generate_single seed", seed, "min greedy margin", d["greedy_margin"].min(), "logit std", d["logit_std"], "beam gaps", (sc[:, 0] - sc[:, 1]).tolist())
+
+
+# ---- multi-image beam-4 cases whose rows DIFFER (generate_beam_safe.npz, second generation)
+BEAM_SAFE = dict(sharpen=16.0, cross_gain=8.0, img_off=1.0, perturb=0.05, steps=10, vocab=200)
+BEAM_SAFE_KINDS = (("plain", 1.0), ("eos", 1.0), ("lp2", 2.0), ("lp05", 0.5))
+
+
+def _beam_safe_model(seed, eos_bias):
+    cfg = tiny_config(vocab_size=BEAM_SAFE["vocab"], decoder_layers=2, depth=(1, 2, 3), image_size=96)
+    model, _ = build(MultiCXREncoderDecoderModel, cfg, seed=seed, perturb=BEAM_SAFE["perturb"], sharpen=BEAM_SAFE["sharpen"], cross_gain=BEAM_SAFE["cross_gain"])
+    model.decoder.cls.predictions.bias.data[EOS] += eos_bias
+    x = distinct_study_pixels(seed + 2000, BEAM_SAFE["img_off"])
+    kw = dict(pixel_values=x, special_token_ids=[SEP], max_length=BEAM_SAFE["steps"] + 1, bos_token_id=BOS, eos_token_id=EOS, pad_token_id=PAD, num_beams=4,
+              num_return_sequences=4, return_dict_in_generate=True, use_cache=True, do_sample=False, output_scores=True)
+    return model, kw
+
+
+def _hyp_lengths(seqs):
+    e = seqs == EOS
+    return torch.where(e.any(-1), e.int().argmax(-1) + 1, torch.full(e.shape[:-1], seqs.shape[-1]))
+
+
+def _beam_safe_accept(name, lp, model, kw):
+    """A case is kept when (i) it survives bf16-sized logit noise (_robust_beam_case), (ii) the three studies' best hypotheses are pairwise different
+    sequences, and per kind: `eos` -- the best hypothesis of some but not all rows ends early; `lp2` / `lp05` -- the final hypotheses of some row have
+    different lengths AND the best hypothesis of some row is not the one length_penalty = 1 returns (the penalty decides a ranking)."""
+    res = _robust_beam_case(model, dict(kw, length_penalty=lp), trials=4, min_rel_gap=0.05)
+    if res is None:
+        return None
+    seqs, sc, tol = res
+    if len({tuple(r.tolist()) for r in seqs[:, 0]}) != seqs.shape[0]:
+        return None
+    lens = _hyp_lengths(seqs)
+    if name == "eos":
+        early = lens[:, 0] < seqs.shape[-1]
+        if not (bool(early.any()) and not bool(early.all())):
+            return None
+    if name in ("lp2", "lp05"):
+        if not any(len(set(lens[b].tolist())) > 1 for b in range(seqs.shape[0])):
+            return None
         with torch.no_grad():
-            eo = model.encoder(x)
-            seq_nc, argm, margins = nocache_greedy(model, "single", eo, steps, special=[SEP])
-        logit_std = float(model(encoder_outputs=eo, decoder_input_ids=seq_nc[:, :-1], decoder_token_type_ids=model.token_ids_to_token_type_ids(seq_nc[:, :-1], [SEP]),
-                                return_dict=True).logits.std())
-        gkw = dict(pixel_values=x, special_token_ids=[SEP], max_length=steps + 1, bos_token_id=BOS, eos_token_id=EOS, pad_token_id=PAD,
-                   return_dict_in_generate=True, use_cache=True, do_sample=False)
-        with torch.no_grad():
-            seq_gen = model.generate(num_beams=1, **gkw)["sequences"]
-        assert torch.equal(seq_nc, seq_gen), (seq_nc, seq_gen)
-        res = _robust_beam_case(model, dict(num_beams=4, num_return_sequences=4, output_scores=True, **gkw))
-        if res is None:
-            continue
-        np.savez_compressed(os.path.join(OUT, "generate_single.npz"), seed=seed, perturb=0.05, sharpen=16.0, pixel_seed=seed + 1000, steps=steps,
-                            greedy=seq_gen.numpy(), greedy_argmax=argm, greedy_margin=margins, logit_std=logit_std,
-                            beam4_all=res[0].numpy(), beam4_all_scores=res[1].numpy())
-        print("generate_single seed", seed, "min greedy margin", margins.min(), "logit std", logit_std, "beam gaps", (res[1][:, 0] - res[1][:, 1]).tolist())
-        return
-    raise SystemExit("no robust single-image generate case found")
+            ref1 = model.generate(**dict(kw, length_penalty=1.0))["sequences"].view(seqs.shape[0], 4, -1)[:, 0]
+        w = min(ref1.shape[-1], seqs.shape[-1])
+        if torch.equal(ref1[:, :w], seqs[:, 0, :w]) and ref1.shape[-1] == seqs.shape[-1]:
+            return None
+    return seqs, sc, tol
+
+
+def _beam_safe_arrays(name, seed, eos_bias, lp, seqs, sc, tol):
+    best = sc[:, 0]
+    row_dist = min(float((best[i] - best[j]).abs()) for i in range(sc.shape[0]) for j in range(i))
+    return {f"{name}_seed": seed, f"{name}_pixel_seed": seed + 2000, f"{name}_eos_bias": eos_bias, f"{name}_length_penalty": lp,
+            f"{name}_all": seqs.numpy(), f"{name}_all_scores": sc.numpy(), f"{name}_score_tol": tol, f"{name}_row_dist": row_dist}
 
 
 def fixture_beam_safe():
-    """Beam-4 of the MULTI-image model where the device-side beam search must equal the reference on every row: plain, with an early EOS in some
-    rows (EOS logit biased), and with length_penalty = 2.0 / 0.5 -- each case accepted only if `trials` repetitions under bf16-sized logit noise return
-    the same best hypothesis and score for every study (so near-ties at any intermediate top-2k selection are excluded by construction)."""
-    cfg = tiny_config(vocab_size=1000, decoder_layers=2, depth=(1, 2, 3), image_size=96)
-    steps = 16
+    """Beam-4 of the MULTI-image model where the device-side beam search must equal the reference on EVERY row, sequences and scores: the
+    sharpened LM head of the first generation of this file made all three studies return the same hypothesis (a cross-study mix-up in the beam
+    bookkeeping would have passed); here the cross-attention output is amplified and the studies differ in contrast / brightness, so every row has
+    its own hypothesis, and the score tolerance stored with each case is below the smallest row-to-row score distance. Kinds: plain; `eos` (EOS logit
+    biased until hypotheses end early in some rows); length_penalty 2.0 / 0.5 on hypotheses of DIFFERENT length where the penalty changes the winner.
+    Cases recorded in the committed file are rebuilt from their seeds (clean reference runs); BEAM_SAFE_SEEDS=lo:hi searches for the missing kinds."""
     out, found = {}, {}
-    path = os.path.join(OUT, "generate_beam_safe.npz")
-    if os.path.exists(path) and os.environ.get("BEAM_SAFE_KEEP", "1") == "1":       # keep the cases already found, search only for the missing kinds
+    path = os.path.join(COMMITTED, "generate_beam_safe.npz")
+    if os.path.exists(path) and os.environ.get("BEAM_SAFE_SEEDS") is None:
         old = np.load(path)
-        for name in ("plain", "lp2", "lp05", "eos"):
-            if f"{name}_seed" in old.files:
-                found[name] = int(old[f"{name}_seed"])
-                out.update({k: old[k] for k in old.files if k.startswith(name + "_")})
-    lo, hi = (int(v) for v in os.environ.get("BEAM_SAFE_SEEDS", "300:420").split(":"))      # (a later search for a still missing kind continues elsewhere)
-    for seed in range(lo, hi):
-        if len(found) == 4:
-            break
-        model, _ = build(MultiCXREncoderDecoderModel, cfg, seed=seed, perturb=0.05, sharpen=16.0)
-        g = torch.Generator().manual_seed(seed + 2000)
-        x = torch.randn(3, 2, 3, 96, 96, generator=g)
-        x[1, 1] = 0.0
-        base = dict(pixel_values=x, special_token_ids=[SEP], max_length=steps + 1, bos_token_id=BOS, eos_token_id=EOS, pad_token_id=PAD, num_beams=4,
-                    num_return_sequences=4, return_dict_in_generate=True, use_cache=True, do_sample=False, output_scores=True)
-        for name, extra, eos_bias in (("plain", {}, 0.0), ("lp2", dict(length_penalty=2.0), 0.0), ("lp05", dict(length_penalty=0.5), 0.0), ("eos", {}, None)):
-            if name in found:
-                continue
-            bias = 0.0
-            if eos_bias is None:
-                # smallest EOS bias (steps of 0.25) that ends at least one hypothesis early in some but not all rows
-                ok = False
-                for k in range(1, 40):
-                    model.decoder.cls.predictions.bias.data[EOS] += 0.25
-                    bias += 0.25
+        if "cross_gain" in old.files:
+            for name, lp in BEAM_SAFE_KINDS:
+                if f"{name}_seed" in old.files:
+                    seed, bias = int(old[f"{name}_seed"]), float(old[f"{name}_eos_bias"])
+                    model, kw = _beam_safe_model(seed, bias)
                     with torch.no_grad():
-                        t = model.generate(**base)["sequences"].view(3, 4, -1)[:, 0]
-                    ended = (t == EOS).any(1)
-                    if ended.any():                               # (the sharpened head makes the rows' best hypotheses end together: early EOS in every row is fine)
-                        ok = True
-                        break
-                if not ok:
-                    model.decoder.cls.predictions.bias.data[EOS] -= bias
-                    continue
-            res = _robust_beam_case(model, dict(base, **extra))
-            if eos_bias is None:
-                model.decoder.cls.predictions.bias.data[EOS] -= bias
-            if res is None:
+                        o = model.generate(**dict(kw, length_penalty=lp))
+                    found[name] = seed
+                    out.update(_beam_safe_arrays(name, seed, bias, lp, o["sequences"].view(3, 4, -1), o["sequences_scores"].view(3, 4), float(old[f"{name}_score_tol"])))
+    lo, hi = (int(v) for v in (os.environ.get("BEAM_SAFE_SEEDS") or "300:600").split(":"))
+    for seed in range(lo, hi):
+        if len(found) == len(BEAM_SAFE_KINDS):
+            break
+        print("beam_safe: seed", seed, "found so far", found, flush=True)
+        for bias in (0.0, 6.0, 8.0, 10.0, 12.0, 14.0, 16.0, 20.0):
+            todo = [(n, lp) for n, lp in BEAM_SAFE_KINDS if n not in found and (bias > 0.0) == (n != "plain")]
+            if not todo:
                 continue
-            found[name] = seed
-            out.update({f"{name}_seed": seed, f"{name}_pixel_seed": seed + 2000, f"{name}_eos_bias": bias,
-                        f"{name}_length_penalty": extra.get("length_penalty", 1.0), f"{name}_all": res[0].numpy(), f"{name}_all_scores": res[1].numpy()})
-            print("beam_safe", name, "seed", seed, "eos bias", bias, "gaps", (res[1][:, 0] - res[1][:, 1]).tolist(), "best", res[0][:, 0, :10].tolist())
-    assert "plain" in found and len(found) >= 3, found
-    np.savez_compressed(os.path.join(OUT, "generate_beam_safe.npz"), perturb=0.05, sharpen=16.0, steps=steps, **out)
+            model, kw = _beam_safe_model(seed, bias)
+            if bias > 0.0:
+                with torch.no_grad():
+                    t = model.generate(**kw)["sequences"].view(3, 4, -1)
+                lens = _hyp_lengths(t)
+                if bool((lens == t.shape[-1]).all()):
+                    continue                                     # nothing ends early yet
+                if bool((lens[:, 0] < 4).all()):
+                    break                                        # every best hypothesis is (almost) empty: larger biases only shorten them
+            for name, lp in todo:
+                res = _beam_safe_accept(name, lp, model, kw)
+                if res is None:
+                    continue
+                found[name] = seed
+                out.update(_beam_safe_arrays(name, seed, bias, lp, *res))
+                print("beam_safe", name, "seed", seed, "eos bias", bias, "tol", res[2], "lens", _hyp_lengths(res[0]).tolist(), "scores", res[1][:, 0].tolist())
+    assert len(found) == len(BEAM_SAFE_KINDS), found
+    np.savez_compressed(os.path.join(OUT, "generate_beam_safe.npz"), **{k: v for k, v in BEAM_SAFE.items()}, **out)
+
+
+def fixture_beam_index():
+    """Beam search as INDEX work, independent of any floating-point model: the reference's beam-4 generate() with the fp32 logits of EVERY step
+    recorded (forward hook on the LM head) together with the token each running beam was fed. Replaying those logits through another
+    implementation of the search (the oracle on the CPU, cxr_beam_step + the cache-reorder kernel on the GPU) must give the same beams at every step
+    and the same final hypotheses, bit for bit -- no bf16 noise is involved. Cases: length_penalty 1.0 / 0.5 / 2.0 with an EOS bias that makes
+    hypotheses end at different lengths (the penalty then decides rankings) and the search stop before max_length in some rows."""
+    V, steps = 200, 14
+    cfg = tiny_config(vocab_size=V, decoder_layers=2, depth=(1, 2, 3), image_size=96)
+    d = dict(vocab=V, steps=steps, seed=52, perturb=0.05, sharpen=16.0, cross_gain=8.0, img_off=1.0, pixel_seed=2052,
+             cases=np.array(["lp1", "lp05", "lp2", "lp2_b22", "lp05_b10"]))
+    cases = (("lp1", 1.0, 18.0), ("lp05", 0.5, 18.0), ("lp2", 2.0, 18.0), ("lp2_b22", 2.0, 22.0), ("lp05_b10", 0.5, 10.0))
+    for name, lp, bias in cases:
+        model, _ = build(MultiCXREncoderDecoderModel, cfg, seed=52, perturb=0.05, sharpen=16.0, cross_gain=8.0)
+        model.decoder.cls.predictions.bias.data[EOS] += bias
+        x = distinct_study_pixels(2052, 1.0)
+        logits, fed = [], []
+        h1 = model.decoder.cls.register_forward_hook(lambda mod, inp, out: logits.append(out[:, -1].detach().float().clone()))
+        h2 = model.decoder.bert.embeddings.register_forward_pre_hook(lambda mod, args, kwargs: fed.append(kwargs["input_ids"][:, -1].clone()), with_kwargs=True)
+        try:
+            with torch.no_grad():
+                o = model.generate(pixel_values=x, special_token_ids=[SEP], max_length=steps + 1, bos_token_id=BOS, eos_token_id=EOS, pad_token_id=PAD, num_beams=4,
+                                   num_return_sequences=4, return_dict_in_generate=True, use_cache=True, do_sample=False, output_scores=True, length_penalty=lp)
+        finally:
+            h1.remove(); h2.remove()
+        seqs, sc = o["sequences"].view(3, 4, -1), o["sequences_scores"].view(3, 4)
+        lens = _hyp_lengths(seqs)
+        assert len(logits) == len(fed) and all(l.shape == (12, V) for l in logits)
+        d.update({f"{name}_length_penalty": lp, f"{name}_eos_bias": bias, f"{name}_logits": torch.stack(logits).numpy(), f"{name}_fed": torch.stack(fed).numpy(),
+                  f"{name}_all": seqs.numpy(), f"{name}_all_scores": sc.numpy()})
+        print("beam_index", name, "steps run", len(logits), "lens", lens.tolist(), "scores", sc[:, 0].tolist())
+    np.savez_compressed(os.path.join(OUT, "beam_index.npz"), **d)
 
 
 def fixture_reward_trunk():
@@ -930,10 +1059,50 @@ def fixture_reward_trunk():
     print("reward_trunk", stats(h))
 
 
+ALL = ["token_ops", "encoder", "tf_single", "tf_single_train", "tf_longitudinal", "tf_longitudinal_train", "generate", "reward_trunk",
+       "encoder_full", "tf_full", "longitudinal_c5", "beam_margins", "generate_single", "beam_safe", "beam_index"]
+
+
+def verify(which):
+    """--verify: rebuild the fixtures into a scratch directory (the seed-searching ones from the seeds recorded in the committed files) and require
+    every array of every committed file to come out bit for bit: the committed data ARE outputs of the reference as it runs here."""
+    import shutil
+    import tempfile
+    global OUT
+    OUT = tempfile.mkdtemp(prefix="golden_verify_")
+    os.environ.pop("BEAM_SAFE_SEEDS", None)
+    try:
+        if "beam_margins" in which and "generate" not in which:
+            shutil.copy(os.path.join(COMMITTED, "generate_multi.npz"), OUT)       # (beam_margins cross-checks against it)
+        for w in which:
+            globals()["fixture_" + w]()
+        bad = []
+        for f in sorted(os.listdir(OUT)):
+            new, old = os.path.join(OUT, f), os.path.join(COMMITTED, f)
+            if not os.path.exists(old):
+                bad.append(f"{f}: not committed")
+            elif f.endswith(".npz"):
+                a, b = np.load(new), np.load(old)
+                if sorted(a.files) != sorted(b.files):
+                    bad.append(f"{f}: keys differ {sorted(set(a.files) ^ set(b.files))}")
+                bad += [f"{f}[{k}] differs" for k in a.files if k in b.files and not (a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"))]
+            elif open(new, "rb").read() != open(old, "rb").read():
+                bad.append(f"{f}: differs")
+        print("verified", sorted(os.listdir(OUT)))
+        if bad:
+            raise SystemExit("fixtures do NOT reproduce:\n  " + "\n  ".join(bad))
+        print("every rebuilt array equals the committed one")
+    finally:
+        shutil.rmtree(OUT, ignore_errors=True)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["token_ops", "encoder", "tf_single", "tf_single_train", "tf_longitudinal", "tf_longitudinal_train", "generate", "reward_trunk",
-                             "encoder_full", "tf_full", "longitudinal_c5", "beam_margins", "generate_single", "beam_safe"]
+    args = [a for a in sys.argv[1:] if a != "--verify"]
+    if "--verify" in sys.argv[1:]:
+        verify(args or ALL)
+        sys.exit(0)
+    which = args or ALL
     meta = {"transformers": transformers.__version__, "torch": torch.__version__,
             "adapter": "SURVEY.md A.3 (D1 legacy decoder.prepare_inputs_for_generation + D2 empty-cache prefill)",
             "reference": "/root/reference (aehrc/cxrmate @ 2025-02-22)", "mode": "eval(), fp32, CPU; tf_single_train: train() with the drawn dropout / DropPath masks recorded"}

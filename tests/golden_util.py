@@ -86,12 +86,26 @@ def generate_multi_case():
 SHARPEN_KEYS = ("decoder.cls.predictions.transform.LayerNorm.weight", "decoder.cls.predictions.transform.LayerNorm.bias")
 
 
-def sharpened_state(cfg, seed, perturb, sharpen):
-    """Seeded weights with the LM head's final LayerNorm scaled by `sharpen` (the generator of the robust generate fixtures does the same)."""
+def sharpened_state(cfg, seed, perturb, sharpen, cross_gain=1.0):
+    """Seeded weights with the LM head's final LayerNorm scaled by `sharpen` and every decoder layer's cross-attention output projection (weight and
+    bias) by `cross_gain` (the generator of the robust generate fixtures does the same: tests/golden/make_golden.py build())."""
     sd = weights.init_encoder_decoder(cfg, seed=seed, perturb=perturb)
     for k in SHARPEN_KEYS:
         sd[k] = sd[k] * sharpen
+    if cross_gain != 1.0:
+        for k in list(sd):
+            if "crossattention.output.dense." in k:
+                sd[k] = sd[k] * cross_gain
     return sd
+
+
+def distinct_study_pixels(pixel_seed, img_off, size=96):
+    """make_golden.distinct_study_pixels: three 2-image studies of different contrast / brightness, study 1 with a zero-padded image."""
+    x = torch.randn(3, 2, 3, size, size, generator=torch.Generator().manual_seed(pixel_seed))
+    for b in range(3):
+        x[b] = x[b] * (1.0 + img_off * b) + img_off * b
+    x[1, 1] = 0.0
+    return x
 
 
 def generate_single_case():
@@ -103,17 +117,18 @@ def generate_single_case():
 
 
 def beam_safe_case(name):
-    """-> (cfg, state dict, pixels, EOS bias, length_penalty, reference hypotheses [3,4,T], scores [3,4]) or None when the generator found no
-    robust case of that kind."""
+    """-> (cfg, state dict, pixels, EOS bias, length_penalty, reference hypotheses [3,4,T], scores [3,4], steps, score tolerance) or None when the
+    fixture holds no case of that kind. The score tolerance is 0.4 x the smallest gap between a row's best hypothesis and its runner-up; rows are told
+    apart by their sequences (pairwise different by construction of the fixture)."""
     g = load("generate_beam_safe.npz")
     if f"{name}_seed" not in g.files:
         return None
-    cfg = tiny_config(vocab_size=1000, decoder_layers=2, image_size=96)
+    cfg = tiny_config(vocab_size=int(g["vocab"]), decoder_layers=2, image_size=96)
     seed = int(g[f"{name}_seed"])
-    sd = sharpened_state(cfg, seed, float(g["perturb"]), float(g["sharpen"]))
-    x = torch.randn(3, 2, 3, 96, 96, generator=torch.Generator().manual_seed(int(g[f"{name}_pixel_seed"])))
-    x[1, 1] = 0.0
-    return cfg, sd, x, float(g[f"{name}_eos_bias"]), float(g[f"{name}_length_penalty"]), g[f"{name}_all"], g[f"{name}_all_scores"], int(g["steps"])
+    sd = sharpened_state(cfg, seed, float(g["perturb"]), float(g["sharpen"]), float(g["cross_gain"]))
+    x = distinct_study_pixels(int(g[f"{name}_pixel_seed"]), float(g["img_off"]))
+    return (cfg, sd, x, float(g[f"{name}_eos_bias"]), float(g[f"{name}_length_penalty"]), g[f"{name}_all"], g[f"{name}_all_scores"], int(g["steps"]),
+            float(g[f"{name}_score_tol"]))
 
 
 def generate_longitudinal_case():
@@ -224,3 +239,29 @@ def longitudinal_c5_case():
     x = torch.randn(2, 3, 3, 384, 384, generator=gen)
     x[1, 2] = 0.0
     return g, cfg, sd, x
+
+
+def beam_index_cases():
+    """beam_index.npz: per case (name, length_penalty, logits [steps, B*nb, V] fp32 as the REFERENCE produced them step by step, the token each
+    running beam was fed [steps, B*nb], the reference's final hypotheses [B, nb, T] and scores [B, nb])."""
+    g = load("beam_index.npz")
+    out = []
+    for name in (str(n) for n in g["cases"]):
+        out.append((name, float(g[f"{name}_length_penalty"]), torch.from_numpy(g[f"{name}_logits"]), torch.from_numpy(g[f"{name}_fed"]),
+                    torch.from_numpy(g[f"{name}_all"]), torch.from_numpy(g[f"{name}_all_scores"])))
+    return int(g["steps"]), out
+
+
+def replay_logits_fn(logits, fed=None):
+    """logits_fn for oracle.generate.beam_search that returns recorded per-step logits [steps, rows, V] (teacher-fed scores: the search becomes pure
+    index work); with `fed` it also asserts that the beams the search feeds at every step end in the recorded tokens."""
+    state = {"t": 0}
+
+    def fn(ids, am, tt, pos):
+        t = state["t"]
+        if fed is not None:
+            assert torch.equal(ids[:, -1], fed[t]), (t, ids[:, -1], fed[t])
+        state["t"] = t + 1
+        return logits[t][:, None, :]
+    fn.state = state
+    return fn

@@ -182,6 +182,63 @@ def test_gradient_accumulation_equals_one_step_on_the_concatenated_batch():
         torch.testing.assert_close(w4[n], w1[n], atol=2e-4, rtol=0)
 
 
+def _order_worker(rank, world, path, q):
+    import torch.distributed as dist
+    from cxrmate_amd import modelling
+    from cxrmate_amd.training import FusedAdamW, tf_train_step
+    dist.init_process_group("gloo", init_method=f"file://{path}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    cfg = gu.tiny_config(vocab_size=1000, decoder_layers=2, image_size=96)
+    m = modelling.SingleCXREncoderDecoderModel(cfg, device="cuda:0", seed=21, perturb=0.05)
+    opt = FusedAdamW(m, lr=1e-3)
+    log = opt.reducer.log = []
+    g = torch.Generator().manual_seed(5)
+    px = torch.randn(8, 3, 96, 96, generator=g)
+    ids = torch.randint(12, 1000, (8, 17), generator=g)
+    ids[:, 0] = 1
+    marks = []
+    for step in range(2):                                   # two optimiser steps of two micro-batches each
+        for j in range(2):
+            sl = slice(rank * 4 + j * 2, rank * 4 + j * 2 + 2)
+            inp, lab = ids[sl, :-1].cuda(), ids[sl, 1:].cuda()
+            tf_train_step(m, opt, px[sl].cuda(), inp, torch.ones_like(inp), m.token_ids_to_token_type_ids(inp, [3]), lab, pad_token_id=4, accumulate=(j, 2))
+            marks.append(len(log))
+    torch.cuda.synchronize()
+    ranges = dict(split=opt.split, total=m._param_total, stages={s_: opt.stage_range(s_) for s_ in opt.stage_start})
+    q.put((rank, list(log), marks, ranges, m.f32("encoder.cvt.encoder.stages.1.layers.0.intermediate.dense.weight").cpu().numpy()))
+    dist.destroy_process_group()
+
+
+def test_dp2_collective_order_is_identical_on_both_ranks_with_per_stage_buckets_under_accumulation():
+    """Two ranks (gloo, one device), accumulate=(j, 2): no collective in the first micro-step (DDP no_sync), and in the last one every rank issues
+    the SAME sequence of all-reduces -- decoder range first (under the encoder backward), then the encoder stage by stage as each stage's backward
+    completes: stage 2 + projection head, stage 1, stage 0 (the reference's DDP buckets, config/train/single_tf.yaml:8). A rank that issued them
+    in another order would deadlock or mix buckets on RCCL."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as d:
+        procs = [ctx.Process(target=_order_worker, args=(r, 2, os.path.join(d, "rdzv"), q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+    (_, log0, marks0, rg, w0), (_, log1, marks1, _, w1) = res
+    assert log0 == log1 and marks0 == marks1
+    assert marks0[0] == 0 and marks0[2] == marks0[1]                   # micro-step 0 of each optimiser step: gradients stay local
+    per_step = log0[: marks0[1]]
+    assert log0[marks0[1]:] == per_step                                # the second optimiser step repeats the sequence
+    st = rg["stages"]
+    want = [(rg["split"], rg["total"]), st[2], st[1], st[0]]           # decoder | stage 2 + head | stage 1 | stage 0
+    assert st[2][1] == rg["split"] and st[0][0] == 0 and st[0][1] == st[1][0] and st[1][1] == st[2][0]
+    assert per_step == want, (per_step, want)
+    assert np.array_equal(w0, w1)                                      # replicas identical after two accumulated steps
+
+
 def _nccl_worker(path, q):
     import torch.distributed as dist
     from cxrmate_amd import dp, modelling

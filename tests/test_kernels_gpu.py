@@ -201,7 +201,8 @@ def test_transpose_colsum_weightgrad(ops):
     close(db, dy.float().sum(0), rtol=1e-3, atol=1e-3, what="db")
 
 
-@pytest.mark.parametrize("R,I,J", [(577, 192, 384), (18464, 384, 1536), (100, 64, 64), (8192, 768, 768), (4100, 1000, 768), (31, 8, 768)])
+@pytest.mark.parametrize("R,I,J", [(577, 192, 384), (18464, 384, 1536), (100, 64, 64), (8192, 768, 768), (4100, 1000, 768), (31, 8, 768),
+                                   (36928, 384, 384), (36928, 1536, 384), (36928, 384, 1536), (40000, 768, 200), (33000, 384, 136)])     # (384 x 128 blocks)
 def test_gemm_tn_weight_grad(ops, R, I, J):
     big = dev(rnd(R, I + 64, seed=1).to(BF))
     p, q = big[:, :I], dev(rnd(R, J, seed=2).to(BF))
@@ -214,9 +215,25 @@ def test_gemm_tn_weight_grad(ops, R, I, J):
     close(db, ref_b, rtol=1e-2, atol=1e-2, what="gemm_tn dbias")
 
 
-def test_gemm_tn_exact_integers(ops):
+@pytest.mark.parametrize("R,I,J", [(96, 128, 256), (4128, 384, 384), (4128, 768, 264), (4128, 512, 384)])
+def test_gemm_tn_exact_integers(ops, R, I, J, monkeypatch):
     # small integers are exact in bf16 and in fp32 accumulation: any row/column permutation of the transposed LDS reads shows up
-    R, I, J = 96, 128, 256
+    # (the larger shapes run the 256 x 256- and the 384 x 128-block kernels: CXR_TN2_MIN=1 sends every shape wider than 128 there)
+    if R > 96:
+        import subprocess, sys, os
+        code = ("import torch; from cxrmate_amd import ops\n"
+                f"R, I, J = {R}, {I}, {J}\n"
+                "BF = torch.bfloat16\n"
+                "p = ((torch.arange(R * I).reshape(R, I) * 7) % 5 - 2).float().to(BF).cuda()\n"
+                "q = ((torch.arange(R * J).reshape(R, J) * 3) % 7 - 3).float().to(BF).cuda()\n"
+                "out = torch.zeros(I, J, device='cuda'); db = torch.zeros(I, device='cuda')\n"
+                "ops.gemm_tn(p, q, out, dbias=db)\n"
+                "assert torch.equal(out.cpu(), (p.double().t() @ q.double()).float().cpu()), 'product'\n"
+                "assert torch.equal(db.cpu(), p.double().sum(0).float().cpu()), 'bias'\n")
+        env = dict(os.environ, CXR_TN2_MIN="1")            # (read once per process by the library: a child process)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        return
     p = ((torch.arange(R * I).reshape(R, I) * 7) % 5 - 2).float().to(BF).cuda()
     q = ((torch.arange(R * J).reshape(R, J) * 3) % 7 - 3).float().to(BF).cuda()
     out = torch.zeros(I, J, device="cuda")
@@ -238,6 +255,66 @@ def test_gemm_tn_is_deterministic(ops, R, I, J):
     assert float(wide[0][:, :8].abs().max()) == 0.0 and float(wide[0][:, 8 + J:].abs().max()) == 0.0
     close(wide[0][:, 8:8 + J], 1.25 * (p.float().t() @ q.float()), rtol=1e-2, atol=1e-2, what="deterministic gemm_tn")
     close(dbs[0], 2.0 * p.float().sum(0), rtol=1e-2, atol=1e-2, what="deterministic gemm_tn dbias")
+
+
+def test_deferred_weight_gradient_sums_equal_the_immediate_ones(ops):
+    """Round 4: on the weight-gradient stream every split-K weight-gradient GEMM only leaves its partial tiles behind (scratch of its own) and ONE
+    batched launch adds all pending sums (cxr_gemm_tn_partial_bf16 + cxr_gemm_tn_reduce_batch, ops.wgrad_reduce). Same lanes, same split order as the
+    per-GEMM reduce launches: the gradients -- 60 of them here (two batches), strided outputs, bias gradients, accumulation into non-zero buffers,
+    the same output hit twice -- are bit-identical to the immediate path, and a second deferred round over the recycled scratch is too."""
+    from cxrmate_amd.training import wgrad_overlap
+    shapes = [(8192, 768, 768), (5000, 384, 1536), (3001, 200, 72), (9280, 384, 384), (4096, 64, 64), (6000, 192, 576), (2048, 3072, 768)]
+    probs = []
+    for n in range(60):
+        R, I, J = shapes[n % len(shapes)]
+        R = R - 32 * (n // len(shapes))
+        probs.append((dev(rnd(R, I, seed=100 + n).to(BF)), dev(rnd(R, J, seed=200 + n).to(BF)), n % 3 != 0, 1.0 if n % 2 else 0.5))
+
+    calls = {"partial": 0, "batch": 0, "single": 0}
+    real_call = ops.LIB.call
+
+    def counting(name, *a):
+        key = {"cxr_gemm_tn_partial_bf16": "partial", "cxr_gemm_tn_reduce_batch": "batch", "cxr_gemm_tn_bf16": "single"}.get(name)
+        if key:
+            calls[key] += 1
+        return real_call(name, *a)
+
+    def run(deferred):
+        outs = [torch.full((p.shape[1], q.shape[1] + 8), 0.25, device="cuda") for p, q, _, _ in probs]
+        dbs = [torch.full((p.shape[1],), -1.0, device="cuda") if b else None for p, _, b, _ in probs]
+        rounds = []
+        for rnd_ in range(2):
+            if deferred:
+                with wgrad_overlap():
+                    for (p, q, b, al), o, d in zip(probs, outs, dbs):
+                        ops.linear_bwd_weight(p, q, o[:, 4:4 + q.shape[1]], d) if al == 1.0 else ops._side_defer(
+                            lambda p=p, q=q, o=o, d=d, al=al: ops.gemm_tn(p, q, o[:, 4:4 + q.shape[1]], dbias=d, alpha=al), p, q, o, d)
+                    ops.wgrad_flush()
+                    ops.wgrad_join()
+                    assert not ops._TN_PENDING
+            else:
+                for (p, q, b, al), o, d in zip(probs, outs, dbs):
+                    ops.gemm_tn(p, q, o[:, 4:4 + q.shape[1]], dbias=d, alpha=al)
+            torch.cuda.synchronize()
+            rounds.append(([o.clone() for o in outs], [None if d is None else d.clone() for d in dbs]))
+        return rounds
+
+    ops.LIB.call = counting
+    try:
+        now, later = run(False), run(True)
+    finally:
+        ops.LIB.call = real_call
+    # the deferred rounds went through the partial-tile entry point and needed far fewer reduce launches than GEMMs (a reduce is issued whenever 40
+    # sums or 64 MB of partial tiles are pending, so that the tiles are still cache-resident when they are read)
+    assert calls["single"] == 120 and calls["partial"] == 120 and 2 <= calls["batch"] <= 40, calls
+    for (o0, d0), (o1, d1) in zip(now, later):
+        for a, b in zip(o0, o1):
+            assert torch.equal(a, b)
+        for a, b in zip(d0, d1):
+            assert (a is None and b is None) or torch.equal(a, b)
+    p, q, _, al = probs[0]
+    close(now[1][0][0][:, 4:4 + q.shape[1]], 0.25 + 2 * al * (p.float().t() @ q.float()), rtol=1e-2, atol=1e-2, what="accumulated twice")
+    assert float((now[0][0][0][:, :4] - 0.25).abs().max()) == 0.0
 
 
 # ------------------------------------------------------------------------------------------------ attention
@@ -283,7 +360,9 @@ def test_attention_fwd(ops, B, H, Tq, Tk, causal, masked):
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,causal,masked", [(2, 1, 1300, 200, False, False), (1, 3, 577, 145, False, False), (2, 2, 300, 300, True, True),
-                                                     (2, 12, 70, 1152, False, True), (1, 2, 100, 33, False, False), (2, 1, 2100, 64, False, False)])
+                                                     (2, 12, 70, 1152, False, True), (1, 2, 100, 33, False, False), (2, 1, 2100, 64, False, False),
+                                                     (2, 3, 600, 576, False, False), (1, 2, 256, 256, True, False), (1, 1, 1000, 2304, False, False),
+                                                     (2, 2, 130, 700, True, True)])
 def test_attention_kernel_generations_agree(ops, B, H, Tq, Tk, causal, masked):
     """cxr_attn_config: the round-3 kernels (64 query rows per wave, one barrier per tile, skipped masked tiles; dQ kernel for unmasked Tq > 1024)
     against the rounds 1-2 kernels on the same inputs: context within one bf16 step of each other (the online softmax advances in 32-key steps
@@ -1111,6 +1190,22 @@ def test_dwproj_fused_train(ops, Bn, C, H, W, tok0):
     cz_y = ops.dwproj_bn_train_bwd_stats(x, H, W, tok0, [dict(base, beta=par[0]["b"], yf=y0, dgamma=dz_y[0], dbeta=dz_y[1])])
     close(dz_y[0], dz[0], rtol=5e-3, atol=5e-3, what="dgamma with a zero gamma channel")
     assert torch.equal(dz_y[0][:64], dz[0][:64]) and torch.equal(cz_y[0][:, :64], cz[0][:, :64])      # the slice with the zero gamma took the convolution path
+    # pretrained-style parameters, |beta| >> |gamma| in one slice (beta 2.0, gamma 0.02: bf16 rounding of the stored output would put an error of
+    # 2^-9 * 100 on the recovered normalised activation): that slice must take the convolution path (bit-identical to the run without yf), the others
+    # may keep the streaming path
+    if C >= 128:
+        g1, b1 = par[1]["g"].clone(), par[1]["b"].clone()
+        g1[64:128] = 0.02; b1[64:128] = 2.0
+        var1 = 1.0 / st[1]["rstd"] ** 2 - 1e-5
+        f1 = ops.bn_fold(par[1]["w"], g1, b1, st[1]["mean"], var1, 1e-5)
+        y1 = ops.dwproj_apply(x, H, W, tok0, [dict(stride=strides[1], taps=f1[0], shift=f1[1])])[0]
+        da, da_y = [torch.zeros(C, device="cuda") for _ in range(2)], [torch.zeros(C, device="cuda") for _ in range(2)]
+        base1 = dict(stride=strides[1], taps=raws[1], y=dys[1], gamma=g1, mean=st[1]["mean"], rstd=st[1]["rstd"])
+        ca = ops.dwproj_bn_train_bwd_stats(x, H, W, tok0, [dict(base1, dgamma=da[0], dbeta=da[1])])
+        ca_y = ops.dwproj_bn_train_bwd_stats(x, H, W, tok0, [dict(base1, beta=b1, yf=y1, dgamma=da_y[0], dbeta=da_y[1])])
+        assert torch.equal(da_y[0][64:128], da[0][64:128]) and torch.equal(ca_y[0][:, 64:128], ca[0][:, 64:128])
+        close(da_y[0], da[0], rtol=5e-3, atol=5e-3, what="dgamma with a large-beta / small-gamma slice")
+        close(ca_y[0], ca[0], rtol=5e-3, atol=5e-3, what="dc coefficients with a large-beta / small-gamma slice")
     GS = ops.dwproj_dc_taps_(x, H, W, tok0, [dict(stride=s_, taps=r, y=d, coef=cf, dw=w_) for s_, r, d, cf, w_ in zip(strides, raws, dys, coefs, dw)], need_GS=True)
     for i, lv in enumerate(leaves):
         if tok0:
@@ -1396,6 +1491,98 @@ def test_beam_step_kernel_follows_the_library_step(ops, nb, penalty, V):
         assert torch.equal(d_hit[cur & 1].bool(), hits.all(1)), cur
         stopped = not (bool(st["unsat"].any()) and not bool(hits.all()))
     assert stopped and bool(st["finished"][:, 0].all())
+
+
+def _device_beam_state(B, nb, L, P, pad, first_token, dev="cuda"):
+    run = torch.full((nb, B, L), pad, dtype=torch.int64, device=dev)
+    run[:, :, :P] = first_token
+    rs = torch.zeros((B, nb), device=dev); rs[:, 1:] = -1.0e9
+    return dict(run=run, seq=run.clone(), rs=rs, bs=torch.full((B, nb), -1.0e9, device=dev), fin=torch.zeros((B, nb), dtype=torch.uint8, device=dev),
+                unsat=torch.ones((2, B), dtype=torch.int32, device=dev), hit=torch.zeros((2, B), dtype=torch.int32, device=dev),
+                idx=torch.zeros(nb * B, dtype=torch.int64, device=dev))
+
+
+def _drive_device_beam_search(ops, logits_steps, lp, B, nb, L, eos, pad, bos, trace, fed=None):
+    """cxr_beam_step + cxr_gather_batch_multi_bf16 driven with GIVEN fp32 logits (study-major rows [B*nb, V] per step, as the oracle / the reference
+    order them): every step is compared with the oracle's trace of the same search -- running beams, parent beam, new token, finished set, finished
+    hypotheses bit for bit -- and a stand-in KV cache (row r, position t holds the token beam r was fed at t) is reordered by the kernel's beam index:
+    after every step each cache row must spell its beam's own history. -> final (sequences [B,nb,L], scores [B,nb])."""
+    dev, P = "cuda", 1
+    V = logits_steps[0].shape[-1]
+    st = _device_beam_state(B, nb, L, P, pad, bos)
+    R, C = nb * B, 8
+    cache, cache2 = (torch.zeros((R, L, C), dtype=BF, device=dev) for _ in range(2))
+    for t, lg in enumerate(logits_steps):
+        cur = P + t
+        tr = trace[t]
+        dev_running = st["run"].permute(1, 0, 2)[:, :, :cur].cpu()                      # [B, nb, cur]
+        assert torch.equal(dev_running, tr["running_in"]), (t, dev_running, tr["running_in"])
+        if fed is not None:
+            assert torch.equal(dev_running[:, :, -1].reshape(-1), fed[t]), t
+        cache[:, cur - 1, :] = st["run"].view(R, L)[:, cur - 1].to(BF)[:, None]         # the "key/value" of the token fed at this step (ids < 256: exact in bf16)
+        bm = lg.view(B, nb, V).permute(1, 0, 2).reshape(R, V).contiguous().cuda()
+        ops.beam_step(bm, st["run"], st["seq"], st["rs"], st["bs"], st["fin"], st["unsat"], st["hit"], st["idx"], cur, L, eos, float(cur + 1 - P) ** lp)
+        ops.gather_batch_multi([cache], st["idx"], cur, [cache2])
+        cache, cache2 = cache2, cache
+        parent = (st["idx"].view(nb, B).t() // B).cpu()
+        assert torch.equal(st["idx"].view(nb, B).t() % B, torch.arange(B, device=dev)[:, None].expand(B, nb)), t      # a beam never leaves its study
+        live = tr["running_scores"] > -1.0e8                                             # (slots at -1e9 are ties between ended continuations)
+        assert torch.equal(parent[live], tr["parent"][live]) and torch.equal(st["run"].permute(1, 0, 2)[:, :, cur].cpu()[live], tr["token"][live]), t
+        np.testing.assert_allclose(st["rs"].cpu().numpy()[live.numpy()], tr["running_scores"].numpy()[live.numpy()], rtol=2e-6, atol=2e-5)   # (fp32 log-sum-exp order)
+        assert torch.equal(st["fin"].bool().cpu(), tr["finished"]), t
+        fin = tr["finished"]
+        assert torch.equal(st["seq"].permute(1, 0, 2).cpu()[fin], tr["sequences"][fin]), t
+        np.testing.assert_allclose(st["bs"].cpu().numpy()[fin.numpy()], tr["beam_scores"].numpy()[fin.numpy()], rtol=2e-6, atol=2e-5)
+        # the reordered cache rows spell their beams' histories (what the next step's attention would read)
+        hist = st["run"].view(R, L)[:, :cur].to(BF)
+        lv = live.t().reshape(-1).cuda()
+        assert torch.equal(cache[:, :cur, 0][lv], hist[lv]) and torch.equal(cache[:, :cur, C - 1][lv], hist[lv]), t
+    par = (P + len(logits_steps) - 1) & 1
+    stopped = not (bool(st["unsat"][par].max() > 0) and bool(st["hit"][par].min() == 0))
+    return st["seq"].permute(1, 0, 2).cpu(), st["bs"].cpu(), stopped
+
+
+def test_device_beam_search_is_bit_equal_on_the_references_recorded_logits(ops):
+    """The last link of the beam-search parity chain, as INDEX work (no model on the device, no bf16 noise): tests/golden/beam_index.npz holds the
+    fp32 logits of every step of the reference's own beam-4 generate (early EOS, hypotheses of different length, length_penalty 0.5 / 1 / 2, searches
+    that end before max_length). Fed to cxr_beam_step + the cache-reorder kernel they must give the reference's four final hypotheses per study bit
+    for bit, and the oracle's beams at every step (oracle == reference on the same data: tests/test_oracle_golden.py)."""
+    import golden_util as gu
+    from oracle import generate as ogen
+    steps, cases = gu.beam_index_cases()
+    for name, lp, logits, fed, ref_all, ref_scores in cases:
+        trace = []
+        ogen.beam_search(gu.replay_logits_fn(logits), "multi", 3, 4, [gu.SEP], gu.BOS, gu.EOS, gu.PAD, steps + 1, length_penalty=lp, return_all=True, trace=trace)
+        seqs, scores, stopped = _drive_device_beam_search(ops, list(logits), lp, 3, 4, steps + 1, gu.EOS, gu.PAD, gu.BOS, trace, fed=fed)
+        assert stopped, name                                                             # the device's stop flags fall on the step the reference stopped on
+        assert torch.equal(seqs[:, :, : ref_all.shape[-1]], ref_all), (name, seqs, ref_all)
+        assert bool((seqs[:, :, ref_all.shape[-1]:] == gu.PAD).all()), name
+        np.testing.assert_allclose(scores.numpy(), ref_scores.numpy(), rtol=2e-6, atol=2e-5, err_msg=name)
+
+
+@pytest.mark.parametrize("nb,lp,V,seed", [(4, 0.5, 30000, 0), (4, 2.0, 30000, 1), (4, 1.0, 9001, 2), (2, 2.0, 30000, 3), (2, 0.5, 4096, 4)])
+def test_device_beam_search_is_bit_equal_to_the_oracle_on_full_vocabulary_logits(ops, nb, lp, V, seed):
+    """The same teacher-fed comparison at the real vocabulary size (several 4096-wide scan chunks per row) on seeded synthetic logits whose EOS
+    column rises step by step, so that hypotheses end at different lengths and the length penalty ranks them: device == oracle.beam_search
+    (pinned against the reference by beam_index.npz) at every step and at the end, bit for bit."""
+    import golden_util as gu
+    from oracle import generate as ogen
+    B, L = 3, 18
+    g = torch.Generator().manual_seed(100 + seed)
+    logits = [torch.randn((B * nb, V), generator=g) * 3.0 for _ in range(L - 1)]
+    base = 3.0 * math.sqrt(2 * math.log(V)) - 8.0                                      # EOS starts ~3 sigma below the row maximum and gains 0.45 per step
+    for t, lg in enumerate(logits):
+        lg[:, gu.EOS] += base + 0.45 * t + 2.0 * torch.rand((B * nb,), generator=g)
+    trace = []
+    ref_all, ref_scores = ogen.beam_search(gu.replay_logits_fn(logits), "multi", B, nb, [gu.SEP], gu.BOS, gu.EOS, gu.PAD, L, length_penalty=lp, return_all=True, trace=trace)
+    assert min(t["min_gap"] for t in trace) > 1e-5
+    seqs, scores, stopped = _drive_device_beam_search(ops, logits[: len(trace)], lp, B, nb, L, gu.EOS, gu.PAD, gu.BOS, trace)
+    assert stopped
+    assert torch.equal(seqs[:, :, : ref_all.shape[-1]], ref_all)
+    np.testing.assert_allclose(scores.numpy(), ref_scores.numpy(), rtol=2e-6, atol=2e-5)
+    e = ref_all == gu.EOS
+    lens = torch.where(e.any(-1), e.int().argmax(-1) + 1, torch.full(e.shape[:-1], ref_all.shape[-1]))
+    assert len(set(lens.reshape(-1).tolist())) >= 3                                      # hypotheses of different length were ranked
 
 
 def test_gather_batch_multi_equals_single_gathers(ops):

@@ -210,6 +210,111 @@ def test_autograd_bridges_bind_gradients_with_torch_semantics(M, monkeypatch):
         assert torch.allclose(a, b, rtol=2e-3, atol=2e-5 * max(1.0, float(b.abs().max()))), ("foreign", i)
 
 
+def test_gradient_binding_is_off_wherever_autograd_hooks_could_observe_it(M, tmp_path):
+    """Binding p.grad to the flat gradient buffer bypasses autograd's AccumulateGrad nodes: Tensor.register_hook, post-accumulate-grad hooks and the
+    DistributedDataParallel reducer (which hangs its hooks on those nodes) would never fire. With a hook on any parameter of a bridge's half of the
+    model, or under a torch.distributed process group, the gradients take the autograd route: hooks see them, and a one-rank DDP wrap of the model -- what Lightning does to the
+    reference's module under `strategy: ddp` -- trains for several iterations (the reducer raises in the second one if a gradient never arrives)."""
+    import torch.distributed as dist
+    g, cfg, sd, x, inp, lab, am, tt = gu.tf_single_case()
+    m = M.SingleCXREncoderDecoderModel(cfg, seed=None)
+    m.load_state_dict(sd)
+    kw = dict(pixel_values=x.cuda(), decoder_input_ids=inp.cuda(), decoder_attention_mask=am.cuda(),
+              decoder_token_type_ids=m.token_ids_to_token_type_ids(inp, [gu.SEP]), return_dict=True)
+
+    def loss_of(model):
+        return torch.nn.functional.cross_entropy(model(**kw).logits.permute(0, 2, 1), lab.cuda(), ignore_index=gu.PAD)
+
+    loss_of(m).backward()
+    torch.cuda.synchronize()
+    ref = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    lo, hi = m.gflat.data_ptr(), m.gflat.data_ptr() + 4 * m.gflat.numel()
+    assert all(lo <= p.grad.data_ptr() < hi for p in m.parameters())                # no hooks: bound
+    seen = {}
+    name = "decoder.bert.encoder.layer.0.output.dense.weight"
+    p0 = dict(m.named_parameters())[name]
+    h1 = p0.register_hook(lambda gr: seen.__setitem__("tensor_hook", gr.detach().clone()) or gr * 2.0)
+    h2 = p0.register_post_accumulate_grad_hook(lambda p_: seen.__setitem__("post_hook", p_.grad.detach().clone()))
+    m.zero_grad(set_to_none=True)
+    loss_of(m).backward()
+    torch.cuda.synchronize()
+    assert torch.allclose(seen["tensor_hook"], ref[name], rtol=1e-3, atol=1e-6) and torch.allclose(seen["post_hook"], 2.0 * ref[name], rtol=1e-3, atol=1e-6)
+    assert torch.allclose(p0.grad, 2.0 * ref[name], rtol=1e-3, atol=1e-6)           # the hook's return value is what accumulates, as in torch
+    # the hooked parameter's half of the model (one autograd bridge per half) went through autograd; the other half has nothing that could observe
+    # the binding and keeps it
+    assert not any(lo <= p.grad.data_ptr() < hi for n, p in m.named_parameters() if n.startswith("decoder."))
+    assert all(lo <= p.grad.data_ptr() < hi for n, p in m.named_parameters() if n.startswith("encoder."))
+    h1.remove(); h2.remove()
+    # one-rank DistributedDataParallel (gloo on device tensors): three iterations with torch.optim.AdamW, gradients equal to the unwrapped model's
+    dist.init_process_group("gloo", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1)
+    try:
+        ddp = torch.nn.parallel.DistributedDataParallel(m)
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+        for it in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss_of(ddp).backward()
+            if it == 0:
+                torch.cuda.synchronize()
+                for n, p in m.named_parameters():
+                    assert torch.allclose(p.grad, ref[n], rtol=2e-3, atol=2e-5 * max(1.0, float(ref[n].abs().max()))), n
+            opt.step()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fused_adamw_behind_the_torch_optimizer_interface(M):
+    """cxrmate_amd.optim.AdamW(model.parameters(), lr) -- what a reference caller's configure_optimizers (modules/lightning_modules/single.py:426-431)
+    returns instead of torch.optim.AdamW: same weights as torch's optimiser after several caller-style steps (zero_grad(set_to_none=True) ->
+    backward -> step), parameter groups / lr changes honoured, state_dict round trip into a fresh optimiser, and the bf16 shadow follows."""
+    from cxrmate_amd.optim import AdamW
+    g, cfg, sd, x, inp, lab, am, tt = gu.tf_single_case()
+
+    def run(make_opt, steps=4, reload_at=None):
+        m = M.SingleCXREncoderDecoderModel(cfg, seed=None)
+        m.load_state_dict(sd)
+        kw = dict(pixel_values=x.cuda(), decoder_input_ids=inp.cuda(), decoder_attention_mask=am.cuda(),
+                  decoder_token_type_ids=m.token_ids_to_token_type_ids(inp, [gu.SEP]), return_dict=True)
+        opt = make_opt(m)
+        losses = []
+        for it in range(steps):
+            if reload_at == it:
+                state = opt.state_dict()
+                opt = make_opt(m)
+                opt.load_state_dict(state)
+            if it == 2:
+                for grp in opt.param_groups:
+                    grp["lr"] = 5e-4                                   # what an lr scheduler does
+            opt.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.cross_entropy(m(**kw).logits.permute(0, 2, 1), lab.cuda(), ignore_index=gu.PAD)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        return m, losses, opt
+
+    groups = lambda m: [{"params": [p for n, p in m.named_parameters() if n.startswith("encoder.")], "weight_decay": 0.0},
+                        {"params": [p for n, p in m.named_parameters() if not n.startswith("encoder.")]}]
+    mt, lt, _ = run(lambda m: torch.optim.AdamW(groups(m), lr=1e-3))
+    mf, lf, of = run(lambda m: AdamW(groups(m), lr=1e-3))
+    mr, lr_, _ = run(lambda m: AdamW(groups(m), lr=1e-3), reload_at=2)
+    assert len(of._plans) == 2                                          # the steady-state path (one launch per contiguous run) was taken
+    assert np.allclose(lt, lf, atol=5e-3) and np.allclose(lf, lr_, atol=1e-3), (lt, lf, lr_)
+    for (n, a), b, c in zip(mt.named_parameters(), mf.parameters(), mr.parameters()):
+        # Adam's first steps move every weight by ~lr * sign(g): the two implementations may differ where a gradient is numerically zero
+        d = (a - b).abs()
+        if not n.endswith("key.bias"):                                  # (a key bias shifts every score of a softmax row alike: its gradient is rounding noise)
+            assert float(d.mean()) < 4e-5 and float((d > 2e-3).float().mean()) < 1e-3, (n, float(d.mean()), float(d.max()))
+        # state_dict round trip mid-training changes nothing (two RUNS are compared: the embedding-table / LayerNorm parameter gradients are summed
+        # with float atomics, so their last bits differ from run to run and Adam turns a flipped sign of a ~0 gradient into 2 * lr)
+        d2 = (b - c).abs()
+        assert float(d2.mean()) < 1e-5 and float((d2 > 2e-3).float().mean()) < 1e-3, (n, float(d2.mean()), float(d2.max()))
+    key = "decoder.bert.encoder.layer.0.output.dense.weight"
+    assert torch.equal(mf.w16(key), mf.f32(key).to(torch.bfloat16))     # shadow written with the master
+    st = of.state_dict()["state"]
+    assert len(st) == len(list(mf.parameters())) and all(int(v["step"]) == 4 for v in st.values())
+
+
 def test_graphed_tf_step_leaves_no_stale_weight_copies(M):
     """After K replays of GraphedTFStep every weight-derived buffer the engines cache per weight version (BN folds, tap re-layouts, LoRA merges,
     transposed copies, packed decode weights, decode sessions) must describe the CURRENT weights: forward and generate of the stepped model ==
@@ -518,6 +623,12 @@ def test_greedy_and_beam_multi(M):
     # sequence must BE one of the reference's final beams, with that beam's score.
     gb = gu.load("generate_multi_beams.npz")
     assert float(gb["beam4_margin"].max()) < MARGIN
+    # A row that is none of them must still be a hypothesis the fp32 search ranks inside that cluster: its sequence is re-scored by the fp32 oracle
+    # (teacher-forced log-probabilities / length, the beam score's definition) and may not fall below the reference's 4th-best final beam by more
+    # than the cluster's own width; the score the device reports for it must be that fp32 score to the bf16 tolerance. EVERY row is checked.
+    from oracle import bert as obert, cvt as ocvt, token_ops as otok
+    with torch.no_grad():
+        h_or, mask_or = ocvt.encoder_forward(x, sd, cfg.encoder)
     hits = 0
     for b in range(3):
         for j in range(4):
@@ -527,6 +638,18 @@ def test_greedy_and_beam_multi(M):
                 assert abs(float(beam["sequences_scores"][b]) - float(gb["beam4_all_scores"][b, j])) < 0.05
                 hits += 1
                 break
+        else:
+            seq = bs[b:b + 1]
+            is_eos = (seq[0, 1:] == gu.EOS).nonzero()
+            n_gen = int(is_eos[0]) + 1 if len(is_eos) else seq.shape[1] - 1
+            inp = seq[:, :n_gen]
+            with torch.no_grad():
+                tt = torch.from_numpy(otok.token_ids_to_token_type_ids(inp.numpy(), [gu.SEP]))
+                lp = torch.log_softmax(obert.decoder_forward(inp, sd, cfg.decoder, h_or[b:b + 1], mask_or[b:b + 1], None, tt, None).float(), -1)
+            fp32_score = float(lp[0, torch.arange(n_gen), seq[0, 1:n_gen + 1]].sum()) / n_gen
+            ref_sc = gb["beam4_all_scores"][b]
+            assert fp32_score >= float(ref_sc.min()) - float(ref_sc.max() - ref_sc.min()) - 1e-3, (b, fp32_score, ref_sc)
+            assert abs(float(beam["sequences_scores"][b]) - fp32_score) < 0.05, (b, float(beam["sequences_scores"][b]), fp32_score)
     assert hits >= 2, (hits, bs, gb["beam4_all"])
     # EOS handling (EOS -> PAD fill, stop/trim when every row has finished): bias the EOS logit well past the fixture's threshold
     with torch.no_grad():
@@ -684,7 +807,20 @@ def test_reference_caller_loss_calls_are_served_by_the_boundary_tensors(M):
     assert bool(torch.isfinite(a[1]).all()) and bool(torch.isfinite(b[1]).all())
     torch.testing.assert_close(a[1], b[1], atol=1e-4, rtol=1e-4)
     assert abs(a[0] - b[0]) < 1e-4 * max(1.0, abs(a[0]))
-    assert gu.rel_rms(b[2].numpy(), a[2].numpy()) < 1e-3
+    assert gu.rel_rms(b[2].numpy(), a[2].numpy()) < 5e-3           # (the served pair emits d(scores) in bf16, like the fused SCST step)
+    # the log_softmax of the recognised stack is PENDING until nll_loss(reduction='none') consumes it; any other use computes it and is torch's result
+    torch.manual_seed(0)
+    smp = m2.generate.__wrapped__(m2, input_ids=prompt.cuda(), special_token_ids=[gu.BOS, gu.SEP], encoder_outputs=eo, bos_token_id=gu.BOS, eos_token_id=gu.EOS,
+                                  pad_token_id=gu.PAD, mask_token_id=gu.PAD, return_dict_in_generate=True, do_sample=True, num_beams=1, use_cache=True,
+                                  output_scores=True, top_p=1.0, top_k=50, temperature=1.0, max_new_tokens=10)
+    stack = torch.stack(smp["scores"], dim=-1)
+    lsm = torch.nn.functional.log_softmax(stack, dim=1)
+    want = torch.log_softmax(stack.as_subclass(torch.Tensor), dim=1)
+    assert lsm.shape == want.shape and lsm.dtype == want.dtype and lsm.device == want.device and lsm.requires_grad
+    assert type(lsm.exp()) is torch.Tensor and torch.equal(lsm.exp(), want.exp()) and torch.equal(lsm[:, 3], want[:, 3]) and torch.equal(lsm + 0.0, want)
+    tgt = smp["sequences"][:, -len(smp["scores"]):]
+    assert torch.allclose(torch.nn.functional.nll_loss(lsm, tgt, ignore_index=gu.PAD, reduction="mean"),
+                          torch.nn.functional.nll_loss(want, tgt, ignore_index=gu.PAD, reduction="mean"))      # not the recognised reduction: torch's own
     # a partial / reordered stack is not the recognised call: torch's own stack
     part = torch.stack(m2.generate.__wrapped__(m2, input_ids=prompt.cuda(), special_token_ids=[gu.BOS, gu.SEP], encoder_outputs=eo, bos_token_id=gu.BOS,
                                                eos_token_id=gu.EOS, pad_token_id=gu.PAD, mask_token_id=gu.PAD, return_dict_in_generate=True, do_sample=True,
@@ -1043,14 +1179,31 @@ def test_single_image_model_generate_matches_the_reference(M):
             tt = m.token_ids_to_token_type_ids(ids, [gu.SEP])
             fed, tt_new = (ids, tt) if past is None else (ids[:, -1:], tt[:, -1:])
             out = m(encoder_outputs=eo, decoder_input_ids=fed, decoder_token_type_ids=tt_new, past_key_values=past, use_cache=True)
-            assert out.logits.shape[:2] == (3, 1)
+            assert out.logits.shape[:2] == (3, fed.shape[1])    # the library's contract: logits for every FED position
             past = out.past_key_values
             ids = torch.cat([ids, out.logits[:, -1].argmax(-1, keepdim=True)], 1)
     assert past.len == L - 1 and torch.equal(ids.cpu(), ref)
+    # use_cache=True without a cache on a multi-token input (a teacher-forced evaluation that merely leaves the flag on, or a prompted prefill): logits
+    # for ALL positions, equal to the plain call's, plus a cache holding them; one more token on top of it continues the sequence
+    with torch.no_grad():
+        tt = m.token_ids_to_token_type_ids(ids, [gu.SEP])
+        plain = m(encoder_outputs=eo, decoder_input_ids=ids[:, :-1], decoder_token_type_ids=tt[:, :-1]).logits
+        pre = m(encoder_outputs=eo, decoder_input_ids=ids[:, :-1], decoder_token_type_ids=tt[:, :-1], use_cache=True)
+        assert pre.logits.shape == plain.shape and torch.equal(pre.logits, plain) and pre.past_key_values.len == ids.shape[1] - 1
+        nxt = m(encoder_outputs=eo, decoder_input_ids=ids[:, -1:], decoder_token_type_ids=tt[:, -1:], past_key_values=pre.past_key_values, use_cache=True)
+        full = m(encoder_outputs=eo, decoder_input_ids=ids, decoder_token_type_ids=tt).logits[:, -1]
+        check_act(nxt.logits[:, 0].float().cpu().numpy(), full.float().cpu().numpy(), "cached step on a prefilled cache vs the teacher-forced pass")
+        with pytest.raises(NotImplementedError):                 # several new tokens on top of a non-empty cache
+            m(encoder_outputs=eo, decoder_input_ids=ids[:, -2:], decoder_token_type_ids=tt[:, -2:], past_key_values=nxt.past_key_values, use_cache=True)
+    for p_ in m.decoder.parameters():
+        p_.requires_grad_(True)
+    tt = m.token_ids_to_token_type_ids(ids, [gu.SEP])
+    tr = m(encoder_outputs=eo, decoder_input_ids=ids, decoder_token_type_ids=tt, use_cache=True)      # under autograd: a teacher-forced pass, no cache
+    assert tr.past_key_values is None and tr.logits.requires_grad and tr.logits.shape[:2] == tuple(ids.shape)
     with pytest.raises(RuntimeError):                            # the cached kernels have no backward
-        for p_ in m.decoder.parameters():
-            p_.requires_grad_(True)
-        m(encoder_outputs=eo, decoder_input_ids=ids, decoder_token_type_ids=m.token_ids_to_token_type_ids(ids, [gu.SEP]), use_cache=True)
+        m(encoder_outputs=eo, decoder_input_ids=ids[:, -1:], decoder_token_type_ids=tt[:, -1:], past_key_values=past, use_cache=True)
+    for p_ in m.decoder.parameters():
+        p_.requires_grad_(False)
     # beam-4: device-side search and the host loop, both equal to the reference's best hypothesis and score on every row
     rb, rs = torch.from_numpy(g["beam4_all"][:, 0]), g["beam4_all_scores"]
     gap = rs[:, 0] - rs[:, 1]
@@ -1093,26 +1246,27 @@ def test_graph_capture_survives_a_garbage_collection_inside_it(M):
 @pytest.mark.parametrize("case", ["plain", "lp2", "lp05", "eos"])
 def test_device_beam_search_equals_the_reference_on_every_row(M, case):
     """generate_beam_safe.npz: beam-4 decodes of the multi-image model whose every decision survives bf16-sized logit noise (checked by noise
-    injection in the generator): plain, length_penalty 2.0 / 0.5, and an EOS that ends some hypotheses early. The device-side search and the
-    host loop must both return the reference's best hypothesis for EVERY study, with its score."""
+    injection in the generator) and whose three studies each have their OWN best hypothesis: plain, an EOS that ends the best hypothesis of some
+    rows early, and length_penalty 2.0 / 0.5 ranking hypotheses of different length. The device-side search and the host loop must both return the
+    reference's best hypothesis for EVERY study -- the three sequences are pairwise different, so a cross-study mix-up in the beam bookkeeping or the
+    cache reorder cannot reproduce them -- with its score to a tolerance below the gap to the row's runner-up."""
     c = gu.beam_safe_case(case)
-    if c is None:
-        pytest.skip(f"the fixture generator found no noise-robust '{case}' case in its seed range")
-    cfg, sd, x, eos_bias, lp, ref_all, ref_scores, steps = c
+    assert c is not None, case
+    cfg, sd, x, eos_bias, lp, ref_all, ref_scores, steps, tol = c
     m = M.MultiCXREncoderDecoderModel(cfg, seed=None)
     m.load_state_dict(sd)
     if eos_bias:
         with torch.no_grad():
             m.param("decoder.cls.predictions.bias")[gu.EOS] += eos_bias
     rb = torch.from_numpy(ref_all[:, 0])
-    gap = ref_scores[:, 0] - ref_scores[:, 1]
+    assert len({tuple(r.tolist()) for r in rb}) == rb.shape[0]
     for device_side in (True, False, True):                      # (the second device-side run replays the captured step graphs)
         m.device_beam_search = device_side
         o = m.generate(pixel_values=x.cuda(), special_token_ids=[gu.SEP], max_length=steps + 1, bos_token_id=gu.BOS, eos_token_id=gu.EOS,
                        pad_token_id=gu.PAD, num_beams=4, length_penalty=lp, return_dict_in_generate=True, use_cache=True, output_scores=True)
         bs = o["sequences"].cpu()
         assert torch.equal(bs, rb[:, :bs.shape[1]]) and bool((rb[:, bs.shape[1]:] == gu.PAD).all()), (case, device_side, bs, rb)
-        assert bool((np.abs(o["sequences_scores"].cpu().numpy() - ref_scores[:, 0]) < 0.4 * gap).all()), (case, o["sequences_scores"], ref_scores[:, 0])
+        assert bool((np.abs(o["sequences_scores"].cpu().numpy() - ref_scores[:, 0]) < tol).all()), (case, o["sequences_scores"], ref_scores[:, 0], tol)
     if case == "eos":
         assert bool((rb == gu.EOS).any(1).any()) and not bool((rb == gu.EOS).any(1).all())
 

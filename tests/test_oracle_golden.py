@@ -170,7 +170,8 @@ def test_greedy_and_beam_multi():
 
 def test_single_image_generate_and_noise_robust_beam_fixtures():
     """generate_single.npz (reference SingleCXREncoderDecoderModel: greedy with cache == no-cache, beam-4) and generate_beam_safe.npz (multi-image
-    beam-4 with length penalties; every case survived bf16-sized logit noise in the generator): the oracle's greedy / beam search reproduce them."""
+    beam-4: plain, an early EOS in some rows, length penalties that decide rankings between hypotheses of different length; every case survived
+    bf16-sized logit noise in the generator and every study has its own hypothesis): the oracle's greedy / beam search reproduce them."""
     g, cfg, sd, x = gu.generate_single_case()
     with torch.no_grad():
         h, _ = ocvt.encoder_forward(x, sd, cfg.encoder)
@@ -186,13 +187,20 @@ def test_single_image_generate_and_noise_robust_beam_fixtures():
         beam, score = ogen.beam_search(fn, "single", 3, 4, [gu.SEP], gu.BOS, gu.EOS, gu.PAD, L)
         assert np.array_equal(beam.numpy(), g["beam4_all"][:, 0, : beam.shape[1]])
         np.testing.assert_allclose(score.numpy(), g["beam4_all_scores"][:, 0], atol=2e-4)
-    found = 0
     for case in ("plain", "lp2", "lp05", "eos"):
         c = gu.beam_safe_case(case)
-        if c is None:
-            continue
-        found += 1
-        cfg, sd, x, eos_bias, lp, ref_all, ref_scores, steps = c
+        assert c is not None, case
+        cfg, sd, x, eos_bias, lp, ref_all, ref_scores, steps, tol = c
+        # the fixture's own guarantees: every study has its OWN best hypothesis (a cross-study mix-up cannot reproduce the sequences), and the score
+        # tolerance separates the best hypothesis of a row from its runner-up
+        assert len({tuple(r.tolist()) for r in ref_all[:, 0]}) == 3, case
+        assert 0 < tol < (ref_scores[:, 0] - ref_scores[:, 1]).min(), case
+        e = ref_all == gu.EOS
+        lens = np.where(e.any(-1), e.argmax(-1) + 1, ref_all.shape[-1])
+        if case == "eos":
+            assert (lens[:, 0] < ref_all.shape[-1]).any() and not (lens[:, 0] < ref_all.shape[-1]).all()
+        if case in ("lp2", "lp05"):
+            assert any(len(set(lens[b].tolist())) > 1 for b in range(3)), case            # hypotheses of different length were ranked
         sd = dict(sd)
         if eos_bias:
             sd["decoder.cls.predictions.bias"] = sd["decoder.cls.predictions.bias"].clone()
@@ -204,10 +212,30 @@ def test_single_image_generate_and_noise_robust_beam_fixtures():
                 r = ids.shape[0] // h.shape[0]
                 return obert.decoder_forward(ids, sd, cfg.decoder, h.repeat_interleave(r, 0), emask.repeat_interleave(r, 0), None, tt, pos)
 
-            beam, score = ogen.beam_search(fn2, "multi", 3, 4, [gu.SEP], gu.BOS, gu.EOS, gu.PAD, steps + 1, length_penalty=lp)
-        assert np.array_equal(beam.numpy(), ref_all[:, 0, : beam.shape[1]]), case
-        np.testing.assert_allclose(score.numpy(), ref_scores[:, 0], atol=2e-4, err_msg=case)
-    assert found >= 3
+            beam, score = ogen.beam_search(fn2, "multi", 3, 4, [gu.SEP], gu.BOS, gu.EOS, gu.PAD, steps + 1, length_penalty=lp, return_all=True)
+        assert np.array_equal(beam.numpy(), ref_all[:, :, : beam.shape[-1]]) and beam.shape[-1] == ref_all.shape[-1], case
+        np.testing.assert_allclose(score.numpy(), ref_scores, atol=2e-4, err_msg=case)
+
+
+def test_beam_search_as_index_work_on_the_references_recorded_logits():
+    """beam_index.npz: the reference's beam-4 generate with its fp32 logits recorded at every step (early EOS, hypotheses of different length,
+    length_penalty 0.5 / 1 / 2, searches that stop before max_length). Fed those logits, the oracle's search must walk the same beams at every step
+    (the token each running beam is fed) and end with the same four hypotheses per study, bit for bit, scores to fp32 rounding."""
+    steps, cases = gu.beam_index_cases()
+    seen_lengths, stopped_early = set(), 0
+    for name, lp, logits, fed, ref_all, ref_scores in cases:
+        fn = gu.replay_logits_fn(logits, fed)
+        trace = []
+        seqs, scores = ogen.beam_search(fn, "multi", 3, 4, [gu.SEP], gu.BOS, gu.EOS, gu.PAD, steps + 1, length_penalty=lp, return_all=True, trace=trace)
+        assert fn.state["t"] == logits.shape[0], (name, fn.state["t"])                    # the search stopped on the step the reference stopped on
+        assert torch.equal(seqs, ref_all[:, :, : seqs.shape[-1]]) and seqs.shape == ref_all.shape, name
+        np.testing.assert_allclose(scores.numpy(), ref_scores.numpy(), rtol=0, atol=2e-6, err_msg=name)
+        assert min(t["min_gap"] for t in trace) > 1e-5, name                             # no selection of the search is a near-tie: exactness is well defined
+        e = ref_all == gu.EOS
+        lens = torch.where(e.any(-1), e.int().argmax(-1) + 1, torch.full(e.shape[:-1], ref_all.shape[-1]))
+        seen_lengths |= set(lens.reshape(-1).tolist())
+        stopped_early += int(logits.shape[0] < steps)
+    assert len(seen_lengths) >= 6 and stopped_early >= 3
 
 
 def test_prompted_greedy_scores_and_reinforce():
