@@ -20,8 +20,20 @@
 // short K loops of this model (K = 384..768 -> 6..24 steps) is covered by more than one step of MFMA work.
 // BN = 128: 128x128 tile (wave tile 64x64). BN = 64: 128x64 tile (wave tile 64x32) for outputs whose 128x128 tiling would leave CUs idle
 // or waste half a tile (N = 64 / 192, or fewer than ~1.5 tiles per CU).
-template <int BK, bool GLDS, int NST, int BN>
-__device__ __forceinline__ void gemm_nt_body(const GemmArgs& g, const int bid, const int nwg) {
+__device__ uint4 g_tn_zero_row[16];       // 256 zero bytes: LDS-DMA source for rows that do not exist (token rows beyond R of the weight-gradient GEMM,
+                                          // taps outside the image of the implicit-GEMM convolution); a zero-initialised device global
+
+// CONV (round 4): the A operand is NOT a matrix in memory but the im2col view of a token-major activation x [Bn, Hin*Win, Cin] under a ksz x ksz
+// convolution (CvT stage-2 / stage-3 patch embeddings, TF5 modeling_cvt.py:77-90: 3 x 3, stride 2, padding 1): row m = output pixel (b, oy, ox),
+// column k = (ky, kx, c) -- the K order the embedding weights are re-laid out in (encoder.prepare). With Cin a multiple of 64 a 64-wide k-step is
+// ONE tap and 64 consecutive channels, i.e. one contiguous 128-byte piece of x per output row: the LDS-DMA source address is per lane anyway, so
+// the gather costs two compares and a select per staged piece and the [M, 9 Cin] im2col matrix (170 / 127 MB per step for stages 2 / 3) is never
+// written or read. Taps outside the image read the zero row.
+struct ConvA { int Hin, Win, Cin, ksz, Ho, Wo, stride, pad; long x_bs, x_rs; };
+
+template <int BK, bool GLDS, int NST, int BN, bool CONV = false>
+__device__ __forceinline__ void gemm_nt_body(const GemmArgs& g, const int bid, const int nwg, const ConvA* cvp = nullptr) {
+    static_assert(!CONV || (BK == 64 && GLDS), "the implicit-GEMM A gather is built on the 64-wide LDS-DMA staging");
     constexpr int BM = 128;
     constexpr int NTL = BN / 32;                // 16-column MFMA tiles per wave along N
     constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
@@ -47,12 +59,23 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs& g, const int bid, c
     // per-thread staging sources (row clamp keeps every load in bounds; out-of-range rows are never stored)
     const bf16_t* srcA[PASSES];
     const bf16_t* srcW[WPASSES];
+    const bf16_t* srcZ[CONV ? PASSES : 1];
+    int civ[CONV ? PASSES : 1], cix[CONV ? PASSES : 1];
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int s = p * 256 + tid;
         const int row = s / CPR, cp = s % CPR;
         const int c = cp ^ Swz<BK>::f(row);
         int ra = tm * BM + row; ra = ra < g.M ? ra : g.M - 1;
+        if constexpr (CONV) {
+            const ConvA& cv = *cvp;
+            const int hw = cv.Ho * cv.Wo;
+            const int b_ = ra / hw, r_ = ra - b_ * hw, oy = r_ / cv.Wo, ox = r_ - oy * cv.Wo;
+            civ[p] = oy * cv.stride - cv.pad; cix[p] = ox * cv.stride - cv.pad;
+            // (window origin: may lie one row / column outside the image -- only dereferenced for taps inside it)
+            srcA[p] = g.A + (long)b_ * cv.x_bs + ((long)civ[p] * cv.Win + cix[p]) * cv.x_rs + c * 8;
+            srcZ[p] = reinterpret_cast<const bf16_t*>(g_tn_zero_row) + c * 8;
+        } else
         srcA[p] = g.A + (long)ra * g.lda + c * 8;
         if (p < WPASSES) {
             int rw = tn * BN + row; rw = rw < g.N ? rw : g.N - 1;
@@ -64,11 +87,23 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs& g, const int bid, c
         unsigned char* la = lds + (buf * 2 + 0) * TILE_BYTES;
         unsigned char* lw = lds + (buf * 2 + 1) * TILE_BYTES;
         const long k0 = (long)kt * BK;
+        int cky = 0, ckx = 0; long coff = 0;                       // CONV: tap and channel block of this k-step (uniform)
+        if constexpr (CONV) {
+            const ConvA& cv = *cvp;
+            const int tap = (int)k0 / cv.Cin, c0 = (int)k0 - tap * cv.Cin;
+            cky = tap / cv.ksz; ckx = tap - cky * cv.ksz;
+            coff = ((long)cky * cv.Win + ckx) * cv.x_rs + c0;
+        }
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             if constexpr (GLDS) {
                 const int wbase = (p * 256 + wave * 64) * 16;      // wave-uniform; hardware adds lane*16
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[p] + k0),
+                const bf16_t* sa;
+                if constexpr (CONV) {
+                    const bool in = (unsigned)(civ[p] + cky) < (unsigned)cvp->Hin && (unsigned)(cix[p] + ckx) < (unsigned)cvp->Win;
+                    sa = in ? srcA[p] + coff : srcZ[p];
+                } else sa = srcA[p] + k0;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
                                                  (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
                 if (p < WPASSES)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[p] + k0),
@@ -385,6 +420,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
     gemm_nt_body<BK, GLDS, NST, BN>(g, blockIdx.x, gridDim.x);
 }
 
+struct GemmConvArgs { GemmArgs g; ConvA cv; };
+template <int BN>
+__global__ __launch_bounds__(256) void gemm_nt_conv_kernel(const GemmConvArgs a) {
+    gemm_nt_body<64, true, 2, BN, true>(a.g, blockIdx.x, gridDim.x, &a.cv);
+}
+
 // Up to three independent problems with the same N, K and epilogue class in ONE launch (workgroups [start[p], start[p+1]) serve problem p):
 // the query / key / value projections of a CvT layer have 145..577 rows per image -- the key and value GEMMs alone fill under half of the
 // 256 CUs (111 tiles at batch 32) and cost a launch latency each; grouped with the query GEMM they ride in its tail.
@@ -479,6 +520,28 @@ extern "C" int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw
     return CXR_OK;
 }
 
+// C[Bn*Ho*Wo, N] = conv_ksz,stride,pad(x) as an implicit GEMM + bias (see ConvA). x [Bn, Hin*Win, Cin] token-major bf16, W [N, ksz*ksz*Cin] in
+// (ky, kx, c) order. Replaces im2col + GEMM for nn.Conv2d(Cin, N, 3, 2, 1) of the CvT stage embeddings (TF5 modeling_cvt.py:77-90).
+extern "C" int cxr_gemm_nt_conv_bf16(const void* x, long x_bs, long x_rs, int Bn, int Hin, int Win, int Cin, int ksz, int stride, int pad,
+                                     const void* W, long ldw, void* C, long ldc, const float* bias, int N, hipStream_t stream) {
+    if (!x || !W || !C || Bn <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || (Cin % 64) || ksz < 1 || stride < 1 || pad < 0 || (x_bs % 8) || (x_rs % 8))
+        return CXR_ERR_ARG;
+    const int Ho = (Hin + 2 * pad - ksz) / stride + 1, Wo = (Win + 2 * pad - ksz) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return CXR_ERR_ARG;
+    const long M = (long)Bn * Ho * Wo;
+    if (M > 0x7fffffffL) return CXR_ERR_ARG;
+    const cxr_gemm_nt_desc d{x, 8, W, ldw, C, ldc, bias, nullptr, 0, nullptr, 0, (int)M, N, ksz * ksz * Cin, 1.0f, 0, 0, 0, 0.f, nullptr, 0u, 1, 0, nullptr, 1, 0};
+    GemmConvArgs a;
+    const int rc = gemm_nt_fill(a.g, d);
+    if (rc) return rc;
+    a.cv = ConvA{Hin, Win, Cin, ksz, Ho, Wo, stride, pad, x_bs, x_rs};
+    const bool bn64 = gemm_nt_narrow(N, (long)cdiv((int)M, 128) * cdiv(N, 128));
+    if (bn64) CXR_LAUNCH((gemm_nt_conv_kernel<64>), dim3(cdiv((int)M, 128) * cdiv(N, 64)), dim3(256), 0, stream, a);
+    else      CXR_LAUNCH((gemm_nt_conv_kernel<128>), dim3(cdiv((int)M, 128) * cdiv(N, 128)), dim3(256), 0, stream, a);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
 // n <= 3 problems with equal N and K in one launch (see gemm_nt_group_kernel); epilogues may differ per problem
 extern "C" int cxr_gemm_nt_group_bf16(const cxr_gemm_nt_desc* d, int n, hipStream_t stream) {
     if (!d || n < 1 || n > 3) return CXR_ERR_ARG;
@@ -532,8 +595,6 @@ struct GemmTnArgs {
     int mode;           // 0 atomics, 1 one split: this workgroup owns its tile -> plain read-modify-write of C, 2 partials to ws
     int debug;          // tuning aid (CXR_TN_DEBUG): 1 skip epilogue atomics, 2 skip MFMA, 4 skip LDS-DMA refills, 8 skip fragment reads
 };
-
-__device__ uint4 g_tn_zero_row[16];       // 256 zero bytes: LDS-DMA source for token rows beyond R (zero-initialised device global)
 
 __device__ __forceinline__ int tn_gsw(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 

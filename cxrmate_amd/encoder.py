@@ -36,6 +36,7 @@ class CvtEncoderEngine:
         self.fp8 = None                             # {"w": {key: (e4m3 weight, scale)}, "a": {key: scale}} after enable_fp8(); None = bf16
         self._bwd_stats_from_y = os.environ.get("CXR_DW3_STATS_FROM_Y", "1") != "0"      # A/B switch: 0 = backward BatchNorm statistics recompute the convolution
         self._q8_fused = os.environ.get("CXR_FP8_FUSED", "1") != "0"      # A/B switch: 0 = separate bf16 -> e4m3 passes in front of the e4m3 GEMMs
+        self._implicit_embed = os.environ.get("CXR_IMPLICIT_EMBED", "1") != "0"      # A/B switch: 0 = im2col + GEMM for the stage-2 / stage-3 embeddings
         self._amax = None                           # calibration pass: {key: running max |activation|}
 
     # ------------------------------------------------------------------------------------------ fp8 (e4m3) linear layers of the frozen encoder
@@ -237,11 +238,18 @@ class CvtEncoderEngine:
             sp = self._stage(s)
             C = cfg.embed_dim[s]
             ep = sp + "embedding.convolution_embeddings."
+            xin, Hin, Win = x, H, W
             if s == 0:
                 col, Ho, Wo = ops.im2col_pixels(px, cfg.patch_sizes[0], cfg.patch_stride[0], cfg.patch_padding[0], prep[("embed", 0)].shape[1])
+                e = ops.gemm_nt(col, prep[("embed", s)], bias=st.f32(ep + "projection.bias"))
+            elif self._implicit_embed and C % 4 == 0 and x.shape[2] % 64 == 0 and cfg.patch_sizes[s] == 3:
+                # stage 2 / 3 embedding as an implicit GEMM: the [tokens, 9 * Cin] im2col matrix is never written (the backward pass builds it on the
+                # weight-gradient stream for the one product that needs it, dW = de^T . col)
+                col = None
+                e, Ho, Wo = ops.gemm_nt_conv(x, H, W, cfg.patch_stride[s], cfg.patch_padding[s], prep[("embed", s)], bias=st.f32(ep + "projection.bias"))
             else:
                 col, Ho, Wo = ops.im2col_tokens(x, H, W, cfg.patch_stride[s], cfg.patch_padding[s])
-            e = ops.gemm_nt(col, prep[("embed", s)], bias=st.f32(ep + "projection.bias"))
+                e = ops.gemm_nt(col, prep[("embed", s)], bias=st.f32(ep + "projection.bias"))
             tok0 = 1 if cfg.cls_token[s] else 0
             L = tok0 + Ho * Wo
             xs = torch.empty((Bn, L, C), dtype=torch.bfloat16, device=px.device)
@@ -253,7 +261,7 @@ class CvtEncoderEngine:
                 _, estats = ops.layernorm(e, st.f32(ep + "normalization.weight"), st.f32(ep + "normalization.bias"), cfg.inner_layer_norm_eps,
                                           need_stats=save, out=xs.view(Bn * L, C))
             H, W = Ho, Wo
-            ssave = {"col": col, "e": e, "estats": estats, "H": H, "W": W, "layers": []} if save else None
+            ssave = {"col": col, "e": e, "estats": estats, "H": H, "W": W, "layers": [], "xin": xin if col is None else None, "Hin": Hin, "Win": Win} if save else None
             cur = xs
             for l in range(cfg.depth[s]):
                 cur, lsave = self._layer_fwd(cur, s, l, H, W, tok0, prep, save)
@@ -428,7 +436,11 @@ class CvtEncoderEngine:
                                    st.grad(ep + "normalization.weight"), st.grad(ep + "normalization.bias"))
             wp = prep[("embed", s)]
             dwp = torch.zeros(wp.shape, dtype=torch.float32, device=dx.device)
-            ops.linear_bwd_weight(de, ss["col"], dwp, st.grad(ep + "projection.bias"))
+            col = ss["col"]
+            if col is None:                                   # implicit-GEMM forward: the im2col matrix is built here, on the weight-gradient stream
+                with ops._on_wgrad_stream(ss["xin"]):
+                    col = ops.im2col_tokens(ss["xin"], ss["Hin"], ss["Win"], cfg.patch_stride[s], cfg.patch_padding[s])[0]
+            ops.linear_bwd_weight(de, col, dwp, st.grad(ep + "projection.bias"))
             gw = st.grad(ep + "projection.weight")
             with ops._on_wgrad_stream(dwp):                  # same stream as the weight-gradient GEMM that fills dwp (ordered after it)
                 if s == 0:

@@ -623,6 +623,19 @@ def im2col_tokens(x, H, W, stride, pad):
     return col, Ho, Wo
 
 
+def gemm_nt_conv(x, H, W, stride, pad, w, bias=None, ksz=3):
+    """Implicit-GEMM convolution of a token-major activation: x [Bn, H*W, Cin] bf16 (batch / row strides free), w [N, ksz*ksz*Cin] in (ky, kx, c) order
+    -> (out [Bn*Ho*Wo, N] bf16 = conv(x) + bias, Ho, Wo). The im2col matrix is never materialised (csrc/gemm.hip ConvA)."""
+    Bn, L, C = x.shape
+    assert L == H * W and x.stride(2) == 1 and x.dtype == BF16 and w.dtype == BF16 and w.shape[1] == ksz * ksz * C
+    Ho, Wo = (H + 2 * pad - ksz) // stride + 1, (W + 2 * pad - ksz) // stride + 1
+    N = w.shape[0]
+    out = torch.empty((Bn * Ho * Wo, N), device=x.device, dtype=BF16)
+    LIB.call("cxr_gemm_nt_conv_bf16", _p(x), x.stride(0), x.stride(1), Bn, H, W, C, int(ksz), int(stride), int(pad), _p(w), w.stride(0), _p(out), out.stride(0),
+             _p(bias), N, _s())
+    return out, Ho, Wo
+
+
 def col2im_tokens(dcol, Bn, C, H, W, stride, pad):
     Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
     dx = torch.empty((Bn, H * W, C), device=dcol.device, dtype=BF16)

@@ -42,6 +42,12 @@ typedef struct cxr_gemm_nt_desc {
     int drop_rows_per_b, drop_t0; const float* row_scale; int rs_rows, rs_after;
 } cxr_gemm_nt_desc;
 int cxr_gemm_nt_group_bf16(const cxr_gemm_nt_desc* d, int n, hipStream_t stream);
+/* nn.Conv2d(Cin, N, ksz, stride, pad) of the CvT stage embeddings (TF5 models/cvt/modeling_cvt.py:77-90, stages 2 / 3: 3 x 3, stride 2, padding 1) as an
+ * IMPLICIT GEMM on a token-major activation x [Bn, Hin*Win, Cin] (bf16, batch / row strides in elements): the im2col matrix is the GEMM's A operand but
+ * never exists in memory -- the kernel's LDS-DMA staging gathers each 64-channel piece of each tap from x itself (zeros outside the image).
+ * W [N, ksz*ksz*Cin] in (ky, kx, c) order, C [Bn*Ho*Wo, N] bf16 = conv + bias. Requires Cin % 64 == 0. */
+int cxr_gemm_nt_conv_bf16(const void* x, long x_bs, long x_rs, int Bn, int Hin, int Win, int Cin, int ksz, int stride, int pad,
+                          const void* W, long ldw, void* C, long ldc, const float* bias, int N, hipStream_t stream);
 /* weight gradient: C[I,J] += alpha * sum_r P[r,I] Q[r,J]  (dW += dY^T X), dbias[I] += colsum(P); token dimension split across
  * workgroups. Deterministic accumulation: one split = the workgroup owns its tile; several splits = partial tiles into `ws` (fp32, the caller's
  * scratch: 8 M floats cover every shape of this model; must not be shared by launches on different streams) + a reduce launch in split order.

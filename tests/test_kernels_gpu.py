@@ -845,6 +845,29 @@ def test_im2col_tokens_and_col2im(ops):
     close(dx, xi.grad.flatten(2).transpose(1, 2), what="col2im")
 
 
+@pytest.mark.parametrize("Bn,Cin,N,H,W", [(2, 64, 192, 24, 24), (3, 192, 384, 12, 12), (2, 64, 192, 7, 5), (5, 128, 136, 9, 20), (64, 64, 192, 96, 96)])
+def test_implicit_gemm_stage_embedding_is_the_im2col_gemm(ops, Bn, Cin, N, H, W):
+    """cxr_gemm_nt_conv_bf16 (round 4): the 3 x 3 / stride 2 / padding 1 stage embeddings of CvT as an implicit GEMM -- the A operand is gathered from
+    the token-major activation by the GEMM's own staging loop, zeros outside the image. Same tile kernel, same K order as im2col + gemm_nt: the
+    results are BIT-identical, also on odd grids (ragged last output row / column), a strided (class-token-offset) input view and a ragged last tile;
+    against torch's conv2d within the bf16 tolerance."""
+    base = dev(rnd(Bn, 1 + H * W, Cin, seed=3).to(BF))
+    x = base[:, 1:, :]                                           # batch / row strides of a view behind a class token
+    w = dev(rnd(N, Cin, 3, 3, seed=1, scale=0.1))
+    bias = dev(rnd(N, seed=2))
+    wp = w.permute(0, 2, 3, 1).reshape(N, 9 * Cin).contiguous().to(BF)
+    col, Ho, Wo = ops.im2col_tokens(x, H, W, 2, 1)
+    with _gemm_route("tiled"):
+        want = ops.gemm_nt(col, wp, bias=bias)
+    got, Ho2, Wo2 = ops.gemm_nt_conv(x, H, W, 2, 1, wp, bias=bias)
+    assert (Ho2, Wo2) == (Ho, Wo) and got.shape == want.shape
+    assert torch.equal(got, want)
+    if Bn * H * W <= 4096:
+        xi = x.float().transpose(1, 2).reshape(Bn, Cin, H, W)
+        ref = torch.nn.functional.conv2d(xi, w.to(BF).float(), bias, stride=2, padding=1)
+        close(got, ref.flatten(2).transpose(1, 2).reshape(-1, N), what="implicit conv 3x3 s2")
+
+
 @pytest.mark.parametrize("C,H,tok0", [(64, 24, 0), (192, 12, 0), (384, 6, 1)])
 def test_dwconv_bn_fwd_bwd(ops, C, H, tok0):
     Bn, W = 3, H
