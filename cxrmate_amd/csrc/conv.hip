@@ -133,6 +133,152 @@ __global__ __launch_bounds__(256) void col2im_tok_kernel(const bf16_t* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 4: the stage-1 patch embedding as ONE kernel -- Conv2d(3, 64, kernel 7, stride 4, padding 2) on the fp32 NCHW pixels as an implicit GEMM on the
+// matrix cores, + bias, + LayerNorm(64) over the channels in the epilogue (TF5 modeling_cvt.py:77-90: projection -> flatten -> LayerNorm).
+// Replaces im2col (147 us: 226 MB written, read again by the GEMM) + GEMM + LayerNorm launch (three passes over the 75 MB token map).
+//   workgroup  = (image, band of PE_RB output rows): the 4 PE_RB + 3 input rows of all three channels are staged ONCE in LDS as bf16, two zero
+//                columns on each side, so that the 8 horizontal taps kx = 0..7 of output pixel ox start at element 4 ox of a row (8-byte aligned).
+//   K order    = (c, ky) group-major with kx padded from 7 to 8 (the 8th tap has a zero weight): one 8-element MFMA operand fragment of a pixel is
+//                ONE contiguous 16-byte piece of one staged row -- no gather, no per-element address arithmetic. K = 21 groups x 8 = 168 -> 192.
+//   MFMA       = D^T[channel, pixel] = W'[channel, k] . X^T[k, pixel] (v_mfma_f32_16x16x32_bf16): the packed weights (64 x 192, 24 KB) live in
+//                registers as A fragments; a lane ends up with 4 x 4 CONSECUTIVE channels of ONE pixel, so the LayerNorm statistics of a pixel are 16
+//                in-lane adds and two cross-lane steps.
+// Written: y = LayerNorm(e) (bf16 token-major), and for a training forward e = conv + bias (bf16, the LayerNorm backward's input) + (mean, rstd).
+constexpr int PE_RB = 4;                     // output rows per workgroup
+constexpr int PE_WS = 392;                   // LDS row stride (bf16 elements): 2 + 384 + 2 zero columns, padded to a multiple of 8
+
+__global__ __launch_bounds__(256) void patch_embed_s1_kernel(const float* __restrict__ px, const bf16_t* __restrict__ Wpk, const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                             bf16_t* __restrict__ e_out, bf16_t* __restrict__ y_out, float* __restrict__ stats,
+                                                             int H, int W, int Ho, int Wo) {
+    constexpr int NR = 4 * PE_RB + 3;
+    __shared__ __attribute__((aligned(16))) bf16_t img[3 * NR * PE_WS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbands = (Ho + PE_RB - 1) / PE_RB;
+    const int b = blockIdx.x / nbands, oy0 = (blockIdx.x % nbands) * PE_RB;
+    const int iy0 = 4 * oy0 - 2;
+    // ---- the packed weights of this lane: A fragments, channel tile ct, k-step s: lane (m = lane & 15, kg = lane >> 4) holds W'[16 ct + m][32 s + 8 kg ..]
+    const int fm = lane & 15, fg = lane >> 4;
+    bf16x8_t wf[4][6];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int s2 = 0; s2 < 6; ++s2) wf[ct][s2] = *reinterpret_cast<const bf16x8_t*>(Wpk + (long)(16 * ct + fm) * 192 + 32 * s2 + 8 * fg);
+    // ---- stage the band: fp32 rows -> bf16 LDS rows (zero outside the image), 16 bytes of pixels per thread and step
+    const int w4 = W / 4;
+    for (int e = tid; e < 3 * NR * w4; e += 256) {
+        const int r = e / w4, x4 = (e - r * w4) * 4;
+        const int c = r / NR, rr = r - c * NR, iy = iy0 + rr;
+        const bool in = iy >= 0 && iy < H;
+        const float4 v = *reinterpret_cast<const float4*>(px + (((long)b * 3 + c) * H + (in ? iy : 0)) * W + x4);      // (unconditional: clamped row)
+        uint32_t* d = reinterpret_cast<uint32_t*>(img + r * PE_WS + 2 + x4);                                           // (4-byte aligned)
+        d[0] = in ? pack2bf(v.x, v.y) : 0u;
+        d[1] = in ? pack2bf(v.z, v.w) : 0u;
+    }
+    for (int r = tid; r < 3 * NR; r += 256) {                      // the zero columns left and right of every row
+        *reinterpret_cast<uint32_t*>(img + r * PE_WS) = 0u;
+#pragma unroll
+        for (int j = 0; j < (PE_WS - 386) / 2; ++j) *reinterpret_cast<uint32_t*>(img + r * PE_WS + 2 + 384 + 2 * j) = 0u;
+    }
+    if (W < 384) {                                                 // narrower images: zeros behind the last pixel up to the widest tap read
+        for (int e = tid; e < 3 * NR * 8; e += 256) img[(e >> 3) * PE_WS + 2 + W + (e & 7)] = 0;
+    }
+    // per-lane epilogue constants: channels 16 ct + 4 fg + r of the lane's pixel
+    float bs[16], gm[16], bt[16];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bias + 16 * ct + 4 * fg), g4 = *reinterpret_cast<const float4*>(gamma + 16 * ct + 4 * fg),
+                     t4 = *reinterpret_cast<const float4*>(beta + 16 * ct + 4 * fg);
+        bs[4 * ct] = b4.x; bs[4 * ct + 1] = b4.y; bs[4 * ct + 2] = b4.z; bs[4 * ct + 3] = b4.w;
+        gm[4 * ct] = g4.x; gm[4 * ct + 1] = g4.y; gm[4 * ct + 2] = g4.z; gm[4 * ct + 3] = g4.w;
+        bt[4 * ct] = t4.x; bt[4 * ct + 1] = t4.y; bt[4 * ct + 2] = t4.z; bt[4 * ct + 3] = t4.w;
+    }
+    __syncthreads();
+    const int tiles = (Wo + 15) >> 4;
+    for (int it = wave; it < PE_RB * tiles; it += 4) {             // (wave-uniform) one (output row, 16-pixel tile) at a time
+        const int oyl = it / tiles, pt = it - oyl * tiles;
+        const int oy = oy0 + oyl;
+        if (oy >= Ho) continue;
+        const int ox = pt * 16 + fm;                               // this lane's pixel (B operand column n = lane & 15)
+        const int oxc = ox < Wo ? ox : Wo - 1;
+        f32x4_t acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 6; ++s2) {
+            int grp = 4 * s2 + fg; grp = grp < 21 ? grp : 20;      // (groups 21..23 are zero padding of K: any staged row will do)
+            const int c = grp / 7, ky = grp - 7 * c;
+            const bf16_t* src = img + (c * NR + 4 * oyl + ky) * PE_WS + 4 * oxc;
+            const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 4);
+            const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][s2], xf, acc[ct], 0, 0, 0);
+        }
+        // D^T tile: lane (n = pixel fm, row group fg) holds channels 16 ct + 4 fg + r -> e = conv + bias, rounded to bf16 (what the LayerNorm -- and its
+        // backward -- see, as when the GEMM wrote e and a LayerNorm kernel read it back)
+        float ev[16];
+        float sum = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = bf2f(f2bf(acc[ct][r] + bs[4 * ct + r]));
+                ev[4 * ct + r] = v;
+                sum += v;
+            }
+        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / 64.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const float d = ev[i] - mean; sq = fmaf(d, d, sq); }
+        sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
+        const float rstd = rsqrtf(sq * (1.0f / 64.0f) + eps);
+        if (ox < Wo) {
+            const long pix = ((long)b * Ho + oy) * Wo + ox;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int ch = 16 * ct + 4 * fg;
+                if (e_out) *reinterpret_cast<uint2*>(e_out + pix * 64 + ch) = make_uint2(pack2bf(ev[4 * ct], ev[4 * ct + 1]), pack2bf(ev[4 * ct + 2], ev[4 * ct + 3]));
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = (ev[4 * ct + r] - mean) * rstd * gm[4 * ct + r] + bt[4 * ct + r];
+                *reinterpret_cast<uint2*>(y_out + pix * 64 + ch) = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+            }
+            if (stats && fg == 0) *reinterpret_cast<float2*>(stats + pix * 2) = make_float2(mean, rstd);
+        }
+    }
+}
+
+// weights [64, 3, 7, 7] fp32 (nn.Conv2d layout) -> the packed bf16 A operand [64][24 groups of (c, ky)][8 taps kx] of patch_embed_s1_kernel (zero where kx = 7 or
+// group >= 21)
+__global__ __launch_bounds__(256) void patch_embed_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 64 * 192) return;
+    const int n = i / 192, k = i % 192, grp = k >> 3, kx = k & 7;
+    out[i] = (grp < 21 && kx < 7) ? f2bf(w[(n * 21 + grp) * 7 + kx]) : (bf16_t)0;
+}
+
+extern "C" int cxr_patch_embed_pack_f32(const float* w, void* out, hipStream_t stream) {
+    if (!w || !out) return CXR_ERR_ARG;
+    CXR_LAUNCH(patch_embed_pack_kernel, dim3(cdiv(64 * 192, 256)), dim3(256), 0, stream, w, (bf16_t*)out);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+extern "C" int cxr_patch_embed_s1_f32(const float* px, const void* Wpk, const float* bias, const float* gamma, const float* beta, float eps,
+                                      void* e_out, void* y_out, float* stats, int Bn, int H, int W, hipStream_t stream) {
+    if (!px || !Wpk || !bias || !gamma || !beta || !y_out || Bn <= 0 || H < 4 || W < 4 || (H % 4) || (W % 4) || W > 384) return CXR_ERR_ARG;
+    if ((((size_t)px) % 16) || (((size_t)Wpk) % 16) || (((size_t)y_out) % 8) || (e_out && (((size_t)e_out) % 8)) || (stats && !e_out)) return CXR_ERR_ARG;
+    const int Ho = H / 4, Wo = W / 4;                              // (H + 2*2 - 7) / 4 + 1 for H % 4 == 0
+    const long grid = (long)Bn * cdiv(Ho, PE_RB);
+    if (grid > 0x7fffffffL) return CXR_ERR_ARG;
+    CXR_LAUNCH(patch_embed_s1_kernel, dim3((unsigned)grid), dim3(256), 0, stream, px, (const bf16_t*)Wpk, bias, gamma, beta, eps, (bf16_t*)e_out,
+               (bf16_t*)y_out, stats, H, W, Ho, Wo);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
 extern "C" int cxr_im2col_nchw_f32(const float* px, void* col, int Bn, int Cin, int H, int W, int KS, int stride, int pad,
                                    int Ho, int Wo, int Kpad, hipStream_t stream) {
     if (Bn <= 0 || (Kpad % 8) || Kpad < Cin * KS * KS) return CXR_ERR_ARG;

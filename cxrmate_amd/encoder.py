@@ -37,6 +37,7 @@ class CvtEncoderEngine:
         self._bwd_stats_from_y = os.environ.get("CXR_DW3_STATS_FROM_Y", "1") != "0"      # A/B switch: 0 = backward BatchNorm statistics recompute the convolution
         self._q8_fused = os.environ.get("CXR_FP8_FUSED", "1") != "0"      # A/B switch: 0 = separate bf16 -> e4m3 passes in front of the e4m3 GEMMs
         self._implicit_embed = os.environ.get("CXR_IMPLICIT_EMBED", "1") != "0"      # A/B switch: 0 = im2col + GEMM for the stage-2 / stage-3 embeddings
+        self._patch_fused = os.environ.get("CXR_PATCH_EMBED_FUSED", "1") != "0"      # A/B switch: 0 = im2col + GEMM + LayerNorm for the stage-1 embedding
         self._amax = None                           # calibration pass: {key: running max |activation|}
 
     # ------------------------------------------------------------------------------------------ fp8 (e4m3) linear layers of the frozen encoder
@@ -106,6 +107,13 @@ class CvtEncoderEngine:
                 if wp is None or wp.device != w.device:
                     wp = self._embed_buf[s] = torch.zeros((co, kpad), dtype=torch.bfloat16, device=w.device)
                 wp[:, :k] = w.reshape(co, k)                         # K order (c, ky, kx) = weight.view(Cout, -1)
+                if self._fused_patch_embed(w.shape):
+                    # the one-launch stage-1 embedding (csrc/conv.hip patch_embed_s1_kernel) reads the weights in its own packed order
+                    pk = self._embed_buf.get("pk0")
+                    if pk is None or pk.device != w.device:
+                        pk = self._embed_buf["pk0"] = torch.empty((64, 192), dtype=torch.bfloat16, device=w.device)
+                    ops.patch_embed_pack(st.f32(sp + "embedding.convolution_embeddings.projection.weight").contiguous(), out=pk)
+                    prep[("embed_pk", 0)] = pk
             else:
                 if wp is None or wp.device != w.device:
                     wp = self._embed_buf[s] = torch.empty((co, w.shape[1] * w.shape[2] * w.shape[3]), dtype=torch.bfloat16, device=w.device)
@@ -115,6 +123,12 @@ class CvtEncoderEngine:
         self._wt_ready = False
         self._fold_cache = {}
         return prep
+
+    def _fused_patch_embed(self, wshape):
+        """The stage-1 embedding runs as ONE kernel (direct 7 x 7 / stride 4 convolution on the matrix cores + bias + LayerNorm) for the reference's
+        geometry: Conv2d(3, 64, 7, 4, 2). CXR_PATCH_EMBED_FUSED=0: im2col + GEMM + LayerNorm (A/B switch)."""
+        cfg = self.cfg
+        return (self._patch_fused and tuple(wshape) == (64, 3, 7, 7) and cfg.patch_stride[0] == 4 and cfg.patch_padding[0] == 2 and not cfg.cls_token[0])
 
     def _conv_prefix(self, s, l, name):
         return self._stage(s) + f"layers.{l}.attention.attention.convolution_projection_{name}.convolution_projection."
@@ -239,7 +253,14 @@ class CvtEncoderEngine:
             C = cfg.embed_dim[s]
             ep = sp + "embedding.convolution_embeddings."
             xin, Hin, Win = x, H, W
-            if s == 0:
+            fused0 = s == 0 and ("embed_pk", 0) in prep and px.shape[2] % 4 == 0 and px.shape[3] % 4 == 0 and px.shape[3] <= 384
+            if fused0:
+                # projection + bias + LayerNorm in one launch; e (the LayerNorm's input) and the statistics only when a backward pass follows
+                col, xin = None, px
+                xs = torch.empty((Bn, (px.shape[2] // 4) * (px.shape[3] // 4), C), dtype=torch.bfloat16, device=px.device)
+                _, e, estats, Ho, Wo = ops.patch_embed_s1(px, prep[("embed_pk", 0)], st.f32(ep + "projection.bias"), st.f32(ep + "normalization.weight"),
+                                                          st.f32(ep + "normalization.bias"), cfg.inner_layer_norm_eps, need_e=save, out=xs.view(-1, C))
+            elif s == 0:
                 col, Ho, Wo = ops.im2col_pixels(px, cfg.patch_sizes[0], cfg.patch_stride[0], cfg.patch_padding[0], prep[("embed", 0)].shape[1])
                 e = ops.gemm_nt(col, prep[("embed", s)], bias=st.f32(ep + "projection.bias"))
             elif self._implicit_embed and C % 4 == 0 and x.shape[2] % 64 == 0 and cfg.patch_sizes[s] == 3:
@@ -252,8 +273,11 @@ class CvtEncoderEngine:
                 e = ops.gemm_nt(col, prep[("embed", s)], bias=st.f32(ep + "projection.bias"))
             tok0 = 1 if cfg.cls_token[s] else 0
             L = tok0 + Ho * Wo
-            xs = torch.empty((Bn, L, C), dtype=torch.bfloat16, device=px.device)
-            if tok0:
+            if not fused0:
+                xs = torch.empty((Bn, L, C), dtype=torch.bfloat16, device=px.device)
+            if fused0:
+                pass
+            elif tok0:
                 y, estats = ops.layernorm(e, st.f32(ep + "normalization.weight"), st.f32(ep + "normalization.bias"), cfg.inner_layer_norm_eps, need_stats=save)
                 ops.copy_rows(y.view(Bn, Ho * Wo, C), xs[:, 1:, :])
                 ops.bcast_row(st.f32(sp + "cls_token"), xs)
@@ -439,7 +463,10 @@ class CvtEncoderEngine:
             col = ss["col"]
             if col is None:                                   # implicit-GEMM forward: the im2col matrix is built here, on the weight-gradient stream
                 with ops._on_wgrad_stream(ss["xin"]):
-                    col = ops.im2col_tokens(ss["xin"], ss["Hin"], ss["Win"], cfg.patch_stride[s], cfg.patch_padding[s])[0]
+                    if s == 0:
+                        col = ops.im2col_pixels(ss["xin"], cfg.patch_sizes[0], cfg.patch_stride[0], cfg.patch_padding[0], wp.shape[1])[0]
+                    else:
+                        col = ops.im2col_tokens(ss["xin"], ss["Hin"], ss["Win"], cfg.patch_stride[s], cfg.patch_padding[s])[0]
             ops.linear_bwd_weight(de, col, dwp, st.grad(ep + "projection.bias"))
             gw = st.grad(ep + "projection.weight")
             with ops._on_wgrad_stream(dwp):                  # same stream as the weight-gradient GEMM that fills dwp (ordered after it)

@@ -613,6 +613,30 @@ def im2col_pixels(px, ks, stride, pad, kpad):
     return col, Ho, Wo
 
 
+def patch_embed_pack(w, out=None):
+    """w [64, 3, 7, 7] fp32 -> the packed bf16 operand [64, 192] of patch_embed_s1 (K order (c, ky) x 8 taps, zero padded)"""
+    assert w.dtype == torch.float32 and tuple(w.shape) == (64, 3, 7, 7) and w.is_contiguous()
+    if out is None:
+        out = torch.empty((64, 192), device=w.device, dtype=BF16)
+    LIB.call("cxr_patch_embed_pack_f32", _p(w), _p(out), _s())
+    return out
+
+
+def patch_embed_s1(px, wpk, bias, gamma, beta, eps, need_e=False, out=None):
+    """px [Bn, 3, H, W] fp32 -> (y [Bn*Ho*Wo, 64] bf16 = LayerNorm(conv7x7s4p2(px) + bias), e | None, stats | None, Ho, Wo): the CvT stage-1 patch
+    embedding in one launch (csrc/conv.hip patch_embed_s1_kernel)."""
+    Bn, Cin, H, W = px.shape
+    assert px.dtype == torch.float32 and px.is_contiguous() and Cin == 3 and H % 4 == 0 and W % 4 == 0 and W <= 384
+    Ho, Wo = H // 4, W // 4
+    rows = Bn * Ho * Wo
+    y = out if out is not None else torch.empty((rows, 64), device=px.device, dtype=BF16)
+    assert y.shape == (rows, 64) and y.is_contiguous()
+    e = torch.empty((rows, 64), device=px.device, dtype=BF16) if need_e else None
+    stats = torch.empty((rows, 2), device=px.device, dtype=torch.float32) if need_e else None
+    LIB.call("cxr_patch_embed_s1_f32", _p(px), _p(wpk), _p(bias), _p(gamma), _p(beta), float(eps), _p(e), _p(y), _p(stats), Bn, H, W, _s())
+    return y, e, stats, Ho, Wo
+
+
 def im2col_tokens(x, H, W, stride, pad):
     """x [Bn, H*W, C] bf16 (batch/row strides free) -> col [Bn*Ho*Wo, 9*C]"""
     Bn, L, C = x.shape

@@ -160,6 +160,14 @@ int cxr_layernorm_bwd_grid(long rows, int C);
  * (TF5:cvt:93-110,157-169) on token-major activations with the class token passed through (TF5:cvt:195-198). */
 int cxr_im2col_nchw_f32(const float* px, void* col, int Bn, int Cin, int H, int W, int KS, int stride, int pad, int Ho, int Wo, int Kpad,
                         hipStream_t stream);
+/* The whole stage-1 patch embedding of CvT in one launch (TF5 models/cvt/modeling_cvt.py:77-90: Conv2d(3, 64, 7, stride 4, padding 2) -> flatten ->
+ * LayerNorm(64)): fp32 NCHW pixels px [Bn, 3, H, W] -> y [Bn*(H/4)*(W/4), 64] bf16 = LayerNorm(conv + bias) as a direct convolution on the matrix
+ * cores (no im2col matrix). e_out (may be NULL) receives conv + bias (bf16: the LayerNorm backward's input), stats (may be NULL; needs e_out) the
+ * per-token (mean, rstd). Wpk = the weights packed by cxr_patch_embed_pack_f32 from the nn.Conv2d layout [64, 3, 7, 7] (fp32). Requires H % 4 == 0,
+ * W % 4 == 0, W <= 384 (the reference's 384 x 384 input), 16-byte aligned px. */
+int cxr_patch_embed_pack_f32(const float* w, void* out, hipStream_t stream);
+int cxr_patch_embed_s1_f32(const float* px, const void* Wpk, const float* bias, const float* gamma, const float* beta, float eps,
+                           void* e_out, void* y_out, float* stats, int Bn, int H, int W, hipStream_t stream);
 int cxr_im2col_tok_bf16(const void* x, long x_bs, long x_rs, void* col, int Bn, int Cin, int H, int W, int stride, int pad, int Ho, int Wo,
                         hipStream_t stream);
 int cxr_col2im_tok_bf16(const void* dcol, void* dx, long dx_bs, long dx_rs, int Bn, int Cin, int H, int W, int stride, int pad, int Ho, int Wo,

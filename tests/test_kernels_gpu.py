@@ -827,6 +827,39 @@ def test_im2col_pixels_matches_conv(ops):
         assert float(col[:, Cin * ks * ks:].float().abs().sum()) == 0
 
 
+@pytest.mark.parametrize("Bn,H,W", [(2, 96, 96), (1, 384, 384), (3, 100, 52), (2, 8, 384)])
+def test_patch_embedding_in_one_launch(ops, Bn, H, W):
+    """cxr_patch_embed_s1_f32 (round 4): Conv2d(3, 64, 7, stride 4, padding 2) + bias + LayerNorm(64) of the CvT stage-1 embedding as a direct
+    convolution on the matrix cores, against torch's conv2d / layer_norm on the same bf16-rounded pixels and weights (fp32 accumulation both sides;
+    e is rounded to bf16 before the LayerNorm, as when a GEMM wrote it), and against the im2col + GEMM + LayerNorm path it replaces. Partial last
+    pixel tile (W / 4 not a multiple of 16), partial last row band, the full 384-pixel row."""
+    px = dev(rnd(Bn, 3, H, W, seed=5) * 1.5 + 0.2)
+    w = dev(rnd(64, 3, 7, 7, seed=6, scale=0.1))
+    bias, gamma, beta = dev(rnd(64, seed=7) * 0.3), dev(1.0 + 0.2 * rnd(64, seed=8)), dev(0.2 * rnd(64, seed=9))
+    wpk = ops.patch_embed_pack(w)
+    assert torch.equal(wpk.view(64, 24, 8)[:, :21, :7].reshape(64, 3, 7, 7), w.to(BF)) and float(wpk.view(64, 24, 8)[:, 21:].abs().max()) == 0.0
+    assert float(wpk.view(64, 24, 8)[:, :, 7].abs().max()) == 0.0
+    y, e, stats, Ho, Wo = ops.patch_embed_s1(px, wpk, bias, gamma, beta, 1e-5, need_e=True)
+    assert (Ho, Wo) == (H // 4, W // 4)
+    ref_e = torch.nn.functional.conv2d(px.to(BF).float(), w.to(BF).float(), bias, stride=4, padding=2).flatten(2).transpose(1, 2).reshape(-1, 64)
+    close(e, ref_e, rtol=4e-3, atol=1e-2, what="patch embedding conv + bias")
+    er = e.float()
+    ref_y = torch.nn.functional.layer_norm(er, (64,), gamma, beta, 1e-5)
+    close(y, ref_y, rtol=4e-3, atol=2e-2, what="LayerNorm of the embedding")
+    close(stats[:, 0], er.mean(1), rtol=1e-4, atol=1e-4, what="mean")
+    close(stats[:, 1], (er.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-3, atol=1e-3, what="rstd")
+    y2 = ops.patch_embed_s1(px, wpk, bias, gamma, beta, 1e-5, need_e=False)[0]           # inference form: nothing but y is written
+    assert torch.equal(y2, y)
+    # the path it replaces
+    wp = torch.zeros((64, 192), dtype=BF, device="cuda")
+    wp[:, :147] = w.reshape(64, 147).to(BF)
+    col, _, _ = ops.im2col_pixels(px, 7, 4, 2, 192)
+    e_old = ops.gemm_nt(col, wp, bias=bias)
+    y_old, st_old = ops.layernorm(e_old, gamma, beta, 1e-5, need_stats=True)
+    close(e, e_old.float(), rtol=4e-3, atol=1e-2, what="e vs im2col + GEMM")
+    close(y, y_old.float(), rtol=6e-3, atol=3e-2, what="y vs im2col + GEMM + LayerNorm")
+
+
 def test_im2col_tokens_and_col2im(ops):
     Bn, C, H, W = 2, 64, 24, 24
     x = dev(rnd(Bn, H * W, C).to(BF))
