@@ -490,6 +490,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd2_kernel(const AttnArgs a)
     }
 }
 
+// (Measured and removed in round 4: a K / V-RESIDENT forward for short key sets -- CvT stage 3, 577 queries x 145 keys per (image, head): one workgroup
+// per (image, head) stages all keys once and its four waves walk the ten 64-query blocks without another barrier, instead of three workgroups that each
+// stage the same three key tiles. Bit-identical (same per-wave step) and SLOWER: 32.2 -> 34.9 us per call, no difference in the step. These calls are
+// not bound by the K / V staging but by each wave's serial MFMA -> softmax -> MFMA chain: 384 workgroups of 4 waves put 1.5 waves on a SIMD where
+// 1152 put 4.5 rounds of 2.)
 template <int NW>
 static void attn_fwd2_launch(const AttnArgs& a, hipStream_t stream) {
     const dim3 grid(cdiv(a.Tq, NW * 64), a.H, a.B), block(NW * 64);
@@ -526,7 +531,7 @@ static int attn_fwd_launch(const void* Q, const void* K, const void* V, void* O,
     a.scale_log2e = scale * 1.4426950408889634f; a.causal = causal; a.causal_shift = causal_shift;
     a.drop_seed = drop_seed; a.drop_site = drop_site; a.drop_thr16 = drop_p > 0.f ? dropout_thr16(drop_p) : 0u;
     a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_t0 = drop_t0;
-    if (g_attn_fwd_version == 2 || O8) {
+    if (g_attn_fwd_version >= 2 || O8) {
         static const int force_nw = getenv("CXR_ATT_NW") ? atoi(getenv("CXR_ATT_NW")) : 0;      // lab switch
         if (force_nw ? force_nw == 4 : Tq > 128) attn_fwd2_launch<4>(a, stream);
         else attn_fwd2_launch<2>(a, stream);
