@@ -8,7 +8,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "cxrmate_hip.h")
-LIB_PATH = os.path.join(HERE, "lib", "libcxrmate_hip.so")
+LIB_PATH = os.environ.get("CXR_LIB") or os.path.join(HERE, "lib", "libcxrmate_hip.so")      # CXR_LIB: a differently BUILT library (A/B of build-time switches)
 
 _CTYPES = {"long": ctypes.c_long, "int": ctypes.c_int, "float": ctypes.c_float, "unsigned int": ctypes.c_uint,
            "hipStream_t": ctypes.c_void_p}

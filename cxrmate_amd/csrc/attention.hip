@@ -333,6 +333,7 @@ __device__ __forceinline__ void att2_step(const AttnArgs& a, const bf16_t* Kc, c
 // MODE 1: key-padding and / or causal mask;  MODE 2: MODE 1 + dropout on the probabilities (decoder, train mode)
 template <int NW, int MODE>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd2_kernel(const AttnArgs a) {
+    CXR_PRIO_MAIN();
     constexpr int NT = NW * 64, CH = 512 / NT;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A2_BUF + 128 + 16];
     unsigned char* Ms = smem + 2 * A2_BUF;

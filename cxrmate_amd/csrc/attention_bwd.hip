@@ -44,6 +44,7 @@ __device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& x, int s) {
 // workgroups the second one staged every Q / dO tile again for 17 keys (one live wave out of four).
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_kernel(const AttnBwdArgs a) {
+    CXR_PRIO_MAIN();
     constexpr int NT = NW * 64;
     __shared__ __attribute__((aligned(16))) bf16_t Qr[64 * RS];
     __shared__ __attribute__((aligned(16))) bf16_t Qt[64 * TS];
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_kernel(const AttnBwd
 }
 
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
+    CXR_PRIO_MAIN();
     __shared__ __attribute__((aligned(16))) bf16_t Kr[64 * RS];
     __shared__ __attribute__((aligned(16))) bf16_t Kt[64 * TS];
     __shared__ __attribute__((aligned(16))) bf16_t Vr[64 * RS];
@@ -455,6 +457,7 @@ __device__ __forceinline__ void dq2_step(const AttnBwdArgs& a, const bf16_t* Kr,
 // MODE 0: no key-padding mask, not causal, no dropout; 1: masks; 2: masks + dropout (as attn_fwd2_kernel)
 template <int NW, int MODE>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq2_kernel(const AttnBwdArgs a) {
+    CXR_PRIO_MAIN();
     constexpr int NT = NW * 64, CH = 512 / NT;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * Q2_BUF + 128 + 16];
     unsigned char* Ms = smem + 2 * Q2_BUF;

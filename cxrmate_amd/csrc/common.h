@@ -14,6 +14,16 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 #define CXR_ERR_ARG (-1)
 #define CXR_ERR_LAUNCH (-2)
 
+// The kernels of the training step's MAIN stream (NT GEMMs, attention, depthwise projections, LayerNorm) raise their waves' issue priority once, at
+// entry: on a SIMD they share with a wave of the weight-gradient stream (priority 0) their MFMA / VALU instructions are arbitrated first
+// (MI355X_MICROARCH.md, "Two waves per SIMD", item 2). Same-box alternation of three builds (-DCXR_MAIN_PRIO=0 / 1 / 3, scripts/r4/build_prio.sh,
+// profiles/r04_ab_wgrad_stream.txt): 41.17 / 41.08 / 41.07 ms per step -- the two streams mostly contend for CU slots, LDS and bandwidth, not for issue
+// slots, so it is worth 0.1 ms, no more. 0 compiles every s_setprio out.
+#ifndef CXR_MAIN_PRIO
+#define CXR_MAIN_PRIO 3
+#endif
+#define CXR_PRIO_MAIN() do { if (CXR_MAIN_PRIO) __builtin_amdgcn_s_setprio(CXR_MAIN_PRIO); } while (0)
+
 // torch (and anything else in the process) may leave a stale error in the HIP runtime's per-thread slot: clear it before launching so that
 // CXR_LAUNCH_CHECK reports only OUR launch failures.
 #define CXR_LAUNCH(...)                                      \

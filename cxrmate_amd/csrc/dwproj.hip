@@ -199,6 +199,7 @@ __device__ __forceinline__ void dw3_reduce_taps(float (&v)[80], float* dw3_red, 
 // ------------------------------------------------------------------------------------------------------------------ forward statistics
 // ws row (b*nbands + band) of [nproj][2][C]: (sum c, sum c^2) over this workgroup's outputs
 __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_stats_kernel(const Dw3Geo g, const Dw3P p0, const Dw3P p1, const Dw3P p2, float* __restrict__ ws) {
+    CXR_PRIO_MAIN();
     __shared__ float red[DW3_RED_SMALL];
     extern __shared__ uint4 dw3_tile[];
     const Dw3Blk k = dw3_block(g);
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_stats_kernel(const Dw3Geo 
 // ------------------------------------------------------------------------------------------------------------------ forward apply
 // y_q = conv(x; folded taps) + shift for every projection; class-token row copied through (TF5:cvt:195-198)
 __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_apply_kernel(const Dw3Geo g, const Dw3P p0, const Dw3P p1, const Dw3P p2) {
+    CXR_PRIO_MAIN();
     extern __shared__ uint4 dw3_tile[];
     const Dw3Blk k = dw3_block(g);
     const int pitch = g.W + 2, pitch8 = pitch * 8;
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_apply_kernel(const Dw3Geo 
 // bf16 rounding the activations carry anyway); a slice with a larger |beta| / |gamma| (pretrained BatchNorm parameters can have one) recomputes the
 // convolution. The remaining per-element error is unbiased and averages out in the two sums (tests: same tolerances as the recomputed path).
 __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_bwd_stats_kernel(const Dw3Geo g, const Dw3P p0, const Dw3P p1, const Dw3P p2, float* __restrict__ ws) {
+    CXR_PRIO_MAIN();
     __shared__ float red[DW3_RED_SMALL];
     extern __shared__ uint4 dw3_tile[];
     const Dw3Blk k = dw3_block(g);
@@ -373,6 +376,7 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_bwd_stats_kernel(const Dw3
 // With coefficients (train mode): dy <- dc = a*dy + kb + kc*c in place (class rows untouched). Always: ws row of [nproj][10][C] =
 // (G[t] = sum dc * x_t for the 9 taps, S = sum dc)
 __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_dc_taps_kernel(const Dw3Geo g, const Dw3P p0, const Dw3P p1, const Dw3P p2, float* __restrict__ ws) {
+    CXR_PRIO_MAIN();
     __shared__ float red[DW3_RED_TAPS];
     __shared__ __attribute__((aligned(16))) float wl[3][12][64];      // per projection: 9 raw taps + (a, kb, kc) of this slice
     extern __shared__ uint4 dw3_tile[];
@@ -512,6 +516,7 @@ __device__ __forceinline__ void dw3_dx_class(const Dw3Geo& g, const Dw3P& p0, co
 // dx[b,(iy,ix)] = sum_q sum_taps taps_q[ky][kx] * dc_q[b, ((iy+1-ky)/st, (ix+1-kx)/st)] (terms with a non-integer or out-of-range source
 // vanish); class row: dx[b,0] = sum_q dc_q[b,0]. g.x is the OUTPUT here; each projection's gradient band is staged in LDS.
 __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_dx_kernel(const Dw3Geo g, const Dw3P p0, const Dw3P p1, const Dw3P p2) {
+    CXR_PRIO_MAIN();
     __shared__ __attribute__((aligned(16))) float wl[3][12][64];      // taps of this slice (the class loops index them by compile-time tap)
     extern __shared__ uint4 dw3_tile[];
     const Dw3Blk k = dw3_block(g);

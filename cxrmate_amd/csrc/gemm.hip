@@ -34,6 +34,7 @@ struct ConvA { int Hin, Win, Cin, ksz, Ho, Wo, stride, pad; long x_bs, x_rs; };
 template <int BK, bool GLDS, int NST, int BN, bool CONV = false>
 __device__ __forceinline__ void gemm_nt_body(const GemmArgs& g, const int bid, const int nwg, const ConvA* cvp = nullptr) {
     static_assert(!CONV || (BK == 64 && GLDS), "the implicit-GEMM A gather is built on the 64-wide LDS-DMA staging");
+    CXR_PRIO_MAIN();
     constexpr int BM = 128;
     constexpr int NTL = BN / 32;                // 16-column MFMA tiles per wave along N
     constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row

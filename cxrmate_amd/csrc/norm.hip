@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
                                                             const float* __restrict__ beta, bf16_t* __restrict__ y, long ldy,
                                                             float* __restrict__ stats, long rows, float eps,
                                                             unsigned char* __restrict__ y8 = nullptr, long ldy8 = 0, float inv8 = 0.f) {
+    CXR_PRIO_MAIN();
     using L = LNCfg<C, true>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % L::LPR, grp = lane / L::LPR;
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ add, long ldadd,
                                                             bf16_t* __restrict__ dx, long lddx, float* __restrict__ partial /*[grid][2][C]*/,
                                                             long rows, LnBwdDrop dd) {
+    CXR_PRIO_MAIN();
     using L = LNCfg<C>;
     __shared__ float red[4][2][C];
     const uint32_t dseed = dd.thr16 ? *dd.seed : 0u;
