@@ -375,6 +375,10 @@ __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_bwd_stats_kernel(const Dw3
 // ------------------------------------------------------------------------------------------------------------------ dc + tap sums
 // With coefficients (train mode): dy <- dc = a*dy + kb + kc*c in place (class rows untouched). Always: ws row of [nproj][10][C] =
 // (G[t] = sum dc * x_t for the 9 taps, S = sum dc)
+// (Round 4, measured and removed: c from the projection's forward output as in dw3_bwd_stats_kernel -- 72 FMAs and 18 LDS reads of tap weights less per
+// output, one more 16-byte stream per projection. The window is unpacked for the tap sums either way, and the step was 0.18 ms SLOWER with it
+// (42.26 -> 42.44 ms, three alternations on one box, scripts/r4/call13.sh): the pass is bound by its memory streams beside the weight-gradient stream,
+// not by the convolution arithmetic.)
 __global__ __launch_bounds__(DW3_THREADS, 2) void dw3_dc_taps_kernel(const Dw3Geo g, const Dw3P p0, const Dw3P p1, const Dw3P p2, float* __restrict__ ws) {
     CXR_PRIO_MAIN();
     __shared__ float red[DW3_RED_TAPS];
