@@ -7,6 +7,7 @@
 //   outer: G(k, r)  += s * sum_m f(m,k)? * a[m,k] * t[m,r]             (dB from dy and t; dA from dropout(x) and dt)
 // Masks come from the same counter-based hash as every other dropout of the path (common.h), so nothing is stored.
 #include "common.h"
+#include "../../include/cxrmate_hip.h"
 
 constexpr int LR = 8;      // rank
 
@@ -208,6 +209,254 @@ extern "C" int cxr_lora_outer_bf16(const void* a, long lda, long M, int K, const
     LoraDrop d; d.seed = seed; d.site = site; d.thr16 = p > 0.f ? dropout_thr16(p) : 0u; d.inv = 1.0f / (1.0f - p); d.rows_per_b = rows_per_b; d.t0 = tpos0;
     const int rpb = (int)(cdiv(M, 256) < 32 ? 32 : cdiv(M, 256));
     CXR_LAUNCH(lora_outer_kernel, dim3(cdiv(M, rpb), cdiv(K, 256)), dim3(256), 0, stream, (const bf16_t*)a, lda, M, K, t, G, g_ks, g_rs, scale, d, rpb);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ teacher-forced pass (many rows)
+// The one-wave-per-row / one-thread-per-8-columns kernels above cost 30-39 us per launch at the 4080 rows of an SCST re-scoring pass (2-byte strided
+// loads, 64-96 weight loads per row, up to 128 same-address atomics) -- 66 launches, 2.3 ms of a 12-ms pass. Below: several problems per launch, the down
+// projection on the matrix cores, weights of the up / outer kernels in registers across the row loop.
+
+__device__ __forceinline__ uint4 lora_mask8(uint4 v, uint32_t key, uint32_t pair0, uint32_t thr16) {        // zero the dropped elements of 8 consecutive columns
+    uint32_t* d = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t bits = dropout_pair_bits(key, pair0 + j);
+        d[j] &= ((bits & 0xffffu) >= thr16 ? 0x0000ffffu : 0u) | ((bits >> 16) >= thr16 ? 0xffff0000u : 0u);
+    }
+    return v;
+}
+
+struct LoraDownMP { const bf16_t* x; long ldx; const bf16_t* W; long w_rs, w_cs; float* t; LoraDrop drop; };
+struct LoraDownMArgs { LoraDownMP p[2]; long M; int K; float scale; };
+constexpr int LDM_PITCH = 1024 + 8;
+
+// t[m, r] = scale * sum_k f(m,k) x[m,k] W(r,k): one workgroup = 16 rows of one problem, its 4 waves split the K / 32 steps of
+// v_mfma_f32_16x16x32_bf16 (A = masked x rows, B = W as [k][r] with columns 8..15 zero); W staged once in LDS as [r][k] whatever its strides.
+__global__ __launch_bounds__(256) void lora_down_mfma_kernel(const LoraDownMArgs g) {
+    __shared__ __attribute__((aligned(16))) bf16_t wl[8 * LDM_PITCH];
+    __shared__ float red[4][16][8];
+    const LoraDownMP& P = g.p[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, fg = lane >> 4;
+    for (int i = tid; i < 8 * g.K; i += 256) {
+        const int r = i / g.K, k = i - r * g.K;
+        wl[r * LDM_PITCH + k] = P.W[r * P.w_rs + k * P.w_cs];
+    }
+    const long m0 = (long)blockIdx.x * 16;
+    const long mc = m0 + n < g.M ? m0 + n : g.M - 1;
+    const uint32_t thr = P.drop.thr16;
+    const uint32_t key = thr ? dropout_row_key(*P.drop.seed, P.drop.site, (uint32_t)(mc / P.drop.rows_per_b), (uint32_t)(P.drop.t0 + (int)(mc % P.drop.rows_per_b))) : 0u;
+    const int nks = g.K >> 5;
+    uint4 xr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                                          // all of this wave's row pieces in flight before the first MFMA
+        int ks = wave + 4 * j; ks = ks < nks ? ks : nks - 1;
+        xr[j] = *reinterpret_cast<const uint4*>(P.x + mc * P.ldx + ks * 32 + fg * 8);
+    }
+    __syncthreads();
+    f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ks = wave + 4 * j;
+        if (ks < nks) {                                                    // (wave-uniform)
+            uint4 xv = xr[j];
+            if (thr) xv = lora_mask8(xv, key, (uint32_t)(ks * 16 + fg * 4), thr);
+            uint4 wv = make_uint4(0, 0, 0, 0);
+            if (n < 8) wv = *reinterpret_cast<const uint4*>(wl + n * LDM_PITCH + ks * 32 + fg * 8);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, xv), __builtin_bit_cast(bf16x8_t, wv), acc, 0, 0, 0);
+        }
+    }
+    if (n < 8) {                                                           // D: lane (column n, group fg) holds rows 4 fg + i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][4 * fg + i][n] = acc[i];
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int row = tid >> 3, r = tid & 7;
+        if (m0 + row < g.M)
+            P.t[(m0 + row) * LR + r] = ((red[0][row][r] + red[1][row][r]) + (red[2][row][r] + red[3][row][r])) * g.scale * (thr ? P.drop.inv : 1.0f);
+    }
+}
+
+extern "C" int cxr_lora_down_multi_bf16(const cxr_lora_down_desc* probs, int nprob, long M, int K, const unsigned int* seed, int rows_per_b, int tpos0,
+                                        float scale, hipStream_t stream) {
+    if (!probs || nprob < 1 || nprob > 2 || M <= 0 || K <= 0 || K > 1024 || (K % 32) || rows_per_b <= 0) return CXR_ERR_ARG;
+    LoraDownMArgs g;
+    g.M = M; g.K = K; g.scale = scale;
+    for (int q = 0; q < 2; ++q) {
+        const cxr_lora_down_desc& s = probs[q < nprob ? q : 0];
+        if (!s.x || !s.W || !s.t || (s.ldx % 8) || (((size_t)s.x) % 16) || (s.p > 0.f && !seed) || s.p >= 1.f) return CXR_ERR_ARG;
+        LoraDownMP& d = g.p[q];
+        d.x = (const bf16_t*)s.x; d.ldx = s.ldx; d.W = (const bf16_t*)s.W; d.w_rs = s.w_rs; d.w_cs = s.w_cs; d.t = s.t;
+        d.drop.seed = seed; d.drop.site = s.site; d.drop.thr16 = s.p > 0.f ? dropout_thr16(s.p) : 0u; d.drop.inv = 1.0f / (1.0f - s.p);
+        d.drop.rows_per_b = rows_per_b; d.drop.t0 = tpos0;
+    }
+    CXR_LAUNCH(lora_down_mfma_kernel, dim3((unsigned)cdiv(M, 16), nprob), dim3(256), 0, stream, g);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// thread = (8-column chunk c, row lane rl): the chunk's 64 weights per problem stay in registers across the row loop
+struct LoraUpMP { bf16_t* y; long ldy; const float* t; const bf16_t* W; long w_rs, w_cs; LoraDrop drop; };
+struct LoraUpMArgs { LoraUpMP p[2]; long M; int N, rows_per_block; };
+
+template <int NQ>
+__global__ __launch_bounds__(256) void lora_up_multi_kernel(const LoraUpMArgs g) {
+    const int nch = g.N >> 3, RL = 256 / nch;
+    const int c = threadIdx.x % nch, rl = threadIdx.x / nch;
+    if (rl >= RL) return;
+    const int q0 = NQ == 2 ? 0 : blockIdx.y;
+    float w[NQ][LR][8];
+    uint32_t seedv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const LoraUpMP& P = g.p[q0 + q];
+        seedv[q] = P.drop.thr16 ? *P.drop.seed : 0u;
+#pragma unroll
+        for (int r = 0; r < LR; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[q][r][j] = bf2f(P.W[r * P.w_rs + (long)(c * 8 + j) * P.w_cs]);
+    }
+    bf16_t* y = g.p[q0].y;
+    const long ldy = g.p[q0].ldy;
+    const long mb = (long)blockIdx.x * g.rows_per_block, me = mb + g.rows_per_block < g.M ? mb + g.rows_per_block : g.M;
+    for (long m = mb + rl; m < me; m += RL) {
+        float o[8];
+        unpack8(*reinterpret_cast<const uint4*>(y + m * ldy + c * 8), o);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const LoraUpMP& P = g.p[q0 + q];
+            const float4 ta = *reinterpret_cast<const float4*>(P.t + m * LR), tb = *reinterpret_cast<const float4*>(P.t + m * LR + 4);
+            const float tv[LR] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = 0.f;
+#pragma unroll
+            for (int r = 0; r < LR; ++r)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = fmaf(tv[r], w[q][r][j], a[j]);
+            if (P.drop.thr16) {
+                const uint32_t key = dropout_row_key(seedv[q], P.drop.site, (uint32_t)(m / P.drop.rows_per_b), (uint32_t)(P.drop.t0 + (int)(m % P.drop.rows_per_b)));
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const uint32_t bits = dropout_pair_bits(key, (uint32_t)(c * 4 + (j >> 1)));
+                    a[j] = (bits & 0xffffu) >= P.drop.thr16 ? a[j] * P.drop.inv : 0.f;
+                    a[j + 1] = (bits >> 16) >= P.drop.thr16 ? a[j + 1] * P.drop.inv : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += a[j];
+        }
+        *reinterpret_cast<uint4*>(y + m * ldy + c * 8) = pack8(o);
+    }
+}
+
+extern "C" int cxr_lora_up_add_multi_bf16(const cxr_lora_up_desc* probs, int nprob, long M, int N, const unsigned int* seed, int rows_per_b, int tpos0,
+                                          hipStream_t stream) {
+    if (!probs || nprob < 1 || nprob > 2 || M <= 0 || N <= 0 || (N % 8) || N > 2048 || rows_per_b <= 0) return CXR_ERR_ARG;
+    LoraUpMArgs g;
+    g.M = M; g.N = N;
+    for (int q = 0; q < 2; ++q) {
+        const cxr_lora_up_desc& s = probs[q < nprob ? q : 0];
+        if (!s.y || !s.t || !s.W || (s.ldy % 8) || (((size_t)s.y) % 16) || (((size_t)s.t) % 16) || (s.p > 0.f && !seed) || s.p >= 1.f) return CXR_ERR_ARG;
+        LoraUpMP& d = g.p[q];
+        d.y = (bf16_t*)s.y; d.ldy = s.ldy; d.t = s.t; d.W = (const bf16_t*)s.W; d.w_rs = s.w_rs; d.w_cs = s.w_cs;
+        d.drop.seed = seed; d.drop.site = s.site; d.drop.thr16 = s.p > 0.f ? dropout_thr16(s.p) : 0u; d.drop.inv = 1.0f / (1.0f - s.p);
+        d.drop.rows_per_b = rows_per_b; d.drop.t0 = tpos0;
+    }
+    const bool same_y = nprob == 2 && probs[0].y == probs[1].y;
+    if (same_y && probs[0].ldy != probs[1].ldy) return CXR_ERR_ARG;
+    const int RL = 256 / (N / 8);
+    long rpb = cdiv(M, 512); rpb = rpb < 4L * RL ? 4L * RL : rpb;
+    g.rows_per_block = (int)rpb;
+    if (same_y) CXR_LAUNCH(lora_up_multi_kernel<2>, dim3((unsigned)cdiv(M, rpb), 1), dim3(256), 0, stream, g);
+    else CXR_LAUNCH(lora_up_multi_kernel<1>, dim3((unsigned)cdiv(M, rpb), nprob), dim3(256), 0, stream, g);
+    CXR_LAUNCH_CHECK();
+    return CXR_OK;
+}
+
+// G[k, r] += scale * sum_m f(m,k) a[m,k] t[m,r]: thread = (8-column chunk of a, row lane), 64 accumulators; one workgroup = a run of rows of one
+// problem; the row lanes meet in LDS, then ONE atomic per (column, r) and workgroup (64 workgroups per problem; the kernel above: one per 32 rows)
+struct LoraOuterMP { const bf16_t* a; long lda; const float* t; float* G; long g_ks, g_rs; LoraDrop drop; };
+struct LoraOuterMArgs { LoraOuterMP p[4]; long M; int K, rows_per_block; float scale; };
+
+__global__ __launch_bounds__(256) void lora_outer_multi_kernel(const LoraOuterMArgs g) {
+    extern __shared__ float lom_red[];                                     // [RL - 1][64][nch]
+    const LoraOuterMP& P = g.p[blockIdx.y];
+    const int nch = g.K >> 3;
+    int RL = 256 / nch; RL = RL < 4 ? RL : 4;
+    const int c = threadIdx.x % nch, rl = threadIdx.x / nch;
+    const bool on = rl < RL;
+    const uint32_t thr = P.drop.thr16;
+    const uint32_t seedv = thr ? *P.drop.seed : 0u;
+    float acc[LR][8];
+#pragma unroll
+    for (int r = 0; r < LR; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[r][j] = 0.f;
+    const long mb = (long)blockIdx.x * g.rows_per_block, me = mb + g.rows_per_block < g.M ? mb + g.rows_per_block : g.M;
+    if (on) {
+#pragma unroll 2
+        for (long m = mb + rl; m < me; m += RL) {
+            uint4 raw = *reinterpret_cast<const uint4*>(P.a + m * P.lda + c * 8);
+            const float4 ta = *reinterpret_cast<const float4*>(P.t + m * LR), tb = *reinterpret_cast<const float4*>(P.t + m * LR + 4);
+            if (thr) {
+                const uint32_t key = dropout_row_key(seedv, P.drop.site, (uint32_t)(m / P.drop.rows_per_b), (uint32_t)(P.drop.t0 + (int)(m % P.drop.rows_per_b)));
+                raw = lora_mask8(raw, key, (uint32_t)(c * 4), thr);
+            }
+            float av[8];
+            unpack8(raw, av);
+            const float tv[LR] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+            for (int r = 0; r < LR; ++r)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[r][j] = fmaf(tv[r], av[j], acc[r][j]);
+        }
+    }
+    if (on && rl > 0) {                                                    // value-major: neighbouring threads, neighbouring words
+        float* dst = lom_red + (long)(rl - 1) * 64 * nch + c;
+#pragma unroll
+        for (int r = 0; r < LR; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[(r * 8 + j) * nch] = acc[r][j];
+    }
+    __syncthreads();
+    if (on && rl == 0) {
+        const float s = g.scale * (thr ? P.drop.inv : 1.0f);
+        for (int o = 1; o < RL; ++o) {
+            const float* src = lom_red + (long)(o - 1) * 64 * nch + c;
+#pragma unroll
+            for (int r = 0; r < LR; ++r)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[r][j] += src[(r * 8 + j) * nch];
+        }
+#pragma unroll
+        for (int r = 0; r < LR; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(P.G + (long)(c * 8 + j) * P.g_ks + r * P.g_rs, acc[r][j] * s);
+    }
+}
+
+extern "C" int cxr_lora_outer_multi_bf16(const cxr_lora_outer_desc* probs, int nprob, long M, int K, float scale, const unsigned int* seed, int rows_per_b,
+                                         int tpos0, hipStream_t stream) {
+    if (!probs || nprob < 1 || nprob > 4 || M <= 0 || K <= 0 || (K % 8) || K > 2048 || rows_per_b <= 0) return CXR_ERR_ARG;
+    LoraOuterMArgs g;
+    g.M = M; g.K = K; g.scale = scale;
+    for (int q = 0; q < 4; ++q) {
+        const cxr_lora_outer_desc& s = probs[q < nprob ? q : 0];
+        if (!s.a || !s.t || !s.G || (s.lda % 8) || (((size_t)s.a) % 16) || (((size_t)s.t) % 16) || (s.p > 0.f && !seed) || s.p >= 1.f) return CXR_ERR_ARG;
+        LoraOuterMP& d = g.p[q];
+        d.a = (const bf16_t*)s.a; d.lda = s.lda; d.t = s.t; d.G = s.G; d.g_ks = s.g_ks; d.g_rs = s.g_rs;
+        d.drop.seed = seed; d.drop.site = s.site; d.drop.thr16 = s.p > 0.f ? dropout_thr16(s.p) : 0u; d.drop.inv = 1.0f / (1.0f - s.p);
+        d.drop.rows_per_b = rows_per_b; d.drop.t0 = tpos0;
+    }
+    const int nch = K / 8;
+    int RL = 256 / nch; RL = RL < 4 ? RL : 4;
+    long rpb = cdiv(M, 64); rpb = rpb < 4L * RL ? 4L * RL : rpb;
+    g.rows_per_block = (int)rpb;
+    const size_t lds = (size_t)(RL - 1) * nch * 64 * sizeof(float);          // <= 48 KB: (RL - 1) * nch <= 192
+    CXR_LAUNCH(lora_outer_multi_kernel, dim3((unsigned)cdiv(M, rpb), nprob), dim3(256), lds, stream, g);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

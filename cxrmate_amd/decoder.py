@@ -28,6 +28,7 @@ SITE_EMBED = 1
 
 _CROSS_KV_FUSED = os.environ.get("CXR_CROSS_KV_FUSED", "1") != "0"      # A/B switch: 0 = one K / V GEMM per layer
 _LORA_IN_KERNEL = os.environ.get("CXR_LORA_IN_KERNEL", "1") != "0"        # A/B switch: 0 = separate LoRA down-projection launch per decode layer
+_LORA_MULTI = os.environ.get("CXR_LORA_MULTI", "1") != "0"                # A/B switch: 0 = one launch per LoRA contraction in teacher-forced passes
 _SELF_QKV_FUSED = os.environ.get("CXR_SELF_QKV_FUSED", "1") != "0"      # A/B switch: 0 = separate query / key / value GEMMs
 _CROSS_WG_KEYS = int(os.environ.get("CXR_CROSS_WG_KEYS", "0"))          # cached cross-attention geometry (ops.attention_decode wg_keys)
 _CROSS_Q_FUSED = os.environ.get("CXR_CROSS_Q_FUSED", "1") != "0"      # A/B switch: 0 = separate query GEMM launch in front of the cached cross-attention
@@ -252,9 +253,16 @@ class BertEngine:
             if lora_tr:
                 # peft Linear under train(): base(x) + (alpha/r) * B(A(dropout(x))): base GEMM + rank-8 branch (one launch for q and k)
                 wq, bq, aq, bq_l = self._lora_parts(lp + "attention.self.query"); wk, bk, ak, bk_l = self._lora_parts(lp + "attention.self.key")
-                tq, tk = ops.lora_down(h, aq, drop0=(pl, _site(l, 5)), W1=ak, drop1=(pl, _site(l, 6)), rows_per_b=T, seed=seed, scale=ls)
-                q = ops.lora_up_add_(ops.gemm_nt(h, wq, bias=bq), tq, bq_l, True).view(B, T, D)
-                k = ops.lora_up_add_(ops.gemm_nt(h, wk, bias=bk), tk, bk_l, True).view(B, T, D)
+                if self._lora_multi(R, D):
+                    # both adapters per launch: down projections on the matrix cores, the two rank-8 updates as one launch
+                    tq, tk = ops.lora_down_multi([dict(x=h, W=aq, drop=(pl, _site(l, 5))), dict(x=h, W=ak, drop=(pl, _site(l, 6)))], rows_per_b=T, seed=seed, scale=ls)
+                    q, k = ops.gemm_nt(h, wq, bias=bq), ops.gemm_nt(h, wk, bias=bk)
+                    ops.lora_up_add_multi_([dict(y=q, t=tq, W=bq_l, w_is_b=True), dict(y=k, t=tk, W=bk_l, w_is_b=True)])
+                    q, k = q.view(B, T, D), k.view(B, T, D)
+                else:
+                    tq, tk = ops.lora_down(h, aq, drop0=(pl, _site(l, 5)), W1=ak, drop1=(pl, _site(l, 6)), rows_per_b=T, seed=seed, scale=ls)
+                    q = ops.lora_up_add_(ops.gemm_nt(h, wq, bias=bq), tq, bq_l, True).view(B, T, D)
+                    k = ops.lora_up_add_(ops.gemm_nt(h, wk, bias=bk), tk, bk_l, True).view(B, T, D)
                 if save:
                     sv.update(tq=tq, tk=tk)
                 v = ops.gemm_nt(h, wv, bias=bv).view(B, T, D)
@@ -362,6 +370,29 @@ class BertEngine:
                                 drop=(cfg.lora_dropout, site), rows_per_b=T, seed=seed)
         return dt
 
+    @staticmethod
+    def _lora_multi(R, D):
+        """Teacher-forced passes take the several-problems-per-launch LoRA kernels (csrc/lora.hip, second half); CXR_LORA_MULTI=0: the per-problem ones."""
+        return _LORA_MULTI and R > 256 and D % 32 == 0 and D <= 1024
+
+    def _wgrad_lora_train_pair(self, lp, dq, dk, x, tq, tk, l, T, seed):
+        """_wgrad_lora_train for the query and key adapters of a layer together: dt of both in one launch, dB / dA of both in one launch."""
+        st, cfg = self.s, self.cfg
+        s_ = cfg.lora_alpha / cfg.lora_r
+        bq, bk = lp + "attention.self.query", lp + "attention.self.key"
+        ops.linear_bwd_weight(dq, x, st.grad(bq + ".base_layer.weight"), st.grad(bq + ".base_layer.bias"))
+        ops.linear_bwd_weight(dk, x, st.grad(bk + ".base_layer.weight"), st.grad(bk + ".base_layer.bias"))
+        dtq, dtk = ops.lora_down_multi([dict(x=dq, W=st.w16(bq + ".lora_B.default.weight"), w_is_b=True),
+                                        dict(x=dk, W=st.w16(bk + ".lora_B.default.weight"), w_is_b=True)], scale=s_)
+        K, r, pl = x.shape[1], cfg.lora_r, cfg.lora_dropout
+        with ops._on_wgrad_stream(dq, dk, x, tq, tk, dtq, dtk):
+            ops.lora_outer_multi_into([dict(a=dq, t=tq, G=st.grad(bq + ".lora_B.default.weight"), g_ks=r, g_rs=1),                               # dB[n,r] += sum dy[m,n] t[m,r]
+                                       dict(a=x, t=dtq, G=st.grad(bq + ".lora_A.default.weight"), g_ks=1, g_rs=K, drop=(pl, _site(l, 5))),        # dA[r,k] += sum drop(x)[m,k] dt[m,r]
+                                       dict(a=dk, t=tk, G=st.grad(bk + ".lora_B.default.weight"), g_ks=r, g_rs=1),
+                                       dict(a=x, t=dtk, G=st.grad(bk + ".lora_A.default.weight"), g_ks=1, g_rs=K, drop=(pl, _site(l, 6)))],
+                                      rows_per_b=T, seed=seed)
+        return dtq, dtk
+
     def backward(self, saved, dlogits=None, dhidden=None, need_denc=False):
         """dlogits bf16 [R, V] (row stride may be padded to a multiple of 64) or dhidden bf16 [R, D]. Accumulates parameter
         gradients into the store; returns d(enc) bf16 [B,S,D] when need_denc."""
@@ -465,7 +496,9 @@ class BertEngine:
                 continue
             dq, dk, dv = ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, scale, kpm=saved["attn_mask"],
                                            causal=saved["causal"], drop=(pa, seed, _site(l, 0), 0))
-            if lora_tr:
+            if lora_tr and self._lora_multi(R, D):
+                dtq, dtk = self._wgrad_lora_train_pair(lp, dq.view(R, D), dk.view(R, D), sv["h"], sv["tq"], sv["tk"], l, T, seed)
+            elif lora_tr:
                 dtq = self._wgrad_lora_train(lp + "attention.self.query", dq.view(R, D), sv["h"], sv["tq"], _site(l, 5), T, seed)
                 dtk = self._wgrad_lora_train(lp + "attention.self.key", dk.view(R, D), sv["h"], sv["tk"], _site(l, 6), T, seed)
             else:
@@ -475,7 +508,12 @@ class BertEngine:
             t1 = ops.gemm_nt(dq.view(R, D), self._wt(lp + "attention.self.query", lora_tr), residual=da1)
             t2 = ops.gemm_nt(dk.view(R, D), self._wt(lp + "attention.self.key", lora_tr), residual=t1)
             dh = ops.gemm_nt(dv.view(R, D), self._wt(lp + "attention.self.value"), residual=t2)
-            if lora_tr:                                                  # dx += dropout-mask * (dt A) of both LoRA branches
+            if lora_tr and self._lora_multi(R, D):                       # dx += dropout-mask * (dt A) of both LoRA branches: one read-modify-write
+                pl = cfg.lora_dropout
+                ops.lora_up_add_multi_([dict(y=dh, t=dtq, W=st.w16(lp + "attention.self.query.lora_A.default.weight"), drop=(pl, _site(l, 5))),
+                                        dict(y=dh, t=dtk, W=st.w16(lp + "attention.self.key.lora_A.default.weight"), drop=(pl, _site(l, 6)))],
+                                       rows_per_b=T, seed=seed)
+            elif lora_tr:
                 pl = cfg.lora_dropout
                 ops.lora_up_add_(dh, dtq, st.w16(lp + "attention.self.query.lora_A.default.weight"), False, drop=(pl, _site(l, 5)), rows_per_b=T, seed=seed)
                 ops.lora_up_add_(dh, dtk, st.w16(lp + "attention.self.key.lora_A.default.weight"), False, drop=(pl, _site(l, 6)), rows_per_b=T, seed=seed)

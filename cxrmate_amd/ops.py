@@ -1462,6 +1462,73 @@ def lora_up_add_(y, t, W, w_is_b, drop=None, rows_per_b=1, tpos0=0, seed=None):
     return y
 
 
+class _LoraDownDesc(_ct.Structure):
+    """Mirror of `cxr_lora_down_desc` (include/cxrmate_hip.h)."""
+    _fields_ = [("x", _ct.c_void_p), ("ldx", _ct.c_long), ("W", _ct.c_void_p), ("w_rs", _ct.c_long), ("w_cs", _ct.c_long), ("t", _ct.c_void_p),
+                ("p", _ct.c_float), ("site", _ct.c_uint)]
+
+
+class _LoraUpDesc(_ct.Structure):
+    """Mirror of `cxr_lora_up_desc`."""
+    _fields_ = [("y", _ct.c_void_p), ("ldy", _ct.c_long), ("t", _ct.c_void_p), ("W", _ct.c_void_p), ("w_rs", _ct.c_long), ("w_cs", _ct.c_long),
+                ("p", _ct.c_float), ("site", _ct.c_uint)]
+
+
+class _LoraOuterDesc(_ct.Structure):
+    """Mirror of `cxr_lora_outer_desc`."""
+    _fields_ = [("a", _ct.c_void_p), ("lda", _ct.c_long), ("t", _ct.c_void_p), ("G", _ct.c_void_p), ("g_ks", _ct.c_long), ("g_rs", _ct.c_long),
+                ("p", _ct.c_float), ("site", _ct.c_uint)]
+
+
+def _lora_w_strides(W, w_is_b):
+    return (1, W.stride(0)) if w_is_b else (W.stride(0), 1)
+
+
+def lora_down_multi(probs, rows_per_b=1, tpos0=0, seed=None, scale=1.0):
+    """Teacher-forced pass: t_i [M,8] fp32 = scale * dropout_i(x_i) @ W_i^T for up to two problems in one launch (matrix cores).
+    probs: [dict(x=[M,K] bf16, W=, w_is_b=False, drop=(p, site) | None)] -> [t_i]"""
+    M, K = probs[0]["x"].shape
+    arr = (_LoraDownDesc * len(probs))()
+    outs = []
+    for d, pr in zip(arr, probs):
+        x, W = pr["x"], pr["W"]
+        assert x.shape == (M, K) and x.dtype == BF16 and x.stride(1) == 1 and W.dtype == BF16
+        t = torch.empty((M, 8), device=x.device, dtype=torch.float32)
+        p, site = pr.get("drop") or (0.0, 0)
+        rs, cs = _lora_w_strides(W, pr.get("w_is_b", False))
+        d.x, d.ldx, d.W, d.w_rs, d.w_cs, d.t, d.p, d.site = _p(x), x.stride(0), _p(W), rs, cs, _p(t), float(p), int(site)
+        outs.append(t)
+    LIB.call("cxr_lora_down_multi_bf16", _ct.addressof(arr), len(probs), M, K, _p(seed), int(rows_per_b), int(tpos0), float(scale), _s())
+    return outs
+
+
+def lora_up_add_multi_(probs, rows_per_b=1, tpos0=0, seed=None):
+    """y_i[m,n] += f_i(m,n) * sum_r t_i[m,r] W_i(r,n) for up to two problems in one launch; two problems naming the same y are added in one
+    read-modify-write. probs: [dict(y=[M,N] bf16 (row stride free), t=, W=, w_is_b=, drop=(p, site) | None)]"""
+    M, N = probs[0]["y"].shape
+    arr = (_LoraUpDesc * len(probs))()
+    for d, pr in zip(arr, probs):
+        y, t, W = pr["y"], pr["t"], pr["W"]
+        assert y.shape == (M, N) and y.dtype == BF16 and y.stride(1) == 1 and t.shape == (M, 8) and t.is_contiguous() and t.dtype == torch.float32
+        p, site = pr.get("drop") or (0.0, 0)
+        rs, cs = _lora_w_strides(W, pr.get("w_is_b", False))
+        d.y, d.ldy, d.t, d.W, d.w_rs, d.w_cs, d.p, d.site = _p(y), y.stride(0), _p(t), _p(W), rs, cs, float(p), int(site)
+    LIB.call("cxr_lora_up_add_multi_bf16", _ct.addressof(arr), len(probs), M, N, _p(seed), int(rows_per_b), int(tpos0), _s())
+
+
+def lora_outer_multi_into(probs, scale=1.0, rows_per_b=1, tpos0=0, seed=None):
+    """G_i[k*g_ks + r*g_rs] += scale * sum_m f_i(m,k) a_i[m,k] t_i[m,r] for up to four problems in one launch.
+    probs: [dict(a=[M,K] bf16, t=[M,8] fp32, G= fp32, g_ks=, g_rs=, drop=(p, site) | None)]"""
+    M, K = probs[0]["a"].shape
+    arr = (_LoraOuterDesc * len(probs))()
+    for d, pr in zip(arr, probs):
+        a, t, G = pr["a"], pr["t"], pr["G"]
+        assert a.shape == (M, K) and a.dtype == BF16 and a.stride(1) == 1 and t.shape == (M, 8) and t.is_contiguous() and G.dtype == torch.float32
+        p, site = pr.get("drop") or (0.0, 0)
+        d.a, d.lda, d.t, d.G, d.g_ks, d.g_rs, d.p, d.site = _p(a), a.stride(0), _p(t), _p(G), int(pr["g_ks"]), int(pr["g_rs"]), float(p), int(site)
+    LIB.call("cxr_lora_outer_multi_bf16", _ct.addressof(arr), len(probs), M, K, float(scale), _p(seed), int(rows_per_b), int(tpos0), _s())
+
+
 def lora_outer_into(a, t, G, g_ks, g_rs, scale=1.0, drop=None, rows_per_b=1, tpos0=0, seed=None):
     """G[k*g_ks + r*g_rs] += scale * sum_m f(m,k) a[m,k] t[m,r]  (fp32 G; strides in elements)."""
     M, K = a.shape

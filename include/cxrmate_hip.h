@@ -136,6 +136,22 @@ int cxr_lora_up_add_bf16(void* y, long ldy, long M, int N, const float* t, const
                          unsigned int site, int rows_per_b, int tpos0, hipStream_t stream);
 int cxr_lora_outer_bf16(const void* a, long lda, long M, int K, const float* t, float* G, long g_ks, long g_rs, float scale, float p,
                         const unsigned int* seed, unsigned int site, int rows_per_b, int tpos0, hipStream_t stream);
+/* The same three contractions for the teacher-forced pass (many rows), several problems per launch -- a BERT layer's query and key adapters
+ * together (REF:modelling_longitudinal.py:163-170; TF5:bert:195-260 BertSelfAttention):
+ *   down_multi  (<= 2 problems, each with its own input rows: forward x / x, backward dq / dk): matrix cores, 16 rows per workgroup, K % 32 == 0,
+ *               K <= 1024, ldx % 8 == 0; no LayerNorm option
+ *   up_add_multi(<= 2 problems; problems that name the SAME y are applied one after the other by the same thread -- the backward adds both
+ *               adapters' terms into dx in one read-modify-write; N % 8 == 0, N <= 2048)
+ *   outer_multi (<= 4 problems: dB and dA of both adapters; K % 8 == 0, K <= 2048; fp32 atomics into G as cxr_lora_outer_bf16) */
+typedef struct cxr_lora_down_desc { const void* x; long ldx; const void* W; long w_rs, w_cs; float* t; float p; unsigned int site; } cxr_lora_down_desc;
+typedef struct cxr_lora_up_desc { void* y; long ldy; const float* t; const void* W; long w_rs, w_cs; float p; unsigned int site; } cxr_lora_up_desc;
+typedef struct cxr_lora_outer_desc { const void* a; long lda; const float* t; float* G; long g_ks, g_rs; float p; unsigned int site; } cxr_lora_outer_desc;
+int cxr_lora_down_multi_bf16(const cxr_lora_down_desc* probs, int nprob, long M, int K, const unsigned int* seed, int rows_per_b, int tpos0,
+                             float scale, hipStream_t stream);
+int cxr_lora_up_add_multi_bf16(const cxr_lora_up_desc* probs, int nprob, long M, int N, const unsigned int* seed, int rows_per_b, int tpos0,
+                               hipStream_t stream);
+int cxr_lora_outer_multi_bf16(const cxr_lora_outer_desc* probs, int nprob, long M, int K, float scale, const unsigned int* seed, int rows_per_b,
+                              int tpos0, hipStream_t stream);
 
 /* ---- LayerNorm (TF5:cvt:79,363-364; REF:modelling_single.py:29; TF5:bert:103,292,350,478) ------------------------------- */
 int cxr_layernorm_fwd_bf16(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* stats, long rows, int C,

@@ -592,6 +592,54 @@ def test_lora_train_mode_kernels(ops, R):
     close(k, base, what="skinny3 problem without LoRA")
 
 
+@pytest.mark.parametrize("R,K", [(528, 768), (4080, 768), (1000, 64), (300, 1024)])
+def test_lora_kernels_with_several_problems_per_launch(ops, R, K):
+    """The teacher-forced forms of the three rank-8 contractions (two adapters per launch: down projection on the matrix cores, both rank-8 updates of dx
+    in one read-modify-write, dB / dA of both adapters in one launch) against fp32 torch with the materialised dropout masks, and against the
+    one-problem kernels."""
+    N, T, r, s_ = K, 24, 8, 4.0
+    x, dq, dk = dev(rnd(R, K).to(BF)), dev(rnd(R, N, seed=1).to(BF)), dev(rnd(R, N, seed=11).to(BF))
+    A, A2 = dev(rnd(r, K, seed=2, scale=0.05).to(BF)), dev(rnd(r, K, seed=4, scale=0.05).to(BF))
+    Bq, Bk = dev(rnd(N, r, seed=3, scale=0.05).to(BF)), dev(rnd(N, r, seed=13, scale=0.05).to(BF))
+    seed = torch.full((1,), 77, dtype=torch.int32, device="cuda")
+    f = ops.dropout_mask(R, K, 0.1, seed, 21, T, factor=True)
+    f2 = ops.dropout_mask(R, K, 0.1, seed, 22, T, factor=True)
+    # forward: t = s * dropout(x) A^T for both adapters, then q += t Bq^T, k += t2 Bk^T (separate outputs; one of them a column view of a wider matrix)
+    t, t2 = ops.lora_down_multi([dict(x=x, W=A, drop=(0.1, 21)), dict(x=x, W=A2, drop=(0.1, 22))], rows_per_b=T, seed=seed, scale=s_)
+    close(t, s_ * (x.float() * f) @ A.float().t(), rtol=1e-3, atol=1e-3, what="down, first adapter")
+    close(t2, s_ * (x.float() * f2) @ A2.float().t(), rtol=1e-3, atol=1e-3, what="down, second adapter")
+    if K <= 1024 and R > 256:
+        o, o2 = ops.lora_down(x, A, drop0=(0.1, 21), W1=A2, drop1=(0.1, 22), rows_per_b=T, seed=seed, scale=s_)
+        close(t, o, rtol=1e-4, atol=1e-4, what="down vs the one-wave-per-row kernel")
+    q0 = dev(rnd(R, N, seed=5).to(BF))
+    wide = dev(rnd(R, 2 * N + 8, seed=6).to(BF))
+    k0 = wide[:, N + 8:]
+    qk = [q0.clone(), wide.clone()]
+    ops.lora_up_add_multi_([dict(y=qk[0], t=t, W=Bq, w_is_b=True), dict(y=qk[1][:, N + 8:], t=t2, W=Bk, w_is_b=True)])
+    close(qk[0], q0.float() + t @ Bq.float().t(), what="up, first output")
+    close(qk[1][:, N + 8:], k0.float() + t2 @ Bk.float().t(), what="up, second output (a column view)")
+    assert torch.equal(qk[1][:, :N + 8], wide[:, :N + 8])
+    # backward: dt = s * dy B for both (different inputs), dB / dA of both in one launch, dx += mask * (dt A) of both in one pass
+    dt, dt2 = ops.lora_down_multi([dict(x=dq, W=Bq, w_is_b=True), dict(x=dk, W=Bk, w_is_b=True)], scale=s_)
+    close(dt, s_ * dq.float() @ Bq.float(), rtol=1e-3, atol=1e-3, what="dt, first adapter")
+    close(dt2, s_ * dk.float() @ Bk.float(), rtol=1e-3, atol=1e-3, what="dt, second adapter")
+    dB, dB2, dA, dA2 = torch.zeros(N, r, device="cuda"), torch.ones(N, r, device="cuda"), torch.zeros(r, K, device="cuda"), torch.zeros(r, K, device="cuda")
+    ops.lora_outer_multi_into([dict(a=dq, t=t, G=dB, g_ks=r, g_rs=1), dict(a=x, t=dt, G=dA, g_ks=1, g_rs=K, drop=(0.1, 21)),
+                               dict(a=dk, t=t2, G=dB2, g_ks=r, g_rs=1), dict(a=x, t=dt2, G=dA2, g_ks=1, g_rs=K, drop=(0.1, 22))], rows_per_b=T, seed=seed)
+    tol = dict(rtol=2e-3, atol=2e-3 * (R / 500.0) ** 0.5)
+    close(dB, dq.float().t() @ t, what="dB", **tol)
+    close(dB2, 1.0 + dk.float().t() @ t2, what="dB of the second adapter accumulates", **tol)
+    close(dA, dt.t() @ (x.float() * f), what="dA", **tol)
+    close(dA2, dt2.t() @ (x.float() * f2), what="dA of the second adapter", **tol)
+    dx0 = dev(rnd(R, K, seed=6).to(BF))
+    dx = dx0.clone()
+    ops.lora_up_add_multi_([dict(y=dx, t=dt, W=A, drop=(0.1, 21)), dict(y=dx, t=dt2, W=A2, drop=(0.1, 22))], rows_per_b=T, seed=seed)
+    close(dx, dx0.float() + f * (dt @ A.float()) + f2 * (dt2 @ A2.float()), what="dx from both adapters")
+    one = dx0.clone()
+    ops.lora_up_add_multi_([dict(y=one, t=dt, W=A, drop=(0.1, 21))], rows_per_b=T, seed=seed)
+    close(one, dx0.float() + f * (dt @ A.float()), what="dx from one adapter")
+
+
 @pytest.mark.parametrize("M", [1, 16, 32, 50])
 def test_gemm_skinny_fused_layernorm(ops, M):
     """LayerNorm folded into the decode GEMMs: `ln_a` normalises the raw A rows inside the kernel and publishes (mean, rstd);
