@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void lora_down_mfma_kernel(const LoraDownMArgs
     const long m0 = (long)blockIdx.x * 16;
     const long mc = m0 + n < g.M ? m0 + n : g.M - 1;
     const uint32_t thr = P.drop.thr16;
-    const uint32_t key = thr ? dropout_row_key(*P.drop.seed, P.drop.site, (uint32_t)(mc / P.drop.rows_per_b), (uint32_t)(P.drop.t0 + (int)(mc % P.drop.rows_per_b))) : 0u;
+    const uint32_t mq = (uint32_t)mc / (uint32_t)P.drop.rows_per_b;        // (32-bit division: rows < 2^31)
+    const uint32_t key = thr ? dropout_row_key(*P.drop.seed, P.drop.site, mq, (uint32_t)(P.drop.t0 + (int)((uint32_t)mc - mq * (uint32_t)P.drop.rows_per_b))) : 0u;
     const int nks = g.K >> 5;
     uint4 xr[8];
 #pragma unroll
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) void lora_down_mfma_kernel(const LoraDownMArgs
 
 extern "C" int cxr_lora_down_multi_bf16(const cxr_lora_down_desc* probs, int nprob, long M, int K, const unsigned int* seed, int rows_per_b, int tpos0,
                                         float scale, hipStream_t stream) {
-    if (!probs || nprob < 1 || nprob > 2 || M <= 0 || K <= 0 || K > 1024 || (K % 32) || rows_per_b <= 0) return CXR_ERR_ARG;
+    if (!probs || nprob < 1 || nprob > 2 || M <= 0 || M > 0x7fffffffL || K <= 0 || K > 1024 || (K % 32) || rows_per_b <= 0) return CXR_ERR_ARG;
     LoraDownMArgs g;
     g.M = M; g.K = K; g.scale = scale;
     for (int q = 0; q < 2; ++q) {
@@ -301,33 +302,65 @@ extern "C" int cxr_lora_down_multi_bf16(const cxr_lora_down_desc* probs, int npr
 struct LoraUpMP { bf16_t* y; long ldy; const float* t; const bf16_t* W; long w_rs, w_cs; LoraDrop drop; };
 struct LoraUpMArgs { LoraUpMP p[2]; long M; int N, rows_per_block; };
 
+constexpr int LUP_RPT = 4;                                                  // rows per thread: their y / t loads are all issued before the first FMA
+
 template <int NQ>
 __global__ __launch_bounds__(256) void lora_up_multi_kernel(const LoraUpMArgs g) {
     const int nch = g.N >> 3, RL = 256 / nch;
     const int c = threadIdx.x % nch, rl = threadIdx.x / nch;
     if (rl >= RL) return;
     const int q0 = NQ == 2 ? 0 : blockIdx.y;
+    bf16_t* y = g.p[q0].y;
+    const long ldy = g.p[q0].ldy;
+    const long mb = (long)blockIdx.x * (RL * LUP_RPT) + rl;
+    uint4 yr[LUP_RPT];
+    float4 tr[NQ][LUP_RPT][2];
+#pragma unroll
+    for (int i = 0; i < LUP_RPT; ++i) {
+        long m = mb + (long)i * RL; m = m < g.M ? m : g.M - 1;
+        yr[i] = *reinterpret_cast<const uint4*>(y + m * ldy + c * 8);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            tr[q][i][0] = *reinterpret_cast<const float4*>(g.p[q0 + q].t + m * LR);
+            tr[q][i][1] = *reinterpret_cast<const float4*>(g.p[q0 + q].t + m * LR + 4);
+        }
+    }
     float w[NQ][LR][8];
     uint32_t seedv[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const LoraUpMP& P = g.p[q0 + q];
         seedv[q] = P.drop.thr16 ? *P.drop.seed : 0u;
+        // the chunk's 64 weights as eight 16-byte loads in the two layouts that occur (one 2-byte load per weight touches 64 cache lines per wave
+        // instruction: 64 such instructions per thread were most of this kernel's 30 us)
+        if (P.w_cs == 1 && (P.w_rs % 8) == 0 && (((size_t)P.W) % 16) == 0) {            // A [8][N]: row r, columns 8c .. 8c+7
 #pragma unroll
-        for (int r = 0; r < LR; ++r)
+            for (int r = 0; r < LR; ++r) unpack8(*reinterpret_cast<const uint4*>(P.W + r * P.w_rs + c * 8), w[q][r]);
+        } else if (P.w_rs == 1 && P.w_cs == LR && (((size_t)P.W) % 16) == 0) {          // B [N][8]: the chunk's 8 rows are 128 consecutive bytes
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w[q][r][j] = bf2f(P.W[r * P.w_rs + (long)(c * 8 + j) * P.w_cs]);
+            for (int j = 0; j < 8; ++j) {
+                float row[LR];
+                unpack8(*reinterpret_cast<const uint4*>(P.W + (long)(c * 8 + j) * LR), row);
+#pragma unroll
+                for (int r = 0; r < LR; ++r) w[q][r][j] = row[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < LR; ++r)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[q][r][j] = bf2f(P.W[r * P.w_rs + (long)(c * 8 + j) * P.w_cs]);
+        }
     }
-    bf16_t* y = g.p[q0].y;
-    const long ldy = g.p[q0].ldy;
-    const long mb = (long)blockIdx.x * g.rows_per_block, me = mb + g.rows_per_block < g.M ? mb + g.rows_per_block : g.M;
-    for (long m = mb + rl; m < me; m += RL) {
+#pragma unroll
+    for (int i = 0; i < LUP_RPT; ++i) {
+        const long m = mb + (long)i * RL;
+        if (m >= g.M) break;
         float o[8];
-        unpack8(*reinterpret_cast<const uint4*>(y + m * ldy + c * 8), o);
+        unpack8(yr[i], o);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const LoraUpMP& P = g.p[q0 + q];
-            const float4 ta = *reinterpret_cast<const float4*>(P.t + m * LR), tb = *reinterpret_cast<const float4*>(P.t + m * LR + 4);
+            const float4 ta = tr[q][i][0], tb = tr[q][i][1];
             const float tv[LR] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
             float a[8];
 #pragma unroll
@@ -337,7 +370,8 @@ __global__ __launch_bounds__(256) void lora_up_multi_kernel(const LoraUpMArgs g)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) a[j] = fmaf(tv[r], w[q][r][j], a[j]);
             if (P.drop.thr16) {
-                const uint32_t key = dropout_row_key(seedv[q], P.drop.site, (uint32_t)(m / P.drop.rows_per_b), (uint32_t)(P.drop.t0 + (int)(m % P.drop.rows_per_b)));
+                const uint32_t mq = (uint32_t)m / (uint32_t)P.drop.rows_per_b;            // (32-bit: rows < 2^31; a 64-bit division is ~150 VALU instructions)
+                const uint32_t key = dropout_row_key(seedv[q], P.drop.site, mq, (uint32_t)(P.drop.t0 + (int)((uint32_t)m - mq * (uint32_t)P.drop.rows_per_b)));
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
                     const uint32_t bits = dropout_pair_bits(key, (uint32_t)(c * 4 + (j >> 1)));
@@ -354,7 +388,7 @@ __global__ __launch_bounds__(256) void lora_up_multi_kernel(const LoraUpMArgs g)
 
 extern "C" int cxr_lora_up_add_multi_bf16(const cxr_lora_up_desc* probs, int nprob, long M, int N, const unsigned int* seed, int rows_per_b, int tpos0,
                                           hipStream_t stream) {
-    if (!probs || nprob < 1 || nprob > 2 || M <= 0 || N <= 0 || (N % 8) || N > 2048 || rows_per_b <= 0) return CXR_ERR_ARG;
+    if (!probs || nprob < 1 || nprob > 2 || M <= 0 || M > 0x7fffffffL || N <= 0 || (N % 8) || N > 2048 || rows_per_b <= 0) return CXR_ERR_ARG;
     LoraUpMArgs g;
     g.M = M; g.N = N;
     for (int q = 0; q < 2; ++q) {
@@ -368,7 +402,7 @@ extern "C" int cxr_lora_up_add_multi_bf16(const cxr_lora_up_desc* probs, int npr
     const bool same_y = nprob == 2 && probs[0].y == probs[1].y;
     if (same_y && probs[0].ldy != probs[1].ldy) return CXR_ERR_ARG;
     const int RL = 256 / (N / 8);
-    long rpb = cdiv(M, 512); rpb = rpb < 4L * RL ? 4L * RL : rpb;
+    const long rpb = (long)RL * LUP_RPT;
     g.rows_per_block = (int)rpb;
     if (same_y) CXR_LAUNCH(lora_up_multi_kernel<2>, dim3((unsigned)cdiv(M, rpb), 1), dim3(256), 0, stream, g);
     else CXR_LAUNCH(lora_up_multi_kernel<1>, dim3((unsigned)cdiv(M, rpb), nprob), dim3(256), 0, stream, g);
@@ -376,18 +410,20 @@ extern "C" int cxr_lora_up_add_multi_bf16(const cxr_lora_up_desc* probs, int npr
     return CXR_OK;
 }
 
-// G[k, r] += scale * sum_m f(m,k) a[m,k] t[m,r]: thread = (8-column chunk of a, row lane), 64 accumulators; one workgroup = a run of rows of one
-// problem; the row lanes meet in LDS, then ONE atomic per (column, r) and workgroup (64 workgroups per problem; the kernel above: one per 32 rows)
+// G[k, r] += scale * sum_m f(m,k) a[m,k] t[m,r]: thread = (8-column chunk of a, row lane), 64 accumulators. One workgroup = (run of rows, block of
+// <= 32 chunks = 256 columns, problem); its 256 / chunks row lanes meet in LDS, then ONE atomic per (column, r) and workgroup. The atomics are what
+// such a kernel costs (device-scope fp32 adds on 24 KB of gradients: ~15 per ns): 16 row runs per problem (the kernel above: one per 32 rows; a first
+// version of this one with 64 runs of all columns: 100 us for four problems)
 struct LoraOuterMP { const bf16_t* a; long lda; const float* t; float* G; long g_ks, g_rs; LoraDrop drop; };
-struct LoraOuterMArgs { LoraOuterMP p[4]; long M; int K, rows_per_block; float scale; };
+struct LoraOuterMArgs { LoraOuterMP p[4]; long M; int K, rows_per_block, nchb, ncb; float scale; };
 
 __global__ __launch_bounds__(256) void lora_outer_multi_kernel(const LoraOuterMArgs g) {
-    extern __shared__ float lom_red[];                                     // [RL - 1][64][nch]
-    const LoraOuterMP& P = g.p[blockIdx.y];
-    const int nch = g.K >> 3;
-    int RL = 256 / nch; RL = RL < 4 ? RL : 4;
-    const int c = threadIdx.x % nch, rl = threadIdx.x / nch;
-    const bool on = rl < RL;
+    extern __shared__ float lom_red[];                                     // [RL - 1][64][nchb]
+    const LoraOuterMP& P = g.p[blockIdx.y / g.ncb];
+    const int cb = blockIdx.y % g.ncb;
+    const int nch = g.K >> 3, nchb = g.nchb, RL = 256 / nchb;
+    const int cl = threadIdx.x % nchb, rl = threadIdx.x / nchb, c = cb * nchb + cl;
+    const bool on = rl < RL && c < nch;
     const uint32_t thr = P.drop.thr16;
     const uint32_t seedv = thr ? *P.drop.seed : 0u;
     float acc[LR][8];
@@ -397,39 +433,53 @@ __global__ __launch_bounds__(256) void lora_outer_multi_kernel(const LoraOuterMA
         for (int j = 0; j < 8; ++j) acc[r][j] = 0.f;
     const long mb = (long)blockIdx.x * g.rows_per_block, me = mb + g.rows_per_block < g.M ? mb + g.rows_per_block : g.M;
     if (on) {
-#pragma unroll 2
-        for (long m = mb + rl; m < me; m += RL) {
-            uint4 raw = *reinterpret_cast<const uint4*>(P.a + m * P.lda + c * 8);
-            const float4 ta = *reinterpret_cast<const float4*>(P.t + m * LR), tb = *reinterpret_cast<const float4*>(P.t + m * LR + 4);
-            if (thr) {
-                const uint32_t key = dropout_row_key(seedv, P.drop.site, (uint32_t)(m / P.drop.rows_per_b), (uint32_t)(P.drop.t0 + (int)(m % P.drop.rows_per_b)));
-                raw = lora_mask8(raw, key, (uint32_t)(c * 4), thr);
+        for (long m0 = mb + rl; m0 < me; m0 += 4L * RL) {                  // four rows per trip: their loads are in flight together
+            uint4 raw[4];
+            float4 ta[4], tb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                long m = m0 + (long)i * RL; m = m < me ? m : me - 1;
+                raw[i] = *reinterpret_cast<const uint4*>(P.a + m * P.lda + c * 8);
+                ta[i] = *reinterpret_cast<const float4*>(P.t + m * LR);
+                tb[i] = *reinterpret_cast<const float4*>(P.t + m * LR + 4);
             }
-            float av[8];
-            unpack8(raw, av);
-            const float tv[LR] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
 #pragma unroll
-            for (int r = 0; r < LR; ++r)
+            for (int i = 0; i < 4; ++i) {
+                const long m = m0 + (long)i * RL;
+                if (m >= me) break;
+                uint4 rv = raw[i];
+                if (thr) {
+                    const uint32_t mq = (uint32_t)m / (uint32_t)P.drop.rows_per_b;
+                    const uint32_t key = dropout_row_key(seedv, P.drop.site, mq, (uint32_t)(P.drop.t0 + (int)((uint32_t)m - mq * (uint32_t)P.drop.rows_per_b)));
+                    rv = lora_mask8(rv, key, (uint32_t)(c * 4), thr);
+                }
+                float av[8];
+                unpack8(rv, av);
+                const float tv[LR] = {ta[i].x, ta[i].y, ta[i].z, ta[i].w, tb[i].x, tb[i].y, tb[i].z, tb[i].w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[r][j] = fmaf(tv[r], av[j], acc[r][j]);
+                for (int r = 0; r < LR; ++r)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[r][j] = fmaf(tv[r], av[j], acc[r][j]);
+            }
         }
     }
-    if (on && rl > 0) {                                                    // value-major: neighbouring threads, neighbouring words
-        float* dst = lom_red + (long)(rl - 1) * 64 * nch + c;
+    // row lanes 1 .. RL-1 -> LDS (value-major: neighbouring threads, neighbouring words), row lane 0 sums
+    if (rl > 0 && rl < RL) {
+        float* dst = lom_red + (long)(rl - 1) * 64 * nchb + cl;
 #pragma unroll
         for (int r = 0; r < LR; ++r)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dst[(r * 8 + j) * nch] = acc[r][j];
+            for (int j = 0; j < 8; ++j) dst[(r * 8 + j) * nchb] = acc[r][j];
     }
     __syncthreads();
     if (on && rl == 0) {
         const float s = g.scale * (thr ? P.drop.inv : 1.0f);
         for (int o = 1; o < RL; ++o) {
-            const float* src = lom_red + (long)(o - 1) * 64 * nch + c;
+            const float* src = lom_red + (long)(o - 1) * 64 * nchb + cl;
 #pragma unroll
             for (int r = 0; r < LR; ++r)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[r][j] += src[(r * 8 + j) * nch];
+                for (int j = 0; j < 8; ++j) acc[r][j] += src[(r * 8 + j) * nchb];
         }
 #pragma unroll
         for (int r = 0; r < LR; ++r)
@@ -440,7 +490,7 @@ __global__ __launch_bounds__(256) void lora_outer_multi_kernel(const LoraOuterMA
 
 extern "C" int cxr_lora_outer_multi_bf16(const cxr_lora_outer_desc* probs, int nprob, long M, int K, float scale, const unsigned int* seed, int rows_per_b,
                                          int tpos0, hipStream_t stream) {
-    if (!probs || nprob < 1 || nprob > 4 || M <= 0 || K <= 0 || (K % 8) || K > 2048 || rows_per_b <= 0) return CXR_ERR_ARG;
+    if (!probs || nprob < 1 || nprob > 4 || M <= 0 || M > 0x7fffffffL || K <= 0 || (K % 8) || K > 2048 || rows_per_b <= 0) return CXR_ERR_ARG;
     LoraOuterMArgs g;
     g.M = M; g.K = K; g.scale = scale;
     for (int q = 0; q < 4; ++q) {
@@ -452,11 +502,13 @@ extern "C" int cxr_lora_outer_multi_bf16(const cxr_lora_outer_desc* probs, int n
         d.drop.rows_per_b = rows_per_b; d.drop.t0 = tpos0;
     }
     const int nch = K / 8;
-    int RL = 256 / nch; RL = RL < 4 ? RL : 4;
-    long rpb = cdiv(M, 64); rpb = rpb < 4L * RL ? 4L * RL : rpb;
+    g.nchb = nch < 32 ? nch : 32;                                            // chunks per column block (8 row lanes at 32)
+    g.ncb = cdiv(nch, g.nchb);
+    const int RL = 256 / g.nchb;
+    long rpb = cdiv(M, 16); rpb = rpb < 4L * RL ? 4L * RL : rpb;
     g.rows_per_block = (int)rpb;
-    const size_t lds = (size_t)(RL - 1) * nch * 64 * sizeof(float);          // <= 48 KB: (RL - 1) * nch <= 192
-    CXR_LAUNCH(lora_outer_multi_kernel, dim3((unsigned)cdiv(M, rpb), nprob), dim3(256), lds, stream, g);
+    const size_t lds = (size_t)(RL - 1) * g.nchb * 64 * sizeof(float);        // <= 63.5 KB ((RL - 1) * nchb < 256)
+    CXR_LAUNCH(lora_outer_multi_kernel, dim3((unsigned)cdiv(M, rpb), nprob * g.ncb), dim3(256), lds, stream, g);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

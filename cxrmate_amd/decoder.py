@@ -28,6 +28,7 @@ SITE_EMBED = 1
 
 _CROSS_KV_FUSED = os.environ.get("CXR_CROSS_KV_FUSED", "1") != "0"      # A/B switch: 0 = one K / V GEMM per layer
 _LORA_IN_KERNEL = os.environ.get("CXR_LORA_IN_KERNEL", "1") != "0"        # A/B switch: 0 = separate LoRA down-projection launch per decode layer
+_CROSS_KV_SHARED = os.environ.get("CXR_CROSS_KV_SHARED", "1") != "0"      # A/B switch: 0 = per-layer cross K / V projections at prefill, projected again by the re-scoring pass
 _LORA_MULTI = os.environ.get("CXR_LORA_MULTI", "1") != "0"                # A/B switch: 0 = one launch per LoRA contraction in teacher-forced passes
 _SELF_QKV_FUSED = os.environ.get("CXR_SELF_QKV_FUSED", "1") != "0"      # A/B switch: 0 = separate query / key / value GEMMs
 _CROSS_WG_KEYS = int(os.environ.get("CXR_CROSS_WG_KEYS", "0"))          # cached cross-attention geometry (ops.attention_decode wg_keys)
@@ -51,6 +52,7 @@ class KVCache:
         self.v2 = [torch.empty((B, Tmax, D), dtype=BF16, device=device) for _ in range(layers)]
         self.ck = [None] * layers
         self.cv = [None] * layers
+        self.kv_all = None               # optional [B, S, 2 L D]: ck / cv of all layers as its column blocks (one projection GEMM at prefill)
         self.cpk = [None] * layers       # fragment-ordered cross-attention (K, V) of the studies (ops.pack_cross_kv): the MFMA cross-attention of the cached steps
         self.cross_ready = False         # ck/cv may be pre-allocated static buffers (graph replay): filled at prefill
         self.enc_bits = None             # optional: the encoder key-padding mask as bit words (ops.pack_mask_bits), read by the cached steps
@@ -203,10 +205,18 @@ class BertEngine:
             seed = self.s.next_dropout_seed()
         return ph, pa, seed
 
+    def cross_kv_fused(self):
+        """True when the cross-attention key / value projections of all layers are one [2 L D, D] matrix in storage order (CXR_CROSS_KV_SHARED=0: off)."""
+        return _CROSS_KV_SHARED and bool(self.cfg.add_cross_attention) and self._cross_kv_all() is not None
+
     def forward(self, ids, enc=None, enc_mask=None, attn_mask=None, token_type_ids=None, position_ids=None, save=False, causal=True,
-                lm_head=True, train=None, seed=None, logits_bf16=False, inputs_embeds=None):
+                lm_head=True, train=None, seed=None, logits_bf16=False, inputs_embeds=None, cross_kv=None, logit_from=0):
         """ids int64 [B,T]; enc bf16 [B,S,D] | None; masks uint8 (1 = attend). -> logits fp32 [B,T,V] (or hidden bf16 [B,T,D]), saved.
-        train (default: the store's nn.Module flag) enables dropout; seed: device int32 [1] to REPRODUCE the masks of an earlier pass."""
+        train (default: the store's nn.Module flag) enables dropout; seed: device int32 [1] to REPRODUCE the masks of an earlier pass.
+        cross_kv: [B, S, 2 L D] bf16, the cross-attention K / V of all layers already projected from THIS enc with the current weights (a decode
+        session's prefill): the projection GEMM is skipped; the backward is unchanged.
+        logit_from = t0 > 0: the LM head runs on positions t0 .. T-1 only -> logits [B, T - t0, V], contiguous (the SCST re-scoring pass scores the
+        sampled positions, not the prompt's; backward(dlogits=[B (T - t0), V]) then)."""
         cfg, st, p = self.cfg, self.s, self.p
         self.prepare()
         lora_tr = self._lora_train(train)
@@ -238,7 +248,11 @@ class BertEngine:
             if kva is not None:
                 # cross-attention K and V of every layer in one GEMM: [B*S, d] x [d, layers*2*d] (all layers project the same encoder output)
                 S_ = enc.shape[1]
-                kv_all = ops.gemm_nt(enc.reshape(B * S_, D), kva[0], bias=kva[1]).view(B, S_, -1)
+                if cross_kv is not None:
+                    assert cross_kv.shape == (B, S_, kva[0].shape[0]) and cross_kv.dtype == BF16 and cross_kv.is_contiguous()
+                    kv_all = cross_kv
+                else:
+                    kv_all = ops.gemm_nt(enc.reshape(B * S_, D), kva[0], bias=kva[1]).view(B, S_, -1)
                 if save:
                     saved["kv_all"] = True
 
@@ -316,10 +330,18 @@ class BertEngine:
             if save:
                 saved["h_out"] = h
             return h.view(B, T, D), saved
-        logits, hs = self._lm_head(h, save, logits_bf16)
+        t0 = int(logit_from)
+        if t0 > 0:
+            assert t0 < T
+            hl = torch.empty((B, T - t0, D), dtype=BF16, device=h.device)
+            ops.copy_rows(h.view(B, T, D)[:, t0:, :], hl)
+            hl = hl.view(B * (T - t0), D)
+        else:
+            hl = h
+        logits, hs = self._lm_head(hl, save, logits_bf16)
         if save:
-            saved.update(h_out=h, **hs)
-        return logits.view(B, T, -1), saved
+            saved.update(h_out=hl, logit_from=t0, **hs)
+        return logits.view(B, T - t0, -1), saved
 
     def _lm_head(self, h, save, logits_bf16=False):
         """BertLMPredictionHead (TF5:bert:466-496): dense -> GELU -> LayerNorm -> tied projection + bias; logits fp32 (API default) or bf16
@@ -410,10 +432,13 @@ class BertEngine:
             c = p + "cls.predictions."
             V = cfg.vocab_size
             Vp = ((V + 63) // 64) * 64
+            t0 = int(saved.get("logit_from", 0))
+            Rl = B * (T - t0)                                                    # rows the LM head ran on (forward(logit_from=))
+            assert dlogits.shape[0] == Rl, (dlogits.shape, Rl)
             if dlogits.stride(0) >= Vp and dlogits.stride(0) % 8 == 0:
-                dlp = dlogits.as_strided((R, Vp), (dlogits.stride(0), 1))        # padded columns are zero by construction (ops.softmax_ce)
+                dlp = dlogits.as_strided((Rl, Vp), (dlogits.stride(0), 1))       # padded columns are zero by construction (ops.softmax_ce)
             else:
-                dlp = torch.zeros((R, Vp), dtype=BF16, device=dlogits.device)
+                dlp = torch.zeros((Rl, Vp), dtype=BF16, device=dlogits.device)
                 ops.copy_rows(dlogits.unsqueeze(0), dlp[:, :V].unsqueeze(0))
             word = st.w16(p + "bert.embeddings.word_embeddings.weight")
             ops.gemm_tn(dlp[:, :V], saved["tn"], g(p + "bert.embeddings.word_embeddings.weight"), dbias=g(c + "bias"))
@@ -423,6 +448,10 @@ class BertEngine:
             dtu = ops.gelu_bwd(dt, saved["tu"])
             ops.linear_bwd_weight(dtu, saved["h_out"], g(c + "transform.dense.weight"), g(c + "transform.dense.bias"))
             dh = ops.gemm_nt(dtu, self._prep[("wt", c + "transform.dense")])
+            if t0 > 0:                                                           # positions in front of t0 fed no logit: zero gradient there
+                dfull = torch.zeros((B, T, D), dtype=BF16, device=dh.device)
+                ops.copy_rows(dh.view(B, T - t0, D), dfull[:, t0:, :])
+                dh = dfull.view(R, D)
         else:
             dh = dhidden
         denc = None
@@ -615,11 +644,16 @@ class BertEngine:
             if cfg.add_cross_attention and enc is not None:
                 Be, S = enc.shape[0], enc.shape[1]          # Be == B, or B/2 when two decodes of the same studies share the encoder rows
                 if cache.ck[l] is None or (not cache.cross_ready and past == 0):
-                    ck, cbk = self._lin(lp + "crossattention.self.key"); cv, cbv = self._lin(lp + "crossattention.self.value")
-                    okb = cache.ck[l].view(Be * S, D) if cache.ck[l] is not None else None
-                    ovb = cache.cv[l].view(Be * S, D) if cache.cv[l] is not None else None
-                    cache.ck[l] = ops.gemm_nt(enc.reshape(Be * S, D), ck, bias=cbk, out=okb).view(Be, S, D)
-                    cache.cv[l] = ops.gemm_nt(enc.reshape(Be * S, D), cv, bias=cbv, out=ovb).view(Be, S, D)
+                    if cache.kv_all is not None:
+                        if l == 0:                                       # K / V of every layer in one GEMM; ck / cv are its column blocks
+                            kva = self._cross_kv_all()
+                            ops.gemm_nt(enc.reshape(Be * S, D), kva[0], bias=kva[1], out=cache.kv_all.view(Be * S, -1))
+                    else:
+                        ck, cbk = self._lin(lp + "crossattention.self.key"); cv, cbv = self._lin(lp + "crossattention.self.value")
+                        okb = cache.ck[l].view(Be * S, D) if cache.ck[l] is not None else None
+                        ovb = cache.cv[l].view(Be * S, D) if cache.cv[l] is not None else None
+                        cache.ck[l] = ops.gemm_nt(enc.reshape(Be * S, D), ck, bias=cbk, out=okb).view(Be, S, D)
+                        cache.cv[l] = ops.gemm_nt(enc.reshape(Be * S, D), cv, bias=cbv, out=ovb).view(Be, S, D)
                     if _CROSS_MFMA and ops.attention_cross_mfma_ok(B, Be, S):      # the cached steps read fragment-ordered copies (one launch per decode and layer)
                         keep = cache.cpk[l] if (cache.cpk[l] is not None and cache.cpk[l][0].numel() == Be * S * D) else None
                         cache.cpk[l] = ops.pack_cross_kv(cache.ck[l], cache.cv[l], nh, out=keep)

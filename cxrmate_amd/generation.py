@@ -36,8 +36,15 @@ class DecodeSession:
         self.enc_bits = torch.zeros((B, (S + 31) // 32), dtype=torch.int32, device=dev) if has_mask else None      # the same mask as bit words (decode kernels)
         self.cache = model._dec.new_cache(rows, Lmax, dev)
         L = model.config.decoder.num_hidden_layers
-        self.cache.ck = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
-        self.cache.cv = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
+        if model._dec.cross_kv_fused():
+            # cross-attention K / V of ALL layers as the column blocks of one [B, S, 2 L D] buffer: ONE projection GEMM at prefill, and the
+            # teacher-forced re-scoring pass of an SCST step reads the same buffer instead of projecting the encoder output again
+            self.cache.kv_all = torch.empty((B, S, 2 * L * D), dtype=torch.bfloat16, device=dev)
+            self.cache.ck = [self.cache.kv_all[:, :, 2 * l * D:(2 * l + 1) * D] for l in range(L)]
+            self.cache.cv = [self.cache.kv_all[:, :, (2 * l + 1) * D:(2 * l + 2) * D] for l in range(L)]
+        else:
+            self.cache.ck = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
+            self.cache.cv = [torch.empty((B, S, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
         if ops.attention_cross_mfma_ok(rows, B, S):             # static fragment-ordered K / V copies (captured by the step graphs)
             self.cache.cpk = [(torch.empty(B * S * D, dtype=torch.bfloat16, device=dev), torch.empty(B * S * D, dtype=torch.bfloat16, device=dev)) for _ in range(L)]
         self.seed = torch.zeros(1, dtype=torch.int32, device=dev)     # dropout seed of the running decode (train mode); graphs read it
@@ -381,6 +388,8 @@ class GenerationMixin:
             mode = (kind, special, mask_token_id, int(top_k or 0), float(temperature), eos_token_id, pad_token_id, bool(self.training), float(top_p))
             if rec is not None:
                 rec["seed"] = ses.seed.clone() if self.training else None
+                # the session's cross-attention K / V of every layer (valid until the session's next decode) and the weight version they belong to
+                rec["cross_kv"] = None if ses.cache.kv_all is None else (ses.cache.kv_all, tuple(ses.enc16.shape), self._weights_stamp())
             cur = prompt_len
             first_tt = first_pos = None
             poll = None                      # (pinned host word, event): "any row unfinished?" as of the PREVIOUS poll -- read without stalling the queue
@@ -425,6 +434,18 @@ class GenerationMixin:
         return out
 
     @torch.no_grad()
+    def _weights_stamp(self):
+        """Changes whenever the decoder weights may have: the bf16 shadow's version (fused AdamW) and the fp32 master's autograd version (torch edits)."""
+        return (getattr(self, "shadow_version", 0), self.flat32._version)
+
+    def _session_cross_kv(self, rec, enc):
+        """The cross-attention K / V of all layers a decode session projected at prefill (rec["cross_kv"]), if they still belong to `enc`'s shape and
+        to the current weights -- the teacher-forced re-scoring pass of the same SCST step then skips its own projection GEMM. Else None."""
+        ckv = rec.get("cross_kv") if rec else None
+        if ckv is None or ckv[1] != tuple(enc.shape) or ckv[2] != self._weights_stamp():
+            return None
+        return ckv[0]
+
     def sample_and_greedy(self, encoder_outputs, prompt_ids, special_sample, special_greedy, mask_token_id, max_length, bos_token_id,
                           eos_token_id, pad_token_id, top_k=50, temperature=1.0, top_p=1.0):
         """The two decodes of one SCST step (reference scst/gt_prompt.py:162-180 sample, :94-112 greedy baseline) as ONE batch of 2B
@@ -446,7 +467,8 @@ class GenerationMixin:
         rec = {"tt": [], "pos": []}
         out = self._generate_session(torch.cat([ids, ids], dim=0), enc16, enc_mask8, (special_sample, special_greedy), mask_token_id,
                                      max_length, bos_token_id, eos_token_id, pad_token_id, "pair", top_k, temperature, rec, top_p=top_p)
-        rec = {"tt": [t[:B] for t in rec["tt"]], "pos": [None if p_ is None else p_[:B] for p_ in rec["pos"]], "seed": rec.get("seed")}
+        rec = {"tt": [t[:B] for t in rec["tt"]], "pos": [None if p_ is None else p_[:B] for p_ in rec["pos"]], "seed": rec.get("seed"),
+               "cross_kv": rec.get("cross_kv")}
 
         def trim(seq):                                   # each half ends where ITS last row finished (HF stops per generate() call)
             if eos_token_id is None:
@@ -471,7 +493,8 @@ class GenerationMixin:
         tt = torch.cat(rec["tt"][:n_new], dim=1)
         pos = torch.cat(rec["pos"][:n_new], dim=1) if rec["pos"][0] is not None else None
         mask = (tf_in != mask_token_id).to(torch.uint8) if self.kind == "longitudinal" else None
-        logits = self._decode_tf(tf_in, enc, None if self.kind == "single" else enc_mask, mask, tt, pos, seed=rec.get("seed"))
+        logits = self._decode_tf(tf_in, enc, None if self.kind == "single" else enc_mask, mask, tt, pos, seed=rec.get("seed"),
+                                 cross_kv=self._session_cross_kv(rec, enc))
         first = prompt_len - stripped - 1
         sc = logits[:, first:, :]
         if temperature is not None and float(temperature) != 1.0:

@@ -89,7 +89,10 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         enc = eo.last_hidden_state
         enc_mask = eo.attention_mask.to(torch.uint8).contiguous()
         # train mode: the same dropout seed as the cached sampling decode -> the re-scored network IS the one that sampled
-        logits, saved = model._dec.forward(tf_in, enc.contiguous(), enc_mask, mask, tt, pos, save=True, seed=rec.get("seed"))
+        # the decode session projected the cross-attention K / V of all layers from this encoder output at prefill: the re-scoring pass reads them
+        # (the LM head runs on the n_new sampled positions only: logits [B, n_new, V], contiguous)
+        logits, saved = model._dec.forward(tf_in, enc.contiguous(), enc_mask, mask, tt, pos, save=True, seed=rec.get("seed"),
+                                           cross_kv=model._session_cross_kv(rec, enc), logit_from=P - 1)
 
         # reward of the sampled and of the greedy reports. A reward_fn with `.pair(sampled, greedy)` scores both in ONE pass (one tokenizer call,
         # one 2B-row CXR-BERT forward: the two B-row forwards of a BERT-base are launch-bound, ~2.6 ms each)
@@ -105,20 +108,17 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         # data parallel: the sampled / greedy sequences and their rewards of ALL ranks (RCCL all-gather over xGMI, <= 64 KB per rank) for the
         # global reward / baseline statistics the step reports; the advantage above stays per study, as in the reference (gt_prompt.py:129-132)
         glob = dp.gather_scst_statistics(sampled, base[:, P:].contiguous(), reward, baseline, pad, max_sampled=decoder_max_len, max_greedy=decoder_max_len)
-        B, T, V = logits.shape
-        sc = logits[:, P - 1:, :]                                            # scores of the n_new sampling steps
+        B, _, V = logits.shape                                               # scores of the n_new sampling steps
         if float(temperature) != 1.0:
             raise NotImplementedError("temperature != 1 (the reference trains with 1.0)")
-        flat = sc.reshape(-1, V) if sc.is_contiguous() else sc.contiguous().view(-1, V)
+        flat = logits.view(-1, V)
         thr = ops.topk_threshold(flat, int(top_k or 0), top_p, temperature) if (top_k or top_p < 1.0) else None
         labels = sampled.reshape(-1)
         w = ops.ce_weights(labels, pad, mode=1, reward=adv, T=n_new)
         loss, _, dl = ops.softmax_ce(flat, labels, pad, w, thr=thr)
-        full = torch.zeros((B, T, dl.shape[1]), dtype=dl.dtype, device=dev)
-        full[:, P - 1:, :] = dl.view(B, n_new, -1)
         from .training import wgrad_overlap
         with wgrad_overlap():                                                # weight-gradient GEMMs beside the dX chain, as in the TF step
-            model._dec.backward(saved, dlogits=full.view(B * T, -1), need_denc=False)
+            model._dec.backward(saved, dlogits=dl, need_denc=False)
             ops.wgrad_join()
         world = dp.world_size()
         if dp.active():

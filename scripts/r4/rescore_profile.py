@@ -48,18 +48,16 @@ with torch.no_grad():
     mask = (tf_in != 4).to(torch.uint8)
     enc, em = eo.last_hidden_state.contiguous(), eo.attention_mask.to(torch.uint8).contiguous()
 
-    def rescore():
+    def rescore():                                            # as scst.scst_step: K / V of the session's prefill, LM head on the sampled positions only
         opt.zero_grad()
-        logits, saved = m._dec.forward(tf_in, enc, em, mask, tt, pos, save=True, seed=rec["seed"])
-        Bq, Tq, V = logits.shape
-        flat = logits[:, P - 1:, :].contiguous().view(-1, V)
+        logits, saved = m._dec.forward(tf_in, enc, em, mask, tt, pos, save=True, seed=rec["seed"], cross_kv=m._session_cross_kv(rec, enc), logit_from=P - 1)
+        Bq, _, V = logits.shape
+        flat = logits.view(-1, V)
         thr = ops.topk_threshold(flat, 50)
         labels = s2[:, P:].reshape(-1)
         w = ops.ce_weights(labels, 4, mode=1, reward=torch.ones(Bq, device=dev), T=n_new)
         loss, _, dl = ops.softmax_ce(flat, labels, 4, w, thr=thr)
-        full = torch.zeros((Bq, Tq, dl.shape[1]), dtype=dl.dtype, device=dev)
-        full[:, P - 1:, :] = dl.view(Bq, n_new, -1)
-        m._dec.backward(saved, dlogits=full.view(Bq * Tq, -1), need_denc=False)
+        m._dec.backward(saved, dlogits=dl, need_denc=False)
         ops.wgrad_join()
     torch.cuda.synchronize()
     T("re-score: TF fwd + REINFORCE loss + decoder bwd", rescore, 10)

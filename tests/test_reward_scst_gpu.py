@@ -205,6 +205,29 @@ def test_fused_sample_and_greedy_decode(cuda):
     with torch.no_grad():
         lg, _ = m._dec.forward(tf_in, eo.last_hidden_state.contiguous(), eo.attention_mask.to(torch.uint8).contiguous(),
                                (tf_in != gu.PAD).to(torch.uint8), tt, pos)
+    # the session projected the cross-attention K / V of all layers in one GEMM at prefill; the re-scoring pass reads that buffer instead of projecting
+    # the encoder output again: same logits bit for bit, same parameter gradients, and a stale buffer (other weights / another batch shape) is refused
+    enc16, em8 = eo.last_hidden_state.contiguous(), eo.attention_mask.to(torch.uint8).contiguous()
+    ckv = m._session_cross_kv(rec, enc16)
+    assert ckv is not None and ckv.shape == (enc16.shape[0], enc16.shape[1], 2 * cfg.decoder.num_hidden_layers * cfg.decoder.hidden_size)
+    with torch.no_grad():
+        lg2, _ = m._dec.forward(tf_in, enc16, em8, (tf_in != gu.PAD).to(torch.uint8), tt, pos, cross_kv=ckv)
+    assert torch.equal(lg, lg2)
+    grads = []
+    for use in (None, ckv):
+        m.zero_grads_prefix("decoder.")
+        lgs, saved = m._dec.forward(tf_in, enc16, em8, (tf_in != gu.PAD).to(torch.uint8), tt, pos, save=True, cross_kv=use)
+        dl = torch.zeros_like(lgs, dtype=torch.bfloat16)
+        dl[:, :, 7] = 1.0
+        m._dec.backward(saved, dlogits=dl.view(-1, dl.shape[-1]), need_denc=False)
+        ops_ = __import__("cxrmate_amd.ops", fromlist=["x"])
+        ops_.wgrad_join()
+        torch.cuda.synchronize()
+        grads.append(m.gflat.clone())
+    assert torch.allclose(grads[0], grads[1], rtol=1e-5, atol=1e-7)
+    assert m._session_cross_kv(rec, enc16[:1]) is None
+    m.flat32.add_(0.0)                                                         # any in-place torch edit of the weights moves the stamp
+    assert m._session_cross_kv(rec, enc16) is None
     sc = lg[:, P - 1:, :].float()
     new = fed[:, P:]
     kth = sc.topk(6, dim=-1).values[..., -1]                                   # one rank of slack for bf16 cached-vs-TF differences
