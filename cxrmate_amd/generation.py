@@ -493,10 +493,11 @@ class GenerationMixin:
         tt = torch.cat(rec["tt"][:n_new], dim=1)
         pos = torch.cat(rec["pos"][:n_new], dim=1) if rec["pos"][0] is not None else None
         mask = (tf_in != mask_token_id).to(torch.uint8) if self.kind == "longitudinal" else None
-        logits = self._decode_tf(tf_in, enc, None if self.kind == "single" else enc_mask, mask, tt, pos, seed=rec.get("seed"),
-                                 cross_kv=self._session_cross_kv(rec, enc))
+        # the LM head runs on the sampled positions only: sc [B, n_new, V] is the (contiguous) output itself, and its gradient goes back as it is --
+        # a slice of full-length logits costs a 490-MB zero fill + copy in backward at the benchmark shape
         first = prompt_len - stripped - 1
-        sc = logits[:, first:, :]
+        sc = self._decode_tf(tf_in, enc, None if self.kind == "single" else enc_mask, mask, tt, pos, seed=rec.get("seed"),
+                             cross_kv=self._session_cross_kv(rec, enc), logit_from=first)
         if temperature is not None and float(temperature) != 1.0:
             sc = sc / float(temperature)
         if top_k or top_p < 1.0:

@@ -227,9 +227,10 @@ class _EncodeFn(torch.autograd.Function):
 
 class _DecodeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, enc, enc_mask, ids, attn_mask, tt, pos, seed, embeds, cross_kv, *params):
+    def forward(ctx, model, enc, enc_mask, ids, attn_mask, tt, pos, seed, embeds, cross_kv, logit_from, *params):
         model._settle_owed_join()
-        logits, saved = model._dec.forward(ids, enc, enc_mask, attn_mask, tt, pos, save=True, seed=seed, inputs_embeds=embeds, cross_kv=cross_kv)
+        logits, saved = model._dec.forward(ids, enc, enc_mask, attn_mask, tt, pos, save=True, seed=seed, inputs_embeds=embeds, cross_kv=cross_kv,
+                                           logit_from=logit_from)
         ctx.model, ctx.saved, ctx.nparams = model, saved, len(params)
         ctx.need_denc = enc is not None and enc.requires_grad
         ctx.embeds_like = embeds if (embeds is not None and embeds.requires_grad) else None
@@ -256,8 +257,8 @@ class _DecodeFn(torch.autograd.Function):
             d_emb = ctx.saved["d_embeds"].view(ctx.embeds_like.shape).to(ctx.embeds_like.dtype)
         ctx.saved = None
         if bound:
-            return (None, denc, None, None, None, None, None, None, d_emb, None) + model._bind_grads("decoder.", ctx.nparams)
-        return (None, denc, None, None, None, None, None, None, d_emb, None) + model._collect_grads("decoder.", ctx.nparams)
+            return (None, denc, None, None, None, None, None, None, d_emb, None, None) + model._bind_grads("decoder.", ctx.nparams)
+        return (None, denc, None, None, None, None, None, None, d_emb, None, None) + model._collect_grads("decoder.", ctx.nparams)
 
 
 # ---------------------------------------------------------------------------------------------------- sub-modules
@@ -625,7 +626,7 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
             return None
         return t.to(device=device, dtype=torch.int64).contiguous()
 
-    def _decode_tf(self, ids, enc, enc_mask, attn_mask, tt, pos, seed=None, embeds=None, cross_kv=None):
+    def _decode_tf(self, ids, enc, enc_mask, attn_mask, tt, pos, seed=None, embeds=None, cross_kv=None, logit_from=0):
         dev = self.device
         ids, tt, pos = self._i64(ids, dev), self._i64(tt, dev), self._i64(pos, dev)
         if embeds is not None:
@@ -635,8 +636,9 @@ class _CXREncoderDecoderBase(ParamStore, GenerationMixin, TokenHelpers):
         enc = enc.contiguous()
         params = [p for _, p in self._grad_params("decoder.")]
         if torch.is_grad_enabled() and (params or enc.requires_grad or (embeds is not None and embeds.requires_grad)):
-            return _DecodeFn.apply(self, enc, enc_mask, ids, attn_mask, tt, pos, seed, embeds, cross_kv, *params)
-        logits, _ = self._dec.forward(ids, enc, enc_mask, attn_mask, tt, pos, save=False, seed=seed, inputs_embeds=embeds, cross_kv=cross_kv)
+            return _DecodeFn.apply(self, enc, enc_mask, ids, attn_mask, tt, pos, seed, embeds, cross_kv, int(logit_from), *params)
+        logits, _ = self._dec.forward(ids, enc, enc_mask, attn_mask, tt, pos, save=False, seed=seed, inputs_embeds=embeds, cross_kv=cross_kv,
+                                      logit_from=logit_from)
         return logits
 
 
