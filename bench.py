@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 # algorithmic work: forward FLOPs, training = 3x forward for trainable parts
 ENC_FWD_GF_PER_IMAGE = 50.04
 MFMA_BF16_PEAK_TF = 2500.0
+MFMA_FP8_PEAK_TF = 5000.0        # dense e4m3 (MI355X_MICROARCH.md; not the 2:1-sparsity headline)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -233,7 +234,13 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
     if c5:
         return {"metric": "scst_steps_per_sec", "value": world * steps / dt, "unit": "steps/s (16 studies x 3 images per GPU per step; all GPUs)",
                 "steps": steps, "ms_per_step": dt / steps * 1e3, "studies_per_sec": world * B * steps / dt, "new_tokens_sampled_and_greedy": n_tok,
-                "prompt_tokens": int(prompt.shape[1]), "encoder_forward_ms": enc_ms, "decode_ms_per_step": dec_ms,
+                "prompt_tokens": int(prompt.shape[1]), "encoder_forward_ms": enc_ms,
+                "encoder_roofline": {"bound": "mfma", "kernel": "frozen CvT-21 forward, 99.5 % of its MACs in gemm_fp8_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3)",
+                                     "achieved": ENC_FWD_GF_PER_IMAGE * enc_ms["images"] / enc_ms["e4m3"], "peak": MFMA_FP8_PEAK_TF, "unit": "TFLOP/s",
+                                     "frac": ENC_FWD_GF_PER_IMAGE * enc_ms["images"] / enc_ms["e4m3"] / MFMA_FP8_PEAK_TF,
+                                     "bf16_achieved": ENC_FWD_GF_PER_IMAGE * enc_ms["images"] / enc_ms["bf16"],
+                                     "what": "algorithmic encoder FLOPs (BASELINE.md section 2) of the step's 48 images / HIP-event time of the forward, train-mode BatchNorm"},
+                "decode_ms_per_step": dec_ms,
                 "us_per_token_step": dec_ms * 1e3 / n_tok, "loss": float(out["loss"].item()),
                 "workload": "BASELINE.json configs[4] per-GPU shape: 16 studies x 3 images, 128-token prior-report prompt, frozen encoder with e4m3 "
                             "(OCP) MFMA linear layers (static per-tensor scales), sample + greedy as one 32-row cached decode, REINFORCE + AdamW; "
@@ -257,7 +264,7 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
                          "traffic_source": decode_traffic()[1], "algorithmic_bytes_per_token_step": step_bytes,
                          "decode_ms_per_step": dec_ms, "us_per_token_step": dec_ms * 1e3 / n_tok,
                          "decode_share_of_step": dec_ms / (dt / steps * 1e3),
-                         "profile": "profiles/r03_scst_decode_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/scst_decode_profile.py)"}}
+                         "profile": "profiles/r04_scst_decode_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/scst_decode_profile.py)"}}
 
 
 def beam_bench(args, dev, host_loop_too=True):
@@ -606,7 +613,7 @@ def main():
     ms_per_step, tokens_per_s = main_res["ms_per_step"], main_res["tokens_per_s"]
     gm = main_res["gemm"]
     traffic, traffic_src = None, None                        # HBM-side bytes per launch from the committed PMC passes (cannot be collected live)
-    for name in ("r03_pmc_tf_hbm_traffic.json", "r02_pmc_tf_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for name in ("r04_pmc_tf_hbm_traffic.json", "r03_pmc_tf_hbm_traffic.json", "r02_pmc_tf_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             traffic = pmc["gemm_nt"]["hbm_bytes_per_launch"]
