@@ -125,6 +125,7 @@ def _phase_encbwd(model, esaved, denc, on_stage_done=None):
 
 _ZERO_ON_SIDE = os.environ.get("CXR_ZERO_ON_SIDE", "1") != "0"              # A/B switch: 0 = gradient zeroing on the main stream
 _EARLY_DEC_ADAMW = os.environ.get("CXR_EARLY_DEC_ADAMW", "1") != "0"      # A/B switch: 0 = one AdamW launch at the end of the step
+_EARLY_ENC_ADAMW = os.environ.get("CXR_EARLY_ENC_ADAMW", "1") != "0"      # A/B switch: 0 = the whole encoder range updated at the end of the step
 _BF16_LOGITS = os.environ.get("CXR_BF16_LOGITS", "1") != "0"      # training step: bf16 logits as under the reference's autocast (0: fp32)
 
 
@@ -206,12 +207,27 @@ def _tf_train_step(model, opt, pixel_values, decoder_input_ids, decoder_attentio
         side.wait_stream(torch.cuda.current_stream())              # every decoder dX kernel (they read the weights) is in front of the update
         with torch.cuda.stream(side):
             opt.step(gscale=gscale, lo_bound=opt.split, begin=True, finish=False)
+    enc_hi = opt.split
+    if dec_early and _EARLY_ENC_ADAMW and opt.enc_tail:
+        # ... and the encoder's last stage + projection head (29 of its 31 M parameters) the same way, as soon as that stage's backward has been issued:
+        # its update runs on the weight-gradient stream under the backward of the earlier stages, which read none of its weights
+        last_lo, last_hi = opt.stage_range(opt.enc_last_stage)
+
+        def early(s):
+            nonlocal enc_hi
+            if s == opt.enc_last_stage and last_lo > 0:
+                ops.wgrad_flush()
+                ops.wgrad_reduce()
+                side.wait_stream(torch.cuda.current_stream())      # the stage's dX kernels (weight readers) and main-stream parameter-gradient writers
+                with torch.cuda.stream(side):
+                    opt.step(gscale=gscale, lo_bound=last_lo, hi_bound=last_hi, begin=False, finish=False)
+                enc_hi = last_lo
     _phase_encbwd(model, esaved, denc, early)
     if sync:
         opt.reducer.reduce_range(0, opt.split if enc_trainable else model._param_total)      # whatever has not been started yet
         opt.reducer.wait()
     if dec_early:
-        opt.step(gscale=gscale, hi_bound=opt.split, begin=False, finish=True)
+        opt.step(gscale=gscale, hi_bound=enc_hi, begin=False, finish=True)
     else:
         opt.step(gscale=gscale)
     return loss

@@ -390,8 +390,9 @@ def test_early_decoder_adamw_equals_the_single_update(M, monkeypatch):
     from cxrmate_amd import training
     g, cfg, sd, x, inp, lab, am, tt = gu.tf_single_case()
     out = {}
-    for early in (True, False):
-        monkeypatch.setattr(training, "_EARLY_DEC_ADAMW", early)
+    for early in (True, "decoder only", False):                     # True: the decoder's range AND the encoder's last stage + head are updated early
+        monkeypatch.setattr(training, "_EARLY_DEC_ADAMW", bool(early))
+        monkeypatch.setattr(training, "_EARLY_ENC_ADAMW", early is True)
         m = M.SingleCXREncoderDecoderModel(cfg, seed=None)
         m.load_state_dict(sd)
         m.eval()                                                    # no dropout seeds: the two runs see the same network
@@ -400,12 +401,15 @@ def test_early_decoder_adamw_equals_the_single_update(M, monkeypatch):
         losses = [float(training.tf_train_step(m, opt, x.cuda(), inp.cuda(), am.cuda(), ttd, lab.cuda(), gu.PAD)) for _ in range(3)]
         torch.cuda.synchronize()
         out[early] = (losses, m.flat32.clone(), opt.m.clone(), opt.v.clone(), opt.t)
-    assert out[True][4] == out[False][4] == 3
-    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-4)
+    assert out[True][4] == out["decoder only"][4] == out[False][4] == 3
     assert out[True][0][-1] < out[True][0][0]
-    for a, b in zip(out[True][1:4], out[False][1:4]):
-        err = float((a - b).norm() / b.norm())
-        assert err < 1e-4, err
+    for mode in (True, "decoder only"):
+        np.testing.assert_allclose(out[mode][0], out[False][0], rtol=1e-4)
+        for a, b in zip(out[mode][1:4], out[False][1:4]):
+            err = float((a - b).norm() / b.norm())
+            assert err < 1e-4, (mode, err)
+    lo, hi = training.FusedAdamW.stage_range(opt, opt.enc_last_stage)          # the early-updated encoder range is not empty in this configuration
+    assert 0 < lo < hi <= opt.split
 
 
 def _hash_masks(m, cfg, B, T, S, enc_seed, dec_seed, Bn):
