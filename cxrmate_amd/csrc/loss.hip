@@ -333,17 +333,55 @@ __device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float((o &
 // (Round 4, measured and removed: one LDS atomic per distinct bin of a wave -- ballot / readlane loop over the 3-6 bins the leading digits of a row of
 // logits fall into -- instead of one per element: topk_threshold_kernel on 4080 x 30000 went from 515 to 1035 us. Same-address LDS atomics of a wave are
 // not what the first radix pass costs.)
+constexpr int KTH_CAP = 2048;            // candidates (ordered keys) kept in LDS after the second radix pass
+
 __device__ float kth_largest(const float* __restrict__ x, int V, int k, unsigned* hist /*[256]*/, unsigned* bcast /*[2]*/) {
+    // Exact k-th largest value of a row: MSD radix select on the order-preserving key, 8 bits per pass. The first two passes scan the row (16-byte
+    // loads, two per thread in flight: with one 4-byte load per trip and the LDS atomic behind it every trip was one exposed memory round trip --
+    // 515 us for the 4080 x 30000 scores of an SCST re-scoring pass); the second one also keeps the keys that share the leading digit in LDS, and
+    // the last two passes read that list (a few hundred entries for k = 50 of 30000) instead of the row. 515 -> 369 (loads) -> see profiles/.
+    __shared__ unsigned cand[KTH_CAP];
+    __shared__ unsigned ncand;
     unsigned prefix = 0u, mask = 0u;
     int remaining = k;
+    const bool vec = (V & 3) == 0 && ((size_t)x & 15) == 0;
+    bool listed = false;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
         __syncthreads();
         hist[threadIdx.x] = 0u;
+        if (pass == 1 && threadIdx.x == 0) ncand = 0u;
         __syncthreads();
-        for (int v = threadIdx.x; v < V; v += 256) {
-            const unsigned o = f2ord(x[v]);
-            if ((o & mask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1u);
+        if (listed) {
+            const int n = (int)ncand;
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const unsigned o = cand[i];
+                if ((o & mask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1u);
+            }
+        } else if (vec) {
+            const float4* x4 = reinterpret_cast<const float4*>(x);
+            const int n4 = V >> 2;
+            for (int i0 = 0; i0 < n4; i0 += 512) {
+                const int ia = i0 + threadIdx.x, ib = ia + 256;
+                const float4 fa = x4[ia < n4 ? ia : n4 - 1], fb = x4[ib < n4 ? ib : n4 - 1];
+                const float e[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned o = f2ord(e[j]);
+                    if ((j < 4 ? ia : ib) < n4 && (o & mask) == prefix) {
+                        atomicAdd(&hist[(o >> shift) & 255u], 1u);
+                        if (pass == 1) { const unsigned c = atomicAdd(&ncand, 1u); if (c < (unsigned)KTH_CAP) cand[c] = o; }
+                    }
+                }
+            }
+        } else {
+            for (int v = threadIdx.x; v < V; v += 256) {
+                const unsigned o = f2ord(x[v]);
+                if ((o & mask) == prefix) {
+                    atomicAdd(&hist[(o >> shift) & 255u], 1u);
+                    if (pass == 1) { const unsigned c = atomicAdd(&ncand, 1u); if (c < (unsigned)KTH_CAP) cand[c] = o; }
+                }
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -355,6 +393,7 @@ __device__ float kth_largest(const float* __restrict__ x, int V, int k, unsigned
         prefix |= bcast[0] << shift;
         mask |= 255u << shift;
         remaining -= (int)bcast[1];
+        if (pass == 1) listed = ncand <= (unsigned)KTH_CAP;          // (block-uniform: read after the barrier)
     }
     return ord2f(prefix);
 }

@@ -1404,6 +1404,17 @@ def test_softmax_ce_and_reinforce(ops):
     thr = ops.topk_threshold(logits, k)
     kth = torch.topk(logits, k)[0][:, -1]
     assert torch.equal(thr, kth)
+    # the radix select keeps the keys that share the two leading digits in LDS (2048 entries) for its last two passes: rows whose values ALL share them
+    # (every entry in [1, 1.0039): 30000 candidates) overflow the list and take the full scans; ragged widths take the 4-byte-load path; ties at the
+    # k-th value; k = 1 and k = V - 1
+    tight = dev(1.0 + rnd(4, V, seed=12).abs() * 1e-3)
+    assert torch.equal(ops.topk_threshold(tight, k), torch.topk(tight, k)[0][:, -1])
+    ragged = logits[:, :V - 3]
+    assert torch.equal(ops.topk_threshold(ragged, k), torch.topk(ragged, k)[0][:, -1])
+    ties = logits.clone(); ties[:, 100:180] = 9.5
+    assert torch.equal(ops.topk_threshold(ties, k), torch.topk(ties, k)[0][:, -1])
+    for kk in (1, 2048, 2049, V - 1):
+        assert torch.equal(ops.topk_threshold(logits, kk), torch.topk(logits, kk)[0][:, -1]), kk
     sampled = torch.topk(logits, k)[1][:, 7].clone()
     sampled[4] = 4
     reward = torch.tensor([0.3, -0.2, 0.9]).cuda()
