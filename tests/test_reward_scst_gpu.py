@@ -225,6 +225,24 @@ def test_fused_sample_and_greedy_decode(cuda):
         torch.cuda.synchronize()
         grads.append(m.gflat.clone())
     assert torch.allclose(grads[0], grads[1], rtol=1e-5, atol=1e-7)
+    # the LM head on positions t0 .. T-1 only (the re-scoring pass scores the sampled positions, not the prompt's): the logits ARE the slice of the full
+    # ones, and a gradient that is zero in front of t0 gives the same parameter gradients either way
+    t0 = P - 1
+    with torch.no_grad():
+        lg3, _ = m._dec.forward(tf_in, enc16, em8, (tf_in != gu.PAD).to(torch.uint8), tt, pos, logit_from=t0)
+    assert lg3.is_contiguous() and torch.equal(lg3, lg[:, t0:, :])
+    gsl = []
+    for frm in (0, t0):
+        m.zero_grads_prefix("decoder.")
+        lgs, saved = m._dec.forward(tf_in, enc16, em8, (tf_in != gu.PAD).to(torch.uint8), tt, pos, save=True, logit_from=frm)
+        dl = torch.zeros_like(lgs, dtype=torch.bfloat16)
+        dl[:, (t0 - frm):, 7] = 1.0
+        dl[:, (t0 - frm):, 11] = -0.5
+        m._dec.backward(saved, dlogits=dl.view(-1, dl.shape[-1]), need_denc=False)
+        ops_.wgrad_join()
+        torch.cuda.synchronize()
+        gsl.append(m.gflat.clone())
+    assert torch.allclose(gsl[0], gsl[1], rtol=1e-4, atol=1e-6), float((gsl[0] - gsl[1]).abs().max())
     assert m._session_cross_kv(rec, enc16[:1]) is None
     m.flat32.add_(0.0)                                                         # any in-place torch edit of the weights moves the stamp
     assert m._session_cross_kv(rec, enc16) is None
