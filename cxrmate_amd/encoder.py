@@ -19,6 +19,9 @@ from . import ops
 from .config import CvtConfig
 
 
+_EARLY_PATCH_COL = os.environ.get("CXR_EARLY_PATCH_COL", "1") != "0"      # A/B switch: 0 = the pixel im2col matrix of the backward is built at the end of the step, 1 = during the forward pass
+
+
 class CvtEncoderEngine:
     def __init__(self, store, cfg: CvtConfig, prefix: str = "encoder."):
         self.s, self.cfg, self.p = store, cfg, prefix
@@ -260,6 +263,12 @@ class CvtEncoderEngine:
                 xs = torch.empty((Bn, (px.shape[2] // 4) * (px.shape[3] // 4), C), dtype=torch.bfloat16, device=px.device)
                 _, e, estats, Ho, Wo = ops.patch_embed_s1(px, prep[("embed_pk", 0)], st.f32(ep + "projection.bias"), st.f32(ep + "normalization.weight"),
                                                           st.f32(ep + "normalization.bias"), cfg.inner_layer_norm_eps, need_e=save, out=xs.view(-1, C))
+                if save and _EARLY_PATCH_COL and ops.WGRAD_STREAM is not None:
+                    # the im2col matrix of the PIXELS feeds the very last weight-gradient GEMM of the step; built where that GEMM is issued, its 100 us
+                    # sit in the tail of the step with nothing on the main stream to hide them. It depends on the input alone: built now, on the
+                    # weight-gradient stream, which has nothing else to do during the forward pass
+                    with ops._on_wgrad_stream(px):
+                        col = ops.im2col_pixels(px, cfg.patch_sizes[0], cfg.patch_stride[0], cfg.patch_padding[0], prep[("embed", 0)].shape[1])[0]
             elif s == 0:
                 col, Ho, Wo = ops.im2col_pixels(px, cfg.patch_sizes[0], cfg.patch_stride[0], cfg.patch_padding[0], prep[("embed", 0)].shape[1])
                 e = ops.gemm_nt(col, prep[("embed", s)], bias=st.f32(ep + "projection.bias"))
