@@ -679,7 +679,7 @@ static int dw3_pick_band(int Bn, int H, int W, int nslices, size_t (*bytes)(int 
         if (!fallback) fallback = band;
         if ((long)Bn * nb * nslices < 384) continue;
         const long cost = (long)nb * (band + 2);
-        if (!best || cost < best_cost) { best = band; best_cost = cost; }
+        if (!best || cost <= best_cost) { best = band; best_cost = cost; }       // (equal cost: the taller band -- fewer, longer workgroups: stage 2 of CvT-21, 8 vs 10 rows, is 5-15 % faster per pass)
     }
     return best ? best : fallback;
 }
