@@ -645,6 +645,16 @@ def main():
                                             "achieved": gm["tn_flops"] / (gm["tn_ms"] * 1e-3) / 1e12 if gm["tn_ms"] else None,
                                             "avg_launch_us": gm["tn_ms"] * 1e3 / max(1, gm["tn_n"])}},
     }
+    # the second workload of BASELINE.json with a number of its own (configs[3]) is measured right behind the headline, in front of the auxiliary keys: on
+    # some boxes of the pool its MFMA-heavy phases run up to 8 ms per step slower after the long MFMA-heavy prelude the auxiliary TF keys make
+    # (profiles/r04_ab_wgrad_stream.txt, calls 33 / 34); the headline key is measured first either way
+    if not args.no_scst:
+        try:
+            out["scst"] = scst_bench(args, rank, world, dev, args.scst_steps)
+        except Exception as e:
+            if world > 1:
+                raise
+            out["scst"] = {"metric": "scst_steps_per_sec", "value": None, "error": str(e)}
     if world == 1 and not args.no_extras:
         try:
             out["forward_only"] = forward_only(args, dev, model, N)
@@ -672,13 +682,6 @@ def main():
         except Exception as e:
             out["tf_dropin"] = {"error": str(e)}
         torch.cuda.empty_cache()
-    if not args.no_scst:
-        try:
-            out["scst"] = scst_bench(args, rank, world, dev, args.scst_steps)
-        except Exception as e:
-            if world > 1:
-                raise
-            out["scst"] = {"metric": "scst_steps_per_sec", "value": None, "error": str(e)}
     if world == 1 and not args.no_extras and not args.no_scst and not args.no_dropin:
         try:
             out["scst_dropin"] = scst_dropin(args, dev)
