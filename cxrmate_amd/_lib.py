@@ -49,6 +49,9 @@ class _Lib:
             if not os.path.exists(LIB_PATH):
                 raise CxrError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(cxrmate_amd has no CPU / PyTorch fallback)")
+            if os.environ.get("CXR_LIB"):
+                import warnings
+                warnings.warn(f"CXR_LIB is set: loading {LIB_PATH} instead of the in-tree libcxrmate_hip.so (A/B of build-time switches)", RuntimeWarning, stacklevel=2)
             import torch  # noqa: F401  -- torch's HIP runtime must be resident first so that the library binds to the same one
             self._dll = ctypes.CDLL(LIB_PATH)
             for name, args in self.protos.items():

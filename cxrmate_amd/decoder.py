@@ -42,6 +42,26 @@ def _site(layer, k):
     return 16 + 8 * layer + k
 
 
+class SharedCrossKV:
+    """The cross-attention K / V of all layers that a decode session projected at its prefill, lent to a teacher-forced pass (the SCST
+    re-scoring forward + its backward read them instead of projecting the encoder output again). The buffer is the session's own static
+    storage: every later prefill of that session overwrites it. `fills` is the session's prefill count when the loan was made; `check()`
+    raises once the session has decoded something else since -- the forward refuses a stale buffer, the backward refuses to differentiate
+    through K / V that are no longer the ones the forward read."""
+
+    def __init__(self, tensor, session, fills):
+        self.tensor, self.session, self.fills = tensor, session, fills
+
+    def valid(self):
+        return self.session is None or self.session.fills == self.fills
+
+    def check(self, where):
+        if not self.valid():
+            raise RuntimeError(f"{where}: the decode session whose cross-attention K / V this teacher-forced pass shares has run another prefill since "
+                               f"(fill {self.session.fills} != {self.fills}); run backward() before the next generate() on the same geometry, or pass "
+                               "cross_kv=None to project K / V again")
+
+
 class KVCache:
     """Per-layer self-attention K/V [B, Tmax, D] (appended in place) and cross-attention K/V [B, S, D] (projected once)."""
 
@@ -249,6 +269,11 @@ class BertEngine:
                 # cross-attention K and V of every layer in one GEMM: [B*S, d] x [d, layers*2*d] (all layers project the same encoder output)
                 S_ = enc.shape[1]
                 if cross_kv is not None:
+                    if isinstance(cross_kv, SharedCrossKV):
+                        cross_kv.check("BertEngine.forward")
+                        if save:
+                            saved["cross_kv_loan"] = cross_kv
+                        cross_kv = cross_kv.tensor
                     assert cross_kv.shape == (B, S_, kva[0].shape[0]) and cross_kv.dtype == BF16 and cross_kv.is_contiguous()
                     kv_all = cross_kv
                 else:
@@ -419,6 +444,9 @@ class BertEngine:
         """dlogits bf16 [R, V] (row stride may be padded to a multiple of 64) or dhidden bf16 [R, D]. Accumulates parameter
         gradients into the store; returns d(enc) bf16 [B,S,D] when need_denc."""
         cfg, st, p = self.cfg, self.s, self.p
+        loan = saved.get("cross_kv_loan")
+        if loan is not None:
+            loan.check("BertEngine.backward")                           # k2 / v2 saved below are VIEWS of a decode session's buffer
         self.prepare()
         lora_tr = bool(saved.get("lora_tr"))
         self._prepare_transposes(lora_tr)

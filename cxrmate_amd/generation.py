@@ -63,6 +63,7 @@ class DecodeSession:
         self.graphs = {}
         self.pool = None
         self.version = -1
+        self.fills = 0                                     # number of reset()s = prefills: every one overwrites the cross K / V (decoder.SharedCrossKV)
         self.beam = None                                   # device-side beam-search state (beam_state)
         self._cache_home = (list(self.cache.k), list(self.cache.v), list(self.cache.k2), list(self.cache.v2))
 
@@ -109,6 +110,7 @@ class DecodeSession:
         self.cache.enc_bits = self.enc_bits
         self.cache.len = 0
         self.cache.cross_ready = False
+        self.fills += 1
         self.cache.k, self.cache.v, self.cache.k2, self.cache.v2 = (list(t) for t in self._cache_home)      # beam search ping-pongs them
         if m.training:
             self.seed.copy_(m.next_dropout_seed())
@@ -389,7 +391,7 @@ class GenerationMixin:
             if rec is not None:
                 rec["seed"] = ses.seed.clone() if self.training else None
                 # the session's cross-attention K / V of every layer (valid until the session's next decode) and the weight version they belong to
-                rec["cross_kv"] = None if ses.cache.kv_all is None else (ses.cache.kv_all, tuple(ses.enc16.shape), self._weights_stamp())
+                rec["cross_kv"] = None if ses.cache.kv_all is None else (ses.cache.kv_all, tuple(ses.enc16.shape), self._weights_stamp(), ses, ses.fills)
             cur = prompt_len
             first_tt = first_pos = None
             poll = None                      # (pinned host word, event): "any row unfinished?" as of the PREVIOUS poll -- read without stalling the queue
@@ -444,7 +446,9 @@ class GenerationMixin:
         ckv = rec.get("cross_kv") if rec else None
         if ckv is None or ckv[1] != tuple(enc.shape) or ckv[2] != self._weights_stamp():
             return None
-        return ckv[0]
+        from .decoder import SharedCrossKV
+        loan = SharedCrossKV(ckv[0], ckv[3], ckv[4])
+        return loan if loan.valid() else None              # the session has decoded another batch since: project again
 
     def sample_and_greedy(self, encoder_outputs, prompt_ids, special_sample, special_greedy, mask_token_id, max_length, bos_token_id,
                           eos_token_id, pad_token_id, top_k=50, temperature=1.0, top_p=1.0):

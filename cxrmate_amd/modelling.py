@@ -73,6 +73,10 @@ class BoundaryTensor(torch.Tensor):
             if out is not NotImplemented:
                 return out
         if func not in _METADATA_ONLY:
+            if _is_inplace(func) and args:
+                m = _meta(args[0])
+                if m is not None and m.get("kind") == "pending_logp":
+                    m["dirty"] = True                       # the edit lands in the cached log-softmax: nll_loss must read that, not the scores
             args, kwargs = _materialise_pending(args), _materialise_pending(kwargs)
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **kwargs)
@@ -142,18 +146,29 @@ def _h_log_softmax(input, dim=None, _stacklevel=3, dtype=None):
 
 def _h_nll_loss(input, target, weight=None, size_average=None, ignore_index=-100, reduce=None, reduction="mean"):
     m = _meta(input)
+    if m is not None and m.get("dirty"):
+        return NotImplemented                               # edited in place since: torch's nll_loss on the (cached, edited) log-probabilities
     if (m is None or m.get("kind") != "pending_logp" or weight is not None or size_average is not None or reduce is not None or reduction != "none"
             or not torch.is_tensor(target) or target.dtype != torch.int64 or tuple(target.shape) != tuple(m["base"].shape[:2])):
         return NotImplemented
     return _RowNllFn.apply(m["base"], _plain(target).to(m["base"].device), int(ignore_index))
 
 
+def _is_inplace(func):
+    name = getattr(func, "__name__", "")
+    return (name.endswith("_") and not name.endswith("__")) or name in ("__setitem__", "__iadd__", "__isub__", "__imul__", "__itruediv__", "__idiv__")
+
+
 def _materialise_pending(obj):
-    """Replace every pending log-softmax in a (nested) argument structure by the computed one."""
+    """Replace every pending log-softmax in a (nested) argument structure by the computed one. Computed ONCE per pending tensor and kept in its
+    meta record: later uses (and in-place edits, which must be visible to later uses) see the same tensor, as with torch's own result."""
     if isinstance(obj, BoundaryTensor):
         m = getattr(obj, "_cxr", None)
         if m is not None and m.get("kind") == "pending_logp":
-            return torch.log_softmax(m["base"], dim=-1).permute(0, 2, 1)
+            v = m.get("value")
+            if v is None:
+                v = m["value"] = torch.log_softmax(m["base"], dim=-1).permute(0, 2, 1)
+            return v
         return obj
     if isinstance(obj, (list, tuple)):
         return type(obj)(_materialise_pending(o) for o in obj)
@@ -204,12 +219,19 @@ class _EncodeFn(torch.autograd.Function):
         model._settle_owed_join()
         feats, saved = model._enc.forward(px, save=True)
         ctx.model, ctx.saved, ctx.nparams = model, saved, len(params)
+        # the stage-1 weight gradient is contracted against an im2col matrix that the BACKWARD builds from the pixels (the forward is an implicit
+        # GEMM): the caller's tensor is held by reference, so an in-place edit between forward and backward must be caught, as autograd's own
+        # saved-tensor version check would (px is not a differentiable input: save_for_backward has nothing to check it against)
+        ctx.px, ctx.px_version = px, px._version
         return feats
 
     @staticmethod
     def backward(ctx, dfeats):
         from .training import wgrad_overlap
         model = ctx.model
+        if ctx.px._version != ctx.px_version:
+            raise RuntimeError("pixel_values was modified in place between the encoder forward and its backward (version "
+                               f"{ctx.px_version} -> {ctx.px._version}): the patch-embedding weight gradient is computed from it in backward")
         bound = model._grads_bindable("encoder.")
         if not model.direct_grads and bound != "accumulate":
             model.zero_grads_prefix("encoder.")
@@ -219,7 +241,7 @@ class _EncodeFn(torch.autograd.Function):
                 ops.wgrad_join()                                           # ... complete before autograd reads them
             else:
                 model._queue_backward_join()
-        ctx.saved = None
+        ctx.saved = ctx.px = None
         if bound:
             return (None, None) + model._bind_grads("encoder.", ctx.nparams)
         return (None, None) + model._collect_grads("encoder.", ctx.nparams)

@@ -218,6 +218,9 @@ def _tn_arena_alloc(device, n):
         bufs.append(torch.empty(max(n, _TN_CHUNK), dtype=torch.float32, device=device))
 
 
+_TN_PENDING_PTRS = set()
+
+
 def wgrad_reduce(side=None):
     """Add every pending split sum of the weight-gradient stream to its gradient (one launch per 40 sums, on that stream, behind the GEMMs that left
     the partial tiles). Called at every point where something may READ a weight gradient: the joins, the fork points of the gradient all-reduce and of
@@ -229,6 +232,7 @@ def wgrad_reduce(side=None):
     arr = (_TnPending * len(_TN_PENDING))(*[d for d, _ in _TN_PENDING])
     LIB.call("cxr_gemm_tn_reduce_batch", _ct.addressof(arr), len(_TN_PENDING), side.cuda_stream)
     _TN_PENDING.clear()
+    _TN_PENDING_PTRS.clear()
     for ar in _TN_ARENA.values():
         ar[1] = ar[2] = 0                                  # the same stream orders the next GEMM's partial tiles behind this reduce
 
@@ -246,6 +250,11 @@ def gemm_tn(p, q, out, dbias=None, alpha=1.0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(pstream)
     stream = _s()
+    # The batched reduce adds every pending split sum with a plain read-modify-write of its destination: two entries of one batch that name the
+    # same C (a weight used twice in one backward, tied / shared parameters), or a one-split launch adding into a C whose sum is still pending,
+    # would race. A destination that is already pending is settled first (stream order then serialises the two, as before the deferral).
+    if _TN_PENDING_PTRS and (out.data_ptr() in _TN_PENDING_PTRS or (dbias is not None and dbias.data_ptr() in _TN_PENDING_PTRS)):
+        wgrad_reduce()
     if _TN_DEFER and _SIDE_RAW is not None and WGRAD_STREAM is not None:
         splits, need = _ct.c_int(0), _ct.c_long(0)
         LIB.call("cxr_gemm_tn_plan", int(R), int(I), int(J), _ct.byref(splits), _ct.byref(need))
@@ -255,6 +264,9 @@ def gemm_tn(p, q, out, dbias=None, alpha=1.0):
                  0 if ws is None else ws.numel(), _ct.byref(pend), stream)
         if pend.splits > 1:
             _TN_PENDING.append((pend, (out, dbias)))
+            _TN_PENDING_PTRS.add(out.data_ptr())
+            if dbias is not None:
+                _TN_PENDING_PTRS.add(dbias.data_ptr())
             # ... but not for long: the partial tiles should still be in the 256-MB Infinity Cache when the reduce reads them (with every sum of a
             # step pending, ~2 GB of partial tiles went out to HBM and came back: the step got 0.16 ms SLOWER than with one reduce launch per GEMM)
             ar = _TN_ARENA[p.device.index]
@@ -402,6 +414,12 @@ def wgrad_wait(ev):
 
 
 _WGRAD_SKIP = __import__("os").environ.get("CXR_WGRAD_SKIP") == "1"       # TIMING EXPERIMENT ONLY (wrong gradients): no weight-gradient GEMM is launched
+if _WGRAD_SKIP:
+    if __import__("os").environ.get("CXR_DEBUG_TIMING") != "1":
+        raise RuntimeError("CXR_WGRAD_SKIP=1 drops every Linear weight gradient (a timing experiment): it is only honoured together with "
+                           "CXR_DEBUG_TIMING=1")
+    __import__("warnings").warn("CXR_WGRAD_SKIP=1: NO Linear weight gradient is computed in this process -- timing experiment, training results are wrong",
+                                RuntimeWarning, stacklevel=1)
 
 
 def linear_bwd_weight(dy, x, dw, db=None):

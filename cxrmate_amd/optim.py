@@ -25,9 +25,11 @@ from .store import ALIGN
 
 class AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 amsgrad: bool = False, maximize: bool = False, **unused):
-        if amsgrad or maximize:
-            raise NotImplementedError("amsgrad / maximize are not used by the reference (torch.optim.AdamW defaults)")
+                 amsgrad: bool = False, maximize: bool = False, foreach=None, capturable: bool = False, differentiable: bool = False, fused=None):
+        # torch.optim.AdamW's remaining keywords: `foreach` / `fused` only choose among torch's own implementations (any value is accepted and
+        # ignored -- this IS a fused implementation); the ones that change semantics are refused, as is anything unknown (TypeError, as in torch)
+        if amsgrad or maximize or capturable or differentiable:
+            raise NotImplementedError("amsgrad / maximize / capturable / differentiable are not used by the reference (torch.optim.AdamW defaults)")
         if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or not 0.0 <= weight_decay:
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
@@ -81,7 +83,9 @@ class AdamW(torch.optim.Optimizer):
 
     # ------------------------------------------------------------------------------------------ step
     def _flush_plan(self, gi):
-        """Write a group's shared step count back into the per-parameter states (the fast path below counts once per group)."""
+        """Write a group's shared step count back into the per-parameter states. While the fast path below is active the per-parameter
+        `state[p]['step']` is NOT advanced every step (one counter per group, `plan['t']`): it is brought up to date here -- whenever the fast path is
+        left -- and by state_dict(); read step counts through state_dict(), as checkpointing code does."""
         plan = self._plans.pop(gi, None)
         if plan is not None:
             for p in plan["params"]:
@@ -107,7 +111,9 @@ class AdamW(torch.optim.Optimizer):
             if plan is not None:
                 # steady state: the same parameters, every gradient where the autograd bridges bind it (a view of the flat gradient buffer), the same
                 # flat buffers -> the launches of the previous step again, nothing per parameter but the pointer check
-                ok = len(group["params"]) == len(plan["params"]) and all(st_.flat32.data_ptr() == ptr for st_, ptr in plan["stores"])
+                gp = group["params"]
+                ok = (len(gp) == len(plan["params"]) and all(a is b for a, b in zip(gp, plan["params"]))      # the SAME parameters, by identity
+                      and all(st_.flat32.data_ptr() == ptr for st_, ptr in plan["stores"]))
                 if ok:
                     for p, ptr in plan["checks"]:
                         g = p.grad

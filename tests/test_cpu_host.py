@@ -308,3 +308,59 @@ def test_failed_step_leaves_no_deferred_weight_gradient_launches(monkeypatch):
             ops._SIDE_PENDING.append(())
             raise ValueError("step failed")
     assert ran == [1] and not ops._SIDE_DEFERRED and not ops._SIDE_PENDING and ops.WGRAD_STREAM is prev
+
+
+def test_pending_log_softmax_behaves_like_the_computed_tensor():
+    """modelling._h_log_softmax hands the SCST caller's `log_softmax(stack(scores), dim=1)` back as a PENDING BoundaryTensor (the fused loss kernel
+    serves `nll_loss(reduction='none')` from the scores). Every other use must see the real log-probabilities: computed once and cached, indexable,
+    and an in-place edit is visible to every later use -- including a later nll_loss, which then is torch's own on the edited tensor (round-4
+    advisor finding). Pure torch-function plumbing: runs on CPU tensors."""
+    from cxrmate_amd.modelling import BoundaryTensor, _as_boundary
+    torch.manual_seed(0)
+    base = torch.randn(2, 5, 7, requires_grad=True)
+    want = torch.log_softmax(base.detach(), -1).permute(0, 2, 1)
+    lp = torch.nn.functional.log_softmax(_as_boundary(base.permute(0, 2, 1), kind="bvt", base=base), dim=1)
+    assert isinstance(lp, BoundaryTensor) and lp._cxr["kind"] == "pending_logp" and lp.shape == want.shape and lp.dtype == want.dtype
+    assert lp._cxr.get("value") is None                                   # shape / dtype reads compute nothing
+    e = lp.exp()
+    assert type(e) is torch.Tensor and torch.allclose(e, want.exp())
+    first = lp._cxr["value"]
+    assert torch.equal(lp[:, 3], want[:, 3]) and lp._cxr["value"] is first  # cached: one log-softmax however often it is used
+    (lp.sum() * 1.0).backward()                                            # ... and it carries autograd back to the scores
+    assert base.grad is not None and torch.isfinite(base.grad).all()
+    with torch.no_grad():
+        lp.mul_(2.0)                                                       # in-place: lands in the cached tensor, not in a temporary
+    assert torch.allclose(lp + 0.0, 2.0 * want)
+    tgt = torch.randint(0, 7, (2, 5))
+    got = torch.nn.functional.nll_loss(lp, tgt, reduction="none")          # the recognised call, but on an edited tensor: torch's own
+    assert torch.allclose(got, torch.nn.functional.nll_loss(2.0 * want, tgt, reduction="none"))
+
+
+def test_fused_adamw_refuses_what_it_does_not_implement():
+    from cxrmate_amd.optim import AdamW
+    p = torch.nn.Parameter(torch.zeros(4))
+    AdamW([p], lr=1e-3, foreach=None, fused=True)                          # implementation selectors of torch.optim.AdamW: accepted
+    with pytest.raises(TypeError):
+        AdamW([p], lr=1e-3, nesterov=True)                                 # unknown keyword: TypeError, as in torch
+    with pytest.raises(NotImplementedError):
+        AdamW([p], lr=1e-3, capturable=True)
+    q = torch.nn.Parameter(torch.ones(3))
+    opt = AdamW([q], lr=0.1, weight_decay=0.0)
+    q.grad = torch.ones(3)
+    opt.step(); opt.step()
+    assert int(opt.state_dict()["state"][0]["step"]) == 2 and float(q[0]) < 1.0
+
+
+def test_debug_switches_in_the_product_path_are_loud(monkeypatch):
+    """CXR_WGRAD_SKIP drops every Linear weight gradient (a timing experiment): refused unless CXR_DEBUG_TIMING=1 is set too, and then it warns."""
+    import importlib
+    import subprocess
+    import sys
+    code = "import cxrmate_amd.ops"
+    env = dict(os.environ, CXR_WGRAD_SKIP="1")
+    env.pop("CXR_DEBUG_TIMING", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode != 0 and "CXR_DEBUG_TIMING" in r.stderr
+    r = subprocess.run([sys.executable, "-W", "always", "-c", code], env=dict(env, CXR_DEBUG_TIMING="1"), capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "NO Linear weight gradient" in r.stderr

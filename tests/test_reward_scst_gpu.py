@@ -209,7 +209,7 @@ def test_fused_sample_and_greedy_decode(cuda):
     # the encoder output again: same logits bit for bit, same parameter gradients, and a stale buffer (other weights / another batch shape) is refused
     enc16, em8 = eo.last_hidden_state.contiguous(), eo.attention_mask.to(torch.uint8).contiguous()
     ckv = m._session_cross_kv(rec, enc16)
-    assert ckv is not None and ckv.shape == (enc16.shape[0], enc16.shape[1], 2 * cfg.decoder.num_hidden_layers * cfg.decoder.hidden_size)
+    assert ckv is not None and ckv.tensor.shape == (enc16.shape[0], enc16.shape[1], 2 * cfg.decoder.num_hidden_layers * cfg.decoder.hidden_size)
     with torch.no_grad():
         lg2, _ = m._dec.forward(tf_in, enc16, em8, (tf_in != gu.PAD).to(torch.uint8), tt, pos, cross_kv=ckv)
     assert torch.equal(lg, lg2)
@@ -244,6 +244,27 @@ def test_fused_sample_and_greedy_decode(cuda):
         gsl.append(m.gflat.clone())
     assert torch.allclose(gsl[0], gsl[1], rtol=1e-4, atol=1e-6), float((gsl[0] - gsl[1]).abs().max())
     assert m._session_cross_kv(rec, enc16[:1]) is None
+    # The lent buffer is the decode session's own storage: a decode of ANOTHER batch of the same geometry between the re-scoring forward and its
+    # backward overwrites the K / V that attention_bwd would read (round-4 advisor finding). The loan carries the session's prefill count: the
+    # backward refuses, a new loan is refused, and the caller's fallback (project again) gives the gradients of the un-shared pass.
+    m.zero_grads_prefix("decoder.")
+    lgs, saved = m._dec.forward(tf_in, enc16, em8, (tf_in != gu.PAD).to(torch.uint8), tt, pos, save=True, cross_kv=m._session_cross_kv(rec, enc16))
+    with torch.no_grad():
+        x2 = x.flip(0).contiguous()
+        eo2 = m.encoder(x2.cuda())
+        m.sample_and_greedy(eo2, prompt.cuda(), [gu.BOS, gu.SEP], [gu.PMT_SEP, gu.BOS, gu.SEP], gu.PAD, L + P, gu.BOS, gu.EOS, gu.PAD, top_k=5)
+    dl = torch.zeros_like(lgs, dtype=torch.bfloat16)
+    dl[:, :, 7] = 1.0
+    with pytest.raises(RuntimeError, match="another prefill"):
+        m._dec.backward(saved, dlogits=dl.view(-1, dl.shape[-1]), need_denc=False)
+    ops_.wgrad_join()
+    assert m._session_cross_kv(rec, enc16) is None                             # the same record can no longer borrow: the caller projects again
+    m.zero_grads_prefix("decoder.")
+    lgs, saved = m._dec.forward(tf_in, enc16, em8, (tf_in != gu.PAD).to(torch.uint8), tt, pos, save=True, cross_kv=m._session_cross_kv(rec, enc16))
+    m._dec.backward(saved, dlogits=dl.view(-1, dl.shape[-1]), need_denc=False)
+    ops_.wgrad_join()
+    torch.cuda.synchronize()
+    assert torch.allclose(m.gflat, grads[0], rtol=1e-5, atol=1e-7)
     m.flat32.add_(0.0)                                                         # any in-place torch edit of the weights moves the stamp
     assert m._session_cross_kv(rec, enc16) is None
     sc = lg[:, P - 1:, :].float()
