@@ -440,15 +440,21 @@ class GenerationMixin:
         """Changes whenever the decoder weights may have: the bf16 shadow's version (fused AdamW) and the fp32 master's autograd version (torch edits)."""
         return (getattr(self, "shadow_version", 0), self.flat32._version)
 
-    def _session_cross_kv(self, rec, enc):
+    def _session_cross_kv(self, rec, enc, own=False):
         """The cross-attention K / V of all layers a decode session projected at prefill (rec["cross_kv"]), if they still belong to `enc`'s shape and
-        to the current weights -- the teacher-forced re-scoring pass of the same SCST step then skips its own projection GEMM. Else None."""
+        to the current weights -- the teacher-forced re-scoring pass of the same SCST step then skips its own projection GEMM. Else None.
+        The result is a LOAN of the session's static buffer (decoder.SharedCrossKV): valid until that session's next prefill. own=True hands out a
+        private copy instead (one 0.15-ms copy at the benchmark shape instead of a 16-GFLOP projection) -- for the autograd bridge, whose backward runs
+        whenever the caller gets to it: the reference's SCST caller decodes its greedy baseline on the same geometry BETWEEN the sampling call and
+        loss.backward() (scst/gt_prompt.py:84-132)."""
         ckv = rec.get("cross_kv") if rec else None
         if ckv is None or ckv[1] != tuple(enc.shape) or ckv[2] != self._weights_stamp():
             return None
         from .decoder import SharedCrossKV
         loan = SharedCrossKV(ckv[0], ckv[3], ckv[4])
-        return loan if loan.valid() else None              # the session has decoded another batch since: project again
+        if not loan.valid():
+            return None                                    # the session has decoded another batch since: project again
+        return SharedCrossKV(ckv[0].clone(), None, 0) if own else loan
 
     def sample_and_greedy(self, encoder_outputs, prompt_ids, special_sample, special_greedy, mask_token_id, max_length, bos_token_id,
                           eos_token_id, pad_token_id, top_k=50, temperature=1.0, top_p=1.0):
@@ -501,7 +507,7 @@ class GenerationMixin:
         # a slice of full-length logits costs a 490-MB zero fill + copy in backward at the benchmark shape
         first = prompt_len - stripped - 1
         sc = self._decode_tf(tf_in, enc, None if self.kind == "single" else enc_mask, mask, tt, pos, seed=rec.get("seed"),
-                             cross_kv=self._session_cross_kv(rec, enc), logit_from=first)
+                             cross_kv=self._session_cross_kv(rec, enc, own=True), logit_from=first)
         if temperature is not None and float(temperature) != 1.0:
             sc = sc / float(temperature)
         if top_k or top_p < 1.0:

@@ -974,7 +974,9 @@ def fixture_beam_safe():
                     with torch.no_grad():
                         o = model.generate(**dict(kw, length_penalty=lp))
                     found[name] = seed
-                    out.update(_beam_safe_arrays(name, seed, bias, lp, o["sequences"].view(3, 4, -1), o["sequences_scores"].view(3, 4), float(old[f"{name}_score_tol"])))
+                    sc_ = o["sequences_scores"].view(3, 4)
+                    tol_ = 0.4 * float((sc_[:, 0] - sc_[:, 1]).min())       # re-DERIVED from the clean run (the definition in _robust_beam_case), not copied
+                    out.update(_beam_safe_arrays(name, seed, bias, lp, o["sequences"].view(3, 4, -1), sc_, tol_))
     lo, hi = (int(v) for v in (os.environ.get("BEAM_SAFE_SEEDS") or "300:600").split(":"))
     for seed in range(lo, hi):
         if len(found) == len(BEAM_SAFE_KINDS):

@@ -118,8 +118,10 @@ def generate_single_case():
 
 def beam_safe_case(name):
     """-> (cfg, state dict, pixels, EOS bias, length_penalty, reference hypotheses [3,4,T], scores [3,4], steps, score tolerance) or None when the
-    fixture holds no case of that kind. The score tolerance is 0.4 x the smallest gap between a row's best hypothesis and its runner-up; rows are told
-    apart by their sequences (pairwise different by construction of the fixture)."""
+    fixture holds no case of that kind. The score tolerance is 0.4 x the smallest gap between a row's best hypothesis and its runner-up: a score
+    within it identifies the HYPOTHESIS of a row. The ROWS are told apart by their sequences (pairwise different by construction of the fixture,
+    asserted here) -- not by their scores: the smallest row-to-row score distance (`<kind>_row_dist`) is above the tolerance for the `plain`, `lp2`
+    and `lp05` cases and BELOW it for `eos` (0.0118 < 0.0229), see beam_safe_rows_differ_by_score()."""
     g = load("generate_beam_safe.npz")
     if f"{name}_seed" not in g.files:
         return None
@@ -127,8 +129,16 @@ def beam_safe_case(name):
     seed = int(g[f"{name}_seed"])
     sd = sharpened_state(cfg, seed, float(g["perturb"]), float(g["sharpen"]), float(g["cross_gain"]))
     x = distinct_study_pixels(int(g[f"{name}_pixel_seed"]), float(g["img_off"]))
+    best = g[f"{name}_all"][:, 0]
+    assert len({tuple(r.tolist()) for r in best}) == best.shape[0], "the studies' best hypotheses must be pairwise different sequences"
     return (cfg, sd, x, float(g[f"{name}_eos_bias"]), float(g[f"{name}_length_penalty"]), g[f"{name}_all"], g[f"{name}_all_scores"], int(g["steps"]),
             float(g[f"{name}_score_tol"]))
+
+
+def beam_safe_rows_differ_by_score(name):
+    """True when the recorded score tolerance of the case is below its smallest row-to-row score distance (then a score alone identifies the row)."""
+    g = load("generate_beam_safe.npz")
+    return float(g[f"{name}_score_tol"]) < float(g[f"{name}_row_dist"])
 
 
 def generate_longitudinal_case():

@@ -1,0 +1,286 @@
+"""GPU: the SCST step at the workloads the metric is quoted on -- BASELINE.json configs[3] (16 studies x 2 images, 5-token prompt, 255 sampled +
+255 greedy tokens) and configs[4] (16 x 3 images, 128-token prompt, e4m3 encoder) -- plus one ragged 5-image study, checked through
+size-independent properties (the CPU oracle cannot run these shapes in seconds). Reference: modules/lightning_modules/longitudinal/scst/
+gt_prompt.py:62-142 (step), :144-209 (sample), :211-246 (reinforce_loss); gen_prompt.py:174-259; config/train/single_tf.yaml:13 (5 images).
+
+  (i)   the fused 32-row sample + greedy decode returns greedy rows equal to a separate 16-row greedy generate() up to the first position whose
+        teacher-forced top-1 / top-2 margin is below the bf16 logit error bound; teacher-forced argmax == greedy token at every safe position;
+  (ii)  every processed score row of generate.__wrapped__ has exactly top_k finite entries (one more where the drawn token sat just below the
+        recomputed threshold) and the sampled id is one of them;
+  (iii) train mode: the re-scoring pass's log-probabilities at the sampled ids equal those of the decode-time processed scores (the cached-step
+        kernels teacher-forced on the sampled ids with the decode's dropout seed) within the bf16 bound, and every token the session sampled lies
+        inside the re-scored top-k (one rank of slack);
+  (iv)  scst_step's loss equals the torch restatement of reinforce_loss on the re-scored logits, the decoder gradient is finite and the same with
+        and without the shared cross-attention K / V;
+  (v)   5 images per study (2,880 encoder keys, above the one-workgroup cross-attention kernel's 1,920): cached greedy == teacher-forced argmax on
+        safe margins, ragged study included.
+These instantiations exist only at this size: 32-row dec_gemm_kernel with the LoRA branch, 1152- / 1728-key attn_cross_mfma_kernel, the 4080 x 30000
+top-k threshold, the sampled-position LM head, the cross K / V shared between the decode prefill and the re-scoring pass.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+MARGIN = 0.05
+BOS, SEP, PAD, PMT, PMT_SEP, NPF, NPI = 1, 3, 4, 8, 9, 10, 11
+SPECIAL = dict(bos=BOS, eos=None, sep=SEP, pad=PAD, pmt_sep=PMT_SEP)
+NEW = 255                                                                              # sampled tokens per row (BASELINE.json configs[3])
+
+
+@pytest.fixture(scope="module")
+def model():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cxrmate_amd.config import EncoderDecoderConfig
+    from cxrmate_amd.modelling import LongitudinalPromptMultiCXREncoderDecoderModel
+    m = LongitudinalPromptMultiCXREncoderDecoderModel(EncoderDecoderConfig(), device="cuda", seed=0, perturb=0.05)
+    for p in m.decoder.parameters():
+        p.requires_grad_(True)                                                         # scst/gt_prompt.py:38-40
+    return m
+
+
+def _images(B, N, seed):
+    return torch.randn(B, N, 3, 384, 384, generator=torch.Generator().manual_seed(seed))
+
+
+def _c4_prompt(B):
+    return torch.tensor([[PMT, NPF, PMT_SEP, NPI, BOS]] * B, device="cuda")
+
+
+def _c5_prompt(B, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    return torch.cat([torch.full((B, 1), PMT), torch.randint(12, 30000, (B, 62), generator=g), torch.full((B, 1), PMT_SEP),
+                      torch.randint(12, 30000, (B, 63), generator=g), torch.full((B, 1), BOS)], 1).cuda()
+
+
+def _strip(seq):
+    return seq[:, 1:] if bool(torch.all(seq[:, 0] == BOS)) else seq
+
+
+def _tf_logits(m, eo, fed, special, seed=None, train=None):
+    """Teacher-forced logits [B, T, V] of the fed sequence with the per-position inputs the cached steps use."""
+    from cxrmate_amd import ops
+    tf_in = fed.contiguous()
+    mask, pos = ops.mask_position_ids(tf_in, PAD)
+    tt = m.token_ids_to_token_type_ids(tf_in, special, [0, 1, 0, 1])
+    lg, _ = m._dec.forward(tf_in, eo.last_hidden_state.contiguous(), eo.attention_mask.to(torch.uint8).contiguous(), mask, tt, pos, seed=seed, train=train)
+    return lg
+
+
+def _first_unsafe(logits_new, tokens_new):
+    """per row: index of the first position whose top-1 / top-2 margin is unsafe (= number of leading safe positions); also the safe mask"""
+    top2 = logits_new.float().topk(2, dim=-1)
+    safe = (top2.values[..., 0] - top2.values[..., 1]) > MARGIN
+    unsafe = ~safe
+    first = torch.where(unsafe.any(1), unsafe.int().argmax(1), torch.full((safe.shape[0],), safe.shape[1], device=safe.device))
+    return first, safe, top2.indices[..., 0]
+
+
+def test_c4_fused_sample_and_greedy_decode_properties(model):
+    m = model.eval()
+    B, N = 16, 2
+    x = _images(B, N, 11)
+    x[3, 1] = 0.0                                                                      # one ragged study
+    prompt = _c4_prompt(B)
+    P = prompt.shape[1]
+    with torch.no_grad():
+        eo = m.encoder(x.cuda())
+        assert eo.last_hidden_state.shape == (B, N * 576, 768)
+        torch.manual_seed(21)
+        smp, grd, rec = m.sample_and_greedy(eo, prompt, [BOS, SEP], [PMT_SEP, BOS, SEP], PAD, NEW + 1 + P, BOS, None, PAD, top_k=50)
+        base = m.generate(encoder_outputs=eo, decoder_input_ids=prompt, special_token_ids=[PMT_SEP, BOS, SEP], max_length=NEW + 1 + P, bos_token_id=BOS,
+                          eos_token_id=None, pad_token_id=PAD, mask_token_id=PAD, num_beams=1, return_dict_in_generate=True, use_cache=True)["sequences"]
+        smp, grd, base = _strip(smp), _strip(grd), _strip(base)
+        assert smp.shape == grd.shape == base.shape == (B, P + NEW)
+        # (i) margins from the teacher-forced pass over the separate greedy call's rows
+        lg = _tf_logits(m, eo, base[:, :-1], [PMT_SEP, BOS, SEP])[:, P - 1:]
+        first, safe, arg = _first_unsafe(lg, base[:, P:])
+        assert float(safe.float().mean()) > 0.5
+        assert torch.equal(arg[safe], base[:, P:][safe])                               # cache == no cache at 16 rows, 1152 keys, LoRA merged
+        for r in range(B):
+            k = int(first[r])
+            assert torch.equal(grd[r, : P + k], base[r, : P + k]), r                   # (the token AT the first unsafe position may already differ)
+        # ... which can be a short prefix (the 16 studies share one prompt: an unsafe first margin is unsafe in every row), so the 32-row decode is
+        # ALSO held against the teacher-forced pass over its own greedy rows: cache == no cache at every safe position
+        lg32 = _tf_logits(m, eo, grd[:, :-1], [PMT_SEP, BOS, SEP])[:, P - 1:]
+        _, safe32, arg32 = _first_unsafe(lg32, grd[:, P:])
+        assert float(safe32.float().mean()) > 0.5 and torch.equal(arg32[safe32], grd[:, P:][safe32])
+        # every sampled token lies inside the top-k of ITS row's teacher-forced logits (2 x the bf16 logit error bound of slack at the threshold)
+        lgs = _tf_logits(m, eo, smp[:, :-1], [BOS, SEP])[:, P - 1:].float()
+        kth = lgs.topk(50, dim=-1).values[..., -1]
+        tok = lgs.gather(-1, smp[:, P:].unsqueeze(-1))[..., 0]
+        assert bool((tok >= kth - 2 * MARGIN).all()), float((kth - tok).max())
+        assert len(torch.unique(smp[:, P:])) > 500                                     # it did sample
+        # (ii) the processed scores the reference's caller receives from generate.__wrapped__
+        torch.manual_seed(22)
+        out = m.generate.__wrapped__(m, input_ids=prompt, special_token_ids=[BOS, SEP], encoder_outputs=eo, bos_token_id=BOS, eos_token_id=None,
+                                     pad_token_id=PAD, mask_token_id=PAD, return_dict_in_generate=True, do_sample=True, num_beams=1, use_cache=True,
+                                     output_scores=True, top_p=1.0, top_k=50, temperature=1.0, max_new_tokens=NEW)
+        seqs = _strip(out["sequences"])
+        scores = torch.stack([s_.as_subclass(torch.Tensor) for s_ in out["scores"]], dim=1)       # [B, NEW, V]
+        assert scores.shape == (B, NEW, 30000)
+        nfin = torch.isfinite(scores).sum(-1)
+        assert int(nfin.min()) >= 50 and int(nfin.max()) <= 51 and float((nfin == 50).float().mean()) > 0.98
+        drawn = scores.gather(-1, seqs[:, P:].unsqueeze(-1))[..., 0]
+        assert bool(torch.isfinite(drawn).all())
+
+
+def test_c4_train_mode_rescoring_equals_the_decode_time_scores(model):
+    """(iii): dropout 0.1 in the 32-row decode and in the re-scoring pass, same seed."""
+    from cxrmate_amd import ops
+    m = model.train()
+    try:
+        B, N = 16, 2
+        x = _images(B, N, 12)
+        prompt = _c4_prompt(B)
+        P = prompt.shape[1]
+        with torch.no_grad():
+            eo = m.encoder(x.cuda())
+            enc16, emask8 = eo.last_hidden_state.contiguous(), eo.attention_mask.to(torch.uint8).contiguous()
+            torch.manual_seed(31)
+            smp, grd, rec = m.sample_and_greedy(eo, prompt, [BOS, SEP], [PMT_SEP, BOS, SEP], PAD, NEW + 1 + P, BOS, None, PAD, top_k=50)
+            smp = _strip(smp)
+            seed = rec["seed"]
+            assert seed is not None
+            sampled = smp[:, P:].contiguous()
+            # the re-scoring pass exactly as scst_step issues it (shared cross K / V, LM head on the sampled positions)
+            tf_in = smp[:, : P + NEW - 1].contiguous()
+            tt = torch.cat(rec["tt"][:NEW], dim=1).contiguous()
+            pos = torch.cat(rec["pos"][:NEW], dim=1).contiguous()
+            loan = m._session_cross_kv(rec, enc16)
+            assert loan is not None
+            rs, _ = m._dec.forward(tf_in, enc16, emask8, (tf_in != PAD).to(torch.uint8), tt, pos, seed=seed, cross_kv=loan, logit_from=P - 1)
+            assert rs.shape == (B, NEW, 30000)
+            # decode-time scores: the cached-step kernels teacher-forced on the sampled ids, same seed (16 rows, host-driven)
+            cache = m._dec.new_cache(B, P + NEW, m.device)
+            steps = []
+            for cur in range(P, P + NEW):
+                new, mask, tt1, pos1 = m._step_inputs(smp[:, :cur], [BOS, SEP], PAD, prefill=cache.len == 0)
+                steps.append(m._dec.decode(cache, new.contiguous(), enc16, emask8, mask, tt1.contiguous(), pos1.contiguous(), train=True, seed=seed))
+            dt = torch.stack(steps, 1)                                                 # [B, NEW, V]
+
+            def logp_at(lg):
+                flat = lg.reshape(-1, lg.shape[-1]).contiguous().float()
+                thr = ops.topk_threshold(flat, 50, 1.0, 1.0).view(-1, 1)
+                keep = (flat >= thr).scatter(1, sampled.view(-1, 1), True)
+                return torch.log_softmax(flat.masked_fill(~keep, float("-inf")), -1).gather(1, sampled.view(-1, 1))[:, 0]
+
+            a, b = logp_at(rs), logp_at(dt)
+            d = (a - b).abs()
+            assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
+            print(f"re-scored vs decode-time log-probabilities at the sampled ids: mean |d| {float(d.mean()):.4f}, 99.9 % {float(d.quantile(0.999)):.4f}, max {float(d.max()):.4f}")
+            # measured: mean 0.0055, 99.9 % 0.031, max 0.033
+            assert float(d.mean()) < 0.02 and float(d.quantile(0.999)) < 0.1, (float(d.mean()), float(d.quantile(0.999)), float(d.max()))
+            # ... and it is the SEED that makes them agree: another seed is a different network
+            other, _ = m._dec.forward(tf_in, enc16, emask8, (tf_in != PAD).to(torch.uint8), tt, pos, seed=seed + 1, logit_from=P - 1)
+            assert float((logp_at(other) - b).abs().mean()) > 4 * float(d.mean())
+            # what the SESSION sampled (32 rows, graph replays) lies inside the re-scored top-k
+            kth = rs.float().topk(50, dim=-1).values[..., -1]
+            tok = rs.float().gather(-1, sampled.unsqueeze(-1))[..., 0]
+            assert bool((tok >= kth - 2 * MARGIN).all()), float((kth - tok).max())
+    finally:
+        m.eval()
+
+
+def _reinforce_restatement(logits, sampled, adv):
+    """reference scst/gt_prompt.py:211-246 on processed scores [B, T, V] (top-k 50 warper restated with torch.topk; the drawn token keeps its score)."""
+    kth = logits.topk(50, dim=-1).values[..., -1:]
+    keep = (logits >= kth).scatter(2, sampled.unsqueeze(-1), True)
+    sc = logits.masked_fill(~keep, float("-inf")).permute(0, 2, 1)                     # [B, V, T] as the caller stacks them
+    nll = torch.nn.functional.nll_loss(torch.log_softmax(sc, dim=1), sampled, ignore_index=PAD, reduction="none")
+    return (nll.sum(-1) * adv).mean()
+
+
+@pytest.mark.parametrize("shape", ["c4", "c5"])
+def test_scst_step_loss_is_the_reinforce_restatement_and_gradients_do_not_depend_on_kv_sharing(model, shape, monkeypatch):
+    """(iv) at both benchmark shapes, train mode; lr = 0 keeps the weights (and so the re-scored logits) fixed across the calls."""
+    from cxrmate_amd.scst import scst_step
+    from cxrmate_amd.training import FusedAdamW
+    m = model.train()
+    try:
+        B, N = 16, (3 if shape == "c5" else 2)
+        x = _images(B, N, 13).cuda()
+        prompt = _c5_prompt(B) if shape == "c5" else _c4_prompt(B)
+        P = prompt.shape[1]
+        if shape == "c5":
+            m.enable_fp8_encoder(_images(4, N, 14).cuda())
+        opt = FusedAdamW(m, lr=0.0, weight_decay=0.0)
+
+        def reward_fn(ids):
+            return ((ids % 97).float().mean(1) / 97.0).to(torch.float32)
+
+        def run(share):
+            if not share:
+                monkeypatch.setattr(m, "_session_cross_kv", lambda rec, enc, own=False: None, raising=False)
+            torch.manual_seed(41)
+            out = scst_step(m, opt, reward_fn, x, prompt, None, SPECIAL, decoder_max_len=NEW + 1)
+            torch.cuda.synchronize()
+            if not share:
+                monkeypatch.undo()
+            return out, m.gflat[opt.split: m._param_total].clone()                    # the decoder's range of the flat gradient buffer
+
+        out, g_shared = run(True)
+        out2, g_own = run(False)
+        assert torch.equal(out["sampled"], out2["sampled"]) and torch.equal(out["baseline_ids"], out2["baseline_ids"])     # same seed, same weights
+        assert bool(torch.isfinite(g_shared).all()) and float(g_shared.abs().max()) > 0
+        tol = 2e-3 * float(g_own.abs().max())
+        assert float((g_shared - g_own).abs().max()) <= tol, (float((g_shared - g_own).abs().max()), tol)
+        assert abs(out["loss"].item() - out2["loss"].item()) <= 1e-4 * max(1.0, abs(out2["loss"].item()))
+        # the torch restatement of reinforce_loss on the re-scored logits of the ids the step sampled
+        sampled = out["sampled"]
+        assert sampled.shape == (B, NEW) and out["baseline_ids"].shape[1] == P + NEW
+        adv = (reward_fn(sampled) - reward_fn(out["baseline_ids"][:, P:])).float()
+        # logits: the same teacher-forced pass, same dropout seed, on the step's OWN encoder output (train-mode BatchNorm / DropPath make the frozen
+        # encoder stochastic): the decode session keeps the bf16 copy it was fed
+        ses = next(s_ for s_ in m._decode_sessions.values() if s_.B == 2 * B and s_.S == N * 576)
+        enc16 = ses.enc16.clone()
+        emask8 = None if ses.enc_mask8 is None else ses.enc_mask8.clone()
+        seqs = torch.cat([prompt, sampled], 1)
+        tf_in = seqs[:, : P + NEW - 1].contiguous()
+        from cxrmate_amd import ops
+        mask, pos = ops.mask_position_ids(tf_in, PAD)
+        tt = m.token_ids_to_token_type_ids(tf_in, [BOS, SEP], [0, 1, 0, 1])
+        with torch.no_grad():
+            lg, _ = m._dec.forward(tf_in, enc16, emask8, mask, tt, pos, seed=out["dropout_seed"], logit_from=P - 1)
+            want = _reinforce_restatement(lg.float(), sampled, adv)
+        assert abs(out["loss"].item() - want.item()) <= 2e-3 * max(1.0, abs(want.item())), (out["loss"].item(), want.item())
+    finally:
+        m.disable_fp8_encoder()
+        m.eval()
+
+
+def test_five_image_studies_decode_like_teacher_forcing(model):
+    """(v) config/train/single_tf.yaml:13 `max_images_per_study: 5` -> 2,880 encoder keys; second study ragged (3 real + 2 zero images)."""
+    m = model.eval()
+    B, N = 2, 5
+    x = _images(B, N, 15)
+    x[1, 3:] = 0.0
+    prompt = _c4_prompt(B)
+    P = prompt.shape[1]
+    L = 48
+    with torch.no_grad():
+        eo = m.encoder(x.cuda())
+        assert eo.last_hidden_state.shape == (B, 2880, 768)
+        assert eo.attention_mask.cpu()[:, ::576].tolist() == [[True] * 5, [True, True, True, False, False]]
+        seq = _strip(m.generate(encoder_outputs=eo, decoder_input_ids=prompt, special_token_ids=[PMT_SEP, BOS, SEP], max_length=L + P, bos_token_id=BOS,
+                                eos_token_id=None, pad_token_id=PAD, mask_token_id=PAD, num_beams=1, return_dict_in_generate=True,
+                                use_cache=True)["sequences"])
+        lg = _tf_logits(m, eo, seq[:, :-1], [PMT_SEP, BOS, SEP])[:, P - 1:]
+        first, safe, arg = _first_unsafe(lg, seq[:, P:])
+        assert float(safe.float().mean()) > 0.5 and torch.equal(arg[safe], seq[:, P:][safe])
+        # the masked images' content is irrelevant to the decode
+        from cxrmate_amd.modelling import ModelOutput
+        noisy = eo.last_hidden_state.clone()
+        noisy[1, 3 * 576:] = torch.randn_like(noisy[1, 3 * 576:])
+        seq2 = _strip(m.generate(encoder_outputs=ModelOutput(last_hidden_state=noisy, attention_mask=eo.attention_mask), decoder_input_ids=prompt,
+                                 special_token_ids=[PMT_SEP, BOS, SEP], max_length=L + P, bos_token_id=BOS, eos_token_id=None, pad_token_id=PAD,
+                                 mask_token_id=PAD, num_beams=1, return_dict_in_generate=True, use_cache=True)["sequences"])
+        assert torch.equal(seq2[1], seq[1])
+        # sample + greedy as one 4-row decode over the 2,880-key studies: greedy half == the separate call up to the first unsafe margin
+        torch.manual_seed(51)
+        smp, grd, rec = m.sample_and_greedy(eo, prompt, [BOS, SEP], [PMT_SEP, BOS, SEP], PAD, L + P, BOS, None, PAD, top_k=50)
+        grd = _strip(grd)
+        for r in range(B):
+            k = int(first[r])
+            assert torch.equal(grd[r, : P + k], seq[r, : P + k]), r

@@ -335,3 +335,19 @@ def test_longitudinal_c5_shape_matches_reference():
         loss = ogen.tf_cross_entropy(logits, lab, gu.PAD)
     assert gu.rel_rms(gu.sample(logits, 65536), g["logits_sample"]) < FP32_TOL
     assert abs(loss.item() - float(g["loss"])) < 1e-4
+
+
+def test_beam_safe_rows_are_told_apart_by_their_sequences():
+    """generate_beam_safe.npz: the recorded score tolerance (0.4 x the best / runner-up gap of a row) identifies the hypothesis inside a row. The rows
+    themselves are identified by pairwise-different best sequences (asserted by beam_safe_case); a score alone identifies the row only where the
+    tolerance is below the smallest row-to-row score distance: true for plain / lp2 / lp05, NOT for eos (0.0229 > 0.0118) -- stated, not hidden."""
+    g = gu.load("generate_beam_safe.npz")
+    for name in ("plain", "lp2", "lp05", "eos"):
+        c = gu.beam_safe_case(name)
+        assert c is not None
+        sc = c[6]
+        assert abs(float(g[f"{name}_score_tol"]) - 0.4 * float((sc[:, 0] - sc[:, 1]).min())) < 1e-7        # the tolerance IS the stated derivation
+        best = sc[:, 0]
+        dist = min(abs(float(best[i] - best[j])) for i in range(len(best)) for j in range(i))
+        assert abs(dist - float(g[f"{name}_row_dist"])) < 1e-7
+    assert [gu.beam_safe_rows_differ_by_score(n) for n in ("plain", "lp2", "lp05", "eos")] == [True, True, True, False]
