@@ -807,14 +807,15 @@ __device__ __forceinline__ void tn2_frag_issue(const unsigned lane_off, const un
 // WI = waves along I (8 / WI along J); i0 / j0 = first output row / column of the block. (NI, NJ, WI) = (3, 1, 4) is round 4's 384 x 128 block: the
 // CvT stage-3 gradients (384 x 384, 384 x 1536, 1536 x 384) are covered by EQUAL blocks -- as 256-blocks they were a mix of 256 x 256, 256 x 128
 // and 128 x 128 blocks with 4 : 2 : 1 work per workgroup, and the launch waited for the big ones.
-template <int NI, int NJ, int WI = 2>
+// NW = waves of the workgroup (8, or 4: round 5's co-resident form, gemm_tn4_kernel), NST = staging depth
+template <int NI, int NJ, int WI = 2, int NW = 8, int NST = 3>
 __device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char* lds, const int i0, const int j0, const bool bias_block, const int split) {
-    constexpr int BR = 32, TILE = BR * 256, NST = 3, LPS = NI + NJ, STAGE = (NI + NJ) * TILE;
-    constexpr int WJ = 8 / WI;
+    constexpr int BR = 32, TILE = BR * 256, SP = 8 / NW, LPS = (NI + NJ) * SP, STAGE = (NI + NJ) * TILE;      // SP = staging passes per sub-image
+    constexpr int WJ = NW / WI;
     constexpr int MI = NI * 8 / WI, MJ = NJ * 8 / WJ;              // 16 x 16 MFMA tiles of a wave: (128 NI / WI) x (128 NJ / WJ) outputs
-    static_assert((NI * 8) % WI == 0 && (NJ * 8) % WJ == 0 && MI % 2 == 0 && MJ >= 1 && MJ <= 4, "wave grid");
+    static_assert((NW == 8 || NW == 4) && (NI * 8) % WI == 0 && (NJ * 8) % WJ == 0 && MI % 2 == 0 && MJ >= 1 && MJ <= 4, "wave grid");
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 8 waves: WI (I) x WJ (J)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // NW waves: WI (I) x WJ (J)
     const int wi = wave % WI, wj = wave / WI;
     const int nrt = (g.R + BR - 1) / BR;
     const int rt0 = split * g.rt_per_split;
@@ -822,27 +823,31 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char
     const int nt = rt1 - rt0;
     if (nt <= 0) return;
 
-    // staging slot of a sub-image: slot = tid -> row = tid >> 4, physical chunk = tid & 15, logical chunk = physical ^ (gsw(row) << 1)
+    // staging slot of a sub-image: slot = pass * (64 NW) + tid -> row = slot >> 4, physical chunk = tid & 15, logical chunk = physical ^ (gsw(row) << 1)
+    // (gsw(row) only depends on row bits 0, 1, 3: with 4 waves the second pass is 16 rows further down and flips bit 4 only -- same column)
     const int srow = tid >> 4;
     const int scol = ((tid & 15) ^ (tn_gsw(srow) << 1)) * 8;
     const bf16_t* zr = reinterpret_cast<const bf16_t*>(g_tn_zero_row) + (tid & 15) * 8;
     auto stage = [&](int st, int rt) {
-        unsigned char* base = lds + st * STAGE + wave * 1024;
-        const long r = (long)rt * BR + srow;
-        const bool ok = r < g.R;
 #pragma unroll
-        for (int u = 0; u < NI; ++u) {
-            int c = i0 + u * 128 + scol; if (c >= g.I) c = 0;
-            const bf16_t* sp = ok ? g.P + r * g.ldp + c : zr;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
-                                             (__attribute__((address_space(3))) void*)(base + u * TILE), 16, 0, 0);
-        }
+        for (int ps = 0; ps < SP; ++ps) {
+            unsigned char* base = lds + st * STAGE + (ps * NW + wave) * 1024;
+            const long r = (long)rt * BR + srow + ps * (NW * 4);
+            const bool ok = r < g.R;
 #pragma unroll
-        for (int u = 0; u < NJ; ++u) {
-            int c = j0 + u * 128 + scol; if (c >= g.J) c = 0;
-            const bf16_t* sq = ok ? g.Q + r * g.ldq + c : zr;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sq,
-                                             (__attribute__((address_space(3))) void*)(base + (NI + u) * TILE), 16, 0, 0);
+            for (int u = 0; u < NI; ++u) {
+                int c = i0 + u * 128 + scol; if (c >= g.I) c = 0;
+                const bf16_t* sp = ok ? g.P + r * g.ldp + c : zr;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                                 (__attribute__((address_space(3))) void*)(base + u * TILE), 16, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < NJ; ++u) {
+                int c = j0 + u * 128 + scol; if (c >= g.J) c = 0;
+                const bf16_t* sq = ok ? g.Q + r * g.ldq + c : zr;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sq,
+                                                 (__attribute__((address_space(3))) void*)(base + (NI + u) * TILE), 16, 0, 0);
+            }
         }
     };
 
@@ -1012,6 +1017,38 @@ __global__ __launch_bounds__(512, 2) void gemm_tn3_kernel(const GemmTnArgs g, co
     gemm_tn2_body<3, 1, 4>(g, lds, bi * 384, bj * 128, bj == 0, split);
 }
 
+// ---- round 5: a weight-gradient workgroup that can SHARE a compute unit with a main-stream GEMM workgroup ---------------------------------------
+// gemm_tn2_kernel (8 waves x ~216 registers = 432 of a SIMD's 512, 96 KB of LDS) and gemm_nt_kernel (4 waves x ~240 registers, 64 KB) can never be
+// resident on the same SIMD: the weight-gradient stream takes WHOLE compute units from the main stream (a spatial partition decided by dispatch
+// order). This form is co-resident by construction: 4 waves (one per SIMD), <= 256 registers, 256 x 128 (or 128 x 256) outputs per workgroup =
+// the same 128 x 64 accumulators per wave as gemm_tn2_kernel, NST stages of 3 sub-images = 72 KB (NST 3) / 96 KB (NST 4): one of these + one
+// gemm_nt_kernel workgroup fit a CU (<= 496 registers per SIMD, <= 160 KB), so the matrix pipe of every SIMD is time-shared by one wave of each at
+// instruction granularity. Opt-in / default per the in-step alternation recorded in profiles/r05_*.
+template <int NST>
+__global__ __launch_bounds__(256, 2) void gemm_tn4_kernel(const GemmTnArgs g, const int blocks_j, const int wide_j) {
+    // NST stages x 3 sub-images of 8 KB, DYNAMIC: with a static 96-KB array hipcc derives "one workgroup per CU" from the LDS size and then ignores the
+    // register cap of __launch_bounds__ (293 registers: no main-stream wave fits beside it)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+    int swz;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int blocks = gridDim.x / g.splits;
+    const int split = swz / blocks, blk = swz % blocks;
+    const int bi = blk / blocks_j, bj = blk % blocks_j;
+    if (wide_j) {                                                   // 128 (I) x 256 (J) blocks: J is the dimension that is a multiple of 256
+        const int nj = g.J - bj * 256 > 128 ? 2 : 1;
+        if (nj == 2) gemm_tn2_body<1, 2, 1, 4, NST>(g, lds_dyn, bi * 128, bj * 256, bj == 0, split);
+        else gemm_tn2_body<1, 1, 2, 4, NST>(g, lds_dyn, bi * 128, bj * 256, bj == 0, split);
+    } else {                                                        // 256 (I) x 128 (J) blocks
+        const int ni = g.I - bi * 256 > 128 ? 2 : 1;
+        if (ni == 2) gemm_tn2_body<2, 1, 2, 4, NST>(g, lds_dyn, bi * 256, bj * 128, bj == 0, split);
+        else gemm_tn2_body<1, 1, 2, 4, NST>(g, lds_dyn, bi * 256, bj * 128, bj == 0, split);
+    }
+}
+
 // C[i][j] += sum of the splits' partial tiles, dbias likewise, in a FIXED order: SL lanes share one group of 4 columns, lane l sums the splits
 // congruent to l (ascending), a butterfly over the SL lanes finishes (small outputs have up to 176 splits: one thread walking them serially is a
 // chain of 176 dependent loads).
@@ -1116,7 +1153,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_batch_kernel(const TnRedBa
 }
 
 // Launch plan of a weight-gradient GEMM (shared by cxr_gemm_tn_bf16 and cxr_gemm_tn_plan)
-struct TnPlan { bool big; bool b384; int tiles_i, tiles_j, blocks_j, wgs_per_split, splits, rt_per_split; long need; };
+struct TnPlan { bool big; bool b384; bool co4; int wide_j; int tiles_i, tiles_j, blocks_j, wgs_per_split, splits, rt_per_split; long need; };
 static TnPlan tn_plan(int R, int I, int J) {
     TnPlan p;
     p.tiles_i = cdiv(I, 128); p.tiles_j = cdiv(J, 128);
@@ -1147,8 +1184,22 @@ static TnPlan tn_plan(int R, int I, int J) {
     if (tn3 < 0) { const char* e = getenv("CXR_TN3"); tn3 = (e && e[0] == '1') ? 1 : 0; }
     p.b384 = p.big && tn3 && (I % 384) == 0 && ((I % 256) != 0 || (J % 256) != 0);
     if (p.b384) p.blocks_j = cdiv(J, 128);
-    p.wgs_per_split = p.b384 ? (I / 384) * p.blocks_j : (p.big ? blocks : p.tiles_i * p.tiles_j);
-    int splits = cdiv(p.big ? target_big : target_wgs, p.wgs_per_split);
+    // round 5: the co-resident 4-wave form (gemm_tn4_kernel) for the shapes gemm_tn2_kernel takes. CXR_TN4=1 turns it on, CXR_TN4_WGS = workgroups a
+    // launch aims for (default 256: one per CU, beside one main-stream workgroup each), CXR_TN4_STAGES = 3 | 4
+    static int tn4 = -1, target_co4 = -1;
+    if (tn4 < 0) { const char* e = getenv("CXR_TN4"); tn4 = (e && e[0] == '1') ? 1 : 0; }
+    if (target_co4 < 0) { const char* e = getenv("CXR_TN4_WGS"); target_co4 = e ? atoi(e) : 256; if (target_co4 < 1) target_co4 = 256; }
+    p.co4 = p.big && !p.b384 && tn4;
+    p.wide_j = 0;
+    int blocks4 = 0;
+    if (p.co4) {
+        // 256 x 128 blocks along the dimension that splits evenly into 256s (equal blocks); I otherwise
+        p.wide_j = ((I % 256) != 0 && (J % 256) == 0) ? 1 : 0;
+        p.blocks_j = p.wide_j ? cdiv(J, 256) : cdiv(J, 128);
+        blocks4 = (p.wide_j ? cdiv(I, 128) : cdiv(I, 256)) * p.blocks_j;
+    }
+    p.wgs_per_split = p.co4 ? blocks4 : (p.b384 ? (I / 384) * p.blocks_j : (p.big ? blocks : p.tiles_i * p.tiles_j));
+    int splits = cdiv(p.co4 ? target_co4 : (p.big ? target_big : target_wgs), p.wgs_per_split);
     const int max_splits = nrt / 8 > 0 ? nrt / 8 : 1;      // at least 256 tokens per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -1196,7 +1247,19 @@ static int tn_launch(const void* P, long ldp, const void* Q, long ldq, float* C,
     if (det && g.splits > 1 && g.splits <= 192 && ws && ws_floats >= need && (J % 4) == 0) { g.mode = 2; g.ws = ws; g.wsb = ws + (long)g.splits * Ip * Jp; }
     static int stages = -1;                                // CXR_TN_STAGES = 2 | 4 (LDS 32 | 64 KB per workgroup)
     if (stages < 0) { const char* e = getenv("CXR_TN_STAGES"); stages = e ? atoi(e) : 4; }
-    if (pl.b384)          CXR_LAUNCH(gemm_tn3_kernel, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
+    static int st4 = -1;
+    if (st4 < 0) { const char* e = getenv("CXR_TN4_STAGES"); st4 = (e && atoi(e) == 4) ? 4 : 3; }
+    if (pl.co4) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_tn4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 24576);
+            (void)hipFuncSetAttribute((const void*)gemm_tn4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
+            attr_set = true;
+        }
+    }
+    if (pl.co4 && st4 == 4) CXR_LAUNCH(gemm_tn4_kernel<4>, dim3(tiles * g.splits), dim3(256), 4 * 24576, stream, g, blocks_j, pl.wide_j);
+    else if (pl.co4)      CXR_LAUNCH(gemm_tn4_kernel<3>, dim3(tiles * g.splits), dim3(256), 3 * 24576, stream, g, blocks_j, pl.wide_j);
+    else if (pl.b384)     CXR_LAUNCH(gemm_tn3_kernel, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
     else if (big)         CXR_LAUNCH(gemm_tn2_kernel, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
     else if (stages == 2) CXR_LAUNCH(gemm_tn_kernel<2>, dim3(tiles * g.splits), dim3(256), 0, stream, g);
     else                  CXR_LAUNCH(gemm_tn_kernel<4>, dim3(tiles * g.splits), dim3(256), 0, stream, g);

@@ -10,6 +10,8 @@ Label embeddings are cached per label tuple: the reference embeds the same label
 """
 from __future__ import annotations
 
+import time
+
 import torch
 
 from . import ops, weights
@@ -44,10 +46,13 @@ def load_cxr_bert_checkpoint(path):
 
 class CXRBERTReward:
     def __init__(self, device, tokenizer=None, config: BertConfig | None = None, state_dict=None, seed: int = 1, max_cache: int = 64,
-                 ckpt_dir: str | None = None):
+                 ckpt_dir: str | None = None, max_length: int | None = None):
         """`CXRBERTReward(device)` is the reference's signature (tools/rewards/cxrbert.py:11). The weights / tokenizer come from, in order:
         the `tokenizer=` / `state_dict=` arguments; a local checkpoint directory `ckpt_dir=` or $CXR_BERT_DIR (load_cxr_bert_checkpoint);
-        otherwise the seeded random-init stand-in without tokenizer (id-level entry points only: there is no Hub access here)."""
+        otherwise the seeded random-init stand-in without tokenizer (id-level entry points only: there is no Hub access here).
+        max_length: truncation length of the tokenizer call; None = the reference's `max_position_embeddings` (512, cxrbert.py:38). bench.py sets 128
+        ("decoded strings re-tokenised to a fixed R = 128 WordPiece ids") so that the string path and the synthetic-id path of the
+        SCST benchmark feed the reward BERT the same number of tokens."""
         import os
         self.device = torch.device(device)
         self.config = config or reward_config()
@@ -56,6 +61,7 @@ class CXRBERTReward:
             tokenizer, state_dict = load_cxr_bert_checkpoint(ckpt_dir)
             self.config.vocab_size = int(state_dict["bert.embeddings.word_embeddings.weight"].shape[0])
         self.tokenizer = tokenizer
+        self.max_length = max_length
         self.model = ParamStore(weights.bert_param_shapes(self.config, prefix=""), {}, self.device, trainable=lambda k: False)
         self.model.load_state_dict(state_dict if state_dict is not None else weights.init_reward(self.config, seed=seed))
         self.engine = BertEngine(self.model, self.config, prefix="")
@@ -78,9 +84,11 @@ class CXRBERTReward:
         # reference: tokenizer.batch_encode_plus(batch_text_or_text_pairs=...) (cxrbert.py:33-40); transformers 5 dropped that
         # spelling in favour of __call__ -- same arguments, same result
         kw = dict(add_special_tokens=True, padding="longest", return_tensors="pt", truncation=True,
-                  max_length=self.config.max_position_embeddings)
+                  max_length=self.max_length or self.config.max_position_embeddings)
         bep = getattr(self.tokenizer, "batch_encode_plus", None) if "batch_encode_plus" in dir(type(self.tokenizer)) else None
+        t0 = time.perf_counter()
         tok = bep(batch_text_or_text_pairs=texts, **kw) if bep is not None else self.tokenizer(texts, **kw)
+        self.last_tokenize_ms = (time.perf_counter() - t0) * 1e3               # host time of the tokenizer call (benchmarks report it)
         return self.embed_ids(tok.input_ids, tok.attention_mask)
 
     def reward(self, predictions, labels):
@@ -132,9 +140,11 @@ class ReportReward:
     def pair(self, sampled_host, greedy_host):
         """(reward of the sampled rows, reward of the greedy rows) from ONE tokenizer call and ONE 2B-row CXR-BERT forward; `last_sections` holds the
         greedy rows' sections afterwards (what the generated-prompt caller writes back)."""
+        t0 = time.perf_counter()
         _, fs, is_ = self.model.split_and_decode_sections(sampled_host, self.special, self.tokenizer)
         _, fg, ig = self.model.split_and_decode_sections(greedy_host, self.special, self.tokenizer)
         self.last_sections = (fg, ig)
+        self.last_decode_ms = (time.perf_counter() - t0) * 1e3                  # ids -> strings, both halves (host)
         both = self.reward.reward([f"{i} {j}" for i, j in zip(list(fs) + list(fg), list(is_) + list(ig))], self.labels + self.labels)
         B = len(fs)
         return both[:B], both[B:]

@@ -94,6 +94,12 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         logits, saved = model._dec.forward(tf_in, enc.contiguous(), enc_mask, mask, tt, pos, save=True, seed=rec.get("seed"),
                                            cross_kv=model._session_cross_kv(rec, enc), logit_from=P - 1)
 
+        B, _, V = logits.shape                                               # scores of the n_new sampling steps
+        if float(temperature) != 1.0:
+            raise NotImplementedError("temperature != 1 (the reference trains with 1.0)")
+        flat = logits.view(-1, V)
+        # (the warper threshold needs no reward either: queued in front of the host's string work)
+        thr = ops.topk_threshold(flat, int(top_k or 0), top_p, temperature) if (top_k or top_p < 1.0) else None
         # reward of the sampled and of the greedy reports. A reward_fn with `.pair(sampled, greedy)` scores both in ONE pass (one tokenizer call,
         # one 2B-row CXR-BERT forward: the two B-row forwards of a BERT-base are launch-bound, ~2.6 ms each)
         pair = getattr(reward_fn, "pair", None)
@@ -108,11 +114,6 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         # data parallel: the sampled / greedy sequences and their rewards of ALL ranks (RCCL all-gather over xGMI, <= 64 KB per rank) for the
         # global reward / baseline statistics the step reports; the advantage above stays per study, as in the reference (gt_prompt.py:129-132)
         glob = dp.gather_scst_statistics(sampled, base[:, P:].contiguous(), reward, baseline, pad, max_sampled=decoder_max_len, max_greedy=decoder_max_len)
-        B, _, V = logits.shape                                               # scores of the n_new sampling steps
-        if float(temperature) != 1.0:
-            raise NotImplementedError("temperature != 1 (the reference trains with 1.0)")
-        flat = logits.view(-1, V)
-        thr = ops.topk_threshold(flat, int(top_k or 0), top_p, temperature) if (top_k or top_p < 1.0) else None
         labels = sampled.reshape(-1)
         w = ops.ce_weights(labels, pad, mode=1, reward=adv, T=n_new)
         loss, _, dl = ops.softmax_ce(flat, labels, pad, w, thr=thr)

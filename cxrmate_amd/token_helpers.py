@@ -53,20 +53,58 @@ class TokenHelpers:
         return {"input_ids": input_ids, "attention_mask": attention_mask}
 
     def split_and_decode_sections(self, token_ids, special_token_ids, tokenizer):
-        """reference :413-457 (quirk Q9). One device->host copy for the whole batch instead of an .item() sync per row/section."""
-        ids = token_ids.detach().to("cpu")
-        _, seq_len = ids.shape
-        sections = {k: [] for k in range(len(special_token_ids))}
-        for row in ids:
+        """reference :413-457 (quirk Q9: a separator found at column 0 -- or not at all -- ends its section at the end of the row). One device->host
+        copy for the whole batch instead of an .item() sync per row/section; the separator columns of all rows come from one numpy comparison per
+        separator, and the B x len(special_token_ids) sections are decoded by ONE call into the `tokenizers` library (decode_many) instead of one
+        Python-level tokenizer.decode per section: inside an SCST step this host work runs while the GPU re-scores (scst.scst_step)."""
+        ids = token_ids.detach().to("cpu").numpy()
+        n_rows, seq_len = ids.shape
+        cols = []
+        for k in special_token_ids:
+            c = (ids == k).argmax(axis=1)
+            c[c == 0] = seq_len
+            cols.append(c.tolist())
+        pieces = []
+        for r in range(n_rows):
             prev_col = 0
-            for j, k in enumerate(special_token_ids):
+            row = ids[r]
+            for j in range(len(special_token_ids)):
                 if prev_col >= seq_len:
-                    sections[j].append("")
+                    pieces.append(None)                       # -> "" (the reference appends an empty string without decoding)
                     continue
-                col = int((row == k).int().argmax())
-                if col == 0:
-                    col = seq_len
-                section_token_ids = row[prev_col:col]
+                col = cols[j][r]
+                pieces.append(row[prev_col:col].tolist())
                 prev_col = col
-                sections[j].append(tokenizer.decode(section_token_ids, skip_special_tokens=True))
-        return tuple(sections.values())
+        texts = iter(decode_many(tokenizer, [p for p in pieces if p is not None]))
+        flat = ["" if p is None else next(texts) for p in pieces]
+        ns = len(special_token_ids)
+        return tuple([flat[r * ns + j] for r in range(n_rows)] for j in range(ns))
+
+
+def decode_many(tokenizer, sequences):
+    """[tokenizer.decode(s, skip_special_tokens=True) for s in sequences] -- the strings the reference's per-section calls produce -- through the
+    batch entry point of the Rust tokenizer when `tokenizer` is a stock fast tokenizer (PreTrainedTokenizerFast._decode = backend decode +
+    optional clean_up_tokenization: restated here over `decode_batch`), through the object's own `decode_many` if it has one, else one by one."""
+    if not sequences:
+        return []
+    own = getattr(tokenizer, "decode_many", None)
+    if own is not None:
+        return own(sequences)
+    backend = getattr(tokenizer, "backend_tokenizer", None)
+    if backend is not None and hasattr(backend, "decode_batch") and _stock_fast_decode(tokenizer):
+        texts = backend.decode_batch(sequences, skip_special_tokens=True)
+        if getattr(tokenizer, "clean_up_tokenization_spaces", False):
+            texts = [tokenizer.clean_up_tokenization(t) for t in texts]
+        return texts
+    return [tokenizer.decode(s, skip_special_tokens=True) for s in sequences]
+
+
+def _stock_fast_decode(tokenizer):
+    """The tokenizer's decode is transformers' own fast-tokenizer implementation (a subclass that overrides decode / _decode keeps its own path)."""
+    try:
+        import transformers
+        base = transformers.PreTrainedTokenizerFast
+    except Exception:
+        return False
+    cls = type(tokenizer)
+    return isinstance(tokenizer, base) and getattr(cls, "_decode", None) is getattr(base, "_decode", None) and cls.decode is base.decode

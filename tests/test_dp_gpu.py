@@ -321,3 +321,131 @@ def test_rccl_backend_executes_the_reducer_and_the_gather_at_world_1():
     assert abs(l32 - float(loss.item())) < 1e-6 and np.array_equal(w32, ref)        # fp32 wire at one rank: bit-identical step
     assert abs(l16 - float(loss.item())) < 1e-6 and np.abs(w16 - ref).max() < 2.5e-3   # bf16 wire: AdamW's first step is lr-sized (1e-3) whatever the gradient's last bits
     assert st["sampled"].shape == (2, 5) and st["greedy"].shape == (2, 6) and np.allclose(st["reward"], [0.1, 0.2]) and np.allclose(st["baseline"], [0.3, 0.4])
+
+
+def _rehearsal_worker(rank, world, path, q):
+    """One of EIGHT ranks sharing the one visible GPU (gloo on device tensors): two accumulated TF optimiser steps with the collective log, then
+    one train-mode SCST step on the same replica family (a longitudinal model of its own)."""
+    import torch.distributed as dist
+    from cxrmate_amd import modelling
+    from cxrmate_amd.scst import scst_step
+    from cxrmate_amd.training import FusedAdamW, tf_train_step
+    import time
+    t_start = time.time()
+
+    def phase(name):
+        if rank == 0 and os.environ.get("CXR_TEST_PHASES"):
+            print(f"[dp8 rank 0] {name}: {time.time() - t_start:.1f} s", flush=True)
+
+    try:
+        dist.init_process_group("gloo", init_method=f"file://{path}", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        phase("process group up")
+        cfg = gu.tiny_config(vocab_size=1000, decoder_layers=2, image_size=96)
+        m = modelling.SingleCXREncoderDecoderModel(cfg, device="cuda:0", seed=21, perturb=0.05)
+        opt = FusedAdamW(m, lr=1e-3)
+        phase("TF model built")
+        log = opt.reducer.log = []
+        g = torch.Generator().manual_seed(5)
+        px = torch.randn(2 * world, 3, 96, 96, generator=g)
+        ids = torch.randint(12, 1000, (2 * world, 17), generator=g)
+        ids[:, 0] = 1
+        marks = []
+        for step in range(2):
+            for j in range(2):                                        # accumulate=(j, 2): one study per micro-step and rank
+                sl = slice(rank * 2 + j, rank * 2 + j + 1)
+                inp, lab = ids[sl, :-1].cuda(), ids[sl, 1:].cuda()
+                tf_train_step(m, opt, px[sl].cuda(), inp, torch.ones_like(inp), m.token_ids_to_token_type_ids(inp, [3]), lab, pad_token_id=4, accumulate=(j, 2))
+                marks.append(len(log))
+        torch.cuda.synchronize()
+        phase("TF steps done")
+        tf_w = m.flat32[: m._param_total].detach().cpu().numpy().copy()
+        # SCST: per-rank study shard, per-rank random streams
+        cfl = gu.tiny_config(vocab_size=1000, decoder_layers=2, image_size=96, lora_r=8)
+        ml = modelling.LongitudinalPromptMultiCXREncoderDecoderModel(cfl, device="cuda:0", seed=33, perturb=0.05)
+        ml.train()
+        ml.graph_decode = False                                       # (eight captures of the same step graphs would only cost test time)
+        for p in ml.decoder.parameters():
+            p.requires_grad_(True)
+        optl = FusedAdamW(ml, lr=1e-3)
+        phase("SCST model built")
+        gi = torch.Generator().manual_seed(7)
+        images = torch.randn(2 * world, 2, 3, 96, 96, generator=gi)
+        prompt = torch.tensor([[8, 10, 9, 11, 1]] * 2, device="cuda")
+        torch.manual_seed(100 + rank)
+        out = scst_step(ml, optl, lambda t: (t % 2 == 0).float().mean(1), images[rank * 2: rank * 2 + 2].cuda(), prompt, None,
+                        dict(bos=1, eos=2, sep=3, pad=4, pmt_sep=9), decoder_max_len=10)
+        torch.cuda.synchronize()
+        gl = out["global"]
+        # (parameters only: the BatchNorm running statistics behind them are per-rank by design -- plain BN, no SyncBN, as in the reference)
+        q.put((rank, "ok", list(log), marks, tf_w, ml.flat32[: ml._param_total].detach().cpu().numpy().copy(), gl["sampled"].cpu().numpy(), gl["reward"].cpu().numpy(),
+               out["sampled"].cpu().numpy(), float(out["reward"])))
+    except Exception:                                                 # pragma: no cover
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_dp8_rehearsal_on_one_device():
+    """What can be proven about 8 ranks without an 8-GPU node (this build has never had one: NO scaling curve exists): EIGHT processes share the
+    one GPU (gloo on device tensors) and run the data-parallel TF step under accumulate=(j, 2) and the train-mode SCST step. Every rank issues the
+    same collective sequence (a different order deadlocks or mixes buckets on RCCL), the replicas are bit-identical afterwards, and
+    gather_scst_statistics returns 8 x B records in rank order. Reference: config/train/single_tf.yaml:8 (`strategy: ddp`), data/prompt.py:142-213."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as d:
+        procs = [ctx.Process(target=_rehearsal_worker, args=(r, world, os.path.join(d, "rdzv"), q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(120)
+    assert all(r[1] == "ok" for r in res), [r[2] for r in res if r[1] != "ok"][:1]
+    assert all(p.exitcode == 0 for p in procs)
+    _, _, log0, marks0, tfw0, sw0, gs0, gr0, _, rw0 = res[0]
+    assert marks0[0] == 0 and marks0[2] == marks0[1] and len(log0) == 2 * marks0[1] and marks0[1] == 4      # decoder | stage 2 + head | stage 1 | stage 0
+    for r in res[1:]:
+        assert r[2] == log0 and r[3] == marks0                          # identical collective order on all 8 ranks
+        assert np.array_equal(r[4], tfw0)                               # TF replicas bit-identical after two accumulated steps
+        assert np.array_equal(r[5], sw0)                                # SCST replicas (LoRA included) bit-identical
+        assert np.array_equal(r[6], gs0) and np.array_equal(r[7], gr0) and r[9] == rw0          # the same global view everywhere
+    assert gs0.shape[0] == 2 * world and gr0.shape[0] == 2 * world
+    for r in res:                                                       # rank order: rank r's own sampled rows sit at [2r, 2r + 2)
+        own = r[8]
+        assert np.array_equal(gs0[2 * r[0]: 2 * r[0] + 2, : own.shape[1]], own)
+    assert len({r[8].tobytes() for r in res}) > 1                        # per-rank random streams / studies
+
+
+def test_bench_gpus_8_rehearsal_and_refusal():
+    """`bench.py --gpus 8` end to end with 8 ranks on the one GPU (CXR_BENCH_REHEARSAL=1: tiny configuration; gloo; every rank on device 0): spawn_ranks
+    finds a port, hands each rank its slice of the host cores, the ranks rendezvous, run the TF and SCST keys with their all-reduces / gather, and
+    rank 0 prints ONE JSON line for n_gpus = 8 that says it is a rehearsal. A process group whose size is not N is refused."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CXR_BENCH_REHEARSAL="1", CXR_SINGLE_DEVICE="1", CXR_DIST_BACKEND="gloo", CXR_BENCH_PREWARM="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "2", "--seq-len", "16",
+                        "--scst-steps", "1", "--new-tokens", "9", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                               # ONE line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["rccl_ranks"] == 8 and out["config"]["global_batch"] == 16 and "rehearsal" in out
+    assert out["scaling"] == "weak" and out["value"] > 0 and np.isfinite(out["config"]["loss"])
+    assert out["scst"]["value"] and np.isfinite(out["scst"]["loss"])
+    # refusal: a one-rank environment asked for an 8-GPU number
+    env1 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env1, capture_output=True,
+                       text=True, timeout=600, cwd=root)
+    assert r.returncode != 0 and "refusing to report" in (r.stderr + r.stdout)
