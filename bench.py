@@ -623,8 +623,13 @@ def main():
     if aff and hasattr(os, "sched_setaffinity"):
         try:
             os.sched_setaffinity(0, {int(c) for c in aff.split(",") if c != ""})
+            # ... and as many CPU threads as the slice has cores: torch otherwise starts one per core of the HOST in every rank (eight ranks drawing
+            # their initial weights at once took 55 s each on a rehearsal box, oversubscribed 8 x)
+            torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
         except (OSError, ValueError):
             pass
+    elif int(os.environ.get("WORLD_SIZE", "1")) > 1 and hasattr(os, "sched_getaffinity"):
+        torch.set_num_threads(max(1, len(os.sched_getaffinity(0)) // int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]))))
     from cxrmate_amd import dp
     rank, local, world = dp.init_from_env()
     if world != args.gpus:

@@ -479,10 +479,70 @@ __device__ float topp_threshold_mass(const float* x, int V, float t_k, float top
     return fmaxf(ord2f(prefix), t_k);
 }
 
+// Round 5: the k-th largest of a row in ONE pass over it, for the shape the SCST re-scoring pass has (k = 50 of 30000, 4080 rows: the radix select
+// above reads the row twice and issues one LDS atomic per element into the 3-6 histogram bins a row of logits falls into: 342 us in the step for
+// 490 MB = 4x its byte floor). The row is held in REGISTERS (30 x 16-byte loads per thread, all in flight before the first use; order-preserving
+// integer keys). Every thread's own maximum is a candidate; the k-th largest of those 256 group maxima, m, is a LOWER bound of the row's k-th largest
+// (k of the maxima are >= m), so the answer lies among the entries >= m: ~k (1 + k / 256 / ...) of them for distinct values -- 55 for k = 50 -- which
+// are compacted into LDS and ranked by counting. Exact, ties included (an entry is the k-th largest iff fewer than k entries are greater and at
+// least k are greater or equal). Returns false (block-uniformly, nothing written) where the form does not apply or the candidate list overflows
+// (k > 128, rows wider than 30720 or not 16-byte aligned, long runs of equal values around the threshold): the radix select takes over.
+constexpr int K1_NV = 30, K1_CAP = 1024;
+__device__ bool kth_largest_onepass(const float* __restrict__ x, int V, int k, float* out, unsigned* gmax /*[256]*/, unsigned* cand /*[K1_CAP]*/,
+                                    unsigned* sh /*[3]*/) {
+    const int n4 = V >> 2;
+    if ((V & 3) != 0 || ((size_t)x & 15) != 0 || n4 < 256 || n4 > 256 * K1_NV || k < 1 || k > 128) return false;
+    const int tid = threadIdx.x;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    float4 f[K1_NV];
+#pragma unroll
+    for (int u = 0; u < K1_NV; ++u) { const int i = tid + 256 * u; f[u] = x4[i < n4 ? i : n4 - 1]; }
+    unsigned key[K1_NV * 4];
+    unsigned mx = 0u;
+#pragma unroll
+    for (int u = 0; u < K1_NV; ++u) {
+        const bool ok = tid + 256 * u < n4;                      // (key 0 is below the key of every float, -inf and NaNs included)
+        key[4 * u + 0] = ok ? f2ord(f[u].x) : 0u; key[4 * u + 1] = ok ? f2ord(f[u].y) : 0u;
+        key[4 * u + 2] = ok ? f2ord(f[u].z) : 0u; key[4 * u + 3] = ok ? f2ord(f[u].w) : 0u;
+        mx = max(max(mx, max(key[4 * u], key[4 * u + 1])), max(key[4 * u + 2], key[4 * u + 3]));
+    }
+    gmax[tid] = mx;
+    if (tid == 0) { sh[0] = 0u; sh[1] = 0u; sh[2] = 0u; }
+    __syncthreads();
+    {   // rank of this thread's maximum among the 256: the one(s) with  #greater < k <= #greater-or-equal  is m
+        int gt = 0, ge = 0;
+        const uint4* g4 = reinterpret_cast<const uint4*>(gmax);
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) {
+            const uint4 g = g4[j];
+            gt += (g.x > mx) + (g.y > mx) + (g.z > mx) + (g.w > mx);
+            ge += (g.x >= mx) + (g.y >= mx) + (g.z >= mx) + (g.w >= mx);
+        }
+        if (gt < k && k <= ge) sh[1] = mx;
+    }
+    __syncthreads();
+    const unsigned m = sh[1];
+#pragma unroll
+    for (int e = 0; e < K1_NV * 4; ++e)
+        if (key[e] >= m && key[e] != 0u) { const unsigned c = atomicAdd(&sh[0], 1u); if (c < (unsigned)K1_CAP) cand[c] = key[e]; }
+    __syncthreads();
+    const int n = (int)sh[0];
+    if (n > K1_CAP) return false;
+    for (int i = tid; i < n; i += 256) {
+        const unsigned my = cand[i];
+        int gt = 0, ge = 0;
+        for (int j = 0; j < n; ++j) { const unsigned c = cand[j]; gt += c > my; ge += c >= my; }
+        if (gt < k && k <= ge) sh[2] = my;
+    }
+    __syncthreads();
+    *out = ord2f(sh[2]);
+    return true;
+}
+
 __global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __restrict__ logits, long ld, int V, int k, float top_p, float invt,
                                                              float* __restrict__ thr) {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned bc[2];
+    __shared__ __attribute__((aligned(16))) unsigned hist[256];
+    __shared__ unsigned bc[4];
     __shared__ float cval[1024];
     __shared__ int cidx[1024];
     __shared__ int ncand;
@@ -490,7 +550,14 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __rest
     __shared__ float histf[256];
     __shared__ float sf[2];
     const float* x = logits + (long)blockIdx.x * ld;
-    float t = (k > 0 && k < V) ? kth_largest(x, V, k, hist, bc) : -INFINITY;
+    float t = -INFINITY;
+    if (k > 0 && k < V) {
+        if (!kth_largest_onepass(x, V, k, &t, hist, reinterpret_cast<unsigned*>(cval), bc)) {
+            __syncthreads();
+            t = kth_largest(x, V, k, hist, bc);
+        }
+        __syncthreads();
+    }
     if (top_p < 1.0f) {                                          // top-p on top of the top-k set: list form up to 1024 entries, mass radix select beyond
         if (threadIdx.x == 0) ncand = 0;
         __syncthreads();

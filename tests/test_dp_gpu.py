@@ -338,11 +338,15 @@ def _rehearsal_worker(rank, world, path, q):
             print(f"[dp8 rank 0] {name}: {time.time() - t_start:.1f} s", flush=True)
 
     try:
+        torch.set_num_threads(1)                                      # eight ranks share this host's cores
         dist.init_process_group("gloo", init_method=f"file://{path}", rank=rank, world_size=world)
         torch.cuda.set_device(0)
         phase("process group up")
         cfg = gu.tiny_config(vocab_size=1000, decoder_layers=2, image_size=96)
-        m = modelling.SingleCXREncoderDecoderModel(cfg, device="cuda:0", seed=21, perturb=0.05)
+        # (the seeded initial weights are drawn ONCE by the parent and read from its scratch directory: eight concurrent CPU initialisations of
+        # 28 M parameters took 55 s each)
+        m = modelling.SingleCXREncoderDecoderModel(cfg, device="cuda:0", seed=None)
+        m.load_state_dict(torch.load(os.path.join(os.path.dirname(path), "tf.pt")))
         opt = FusedAdamW(m, lr=1e-3)
         phase("TF model built")
         log = opt.reducer.log = []
@@ -362,7 +366,8 @@ def _rehearsal_worker(rank, world, path, q):
         tf_w = m.flat32[: m._param_total].detach().cpu().numpy().copy()
         # SCST: per-rank study shard, per-rank random streams
         cfl = gu.tiny_config(vocab_size=1000, decoder_layers=2, image_size=96, lora_r=8)
-        ml = modelling.LongitudinalPromptMultiCXREncoderDecoderModel(cfl, device="cuda:0", seed=33, perturb=0.05)
+        ml = modelling.LongitudinalPromptMultiCXREncoderDecoderModel(cfl, device="cuda:0", seed=None)
+        ml.load_state_dict(torch.load(os.path.join(os.path.dirname(path), "scst.pt")))
         ml.train()
         ml.graph_decode = False                                       # (eight captures of the same step graphs would only cost test time)
         for p in ml.decoder.parameters():
@@ -399,7 +404,11 @@ def test_dp8_rehearsal_on_one_device():
     world = 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
+    from cxrmate_amd import weights
     with tempfile.TemporaryDirectory() as d:
+        torch.save(weights.init_encoder_decoder(gu.tiny_config(vocab_size=1000, decoder_layers=2, image_size=96), seed=21, perturb=0.05), os.path.join(d, "tf.pt"))
+        torch.save(weights.init_encoder_decoder(gu.tiny_config(vocab_size=1000, decoder_layers=2, image_size=96, lora_r=8), seed=33, perturb=0.05),
+                   os.path.join(d, "scst.pt"))
         procs = [ctx.Process(target=_rehearsal_worker, args=(r, world, os.path.join(d, "rdzv"), q)) for r in range(world)]
         for p in procs:
             p.start()
@@ -432,10 +441,10 @@ def test_bench_gpus_8_rehearsal_and_refusal():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CXR_BENCH_REHEARSAL="1", CXR_SINGLE_DEVICE="1", CXR_DIST_BACKEND="gloo", CXR_BENCH_PREWARM="2")
+    env = dict(os.environ, CXR_BENCH_REHEARSAL="1", CXR_SINGLE_DEVICE="1", CXR_DIST_BACKEND="gloo", CXR_BENCH_PREWARM="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "2", "--seq-len", "16",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "0", "--batch", "2", "--seq-len", "16",
                         "--scst-steps", "1", "--new-tokens", "9", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

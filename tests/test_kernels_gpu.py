@@ -1377,6 +1377,33 @@ def test_token_ops_bit_exact(ops):
 
 
 # ------------------------------------------------------------------------------------------------ losses / selection
+def test_topk_threshold_one_pass_form_is_exact(ops):
+    """Round 5: the k-th largest of a row in ONE pass (row in registers, group maxima as a lower bound, candidates ranked by counting;
+    csrc/loss.hip kth_largest_onepass) at the shape of the SCST re-scoring pass (4080 x 30000, k = 50) and at its edges: bit-equal to torch.topk on
+    random rows, on rows with -inf entries (earlier warpers), with ties AT the threshold, with long runs of equal values around it (the candidate
+    list overflows: the radix select takes over), for k = 1 / 128 (one pass) and k = 129 (radix), and on a strided view."""
+    V, k = 30000, 50
+    g = torch.Generator().manual_seed(5)
+    big = (torch.randn(4080, V, generator=g) * 3).cuda()
+    assert torch.equal(ops.topk_threshold(big, k), torch.topk(big, k)[0][:, -1])
+    x = (torch.randn(16, V, generator=g) * 2).cuda()
+    x[0, 1000:] = float("-inf")                                       # only 1000 finite entries
+    x[1, :] = float("-inf"); x[1, 17] = 0.5; x[1, 29999] = -1.0      # fewer finite entries than k: the threshold is -inf
+    x[2, 5000:5040] = 7.25; x[2, 77] = 9.0                            # 40 tied entries straddle rank 50? (1 above + 40 tied = 41 < 50: below the ties)
+    x[3, 100:180] = 9.5                                               # 80 tied entries AT the threshold
+    x[4, :] = 1.0                                                      # every entry equal: candidate list overflows -> radix select
+    x[5, :] = torch.arange(V, device="cuda", dtype=torch.float32) * 1e-3          # sorted ascending
+    x[6, :] = torch.arange(V, 0, -1, device="cuda", dtype=torch.float32) * 1e-3    # sorted descending: every group maximum sits in the first loads
+    x[7, ::2] = -0.0; x[7, 1::2] = 0.0                                 # signed zeros: equal as floats, distinct as ordered keys (torch.topk compares values)
+    for kk in (1, 2, 50, 128, 129, 300):
+        got, want = ops.topk_threshold(x, kk), torch.topk(x, kk)[0][:, -1]
+        assert torch.equal(got[:7], want[:7]), (kk, got[:7], want[:7])
+        assert float(got[7]) == 0.0                                    # +0.0 or -0.0: the same float threshold
+    wide = torch.zeros(8, V + 40, device="cuda")
+    wide[:, 8:8 + V] = x[:8]
+    assert torch.equal(ops.topk_threshold(wide[:, 8:8 + V], k)[:7], torch.topk(x[:8], k)[0][:7, -1])       # (row base 32-byte aligned, ld = V + 40)
+
+
 def test_softmax_ce_and_reinforce(ops):
     R, V = 37, 30000
     logits = dev(rnd(R, V) * 2)
