@@ -394,7 +394,12 @@ def tf_bench(args, rank, world, dev, model, n_images, steps, profile_gemm):
     def eager_step():
         return tf_train_step(model, opt, px, inp, am, tt, lab, pad_token_id=4)
 
-    if not args.graph:
+    if os.environ.get("CXR_BENCH_SYNC_EACH") == "1":            # lab switch: the host does not run ahead of the GPU across steps
+        def step():
+            out = eager_step()
+            torch.cuda.synchronize()
+            return out
+    elif not args.graph:
         step = eager_step
     else:
         graphed = GraphedTFStep(model, opt, px, inp, am, tt, lab, pad_token_id=4)          # hipGraph capture (3 segments)

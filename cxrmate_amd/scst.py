@@ -22,6 +22,11 @@ from . import dp, ops
 
 
 _SIDE = {}
+# CXR_SCST_AHEAD=1: queue the re-scoring pass behind the decode WITHOUT reading the decoded sequences back first (the fused decode knows from the prompt
+# whether a BOS column has to be stripped). Measured in round 5 and left OFF: with everything of the step queued while the GPU still replays the decode
+# graphs, the part of the step behind the decode takes ~9.5 ms LONGER (synthetic-id step 103.9 -> 113.0 ms, three same-box alternations,
+# scripts/r5/call10.sh) -- the host round trip at the end of the decode is not what the step waits for.
+_SYNC_STRIP = __import__("os").environ.get("CXR_SCST_AHEAD") != "1"
 
 
 def _host_copies(tensors):
@@ -70,10 +75,9 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
             base = model.generate(encoder_outputs=eo, decoder_input_ids=prompt_ids, special_token_ids=[pmt_sep, bos, sep],
                                   max_length=decoder_max_len + P, bos_token_id=bos, eos_token_id=eos, pad_token_id=pad, mask_token_id=pad,
                                   num_beams=1, return_dict_in_generate=True, use_cache=True)["sequences"]
-        # strip the leading BOS column (gt_prompt.py:185-186). The fused decode knows from the PROMPT whether every row starts with it; reading the
-        # sequences back here would make the host wait for the whole decode before it can queue the re-scoring pass -- with EOS disabled (fixed
-        # length: the benchmark workload) nothing else needs the host until the rewards do, and the pass is queued while the GPU still decodes
-        known = rec.get("all_bos_first") if fused_decode else None
+        # strip the leading BOS column (gt_prompt.py:185-186): read back from the sequences (one host round trip at the end of the decode), or -- opt-in,
+        # see _SYNC_STRIP -- taken from what the fused decode learned from the prompt
+        known = rec.get("all_bos_first") if (fused_decode and not _SYNC_STRIP) else None
         if known if known is not None else bool(torch.all(seqs[:, 0] == bos)):
             seqs = seqs[:, 1:]
         if known if known is not None else bool(torch.all(base[:, 0] == bos)):

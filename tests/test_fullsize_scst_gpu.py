@@ -284,3 +284,57 @@ def test_five_image_studies_decode_like_teacher_forcing(model):
         for r in range(B):
             k = int(first[r])
             assert torch.equal(grd[r, : P + k], seq[r, : P + k]), r
+
+
+def test_five_image_studies_beam_search_and_a_training_step(model):
+    """The remaining consumers of a 2,880-key study (config/train/single_tf.yaml:13): beam-4 generation (the reference's test_step, modules/
+    lightning_modules/single.py:552-562) -- beams x studies rows share the study's cross-attention K / V above the one-workgroup kernel's 1,920-key
+    limit -- is replay-deterministic, agrees with the host-loop search in score, and its score IS the teacher-forced log-probability of the returned
+    hypothesis; and one teacher-forced optimisation step on 5-image studies (ragged) runs with finite loss and gradients."""
+    from cxrmate_amd import ops
+    m = model.eval()
+    B, N, L = 2, 5, 40
+    x = _images(B, N, 16)
+    x[1, 2:] = 0.0
+    prompt = _c4_prompt(B)
+    P = prompt.shape[1]
+    with torch.no_grad():
+        eo = m.encoder(x.cuda())
+        kw = dict(encoder_outputs=eo, decoder_input_ids=prompt, special_token_ids=[PMT_SEP, BOS, SEP], max_length=L + P, bos_token_id=BOS, eos_token_id=None,
+                  pad_token_id=PAD, mask_token_id=PAD, num_beams=4, return_dict_in_generate=True, use_cache=True, output_scores=True)
+        d1 = m.generate(**kw)
+        d2 = m.generate(**kw)
+        assert torch.equal(d1["sequences"], d2["sequences"]) and torch.equal(d1["sequences_scores"], d2["sequences_scores"])
+        m.device_beam_search = False
+        try:
+            h = m.generate(**kw)
+        finally:
+            m.device_beam_search = True
+        torch.testing.assert_close(d1["sequences_scores"], h["sequences_scores"], atol=0.05, rtol=0)
+        s = _strip(d1["sequences"])
+        assert s.shape == (B, P + L) and int(s.max()) < 30000 and int(s.min()) >= 0 and torch.equal(s[:, :P], prompt)
+        lp = torch.log_softmax(_tf_logits(m, eo, s[:, :-1], [PMT_SEP, BOS, SEP])[:, P - 1:].float(), -1)
+        tok = lp.gather(2, s[:, P:, None])[..., 0].sum(1)
+        n_gen = s.shape[1] - P
+        # transformers normalises by the hypothesis length INCLUDING the prompt (generation/utils.py _beam_search: cur_len ** length_penalty)
+        got = d1["sequences_scores"].float()
+        cand = [tok / float(n_gen), tok / float(d1["sequences"].shape[1]), tok / float(s.shape[1])]
+        assert any(torch.allclose(got, c, atol=0.05, rtol=0) for c in cand), (got, [c.tolist() for c in cand])
+    # one teacher-forced optimisation step on the same ragged 5-image studies
+    from cxrmate_amd.training import FusedAdamW, tf_train_step
+    m.train()
+    try:
+        opt = FusedAdamW(m, lr=1e-5)
+        g = torch.Generator().manual_seed(3)
+        T = 32
+        full = torch.randint(12, 30000, (B, T + 1), generator=g)
+        full[:, 0] = 1
+        inp, lab = full[:, :-1].cuda(), full[:, 1:].contiguous().cuda()
+        mask, pos = ops.mask_position_ids(inp, PAD)
+        tt = m.token_ids_to_token_type_ids(inp, [PMT_SEP, BOS, SEP], [0, 1, 0, 1])
+        l0 = float(tf_train_step(m, opt, x.cuda(), inp, mask, tt, lab, PAD, decoder_position_ids=pos).item())
+        torch.cuda.synchronize()
+        gdec = m.gflat[opt.split: m._param_total]
+        assert np.isfinite(l0) and bool(torch.isfinite(gdec).all()) and float(gdec.abs().max()) > 0
+    finally:
+        m.eval()
