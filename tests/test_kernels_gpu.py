@@ -1399,6 +1399,10 @@ def test_topk_threshold_one_pass_form_is_exact(ops):
         got, want = ops.topk_threshold(x, kk), torch.topk(x, kk)[0][:, -1]
         assert torch.equal(got[:7], want[:7]), (kk, got[:7], want[:7])
         assert float(got[7]) == 0.0                                    # +0.0 or -0.0: the same float threshold
+    for Vw in (1000, 1024, 1028, 4096, 30720, 30724):                  # both edges of the one-pass form's width range (1024 .. 30720, multiples of 4)
+        y = (torch.randn(5, Vw, generator=g) * 2).cuda()
+        for kk in (1, 50, 128):
+            assert torch.equal(ops.topk_threshold(y, kk), torch.topk(y, kk)[0][:, -1]), (Vw, kk)
     wide = torch.zeros(8, V + 40, device="cuda")
     wide[:, 8:8 + V] = x[:8]
     assert torch.equal(ops.topk_threshold(wide[:, 8:8 + V], k)[:7], torch.topk(x[:8], k)[0][:7, -1])       # (row base 32-byte aligned, ld = V + 40)
