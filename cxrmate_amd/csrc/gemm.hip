@@ -808,7 +808,8 @@ __device__ __forceinline__ void tn2_frag_issue(const unsigned lane_off, const un
 // CvT stage-3 gradients (384 x 384, 384 x 1536, 1536 x 384) are covered by EQUAL blocks -- as 256-blocks they were a mix of 256 x 256, 256 x 128
 // and 128 x 128 blocks with 4 : 2 : 1 work per workgroup, and the launch waited for the big ones.
 // NW = waves of the workgroup (8, or 4: round 5's co-resident form, gemm_tn4_kernel), NST = staging depth
-template <int NI, int NJ, int WI = 2, int NW = 8, int NST = 3>
+// AUX = cache policy of the staging loads (0 default, 2 = non-temporal: lab switch CXR_TN_NT=1, round 5)
+template <int NI, int NJ, int WI = 2, int NW = 8, int NST = 3, int AUX = 0>
 __device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char* lds, const int i0, const int j0, const bool bias_block, const int split) {
     constexpr int BR = 32, TILE = BR * 256, SP = 8 / NW, LPS = (NI + NJ) * SP, STAGE = (NI + NJ) * TILE;      // SP = staging passes per sub-image
     constexpr int WJ = NW / WI;
@@ -839,14 +840,14 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char
                 int c = i0 + u * 128 + scol; if (c >= g.I) c = 0;
                 const bf16_t* sp = ok ? g.P + r * g.ldp + c : zr;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
-                                                 (__attribute__((address_space(3))) void*)(base + u * TILE), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(base + u * TILE), 16, 0, AUX);
             }
 #pragma unroll
             for (int u = 0; u < NJ; ++u) {
                 int c = j0 + u * 128 + scol; if (c >= g.J) c = 0;
                 const bf16_t* sq = ok ? g.Q + r * g.ldq + c : zr;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sq,
-                                                 (__attribute__((address_space(3))) void*)(base + (NI + u) * TILE), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(base + (NI + u) * TILE), 16, 0, AUX);
             }
         }
     };
@@ -984,6 +985,7 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char
     }
 }
 
+template <int AUX>
 __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(const GemmTnArgs g, const int blocks_j) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * 4 * 32 * 256];      // 3 stages x (2 + 2) sub-images = 96 KB
     int swz;
@@ -996,10 +998,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(const GemmTnArgs g, co
     const int split = swz / blocks, blk = swz % blocks;
     const int bi = blk / blocks_j, bj = blk % blocks_j;
     const int ni = g.I - bi * 256 > 128 ? 2 : 1, nj = g.J - bj * 256 > 128 ? 2 : 1;      // block-uniform
-    if (ni == 2 && nj == 2) gemm_tn2_body<2, 2>(g, lds, bi * 256, bj * 256, bj == 0, split);
-    else if (ni == 2) gemm_tn2_body<2, 1>(g, lds, bi * 256, bj * 256, bj == 0, split);
-    else if (nj == 2) gemm_tn2_body<1, 2>(g, lds, bi * 256, bj * 256, bj == 0, split);
-    else gemm_tn2_body<1, 1>(g, lds, bi * 256, bj * 256, bj == 0, split);
+    if (ni == 2 && nj == 2) gemm_tn2_body<2, 2, 2, 8, 3, AUX>(g, lds, bi * 256, bj * 256, bj == 0, split);
+    else if (ni == 2) gemm_tn2_body<2, 1, 2, 8, 3, AUX>(g, lds, bi * 256, bj * 256, bj == 0, split);
+    else if (nj == 2) gemm_tn2_body<1, 2, 2, 8, 3, AUX>(g, lds, bi * 256, bj * 256, bj == 0, split);
+    else gemm_tn2_body<1, 1, 2, 8, 3, AUX>(g, lds, bi * 256, bj * 256, bj == 0, split);
 }
 
 // 384 x 128 blocks (I a multiple of 384): see gemm_tn2_body
@@ -1247,6 +1249,8 @@ static int tn_launch(const void* P, long ldp, const void* Q, long ldq, float* C,
     if (det && g.splits > 1 && g.splits <= 192 && ws && ws_floats >= need && (J % 4) == 0) { g.mode = 2; g.ws = ws; g.wsb = ws + (long)g.splits * Ip * Jp; }
     static int stages = -1;                                // CXR_TN_STAGES = 2 | 4 (LDS 32 | 64 KB per workgroup)
     if (stages < 0) { const char* e = getenv("CXR_TN_STAGES"); stages = e ? atoi(e) : 4; }
+    static int tn_nt = -1;                                  // CXR_TN_NT=1: non-temporal operand loads in gemm_tn2_kernel (lab, round 5)
+    if (tn_nt < 0) { const char* e = getenv("CXR_TN_NT"); tn_nt = (e && e[0] == '1') ? 1 : 0; }
     static int st4 = -1;
     if (st4 < 0) { const char* e = getenv("CXR_TN4_STAGES"); st4 = (e && atoi(e) == 4) ? 4 : 3; }
     if (pl.co4) {
@@ -1260,7 +1264,8 @@ static int tn_launch(const void* P, long ldp, const void* Q, long ldq, float* C,
     if (pl.co4 && st4 == 4) CXR_LAUNCH(gemm_tn4_kernel<4>, dim3(tiles * g.splits), dim3(256), 4 * 24576, stream, g, blocks_j, pl.wide_j);
     else if (pl.co4)      CXR_LAUNCH(gemm_tn4_kernel<3>, dim3(tiles * g.splits), dim3(256), 3 * 24576, stream, g, blocks_j, pl.wide_j);
     else if (pl.b384)     CXR_LAUNCH(gemm_tn3_kernel, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
-    else if (big)         CXR_LAUNCH(gemm_tn2_kernel, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
+    else if (big && tn_nt) CXR_LAUNCH(gemm_tn2_kernel<2>, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
+    else if (big)         CXR_LAUNCH(gemm_tn2_kernel<0>, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
     else if (stages == 2) CXR_LAUNCH(gemm_tn_kernel<2>, dim3(tiles * g.splits), dim3(256), 0, stream, g);
     else                  CXR_LAUNCH(gemm_tn_kernel<4>, dim3(tiles * g.splits), dim3(256), 0, stream, g);
     if (g.mode == 2 && pending) {
