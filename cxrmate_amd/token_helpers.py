@@ -81,21 +81,31 @@ class TokenHelpers:
         return tuple([flat[r * ns + j] for r in range(n_rows)] for j in range(ns))
 
 
+_NO_BATCH_DECODE = set()        # ids of tokenizer objects whose batch path disagreed with tokenizer.decode once (kept on the per-sequence path)
+
+
 def decode_many(tokenizer, sequences):
     """[tokenizer.decode(s, skip_special_tokens=True) for s in sequences] -- the strings the reference's per-section calls produce -- through the
     batch entry point of the Rust tokenizer when `tokenizer` is a stock fast tokenizer (PreTrainedTokenizerFast._decode = backend decode +
-    optional clean_up_tokenization: restated here over `decode_batch`), through the object's own `decode_many` if it has one, else one by one."""
+    clean_up_tokenization where the tokenizer asks for it: restated here over `decode_batch`), through the object's own `decode_many` if it has
+    one, else one by one. The restatement is CHECKED on every call: the first sequence is also decoded by tokenizer.decode itself, and a tokenizer
+    whose result differs (another transformers version with other post-processing) stays on the per-sequence path from then on."""
     if not sequences:
         return []
     own = getattr(tokenizer, "decode_many", None)
     if own is not None:
         return own(sequences)
     backend = getattr(tokenizer, "backend_tokenizer", None)
-    if backend is not None and hasattr(backend, "decode_batch") and _stock_fast_decode(tokenizer):
+    if backend is not None and hasattr(backend, "decode_batch") and id(tokenizer) not in _NO_BATCH_DECODE and _stock_fast_decode(tokenizer):
         texts = backend.decode_batch(sequences, skip_special_tokens=True)
         if getattr(tokenizer, "clean_up_tokenization_spaces", False):
-            texts = [tokenizer.clean_up_tokenization(t) for t in texts]
-        return texts
+            # transformers >= 5 skips the WordPiece-style clean-up for BPE models unless explicitly told otherwise (tokenization_utils_tokenizers._decode)
+            bpe = type(backend.model).__name__ == "BPE"
+            if not bpe or getattr(tokenizer, "clean_up_tokenization_spaces_for_bpe_even_though_it_will_corrupt_output", False):
+                texts = [tokenizer.clean_up_tokenization(t) for t in texts]
+        if texts[0] == tokenizer.decode(sequences[0], skip_special_tokens=True):
+            return texts
+        _NO_BATCH_DECODE.add(id(tokenizer))
     return [tokenizer.decode(s, skip_special_tokens=True) for s in sequences]
 
 

@@ -364,3 +364,60 @@ def test_debug_switches_in_the_product_path_are_loud(monkeypatch):
     r = subprocess.run([sys.executable, "-W", "always", "-c", code], env=dict(env, CXR_DEBUG_TIMING="1"), capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "NO Linear weight gradient" in r.stderr
+
+
+def test_batch_section_decode_equals_the_per_section_decode_for_wordpiece_and_bpe_tokenizers():
+    """token_helpers.split_and_decode_sections decodes all sections of a batch through ONE call into the tokenizers library (decode_many). The
+    strings must be the ones the reference's per-section `tokenizer.decode(ids, skip_special_tokens=True)` produces (modelling_longitudinal.py:
+    413-457) -- for the byte-BPE report tokenizer of the fixtures and for a WordPiece tokenizer with clean_up_tokenization_spaces=True (the
+    CXR-BERT kind: BertTokenizerFast's default), whose post-processing the batch path restates; a tokenizer the restatement does not reproduce
+    falls back to the per-sequence path."""
+    import tokenizers
+    import transformers
+    from cxrmate_amd import token_helpers as th
+
+    def per_section(token_ids, special_token_ids, tokenizer):               # the reference's loop, restated on CPU tensors
+        sections = {k: [] for k in range(len(special_token_ids))}
+        seq_len = token_ids.shape[1]
+        for row in token_ids:
+            prev = 0
+            for j, k in enumerate(special_token_ids):
+                if prev >= seq_len:
+                    sections[j].append("")
+                    continue
+                col = int((row == k).int().argmax())
+                col = seq_len if col == 0 else col
+                sections[j].append(tokenizer.decode(row[prev:col], skip_special_tokens=True))
+                prev = col
+        return tuple(sections.values())
+
+    class H(th.TokenHelpers):
+        device = torch.device("cpu")
+
+    bpe = transformers.PreTrainedTokenizerFast(tokenizer_file=os.path.join(os.path.dirname(__file__), "golden", "tokenizer.json"), unk_token="[UNK]", pad_token="[PAD]",
+                                               cls_token="[BOS]", sep_token="[SEP]", mask_token="[MASK]", bos_token="[BOS]", eos_token="[EOS]")
+    words = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "the", "lungs", "are", "clear", ".", ",", "no", "pleural", "effusion", "##s", "##ly", "heart", "size",
+             "is", "normal", "'", "s", "(", ")", "pneumo", "##thorax", "!", "?", "do", "n", "t"]
+    wp = tokenizers.Tokenizer(tokenizers.models.WordPiece({w: i for i, w in enumerate(words)}, unk_token="[UNK]"))
+    wp.pre_tokenizer = tokenizers.pre_tokenizers.BertPreTokenizer()
+    wp.decoder = tokenizers.decoders.WordPiece(prefix="##", cleanup=False)
+    wpt = transformers.PreTrainedTokenizerFast(tokenizer_object=wp, unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]", sep_token="[SEP]", mask_token="[MASK]",
+                                               clean_up_tokenization_spaces=True)
+    g = torch.Generator().manual_seed(3)
+    for tok, hi, special in ((bpe, len(bpe), [1, 3, 2]), (wpt, len(words), [2, 3, 0])):
+        ids = torch.randint(0, hi, (12, 40), generator=g)
+        ids[0, 0] = special[0]                                               # a separator at column 0 (quirk Q9), rows with none, rows with all
+        ids[1, :] = torch.randint(5, hi, (40,), generator=g)
+        ids[2, 7], ids[2, 19], ids[2, 33] = special
+        want = per_section(ids, special, tok)
+        got = H().split_and_decode_sections(ids, special, tok)
+        assert got == want, (type(tok.backend_tokenizer.model).__name__,)
+        assert id(tok) not in th._NO_BATCH_DECODE                          # ... and it WAS the batch path that produced them
+    assert any(" ." not in s_ and s_ for s_ in H().split_and_decode_sections(torch.tensor([[5, 6, 7, 8, 9, 3, 11, 12, 13, 14, 9, 0]]), [3, 0], wpt)[0])     # clean-up applied
+
+    class Odd(transformers.PreTrainedTokenizerFast):                          # a subclass with its own decode keeps its own path
+        def decode(self, token_ids, **kw):
+            return "odd:" + super().decode(token_ids, **kw)
+
+    odd = Odd(tokenizer_object=wp, unk_token="[UNK]", pad_token="[PAD]")
+    assert th.decode_many(odd, [[5, 6], [7, 8]]) == ["odd:the lungs", "odd:are clear"]
