@@ -11,7 +11,9 @@ BASELINE.json `metric` = "SCST steps/sec + TF tokens/sec/GPU, 2-image 384x384 st
     model.train(), bf16 MFMA with fp32 accumulation and fp32 master weights, synthetic data, random-init weights. Weak scaling (pure data
     parallel, study-level sharding), gradients all-reduced over RCCL.
   * `scst`: SCST steps/s at the per-GPU shape of configs[3] (16 studies x 2 images, 255 sampled + 255 greedy tokens, CXR-BERT stand-in reward,
-    REINFORCE + AdamW on the decoder), with the roofline of its cached decode token-step.
+    REINFORCE + AdamW on the decoder), with the roofline of its cached decode token-step. Since round 5 its `value` is the reference's own step --
+    generated ids -> strings -> tokenizer -> reward at R = 128 reward tokens (scst/gt_prompt.py:90-91,120-128,192-197) -- and the step with
+    synthetic reward ids in place of the string round trip (rounds 1-4) stands beside it as `scst.synthetic_ids`.
   * `tf_single`: configs[1] (single-image studies, batch 32), `forward_only`: bf16 MFMA utilisation of the encoder + decoder FORWARD (the
     north_star's >= 40 % target is defined on it), `cpu_baseline`: the oracle/ restatement of the reference path on the host cores.
 Prints ONE JSON line on rank 0.
