@@ -240,10 +240,8 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
     if not c5 and not REHEARSAL:
         try:
             strings = scst_string_round_trip(args, model, opt, images, prompt, special, dev, B, steps=steps, world=world)
-        except Exception as e:                                    # transformers / the fixture tokenizer missing: the synthetic-id number stands alone
-            if world > 1:
-                raise
-            strings = {"error": str(e)}
+        except Exception as e:                                    # transformers / the fixture tokenizer missing (the same on every rank): the synthetic-id
+            strings = {"error": str(e)}                           # number stands alone and `headline_is` says so
     n_tok = args.new_tokens
     dec_ms = e0.elapsed_time(e1)
     t_ctx = prompt.shape[1] + n_tok / 2.0                          # mean self-attention context over the decode
