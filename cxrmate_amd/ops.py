@@ -372,6 +372,7 @@ def wgrad_discard():
     _SIDE_DEFERRED.clear()
     _SIDE_PENDING.clear()
     _TN_PENDING.clear()
+    _TN_PENDING_PTRS.clear()
     for ar in _TN_ARENA.values():
         ar[1] = ar[2] = 0
 
