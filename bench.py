@@ -333,22 +333,7 @@ def beam_bench(args, dev, host_loop_too=True):
     return res
 
 
-class _InVocabTokenizer:
-    """The synthetic byte-BPE tokenizer of tests/golden (400 entries, reference id layout) in front of a random-init model that emits ids up to
-    30000: ids are folded into the vocabulary before decoding so that every generated token becomes text."""
-
-    def __init__(self, tok):
-        self.tok, self.n = tok, len(tok)
-
-    def decode(self, ids, skip_special_tokens=True):
-        ids = [int(i) for i in ids]
-        return self.tok.decode([i if i < 12 else 12 + (i - 12) % (self.n - 12) for i in ids], skip_special_tokens=skip_special_tokens)
-
-    def decode_many(self, sequences):
-        """token_helpers.decode_many hook: all sections of a batch through ONE call into the `tokenizers` library (this fixture tokenizer does
-        no clean-up of tokenisation spaces, so the backend's strings are decode()'s strings)."""
-        n = self.n
-        return self.tok.backend_tokenizer.decode_batch([[i if i < 12 else 12 + (i - 12) % (n - 12) for i in s_] for s_ in sequences], skip_special_tokens=True)
+from cxrmate_amd.strings import FoldedVocabTokenizer as _InVocabTokenizer      # the 400-entry fixture byte-BPE in front of a random-init model that emits ids up to 30000
 
 
 def scst_string_round_trip(args, model, opt, images, prompt, special, dev, B, steps=3, world=1):
@@ -365,20 +350,29 @@ def scst_string_round_trip(args, model, opt, images, prompt, special, dev, B, st
                                                eos_token="[EOS]")
     reward = CXRBERTReward(dev, tokenizer=tok, seed=1, max_length=128)
     labels = [["The lungs are clear without focal consolidation. No pleural effusion or pneumothorax. No acute cardiopulmonary process."]] * B
-    rfn = ReportReward(model, _InVocabTokenizer(tok), reward, labels, 1, 3, 2)
+    # CXR_STRING_WORKER=1: the CPU part of the reward (ids -> strings -> reward-tokenizer ids) in a child process, beside this process's kernel launches
+    # (reward.ReportReward(worker=True)). Default: in-process -- three same-box alternations put the child process at -1.4 ms +- 2 ms per step (scripts/r5/call18.sh): inside the noise
+    rfn = ReportReward(model, _InVocabTokenizer(tok), reward, labels, 1, 3, 2, worker=os.environ.get("CXR_STRING_WORKER", "0") == "1")
 
     def step():
         return scst_step(model, opt, rfn, images, prompt, None, special, decoder_max_len=args.new_tokens + 1, reward_on_host=True)
 
-    step()
-    dt, out = timed(step, steps, world, dev)
+    try:
+        step()
+        used0 = rfn.worker_used
+        dt, out = timed(step, steps, world, dev)
+        served = rfn.worker_used - used0
+    finally:
+        rfn.close()
     dt /= steps
     return {"ms_per_step": dt * 1e3, "steps_per_sec": world / dt, "steps": steps, "loss": float(out["loss"].item()), "reward_tokens": 128,
-            "host_ms": {"ids_to_strings": getattr(rfn, "last_decode_ms", None), "strings_to_ids": getattr(reward, "last_tokenize_ms", None)},
-            "what": "scst_step(reward_on_host=True) with reward.ReportReward: async pinned copies of the sequences, all sections of a half decoded by one "
-                    "call into the tokenizers library, both halves re-tokenised by one call (truncated to R = 128) and scored by one 32-row CXR-BERT forward "
-                    "while the re-scoring forward + warper threshold run on the GPU, label embeddings cached; synthetic byte-BPE tokenizer "
-                    "(tests/golden/tokenizer.json) on the random-init model's strings"}
+            "string_worker": {"steps_served_by_the_child_process": served, "of": steps},
+            "host_ms": {"ids_to_strings": getattr(rfn, "last_decode_ms", None), "strings_to_ids": getattr(reward, "last_tokenize_ms", None),
+                        "note": "in-process path only (the child process does this work when it serves a step)"},
+            "what": "scst_step(reward_on_host=True) with reward.ReportReward: async pinned copies of the sequences; all sections decoded by one call into the tokenizers "
+                    "library and both halves re-tokenised by one call (truncated to R = 128) -- in this process, or with CXR_STRING_WORKER=1 in a child process "
+                    "(strings.StringWorker) beside the launches of the re-scoring forward + warper threshold --, token ids uploaded through a pinned staging buffer, "
+                    "one 32-row CXR-BERT forward, label embeddings cached; synthetic byte-BPE tokenizer (tests/golden/tokenizer.json) on the random-init model's strings"}
 
 
 def tf_bench(args, rank, world, dev, model, n_images, steps, profile_gemm):

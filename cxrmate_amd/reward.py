@@ -75,16 +75,53 @@ class CXRBERTReward:
     @torch.no_grad()
     def embed_ids(self, input_ids, attention_mask):
         """ids/mask [B,R] -> projected CLS embedding fp32 [B,128]  (tuple element [2] of the reference call, cxrbert.py:42-47)."""
-        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
-        mask = attention_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        ids, mask = self._to_device(input_ids, torch.int64, 0), self._to_device(attention_mask, torch.uint8, 1)
         hidden, _ = self.engine.forward(ids, attn_mask=mask, causal=False, lm_head=False)
         return self.engine.cls_projection(hidden)
+
+    def _to_device(self, t, dtype, slot):
+        """Host tensors (the tokenizer's output) go up through a PINNED staging buffer with an asynchronous copy: `.to(device)` from pageable memory
+        makes the host wait for everything queued on the stream -- inside an SCST step that is the whole re-scoring forward, and the reward's own
+        launches then start late (measured: 2 ms per step). The buffer is reused once the previous copy out of it has completed (event)."""
+        if t.is_cuda:
+            return t.to(device=self.device, dtype=dtype).contiguous()
+        if self.device.type != "cuda":
+            return t.to(dtype=dtype).contiguous()
+        t = t.to(dtype=dtype).contiguous()
+        st = self.__dict__.setdefault("_staging", {})
+        buf, ev = st.get(slot, (None, None))
+        if buf is None or buf.numel() < t.numel() or buf.dtype != dtype:
+            buf = torch.empty(max(t.numel(), 1 << 14), dtype=dtype, pin_memory=True)
+            ev = torch.cuda.Event()
+        else:
+            ev.synchronize()
+        view = buf[: t.numel()].view(t.shape)
+        view.copy_(t)
+        out = view.to(self.device, non_blocking=True)
+        ev.record()
+        st[slot] = (buf, ev)
+        return out
+
+    def encode_kw(self, return_tensors="pt"):
+        """Arguments of the reference's tokenizer call (tools/rewards/cxrbert.py:33-40)."""
+        return dict(add_special_tokens=True, padding="longest", return_tensors=return_tensors, truncation=True,
+                    max_length=self.max_length or self.config.max_position_embeddings)
+
+    def label_embeddings(self, labels):
+        """Projected CLS embeddings of the label strings, cached per label tuple (the reference embeds the same labels twice per SCST step)."""
+        flat = tuple(j for i in labels for j in i)
+        lab = self._label_cache.get(flat)
+        if lab is None:
+            lab = self._encode(list(flat))
+            if len(self._label_cache) >= self._max_cache:
+                self._label_cache.clear()
+            self._label_cache[flat] = lab
+        return lab
 
     def _encode(self, texts):
         # reference: tokenizer.batch_encode_plus(batch_text_or_text_pairs=...) (cxrbert.py:33-40); transformers 5 dropped that
         # spelling in favour of __call__ -- same arguments, same result
-        kw = dict(add_special_tokens=True, padding="longest", return_tensors="pt", truncation=True,
-                  max_length=self.max_length or self.config.max_position_embeddings)
+        kw = self.encode_kw()
         bep = getattr(self.tokenizer, "batch_encode_plus", None) if "batch_encode_plus" in dir(type(self.tokenizer)) else None
         t0 = time.perf_counter()
         tok = bep(batch_text_or_text_pairs=texts, **kw) if bep is not None else self.tokenizer(texts, **kw)
@@ -100,14 +137,7 @@ class CXRBERTReward:
         if self.tokenizer is None:
             raise RuntimeError("CXRBERTReward needs the CXR-BERT tokenizer (not available offline): pass tokenizer=...")
         pred = self._encode(predictions)
-        flat = tuple(j for i in labels for j in i)
-        lab = self._label_cache.get(flat)
-        if lab is None:
-            lab = self._encode(list(flat))
-            if len(self._label_cache) >= self._max_cache:
-                self._label_cache.clear()
-            self._label_cache[flat] = lab
-        return ops.cosine_rows(pred, lab)
+        return ops.cosine_rows(pred, self.label_embeddings(labels))
 
     @torch.no_grad()
     def similarity(self, predictions, labels):
@@ -130,12 +160,45 @@ class ReportReward:
     against the study's labels. Works on PINNED HOST copies of the sequences (one asynchronous copy per decode, no per-row sync); the label
     embeddings are computed once per batch (CXRBERTReward caches them per label tuple: the reference embeds them twice per step)."""
 
-    def __init__(self, model, tokenizer, reward: CXRBERTReward, labels, bos_token_id, sep_token_id, eos_token_id):
+    def __init__(self, model, tokenizer, reward: CXRBERTReward, labels, bos_token_id, sep_token_id, eos_token_id, worker: bool = False):
+        """worker=True: the CPU part of pair() -- ids -> strings -> reward-tokenizer ids -- runs in a child process (strings.StringWorker) between
+        pair_start() and pair_finish(), i.e. WHILE this process's Python thread queues the re-scoring pass: scst.scst_step uses the two calls when
+        they exist. Both tokenizers must pickle (HF fast tokenizers and strings.FoldedVocabTokenizer do). Any failure of the child -- start-up,
+        time-out, exception -- falls back to the in-process path; results are the same either way."""
         self.model, self.tokenizer, self.reward = model, tokenizer, reward
         self.labels = labels                                  # [[f"{findings} {impression}"], ...] as the reference builds them (gt_prompt.py:90)
         self.special = [bos_token_id, sep_token_id, eos_token_id]
 
         self.last_sections = None                             # (findings, impression) strings of the most recent call
+        self.worker = None
+        self.worker_used = 0                                  # pairs the child process has served (benchmarks / tests report it)
+        if worker and reward.tokenizer is not None:
+            from .strings import StringWorker
+            w = StringWorker(tokenizer, reward.tokenizer, self.special, reward.encode_kw(return_tensors="np"))
+            self.worker = w if w.alive else None
+
+    def pair_start(self, sampled_host, greedy_host):
+        """Hand both halves' ids (host tensors whose copies have LANDED) to the child process. -> ticket for pair_finish()."""
+        if self.worker is not None and self.worker.alive and self.worker.submit(sampled_host.numpy(), greedy_host.numpy()):
+            return ("worker", sampled_host, greedy_host)
+        return ("inline", sampled_host, greedy_host)
+
+    def pair_finish(self, ticket):
+        kind, sampled_host, greedy_host = ticket
+        got = self.worker.result() if kind == "worker" else None
+        if got is None:                                       # no worker, or it failed: the in-process path (same strings, same ids)
+            return self.pair(sampled_host, greedy_host)
+        ids, mask, fg, ig = got
+        self.last_sections = (fg, ig)
+        self.worker_used += 1
+        both = ops.cosine_rows(self.reward.embed_ids(torch.from_numpy(ids), torch.from_numpy(mask)), self.reward.label_embeddings(self.labels + self.labels))
+        B = ids.shape[0] // 2
+        return both[:B], both[B:]
+
+    def close(self):
+        if self.worker is not None:
+            self.worker.close()
+            self.worker = None
 
     def pair(self, sampled_host, greedy_host):
         """(reward of the sampled rows, reward of the greedy rows) from ONE tokenizer call and ONE 2B-row CXR-BERT forward; `last_sections` holds the

@@ -83,9 +83,16 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         if known if known is not None else bool(torch.all(base[:, 0] == bos)):
             base = base[:, 1:]
         sampled = seqs[:, P:].contiguous()
-        host = None
+        host = ticket = None
         if reward_on_host:
             host = _host_copies([seqs.contiguous(), base.contiguous()])
+            start = getattr(reward_fn, "pair_start", None)
+            if start is not None and _SYNC_STRIP:
+                # the decode is complete here (the BOS check above read the sequences back), so the copies land within ~0.1 ms: hand the ids to the
+                # reward's string worker NOW -- a child process turns them into strings and reward-tokenizer ids while this thread queues the
+                # re-scoring pass below (the tokenizers library keeps the GIL: a thread of this process could not run beside the launches)
+                host[1].synchronize()
+                ticket = start(host[0][0], host[0][1])
 
         # ---- REINFORCE through one teacher-forced pass: the forward needs no reward, so it is queued first
         opt.zero_grad()
@@ -114,7 +121,10 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         if reward_on_host:
             (seqs_h, base_h), done = host
             done.synchronize()                                               # only the decode had to finish; the forward above keeps the GPU busy
-            reward, baseline = pair(seqs_h, base_h) if pair else (reward_fn(seqs_h), reward_fn(base_h))
+            if ticket is not None:
+                reward, baseline = reward_fn.pair_finish(ticket)
+            else:
+                reward, baseline = pair(seqs_h, base_h) if pair else (reward_fn(seqs_h), reward_fn(base_h))
         else:
             base_new = base[:, P:].contiguous()
             reward, baseline = pair(sampled, base_new) if pair else (reward_fn(sampled), reward_fn(base_new))

@@ -421,3 +421,42 @@ def test_batch_section_decode_equals_the_per_section_decode_for_wordpiece_and_bp
 
     odd = Odd(tokenizer_object=wp, unk_token="[UNK]", pad_token="[PAD]")
     assert th.decode_many(odd, [[5, 6], [7, 8]]) == ["odd:the lungs", "odd:are clear"]
+
+
+def test_string_worker_child_process_returns_the_in_process_result_and_fails_soft():
+    """strings.StringWorker: the CPU part of an SCST reward (ids -> sections -> strings -> reward-tokenizer ids; reference scst/gt_prompt.py:90-91,
+    192-197, tools/rewards/cxrbert.py:33-40) in a child process that imports neither torch nor the HIP library. Same ids / masks / greedy sections as
+    the in-process function on ragged rows; a request the child cannot serve, a dead child and an unpicklable tokenizer all end in `None` / not
+    alive (the caller's in-process path), never in a hang."""
+    import transformers
+    from cxrmate_amd import strings
+    tok = transformers.PreTrainedTokenizerFast(tokenizer_file=os.path.join(os.path.dirname(__file__), "golden", "tokenizer.json"), unk_token="[UNK]", pad_token="[PAD]",
+                                               cls_token="[BOS]", sep_token="[SEP]", mask_token="[MASK]", bos_token="[BOS]", eos_token="[EOS]")
+    kw = dict(add_special_tokens=True, padding="longest", return_tensors="np", truncation=True, max_length=64)
+    rep = strings.FoldedVocabTokenizer(tok)
+    w = strings.StringWorker(rep, tok, [1, 3, 2], kw)
+    try:
+        assert w.alive
+        g = torch.Generator().manual_seed(1)
+        for _ in range(2):
+            a = torch.randint(12, 30000, (3, 40), generator=g).numpy()
+            b = torch.randint(12, 30000, (3, 40), generator=g).numpy()
+            a[:, :5] = [8, 10, 9, 11, 1]; b[:, :5] = [8, 10, 9, 11, 1]
+            a[0, 20], a[0, 33] = 3, 2                                       # findings [SEP] impression [EOS]
+            b[1, 9] = 3                                                     # no EOS: the impression runs to the end of the row (quirk Q9)
+            assert w.submit(a, b)
+            got = w.result(timeout=60)
+            want = strings.report_pair_tokens(a, b, [1, 3, 2], rep, tok, kw)
+            assert got is not None and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2] and got[3] == want[3]
+            assert got[0].shape[0] == 6 and got[0].shape[1] <= 64
+        assert w.result(timeout=1) is None                                  # nothing pending: no wait, no answer
+        assert w.submit(np.zeros((2, 3, 4), dtype=np.int64), np.zeros((2, 3), dtype=np.int64))      # a request the child cannot serve (3-D ids)
+        assert w.result(timeout=60) is None and w.alive                     # ... is an error reply, not a dead worker
+        w.proc.kill(); w.proc.wait()
+        assert not w.submit(a, b) or w.result(timeout=5) is None            # a dead child: soft failure
+        assert not w.alive
+    finally:
+        w.close()
+    w2 = strings.StringWorker(lambda ids: "x", tok, [1, 3, 2], kw, start_timeout=60)      # a tokenizer that does not pickle
+    assert not w2.alive
+    w2.close()

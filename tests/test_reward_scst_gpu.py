@@ -362,3 +362,49 @@ def test_scst_generated_prompt_steps_chain_through_the_written_back_report(cuda)
         assert base.shape[1] <= out["prompt_ids"].shape[1] + 12
         prev_f, prev_i = out["baseline_findings"], out["baseline_impression"]          # written back: the next study's prompt
     assert not torch.equal(w0, m.param("decoder.base_model.model.bert.encoder.layer.0.output.dense.weight").detach())
+
+
+def test_scst_step_with_the_string_worker_equals_the_in_process_path(cuda):
+    """reward.ReportReward(worker=True): the CPU part of the reward (ids -> strings -> reward-tokenizer ids) runs in a child process between
+    pair_start() and pair_finish() while scst_step queues its re-scoring pass. Same seeds, lr = 0: the step with the worker reports the rewards,
+    the advantage-weighted loss and the greedy sections of the in-process step bit for bit, the child did serve it, and a worker that dies between
+    two steps leaves a step that still works (in-process fallback)."""
+    import os
+    import transformers
+    from cxrmate_amd import modelling
+    from cxrmate_amd.reward import CXRBERTReward, ReportReward
+    from cxrmate_amd.scst import scst_step
+    from cxrmate_amd.training import FusedAdamW
+    g, cfg, sd, x, prompt = gu.generate_longitudinal_case()
+    m = modelling.LongitudinalPromptMultiCXREncoderDecoderModel(cfg, device=cuda, seed=None)
+    m.load_state_dict(sd)
+    for p in m.decoder.parameters():
+        p.requires_grad_(True)
+    opt = FusedAdamW(m, lr=0.0, weight_decay=0.0)
+    tok = transformers.PreTrainedTokenizerFast(tokenizer_file=os.path.join(gu.GOLDEN, "tokenizer.json"), unk_token="[UNK]", pad_token="[PAD]",
+                                               cls_token="[BOS]", sep_token="[SEP]", mask_token="[MASK]", bos_token="[BOS]", eos_token="[EOS]")
+    rcfg = gu.BertConfig(vocab_size=600, num_hidden_layers=2, is_decoder=False, add_cross_attention=False, cls_projection_size=128)
+    reward = CXRBERTReward(cuda, tokenizer=tok, config=rcfg, max_length=48)
+    labels = [["The lungs are clear. No acute cardiopulmonary process."], ["Mild cardiomegaly is stable. Small left pleural effusion."]]
+    special = dict(bos=gu.BOS, eos=gu.EOS, sep=gu.SEP, pad=gu.PAD, pmt_sep=gu.PMT_SEP)
+
+    def run(rfn):
+        torch.manual_seed(3)
+        out = scst_step(m, opt, rfn, x.cuda(), prompt.cuda(), None, special, decoder_max_len=10, reward_on_host=True)
+        torch.cuda.synchronize()
+        return (out["loss"].item(), out["global"]["reward"].cpu().numpy(), out["global"]["baseline"].cpu().numpy(), out["sampled"].cpu().numpy(),
+                tuple(map(tuple, rfn.last_sections)))
+
+    plain = ReportReward(m, tok, reward, labels, gu.BOS, gu.SEP, gu.EOS)
+    ref = run(plain)
+    wrk = ReportReward(m, tok, reward, labels, gu.BOS, gu.SEP, gu.EOS, worker=True)
+    try:
+        assert wrk.worker is not None and wrk.worker.alive
+        got = run(wrk)
+        assert wrk.worker_used == 1
+        assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]) and got[4] == ref[4]
+        wrk.worker.proc.kill(); wrk.worker.proc.wait()
+        again = run(wrk)                                          # the child is gone: the step falls back to the in-process path, same numbers
+        assert wrk.worker_used == 1 and again[0] == ref[0] and np.array_equal(again[1], ref[1]) and again[4] == ref[4]
+    finally:
+        wrk.close()
