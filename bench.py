@@ -350,9 +350,12 @@ def scst_string_round_trip(args, model, opt, images, prompt, special, dev, B, st
                                                eos_token="[EOS]")
     reward = CXRBERTReward(dev, tokenizer=tok, seed=1, max_length=128)
     labels = [["The lungs are clear without focal consolidation. No pleural effusion or pneumothorax. No acute cardiopulmonary process."]] * B
-    # CXR_STRING_WORKER=1: the CPU part of the reward (ids -> strings -> reward-tokenizer ids) in a child process, beside this process's kernel launches
-    # (reward.ReportReward(worker=True)). Default: in-process -- three same-box alternations put the child process at -1.4 ms +- 2 ms per step (scripts/r5/call18.sh): inside the noise
-    rfn = ReportReward(model, _InVocabTokenizer(tok), reward, labels, 1, 3, 2, worker=os.environ.get("CXR_STRING_WORKER", "0") == "1")
+    # The CPU part of the reward (ids -> strings -> reward-tokenizer ids) runs in a child process beside this process's kernel launches
+    # (reward.ReportReward(worker=True); CXR_STRING_WORKER=0: in-process). Host / GPU timeline of the step, scripts/r5/scst_timeline.py: in-process the GPU
+    # idles ~3 ms between the re-scoring forward and the reward forward while the host turns ids into strings into ids (105.7 ms per step); with the child
+    # process the host only waits for the child's answer (103.9 ms). Same-box alternations of the bench key: -0.9 to -1.8 ms. Any failure of the child falls
+    # back to the in-process path (time-outs on every wait).
+    rfn = ReportReward(model, _InVocabTokenizer(tok), reward, labels, 1, 3, 2, worker=os.environ.get("CXR_STRING_WORKER", "1") != "0")
 
     def step():
         return scst_step(model, opt, rfn, images, prompt, None, special, decoder_max_len=args.new_tokens + 1, reward_on_host=True)
@@ -370,8 +373,8 @@ def scst_string_round_trip(args, model, opt, images, prompt, special, dev, B, st
             "host_ms": {"ids_to_strings": getattr(rfn, "last_decode_ms", None), "strings_to_ids": getattr(reward, "last_tokenize_ms", None),
                         "note": "in-process path only (the child process does this work when it serves a step)"},
             "what": "scst_step(reward_on_host=True) with reward.ReportReward: async pinned copies of the sequences; all sections decoded by one call into the tokenizers "
-                    "library and both halves re-tokenised by one call (truncated to R = 128) -- in this process, or with CXR_STRING_WORKER=1 in a child process "
-                    "(strings.StringWorker) beside the launches of the re-scoring forward + warper threshold --, token ids uploaded through a pinned staging buffer, "
+                    "library and both halves re-tokenised by one call (truncated to R = 128) -- in a child process (strings.StringWorker; CXR_STRING_WORKER=0 or any "
+                    "failure of the child: in this process) beside the launches of the re-scoring forward + warper threshold --, token ids uploaded through a pinned staging buffer, "
                     "one 32-row CXR-BERT forward, label embeddings cached; synthetic byte-BPE tokenizer (tests/golden/tokenizer.json) on the random-init model's strings"}
 
 

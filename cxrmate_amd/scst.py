@@ -22,6 +22,14 @@ from . import dp, ops
 
 
 _SIDE = {}
+TRACE = None            # set to a list (scripts/r5/scst_timeline.py): scst_step appends (label, host seconds, CUDA event) at its phase boundaries
+
+
+def _mark(label):
+    if TRACE is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        TRACE.append((label, __import__("time").perf_counter(), ev))
 # CXR_SCST_AHEAD=1: queue the re-scoring pass behind the decode WITHOUT reading the decoded sequences back first (the fused decode knows from the prompt
 # whether a BOS column has to be stripped). Measured in round 5 and left OFF: with everything of the step queued while the GPU still replays the decode
 # graphs, the part of the step behind the decode takes ~9.5 ms LONGER (synthetic-id step 103.9 -> 113.0 ms, three same-box alternations,
@@ -62,7 +70,9 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
     dev = model.device
     P = prompt_ids.shape[1]
     with torch.no_grad():
+        _mark("start")
         eo = model.encoder(images)
+        _mark("encoder queued")
         if fused_decode:
             # sample + greedy baseline as one 2B-row cached decode (same per-row inputs as the two separate calls below)
             seqs, base, rec = model.sample_and_greedy(eo, prompt_ids, [bos, sep], [pmt_sep, bos, sep], pad, decoder_max_len + P, bos, eos, pad,
@@ -83,6 +93,7 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         if known if known is not None else bool(torch.all(base[:, 0] == bos)):
             base = base[:, 1:]
         sampled = seqs[:, P:].contiguous()
+        _mark("decode done (host has read the sequences)")
         host = ticket = None
         if reward_on_host:
             host = _host_copies([seqs.contiguous(), base.contiguous()])
@@ -115,6 +126,7 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         flat = logits.view(-1, V)
         # (the warper threshold needs no reward either: queued in front of the host's string work)
         thr = ops.topk_threshold(flat, int(top_k or 0), top_p, temperature) if (top_k or top_p < 1.0) else None
+        _mark("re-scoring forward + threshold queued")
         # reward of the sampled and of the greedy reports. A reward_fn with `.pair(sampled, greedy)` scores both in ONE pass (one tokenizer call,
         # one 2B-row CXR-BERT forward: the two B-row forwards of a BERT-base are launch-bound, ~2.6 ms each)
         pair = getattr(reward_fn, "pair", None)
@@ -128,6 +140,7 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         else:
             base_new = base[:, P:].contiguous()
             reward, baseline = pair(sampled, base_new) if pair else (reward_fn(sampled), reward_fn(base_new))
+        _mark("rewards queued (strings done)")
         adv = (reward - baseline).float().contiguous()
         # data parallel: the sampled / greedy sequences and their rewards of ALL ranks (RCCL all-gather over xGMI, <= 64 KB per rank) for the
         # global reward / baseline statistics the step reports; the advantage above stays per study, as in the reference (gt_prompt.py:129-132)
@@ -139,11 +152,13 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         with wgrad_overlap():                                                # weight-gradient GEMMs beside the dX chain, as in the TF step
             model._dec.backward(saved, dlogits=dl, need_denc=False)
             ops.wgrad_join()
+        _mark("backward queued + joined")
         world = dp.world_size()
         if dp.active():
             opt.reducer.reduce_range(0, model._param_total)
             opt.reducer.wait()
         opt.step(gscale=1.0 / world)
+        _mark("optimiser queued")
         seq_len = (glob["sampled"] != pad).sum(-1).float().mean()
     # dropout_seed / encoder_seed: the device words the counter-based dropout / DropPath hashes of this step were keyed with (None in eval
     # mode) -- cxr_dropout_mask materialises the masks from them (parity tests hand them to the CPU oracle)
