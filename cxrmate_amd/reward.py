@@ -170,35 +170,53 @@ class ReportReward:
         self.special = [bos_token_id, sep_token_id, eos_token_id]
 
         self.last_sections = None                             # (findings, impression) strings of the most recent call
-        self.worker = None
-        self.worker_used = 0                                  # pairs the child process has served (benchmarks / tests report it)
+        self.workers = []
+        self.worker_used = 0                                  # pairs the child processes have served (benchmarks / tests report it)
         if worker and reward.tokenizer is not None:
             from .strings import StringWorker
-            w = StringWorker(tokenizer, reward.tokenizer, self.special, reward.encode_kw(return_tensors="np"))
-            self.worker = w if w.alive else None
+            # one child per half (sampled rows | greedy rows): the two halves are decoded and re-tokenised side by side, and the parent pads them
+            # to the common length (what padding="longest" over all rows gives)
+            ws = [StringWorker(tokenizer, reward.tokenizer, self.special, reward.encode_kw(return_tensors="np")) for _ in range(2)]
+            if all(w.alive for w in ws):
+                self.workers = ws
+            else:
+                for w in ws:
+                    w.close()
+
+    @property
+    def worker(self):
+        """The first child process (None without workers): kept for callers / tests that look at one."""
+        return self.workers[0] if self.workers else None
 
     def pair_start(self, sampled_host, greedy_host):
-        """Hand both halves' ids (host tensors whose copies have LANDED) to the child process. -> ticket for pair_finish()."""
-        if self.worker is not None and self.worker.alive and self.worker.submit(sampled_host.numpy(), greedy_host.numpy()):
-            return ("worker", sampled_host, greedy_host)
+        """Hand both halves' ids (host tensors whose copies have LANDED) to the child processes. -> ticket for pair_finish()."""
+        if len(self.workers) == 2 and all(w.alive for w in self.workers):
+            if self.workers[0].submit(sampled_host.numpy()) and self.workers[1].submit(greedy_host.numpy()):
+                return ("worker", sampled_host, greedy_host)
         return ("inline", sampled_host, greedy_host)
 
     def pair_finish(self, ticket):
         kind, sampled_host, greedy_host = ticket
-        got = self.worker.result() if kind == "worker" else None
-        if got is None:                                       # no worker, or it failed: the in-process path (same strings, same ids)
+        got = [w.result() for w in self.workers] if kind == "worker" else [None]
+        if any(g is None for g in got):                       # no workers, or one failed: the in-process path (same strings, same ids)
+            for w in self.workers:
+                w.pending = False
+            if self.workers and not all(w.alive for w in self.workers):
+                self.close()
             return self.pair(sampled_host, greedy_host)
-        ids, mask, fg, ig = got
-        self.last_sections = (fg, ig)
+        from .strings import pad_and_stack
+        pad_id = self.reward.tokenizer.pad_token_id
+        ids, mask = pad_and_stack([(g[0], g[1]) for g in got], 0 if pad_id is None else pad_id)
+        self.last_sections = (got[1][2], got[1][3])
         self.worker_used += 1
         both = ops.cosine_rows(self.reward.embed_ids(torch.from_numpy(ids), torch.from_numpy(mask)), self.reward.label_embeddings(self.labels + self.labels))
         B = ids.shape[0] // 2
         return both[:B], both[B:]
 
     def close(self):
-        if self.worker is not None:
-            self.worker.close()
-            self.worker = None
+        for w in self.workers:
+            w.close()
+        self.workers = []
 
     def pair(self, sampled_host, greedy_host):
         """(reward of the sampled rows, reward of the greedy rows) from ONE tokenizer call and ONE 2B-row CXR-BERT forward; `last_sections` holds the

@@ -107,15 +107,33 @@ class FoldedVocabTokenizer:
         return self.tok.backend_tokenizer.decode_batch([self._fold(s_) for s_ in sequences], skip_special_tokens=True)
 
 
-def report_pair_tokens(sampled, greedy, special_token_ids, tokenizer, reward_tokenizer, encode_kw):
-    """The CPU part of one SCST reward: both halves' ids -> sections -> f"{findings} {impression}" -> reward tokenizer (numpy tensors).
-    -> (input_ids [2B, R], attention_mask [2B, R], greedy findings, greedy impression)."""
-    _, fs, is_ = split_and_decode(sampled, special_token_ids, tokenizer)
-    _, fg, ig = split_and_decode(greedy, special_token_ids, tokenizer)
-    texts = [f"{i} {j}" for i, j in zip(list(fs) + list(fg), list(is_) + list(ig))]
+def report_tokens(id_matrices, special_token_ids, tokenizer, reward_tokenizer, encode_kw):
+    """The CPU part of an SCST reward for the rows of several id matrices (in order): ids -> sections -> f"{findings} {impression}" -> reward
+    tokenizer (numpy tensors). -> (input_ids [rows, R], attention_mask [rows, R], findings [rows], impression [rows])."""
+    findings, impression = [], []
+    for ids in id_matrices:
+        _, f, i = split_and_decode(ids, special_token_ids, tokenizer)
+        findings += list(f)
+        impression += list(i)
+    texts = [f"{i} {j}" for i, j in zip(findings, impression)]
     bep = getattr(reward_tokenizer, "batch_encode_plus", None) if "batch_encode_plus" in dir(type(reward_tokenizer)) else None
     tok = bep(batch_text_or_text_pairs=texts, **encode_kw) if bep is not None else reward_tokenizer(texts, **encode_kw)
-    return np.asarray(tok["input_ids"]), np.asarray(tok["attention_mask"]), list(fg), list(ig)
+    return np.asarray(tok["input_ids"]), np.asarray(tok["attention_mask"]), findings, impression
+
+
+def report_pair_tokens(sampled, greedy, special_token_ids, tokenizer, reward_tokenizer, encode_kw):
+    """Both halves of one SCST reward in one go. -> (input_ids [2B, R], attention_mask [2B, R], greedy findings, greedy impression)."""
+    ids, mask, f, i = report_tokens([sampled, greedy], special_token_ids, tokenizer, reward_tokenizer, encode_kw)
+    n = len(f) - np.asarray(greedy).shape[0]
+    return ids, mask, f[n:], i[n:]
+
+
+def pad_and_stack(parts, pad_id):
+    """[(ids [b_k, L_k], mask [b_k, L_k])] -> (ids, mask) [sum b_k, max L_k]: what padding="longest" over ALL rows would have produced."""
+    L = max(p[0].shape[1] for p in parts)
+    ids = np.concatenate([np.pad(p[0], ((0, 0), (0, L - p[0].shape[1])), constant_values=pad_id) for p in parts], 0)
+    mask = np.concatenate([np.pad(p[1], ((0, 0), (0, L - p[1].shape[1])), constant_values=0) for p in parts], 0)
+    return ids, mask
 
 
 # ------------------------------------------------------------------------------------------------ the child process
@@ -146,7 +164,7 @@ def _recv(fd, timeout=None):
 
 
 def _worker_main():
-    """`python -m cxrmate_amd.strings`: first message = (tokenizer, reward_tokenizer, special_token_ids, encode_kw); then (sampled, greedy) pairs."""
+    """`python -m cxrmate_amd.strings`: first message = (tokenizer, reward_tokenizer, special_token_ids, encode_kw); then tuples of id matrices."""
     fin, fout = sys.stdin.buffer, sys.stdout.buffer
     sys.stdout = sys.stderr                                       # nothing but the protocol may reach the pipe
     fd = fin.fileno()
@@ -158,7 +176,7 @@ def _worker_main():
             if msg is None:
                 return
             try:
-                _send(fout, ("ok",) + report_pair_tokens(msg[0], msg[1], special, tokenizer, reward_tokenizer, encode_kw))
+                _send(fout, ("ok",) + report_tokens(list(msg), special, tokenizer, reward_tokenizer, encode_kw))
             except Exception as e:                                 # the parent falls back to its in-process path
                 _send(fout, ("error", repr(e)))
     except EOFError:
@@ -182,11 +200,11 @@ class StringWorker:
         except Exception:
             self.close()
 
-    def submit(self, sampled, greedy):
+    def submit(self, *id_matrices):
         if not self.alive:
             return False
         try:
-            _send(self.proc.stdin, (np.ascontiguousarray(sampled), np.ascontiguousarray(greedy)))
+            _send(self.proc.stdin, tuple(np.ascontiguousarray(m) for m in id_matrices))
             self.pending = True
             return True
         except Exception:
@@ -194,7 +212,7 @@ class StringWorker:
             return False
 
     def result(self, timeout: float = 30.0):
-        """-> (input_ids, attention_mask, greedy findings, greedy impression) or None (the caller falls back)."""
+        """-> (input_ids, attention_mask, findings, impression) of the submitted rows, or None (the caller falls back)."""
         if not (self.alive and self.pending):
             return None
         self.pending = False

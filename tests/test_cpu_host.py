@@ -446,11 +446,17 @@ def test_string_worker_child_process_returns_the_in_process_result_and_fails_sof
             b[1, 9] = 3                                                     # no EOS: the impression runs to the end of the row (quirk Q9)
             assert w.submit(a, b)
             got = w.result(timeout=60)
-            want = strings.report_pair_tokens(a, b, [1, 3, 2], rep, tok, kw)
+            want = strings.report_tokens([a, b], [1, 3, 2], rep, tok, kw)
             assert got is not None and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2] and got[3] == want[3]
-            assert got[0].shape[0] == 6 and got[0].shape[1] <= 64
+            assert got[0].shape[0] == 6 and got[0].shape[1] <= 64 and len(got[2]) == 6
+            pair = strings.report_pair_tokens(a, b, [1, 3, 2], rep, tok, kw)                   # (the one-call form hands back the greedy half's sections)
+            assert np.array_equal(pair[0], want[0]) and pair[2] == want[2][3:] and pair[3] == want[3][3:]
+            # one half per child, padded to the common length by the parent == all rows tokenised together
+            ha, hb = strings.report_tokens([a], [1, 3, 2], rep, tok, kw), strings.report_tokens([b], [1, 3, 2], rep, tok, kw)
+            ids2, mask2 = strings.pad_and_stack([(ha[0], ha[1]), (hb[0], hb[1])], tok.pad_token_id)
+            assert np.array_equal(ids2, want[0]) and np.array_equal(mask2, want[1])
         assert w.result(timeout=1) is None                                  # nothing pending: no wait, no answer
-        assert w.submit(np.zeros((2, 3, 4), dtype=np.int64), np.zeros((2, 3), dtype=np.int64))      # a request the child cannot serve (3-D ids)
+        assert w.submit(np.zeros((2, 3, 4), dtype=np.int64))                # a request the child cannot serve (3-D ids)
         assert w.result(timeout=60) is None and w.alive                     # ... is an error reply, not a dead worker
         w.proc.kill(); w.proc.wait()
         assert not w.submit(a, b) or w.result(timeout=5) is None            # a dead child: soft failure
