@@ -322,7 +322,8 @@ class GenerationMixin:
                                          top_p=top_p)
         else:
             ids, margins = self._generate_eager(ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, bos_token_id, eos_token_id,
-                                                pad_token_id, forced_tokens, return_margins)
+                                                pad_token_id, forced_tokens, return_margins,
+                                                rec if ((output_scores and do_sample) or record_inputs) else None)
 
         scores = None
         if output_scores and do_sample:
@@ -339,8 +340,10 @@ class GenerationMixin:
         return ids
 
     def _generate_eager(self, ids, enc16, enc_mask8, special_token_ids, mask_token_id, max_length, bos_token_id, eos_token_id, pad_token_id,
-                        forced_tokens, return_margins):
-        """Eagerly launched greedy loop with per-step argmax / margin capture and optional teacher forcing (parity tests)."""
+                        forced_tokens, return_margins, rec=None):
+        """Eagerly launched greedy loop with per-step argmax / margin capture and optional teacher forcing (parity tests). rec: the per-step
+        token-type / position inputs are recorded as _generate_session records them (a sampling call with forced_tokens then returns the processed
+        scores of the FORCED ids: the reference's sampled sequence can be pushed through the grad-enabled generate body)."""
         dev = self.device
         B = ids.shape[0]
         prompt_len = ids.shape[1]
@@ -353,6 +356,10 @@ class GenerationMixin:
             while ids.shape[1] < max_length:
                 fed = self._fed(ids, bos_token_id)
                 new, mask, tt, pos = self._step_inputs(fed, special_token_ids, mask_token_id, prefill=cache.len == 0)
+                if rec is not None:
+                    rec["tt"].append(tt.clone())
+                    rec["pos"].append(None if pos is None else pos.clone())
+                    rec["seed"] = seed
                 logits = self._dec.decode(cache, new.contiguous(), enc16, enc_mask8, mask, tt.contiguous(), None if pos is None else pos.contiguous(),
                                           seed=seed)
                 if forced_tokens is not None:

@@ -176,11 +176,16 @@ class ReportReward:
             from .strings import StringWorker
             # one child per half (sampled rows | greedy rows): the two halves are decoded and re-tokenised side by side, and the parent pads them
             # to the common length (what padding="longest" over all rows gives)
-            ws = [StringWorker(tokenizer, reward.tokenizer, self.special, reward.encode_kw(return_tensors="np")) for _ in range(2)]
-            if all(w.alive for w in ws):
+            ws = []
+            try:
+                for _ in range(2):
+                    ws.append(StringWorker(tokenizer, reward.tokenizer, self.special, reward.encode_kw(return_tensors="np")))
+            except Exception:                                 # (StringWorker itself degrades on start-up failures; this is for what it cannot foresee)
+                pass
+            if len(ws) == 2 and all(w.alive for w in ws):
                 self.workers = ws
             else:
-                for w in ws:
+                for w in ws:                                  # whichever were created: none is left running
                     w.close()
 
     @property

@@ -67,6 +67,9 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         decodes and re-tokenises the reports.
     Returns dict(loss, reward, baseline, seq_len)."""
     bos, eos, sep, pad, pmt_sep = (special[k] for k in ("bos", "eos", "sep", "pad", "pmt_sep"))
+    temperature = 1.0 if temperature is None else float(temperature)
+    if temperature <= 0.0:
+        raise ValueError("temperature must be positive")
     dev = model.device
     P = prompt_ids.shape[1]
     with torch.no_grad():
@@ -121,11 +124,13 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
                                            cross_kv=model._session_cross_kv(rec, enc), logit_from=P - 1)
 
         B, _, V = logits.shape                                               # scores of the n_new sampling steps
-        if float(temperature) != 1.0:
-            raise NotImplementedError("temperature != 1 (the reference trains with 1.0)")
         flat = logits.view(-1, V)
+        if temperature != 1.0:
+            # scst_sample_temperature (gt_prompt.py:13-15,177): the processed scores are logits / T (TemperatureLogitsWarper runs first), so the loss is
+            # taken on the scaled scores and d(logits) = d(scores) / T below; the warpers then see temperature 1, as in the drop-in generate body
+            flat.mul_(1.0 / temperature)
         # (the warper threshold needs no reward either: queued in front of the host's string work)
-        thr = ops.topk_threshold(flat, int(top_k or 0), top_p, temperature) if (top_k or top_p < 1.0) else None
+        thr = ops.topk_threshold(flat, int(top_k or 0), top_p, 1.0) if (top_k or top_p < 1.0) else None
         _mark("re-scoring forward + threshold queued")
         # reward of the sampled and of the greedy reports. A reward_fn with `.pair(sampled, greedy)` scores both in ONE pass (one tokenizer call,
         # one 2B-row CXR-BERT forward: the two B-row forwards of a BERT-base are launch-bound, ~2.6 ms each)
@@ -148,6 +153,8 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         labels = sampled.reshape(-1)
         w = ops.ce_weights(labels, pad, mode=1, reward=adv, T=n_new)
         loss, _, dl = ops.softmax_ce(flat, labels, pad, w, thr=thr)
+        if temperature != 1.0:
+            dl.mul_(1.0 / temperature)
         from .training import wgrad_overlap
         with wgrad_overlap():                                                # weight-gradient GEMMs beside the dX chain, as in the TF step
             model._dec.backward(saved, dlogits=dl, need_denc=False)

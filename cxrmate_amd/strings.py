@@ -17,6 +17,7 @@ import select
 import struct
 import subprocess
 import sys
+import time
 
 import numpy as np
 
@@ -175,36 +176,43 @@ def _worker_main():
             msg = _recv(fd)
             if msg is None:
                 return
+            seq, mats = msg                                        # every answer carries the sequence number of the request it belongs to
             try:
-                _send(fout, ("ok",) + report_tokens(list(msg), special, tokenizer, reward_tokenizer, encode_kw))
+                _send(fout, ("ok", seq) + report_tokens(list(mats), special, tokenizer, reward_tokenizer, encode_kw))
             except Exception as e:                                 # the parent falls back to its in-process path
-                _send(fout, ("error", repr(e)))
+                _send(fout, ("error", seq, repr(e)))
     except EOFError:
         return
 
 
 class StringWorker:
-    """Parent-side handle of the child process. submit() is asynchronous (one request in flight), result() waits with a timeout; after any
-    failure `alive` is False and the caller uses its in-process path."""
+    """Parent-side handle of the child process. submit() is asynchronous, result() waits with a timeout; after any failure `alive` is False and
+    the caller uses its in-process path. Requests carry a sequence number and result() returns only the answer to the LAST submitted request:
+    a step that failed between submit() and result() (an exception in the caller, an interrupt) leaves an unread answer in the pipe, and the next
+    step must not take it for its own -- answers with an older number are read and dropped."""
 
     def __init__(self, tokenizer, reward_tokenizer, special_token_ids, encode_kw, start_timeout: float = 120.0):
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), TOKENIZERS_PARALLELISM="true")
         self.alive = False
         self.pending = False
-        self.proc = subprocess.Popen([sys.executable, "-m", "cxrmate_amd.strings"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env, cwd=root)
+        self.seq = 0                                              # number of the last submitted request
+        self.dropped = 0                                          # stale answers discarded (tests look at it)
+        self.proc = None
         try:
+            self.proc = subprocess.Popen([sys.executable, "-m", "cxrmate_amd.strings"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env, cwd=root)
             _send(self.proc.stdin, (tokenizer, reward_tokenizer, list(special_token_ids), dict(encode_kw)))
             tag, _ = _recv(self.proc.stdout.fileno(), start_timeout)
             self.alive = tag == "ready"
-        except Exception:
+        except Exception:                                         # OSError from fork/exec included: the caller degrades to its in-process path
             self.close()
 
     def submit(self, *id_matrices):
         if not self.alive:
             return False
         try:
-            _send(self.proc.stdin, tuple(np.ascontiguousarray(m) for m in id_matrices))
+            self.seq += 1
+            _send(self.proc.stdin, (self.seq, tuple(np.ascontiguousarray(m) for m in id_matrices)))
             self.pending = True
             return True
         except Exception:
@@ -212,14 +220,19 @@ class StringWorker:
             return False
 
     def result(self, timeout: float = 30.0):
-        """-> (input_ids, attention_mask, findings, impression) of the submitted rows, or None (the caller falls back)."""
+        """-> (input_ids, attention_mask, findings, impression) of the rows of the LAST submit(), or None (the caller falls back)."""
         if not (self.alive and self.pending):
             return None
         self.pending = False
         try:
-            msg = _recv(self.proc.stdout.fileno(), timeout)
+            deadline = time.monotonic() + timeout
+            while True:
+                msg = _recv(self.proc.stdout.fileno(), max(deadline - time.monotonic(), 0.0))
+                if msg[1] == self.seq:
+                    break
+                self.dropped += 1                                  # the answer to a request whose step never came back for it
             if msg[0] == "ok":
-                return msg[1:]
+                return msg[2:]
             return None
         except Exception:
             self.close()

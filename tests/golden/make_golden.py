@@ -711,6 +711,46 @@ def fixture_encoder_full():
     print("encoder_full", d["last_hidden_state_stats"])
 
 
+_CVT = "encoder.cvt.encoder.stages.{}."
+_ATT = "layers.{}.attention.attention."
+TF_FULL_GRADS = [
+    _CVT.format(0) + "embedding.convolution_embeddings.projection.weight",                                   # patch-embed conv 7x7/s4
+    _CVT.format(0) + "embedding.convolution_embeddings.normalization.weight",
+    _CVT.format(0) + _ATT.format(0) + "convolution_projection_query.convolution_projection.convolution.weight",     # stage-1 depthwise taps
+    _CVT.format(0) + _ATT.format(0) + "convolution_projection_key.convolution_projection.normalization.weight",      # ... and BatchNorm gamma
+    _CVT.format(0) + _ATT.format(0) + "projection_query.weight",                                             # stage-1 attention (1 head, 9216 x 2304)
+    _CVT.format(0) + _ATT.format(0) + "projection_value.weight",
+    _CVT.format(0) + "layers.0.intermediate.dense.weight",
+    _CVT.format(1) + "embedding.convolution_embeddings.projection.weight",                                   # stage-2 patch embedding 3x3/s2
+    _CVT.format(1) + _ATT.format(1) + "projection_key.weight",                                               # stage-2 attention (3 heads, 2304 x 576)
+    _CVT.format(1) + _ATT.format(3) + "convolution_projection_value.convolution_projection.convolution.weight",
+    _CVT.format(1) + "layers.2.output.dense.weight",
+    _CVT.format(2) + "cls_token",
+    _CVT.format(2) + _ATT.format(7) + "projection_value.weight",                                             # stage-3 attention (6 heads, 577 x 145)
+    _CVT.format(2) + _ATT.format(0) + "projection_query.weight",
+    _CVT.format(2) + _ATT.format(15) + "convolution_projection_query.convolution_projection.normalization.bias",
+    _CVT.format(2) + "layers.15.intermediate.dense.weight",                                                  # stage-3 MLP
+    _CVT.format(2) + "layers.8.output.dense.weight",
+    _CVT.format(2) + "layers.4.layernorm_after.weight",
+    "encoder.projection_head.projection.weight",
+    "encoder.projection_head.layer_norm.weight",
+    "decoder.bert.encoder.layer.0.attention.self.query.weight",
+    "decoder.bert.encoder.layer.5.attention.self.value.weight",
+    "decoder.bert.encoder.layer.3.attention.output.dense.weight",
+    "decoder.bert.encoder.layer.2.crossattention.self.key.weight",
+    "decoder.bert.encoder.layer.0.crossattention.self.query.weight",
+    "decoder.bert.encoder.layer.3.crossattention.output.dense.weight",
+    "decoder.bert.encoder.layer.4.intermediate.dense.weight",
+    "decoder.bert.encoder.layer.5.output.dense.weight",
+    "decoder.bert.encoder.layer.1.output.LayerNorm.weight",
+    "decoder.bert.embeddings.word_embeddings.weight",                                                        # tied LM head
+    "decoder.bert.embeddings.position_embeddings.weight",
+    "decoder.bert.embeddings.token_type_embeddings.weight",
+    "decoder.cls.predictions.transform.dense.weight",
+    "decoder.cls.predictions.bias",
+]
+
+
 def fixture_tf_full():
     """The full-size multi-image model (CvT-21 + BERT-6, vocab 30000) teacher-forced at T = 256: logits sample, argmax + margins at sampled
     positions, cross-entropy loss (configs[1]/[2] shapes at batch 2)."""
@@ -734,8 +774,45 @@ def fixture_tf_full():
          "logits_sample": sample(lg, 65536), "logits_stats": stats(lg), "loss": np.array(loss.item()),
          "logits_argmax": lg.argmax(-1).numpy(), "logits_margin": (top2[..., 0] - top2[..., 1]).numpy(),
          "logits_rows": rows.numpy(), "logits_row_slices": lg[:, rows, :512].numpy().astype(np.float16)}
+    # ---- the training step's gradients at this size (single.py:449-475: forward -> F.cross_entropy -> loss.backward()), eval-mode dropout /
+    # BatchNorm: the second pass below runs with autograd on EVERY parameter; slices of parameters spanning every kernel family of the backward
+    for p in model.parameters():
+        p.requires_grad_(True)
+    out = model(pixel_values=x, decoder_input_ids=inp, decoder_attention_mask=am, decoder_token_type_ids=tt, return_dict=True)
+    loss_g = torch.nn.functional.cross_entropy(out.logits.permute(0, 2, 1), lab, ignore_index=PAD)
+    assert torch.equal(out.logits.detach(), lg)
+    loss_g.backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    d["grad_names"] = np.array(TF_FULL_GRADS)
+    for i, n in enumerate(TF_FULL_GRADS):
+        d[f"grad{i}_sample"] = sample(grads[n], 4096)
+        d[f"grad{i}_stats"] = stats(grads[n])
+    d["grad_total_norm"] = np.array(torch.sqrt(sum((v.double() ** 2).sum() for v in grads.values())).item())
+    d["grad_encoder_norm"] = np.array(torch.sqrt(sum((v.double() ** 2).sum() for n, v in grads.items() if n.startswith("encoder."))).item())
+    d["grad_decoder_norm"] = np.array(torch.sqrt(sum((v.double() ** 2).sum() for n, v in grads.items() if n.startswith("decoder."))).item())
     np.savez_compressed(os.path.join(OUT, "tf_full.npz"), **d)
-    print("tf_full loss", loss.item(), stats(lg))
+    print("tf_full loss", loss.item(), stats(lg), "gradnorm", d["grad_total_norm"], d["grad_encoder_norm"], d["grad_decoder_norm"])
+
+
+_LDEC = "decoder.base_model.model."
+C5_SCST_GRADS = [
+    _LDEC + "bert.encoder.layer.0.attention.self.query.lora_A.default.weight",
+    _LDEC + "bert.encoder.layer.0.attention.self.query.lora_B.default.weight",
+    _LDEC + "bert.encoder.layer.5.attention.self.key.lora_A.default.weight",
+    _LDEC + "bert.encoder.layer.3.attention.self.key.lora_B.default.weight",
+    _LDEC + "bert.encoder.layer.2.attention.self.query.base_layer.weight",
+    _LDEC + "bert.encoder.layer.4.attention.self.value.weight",
+    _LDEC + "bert.encoder.layer.1.attention.output.dense.weight",
+    _LDEC + "bert.encoder.layer.0.crossattention.self.key.weight",
+    _LDEC + "bert.encoder.layer.5.crossattention.self.value.weight",
+    _LDEC + "bert.encoder.layer.3.crossattention.self.query.weight",
+    _LDEC + "bert.encoder.layer.2.intermediate.dense.weight",
+    _LDEC + "bert.encoder.layer.5.output.dense.weight",
+    _LDEC + "bert.encoder.layer.4.output.LayerNorm.bias",
+    _LDEC + "bert.embeddings.word_embeddings.weight",
+    _LDEC + "bert.embeddings.position_embeddings.weight",
+    _LDEC + "cls.predictions.transform.dense.weight",
+]
 
 
 def fixture_longitudinal_c5():
@@ -771,7 +848,46 @@ def fixture_longitudinal_c5():
          "enc_sample": sample(eo.last_hidden_state, 16384), "logits_sample": sample(lg, 65536), "logits_stats": stats(lg),
          "loss": np.array(loss.item()), "logits_argmax": lg.argmax(-1).numpy(), "logits_margin": (top2[..., 0] - top2[..., 1]).numpy(),
          "greedy": greedy.numpy(), "greedy_margin": margins, "greedy_argmax": argm}
+    # ---- the SCST sampling call + REINFORCE backward at this size (scst/gt_prompt.py:38-40 every decoder parameter trainable, :162-180 the
+    # grad-enabled generate.__wrapped__ with top-k 50, :211-246 reinforce_loss): sampled ids, the processed scores' kept sets, per-token nll,
+    # the loss for a fixed advantage and gradient slices of the decoder (LoRA adapters and base weights)
+    for p in model.decoder.parameters():
+        p.requires_grad_(True)
+    new = 24
+    torch.manual_seed(233)
+    smp = type(model).generate.__wrapped__(model, input_ids=prompt, special_token_ids=[BOS, SEP], encoder_outputs=eo, bos_token_id=BOS,
+                                           eos_token_id=EOS, pad_token_id=PAD, mask_token_id=PAD, return_dict_in_generate=True,
+                                           do_sample=True, num_beams=1, use_cache=True, output_scores=True, top_p=1.0, top_k=50,
+                                           temperature=1.0, max_new_tokens=new)
+    seqs = smp["sequences"]
+    if torch.all(seqs[:, 0] == BOS):
+        seqs = seqs[:, 1:]
+    scores = torch.stack(smp["scores"], dim=-1)                           # [B, V, T], carries autograd
+    assert scores.requires_grad
+    sampled = seqs[:, P:]
+    adv = torch.tensor([0.31, -0.27])
+    nll = torch.nn.functional.nll_loss(torch.log_softmax(scores, dim=1), sampled, ignore_index=PAD, reduction="none")
+    rl = (nll.sum(-1) * adv).mean()
+    rl.backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert not any(n.startswith("encoder.") for n in grads)
+    finite = torch.isfinite(scores.detach())
+    d.update({"scst_sampled_sequences": seqs.numpy(), "scst_advantage": adv.numpy(), "scst_nll": nll.detach().numpy(),
+              "scst_reinforce_loss": np.array(rl.item()), "scst_finite_count": finite.sum(1).numpy(),
+              "scst_scores_at_sampled": torch.gather(scores.detach(), 1, sampled[:, None, :])[:, 0].numpy(),
+              "scst_kth_score": torch.topk(scores.detach(), 50, dim=1)[0][:, -1].numpy(), "scst_grad_names": np.array(C5_SCST_GRADS)})
+    for i, n in enumerate(C5_SCST_GRADS):
+        d[f"scst_grad{i}_sample"] = sample(grads[n], 4096)
+        d[f"scst_grad{i}_stats"] = stats(grads[n])
+    d["scst_grad_total_norm"] = np.array(torch.sqrt(sum((v.double() ** 2).sum() for v in grads.values())).item())
+    # the tied word-embedding / LM-head matrix: 99 % of its gradient norm sits in the rows of the tokens that were fed or sampled; the other ~2400
+    # non-zero rows are the kept-but-not-sampled entries of the top-50 sets, whose membership at the 50th place a bf16 implementation decides
+    # differently (a strided sample of the matrix is dominated by them) -- so whole rows of sampled and prompt tokens are recorded as well
+    rows = torch.unique(torch.cat([sampled.reshape(-1), prompt[0, :16]]))
+    d["scst_wordemb_rows"] = rows.numpy()
+    d["scst_wordemb_row_grads"] = grads[_LDEC + "bert.embeddings.word_embeddings.weight"][rows].numpy()
     np.savez_compressed(os.path.join(OUT, "longitudinal_c5.npz"), **d)
+    print("longitudinal_c5 reinforce", rl.item(), "gradnorm", d["scst_grad_total_norm"], "sampled", sampled[0, :8].tolist())
     print("longitudinal_c5 loss", loss.item(), "greedy", greedy[:, P:].tolist())
 
 

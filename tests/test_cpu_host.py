@@ -456,6 +456,14 @@ def test_string_worker_child_process_returns_the_in_process_result_and_fails_sof
             ids2, mask2 = strings.pad_and_stack([(ha[0], ha[1]), (hb[0], hb[1])], tok.pad_token_id)
             assert np.array_equal(ids2, want[0]) and np.array_equal(mask2, want[1])
         assert w.result(timeout=1) is None                                  # nothing pending: no wait, no answer
+        # a step that failed between submit() and result() leaves an unread answer behind: the NEXT step's result() must return the answer to ITS
+        # request (requests carry a sequence number), not the previous batch's -- same shapes, silently wrong rewards otherwise
+        a2 = a.copy(); a2[:, 5:20] = 77
+        assert w.submit(a, b) and w.submit(a2, b)
+        got = w.result(timeout=60)
+        want2 = strings.report_tokens([a2, b], [1, 3, 2], rep, tok, kw)
+        assert got is not None and np.array_equal(got[0], want2[0]) and got[2] == want2[2] and not np.array_equal(want2[0], want[0])
+        assert w.dropped == 1 and w.result(timeout=1) is None
         assert w.submit(np.zeros((2, 3, 4), dtype=np.int64))                # a request the child cannot serve (3-D ids)
         assert w.result(timeout=60) is None and w.alive                     # ... is an error reply, not a dead worker
         w.proc.kill(); w.proc.wait()

@@ -436,7 +436,10 @@ def test_attention_strided_views(ops):
 
 @pytest.mark.parametrize("B,H,Tq,Tk,causal,masked", [(2, 1, 200, 77, False, False), (1, 3, 577, 145, False, False),
                                                      (2, 12, 40, 40, True, True), (2, 12, 256, 256, True, False),
-                                                     (2, 12, 70, 1152, False, True)])
+                                                     (2, 12, 70, 1152, False, True),
+                                                     # the CvT-21 @384 stage-1 / stage-2 shapes of the benchmark (1 head, 9216 queries x 2304 keys;
+                                                     # 3 heads, 2304 x 576): they select attn_bwd_dq2_kernel<4,0> and the large-grid dK/dV kernels
+                                                     (2, 1, 9216, 2304, False, False), (2, 3, 2304, 576, False, False)])
 def test_attention_bwd(ops, B, H, Tq, Tk, causal, masked):
     D = H * 64
     q, k, v = dev(rnd(B, Tq, D).to(BF)), dev(rnd(B, Tk, D, seed=1).to(BF)), dev(rnd(B, Tk, D, seed=2).to(BF))
@@ -459,7 +462,7 @@ def test_attention_bwd(ops, B, H, Tq, Tk, causal, masked):
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,causal,masked", [(2, 12, 40, 40, True, True), (2, 12, 256, 256, True, False), (2, 12, 70, 1152, False, True),
-                                                     (1, 3, 200, 77, False, False)])
+                                                     (1, 3, 200, 77, False, False), (1, 1, 9216, 2304, False, False), (1, 3, 2304, 576, False, False)])
 def test_attention_dropout_fwd_bwd(ops, B, H, Tq, Tk, causal, masked):
     """Train-mode dropout on the probabilities: forward and both backward kernels regenerate the SAME counter-based mask that
     cxr_dropout_mask materialises (rows = (b*H+h, query), cols = key), and match autograd of softmax -> mask/(1-p) -> .V"""

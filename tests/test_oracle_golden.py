@@ -320,6 +320,58 @@ def test_full_size_tf_logits_and_loss_match_reference():
     assert np.array_equal(logits.argmax(-1).numpy()[safe], g["logits_argmax"][safe])
 
 
+def test_full_size_tf_gradients_match_reference():
+    """The training step's backward at the size the headline is measured on (CvT-21 @384, BERT-6, V = 30000, T = 256; single.py:449-475): the
+    oracle's autograd gradients of 34 parameters spanning every kernel family equal the reference's, and so does the total norm over them."""
+    g, cfg, sd, x, inp, lab, am, tt = gu.tf_full_case()
+    names = [str(n) for n in g["grad_names"]]
+    assert len(names) >= 30
+    leaves = {n: sd[n].clone().requires_grad_(True) for n in names}
+    sd2 = dict(sd)
+    sd2.update(leaves)                                           # (the oracle's LM head reads word_embeddings.weight itself: tied as in the reference)
+    h, mask = ocvt.encoder_forward(x, sd2, cfg.encoder)
+    logits = obert.decoder_forward(inp, sd2, cfg.decoder, h, mask, am, tt, None)
+    loss = ogen.tf_cross_entropy(logits, lab, gu.PAD)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    loss.backward()
+    for i, n in enumerate(names):
+        gr = leaves[n].grad
+        assert gu.rel_rms(gu.sample(gr, 4096), g[f"grad{i}_sample"]) < 2e-3, (n, gu.rel_rms(gu.sample(gr, 4096), g[f"grad{i}_sample"]))
+        np.testing.assert_allclose(gu.stats(gr)[3], g[f"grad{i}_stats"][3], rtol=2e-3, err_msg=n)
+
+
+def test_longitudinal_c5_scst_reinforce_gradients_match_reference():
+    """configs[4] shape (3 images, 128-token prompt, LoRA): the reference's sampling call (generate.__wrapped__, top-k 50) + reinforce_loss +
+    backward with every decoder parameter trainable (scst/gt_prompt.py:38-40,162-180,211-246), restated as ONE teacher-forced pass over the
+    reference's sampled ids: kept sets, per-token nll, loss and 16 gradient slices."""
+    g, cfg, sd, x = gu.longitudinal_c5_case()
+    seqs = torch.from_numpy(g["scst_sampled_sequences"])
+    P = g["prompt_ids"].shape[1]
+    sampled = seqs[:, P:]
+    names = [str(n) for n in g["scst_grad_names"]]
+    leaves = {n: sd[n].clone().requires_grad_(True) for n in names}
+    sd2 = dict(sd)
+    sd2.update(leaves)                                           # (the oracle's LM head reads word_embeddings.weight itself: tied as in the reference)
+    with torch.no_grad():
+        h, mask = ocvt.encoder_forward(x, sd, cfg.encoder)
+    fed, am, tt, pos = ogen.step_inputs("longitudinal", seqs, [gu.BOS, gu.SEP], gu.PAD, gu.BOS)
+    lg = obert.decoder_forward(fed, sd2, cfg.decoder, h, mask, am, tt, pos)[:, P - 1:-1]
+    sc = ogen.top_k_filter(lg, 50).permute(0, 2, 1)
+    assert np.array_equal(torch.isfinite(sc).sum(1).numpy(), g["scst_finite_count"])
+    np.testing.assert_allclose(torch.gather(sc, 1, sampled[:, None, :])[:, 0].detach().numpy(), g["scst_scores_at_sampled"], atol=2e-4)
+    nll = torch.nn.functional.nll_loss(torch.log_softmax(sc, dim=1), sampled, ignore_index=gu.PAD, reduction="none")
+    np.testing.assert_allclose(nll.detach().numpy(), g["scst_nll"], atol=2e-4)
+    loss = ogen.reinforce_loss(sc, sampled, torch.from_numpy(g["scst_advantage"]), gu.PAD)
+    assert abs(loss.item() - float(g["scst_reinforce_loss"])) < 2e-4
+    loss.backward()
+    for i, n in enumerate(names):
+        gr = leaves[n].grad
+        assert gu.rel_rms(gu.sample(gr, 4096), g[f"scst_grad{i}_sample"]) < 2e-3, (n, gu.rel_rms(gu.sample(gr, 4096), g[f"scst_grad{i}_sample"]))
+        np.testing.assert_allclose(gu.stats(gr)[3], g[f"scst_grad{i}_stats"][3], rtol=2e-3, err_msg=n)
+    wg = leaves["decoder.base_model.model.bert.embeddings.word_embeddings.weight"].grad[torch.from_numpy(g["scst_wordemb_rows"])]
+    assert gu.rel_rms(wg.numpy(), g["scst_wordemb_row_grads"]) < 2e-3
+
+
 def test_longitudinal_c5_shape_matches_reference():
     g, cfg, sd, x = gu.longitudinal_c5_case()
     inp, am, pos = (torch.from_numpy(g[k]) for k in ("input_ids", "attention_mask", "position_ids"))

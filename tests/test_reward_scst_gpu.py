@@ -128,7 +128,8 @@ def test_chexbert_labeller_heads(cuda):
         o += n
 
 
-def test_scst_step_matches_oracle_reinforce(cuda):
+@pytest.mark.parametrize("temperature", [1.0, 0.7])
+def test_scst_step_matches_oracle_reinforce(cuda, temperature):
     from cxrmate_amd import modelling
     from cxrmate_amd.scst import scst_step
     from cxrmate_amd.training import FusedAdamW
@@ -149,7 +150,7 @@ def test_scst_step_matches_oracle_reinforce(cuda):
 
     special = dict(bos=gu.BOS, eos=gu.EOS, sep=gu.SEP, pad=gu.PAD, pmt_sep=gu.PMT_SEP)
     torch.manual_seed(3)
-    out = scst_step(m, opt, reward_fn, x.cuda(), prompt.cuda(), None, special, decoder_max_len=10)
+    out = scst_step(m, opt, reward_fn, x.cuda(), prompt.cuda(), None, special, decoder_max_len=10, temperature=temperature)      # scst_sample_temperature
     torch.cuda.synchronize()
     assert len(calls) == 2 and np.isfinite(out["loss"].item())
     sampled = out["sampled"].cpu()
@@ -165,7 +166,7 @@ def test_scst_step_matches_oracle_reinforce(cuda):
         lg = obert.decoder_forward(fed, sd, cfg.decoder, h, emask, am, tt, pos)
         # the oracle's filter keeps its fp32 top-50 AND the sampled token (which can sit at the edge of the bf16 top-50, see test_model_gpu):
         # the loss is compared unconditionally
-        sc = ogen.top_k_filter(lg[:, P - 1:-1].float(), 50, keep=sampled).permute(0, 2, 1)
+        sc = ogen.top_k_filter(lg[:, P - 1:-1].float() / temperature, 50, keep=sampled).permute(0, 2, 1)        # TemperatureLogitsWarper, then top-k
         nll = torch.nn.functional.nll_loss(torch.log_softmax(sc, 1), sampled, ignore_index=gu.PAD, reduction="none")
     assert bool(torch.isfinite(nll).all())
     oloss = (nll.sum(-1) * adv).mean()
