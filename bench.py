@@ -11,9 +11,11 @@ BASELINE.json `metric` = "SCST steps/sec + TF tokens/sec/GPU, 2-image 384x384 st
     model.train(), bf16 MFMA with fp32 accumulation and fp32 master weights, synthetic data, random-init weights. Weak scaling (pure data
     parallel, study-level sharding), gradients all-reduced over RCCL.
   * `scst`: SCST steps/s at the per-GPU shape of configs[3] (16 studies x 2 images, 255 sampled + 255 greedy tokens, CXR-BERT stand-in reward,
-    REINFORCE + AdamW on the decoder), with the roofline of its cached decode token-step. Since round 5 its `value` is the reference's own step --
-    generated ids -> strings -> tokenizer -> reward at R = 128 reward tokens (scst/gt_prompt.py:90-91,120-128,192-197) -- and the step with
-    synthetic reward ids in place of the string round trip (rounds 1-4) stands beside it as `scst.synthetic_ids`.
+    REINFORCE + AdamW on the decoder), with the roofline of its cached decode token-step. Since round 5 its `value` is the step with the reference's
+    string round trip -- generated ids -> strings -> tokenizer -> reward (scst/gt_prompt.py:90-91,120-128,192-197) -- with the reward tokenizer
+    TRUNCATED AT R = 128 tokens (the reference's own limit is 512: the same step at 512 is `scst.string_round_trip.r512`); the step with
+    synthetic reward ids in place of the string round trip (rounds 1-4) stands beside it as `scst.synthetic_ids`. Since round 6 the labels change
+    every step in all variants: their rows are tokenised and embedded inside the timed step.
   * `tf_single`: configs[1] (single-image studies, batch 32), `forward_only`: bf16 MFMA utilisation of the encoder + decoder FORWARD (the
     north_star's >= 40 % target is defined on it), `cpu_baseline`: the oracle/ restatement of the reference path on the host cores.
 Prints ONE JSON line on rank 0.
@@ -196,8 +198,12 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
         enc_ms = {"bf16": t16, "e4m3": enc_time(), "images": B * N}
     else:
         prompt = torch.tensor([[8, 10, 9, 11, 1]] * B, device=dev)
-    label_ids = torch.randint(1000, 30000, (B, 128), generator=g).to(dev)
+    # labels change every step, as in training (a new mini-batch of studies): a pool of label id matrices, one per step; the label rows are embedded
+    # INSIDE the timed step (once per step: the reference embeds them in both of its reward calls, tools/rewards/cxrbert.py:49-64)
+    n_pool = 64
+    label_pool = torch.randint(1000, 30000, (n_pool, B, 128), generator=g).to(dev)
     ones = torch.ones(B, 128, dtype=torch.int64, device=dev)
+    step_no = {"k": 0}
 
     def retok(ids):                                               # ids [B, L] -> synthetic "re-tokenised" R=128 WordPiece ids
         pred = torch.zeros(ids.shape[0], 128, dtype=torch.int64, device=dev)
@@ -205,17 +211,13 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
         pred[:, :n] = ids[:, :n] % 30522
         return pred
 
-    label_emb = {}
-
     def reward_fn(ids):
-        return reward.reward_from_ids(retok(ids), ones, label_ids, ones)
+        return reward.reward_from_ids(retok(ids), ones, label_pool[step_no["k"] % n_pool], ones)
 
-    def reward_pair(a, b):                                        # sampled + greedy rows as ONE 2B-row CXR-BERT forward, labels embedded once
+    def reward_pair(a, b):                           # sampled + greedy + THIS STEP'S label rows as ONE 3B-row CXR-BERT forward (labels embedded once per step)
         from cxrmate_amd import ops
-        if "e" not in label_emb:
-            label_emb["e"] = reward.embed_ids(label_ids, ones)
-        pe = reward.embed_ids(torch.cat([retok(a), retok(b)], 0), torch.cat([ones, ones], 0))
-        r = ops.cosine_rows(pe, torch.cat([label_emb["e"], label_emb["e"]], 0))
+        e = reward.embed_ids(torch.cat([retok(a), retok(b), label_pool[step_no["k"] % n_pool]], 0), torch.cat([ones, ones, ones], 0))
+        r = ops.cosine_rows(e[:2 * B], torch.cat([e[2 * B:], e[2 * B:]], 0))
         return r[:B], r[B:]
 
     reward_fn.pair = reward_pair
@@ -223,11 +225,43 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
     special = dict(bos=1, eos=None, sep=3, pad=4, pmt_sep=9)
 
     def step():
+        step_no["k"] += 1
         return scst_step(model, opt, reward_fn, images, prompt, None, special, decoder_max_len=args.new_tokens + 1)
 
     for _ in range(max(2, args.warmup)):                          # the first two steps capture the decode hipGraphs (sample + greedy)
         step()
     dt, out = timed(step, steps, world, dev)
+    # what the label rows cost: the reward forward with and without them, alone on the stream (HIP events; inside the step they ride in one launch chain)
+    with torch.no_grad():
+        pa = torch.cat([retok(label_pool[1]), retok(label_pool[2])], 0)
+
+        def fwd_ms(with_labels):
+            ids = torch.cat([pa, label_pool[3]], 0) if with_labels else pa
+            m_ = torch.ones_like(ids)
+            for _ in range(2):
+                reward.embed_ids(ids, m_)
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            for _ in range(5):
+                reward.embed_ids(ids, m_)
+            a1.record()
+            torch.cuda.synchronize()
+            return a0.elapsed_time(a1) / 5
+        label_forward = {"reward_forward_2B_rows_ms": fwd_ms(False), "reward_forward_3B_rows_with_labels_ms": fwd_ms(True),
+                         "separate_B_row_label_forward_ms": None}
+        lab1 = label_pool[4]
+        for _ in range(2):
+            reward.embed_ids(lab1, ones)
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        for _ in range(5):
+            reward.embed_ids(lab1, ones)
+        a1.record()
+        torch.cuda.synchronize()
+        label_forward["separate_B_row_label_forward_ms"] = a0.elapsed_time(a1) / 5
+        label_forward["label_forward_ms"] = label_forward["reward_forward_3B_rows_with_labels_ms"] - label_forward["reward_forward_2B_rows_ms"]
+        label_forward["what"] = ("labels change every step; their B rows are embedded inside the timed step, once per step, in the same forward as the 2B prediction "
+                                 "rows (the reference embeds them in each of its two reward calls per step)")
     # the cached decode of one step, timed live with HIP events on the launch stream (the graph replays run on torch's current stream)
     with torch.no_grad():
         eo = model.encoder(images)
@@ -256,7 +290,7 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
                                      "frac": ENC_FWD_GF_PER_IMAGE * enc_ms["images"] / enc_ms["e4m3"] / MFMA_FP8_PEAK_TF,
                                      "bf16_achieved": ENC_FWD_GF_PER_IMAGE * enc_ms["images"] / enc_ms["bf16"],
                                      "what": "algorithmic encoder FLOPs (BASELINE.md section 2) of the step's 48 images / HIP-event time of the forward, train-mode BatchNorm"},
-                "decode_ms_per_step": dec_ms,
+                "decode_ms_per_step": dec_ms, "labels": "change every step (embedded inside the timed step)", "label_forward": label_forward,
                 "us_per_token_step": dec_ms * 1e3 / n_tok, "loss": float(out["loss"].item()),
                 "workload": "BASELINE.json configs[4] per-GPU shape: 16 studies x 3 images, 128-token prior-report prompt, frozen encoder with e4m3 "
                             "(OCP) MFMA linear layers (static per-tensor scales), sample + greedy as one 32-row cached decode, REINFORCE + AdamW; "
@@ -269,7 +303,8 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
     # reward tokens. The same step with R = 128 SYNTHETIC ids in place of the string round trip (what rounds 1-4 reported as `value`) stands beside
     # it as `synthetic_ids`: equal GPU work, no host string work.
     synth = {"value": world * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "loss": float(out["loss"].item()),
-             "what": "retok(ids) % 30522 on the device in place of decode -> strings -> tokenizer (rounds 1-4 headline)"}
+             "labels": "change every step (embedded inside the timed step)", "label_forward": label_forward,
+             "what": "retok(ids) % 30522 on the device in place of decode -> strings -> tokenizer (rounds 1-4 headline; since round 6 with new labels every step)"}
     head_dt = (strings["ms_per_step"] * 1e-3 * steps) if (strings and strings.get("ms_per_step")) else dt
     if strings and strings.get("ms_per_step"):
         strings["vs_synthetic_ids_step"] = strings["ms_per_step"] / synth["ms_per_step"]
@@ -277,8 +312,10 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
             "headline_is": "string_round_trip" if head_dt is not dt else "synthetic_ids",
             "steps_per_sec_per_gpu": steps / head_dt, "steps": steps, "ms_per_step": head_dt / steps * 1e3, "studies_per_sec": world * B * steps / head_dt,
             "new_tokens_sampled_and_greedy": n_tok, "synthetic_ids": synth,
-            "reward": "CXR-BERT stand-in (BERT-base + CLS projection head: architecture assumed, PARITY UNPINNED -- SURVEY.md 8c), R = 128 reward tokens "
-                      "on both paths, ONE 32-row forward per step (sampled + greedy together, labels cached)",
+            "labels": "change every step: new label strings / ids per step, tokenised and embedded inside the timed step (once per step)",
+            "reward": "CXR-BERT stand-in (BERT-base + CLS projection head: architecture assumed, PARITY UNPINNED -- SURVEY.md 8c), reward tokenizer truncated at "
+                      "R = 128 on both paths (SURVEY.md 8d; the reference's limit is 512: `string_round_trip.r512`), ONE 48-row forward per step (sampled + greedy "
+                      "+ this step's label rows together)",
             "workload": "BASELINE.json configs[3] per-GPU shape: sample (top-k 50) + greedy baseline as one 32-row cached decode replayed from "
                         "hipGraphs, REINFORCE through one teacher-forced pass, AdamW on the 80.9 M decoder parameters",
             "mode": "eval" if args.eval_mode else "model.train(): batch-statistics BatchNorm in the frozen encoder, dropout 0.1 in both decodes and in "
@@ -341,15 +378,42 @@ def scst_string_round_trip(args, model, opt, images, prompt, special, dev, B, st
     impression strings (split_and_decode_sections + tokenizer.decode) -> CXR-BERT tokenizer -> BERT-base forwards, through reward.ReportReward on
     pinned host copies. Tokenizer: the synthetic byte-BPE of tests/golden (no real vocabulary offline). The tokenizer call truncates at R = 128
     (the reference's own limit is 512, tools/rewards/cxrbert.py:38): the reward BERT then sees as many tokens as on the synthetic-id
-    path, so the two step times differ by the host's string work only."""
+    path, so the two step times differ by the host's string work only. The same step at the reference's 512 limit is reported as `r512`."""
     import transformers
-    from cxrmate_amd.reward import CXRBERTReward, ReportReward
-    from cxrmate_amd.scst import scst_step
+    from cxrmate_amd.reward import CXRBERTReward
     tok = transformers.PreTrainedTokenizerFast(tokenizer_file=os.path.join(ROOT, "tests", "golden", "tokenizer.json"), unk_token="[UNK]",
                                                pad_token="[PAD]", cls_token="[BOS]", sep_token="[SEP]", mask_token="[MASK]", bos_token="[BOS]",
                                                eos_token="[EOS]")
-    reward = CXRBERTReward(dev, tokenizer=tok, seed=1, max_length=128)
-    labels = [["The lungs are clear without focal consolidation. No pleural effusion or pneumothorax. No acute cardiopulmonary process."]] * B
+    # labels change every step, as in training: a pool of report-like label strings, B different ones per step (so neither the reward's label cache
+    # nor the tokenizer sees a repeated batch inside the timed region); they are tokenised and embedded inside the timed step, once per step
+    findings = ["The lungs are clear without focal consolidation.", "There is a small left pleural effusion.", "Heart size is mildly enlarged.",
+                "No pneumothorax is seen.", "Bibasilar atelectasis is noted.", "The mediastinal contours are unremarkable.",
+                "Interval placement of a right internal jugular catheter.", "Mild pulmonary vascular congestion."]
+    impressions = ["No acute cardiopulmonary process.", "Findings suggest mild pulmonary edema.", "Stable appearance of the chest.",
+                   "Small effusion, otherwise unremarkable.", "Possible early pneumonia in the right lower lobe."]
+
+    def labels_of(k):
+        return [[f"{findings[(k * 7 + b) % 8]} {findings[(k * 3 + 2 * b + 1) % 8]} Study {k * B + b}. {impressions[(k + b) % 5]}"] for b in range(B)]
+
+    def run(max_length, n_steps):
+        reward = CXRBERTReward(dev, tokenizer=tok, seed=1, max_length=max_length)
+        return _scst_string_steps(args, model, opt, images, prompt, special, dev, B, reward, labels_of, tok, n_steps, world, max_length)
+    res = run(128, steps)
+    if os.environ.get("CXR_BENCH_R512", "1") != "0":
+        # the same step with the reward tokenizer's limit at the reference's own 512 (tools/rewards/cxrbert.py:38): the 255 generated tokens decode through
+        # the 400-entry byte-BPE fixture to strings of more than 128 reward tokens, so the reward BERT and the host tokenizer do more work here
+        try:
+            r512 = run(512, max(2, min(steps, 4)))
+            res["r512"] = {k: r512[k] for k in ("ms_per_step", "steps_per_sec", "steps", "reward_tokens", "reward_token_rows", "string_worker")}
+        except Exception as e:
+            res["r512"] = {"error": str(e)}
+    return res
+
+
+def _scst_string_steps(args, model, opt, images, prompt, special, dev, B, reward, labels_of, tok, steps, world, max_length):
+    from cxrmate_amd.reward import ReportReward
+    from cxrmate_amd.scst import scst_step
+    labels = labels_of(0)
     # The CPU part of the reward (ids -> strings -> reward-tokenizer ids) runs in a child process beside this process's kernel launches
     # (reward.ReportReward(worker=True); CXR_STRING_WORKER=0: in-process). Host / GPU timeline of the step, scripts/r5/scst_timeline.py: in-process the GPU
     # idles ~3 ms between the re-scoring forward and the reward forward while the host turns ids into strings into ids (105.7 ms per step); with the child
@@ -357,18 +421,32 @@ def scst_string_round_trip(args, model, opt, images, prompt, special, dev, B, st
     # back to the in-process path (time-outs on every wait).
     rfn = ReportReward(model, _InVocabTokenizer(tok), reward, labels, 1, 3, 2, worker=os.environ.get("CXR_STRING_WORKER", "1") != "0")
 
+    k = {"k": 0}
+    widths = []
+    embed_ids = reward.embed_ids
+
+    def counting_embed(ids, mask):                                # (bookkeeping only: rows x tokens of every reward forward)
+        widths.append(tuple(ids.shape))
+        return embed_ids(ids, mask)
+    reward.embed_ids = counting_embed
+
     def step():
+        k["k"] += 1
+        rfn.labels = labels_of(k["k"])                            # a new mini-batch's labels
         return scst_step(model, opt, rfn, images, prompt, None, special, decoder_max_len=args.new_tokens + 1, reward_on_host=True)
 
     try:
         step()
         used0 = rfn.worker_used
+        del widths[:]
         dt, out = timed(step, steps, world, dev)
         served = rfn.worker_used - used0
     finally:
         rfn.close()
     dt /= steps
-    return {"ms_per_step": dt * 1e3, "steps_per_sec": world / dt, "steps": steps, "loss": float(out["loss"].item()), "reward_tokens": 128,
+    return {"ms_per_step": dt * 1e3, "steps_per_sec": world / dt, "steps": steps, "loss": float(out["loss"].item()), "reward_tokens": max_length,
+            "reward_token_rows": {"forwards_per_step": len(widths) / max(steps, 1), "rows_x_tokens_of_the_last_forward": list(widths[-1]) if widths else None},
+            "labels": "B new label strings every step, tokenised beside the children's string work and embedded in the predictions' forward",
             "string_worker": {"steps_served_by_the_child_process": served, "of": steps},
             "host_ms": {"ids_to_strings": getattr(rfn, "last_decode_ms", None), "strings_to_ids": getattr(reward, "last_tokenize_ms", None),
                         "note": "in-process path only (the child process does this work when it serves a step)"},
@@ -528,8 +606,11 @@ def scst_dropin(args, dev, steps=3):
     bos, eos, sep, pad = tok.bos_token_id, None, tok.sep_token_id, tok.pad_token_id
     pmt_sep = tok.convert_tokens_to_ids("[PMT-SEP]")
     max_len = args.new_tokens + 1
+    step_no = {"k": 0}
 
     def step():
+        step_no["k"] += 1                                          # a new mini-batch's labels every step (no label cache hit inside the timed region)
+        batch["impression"] = [f"No acute cardiopulmonary process. Study {step_no['k'] * B + b}." for b in range(B)]
         prompt = model.tokenize_prompt(batch["previous_findings"], batch["previous_impression"], tok, max_len, add_bos_token_id=True)
         ids = prompt["input_ids"].to(dev)
         encoder_outputs = model.encoder(images)
@@ -565,7 +646,8 @@ def scst_dropin(args, dev, steps=3):
     return {"ms_per_step": dt / steps * 1e3, "steps_per_sec": steps / dt, "steps": steps, "loss": float(loss.item()),
             "what": "reference SCST caller sequence (scst/gt_prompt.py:62-246) on the drop-in classes: tokenize_prompt, encoder, generate.__wrapped__("
                     "do_sample=True, output_scores=True, top_k=50), torch.stack(scores, -1) [16, 30000, 255] fp32, split_and_decode_sections + string reward "
-                    "twice, greedy generate, log_softmax / nll_loss, backward, optimizer.step() on the decoder; 16 studies x 2 images, 255 new tokens",
+                    "twice, greedy generate, log_softmax / nll_loss, backward, optimizer.step() on the decoder; 16 studies x 2 images, 255 new tokens; labels "
+                    "change every step (embedded inside the step, once: the second reward call finds them cached)",
             "optimizer": "torch.optim.AdamW" if torch_adamw else "cxrmate_amd.optim.AdamW (torch.optim.Optimizer subclass on the fused kernel)"}
 
 

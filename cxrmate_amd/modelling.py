@@ -146,8 +146,10 @@ def _h_log_softmax(input, dim=None, _stacklevel=3, dtype=None):
 
 def _h_nll_loss(input, target, weight=None, size_average=None, ignore_index=-100, reduce=None, reduction="mean"):
     m = _meta(input)
-    if m is not None and m.get("dirty"):
-        return NotImplemented                               # edited in place since: torch's nll_loss on the (cached, edited) log-probabilities
+    if m is not None and (m.get("dirty") or (m.get("value") is not None and m["value"]._version != m.get("value_version"))):
+        # edited in place since -- directly (dirty) or through a view of the materialised value (`lp[:, 3].zero_()` goes through getitem, which
+        # hands out a plain view; the edit moves the value's version counter): torch's nll_loss on the (cached, edited) log-probabilities
+        return NotImplemented
     if (m is None or m.get("kind") != "pending_logp" or weight is not None or size_average is not None or reduce is not None or reduction != "none"
             or not torch.is_tensor(target) or target.dtype != torch.int64 or tuple(target.shape) != tuple(m["base"].shape[:2])):
         return NotImplemented
@@ -168,6 +170,7 @@ def _materialise_pending(obj):
             v = m.get("value")
             if v is None:
                 v = m["value"] = torch.log_softmax(m["base"], dim=-1).permute(0, 2, 1)
+                m["value_version"] = v._version
             return v
         return obj
     if isinstance(obj, (list, tuple)):

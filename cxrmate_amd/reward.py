@@ -113,20 +113,78 @@ class CXRBERTReward:
         lab = self._label_cache.get(flat)
         if lab is None:
             lab = self._encode(list(flat))
-            if len(self._label_cache) >= self._max_cache:
-                self._label_cache.clear()
-            self._label_cache[flat] = lab
+            self._remember(flat, lab)
         return lab
 
-    def _encode(self, texts):
+    def _remember(self, flat, lab):
+        if len(self._label_cache) >= self._max_cache:
+            self._label_cache.clear()
+        self._label_cache[flat] = lab
+
+    def _tokenize(self, texts):
         # reference: tokenizer.batch_encode_plus(batch_text_or_text_pairs=...) (cxrbert.py:33-40); transformers 5 dropped that
         # spelling in favour of __call__ -- same arguments, same result
         kw = self.encode_kw()
         bep = getattr(self.tokenizer, "batch_encode_plus", None) if "batch_encode_plus" in dir(type(self.tokenizer)) else None
+        return bep(batch_text_or_text_pairs=texts, **kw) if bep is not None else self.tokenizer(texts, **kw)
+
+    def _encode(self, texts):
         t0 = time.perf_counter()
-        tok = bep(batch_text_or_text_pairs=texts, **kw) if bep is not None else self.tokenizer(texts, **kw)
+        tok = self._tokenize(texts)
         self.last_tokenize_ms = (time.perf_counter() - t0) * 1e3               # host time of the tokenizer call (benchmarks report it)
         return self.embed_ids(tok.input_ids, tok.attention_mask)
+
+    def prepare_labels(self, labels):
+        """Tokenise the label strings of the coming reward call NOW (host work, no GPU call): ReportReward does it while its string workers decode the
+        generated ids, so that embed_with_labels finds the ids ready. No effect when the labels' embeddings are cached."""
+        flat = tuple(j for i in labels for j in i)
+        if flat in self._label_cache or self.tokenizer is None:
+            return
+        uniq = list(dict.fromkeys(flat))
+        tok = self._tokenize(uniq)
+        self.__dict__["_label_tok"] = (flat, uniq, tok.input_ids, tok.attention_mask)
+
+    @torch.no_grad()
+    def embed_with_labels(self, pred_ids, pred_mask, labels):
+        """(embeddings of the prediction rows [P,128], embeddings of the flattened labels [len,128]). The reference embeds predictions and labels by two
+        model calls per reward() and calls reward() twice per SCST step with the same labels (cxrbert.py:49-64; scst/gt_prompt.py:90-91,126-128). Here
+        the labels of a step are embedded ONCE -- duplicates removed -- and, when they are not cached from an earlier call, IN THE SAME forward as the
+        prediction rows (one 3B-row launch chain instead of a 2B-row and a B-row one: a BERT-base forward over <= 48 rows is launch-bound).
+        Padding both to the common length changes nothing: padded keys are masked and only the CLS row is read."""
+        flat = tuple(j for i in labels for j in i)
+        lab = self._label_cache.get(flat)
+        if lab is not None:
+            return self.embed_ids(pred_ids, pred_mask), lab
+        pre = self.__dict__.pop("_label_tok", None)
+        if pre is not None and pre[0] == flat:
+            uniq, lids, lmask = pre[1], pre[2], pre[3]
+        else:
+            uniq = list(dict.fromkeys(flat))
+            tok = self._tokenize(uniq)
+            lids, lmask = tok.input_ids, tok.attention_mask
+        pred_ids, pred_mask, lids, lmask = (torch.as_tensor(t) for t in (pred_ids, pred_mask, lids, lmask))
+        pad = getattr(self.tokenizer, "pad_token_id", None) or 0
+        L = max(pred_ids.shape[1], lids.shape[1])
+
+        def widen(t, fill):
+            if t.shape[1] == L:
+                return t
+            out = t.new_full((t.shape[0], L), fill)
+            out[:, : t.shape[1]] = t
+            return out
+        dev_side = pred_ids.device
+        ids = torch.cat([widen(pred_ids, pad), widen(lids.to(dev_side), pad)], 0)
+        mask = torch.cat([widen(pred_mask, 0), widen(lmask.to(dev_side), 0).to(pred_mask.dtype)], 0)
+        emb = self.embed_ids(ids, mask)
+        P = pred_ids.shape[0]
+        pos = {s_: i for i, s_ in enumerate(uniq)}
+        lab_u = emb[P:]
+        if len(flat) == len(uniq):
+            lab = lab_u
+        else:
+            lab = lab_u[torch.tensor([pos[s_] for s_ in flat], dtype=torch.int64, device=emb.device)]      # (row copies, no arithmetic)
+        self._remember(flat, lab)
+        return emb[:P], lab
 
     def reward(self, predictions, labels):
         assert isinstance(predictions, list), '"predictions" must be a list of strings.'
@@ -136,8 +194,11 @@ class CXRBERTReward:
         assert all(isinstance(j, str) for i in labels for j in i), 'each sub-list must have one or more strings.'
         if self.tokenizer is None:
             raise RuntimeError("CXRBERTReward needs the CXR-BERT tokenizer (not available offline): pass tokenizer=...")
-        pred = self._encode(predictions)
-        return ops.cosine_rows(pred, self.label_embeddings(labels))
+        t0 = time.perf_counter()
+        tok = self._tokenize(predictions)
+        self.last_tokenize_ms = (time.perf_counter() - t0) * 1e3               # host time of the tokenizer call (benchmarks report it)
+        pred, lab = self.embed_with_labels(tok.input_ids, tok.attention_mask, labels)
+        return ops.cosine_rows(pred, lab)
 
     @torch.no_grad()
     def similarity(self, predictions, labels):
@@ -197,6 +258,7 @@ class ReportReward:
         """Hand both halves' ids (host tensors whose copies have LANDED) to the child processes. -> ticket for pair_finish()."""
         if len(self.workers) == 2 and all(w.alive for w in self.workers):
             if self.workers[0].submit(sampled_host.numpy()) and self.workers[1].submit(greedy_host.numpy()):
+                self.reward.prepare_labels(self.labels)       # this step's labels are tokenised here while the children decode the generated ids
                 return ("worker", sampled_host, greedy_host)
         return ("inline", sampled_host, greedy_host)
 
@@ -214,7 +276,8 @@ class ReportReward:
         ids, mask = pad_and_stack([(g[0], g[1]) for g in got], 0 if pad_id is None else pad_id)
         self.last_sections = (got[1][2], got[1][3])
         self.worker_used += 1
-        both = ops.cosine_rows(self.reward.embed_ids(torch.from_numpy(ids), torch.from_numpy(mask)), self.reward.label_embeddings(self.labels + self.labels))
+        pe, le = self.reward.embed_with_labels(torch.from_numpy(ids), torch.from_numpy(mask), self.labels + self.labels)
+        both = ops.cosine_rows(pe, le)
         B = ids.shape[0] // 2
         return both[:B], both[B:]
 

@@ -126,7 +126,7 @@ def test_shard_studies_partition():
         assert sorted(sum(parts, [])) == list(range(n))
 
 
-def _dp_worker(rank, world, path, q):
+def _dp_worker(rank, world, path, q, fetched):
     import torch.distributed as dist
     from cxrmate_amd import dp
     dist.init_process_group("gloo", init_method=f"file://{path}", rank=rank, world_size=world)
@@ -154,6 +154,7 @@ def _dp_worker(rank, world, path, q):
     red16.wait()
     gathered = (gathered, st, st_fixed, flat16)
     q.put((rank, mine, flat, gathered, mean))
+    fetched.wait(120)                       # tensors travel as file descriptors served by THIS process: stay alive until the parent has rebuilt them
     dist.destroy_process_group()
 
 
@@ -163,10 +164,12 @@ def test_gradient_allreduce_and_sequence_allgather_gloo_world2():
     q = ctx.Queue()
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "rdzv")
-        procs = [ctx.Process(target=_dp_worker, args=(r, 2, path, q)) for r in range(2)]
+        fetched = ctx.Event()
+        procs = [ctx.Process(target=_dp_worker, args=(r, 2, path, q, fetched)) for r in range(2)]
         for p in procs:
             p.start()
         res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+        fetched.set()
         for p in procs:
             p.join(60)
             assert p.exitcode == 0
@@ -334,6 +337,15 @@ def test_pending_log_softmax_behaves_like_the_computed_tensor():
     tgt = torch.randint(0, 7, (2, 5))
     got = torch.nn.functional.nll_loss(lp, tgt, reduction="none")          # the recognised call, but on an edited tensor: torch's own
     assert torch.allclose(got, torch.nn.functional.nll_loss(2.0 * want, tgt, reduction="none"))
+    # an edit THROUGH A VIEW (getitem hands out a plain view of the cached value): no in-place call ever sees the pending tensor itself, the cached
+    # value's version counter moves -- a later nll_loss must again be torch's own on the edited values (round-5 advisor finding)
+    lp2 = torch.nn.functional.log_softmax(_as_boundary(base.detach().permute(0, 2, 1), kind="bvt", base=base.detach()), dim=1)
+    with torch.no_grad():
+        lp2[:, 3].zero_()
+    assert not lp2._cxr.get("dirty")
+    edited = want.clone(); edited[:, 3] = 0.0
+    got2 = torch.nn.functional.nll_loss(lp2, tgt, reduction="none")
+    assert torch.allclose(got2, torch.nn.functional.nll_loss(edited, tgt, reduction="none"))
 
 
 def test_fused_adamw_refuses_what_it_does_not_implement():
