@@ -453,7 +453,7 @@ def _scst_string_steps(args, model, opt, images, prompt, special, dev, B, reward
             "what": "scst_step(reward_on_host=True) with reward.ReportReward: async pinned copies of the sequences; all sections decoded by one call into the tokenizers "
                     "library and both halves re-tokenised by one call (truncated to R = 128) -- in a child process (strings.StringWorker; CXR_STRING_WORKER=0 or any "
                     "failure of the child: in this process) beside the launches of the re-scoring forward + warper threshold --, token ids uploaded through a pinned staging buffer, "
-                    "one 32-row CXR-BERT forward, label embeddings cached; synthetic byte-BPE tokenizer (tests/golden/tokenizer.json) on the random-init model's strings"}
+                    "one 48-row CXR-BERT forward (sampled + greedy + this step's label rows); synthetic byte-BPE tokenizer (tests/golden/tokenizer.json) on the random-init model's strings"}
 
 
 def tf_bench(args, rank, world, dev, model, n_images, steps, profile_gemm):

@@ -620,34 +620,3 @@ extern "C" int cxr_decode_step_inputs(const long* ids, long ld, int rows, int st
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }
-
-
-// ---------------------------------------------------------------------------------------------- round 5: CU-masked stream + placement probe (lab)
-extern "C" int cxr_stream_create_cu_mask(const unsigned int* mask, int words, void** stream_out) {
-    if (!mask || words <= 0 || !stream_out) return CXR_ERR_ARG;
-    hipStream_t s = nullptr;
-    const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
-    if (e != hipSuccess) { g_cxr_last_hip_error = (int)e; return CXR_ERR_LAUNCH; }
-    *stream_out = (void*)s;
-    return CXR_OK;
-}
-extern "C" int cxr_stream_destroy(void* stream) {
-    if (!stream) return CXR_ERR_ARG;
-    const hipError_t e = hipStreamDestroy((hipStream_t)stream);
-    if (e != hipSuccess) { g_cxr_last_hip_error = (int)e; return CXR_ERR_LAUNCH; }
-    return CXR_OK;
-}
-__global__ __launch_bounds__(256) void probe_placement_kernel(unsigned int* __restrict__ out, int spin) {
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);        // HW_REG_XCC_ID[3:0]
-    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);       // HW_REG_HW_ID (wave / SIMD / CU / SH / SE ids)
-    const unsigned t0 = (unsigned)__builtin_amdgcn_s_memtime();
-    float x = (float)threadIdx.x;
-    for (int i = 0; i < spin; ++i) x = x * 1.0000001f + 0.5f;                          // keeps the workgroup resident so that a launch spreads over its CUs
-    if (threadIdx.x == 0) { out[3 * blockIdx.x] = xcc; out[3 * blockIdx.x + 1] = hwid; out[3 * blockIdx.x + 2] = t0 + (x == 123.f ? 1u : 0u); }
-}
-extern "C" int cxr_probe_placement(unsigned int* out, int workgroups, int spin, hipStream_t stream) {
-    if (!out || workgroups <= 0 || spin < 0) return CXR_ERR_ARG;
-    CXR_LAUNCH(probe_placement_kernel, dim3(workgroups), dim3(256), 0, stream, out, spin);
-    CXR_LAUNCH_CHECK();
-    return CXR_OK;
-}

@@ -102,7 +102,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
 struct LnBwdDrop { bf16_t* dx2; long lddx2; const uint32_t* seed; uint32_t site, thr16; float inv; int rows_per_b, t0; const float* row_scale; };
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ;  dgamma += sum dy*xhat ; dbeta += sum dy
-template <int C, int U>
+// PF (round 6): the loads of the NEXT row block are issued before the current block's arithmetic and stores (two register stages, the loop unrolled
+// by two so that both are statically indexed). Without it a wave alternates between "all loads in flight" and "no load in flight" (reductions,
+// stores): at 18 rows per wave (36928 x 384 over 512 workgroups) the kernel is a chain of ~9 dependent HBM round trips, 2.9 TB/s alone.
+template <int C, int U, bool PF = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
                                                             const float* __restrict__ gamma, const float* __restrict__ stats,
                                                             const bf16_t* __restrict__ add, long ldadd,
@@ -122,43 +125,43 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < 8; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; gam[i][j] = ch < L::CH ? gamma[ch * 8 + j] : 0.f; }
     }
-    for (long base = (long)blockIdx.x * rows_per_block; base < rows; base += (long)gridDim.x * rows_per_block) {
-        uint4 xr[U][L::CPL], dr[U][L::CPL], ar[U][L::CPL];
-        long row[U];
-        float mean[U], rstd[U], rsf[U];
+    struct Stage { uint4 xr[U][L::CPL], dr[U][L::CPL], ar[U][L::CPL]; long row[U]; float mean[U], rstd[U], rsf[U]; };
+    auto load = [&](Stage& s, const long base) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            row[u] = base + u * 4 * L::RPW + wave * L::RPW + grp;
-            const bool live = row[u] < rows;
-            const long rc = live ? row[u] : rows - 1;
-            mean[u] = stats[2 * rc]; rstd[u] = stats[2 * rc + 1];
+            s.row[u] = base + u * 4 * L::RPW + wave * L::RPW + grp;
+            const bool live = s.row[u] < rows;
+            const long rc = live ? s.row[u] : rows - 1;
+            s.mean[u] = stats[2 * rc]; s.rstd[u] = stats[2 * rc + 1];
             // the DropPath factor of the row, fetched WITH the row (unconditional, stand-in address when unused): loaded where it is used, after
             // the dx store, it was a dependent round trip (load + s_waitcnt vmcnt(0)) per row in the middle of the loop
-            rsf[u] = (dd.row_scale ? dd.row_scale : stats)[dd.row_scale ? (uint32_t)rc / (uint32_t)dd.rows_per_b : 0u];      // (32-bit division: rows < 2^31)
+            s.rsf[u] = (dd.row_scale ? dd.row_scale : stats)[dd.row_scale ? (uint32_t)rc / (uint32_t)dd.rows_per_b : 0u];      // (32-bit division: rows < 2^31)
 #pragma unroll
             for (int i = 0; i < L::CPL; ++i) {
                 const int ch = sub + i * L::LPR;
                 const int cc = ch < L::CH ? ch : 0;
-                xr[u][i] = ld_stream16(x + rc * ldx + cc * 8);
-                dr[u][i] = ld_stream16(dy + rc * lddy + cc * 8);
-                if (add) ar[u][i] = ld_stream16(add + rc * ldadd + cc * 8);
+                s.xr[u][i] = ld_stream16(x + rc * ldx + cc * 8);
+                s.dr[u][i] = ld_stream16(dy + rc * lddy + cc * 8);
+                if (add) s.ar[u][i] = ld_stream16(add + rc * ldadd + cc * 8);
             }
         }
+    };
+    auto compute = [&](Stage& s) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool live = row[u] < rows;
+            const bool live = s.row[u] < rows;
             float xh[L::CPL][8], g[L::CPL][8];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < L::CPL; ++i) {
                 const int ch = sub + i * L::LPR;
                 float xv[8], dv[8];
-                unpack8(xr[u][i], xv);
-                unpack8(dr[u][i], dv);
+                unpack8(s.xr[u][i], xv);
+                unpack8(s.dr[u][i], dv);
                 const bool on = live && ch < L::CH;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    xh[i][j] = on ? (xv[j] - mean[u]) * rstd[u] : 0.f;
+                    xh[i][j] = on ? (xv[j] - s.mean[u]) * s.rstd[u] : 0.f;
                     const float d = on ? dv[j] : 0.f;
                     g[i][j] = d * gam[i][j];
                     s1 += g[i][j];
@@ -176,22 +179,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
                 if (ch < L::CH) {
                     float o[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = rstd[u] * (g[i][j] - s1 - xh[i][j] * s2);
+                    for (int j = 0; j < 8; ++j) o[j] = s.rstd[u] * (g[i][j] - s1 - xh[i][j] * s2);
                     if (add) {
                         float av[8];
-                        unpack8(ar[u][i], av);
+                        unpack8(s.ar[u][i], av);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] += av[j];
                     }
-                    if (dx) *reinterpret_cast<uint4*>(dx + row[u] * lddx + ch * 8) = pack8(o);      // (dx may be null when only the scaled copy dx2 is wanted)
+                    if (dx) *reinterpret_cast<uint4*>(dx + s.row[u] * lddx + ch * 8) = pack8(o);      // (dx may be null when only the scaled copy dx2 is wanted)
                     if (dd.dx2) {
                         if (dd.row_scale) {
-                            const float f = rsf[u];
+                            const float f = s.rsf[u];
 #pragma unroll
                             for (int j = 0; j < 8; ++j) o[j] *= f;
                         } else {
-                            const uint32_t rq = (uint32_t)row[u] / (uint32_t)dd.rows_per_b;          // (32-bit: a 64-bit division is ~150 VALU instructions)
-                            const uint32_t key = dropout_row_key(dseed, dd.site, rq, (uint32_t)(dd.t0 + (int)((uint32_t)row[u] - rq * (uint32_t)dd.rows_per_b)));
+                            const uint32_t rq = (uint32_t)s.row[u] / (uint32_t)dd.rows_per_b;          // (32-bit: a 64-bit division is ~150 VALU instructions)
+                            const uint32_t key = dropout_row_key(dseed, dd.site, rq, (uint32_t)(dd.t0 + (int)((uint32_t)s.row[u] - rq * (uint32_t)dd.rows_per_b)));
 #pragma unroll
                             for (int j = 0; j < 8; j += 2) {
                                 const uint32_t bits = dropout_pair_bits(key, (uint32_t)(ch * 8 + j) >> 1);
@@ -199,10 +202,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
                                 o[j + 1] = (bits >> 16) >= dd.thr16 ? o[j + 1] * dd.inv : 0.f;
                             }
                         }
-                        *reinterpret_cast<uint4*>(dd.dx2 + row[u] * dd.lddx2 + ch * 8) = pack8(o);
+                        *reinterpret_cast<uint4*>(dd.dx2 + s.row[u] * dd.lddx2 + ch * 8) = pack8(o);
                     }
                 }
             }
+        }
+    };
+    const long step = (long)gridDim.x * rows_per_block;
+    if constexpr (PF) {
+        Stage s0, s1;
+        long base = (long)blockIdx.x * rows_per_block;
+        if (base < rows) load(s0, base);
+        while (base < rows) {
+            const bool more1 = base + step < rows;
+            if (more1) load(s1, base + step);
+            compute(s0);
+            if (!more1) break;
+            base += step;
+            const bool more0 = base + step < rows;
+            if (more0) load(s0, base + step);
+            compute(s1);
+            if (!more0) break;
+            base += step;
+        }
+    } else {
+        for (long base = (long)blockIdx.x * rows_per_block; base < rows; base += step) {
+            Stage s0;
+            load(s0, base);
+            compute(s0);
         }
     }
     if (partial) {
@@ -328,8 +355,24 @@ extern "C" int cxr_layernorm_bwd_bf16(const void* x, long ldx, const void* dy, l
     const int grid = cxr_layernorm_bwd_grid(rows, C);
     float* partial = workspace;                                   // partial rows are written whenever a workspace is given; the caller may run
                                                                   // cxr_layernorm_bwd_reduce on another stream (dgamma == NULL here)
-    LN_DISPATCH(C, layernorm_bwd_kernel, 2, 2, 4, 2, 1, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, gamma, stats, (const bf16_t*)add, ldadd,
-                (bf16_t*)dx, lddx, partial, rows, dd);
+    static int pf = -1;                                           // CXR_LN_BWD_PF=0: the un-pipelined loop of rounds 1-5 (A/B)
+    if (pf < 0) { const char* e = getenv("CXR_LN_BWD_PF"); pf = (e && e[0] == '0') ? 0 : 1; }
+#define LN_BWD(C_, U_) do { if (pf) CXR_LAUNCH((layernorm_bwd_kernel<C_, U_, true>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, gamma, stats, \
+                                               (const bf16_t*)add, ldadd, (bf16_t*)dx, lddx, partial, rows, dd);                                                              \
+                            else CXR_LAUNCH((layernorm_bwd_kernel<C_, U_, false>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, gamma, stats, \
+                                            (const bf16_t*)add, ldadd, (bf16_t*)dx, lddx, partial, rows, dd); } while (0)
+    switch (C) {
+        case 64: LN_BWD(64, 2); break;
+        case 128: LN_BWD(128, 2); break;
+        // (C = 192 at U = 4 needs 256 registers with the second stage: measured 49.9 -> 64.5 us at 147456 rows; it keeps the old loop.
+        //  384: 30.7 -> 28.2 us at 36928 rows, 64: 57.1 -> 54.1 at 589824, 768: 16.6 -> 16.4 at 8192 -- gpurun_out r6 call 3, profiles/r06_ln_bwd.txt)
+        case 192: CXR_LAUNCH((layernorm_bwd_kernel<192, 4, false>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, gamma, stats,
+                             (const bf16_t*)add, ldadd, (bf16_t*)dx, lddx, partial, rows, dd); break;
+        case 384: LN_BWD(384, 2); break;
+        case 768: LN_BWD(768, 1); break;
+        default: return CXR_ERR_ARG;
+    }
+#undef LN_BWD
     if (dgamma) CXR_LAUNCH(layernorm_bwd_reduce_kernel, dim3(cdiv(2 * C, 32), cdiv(grid, 64)), dim3(256), 0, stream, partial, grid, C, dgamma, dbeta);
     CXR_LAUNCH_CHECK();
     return CXR_OK;

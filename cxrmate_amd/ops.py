@@ -1567,25 +1567,3 @@ def lora_outer_into(a, t, G, g_ks, g_rs, scale=1.0, drop=None, rows_per_b=1, tpo
     p, site = drop if drop is not None else (0.0, 0)
     LIB.call("cxr_lora_outer_bf16", _p(a), a.stride(0), M, K, _p(t), _p(G), int(g_ks), int(g_rs), float(scale), float(p), _p(seed), int(site),
              int(rows_per_b), int(tpos0), _s())
-
-
-# ------------------------------------------------------------------------------------------------ round 5 (lab): a stream restricted to some CUs
-_MASKED_STREAMS = []        # (torch ExternalStream, raw handle): kept alive for the life of the process
-
-
-def masked_stream(mask_words):
-    """torch stream whose kernels may only run on the compute units whose bits are set in `mask_words` (list of 32-bit words, bit i = CU i in the
-    runtime's numbering: hipExtStreamCreateWithCUMask through the C ABI). scripts/r5/cu_mask_probe.py maps the numbering to XCDs."""
-    arr = (_ct.c_uint * len(mask_words))(*[int(w) & 0xFFFFFFFF for w in mask_words])
-    handle = _ct.c_void_p()
-    LIB.call("cxr_stream_create_cu_mask", arr, len(mask_words), _ct.byref(handle))
-    st = torch.cuda.ExternalStream(handle.value)
-    _MASKED_STREAMS.append((st, handle.value))
-    return st
-
-
-def probe_placement(workgroups, spin=20000, stream=None):
-    """-> int32 tensor [workgroups, 3] = (XCC id, HW_ID register, s_memtime low word) of a probe launch on `stream` (default: current)."""
-    out = torch.zeros((workgroups, 3), dtype=torch.int32, device="cuda")
-    LIB.call("cxr_probe_placement", _p(out), int(workgroups), int(spin), stream.cuda_stream if stream is not None else _s())
-    return out

@@ -462,14 +462,6 @@ int cxr_copy_rows_bf16(const void* in, long in_bs, long in_rs, void* out, long o
 int cxr_bcast_row_f32_bf16(const float* row, void* out, long out_bs, int B, int C, hipStream_t stream);
 int cxr_sum_row0_bf16_f32(const void* in, long in_bs, float* out, int B, int C, hipStream_t stream);
 
-/* ---- round 5: a stream restricted to a set of compute units (hipExtStreamCreateWithCUMask) for the weight-gradient kernels, and a probe that
- * reports where the workgroups of a launch on a stream actually ran (lab: scripts/r5/cu_mask_probe.py). No reference counterpart: the reference has
- * one stream (SURVEY.md 8b "threading"). mask: `words` 32-bit words, bit i = CU i in the runtime's numbering; *stream_out receives the hipStream_t. */
-int cxr_stream_create_cu_mask(const unsigned int* mask, int words, void** stream_out);
-int cxr_stream_destroy(void* stream);
-/* out[3 * w + {0,1,2}] = (XCC id, HW_ID register, low 32 bits of s_memtime at entry) of workgroup w; every workgroup spins `spin` iterations */
-int cxr_probe_placement(unsigned int* out, int workgroups, int spin, hipStream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

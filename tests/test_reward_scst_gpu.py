@@ -306,14 +306,15 @@ def test_scst_step_through_real_strings(cuda):
     labels = [["The lungs are clear. No acute cardiopulmonary process."], ["Mild cardiomegaly is stable. Small left pleural effusion."]]
     rfn = ReportReward(m, tok, reward, labels, gu.BOS, gu.SEP, gu.EOS)
     n_label_embeds = []
-    orig = reward._encode
-    reward._encode = lambda texts: (n_label_embeds.append(len(texts)), orig(texts))[1]
+    orig = reward.embed_ids
+    reward.embed_ids = lambda ids, mask: (n_label_embeds.append(int(ids.shape[0])), orig(ids, mask))[1]
     special = dict(bos=gu.BOS, eos=gu.EOS, sep=gu.SEP, pad=gu.PAD, pmt_sep=gu.PMT_SEP)
     torch.manual_seed(3)
     out = scst_step(m, opt, rfn, x.cuda(), prompt.cuda(), None, special, decoder_max_len=10, reward_on_host=True)
     torch.cuda.synchronize()
     assert np.isfinite(out["loss"].item())
-    assert n_label_embeds == [4, 4]                              # ONE pass for sampled + greedy predictions (2 x 2 studies), the labels embedded once
+    # ONE reward forward per step: sampled + greedy predictions (2 x 2 studies) and, in the same launch chain, the step's 2 label rows (embedded once)
+    assert n_label_embeds == [6], n_label_embeds
     P = prompt.shape[1]
     full_s = torch.cat([prompt, out["sampled"].cpu()], 1)
     want_r = rfn(full_s).float().cpu().numpy()
