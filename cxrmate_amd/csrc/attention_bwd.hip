@@ -675,12 +675,10 @@ extern "C" int cxr_attn_bwd_bf16(const void* Q, const void* K, const void* V, co
     } else {
         CXR_LAUNCH(attn_bwd_dq_kernel, dim3(cdiv(Tq, 128), H, B), dim3(256), 0, stream, a);
     }
-    // (NW = 5, one 160-key workgroup per (image, head) at Tk = 145: measured SLOWER, 95 -> 104 us per CvT stage-3 call -- 384 workgroups of 5 waves fill
-    // the chip worse than 768 of 4, of which every second one retires almost at once. CXR_ATTN_DKDV_NW5=1 selects it for A/B.)
-    static int nw5 = -1;
-    if (nw5 < 0) { const char* e = getenv("CXR_ATTN_DKDV_NW5"); nw5 = (e && atoi(e)) ? 1 : 0; }
-    if (nw5 && Tk > 128 && Tk <= 160) CXR_LAUNCH(attn_bwd_dkdv_kernel<5>, dim3(1, H, B), dim3(320), 0, stream, a);
-    else                              CXR_LAUNCH(attn_bwd_dkdv_kernel<4>, dim3(cdiv(Tk, 128), H, B), dim3(256), 0, stream, a);
+    // (NW = 5, one 160-key workgroup per (image, head) at Tk = 145: measured SLOWER in round 4, 95 -> 104 us per CvT stage-3 call -- 384 workgroups of 5
+    // waves fill the chip worse than 768 of 4, of which every second one retires almost at once; the switch was removed in round 6,
+    // profiles/r04_attention_dkdv_variants.txt)
+    CXR_LAUNCH(attn_bwd_dkdv_kernel<4>, dim3(cdiv(Tk, 128), H, B), dim3(256), 0, stream, a);
     CXR_LAUNCH_CHECK();
     return CXR_OK;
 }

@@ -1291,9 +1291,7 @@ extern "C" int cxr_attn_cross_mfma_bf16(const void* Q, const void* Kp, const voi
     // (B*H*nsplit*66 floats) -> attn_decode_merge_kernel
     const int nblk_all = Tk / 32;
     a.nsplit = cdiv(nblk_all, 36); a.bps = cdiv(nblk_all, a.nsplit); a.ws = ws;
-    static int phased = -1;                                       // CXR_CROSS_PHASED=0: 37..60 blocks split + merge as before (A/B)
-    if (phased < 0) { const char* e = getenv("CXR_CROSS_PHASED"); phased = (e && e[0] == '0') ? 0 : 1; }
-    if (phased && nblk_all > 36 && nblk_all <= 60) {              // one workgroup per (study, head), K phase then V phase: no partial states, no merge launch
+    if (nblk_all > 36 && nblk_all <= 60) {              // one workgroup per (study, head), K phase then V phase: no partial states, no merge launch
         a.nsplit = 1; a.bps = nblk_all;
         CXR_LAUNCH((attn_cross_mfma_kernel<5, true>), dim3(a.Bkv * H), dim3(768), 0, stream, a);
         CXR_LAUNCH_CHECK();

@@ -809,12 +809,15 @@ __device__ __forceinline__ void tn2_frag_issue(const unsigned lane_off, const un
 // and 128 x 128 blocks with 4 : 2 : 1 work per workgroup, and the launch waited for the big ones.
 // NW = waves of the workgroup (8, or 4: round 5's co-resident form, gemm_tn4_kernel), NST = staging depth
 // AUX = cache policy of the staging loads (0 default, 2 = non-temporal: lab switch CXR_TN_NT=1, round 5)
-template <int NI, int NJ, int WI = 2, int NW = 8, int NST = 3, int AUX = 0>
+// JT = 16-column tiles of the block along J that hold data (0: all NJ * 8). Round 6: (NI, NJ, WI, JT) = (3, 2, 4, 12) is a 384 x 192 block -- the last
+// Q sub-image is staged for its first 64 columns only (the other lanes of its LDS-DMA pieces fetch the cached zero row) and no wave reads the rest.
+template <int NI, int NJ, int WI = 2, int NW = 8, int NST = 3, int AUX = 0, int JT = 0>
 __device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char* lds, const int i0, const int j0, const bool bias_block, const int split) {
     constexpr int BR = 32, TILE = BR * 256, SP = 8 / NW, LPS = (NI + NJ) * SP, STAGE = (NI + NJ) * TILE;      // SP = staging passes per sub-image
     constexpr int WJ = NW / WI;
-    constexpr int MI = NI * 8 / WI, MJ = NJ * 8 / WJ;              // 16 x 16 MFMA tiles of a wave: (128 NI / WI) x (128 NJ / WJ) outputs
-    static_assert((NW == 8 || NW == 4) && (NI * 8) % WI == 0 && (NJ * 8) % WJ == 0 && MI % 2 == 0 && MJ >= 1 && MJ <= 4, "wave grid");
+    constexpr int JT16 = JT ? JT : NJ * 8;                         // live 16-column tiles along J
+    constexpr int MI = NI * 8 / WI, MJ = JT16 / WJ;                // 16 x 16 MFMA tiles of a wave: (128 NI / WI) x (16 JT16 / WJ) outputs
+    static_assert((NW == 8 || NW == 4) && (NI * 8) % WI == 0 && JT16 % WJ == 0 && JT16 <= NJ * 8 && MI % 2 == 0 && MJ >= 1 && MJ <= 6, "wave grid");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // NW waves: WI (I) x WJ (J)
     const int wi = wave % WI, wj = wave / WI;
@@ -845,7 +848,8 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char
 #pragma unroll
             for (int u = 0; u < NJ; ++u) {
                 int c = j0 + u * 128 + scol; if (c >= g.J) c = 0;
-                const bf16_t* sq = ok ? g.Q + r * g.ldq + c : zr;
+                const bool live = JT == 0 || u * 128 + scol < JT16 * 16;       // (compile-time true for full blocks)
+                const bf16_t* sq = (ok && live) ? g.Q + r * g.ldq + c : zr;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sq,
                                                  (__attribute__((address_space(3))) void*)(base + (NI + u) * TILE), 16, 0, AUX);
             }
@@ -896,7 +900,9 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char
         bf16x8_t fa[MI];
 #pragma unroll
         for (int j2 = 0; j2 < MJ; ++j2) {
-            if (MJ - 1 - j2 == 3) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            if (MJ - 1 - j2 == 5) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+            else if (MJ - 1 - j2 == 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            else if (MJ - 1 - j2 == 3) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
             else if (MJ - 1 - j2 == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
             else if (MJ - 1 - j2 == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -925,8 +931,66 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char
     // row pieces per wave-instruction, as gemm_tn_kernel does
     const int fr = lane & 15, fq = lane >> 4;
     __syncthreads();
-    constexpr int WCOLS = 16 * MJ;                                 // columns of a wave's sub-tile (64 or 32)
-    constexpr int RPI = 64 / WCOLS;                                // rows per store instruction (1 or 2)
+    constexpr int WCOLS = 16 * MJ;                                 // columns of a wave's sub-tile (64 or 32; 96 for the 384 x 192 block)
+    if constexpr (WCOLS == 96) {
+        // 96-column wave tiles: 32 rows x 96 floats parked per pass; handed out as 64 columns of one row per instruction, then the remaining 32
+        // columns of two rows per instruction (whole 256- / 128-byte row pieces, as below)
+        float* wt = reinterpret_cast<float*>(lds) + wave * (32 * 96);
+        const int Jp_ = g.tiles_j * 128;
+        const int Ipad_ = ((g.I + 127) / 128) * 128;
+        const int iw = i0 + ri0 * 16, jw = j0 + rj0 * 16;
+        const int fr_ = lane & 15, fq_ = lane >> 4;
+#pragma unroll
+        for (int pass = 0; pass < MI / 2; ++pass) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int jt = 0; jt < MJ; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        wt[(it * 16 + fq_ * 4 + r) * 96 + jt * 16 + fr_] = acc[pass * 2 + it][jt][r] * g.alpha;
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            const int ib = iw + pass * 32;
+            const int jA = jw + lane, jB = jw + 64 + (lane & 31), rB = lane >> 5;
+            if (g.mode == 2) {
+                float* wa = g.ws + ((long)split * Ipad_ + ib) * Jp_ + jA;
+                float* wb = g.ws + ((long)split * Ipad_ + ib + rB) * Jp_ + jB;
+#pragma unroll 8
+                for (int row = 0; row < 32; ++row) wa[(long)row * Jp_] = wt[row * 96 + lane];
+#pragma unroll 8
+                for (int row = 0; row < 32; row += 2) wb[(long)row * Jp_] = wt[(row + rB) * 96 + 64 + (lane & 31)];
+            } else {
+#pragma unroll 8
+                for (int row = 0; row < 32; ++row) {
+                    const int i = ib + row;
+                    if (i < g.I && jA < g.J) { if (g.mode == 1) g.C[(long)i * g.ldc + jA] += wt[row * 96 + lane]; else atomicAdd(g.C + (long)i * g.ldc + jA, wt[row * 96 + lane]); }
+                }
+#pragma unroll 8
+                for (int row = 0; row < 32; row += 2) {
+                    const int i = ib + row + rB;
+                    const float v = wt[(row + rB) * 96 + 64 + (lane & 31)];
+                    if (i < g.I && jB < g.J) { if (g.mode == 1) g.C[(long)i * g.ldc + jB] += v; else atomicAdd(g.C + (long)i * g.ldc + jB, v); }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int it = 0; it < MI; ++it) {
+                float v = accb[it];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                const int i = iw + it * 16 + fr_;
+                if (fq_ == 0) {
+                    if (g.mode == 2) g.wsb[(long)split * Ipad_ + i] = v;
+                    else if (i < g.I) { if (g.mode == 1) g.dbias[i] += v; else atomicAdd(g.dbias + i, v); }
+                }
+            }
+        }
+        return;
+    }
+    constexpr int RPI = WCOLS == 96 ? 1 : 64 / WCOLS;              // rows per store instruction (1 or 2)
     float* wtile = reinterpret_cast<float*>(lds) + wave * (32 * WCOLS);
     const int Jp = g.tiles_j * 128;
     const int Ipad = ((g.I + 127) / 128) * 128;
@@ -985,7 +1049,6 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTnArgs& g, unsigned char
     }
 }
 
-template <int AUX>
 __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(const GemmTnArgs g, const int blocks_j) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * 4 * 32 * 256];      // 3 stages x (2 + 2) sub-images = 96 KB
     int swz;
@@ -998,39 +1061,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(const GemmTnArgs g, co
     const int split = swz / blocks, blk = swz % blocks;
     const int bi = blk / blocks_j, bj = blk % blocks_j;
     const int ni = g.I - bi * 256 > 128 ? 2 : 1, nj = g.J - bj * 256 > 128 ? 2 : 1;      // block-uniform
-    if (ni == 2 && nj == 2) gemm_tn2_body<2, 2, 2, 8, 3, AUX>(g, lds, bi * 256, bj * 256, bj == 0, split);
-    else if (ni == 2) gemm_tn2_body<2, 1, 2, 8, 3, AUX>(g, lds, bi * 256, bj * 256, bj == 0, split);
-    else if (nj == 2) gemm_tn2_body<1, 2, 2, 8, 3, AUX>(g, lds, bi * 256, bj * 256, bj == 0, split);
-    else gemm_tn2_body<1, 1, 2, 8, 3, AUX>(g, lds, bi * 256, bj * 256, bj == 0, split);
+    if (ni == 2 && nj == 2) gemm_tn2_body<2, 2>(g, lds, bi * 256, bj * 256, bj == 0, split);
+    else if (ni == 2) gemm_tn2_body<2, 1>(g, lds, bi * 256, bj * 256, bj == 0, split);
+    else if (nj == 2) gemm_tn2_body<1, 2>(g, lds, bi * 256, bj * 256, bj == 0, split);
+    else gemm_tn2_body<1, 1>(g, lds, bi * 256, bj * 256, bj == 0, split);
 }
 
-// 384 x 128 blocks (I a multiple of 384): see gemm_tn2_body
-__global__ __launch_bounds__(512, 2) void gemm_tn3_kernel(const GemmTnArgs g, const int blocks_j) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * 4 * 32 * 256];      // 3 stages x (3 + 1) sub-images = 96 KB
-    int swz;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int blocks = gridDim.x / g.splits;
-    const int split = swz / blocks, blk = swz % blocks;
-    const int bi = blk / blocks_j, bj = blk % blocks_j;
-    gemm_tn2_body<3, 1, 4>(g, lds, bi * 384, bj * 128, bj == 0, split);
-}
-
-// ---- round 5: a weight-gradient workgroup that can SHARE a compute unit with a main-stream GEMM workgroup ---------------------------------------
-// gemm_tn2_kernel (8 waves x ~216 registers = 432 of a SIMD's 512, 96 KB of LDS) and gemm_nt_kernel (4 waves x ~240 registers, 64 KB) can never be
-// resident on the same SIMD: the weight-gradient stream takes WHOLE compute units from the main stream (a spatial partition decided by dispatch
-// order). This form is co-resident by construction: 4 waves (one per SIMD), <= 256 registers, 256 x 128 (or 128 x 256) outputs per workgroup =
-// the same 128 x 64 accumulators per wave as gemm_tn2_kernel, NST stages of 3 sub-images = 72 KB (NST 3) / 96 KB (NST 4): one of these + one
-// gemm_nt_kernel workgroup fit a CU (<= 496 registers per SIMD, <= 160 KB), so the matrix pipe of every SIMD is time-shared by one wave of each at
-// instruction granularity. Opt-in / default per the in-step alternation recorded in profiles/r05_*.
+// ---- round 6: 384 x 192 blocks for outputs whose dimensions are multiples of 384 / 192 but not both of 256 (CvT stage 3: 384 x 384, 1536 x 384,
+// 384 x 1536). As 256-blocks such an output is a mix of 256 x 256, 256 x 128 and 128 x 128 blocks: per 32 tokens a 384 x 384 output stages 1536
+// columns for 147456 products (96 per column), equal 384 x 192 blocks stage 1152 (128 per column, what a 256 x 256 block gets) -- the operand bytes a
+// launch pulls through its CUs (and from HBM: the blocks of a split run on one XCD but drift apart) drop by a quarter (1536 x 384: by a seventh).
+// Eight waves as 4 (I) x 2 (J): 96 x 96 outputs = 6 x 6 MFMA tiles = 144 accumulator registers per lane; three stages of 3 + 2 sub-images = 120 KB.
 template <int NST>
-__global__ __launch_bounds__(256, 2) void gemm_tn4_kernel(const GemmTnArgs g, const int blocks_j, const int wide_j) {
-    // NST stages x 3 sub-images of 8 KB, DYNAMIC: with a static 96-KB array hipcc derives "one workgroup per CU" from the LDS size and then ignores the
-    // register cap of __launch_bounds__ (293 registers: no main-stream wave fits beside it)
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+__global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(const GemmTnArgs g, const int blocks_j) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(NST * 5 * 32 * 256 > 8 * 32 * 96 * 4) ? NST * 5 * 32 * 256 : 8 * 32 * 96 * 4];      // NST stages x (3 + 2) sub-images (120 KB at 3); epilogue: 8 x 12 KB
     int swz;
     {
         const int nwg = gridDim.x, bid = blockIdx.x;
@@ -1040,15 +1084,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn4_kernel(const GemmTnArgs g, co
     const int blocks = gridDim.x / g.splits;
     const int split = swz / blocks, blk = swz % blocks;
     const int bi = blk / blocks_j, bj = blk % blocks_j;
-    if (wide_j) {                                                   // 128 (I) x 256 (J) blocks: J is the dimension that is a multiple of 256
-        const int nj = g.J - bj * 256 > 128 ? 2 : 1;
-        if (nj == 2) gemm_tn2_body<1, 2, 1, 4, NST>(g, lds_dyn, bi * 128, bj * 256, bj == 0, split);
-        else gemm_tn2_body<1, 1, 2, 4, NST>(g, lds_dyn, bi * 128, bj * 256, bj == 0, split);
-    } else {                                                        // 256 (I) x 128 (J) blocks
-        const int ni = g.I - bi * 256 > 128 ? 2 : 1;
-        if (ni == 2) gemm_tn2_body<2, 1, 2, 4, NST>(g, lds_dyn, bi * 256, bj * 128, bj == 0, split);
-        else gemm_tn2_body<1, 1, 2, 4, NST>(g, lds_dyn, bi * 256, bj * 128, bj == 0, split);
-    }
+    gemm_tn2_body<3, 2, 4, 8, NST, 0, 12>(g, lds, bi * 384, bj * 192, bj == 0, split);
 }
 
 // C[i][j] += sum of the splits' partial tiles, dbias likewise, in a FIXED order: SL lanes share one group of 4 columns, lane l sums the splits
@@ -1155,7 +1191,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_batch_kernel(const TnRedBa
 }
 
 // Launch plan of a weight-gradient GEMM (shared by cxr_gemm_tn_bf16 and cxr_gemm_tn_plan)
-struct TnPlan { bool big; bool b384; bool co4; int wide_j; int tiles_i, tiles_j, blocks_j, wgs_per_split, splits, rt_per_split; long need; };
+struct TnPlan { bool big; bool b5; int tiles_i, tiles_j, blocks_j, wgs_per_split, splits, rt_per_split; long need; };
 static TnPlan tn_plan(int R, int I, int J) {
     TnPlan p;
     p.tiles_i = cdiv(I, 128); p.tiles_j = cdiv(J, 128);
@@ -1177,31 +1213,20 @@ static TnPlan tn_plan(int R, int I, int J) {
     static long min_steps = -1;                            // CXR_TN2_MIN: blocks x 32-token steps from which the 256 x 256 blocks are used
     if (min_steps < 0) { const char* e = getenv("CXR_TN2_MIN"); min_steps = e ? atol(e) : 4096; }
     p.big = tn2 && I > 128 && J > 128 && (long)blocks * nrt >= min_steps;
-    // 384 x 128 blocks where 256-blocks would be of unequal size (a dimension that is 128 mod 256) and I is a multiple of 384: CvT stage 3
-    static int tn3 = -1;
-    // Default OFF: alone the equal blocks are 15-25 % faster (384 x 384 x 36928: 56 -> 42 us, 1536 x 384: 136 -> 117, 384 x 1536: 133 -> 115,
-    // profiles/r04_tn_micro_blocks384.txt), but beside the main stream the training step gets 0.2-0.4 ms SLOWER with them (same-box alternation, two
-    // boxes, 64 / 96 / 128 workgroups per launch: profiles/r04_ab_wgrad_stream.txt) -- a faster weight-gradient kernel takes more of the shared
-    // LDS-DMA / L2 bandwidth from the dX GEMMs while it runs, and the weight-gradient stream was not the critical path. CXR_TN3=1 turns them on.
-    if (tn3 < 0) { const char* e = getenv("CXR_TN3"); tn3 = (e && e[0] == '1') ? 1 : 0; }
-    p.b384 = p.big && tn3 && (I % 384) == 0 && ((I % 256) != 0 || (J % 256) != 0);
-    if (p.b384) p.blocks_j = cdiv(J, 128);
-    // round 5: the co-resident 4-wave form (gemm_tn4_kernel) for the shapes gemm_tn2_kernel takes. CXR_TN4=1 turns it on, CXR_TN4_WGS = workgroups a
-    // launch aims for (default 256: one per CU, beside one main-stream workgroup each), CXR_TN4_STAGES = 3 | 4
-    static int tn4 = -1, target_co4 = -1;
-    if (tn4 < 0) { const char* e = getenv("CXR_TN4"); tn4 = (e && e[0] == '1') ? 1 : 0; }
-    if (target_co4 < 0) { const char* e = getenv("CXR_TN4_WGS"); target_co4 = e ? atoi(e) : 256; if (target_co4 < 1) target_co4 = 256; }
-    p.co4 = p.big && !p.b384 && tn4;
-    p.wide_j = 0;
-    int blocks4 = 0;
-    if (p.co4) {
-        // 256 x 128 blocks along the dimension that splits evenly into 256s (equal blocks); I otherwise
-        p.wide_j = ((I % 256) != 0 && (J % 256) == 0) ? 1 : 0;
-        p.blocks_j = p.wide_j ? cdiv(J, 256) : cdiv(J, 128);
-        blocks4 = (p.wide_j ? cdiv(I, 128) : cdiv(I, 256)) * p.blocks_j;
-    }
-    p.wgs_per_split = p.co4 ? blocks4 : (p.b384 ? (I / 384) * p.blocks_j : (p.big ? blocks : p.tiles_i * p.tiles_j));
-    int splits = cdiv(p.co4 ? target_co4 : (p.big ? target_big : target_wgs), p.wgs_per_split);
+    // (round 4's 384 x 128 blocks and round 5's co-resident 4-wave form were faster alone and 0.2 - 1.0 ms SLOWER in the step; both were removed in
+    //  round 6, their measurements stay in profiles/r04_tn_micro_blocks384.txt, r04_ab_wgrad_stream.txt, r05_tn4_coresident.txt)
+    // round 6: equal 384 x 192 blocks (gemm_tn5_kernel) where 256-blocks would be of unequal size. CXR_TN5=0: the 256-blocks (A/B)
+    static int tn5 = -1;
+    if (tn5 < 0) { const char* e = getenv("CXR_TN5"); tn5 = (e && e[0] == '0') ? 0 : 1; }
+    static long min5 = -1;                                 // CXR_TN5_MIN: blocks x 32-token steps from which the 384 x 192 blocks are used
+    if (min5 < 0) { const char* e = getenv("CXR_TN5_MIN"); min5 = e ? atol(e) : 4096; }
+    p.b5 = tn2 && tn5 && (I % 384) == 0 && (J % 192) == 0 && ((I % 256) != 0 || (J % 256) != 0) && (long)(I / 384) * (J / 192) * nrt >= min5;
+    if (p.b5) p.big = true;
+    if (p.b5) p.blocks_j = J / 192;
+    p.wgs_per_split = p.b5 ? (I / 384) * p.blocks_j : (p.big ? blocks : p.tiles_i * p.tiles_j);
+    static int target_b5 = -1;                             // CXR_TN5_WGS: workgroups a 384 x 192-block launch aims for
+    if (target_b5 < 0) { const char* e = getenv("CXR_TN5_WGS"); target_b5 = e ? atoi(e) : 64; if (target_b5 < 1) target_b5 = 64; }
+    int splits = cdiv(p.b5 ? target_b5 : (p.big ? target_big : target_wgs), p.wgs_per_split);
     const int max_splits = nrt / 8 > 0 ? nrt / 8 : 1;      // at least 256 tokens per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -1238,34 +1263,20 @@ static int tn_launch(const void* P, long ldp, const void* Q, long ldq, float* C,
     const int tiles_i = pl.tiles_i, blocks_j = pl.blocks_j, tiles = pl.wgs_per_split;
     g.tiles_j = pl.tiles_j; g.rt_per_split = pl.rt_per_split; g.splits = pl.splits;
     // accumulation: one split -> atomics (each element receives exactly one add per launch: order-free); several splits -> partial tiles into the
-    // caller's workspace + a reduce that adds them in a fixed order (deterministic; measured at the same speed as 64 KB of fp32 atomics per workgroup,
-    // scripts/tn_micro.py with CXR_TN_ATOMICS=1); no / too small a workspace: atomics
+    // caller's workspace + a reduce that adds them in a fixed order (deterministic; float atomics from several splits were measured in round 5:
+    // 75 - 119 ms per step, the 256 x 256 blocks of the splits collide on the same rows); no / too small a workspace: atomics
     const int Ip = tiles_i * 128, Jp = g.tiles_j * 128;
     const long need = pl.need;
-    static int det = -1;
-    if (det < 0) { const char* e = getenv("CXR_TN_ATOMICS"); det = (e && atoi(e)) ? 0 : 1; }
     g.ws = nullptr; g.wsb = nullptr;
     g.mode = 0;                                            // one split: every element gets exactly ONE atomic add per launch -- deterministic as it is
-    if (det && g.splits > 1 && g.splits <= 192 && ws && ws_floats >= need && (J % 4) == 0) { g.mode = 2; g.ws = ws; g.wsb = ws + (long)g.splits * Ip * Jp; }
+    if (g.splits > 1 && g.splits <= 192 && ws && ws_floats >= need && (J % 4) == 0) { g.mode = 2; g.ws = ws; g.wsb = ws + (long)g.splits * Ip * Jp; }
     static int stages = -1;                                // CXR_TN_STAGES = 2 | 4 (LDS 32 | 64 KB per workgroup)
     if (stages < 0) { const char* e = getenv("CXR_TN_STAGES"); stages = e ? atoi(e) : 4; }
-    static int tn_nt = -1;                                  // CXR_TN_NT=1: non-temporal operand loads in gemm_tn2_kernel (lab, round 5)
-    if (tn_nt < 0) { const char* e = getenv("CXR_TN_NT"); tn_nt = (e && e[0] == '1') ? 1 : 0; }
-    static int st4 = -1;
-    if (st4 < 0) { const char* e = getenv("CXR_TN4_STAGES"); st4 = (e && atoi(e) == 4) ? 4 : 3; }
-    if (pl.co4) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)gemm_tn4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 24576);
-            (void)hipFuncSetAttribute((const void*)gemm_tn4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
-            attr_set = true;
-        }
-    }
-    if (pl.co4 && st4 == 4) CXR_LAUNCH(gemm_tn4_kernel<4>, dim3(tiles * g.splits), dim3(256), 4 * 24576, stream, g, blocks_j, pl.wide_j);
-    else if (pl.co4)      CXR_LAUNCH(gemm_tn4_kernel<3>, dim3(tiles * g.splits), dim3(256), 3 * 24576, stream, g, blocks_j, pl.wide_j);
-    else if (pl.b384)     CXR_LAUNCH(gemm_tn3_kernel, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
-    else if (big && tn_nt) CXR_LAUNCH(gemm_tn2_kernel<2>, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
-    else if (big)         CXR_LAUNCH(gemm_tn2_kernel<0>, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
+    static int st5 = -1;                                   // CXR_TN5_STAGES = 2 | 3 (LDS 96 (epilogue) | 120 KB per workgroup)
+    if (st5 < 0) { const char* e = getenv("CXR_TN5_STAGES"); st5 = (e && atoi(e) == 2) ? 2 : 3; }
+    if (pl.b5 && st5 == 2) CXR_LAUNCH(gemm_tn5_kernel<2>, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
+    else if (pl.b5)       CXR_LAUNCH(gemm_tn5_kernel<3>, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
+    else if (big)         CXR_LAUNCH(gemm_tn2_kernel, dim3(tiles * g.splits), dim3(512), 0, stream, g, blocks_j);
     else if (stages == 2) CXR_LAUNCH(gemm_tn_kernel<2>, dim3(tiles * g.splits), dim3(256), 0, stream, g);
     else                  CXR_LAUNCH(gemm_tn_kernel<4>, dim3(tiles * g.splits), dim3(256), 0, stream, g);
     if (g.mode == 2 && pending) {

@@ -521,13 +521,11 @@ class BertEngine:
                 self._wgrad(lp + "crossattention.output.dense", dd2, sv["ctx2"].view(R, D))
                 dctx2 = ops.gemm_nt(dd2, self._wt(lp + "crossattention.output.dense")).view(B, T, D)
                 if dkv_all is not None:
-                    ops.wgrad_gate()
                     dq2, _, _ = ops.attention_bwd(sv["q2"], sv["k2"], sv["v2"], sv["ctx2"], dctx2, sv["lse2"], nh, scale, kpm=saved["enc_mask"],
                                                   drop=(pa, seed, _site(l, 2), 0), dk_out=dkv_all[:, :, 2 * l * D:(2 * l + 1) * D],
                                                   dv_out=dkv_all[:, :, (2 * l + 1) * D:(2 * l + 2) * D])
                     self._wgrad(lp + "crossattention.self.query", dq2.view(R, D), sv["h1"])
                 else:
-                    ops.wgrad_gate()
                     dq2, dk2, dv2 = ops.attention_bwd(sv["q2"], sv["k2"], sv["v2"], sv["ctx2"], dctx2, sv["lse2"], nh, scale, kpm=saved["enc_mask"],
                                                       drop=(pa, seed, _site(l, 2), 0))
                     self._wgrad(lp + "crossattention.self.query", dq2.view(R, D), sv["h1"])
@@ -547,14 +545,12 @@ class BertEngine:
             if sv.get("qkv_fused"):
                 qkv_w = self._self_qkv(l)
                 dqkv = torch.empty((B, T, 3 * D), dtype=BF16, device=dctx.device)
-                ops.wgrad_gate()
                 ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, scale, kpm=saved["attn_mask"], causal=saved["causal"],
                                   drop=(pa, seed, _site(l, 0), 0), dq_out=dqkv[:, :, :D], dk_out=dqkv[:, :, D:2 * D], dv_out=dqkv[:, :, 2 * D:])
                 d2 = dqkv.view(R, 3 * D)
                 ops.linear_bwd_weight(d2, sv["h"], st.span(qkv_w[2], "grad").view(3 * D, D), st.span(qkv_w[3], "grad"))
                 dh = ops.gemm_nt(d2, self._prep[("wt", ("self_qkv", l))], residual=da1)
                 continue
-            ops.wgrad_gate()
             dq, dk, dv = ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, scale, kpm=saved["attn_mask"],
                                            causal=saved["causal"], drop=(pa, seed, _site(l, 0), 0))
             if lora_tr and self._lora_multi(R, D):

@@ -515,7 +515,6 @@ class CvtEncoderEngine:
         # attention output projection: x2 = x + droppath(Wo ctx + bo)
         ops.linear_bwd_weight(da, sv["ctx"].view(-1, C), g(lp + "attention.output.dense.weight"), g(lp + "attention.output.dense.bias"))
         dctx = ops.gemm_nt(da, self._wt(lp + "attention.output.dense.weight")).view(Bn, L, C)
-        ops.wgrad_gate()
         dq, dk, dv = ops.attention_bwd(sv["q"], sv["k"], sv["v"], sv["ctx"], dctx, sv["lse"], nh, C ** -0.5)
         for name, d, inp in (("query", dq, sv["qc"]), ("key", dk, sv["kc"]), ("value", dv, sv["vc"])):
             ops.linear_bwd_weight(d.view(-1, C), inp.view(-1, C), g(ap + f"projection_{name}.weight"), g(ap + f"projection_{name}.bias"))
@@ -538,7 +537,6 @@ class CvtEncoderEngine:
                 bp.append(dict(stride=b["stride"], taps=b["taps"], y=dcs[n], gamma=b["gamma"], mean=mean, rstd=rstd, beta=b["beta"],
                                yf=sv[{"query": "qc", "key": "kc", "value": "vc"}[n]] if self._bwd_stats_from_y else None,
                                dgamma=g(cp + "normalization.weight"), dbeta=g(cp + "normalization.bias"), dw=g(cp + "convolution.weight").view(C, 9)))
-            ops.wgrad_gate()
             coefs = ops.dwproj_bn_train_bwd_stats(h1, H, W, tok0, bp)
             for b, cf in zip(bp, coefs):
                 b["coef"] = cf

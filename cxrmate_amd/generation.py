@@ -481,16 +481,13 @@ class GenerationMixin:
         first = prompt[:, 0].tolist()                                        # (the one host read of this call: the prompt's first column)
         prepend = all(v != bos_token_id for v in first)
         ids = torch.cat([start, prompt], dim=-1) if prepend else prompt
-        # every returned row starts with BOS iff it was prepended or every prompt row starts with it: the caller strips that column
-        # (scst/gt_prompt.py:185-186) and can decide so WITHOUT reading the sequences back -- i.e. without waiting for the decode
-        all_bos_first = prepend or all(v == bos_token_id for v in first)
         enc16 = (enc if enc.dtype == torch.bfloat16 else ops.cast_to_bf16(enc.float().contiguous())).detach().contiguous()
         enc_mask8 = None if enc_mask is None else enc_mask.to(device=dev, dtype=torch.uint8).contiguous()      # B rows serve the 2B decode rows
         rec = {"tt": [], "pos": []}
         out = self._generate_session(torch.cat([ids, ids], dim=0), enc16, enc_mask8, (special_sample, special_greedy), mask_token_id,
                                      max_length, bos_token_id, eos_token_id, pad_token_id, "pair", top_k, temperature, rec, top_p=top_p)
         rec = {"tt": [t[:B] for t in rec["tt"]], "pos": [None if p_ is None else p_[:B] for p_ in rec["pos"]], "seed": rec.get("seed"),
-               "cross_kv": rec.get("cross_kv"), "all_bos_first": all_bos_first}
+               "cross_kv": rec.get("cross_kv")}
 
         def trim(seq):                                   # each half ends where ITS last row finished (HF stops per generate() call)
             if eos_token_id is None:

@@ -331,20 +331,7 @@ def _side_defer(fn, *tensors):
         return
     _SIDE_DEFERRED.append(fn)
     _SIDE_PENDING.append(tensors)
-    if len(_SIDE_DEFERRED) >= (_WGRAD_GATE_MAX if _WGRAD_GATED else _WGRAD_BATCH):
-        wgrad_flush()
-
-
-# Round-5 experiment (CXR_WGRAD_GATE=1, default off): the collected weight-gradient launches are forked where the backward passes call wgrad_gate() --
-# right in front of their attention-backward and depthwise-projection kernels, whose small LDS / register footprint leaves room for a weight-gradient
-# workgroup on the same CU -- instead of every CXR_WGRAD_BATCH launches wherever that count happens to fill up (often in front of a dX GEMM, the
-# kernel that suffers most from a neighbour). Measured: profiles/r05_wgrad_gate.txt.
-_WGRAD_GATED = __import__("os").environ.get("CXR_WGRAD_GATE") == "1"
-_WGRAD_GATE_MAX = max(1, int(__import__("os").environ.get("CXR_WGRAD_GATE_MAX", "64")))
-
-
-def wgrad_gate():
-    if _WGRAD_GATED and WGRAD_STREAM is not None:
+    if len(_SIDE_DEFERRED) >= _WGRAD_BATCH:
         wgrad_flush()
 
 

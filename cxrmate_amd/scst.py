@@ -30,12 +30,6 @@ def _mark(label):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         TRACE.append((label, __import__("time").perf_counter(), ev))
-# CXR_SCST_AHEAD=1: queue the re-scoring pass behind the decode WITHOUT reading the decoded sequences back first (the fused decode knows from the prompt
-# whether a BOS column has to be stripped). Measured in round 5 and left OFF: with everything of the step queued while the GPU still replays the decode
-# graphs, the part of the step behind the decode takes ~9.5 ms LONGER (synthetic-id step 103.9 -> 113.0 ms, three same-box alternations,
-# scripts/r5/call10.sh) -- the host round trip at the end of the decode is not what the step waits for.
-_SYNC_STRIP = __import__("os").environ.get("CXR_SCST_AHEAD") != "1"
-
 
 def _host_copies(tensors):
     """Asynchronous device -> pinned-host copies on a side stream that waits only for what is queued so far (the decode): the main stream
@@ -88,12 +82,12 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
             base = model.generate(encoder_outputs=eo, decoder_input_ids=prompt_ids, special_token_ids=[pmt_sep, bos, sep],
                                   max_length=decoder_max_len + P, bos_token_id=bos, eos_token_id=eos, pad_token_id=pad, mask_token_id=pad,
                                   num_beams=1, return_dict_in_generate=True, use_cache=True)["sequences"]
-        # strip the leading BOS column (gt_prompt.py:185-186): read back from the sequences (one host round trip at the end of the decode), or -- opt-in,
-        # see _SYNC_STRIP -- taken from what the fused decode learned from the prompt
-        known = rec.get("all_bos_first") if (fused_decode and not _SYNC_STRIP) else None
-        if known if known is not None else bool(torch.all(seqs[:, 0] == bos)):
+        # strip the leading BOS column (gt_prompt.py:185-186): read back from the sequences (one host round trip at the end of the decode). Queueing the
+        # rest of the step WITHOUT that read (the fused decode knows from the prompt whether the column is there) was measured in round 5 and removed in
+        # round 6: beside the weight-gradient stream the part of the step behind the decode then takes ~9.5 ms LONGER (103.9 -> 113.0 ms)
+        if bool(torch.all(seqs[:, 0] == bos)):
             seqs = seqs[:, 1:]
-        if known if known is not None else bool(torch.all(base[:, 0] == bos)):
+        if bool(torch.all(base[:, 0] == bos)):
             base = base[:, 1:]
         sampled = seqs[:, P:].contiguous()
         _mark("decode done (host has read the sequences)")
@@ -101,7 +95,7 @@ def scst_step(model, opt, reward_fn, images, prompt_ids, label_texts, special, d
         if reward_on_host:
             host = _host_copies([seqs.contiguous(), base.contiguous()])
             start = getattr(reward_fn, "pair_start", None)
-            if start is not None and _SYNC_STRIP:
+            if start is not None:
                 # the decode is complete here (the BOS check above read the sequences back), so the copies land within ~0.1 ms: hand the ids to the
                 # reward's string worker NOW -- a child process turns them into strings and reward-tokenizer ids while this thread queues the
                 # re-scoring pass below (the tokenizers library keeps the GIL: a thread of this process could not run beside the launches)

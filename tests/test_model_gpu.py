@@ -1503,3 +1503,38 @@ def test_beam_counts_without_a_shared_kv_kernel_fall_back_to_the_host_loop(M):
                      num_beams=3, return_dict_in_generate=True, use_cache=True, output_scores=True)
     s = out["sequences"].cpu()
     assert s.shape[0] == 3 and bool((s[:, 0] == gu.BOS).all()) and s.shape[1] <= 14 and bool(torch.isfinite(out["sequences_scores"]).all())
+
+
+# ------------------------------------------------------------------------------------------------ the A/B switches that ship
+# Every environment switch of the package / the library selects a path that is NOT the default one. They are read once per process, so each group runs
+# the reference-fixture parity tests in a CHILD process with the switches set (round-5 review: nothing that ships may go unexecuted by the suite).
+_SWITCH_GROUPS = {
+    "decoder fallbacks": (dict(CXR_CROSS_KV_FUSED="0", CXR_LORA_IN_KERNEL="0", CXR_CROSS_KV_SHARED="0", CXR_LORA_MULTI="0", CXR_SELF_QKV_FUSED="0", CXR_CROSS_Q_FUSED="0"),
+                          "tf_single_logits_loss_grads or tf_longitudinal_lora_prompt or greedy_and_beam_multi or prompted_generate_and_scst_scores or tf_longitudinal_train_mode"),
+    "VALU cross-attention": (dict(CXR_CROSS_MFMA="0", CXR_CROSS_WG_KEYS="288"), "greedy_and_beam_multi or prompted_generate_and_scst_scores"),
+    "encoder fallbacks": (dict(CXR_EARLY_PATCH_COL="0", CXR_DWPROJ="0", CXR_DW3_STATS_FROM_Y="0", CXR_IMPLICIT_EMBED="0", CXR_PATCH_EMBED_FUSED="0", CXR_FP8_FUSED="0"),
+                          "encoder_matches_reference_fixture or tf_single_logits_loss_grads or tf_train_mode_matches_oracle or fp8_encoder_against"),
+    "library kernels": (dict(CXR_TN2="0", CXR_TN_STAGES="2", CXR_TN5="0", CXR_LN_BWD_PF="0", CXR_GEMM_WS="0", CXR_IM2COL_ROWS="0", CXR_CE_BF16ROW="0", CXR_GEMM_LDS_EPILOGUE="0"),
+                        "encoder_matches_reference_fixture or tf_single_logits_loss_grads or tf_train_mode_matches_oracle or forward_with_labels"),
+    "library kernels 2": (dict(CXR_TN2_MIN="1", CXR_TN_WGS="64", CXR_TN2_WGS="48", CXR_LN_BWD_GRID="128", CXR_GEMM_BK="32", CXR_GEMM_STAGES="3", CXR_DW3_BAND="4"),
+                          "tf_single_logits_loss_grads or tf_train_mode_matches_oracle"),
+    "training-step schedule": (dict(CXR_ZERO_ON_SIDE="0", CXR_EARLY_DEC_ADAMW="0", CXR_EARLY_ENC_ADAMW="0", CXR_BF16_LOGITS="0", CXR_WGRAD_OVERLAP="0", CXR_BIND_GRADS="0"),
+                               "tf_single_logits_loss_grads or torch_optimizer_updates or fused_adamw_behind or graphed_tf_step"),
+}
+
+
+@pytest.mark.parametrize("group", list(_SWITCH_GROUPS))
+def test_parity_tests_under_the_shipped_ab_switches(M, group):
+    import os
+    import subprocess
+    import sys
+    env_add, expr = _SWITCH_GROUPS[group]
+    if os.environ.get("CXR_SWITCH_CHILD") == "1":
+        pytest.skip("child of this test")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, CXR_SWITCH_CHILD="1", **env_add)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_model_gpu.py"), "-x", "-q", "-m", "gpu", "-k", expr, "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(here))
+    tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-1500:]
+    assert r.returncode == 0, f"{group}: {env_add}\n{tail}"
+    assert " passed" in r.stdout and " failed" not in r.stdout, tail
