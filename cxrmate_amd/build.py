@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcxrmate_hip.so")
-SOURCES = ["gemm.hip", "gemm_pk.hip", "gemm_ws.hip", "attention.hip", "attention_bwd.hip", "norm.hip", "conv.hip", "misc.hip", "loss.hip", "decode.hip", "decode_gemm.hip", "dropout.hip", "lora.hip", "dwproj.hip", "gemm_fp8.hip"]
+SOURCES = ["gemm.hip", "gemm_pk.hip", "gemm_ws.hip", "gemm_strip.hip", "attention.hip", "attention_bwd.hip", "norm.hip", "conv.hip", "misc.hip", "loss.hip", "decode.hip", "decode_gemm.hip", "dropout.hip", "lora.hip", "dwproj.hip", "gemm_fp8.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 
 

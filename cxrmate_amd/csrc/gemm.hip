@@ -493,6 +493,7 @@ extern "C" int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw
     // Persistent one-workgroup-per-CU kernels (144 KB of LDS each) for the shapes they win on -- only while the launching stream has the GPU to
     // itself (cxr_gemm_set_exclusive): beside the weight-gradient stream's kernels their workgroups cannot be co-resident and the static work
     // partition waits for the last CU to free up.
+    if (gemm_strip_launch(g, stream)) { CXR_LAUNCH_CHECK(); return CXR_OK; }   // M x 384 x K: one strip of rows x all 384 columns per workgroup (gemm_strip.hip)
     if (g_gemm_exclusive) {
         if (gemm_ws_launch(g, stream)) { CXR_LAUNCH_CHECK(); return CXR_OK; }   // K = 384, N >= 768: W resident in registers (gemm_ws.hip)
         if (gemm_pk_launch(g, stream)) { CXR_LAUNCH_CHECK(); return CXR_OK; }   // tall / very wide problems: persistent 256-row tiles (gemm_pk.hip)

@@ -51,8 +51,12 @@ class _gemm_route:
     def __enter__(self):
         from cxrmate_amd._lib import LIB
         r = self.route
+        LIB.call("cxr_gemm_strip_config", 0, -1, -1, -1)
         if r == "tiled":
             LIB.call("cxr_gemm_set_exclusive", 0)
+        elif isinstance(r, tuple) and r[0] == "strip":
+            LIB.call("cxr_gemm_set_exclusive", 0)
+            LIB.call("cxr_gemm_strip_config", 1, r[1], 1, r[2])
         elif r == "ws":
             LIB.call("cxr_gemm_set_exclusive", 1)
             LIB.call("cxr_gemm_ws_config", 1, 1, 1, -1, 0)
@@ -68,6 +72,7 @@ class _gemm_route:
         LIB.call("cxr_gemm_set_exclusive", 1)
         LIB.call("cxr_gemm_ws_config", 1, 0, 2048, -1, 0)
         LIB.call("cxr_gemm_pk_config", 1, 0, 2048, 0)
+        LIB.call("cxr_gemm_strip_config", 1, 0, 24577, 0)
         return False
 
 
@@ -124,6 +129,26 @@ def test_gemm_w_stationary_kernel_is_bit_identical_to_the_tiled_kernel(ops, M, N
         assert ref_aux is None or torch.equal(ref_aux, out_aux), f"ws {M}x{N} {name}: saved pre-activation differs"
         if name == "plain":
             close(out, a.float() @ w.float().t(), rtol=1e-2, atol=1e-2, what=f"ws {M}x{N}")
+
+
+@pytest.mark.parametrize("mt,stages", [(10, 0), (6, 0), (4, 0), (2, 0), (10, 2), (4, 2)])
+@pytest.mark.parametrize("M,K", [(36928, 384), (9280, 384), (5003, 1536), (100, 64)])
+def test_gemm_row_strip_kernel_is_bit_identical_to_the_tiled_kernel(ops, mt, stages, M, K):
+    """csrc/gemm_strip.hip (M x 384 x K: a strip of 16 mt rows x all 384 columns per workgroup, every strip height and stage count; ragged row tails,
+    row strides != K, every epilogue it takes) against gemm_nt_kernel: same MFMA orientation and K order -> the same bits; the epilogues it does not take
+    (GELU, dropout, fp32 output) must fall through to the tiled kernel unchanged."""
+    N = 384
+    a = dev(rnd(M + 3, K + 8, seed=M).to(BF))[:M, :K]
+    w = dev((rnd(N, K, seed=N) * 0.1).to(BF))
+    for name, kw in _gemm_variants(M, N, M + N).items():
+        with _gemm_route("tiled"):
+            ref, ref_aux = _run_variant(ops, a, w, kw)
+        with _gemm_route(("strip", mt, stages)):
+            out, out_aux = _run_variant(ops, a, w, kw)
+        assert torch.equal(ref, out), f"strip mt={mt} {M}x{N}x{K} {name}: {int((ref != out).sum())} elements differ"
+        assert ref_aux is None or torch.equal(ref_aux, out_aux), f"strip {M}x{N}x{K} {name}: saved pre-activation differs"
+        if name == "plain":
+            close(out, a.float() @ w.float().t(), rtol=1e-2, atol=1e-2, what=f"strip {M}x{N}x{K}")
 
 
 def test_gemm_persistent_asymmetric_identity(ops):
