@@ -12,17 +12,17 @@
 // strips dispatched by the hardware as CUs become free (no static partition: beside the weight-gradient stream some CUs are taken).
 //   * 8 waves as 2 (rows) x 4 (columns): a wave owns 8 MT rows x 96 columns = (MT / 2) x 6 MFMA tiles (16x16x32), issued as D^T = W . A^T so that a
 //     lane owns 4 consecutive output columns (as gemm_nt_kernel);
-//   * BK = 32 steps, NST LDS stages filled by 16-byte LDS-DMA NST - 1 steps ahead (counted vmcnt, one raw barrier per step), the images XOR-swizzled on the
-//     source address as in gemm_nt_kernel (Swz<32>): conflict-free ds_read_b128 fragment reads;
+//   * BK-deep steps (64 by default, two LDS stages; 32 with 2 - 4 stages for A/B), filled by 16-byte LDS-DMA NST - 1 steps ahead (counted vmcnt, one raw
+//     barrier per step), the images XOR-swizzled on the source address as in gemm_nt_kernel (Swz<BK>): conflict-free ds_read_b128 fragment reads;
 //   * epilogue through the idle staging LDS, one 16-row MFMA tile row per wave and pass: 16-byte accesses, 192 contiguous bytes per row and wave.
 #include "gemm_args.h"
 #include "../../include/cxrmate_hip.h"
 #include <stdlib.h>
 
-template <int MT, int NST>
+template <int MT, int NST, int BK = 32>
 __global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, const int dbg) {      // dbg (timing experiments): 1 no MFMA, 2 no refills, 4 no fragment reads
     CXR_PRIO_MAIN();
-    constexpr int BK = 32, CPR = BK / 8;                         // 4 chunks of 16 bytes per tile row
+    constexpr int CPR = BK / 8;                                  // 16-byte chunks per tile row (4 at BK = 32)
     constexpr int BM = 16 * MT, MW = MT / 2;                     // rows of the strip; MFMA tile rows per wave
     constexpr int A_PASSES = (BM * CPR + 511) / 512, W_PASSES = 384 * CPR / 512;      // LDS-DMA instructions per thread per stage: 1-2 + 3
     constexpr int A_BYTES = A_PASSES * 512 * 16, W_BYTES = W_PASSES * 512 * 16, STAGE = A_BYTES + W_BYTES;
@@ -91,27 +91,30 @@ __global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, co
         if (kt + NST - 1 < nk && !(dbg & 2)) stage((kt + NST - 1) % NST, kt + NST - 1);          // refills the stage consumed in step kt - 1
         const unsigned char* la = lds + (kt % NST) * STAGE;
         const unsigned char* lw = la + A_BYTES;
-        bf16x8_t fa[MW], fw[6];
-        if (!(dbg & 4) || kt == 0) {
 #pragma unroll
-            for (int t = 0; t < MW; ++t) {
-                const int ra = wm * (BM / 2) + t * 16 + fr;
-                fa[t] = *reinterpret_cast<const bf16x8_t*>(la + (ra * CPR + (fq ^ Swz<BK>::f(ra))) * 16);
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8_t fa[MW], fw[6];
+            if (!(dbg & 4) || kt == 0) {
+#pragma unroll
+                for (int t = 0; t < MW; ++t) {
+                    const int ra = wm * (BM / 2) + t * 16 + fr;
+                    fa[t] = *reinterpret_cast<const bf16x8_t*>(la + (ra * CPR + ((kk * 4 + fq) ^ Swz<BK>::f(ra))) * 16);
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const int rw = wn * 96 + t * 16 + fr;
+                    fw[t] = *reinterpret_cast<const bf16x8_t*>(lw + (rw * CPR + ((kk * 4 + fq) ^ Swz<BK>::f(rw))) * 16);
+                }
             }
+            if (!(dbg & 1)) {
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                const int rw = wn * 96 + t * 16 + fr;
-                fw[t] = *reinterpret_cast<const bf16x8_t*>(lw + (rw * CPR + (fq ^ Swz<BK>::f(rw))) * 16);
+                for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MW; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+            } else {
+                acc[0][0][0] += (float)fa[0][0] + (float)fw[5][7];
             }
-        }
-        if (!(dbg & 1)) {
-#pragma unroll
-            for (int nt = 0; nt < 6; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < MW; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
-        } else {
-            acc[0][0][0] += (float)fa[0][0] + (float)fw[5][7];
         }
     }
 
@@ -185,6 +188,10 @@ __global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, co
     }
 }
 
+// (A staggered form of this loop -- the two waves of every SIMD half a step apart, one feeding the matrix pipe while the other reads fragments and issues
+// its LDS-DMA share, two barriers per step -- was built, bit-identical, and measured SLOWER: 79.9 vs 62.2 us at K = 1536, TF step +0.6 ms. A barrier
+// phase costs ~0.2 - 0.4 us by itself here (the empty phase loop: 51 us against 21), more than the overlap it buys: profiles/r06_gemm_strip.txt.)
+
 static int strip_env(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -199,18 +206,18 @@ static void strip_init() {
     // persistent kernels (scripts/r6/strip_micro.py, profiles/r06_gemm_strip.txt) 36928 rows: 64 vs 70 / 62 us at K = 1536, 22 vs 28 / 26 at K = 384;
     // 18464 rows: 42 vs 36 / 35 and 16.4 vs 16.9 / 14.6; 9280 rows: 12.3 vs 14.9 / 10.4 -- the shorter strips re-stream the weights too often
     strip_min_rows = strip_env("CXR_STRIP_MIN_M", 24577);
-    strip_stages = strip_env("CXR_STRIP_STAGES", 0);            // 0: automatic, 2: two LDS stages
+    strip_stages = strip_env("CXR_STRIP_STAGES", 0);            // 0: automatic; 2 | 3 | 4: that many stages of 32-deep steps
     strip_dbg = strip_env("CXR_STRIP_DEBUG", 0);                // timing experiments (wrong results): 1 no MFMA, 2 no LDS-DMA refills, 4 no fragment reads
 }
 
-// tuning / A-B aid (like cxr_gemm_pk_config): enabled 0 | 1, mt 0 (automatic) | 2 | 4 | 6 | 10, min_rows, stages 0 (automatic) | 2 | 4 (mt 10 only); negative = keep
+// tuning / A-B aid (like cxr_gemm_pk_config): enabled 0 | 1, mt 0 (automatic) | 2 | 4 | 6 | 10, min_rows, stages 0 (automatic: mt 10 = two stages of 64-deep steps, else four of 32) | 2 | 3 | 4 (stages of 32-deep steps; 3, 4: mt 10 only); negative = keep
 extern "C" int cxr_gemm_strip_config(int enabled, int mt, int min_rows, int stages) {
     strip_init();
     if (mt > 0 && mt != 2 && mt != 4 && mt != 6 && mt != 10) return CXR_ERR_ARG;
     if (enabled >= 0) strip_enabled = enabled != 0;
     if (mt >= 0) strip_force_mt = mt;
     if (min_rows >= 0) strip_min_rows = min_rows;
-    if (stages >= 0) strip_stages = stages;
+    if (stages >= 0) strip_stages = stages;                       // (64: two stages of 64-deep steps, mt 10)
     return CXR_OK;
 }
 
@@ -227,9 +234,11 @@ bool gemm_strip_launch(const GemmArgs& g, hipStream_t stream) {
     if (!mt) mt = rg > 256 * 6 ? 10 : (rg > 256 * 4 ? 6 : (rg > 256 * 2 ? 4 : 2));
     const int grid = cdiv(g.M, 16 * mt);
     switch (mt) {
+        // default: two stages of 64-deep steps (half the barriers of the 32-deep loop: 64.8 -> 56.2 us at K = 1536, TF step -0.22 ms; call 16)
         case 10: if (stages == 2) CXR_LAUNCH((gemm_strip384_kernel<10, 2>), dim3(grid), dim3(512), 0, stream, g, strip_dbg);
+                 else if (stages == 3) CXR_LAUNCH((gemm_strip384_kernel<10, 3>), dim3(grid), dim3(512), 0, stream, g, strip_dbg);
                  else if (stages == 4) CXR_LAUNCH((gemm_strip384_kernel<10, 4>), dim3(grid), dim3(512), 0, stream, g, strip_dbg);
-                 else CXR_LAUNCH((gemm_strip384_kernel<10, 3>), dim3(grid), dim3(512), 0, stream, g, strip_dbg);
+                 else CXR_LAUNCH((gemm_strip384_kernel<10, 2, 64>), dim3(grid), dim3(512), 0, stream, g, strip_dbg);
                  break;
         case 6:  if (stages == 2) CXR_LAUNCH((gemm_strip384_kernel<6, 2>), dim3(grid), dim3(512), 0, stream, g, strip_dbg);
                  else CXR_LAUNCH((gemm_strip384_kernel<6, 4>), dim3(grid), dim3(512), 0, stream, g, strip_dbg);

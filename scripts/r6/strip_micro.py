@@ -28,7 +28,7 @@ def route(name):
 
 
 SHAPES = [(36928, 1536), (36928, 384)] if os.environ.get("STRIP_QUICK") else [(36928, 1536), (36928, 384), (9280, 384), (18464, 1536), (18464, 384)]
-ROUTES = ("tiled", "persistent", "strip:10:0", "strip:10:4") if os.environ.get("STRIP_QUICK") else ("tiled", "persistent", "strip:10:0", "strip:10:2", "strip:6:0", "strip:6:2", "strip:4:0", "strip:4:2", "strip:2:0", "strip:2:2")
+ROUTES = ("tiled", "persistent", "strip:10:0", "strip:10:64") if os.environ.get("STRIP_QUICK") else ("tiled", "persistent", "strip:10:0", "strip:10:2", "strip:6:0", "strip:6:2", "strip:4:0", "strip:4:2", "strip:2:0", "strip:2:2")
 for M, K in SHAPES:
     nb = max(2, int(1.2e9 / (M * K * 2)))
     As = [torch.randn(M, K, device="cuda").to(BF) for _ in range(nb)]

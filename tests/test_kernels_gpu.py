@@ -131,7 +131,7 @@ def test_gemm_w_stationary_kernel_is_bit_identical_to_the_tiled_kernel(ops, M, N
             close(out, a.float() @ w.float().t(), rtol=1e-2, atol=1e-2, what=f"ws {M}x{N}")
 
 
-@pytest.mark.parametrize("mt,stages", [(10, 0), (6, 0), (4, 0), (2, 0), (10, 2), (4, 2)])
+@pytest.mark.parametrize("mt,stages", [(10, 0), (6, 0), (4, 0), (2, 0), (10, 2), (4, 2), (10, 3), (10, 4)])      # (stages 0 at mt 10 = two stages of 64-deep steps, the default)
 @pytest.mark.parametrize("M,K", [(36928, 384), (9280, 384), (5003, 1536), (100, 64)])
 def test_gemm_row_strip_kernel_is_bit_identical_to_the_tiled_kernel(ops, mt, stages, M, K):
     """csrc/gemm_strip.hip (M x 384 x K: a strip of 16 mt rows x all 384 columns per workgroup, every strip height and stage count; ragged row tails,
