@@ -19,18 +19,20 @@
 #include "../../include/cxrmate_hip.h"
 #include <stdlib.h>
 
-template <int MT, int NST, int BK = 32>
+template <int MT, int NST, int BK = 32, int NTW = 6>            // NTW = 16-column MFMA tiles per wave: 6 (N = 384) | 3 (N = 192)
 __global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, const int dbg) {      // dbg (timing experiments): 1 no MFMA, 2 no refills, 4 no fragment reads
     CXR_PRIO_MAIN();
     constexpr int CPR = BK / 8;                                  // 16-byte chunks per tile row (4 at BK = 32)
     constexpr int BM = 16 * MT, MW = MT / 2;                     // rows of the strip; MFMA tile rows per wave
-    constexpr int A_PASSES = (BM * CPR + 511) / 512, W_PASSES = 384 * CPR / 512;      // LDS-DMA instructions per thread per stage: 1-2 + 3
+    constexpr int NCOLS = 64 * NTW, WCOLS = 16 * NTW;               // columns of the output / of a wave
+    constexpr int A_PASSES = (BM * CPR + 511) / 512, W_PASSES = (NCOLS * CPR + 511) / 512;      // LDS-DMA instructions per thread per stage
     constexpr int A_BYTES = A_PASSES * 512 * 16, W_BYTES = W_PASSES * 512 * 16, STAGE = A_BYTES + W_BYTES;
     constexpr int LPS = A_PASSES + W_PASSES;
-    constexpr int EPI_BYTES = 8 * 16 * 100 * 4;                  // epilogue: 8 waves x 16 rows x (96 + 4 pad) floats
+    constexpr int ESTR = WCOLS + 4;                              // epilogue row stride in floats (pad: the 16 rows of a write land on distinct banks)
+    constexpr int EPI_BYTES = 8 * 16 * ESTR * 4;                 // epilogue: 8 waves x 16 rows x (WCOLS + 4 pad) floats
     constexpr int LDS_BYTES = NST * STAGE > EPI_BYTES ? NST * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-    static_assert(MT % 2 == 0 && MT >= 2 && MT <= 10 && NST >= 2 && NST <= 5, "strip geometry");
+    static_assert(MT % 2 == 0 && MT >= 2 && MT <= 16 && MT * NTW <= 60 && NST >= 2 && NST <= 5 && (NTW == 6 || NTW == 3), "strip geometry");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, co
 #pragma unroll
     for (int p = 0; p < W_PASSES; ++p) {
         const int s = p * 512 + tid;
-        const int row = s / CPR, c = (s % CPR) ^ Swz<BK>::f(row);
+        const int row = s / CPR < NCOLS ? s / CPR : NCOLS - 1, c = (s % CPR) ^ Swz<BK>::f(row);
         srcW[p] = g.W + (long)row * g.ldw + c * 8;
     }
     auto stage = [&](int buf, int kt) {
@@ -70,9 +72,9 @@ __global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, co
                                              (__attribute__((address_space(3))) void*)(lw + (p * 512 + wave * 64) * 16), 16, 0, 0);
     };
 
-    f32x4_t acc[6][MW];
+    f32x4_t acc[NTW][MW];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < NTW; ++i)
 #pragma unroll
         for (int j = 0; j < MW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, co
         const unsigned char* lw = la + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
-            bf16x8_t fa[MW], fw[6];
+            bf16x8_t fa[MW], fw[NTW];
             if (!(dbg & 4) || kt == 0) {
 #pragma unroll
                 for (int t = 0; t < MW; ++t) {
@@ -101,19 +103,19 @@ __global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, co
                     fa[t] = *reinterpret_cast<const bf16x8_t*>(la + (ra * CPR + ((kk * 4 + fq) ^ Swz<BK>::f(ra))) * 16);
                 }
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    const int rw = wn * 96 + t * 16 + fr;
+                for (int t = 0; t < NTW; ++t) {
+                    const int rw = wn * WCOLS + t * 16 + fr;
                     fw[t] = *reinterpret_cast<const bf16x8_t*>(lw + (rw * CPR + ((kk * 4 + fq) ^ Swz<BK>::f(rw))) * 16);
                 }
             }
             if (!(dbg & 1)) {
 #pragma unroll
-                for (int nt = 0; nt < 6; ++nt)
+                for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < MW; ++mt)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
             } else {
-                acc[0][0][0] += (float)fa[0][0] + (float)fw[5][7];
+                acc[0][0][0] += (float)fa[0][0] + (float)fw[NTW - 1][7];
             }
         }
     }
@@ -122,12 +124,12 @@ __global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, co
     // values (bias added) in its own 6.4 KB of the idle staging LDS (row stride 100 floats: the 16 rows of a write land on distinct banks) and reads
     // them back as 8 columns per lane, 12 lanes per row: every global access is 16 bytes per lane, 192 contiguous bytes per row.
     __syncthreads();                                             // every wave has finished reading the last step's fragments
-    float* stg = reinterpret_cast<float*>(lds) + wave * (16 * 100);
-    float4 bv[6];
+    float* stg = reinterpret_cast<float*>(lds) + wave * (16 * ESTR);
+    float4 bv[NTW];
 #pragma unroll
-    for (int nt = 0; nt < 6; ++nt) {
+    for (int nt = 0; nt < NTW; ++nt) {
         bv[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g.bias) bv[nt] = *reinterpret_cast<const float4*>(g.bias + wn * 96 + nt * 16 + fq * 4);
+        if (g.bias) bv[nt] = *reinterpret_cast<const float4*>(g.bias + wn * WCOLS + nt * 16 + fq * 4);
     }
     const bool rd_aux = g.act == 2;
     const bf16_t* opp = rd_aux ? g.aux : g.residual;
@@ -135,31 +137,32 @@ __global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, co
 #pragma unroll
     for (int mt = 0; mt < MW; ++mt) {
 #pragma unroll
-        for (int nt = 0; nt < 6; ++nt) {
+        for (int nt = 0; nt < NTW; ++nt) {
             const float4 v = make_float4(acc[nt][mt][0] * g.alpha + bv[nt].x, acc[nt][mt][1] * g.alpha + bv[nt].y, acc[nt][mt][2] * g.alpha + bv[nt].z,
                                          acc[nt][mt][3] * g.alpha + bv[nt].w);
-            *reinterpret_cast<float4*>(stg + fr * 100 + nt * 16 + fq * 4) = v;
+            *reinterpret_cast<float4*>(stg + fr * ESTR + nt * 16 + fq * 4) = v;
         }
         // the wave reads back only what it wrote itself: no workgroup barrier, the reads below wait for the writes through lgkmcnt
-        uint4 rop[3];
-        float rsc[3];
+        constexpr int CPW = WCOLS / 8, EIT = (16 * CPW + 63) / 64;      // 8-column chunks per wave row; read-back passes (16 rows x CPW slots)
+        uint4 rop[EIT];
+        float rsc[EIT];
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {                          // 16 rows x 12 chunks of 8 columns = 192 slots
-            const int sl = it * 64 + lane;
-            const int row = sl / 12, cc = sl % 12;
+        for (int it = 0; it < EIT; ++it) {
+            const int sl0 = it * 64 + lane, sl = sl0 < 16 * CPW ? sl0 : 16 * CPW - 1;
+            const int row = sl / CPW, cc = sl % CPW;
             int m = m0 + wm * (BM / 2) + mt * 16 + row; m = m < g.M ? m : g.M - 1;
-            const int n = wn * 96 + cc * 8;
+            const int n = wn * WCOLS + cc * 8;
             if (opp) rop[it] = *reinterpret_cast<const uint4*>(opp + (long)m * ldop + n);
             if (g.row_scale) rsc[it] = g.row_scale[(unsigned)m / (unsigned)g.rs_rows];
         }
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int sl = it * 64 + lane;
-            const int row = sl / 12, cc = sl % 12;
+        for (int it = 0; it < EIT; ++it) {
+            const int sl0 = it * 64 + lane, sl = sl0 < 16 * CPW ? sl0 : 16 * CPW - 1;
+            const int row = sl / CPW, cc = sl % CPW;
             const int m = m0 + wm * (BM / 2) + mt * 16 + row;
-            const int n = wn * 96 + cc * 8;
-            const float4 lo = *reinterpret_cast<const float4*>(stg + row * 100 + cc * 8);
-            const float4 hi = *reinterpret_cast<const float4*>(stg + row * 100 + cc * 8 + 4);
+            const int n = wn * WCOLS + cc * 8;
+            const float4 lo = *reinterpret_cast<const float4*>(stg + row * ESTR + cc * 8);
+            const float4 hi = *reinterpret_cast<const float4*>(stg + row * ESTR + cc * 8 + 4);
             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             if (rd_aux) {
                 float a8[8];
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, co
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] *= rscale;
             }
-            if (m < g.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = pack8(v);
+            if (m < g.M && sl0 < 16 * CPW) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = pack8(v);
         }
         // the next tile row overwrites the parked values: this wave's reads above have returned (their values were consumed)
     }
@@ -197,7 +200,7 @@ static int strip_env(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-static int strip_enabled = -1, strip_force_mt = 0, strip_min_rows = 24577, strip_stages = 0, strip_dbg = 0;
+static int strip_enabled = -1, strip_force_mt = 0, strip_min_rows = 24577, strip_min_rows192 = 32768, strip_stages = 0, strip_dbg = 0;
 static void strip_init() {
     if (strip_enabled >= 0) return;
     strip_enabled = strip_env("CXR_GEMM_STRIP", 1);             // CXR_GEMM_STRIP=0: the tiled / persistent kernels of rounds 1-5 (A/B)
@@ -206,17 +209,21 @@ static void strip_init() {
     // persistent kernels (scripts/r6/strip_micro.py, profiles/r06_gemm_strip.txt) 36928 rows: 64 vs 70 / 62 us at K = 1536, 22 vs 28 / 26 at K = 384;
     // 18464 rows: 42 vs 36 / 35 and 16.4 vs 16.9 / 14.6; 9280 rows: 12.3 vs 14.9 / 10.4 -- the shorter strips re-stream the weights too often
     strip_min_rows = strip_env("CXR_STRIP_MIN_M", 24577);
+    // N = 192 (CvT stage 2) strips of 192 rows from 32768 rows: alone 147456 x 192 x 768 111 (tiled) / 91 (persistent) -> 80 us, x 192: 44 / 38 -> 36,
+    // 36864 x 192 x 192: 16 / 17 -> 12 us; TF step -0.03 .. -0.2 ms (call 19)
+    strip_min_rows192 = strip_env("CXR_STRIP_MIN_M192", 32768);
     strip_stages = strip_env("CXR_STRIP_STAGES", 0);            // 0: automatic; 2 | 3 | 4: that many stages of 32-deep steps
     strip_dbg = strip_env("CXR_STRIP_DEBUG", 0);                // timing experiments (wrong results): 1 no MFMA, 2 no LDS-DMA refills, 4 no fragment reads
 }
 
-// tuning / A-B aid (like cxr_gemm_pk_config): enabled 0 | 1, mt 0 (automatic) | 2 | 4 | 6 | 10, min_rows, stages 0 (automatic: mt 10 = two stages of 64-deep steps, else four of 32) | 2 | 3 | 4 (stages of 32-deep steps; 3, 4: mt 10 only); negative = keep
+// tuning / A-B aid (like cxr_gemm_pk_config): enabled 0 | 1, mt 0 (automatic) | 2 | 4 | 6 | 10 (N = 384) | 8 | 12 | 16 (N = 192), min_rows (-2: the shipped thresholds), stages 0 (automatic: mt 10 = two stages of 64-deep steps, else four of 32) | 2 | 3 | 4 (stages of 32-deep steps; 3, 4: mt 10 only); negative = keep
 extern "C" int cxr_gemm_strip_config(int enabled, int mt, int min_rows, int stages) {
     strip_init();
-    if (mt > 0 && mt != 2 && mt != 4 && mt != 6 && mt != 10) return CXR_ERR_ARG;
+    if (mt > 0 && mt != 2 && mt != 4 && mt != 6 && mt != 10 && mt != 8 && mt != 12 && mt != 16) return CXR_ERR_ARG;      // (8 / 12 / 16: the N = 192 form)
     if (enabled >= 0) strip_enabled = enabled != 0;
     if (mt >= 0) strip_force_mt = mt;
-    if (min_rows >= 0) strip_min_rows = min_rows;
+    if (min_rows >= 0) { strip_min_rows = min_rows; strip_min_rows192 = min_rows; }
+    else if (min_rows == -2) { strip_min_rows = 24577; strip_min_rows192 = 32768; }       // back to the shipped thresholds
     if (stages >= 0) strip_stages = stages;                       // (64: two stages of 64-deep steps, mt 10)
     return CXR_OK;
 }
@@ -226,9 +233,22 @@ bool gemm_strip_launch(const GemmArgs& g, hipStream_t stream) {
     strip_init();
     const int enabled = strip_enabled, force_mt = strip_force_mt, min_rows = strip_min_rows, stages = strip_stages;
     if (!enabled) return false;
+    if (g.N == 192) {
+        // N = 192 (CvT stage 2): strips of 256 rows x all 192 columns (8 x 3 MFMA tiles per wave), two stages of 64-deep steps
+        if ((g.K % 64) || g.M < strip_min_rows192 || g.out_f32 || g.act == 1 || g.drop_thr16 || !g.lds_epilogue || (g.act == 2 && g.residual)) return false;
+        if ((g.lda % 8) || (g.ldw % 8) || (g.ldc % 8) || (((size_t)g.A | (size_t)g.W | (size_t)g.C) & 15)) return false;
+        if (force_mt && force_mt != 16 && force_mt != 12 && force_mt != 8) return false;
+        const int mt192 = force_mt ? force_mt : 12;
+        const int grid192 = cdiv(g.M, 16 * mt192);
+        if (mt192 == 16)      CXR_LAUNCH((gemm_strip384_kernel<16, 2, 64, 3>), dim3(grid192), dim3(512), 0, stream, g, strip_dbg);
+        else if (mt192 == 12) CXR_LAUNCH((gemm_strip384_kernel<12, 2, 64, 3>), dim3(grid192), dim3(512), 0, stream, g, strip_dbg);
+        else                  CXR_LAUNCH((gemm_strip384_kernel<8, 2, 64, 3>), dim3(grid192), dim3(512), 0, stream, g, strip_dbg);
+        return true;
+    }
     if (g.N != 384 || (g.K % 64) || g.M < min_rows || g.out_f32 || g.act == 1 || g.drop_thr16 || !g.lds_epilogue || (g.act == 2 && g.residual)) return false;
     if ((g.lda % 8) || (g.ldw % 8) || (g.ldc % 8) || (((size_t)g.A | (size_t)g.W | (size_t)g.C) & 15)) return false;
     // strip height: the largest that still gives every CU a strip (one round), at least 32 rows
+    if (force_mt && force_mt != 2 && force_mt != 4 && force_mt != 6 && force_mt != 10) return false;      // (8 / 12 / 16 belong to the N = 192 form)
     const int rg = cdiv(g.M, 16);
     int mt = force_mt;
     if (!mt) mt = rg > 256 * 6 ? 10 : (rg > 256 * 4 ? 6 : (rg > 256 * 2 ? 4 : 2));

@@ -81,8 +81,9 @@ int cxr_gemm_pk_stamps(void* out, long bytes);   /* timing experiments: copies t
  * registers, A row blocks streamed through LDS; same results bit for bit). Tuning / A-B aid: enabled 0|1, bm 0 (automatic) | 32 | 64 rows per block,
  * wgs = workgroups of a launch, dbg = timing-experiment bits; a negative argument keeps the current value. */
 int cxr_gemm_ws_config(int enabled, int bm, int min_rows, int wgs, int dbg);
-/* round 6: row-strip kernel for M x 384 x K products (csrc/gemm_strip.hip: one strip of 16 mt rows x all 384 columns per workgroup). Tuning / A-B aid:
-   enabled 0 | 1, mt 0 (automatic) | 2 | 4 | 6 | 10, min_rows, stages 0 (automatic) | 2; negative = keep */
+/* round 6: row-strip kernel for M x 384 x K and M x 192 x K products (csrc/gemm_strip.hip: one strip of 16 mt rows x ALL columns per workgroup).
+   Tuning / A-B aid: enabled 0 | 1, mt 0 (automatic) | 2 | 4 | 6 | 10 (N = 384) | 8 | 12 | 16 (N = 192), min_rows (rows from which it is used; -2: the
+   shipped thresholds), stages 0 (automatic) | 2 | 3 | 4 (stages of 32-deep steps); negative = keep */
 int cxr_gemm_strip_config(int enabled, int mt, int min_rows, int stages);
 int cxr_gemm_ws_stamps(void* out, long bytes);   /* timing experiments: in-kernel s_memtime stamps of the last stamped launch -> HOST memory */
 int cxr_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int C, hipStream_t stream);

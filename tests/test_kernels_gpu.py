@@ -72,7 +72,7 @@ class _gemm_route:
         LIB.call("cxr_gemm_set_exclusive", 1)
         LIB.call("cxr_gemm_ws_config", 1, 0, 2048, -1, 0)
         LIB.call("cxr_gemm_pk_config", 1, 0, 2048, 0)
-        LIB.call("cxr_gemm_strip_config", 1, 0, 24577, 0)
+        LIB.call("cxr_gemm_strip_config", 1, 0, -2, 0)
         return False
 
 
@@ -149,6 +149,24 @@ def test_gemm_row_strip_kernel_is_bit_identical_to_the_tiled_kernel(ops, mt, sta
         assert ref_aux is None or torch.equal(ref_aux, out_aux), f"strip {M}x{N}x{K} {name}: saved pre-activation differs"
         if name == "plain":
             close(out, a.float() @ w.float().t(), rtol=1e-2, atol=1e-2, what=f"strip {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("mt", [8, 12, 16])
+@pytest.mark.parametrize("M,K", [(36864, 192), (5003, 768), (100, 64)])
+def test_gemm_row_strip_kernel_n192_is_bit_identical_to_the_tiled_kernel(ops, mt, M, K):
+    """The N = 192 form of csrc/gemm_strip.hip (CvT stage 2: strips of 16 mt rows x all 192 columns, 3 MFMA tile columns per wave) against gemm_nt_kernel."""
+    N = 192
+    a = dev(rnd(M + 3, K + 8, seed=M).to(BF))[:M, :K]
+    w = dev((rnd(N, K, seed=N) * 0.1).to(BF))
+    for name, kw in _gemm_variants(M, N, M + N).items():
+        with _gemm_route("tiled"):
+            ref, ref_aux = _run_variant(ops, a, w, kw)
+        with _gemm_route(("strip", mt, 0)):
+            out, out_aux = _run_variant(ops, a, w, kw)
+        assert torch.equal(ref, out), f"strip192 mt={mt} {M}x{N}x{K} {name}: {int((ref != out).sum())} elements differ"
+        assert ref_aux is None or torch.equal(ref_aux, out_aux), f"strip192 {M}x{N}x{K} {name}: saved pre-activation differs"
+        if name == "plain":
+            close(out, a.float() @ w.float().t(), rtol=1e-2, atol=1e-2, what=f"strip192 {M}x{N}x{K}")
 
 
 def test_gemm_persistent_asymmetric_identity(ops):
