@@ -139,11 +139,11 @@ def timed(step, steps, world, dev):
 
 
 def decode_traffic(c5=False):
-    """HBM-side bytes per cached token-step from the committed PMC passes (profiles/r03_pmc_decode[_c5]_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+    """HBM-side bytes per cached token-step from the committed PMC passes (profiles/r06_pmc_decode_hbm_traffic.json, r06_pmc_decode_c5_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate runs over one sample+greedy decode of the configs[3] / configs[4] shape, kernels launched one by one -- counters cannot
     be collected live, and hipGraph replays under --pmc take tens of minutes): the decode-step kernels only (the encoder / prefill kernels of the
     same run are left out)."""
-    for name in (("r03_pmc_decode_c5_hbm_traffic.json",) if c5 else ("r03_pmc_decode_hbm_traffic.json", "r02_pmc_decode_hbm_traffic.json")):
+    for name in (("r06_pmc_decode_c5_hbm_traffic.json", "r03_pmc_decode_c5_hbm_traffic.json") if c5 else ("r06_pmc_decode_hbm_traffic.json", "r03_pmc_decode_hbm_traffic.json", "r02_pmc_decode_hbm_traffic.json")):
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         if os.path.exists(path):
             pmc = json.load(open(path))
@@ -298,7 +298,7 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
                 "roofline": {"bound": "hbm", "kernel": "cached decode token-step, 32 rows, 1728 encoder keys", "achieved": achieved, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": decode_traffic(True)[0], "traffic_unit": "bytes per token-step",
                              "traffic_source": decode_traffic(True)[1], "algorithmic_bytes_per_token_step": step_bytes,
-                             "profile": "profiles/r03_scst_c5_decode_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/scst_c5_decode_profile.py)"}}
+                             "profile": "profiles/r06_scst_c5_decode_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/scst_c5_decode_profile.py)"}}
     # The HEADLINE of this key is the reference's step: decode -> strings -> tokenizer -> reward (scst/gt_prompt.py:90-91,120-128,192-197) at R = 128
     # reward tokens. The same step with R = 128 SYNTHETIC ids in place of the string round trip (what rounds 1-4 reported as `value`) stands beside
     # it as `synthetic_ids`: equal GPU work, no host string work.
@@ -326,7 +326,7 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
                          "traffic_source": decode_traffic()[1], "algorithmic_bytes_per_token_step": step_bytes,
                          "decode_ms_per_step": dec_ms, "us_per_token_step": dec_ms * 1e3 / n_tok,
                          "decode_share_of_step": dec_ms / (head_dt / steps * 1e3),
-                         "profile": "profiles/r04_scst_decode_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/scst_decode_profile.py)"}}
+                         "profile": "profiles/r06_scst_decode_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/scst_decode_profile.py)"}}
 
 
 def beam_bench(args, dev, host_loop_too=True):
@@ -734,7 +734,7 @@ def main():
     ms_per_step, tokens_per_s = main_res["ms_per_step"], main_res["tokens_per_s"]
     gm = main_res["gemm"]
     traffic, traffic_src = None, None                        # HBM-side bytes per launch from the committed PMC passes (cannot be collected live)
-    for name in ("r04_pmc_tf_hbm_traffic.json", "r03_pmc_tf_hbm_traffic.json", "r02_pmc_tf_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for name in ("r06_pmc_tf_hbm_traffic.json", "r04_pmc_tf_hbm_traffic.json", "r03_pmc_tf_hbm_traffic.json", "r02_pmc_tf_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             traffic = pmc["gemm_nt"]["hbm_bytes_per_launch"]
@@ -757,14 +757,14 @@ def main():
                    "rccl_ranks": world, "launch": "hipGraph replay (3 segments, RCCL between)" if args.graph else "eager, weight-gradient kernels on a side stream",
                    "mode": mode, "loss": main_res["loss"], "tokens_per_sec_per_gpu": tokens_per_s / world,
                    "model_tflops_per_gpu": main_res["step_gflop_per_gpu"] * 1e-3 / (ms_per_step * 1e-3)},
-        "roofline": {"bound": "mfma", "kernel": "NT GEMM family (gemm_nt_kernel tile variants, gemm_nt_group_kernel, and in the forward pass the persistent "
-                               "gemm_nt_pk_kernel / gemm_ws384_kernel; v_mfma_f32_16x16x32_bf16), timed while the weight-gradient stream runs beside it, "
-                               "as in the timed region", "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": "NT GEMM family (gemm_nt_kernel tile variants, gemm_nt_group_kernel, the row-strip kernel gemm_strip384_kernel for the 384- / "
+                               "192-wide outputs of CvT stages 3 / 2, and in the forward pass the persistent gemm_nt_pk_kernel / gemm_ws384_kernel; "
+                               "v_mfma_f32_16x16x32_bf16), timed while the weight-gradient stream runs beside it, as in the timed region", "achieved": achieved,
                      "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TF, "traffic": traffic,
                      "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "algorithmic_bytes_per_launch": gm["nt_bytes"] / max(1, gm["nt_n"]),
                      "launches_per_step": gm["nt_n"], "avg_launch_us": gm["nt_ms"] * 1e3 / max(1, gm["nt_n"]),
                      "avg_launch_gflop": gm["nt_flops"] / max(1, gm["nt_n"]) * 1e-9, "gemm_share_of_step": gm["nt_ms"] / ms_per_step,
-                     "weight_grad_kernel": {"kernel": "gemm_tn_kernel (128x128 tiles) / gemm_tn2_kernel (256x256 blocks, long token runs)", "launches_per_step": gm["tn_n"],
+                     "weight_grad_kernel": {"kernel": "gemm_tn_kernel (128x128 tiles) / gemm_tn2_kernel (256x256 blocks, long token runs) / gemm_tn5_kernel (384x192 blocks, CvT stage 3)", "launches_per_step": gm["tn_n"],
                                             "achieved": gm["tn_flops"] / (gm["tn_ms"] * 1e-3) / 1e12 if gm["tn_ms"] else None,
                                             "avg_launch_us": gm["tn_ms"] * 1e3 / max(1, gm["tn_n"])}},
     }

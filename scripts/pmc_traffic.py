@@ -8,7 +8,7 @@ import collections, csv, glob, json, sys
 
 
 def family(n):
-    for key, fam in (("gemm_nt", "gemm_nt"), ("gemm_tn", "gemm_tn"), ("dec_gemm", "dec_gemm"), ("attn_decode", "attn_decode"), ("attn_cross_mfma", "attn_decode"), ("pack_cross_kv", "cross_kv_packing"), ("gemm_skinny", "gemm_skinny"),
+    for key, fam in (("gemm_nt", "gemm_nt"), ("gemm_strip", "gemm_nt"), ("gemm_ws", "gemm_nt"), ("gemm_tn", "gemm_tn"), ("dec_gemm", "dec_gemm"), ("attn_decode", "attn_decode"), ("attn_cross_mfma", "attn_decode"), ("pack_cross_kv", "cross_kv_packing"), ("gemm_skinny", "gemm_skinny"),
                      ("gemm_fp8", "gemm_fp8"), ("beam_", "beam_step"), ("gather_multi", "cache_reorder"), ("sample_", "token_selection"),
                      ("select_token", "token_selection"), ("decode_step", "step_inputs_embedding"), ("dw3_", "conv_projections"), ("layernorm", "layernorm")):
         if key in n:
