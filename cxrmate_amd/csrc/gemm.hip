@@ -561,6 +561,7 @@ extern "C" int cxr_gemm_nt_group_bf16(const cxr_gemm_nt_desc* d, int n, hipStrea
     }
     if (m == 0) { CXR_LAUNCH_CHECK(); return CXR_OK; }
     n = m;
+    if (gemm_strip_group_launch(gg.g, n, stream)) { CXR_LAUNCH_CHECK(); return CXR_OK; }       // round 6: all members as strips of ONE launch (gemm_strip.hip)
     for (int i = n; i < 3; ++i) gg.g[i] = gg.g[0];
     const int N = gg.g[0].N, K = gg.g[0].K;
     const bool bk64 = (K % 64) == 0;

@@ -35,3 +35,5 @@ bool gemm_pk_launch(const GemmArgs& g, hipStream_t stream);
 bool gemm_ws_launch(const GemmArgs& g, hipStream_t stream);
 // defined in gemm_strip.hip: true when the row-strip kernel took the problem (N == 384, K % 64 == 0, bf16 output, no GELU / dropout epilogue)
 bool gemm_strip_launch(const GemmArgs& g, hipStream_t stream);
+// ... and the grouped form: true when ONE row-strip launch took all n (<= 3) problems
+bool gemm_strip_group_launch(const GemmArgs* g, int n, hipStream_t stream);

@@ -20,7 +20,7 @@
 #include <stdlib.h>
 
 template <int MT, int NST, int BK = 32, int NTW = 6>            // NTW = 16-column MFMA tiles per wave: 6 (N = 384) | 3 (N = 192)
-__global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, const int dbg) {      // dbg (timing experiments): 1 no MFMA, 2 no refills, 4 no fragment reads
+__device__ __forceinline__ void gemm_strip_body(const GemmArgs& g, const int strip, const int dbg) {      // dbg (timing experiments): 1 no MFMA, 2 no refills, 4 no fragment reads
     CXR_PRIO_MAIN();
     constexpr int CPR = BK / 8;                                  // 16-byte chunks per tile row (4 at BK = 32)
     constexpr int BM = 16 * MT, MW = MT / 2;                     // rows of the strip; MFMA tile rows per wave
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
     const int fr = lane & 15, fq = lane >> 4;
-    const int m0 = blockIdx.x * BM;
+    const int m0 = strip * BM;
 
     // per-thread staging sources: slot s = p * 512 + tid -> tile row s / 4, physical chunk s % 4 holds logical chunk (s % 4) ^ Swz<32>::f(row)
     const bf16_t* srcA[A_PASSES];
@@ -191,6 +191,24 @@ __global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, co
     }
 }
 
+template <int MT, int NST, int BK = 32, int NTW = 6>
+__global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, const int dbg) {
+    gemm_strip_body<MT, NST, BK, NTW>(g, blockIdx.x, dbg);
+}
+
+// Up to three problems with the same N = 384 and K in ONE launch (the query / key / value projections of a CvT stage-3 layer and their input gradients:
+// 36928 + 9280 + 9280 rows): workgroups [start[p], start[p + 1]) own the strips of problem p. As separate launches the two 9280-row problems run on a
+// third of the chip behind the big one (measured: -0.7 ms of the strip kernel's gain, scripts/r6/call17.sh); grouped, their strips fill the tail of its wave.
+struct StripGroupArgs { GemmArgs g[3]; int start[3]; int n; };
+template <int MT, int NST, int BK>
+__global__ __launch_bounds__(512) void gemm_strip384_group_kernel(const StripGroupArgs gg, const int dbg) {
+    const int b = blockIdx.x;
+    const int p = (gg.n > 2 && b >= gg.start[2]) ? 2 : ((gg.n > 1 && b >= gg.start[1]) ? 1 : 0);
+    if (p == 0)      gemm_strip_body<MT, NST, BK, 6>(gg.g[0], b, dbg);
+    else if (p == 1) gemm_strip_body<MT, NST, BK, 6>(gg.g[1], b - gg.start[1], dbg);
+    else             gemm_strip_body<MT, NST, BK, 6>(gg.g[2], b - gg.start[2], dbg);
+}
+
 // (A staggered form of this loop -- the two waves of every SIMD half a step apart, one feeding the matrix pipe while the other reads fragments and issues
 // its LDS-DMA share, two barriers per step -- was built, bit-identical, and measured SLOWER: 79.9 vs 62.2 us at K = 1536, TF step +0.6 ms. A barrier
 // phase costs ~0.2 - 0.4 us by itself here (the empty phase loop: 51 us against 21), more than the overlap it buys: profiles/r06_gemm_strip.txt.)
@@ -270,5 +288,34 @@ bool gemm_strip_launch(const GemmArgs& g, hipStream_t stream) {
                  else CXR_LAUNCH((gemm_strip384_kernel<2, 4>), dim3(grid), dim3(512), 0, stream, g, strip_dbg);
                  break;
     }
+    return true;
+}
+
+static bool strip_takes(const GemmArgs& g) {
+    return g.N == 384 && (g.K % 64) == 0 && !g.out_f32 && g.act != 1 && !g.drop_thr16 && g.lds_epilogue && !(g.act == 2 && g.residual) && !(g.lda % 8) && !(g.ldw % 8) &&
+           !(g.ldc % 8) && !(((size_t)g.A | (size_t)g.W | (size_t)g.C) & 15);
+}
+
+// true when the grouped row-strip launch took ALL n problems (same N = 384 and K; the largest has at least the automatic row threshold)
+bool gemm_strip_group_launch(const GemmArgs* g, int n, hipStream_t stream) {
+    strip_init();
+    static int grp = -1;
+    if (grp < 0) grp = strip_env("CXR_STRIP_GROUP", 1);          // CXR_STRIP_GROUP=0: grouped problems stay on gemm_nt_group_kernel (A/B)
+    if (!strip_enabled || !grp || n < 1 || n > 3 || strip_force_mt) return false;
+    int mmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!strip_takes(g[i]) || g[i].K != g[0].K) return false;
+        mmax = g[i].M > mmax ? g[i].M : mmax;
+    }
+    if (mmax < strip_min_rows) return false;
+    StripGroupArgs gg;
+    int grid = 0;
+    for (int i = 0; i < 3; ++i) {
+        gg.g[i] = g[i < n ? i : 0];
+        gg.start[i] = grid;
+        if (i < n) grid += cdiv(g[i].M, 160);
+    }
+    gg.n = n;
+    CXR_LAUNCH((gemm_strip384_group_kernel<10, 2, 64>), dim3(grid), dim3(512), 0, stream, gg, strip_dbg);
     return true;
 }

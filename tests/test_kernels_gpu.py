@@ -1107,15 +1107,19 @@ def test_dwconv_batchnorm_train_mode(ops, C, H, tok0):
         close(dx[:, tok0:], xs.grad.flatten(2).transpose(1, 2), rtol=3e-2, atol=3e-2, what=f"train-mode dx {name}")
 
 
-@pytest.mark.parametrize("Ms,N,K", [((18464, 4640, 4640), 384, 384), ((300, 77), 192, 192), ((8192, 8192, 8192), 768, 768), ((130,), 64, 96)])
+@pytest.mark.parametrize("Ms,N,K", [((18464, 4640, 4640), 384, 384), ((300, 77), 192, 192), ((8192, 8192, 8192), 768, 768), ((130,), 64, 96),
+                                    ((36928, 9280, 9280), 384, 384), ((36928, 9283), 384, 1536)])       # (the last two: the grouped row-strip launch)
 def test_gemm_nt_group_equals_single_launches(ops, Ms, N, K):
-    """Grouped launch (query / key / value projections in one kernel) == the same problems launched one by one, bit for bit."""
+    """Grouped launch (query / key / value projections in one kernel) == the same problems launched one by one, bit for bit; with a member of >= 24577
+    rows at N = 384 the group goes out as ONE row-strip launch (csrc/gemm_strip.hip), compared here with the tiled kernel too."""
     probs = []
     for i, M in enumerate(Ms):
         probs.append((dev(rnd(M, K, seed=i).to(BF)), dev(rnd(N, K, seed=10 + i, scale=0.1).to(BF)), dev(rnd(N, seed=20 + i)) if i != 1 else None))
     outs = ops.gemm_nt_group(probs)
     for (a, w, b), o in zip(probs, outs):
         assert torch.equal(o, ops.gemm_nt(a, w, bias=b))
+        with _gemm_route("tiled"):
+            assert torch.equal(o, ops.gemm_nt(a, w, bias=b))
         close(o, a.float() @ w.float().t() + (b if b is not None else 0), what="grouped gemm")
 
 
