@@ -23,7 +23,9 @@ for n in tf fwd dec c5; do f=$(ls $O/${n}_prof/*/*kernel_stats.csv 2>/dev/null |
 STEPS=$(python - <<PY
 import csv, glob
 f = sorted(glob.glob("$O/tf_fetch/**/*counter_collection.csv", recursive=True))[-1]
-print(sum(1 for r in csv.DictReader(open(f)) if r["Counter_Name"] == "FETCH_SIZE" and r["Kernel_Name"].startswith("adamw_kernel")) // 2)
+# one softmax-CE launch per optimiser step (AdamW is THREE launches per step on one rank: the round-4 / round-5 scripts divided its count by two and
+# so reported 2/3 of the true bytes per step)
+print(sum(1 for r in csv.DictReader(open(f)) if r["Counter_Name"] == "FETCH_SIZE" and r["Kernel_Name"].startswith("softmax_ce")))
 PY
 )
 echo "optimiser steps in the counter run: $STEPS"
