@@ -23,7 +23,15 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 
 // row_loss[r] = logsumexp_kept(logits[r]) - logits[r][label]   (0 for ignored rows)
 // dlogits[r][v] = row_w[r] * (softmax_kept - onehot)            (0 for ignored rows and for filtered entries)
-// "kept" = entries >= thr[r] when thr != null (top-k filtered distribution of the SCST sampler, reference scst/gt_prompt.py:189,230-235)
+// "kept" = entries >= thr[r] when thr != null (top-k filtered distribution of the SCST sampler, reference scst/gt_prompt.py:189,230-235).
+// The label of a row IS in its kept set (the reference's scores are the ones the token was drawn from): where the re-scored logit of the drawn
+// token fell below the re-computed threshold (last bf16 bits at the edge of the top-k) it takes the place of the k-th entry -- kept = { > thr }
+// + label, still k finite entries -- see kept_threshold().
+__device__ __forceinline__ float kept_threshold(const float* __restrict__ thr, long r, float xlab) {
+    if (!thr) return -INFINITY;
+    const float t = thr[r];
+    return xlab < t ? nextafterf(t, INFINITY) : t;
+}
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ labels,
                                                          long ignore_index, const float* __restrict__ thr, const float* __restrict__ row_w,
                                                          float* __restrict__ row_loss, bf16_t* __restrict__ dlogits, long lddl, int V) {
@@ -38,12 +46,13 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
             *reinterpret_cast<uint4*>(dlogits + r * lddl + v) = make_uint4(0, 0, 0, 0);
         return;
     }
-    const float t = thr ? thr[r] : -INFINITY;
-    float mx = -INFINITY;
+    const float xlab = x[label];
+    const float t = kept_threshold(thr, r, xlab);
+    float mx = xlab;
     for (int v = threadIdx.x; v < V; v += 256) { const float a = x[v]; if (a >= t) mx = fmaxf(mx, a); }
     mx = block_max(mx, sh);
     float s = 0.f;
-    for (int v = threadIdx.x; v < V; v += 256) { const float a = x[v]; if (a >= t) s += __expf(a - mx); }
+    for (int v = threadIdx.x; v < V; v += 256) { const float a = x[v]; if (a >= t || v == (int)label) s += __expf(a - mx); }
     s = block_sum(s, sh);
     const float lse = mx + __logf(s);
     if (row_loss && threadIdx.x == 0) row_loss[r] = lse - x[label];
@@ -55,7 +64,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
             for (int j = 0; j < 8; ++j) {
                 const int vv = v + j;
                 float gv = 0.f;
-                if (vv < V) { const float a = x[vv]; if (a >= t) gv = __expf(a - mx) * inv; if (vv == label) gv -= 1.0f; }
+                if (vv < V) { const float a = x[vv]; if (a >= t || vv == label) gv = __expf(a - mx) * inv; if (vv == label) gv -= 1.0f; }
                 o[j] = gv * w;
             }
             *reinterpret_cast<uint4*>(dlogits + r * lddl + v) = pack8(o);
@@ -82,10 +91,11 @@ __device__ __forceinline__ void softmax_ce_reg_body(const void* __restrict__ log
             *reinterpret_cast<uint4*>(dlogits + r * lddl + v) = make_uint4(0, 0, 0, 0);
         return;
     }
-    const float t = thr ? thr[r] : -INFINITY;
+    const float xlab = thr ? (BF16IN ? bf2f(x16[label]) : x[label]) : -INFINITY;
+    const float t = kept_threshold(thr, r, xlab);
     // thread owns columns [8*tid + 8192*i, +8): two float4 per chunk, 4 chunks
     float4 a[4][2];
-    float mx = -INFINITY;
+    float mx = xlab;                                                         // the label is always kept
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int v = tid * 8 + 8192 * i;
@@ -132,8 +142,8 @@ __device__ __forceinline__ void softmax_ce_reg_body(const void* __restrict__ log
             float* q = reinterpret_cast<float*>(&a[i][h]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float e = q[j] >= t ? __expf(q[j] - mx) : 0.f;       // -inf padding / filtered entries -> 0
                 const int vv = tid * 8 + 8192 * i + 4 * h + j;
+                const float e = (q[j] >= t || vv == (int)label) ? __expf(q[j] - mx) : 0.f;       // -inf padding / filtered entries -> 0
                 if (vv == (int)label) xl = q[j];
                 q[j] = e;
             }
@@ -198,14 +208,15 @@ __global__ __launch_bounds__(1024, 8) void softmax_ce_bf16row_kernel(const bf16_
             *reinterpret_cast<uint4*>(dlogits + r * lddl + v) = make_uint4(0, 0, 0, 0);
         return;
     }
-    const float t = thr ? thr[r] : -INFINITY;
+    const float xlab = thr ? bf2f(x16[label]) : -INFINITY;
+    const float t = kept_threshold(thr, r, xlab);
     uint4 raw[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int v = tid * 8 + 8192 * i;
         raw[i] = *reinterpret_cast<const uint4*>(x16 + (v < V ? v : V - 8));
     }
-    float mx = -INFINITY;
+    float mx = xlab;                                                         // the label is always kept
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (tid * 8 + 8192 * i >= V) continue;
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(1024, 8) void softmax_ce_bf16row_kernel(const bf16_
         unpack8(raw[i], f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            e[j] = f[j] >= t ? __expf(f[j] - mx) : 0.f;
+            e[j] = (f[j] >= t || v + j == (int)label) ? __expf(f[j] - mx) : 0.f;
             if (v + j == (int)label) xl = f[j];
         }
         s += (e[0] + e[1]) + (e[2] + e[3]);                              // (the summation order of softmax_ce_reg_kernel: bit-identical results)
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(1024, 8) void softmax_ce_bf16row_kernel(const bf16_
             unpack8(raw[i], f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float gv = (f[j] >= t ? __expf(f[j] - mx) : 0.f) * inv;
+                float gv = ((f[j] >= t || v + j == (int)label) ? __expf(f[j] - mx) : 0.f) * inv;
                 if (v + j == (int)label) gv -= 1.0f;
                 o[j] = v < V ? gv * w : 0.f;
             }

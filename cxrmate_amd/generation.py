@@ -523,13 +523,17 @@ class GenerationMixin:
             with torch.no_grad():                                            # sc is already temperature-scaled: warpers see temperature 1
                 flat = sc.detach().reshape(-1, sc.shape[-1]).contiguous()
                 thr = ops.topk_threshold(flat, int(top_k or 0), top_p, 1.0).view(sc.shape[0], sc.shape[1], 1)
-            drop = sc < thr                                                  # TopK (+ TopP) LogitsWarper semantics (ties at the threshold kept)
             # The token that WAS sampled at a step is inside that step's kept set by construction (reference: the scores are the ones it was
             # drawn from). These scores are recomputed by a teacher-forced pass whose logits differ from the cached step's in the last bf16
             # bits, so a token drawn at the very edge of the top-k can fall just below the recomputed threshold (a few per 4080 draws at the
-            # benchmark shape): it keeps its score -- a -inf there would turn the caller's REINFORCE loss into inf - inf.
-            drawn = ids[:, prompt_len: prompt_len + n_new]
-            drop = drop.scatter(2, drawn.unsqueeze(-1).clamp(min=0), False)
+            # benchmark shape). It keeps its score -- a -inf there would turn the caller's REINFORCE loss into inf - inf -- and takes the place of
+            # the k-th entry, so the row still has top_k finite entries, as the reference's rows do (same rule as csrc/loss.hip kept_threshold).
+            drawn = ids[:, prompt_len: prompt_len + n_new].unsqueeze(-1).clamp(min=0)
+            with torch.no_grad():
+                below = sc.detach().gather(2, drawn) < thr
+                thr = torch.where(below, torch.nextafter(thr, torch.full_like(thr, float("inf"))), thr)
+            drop = sc < thr                                                  # TopK (+ TopP) LogitsWarper semantics (ties at the threshold kept)
+            drop = drop.scatter(2, drawn, False)
             sc = sc.masked_fill(drop, float("-inf"))
         # one unbind (its backward is ONE stack of the steps' gradients; 255 separate slices each scattered their gradient into a zero tensor of
         # the full [B, T, V] size: 85 ms per SCST step at the benchmark shape). Each step remembers where it came from so that the caller's

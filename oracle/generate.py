@@ -42,12 +42,14 @@ def step_inputs(kind, input_ids, special_token_ids, mask_token_id=None, bos_toke
 def top_k_filter(scores, top_k, keep=None):
     """TopKLogitsWarper (TF5 logits_process.py): entries below the k-th largest become -inf (ties at the k-th kept).
     keep (int64, scores.shape[:-1]): token per row that stays finite whatever its rank -- for checking a bf16 implementation whose sampled token
-    sat at the edge of ITS top-k and falls just outside the fp32 one (the filtered distributions then differ by that one boundary entry)."""
+    sat at the edge of ITS top-k and falls just outside the fp32 one: it takes the place of the k-th entry, so the row keeps top_k finite entries
+    (the rule of cxrmate_amd/csrc/loss.hip kept_threshold; the filtered distributions then differ by that one boundary entry)."""
     top_k = min(top_k, scores.shape[-1])
     kth = torch.topk(scores, top_k)[0][..., -1, None]
     drop = scores < kth
     if keep is not None:
-        drop = drop.scatter(-1, keep.clamp(min=0)[..., None], False)
+        at = keep.clamp(min=0)[..., None]
+        drop = torch.where(scores.gather(-1, at) < kth, scores <= kth, drop).scatter(-1, at, False)
     return scores.masked_fill(drop, float("-inf"))
 
 

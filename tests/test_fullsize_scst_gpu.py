@@ -5,8 +5,8 @@ gt_prompt.py:62-142 (step), :144-209 (sample), :211-246 (reinforce_loss); gen_pr
 
   (i)   the fused 32-row sample + greedy decode returns greedy rows equal to a separate 16-row greedy generate() up to the first position whose
         teacher-forced top-1 / top-2 margin is below the bf16 logit error bound; teacher-forced argmax == greedy token at every safe position;
-  (ii)  every processed score row of generate.__wrapped__ has exactly top_k finite entries (one more where the drawn token sat just below the
-        recomputed threshold) and the sampled id is one of them;
+  (ii)  every processed score row of generate.__wrapped__ has exactly top_k finite entries (a drawn token that sat just below the recomputed
+        threshold takes the k-th entry's place) and the sampled id is one of them;
   (iii) train mode: the re-scoring pass's log-probabilities at the sampled ids equal those of the decode-time processed scores (the cached-step
         kernels teacher-forced on the sampled ids with the decode's dropout seed) within the bf16 bound, and every token the session sampled lies
         inside the re-scored top-k (one rank of slack);
@@ -121,7 +121,11 @@ def test_c4_fused_sample_and_greedy_decode_properties(model):
         scores = torch.stack([s_.as_subclass(torch.Tensor) for s_ in out["scores"]], dim=1)       # [B, NEW, V]
         assert scores.shape == (B, NEW, 30000)
         nfin = torch.isfinite(scores).sum(-1)
-        assert int(nfin.min()) >= 50 and int(nfin.max()) <= 51 and float((nfin == 50).float().mean()) > 0.98
+        # exactly top_k per row, as in the reference: a token drawn at the edge of the top-k whose re-scored logit fell below the re-computed
+        # threshold takes the k-th entry's place (ties AT the threshold are kept by the warper, here and in the reference: 51; dropped with the
+        # k-th entry in a replaced row: 49)
+        print("finite entries per processed row:", {int(v): int(c) for v, c in zip(*torch.unique(nfin, return_counts=True))})
+        assert int(nfin.min()) >= 49 and int(nfin.max()) <= 51 and float((nfin == 50).float().mean()) > 0.999
         drawn = scores.gather(-1, seqs[:, P:].unsqueeze(-1))[..., 0]
         assert bool(torch.isfinite(drawn).all())
 
@@ -163,7 +167,8 @@ def test_c4_train_mode_rescoring_equals_the_decode_time_scores(model):
             def logp_at(lg):
                 flat = lg.reshape(-1, lg.shape[-1]).contiguous().float()
                 thr = ops.topk_threshold(flat, 50, 1.0, 1.0).view(-1, 1)
-                keep = (flat >= thr).scatter(1, sampled.view(-1, 1), True)
+                at = flat.gather(1, sampled.view(-1, 1))
+                keep = torch.where(at < thr, flat > thr, flat >= thr).scatter(1, sampled.view(-1, 1), True)
                 return torch.log_softmax(flat.masked_fill(~keep, float("-inf")), -1).gather(1, sampled.view(-1, 1))[:, 0]
 
             a, b = logp_at(rs), logp_at(dt)
@@ -184,9 +189,10 @@ def test_c4_train_mode_rescoring_equals_the_decode_time_scores(model):
 
 
 def _reinforce_restatement(logits, sampled, adv):
-    """reference scst/gt_prompt.py:211-246 on processed scores [B, T, V] (top-k 50 warper restated with torch.topk; the drawn token keeps its score)."""
+    """reference scst/gt_prompt.py:211-246 on processed scores [B, T, V] (top-k 50 warper restated with torch.topk; the drawn token keeps its score, in place of the k-th entry where it fell below)."""
     kth = logits.topk(50, dim=-1).values[..., -1:]
-    keep = (logits >= kth).scatter(2, sampled.unsqueeze(-1), True)
+    at = logits.gather(2, sampled.unsqueeze(-1))
+    keep = torch.where(at < kth, logits > kth, logits >= kth).scatter(2, sampled.unsqueeze(-1), True)      # csrc/loss.hip kept_threshold
     sc = logits.masked_fill(~keep, float("-inf")).permute(0, 2, 1)                     # [B, V, T] as the caller stacks them
     nll = torch.nn.functional.nll_loss(torch.log_softmax(sc, dim=1), sampled, ignore_index=PAD, reduction="none")
     return (nll.sum(-1) * adv).mean()

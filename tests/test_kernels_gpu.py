@@ -1508,6 +1508,35 @@ def test_softmax_ce_and_reinforce(ops):
     ref.backward()
     assert abs(loss.item() - ref.item()) < 1e-4, (loss.item(), ref.item())
     close(dl, lr.grad, rtol=2e-2, atol=2e-2, what="reinforce dlogits")
+    # a drawn token whose re-scored logit sits BELOW the re-computed threshold (rank 51 / rank 300) takes the place of the k-th entry: kept =
+    # { > thr } + the token, still k entries with a gradient; fp32 rows through the register kernel and the generic one (ld % 4 != 0), bf16 rows
+    order = torch.topk(logits, 300)[1]
+    below = sampled.clone()
+    below[0], below[7], below[11] = order[0, 50], order[7, 299], order[11, 50]
+    wb = ops.ce_weights(below, 4, mode=1, reward=reward, T=T)
+    def restated(lg32, exact=True):
+        lr2 = lg32.clone().requires_grad_(True)
+        kth2 = torch.topk(lg32, k)[0][:, -1]
+        at = lg32.gather(1, below.view(-1, 1))[:, 0]
+        keep = torch.where((at < kth2)[:, None], lg32 > kth2[:, None], lg32 >= kth2[:, None]).scatter(1, below.view(-1, 1), True)
+        assert not exact or (int(keep.sum(1).min()) == k and int(keep.sum(1).max()) == k)     # (bf16 rows: values tie at the threshold)
+        sc2 = lr2.masked_fill(~keep, float("-inf")).view(B, T, V).permute(0, 2, 1)
+        nll2 = torch.nn.functional.nll_loss(torch.log_softmax(sc2, 1), below.view(B, T), ignore_index=4, reduction="none")
+        r2 = (nll2.sum(-1) * reward).mean()
+        r2.backward()
+        return r2, lr2.grad
+    ref2, g2 = restated(logits)
+    for lg in (logits, torch.cat([logits, logits[:, :1]], 1)[:, :V]):           # second form: row stride V + 1 -> the 256-thread kernel
+        loss2, _, dl2 = ops.softmax_ce(lg, below, 4, wb, thr=thr)
+        assert abs(loss2.item() - ref2.item()) < 1e-4, (loss2.item(), ref2.item())
+        close(dl2, g2, rtol=2e-2, atol=2e-2, what="reinforce dlogits, drawn token below the threshold")
+        live = (dl2[:, :V].float() != 0).sum(1)
+        assert int(live[0]) == k and int(live[7]) == k and int(live[11]) == k and int(live[4]) == 0, live
+    l16 = logits.to(torch.bfloat16)
+    ref3, g3 = restated(l16.float(), exact=False)
+    loss3, _, dl3 = ops.softmax_ce(l16, below, 4, wb, thr=ops.topk_threshold(l16.float(), k))
+    assert abs(loss3.item() - ref3.item()) < 1e-4, (loss3.item(), ref3.item())
+    close(dl3, g3, rtol=2e-2, atol=2e-2, what="reinforce dlogits bf16 rows, drawn token below the threshold")
 
 
 def test_select_token(ops):
