@@ -177,27 +177,28 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
     g = torch.Generator().manual_seed(2000 + rank)
     images = torch.randn(B, N, 3, IMG, IMG, generator=g).to(dev)
     enc_ms = None
+
+    def enc_time():
+        with torch.no_grad():
+            for _ in range(2):
+                model.encoder(images)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                model.encoder(images)
+            e1.record()
+            torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 5
+
+    t16 = enc_time()                                             # the step's frozen-encoder forward on its own (train-mode BatchNorm, no_grad)
     if c5:
         prompt = torch.cat([torch.full((B, 1), 8), torch.randint(12, 30000, (B, 62), generator=g), torch.full((B, 1), 9),
                             torch.randint(12, 30000, (B, 63), generator=g), torch.full((B, 1), 1)], 1).to(dev)
-
-        def enc_time():
-            with torch.no_grad():
-                for _ in range(2):
-                    model.encoder(images)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(5):
-                    model.encoder(images)
-                e1.record()
-                torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / 5
-
-        t16 = enc_time()
         model.enable_fp8_encoder(torch.randn(4, N, 3, 384, 384, generator=g).to(dev))
         enc_ms = {"bf16": t16, "e4m3": enc_time(), "images": B * N}
     else:
         prompt = torch.tensor([[8, 10, 9, 11, 1]] * B, device=dev)
+        enc_ms = {"bf16": t16, "images": B * N}
     # labels change every step, as in training (a new mini-batch of studies): a pool of label id matrices, one per step; the label rows are embedded
     # INSIDE the timed step (once per step: the reference embeds them in both of its reward calls, tools/rewards/cxrbert.py:49-64)
     n_pool = 64
@@ -320,6 +321,11 @@ def scst_bench(args, rank, world, dev, steps, c5=False):
                         "hipGraphs, REINFORCE through one teacher-forced pass, AdamW on the 80.9 M decoder parameters",
             "mode": "eval" if args.eval_mode else "model.train(): batch-statistics BatchNorm in the frozen encoder, dropout 0.1 in both decodes and in "
                     "the re-scoring pass (same seed)", "loss": float(out["loss"].item()), "string_round_trip": strings,
+            "encoder_forward_ms": enc_ms,
+            "encoder_roofline": {"bound": "mfma", "kernel": "frozen CvT-21 forward of the step's 32 images (bf16 NT GEMMs: row-strip / W-stationary / persistent / tiled)",
+                                 "achieved": ENC_FWD_GF_PER_IMAGE * enc_ms["images"] / enc_ms["bf16"], "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                                 "frac": ENC_FWD_GF_PER_IMAGE * enc_ms["images"] / enc_ms["bf16"] / MFMA_BF16_PEAK_TF,
+                                 "what": "algorithmic encoder FLOPs (BASELINE.md section 2) of the step's images / HIP-event time of the forward, no_grad, train-mode BatchNorm"},
             "roofline": {"bound": "hbm", "kernel": "cached decode token-step (one hipGraph of ~48 kernels: dec_gemm_kernel x32, attn_cross_mfma_kernel (query projection inside) x6, attn_decode_kernel x6, "
                          "embedding, step inputs, token selection), 32 rows", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": decode_traffic()[0], "traffic_unit": "bytes per token-step",
