@@ -19,6 +19,7 @@ from . import ops
 from .config import CvtConfig
 
 
+_TAIL_ON_MAIN = os.environ.get("CXR_TAIL_ON_MAIN", "1") != "0"      # A/B switch: 0 = the patch embedding's weight gradient (the step's last GEMM) on the weight-gradient stream like every other
 _EARLY_PATCH_COL = os.environ.get("CXR_EARLY_PATCH_COL", "1") != "0"      # A/B switch: 0 = the pixel im2col matrix of the backward is built at the end of the step, 1 = during the forward pass
 
 
@@ -256,6 +257,7 @@ class CvtEncoderEngine:
             C = cfg.embed_dim[s]
             ep = sp + "embedding.convolution_embeddings."
             xin, Hin, Win = x, H, W
+            col_ev = None
             fused0 = s == 0 and ("embed_pk", 0) in prep and px.shape[2] % 4 == 0 and px.shape[3] % 4 == 0 and px.shape[3] <= 384
             if fused0:
                 # projection + bias + LayerNorm in one launch; e (the LayerNorm's input) and the statistics only when a backward pass follows
@@ -269,6 +271,8 @@ class CvtEncoderEngine:
                     # weight-gradient stream, which has nothing else to do during the forward pass
                     with ops._on_wgrad_stream(px):
                         col = ops.im2col_pixels(px, cfg.patch_sizes[0], cfg.patch_stride[0], cfg.patch_padding[0], prep[("embed", 0)].shape[1])[0]
+                        col_ev = torch.cuda.Event()
+                        col_ev.record()                   # (the backward's last GEMM may read it from the main stream: see backward)
             elif s == 0:
                 col, Ho, Wo = ops.im2col_pixels(px, cfg.patch_sizes[0], cfg.patch_stride[0], cfg.patch_padding[0], prep[("embed", 0)].shape[1])
                 e = ops.gemm_nt(col, prep[("embed", s)], bias=st.f32(ep + "projection.bias"))
@@ -294,7 +298,8 @@ class CvtEncoderEngine:
                 _, estats = ops.layernorm(e, st.f32(ep + "normalization.weight"), st.f32(ep + "normalization.bias"), cfg.inner_layer_norm_eps,
                                           need_stats=save, out=xs.view(Bn * L, C))
             H, W = Ho, Wo
-            ssave = {"col": col, "e": e, "estats": estats, "H": H, "W": W, "layers": [], "xin": xin if col is None else None, "Hin": Hin, "Win": Win} if save else None
+            ssave = {"col": col, "e": e, "estats": estats, "H": H, "W": W, "layers": [], "xin": xin if col is None else None, "Hin": Hin, "Win": Win,
+                     "col_ev": col_ev} if save else None
             cur = xs
             for l in range(cfg.depth[s]):
                 cur, lsave = self._layer_fwd(cur, s, l, H, W, tok0, prep, save)
@@ -476,13 +481,24 @@ class CvtEncoderEngine:
                         col = ops.im2col_pixels(ss["xin"], cfg.patch_sizes[0], cfg.patch_stride[0], cfg.patch_padding[0], wp.shape[1])[0]
                     else:
                         col = ops.im2col_tokens(ss["xin"], ss["Hin"], ss["Win"], cfg.patch_stride[s], cfg.patch_padding[s])[0]
-            ops.linear_bwd_weight(de, col, dwp, st.grad(ep + "projection.bias"))
             gw = st.grad(ep + "projection.weight")
-            with ops._on_wgrad_stream(dwp):                  # same stream as the weight-gradient GEMM that fills dwp (ordered after it)
-                if s == 0:
-                    gw.add_(dwp[:, :gw[0].numel()].view(gw.shape))                       # layout plumbing back to [Co,Ci,kh,kw]
-                else:
-                    gw.add_(dwp.view(gw.shape[0], gw.shape[2], gw.shape[3], gw.shape[1]).permute(0, 3, 1, 2))
+            if (s == 0 and _TAIL_ON_MAIN and ss.get("col_ev") is not None and ops.WGRAD_STREAM is not None and not ops._WGRAD_SKIP
+                    and not torch.cuda.is_current_stream_capturing()):
+                # The step's LAST weight gradient (64 x 192 x 589824 at the benchmark batch, ~0.15 ms): its operand `de` is the main stream's last
+                # product, and on the weight-gradient stream it queues behind that stream's backlog of the stage-1 layer -- the main stream, which has
+                # nothing left to do, runs it instead, beside that backlog (profiles/r06_step_tail.txt: 0.33 ms of exposed tail per step before)
+                ops.wgrad_flush()
+                torch.cuda.current_stream().wait_event(ss["col_ev"])
+                col.record_stream(torch.cuda.current_stream())
+                ops.gemm_tn(de, col, dwp, dbias=st.grad(ep + "projection.bias"))
+                gw.add_(dwp[:, :gw[0].numel()].view(gw.shape))
+            else:
+                ops.linear_bwd_weight(de, col, dwp, st.grad(ep + "projection.bias"))
+                with ops._on_wgrad_stream(dwp):                  # same stream as the weight-gradient GEMM that fills dwp (ordered after it)
+                    if s == 0:
+                        gw.add_(dwp[:, :gw[0].numel()].view(gw.shape))                       # layout plumbing back to [Co,Ci,kh,kw]
+                    else:
+                        gw.add_(dwp.view(gw.shape[0], gw.shape[2], gw.shape[3], gw.shape[1]).permute(0, 3, 1, 2))
             if s > 0:
                 dcol = ops.gemm_nt(de, self._wt(("embed", s)))
                 Hp = Wp = cfg.grid(s - 1)

@@ -1516,7 +1516,7 @@ _SWITCH_GROUPS = {
                           "encoder_matches_reference_fixture or tf_single_logits_loss_grads or tf_train_mode_matches_oracle or fp8_encoder_against"),
     "library kernels": (dict(CXR_TN2="0", CXR_TN_STAGES="2", CXR_TN5="0", CXR_STRIP_GROUP="0", CXR_LN_BWD_PF="0", CXR_GEMM_WS="0", CXR_IM2COL_ROWS="0", CXR_CE_BF16ROW="0", CXR_GEMM_LDS_EPILOGUE="0"),
                         "encoder_matches_reference_fixture or tf_single_logits_loss_grads or tf_train_mode_matches_oracle or forward_with_labels"),
-    "library kernels 2": (dict(CXR_TN2_MIN="1", CXR_TN_WGS="64", CXR_TN2_WGS="48", CXR_LN_BWD_GRID="128", CXR_GEMM_BK="32", CXR_GEMM_STAGES="3", CXR_DW3_BAND="4"),
+    "library kernels 2": (dict(CXR_TN2_MIN="1", CXR_TN_WGS="64", CXR_TN2_WGS="48", CXR_LN_BWD_GRID="128", CXR_GEMM_BK="32", CXR_GEMM_STAGES="3", CXR_DW3_BAND="4", CXR_TAIL_ON_MAIN="0"),
                           "tf_single_logits_loss_grads or tf_train_mode_matches_oracle"),
     "training-step schedule": (dict(CXR_ZERO_ON_SIDE="0", CXR_EARLY_DEC_ADAMW="0", CXR_EARLY_ENC_ADAMW="0", CXR_BF16_LOGITS="0", CXR_WGRAD_OVERLAP="0", CXR_BIND_GRADS="0"),
                                "tf_single_logits_loss_grads or torch_optimizer_updates or graphed_tf_step or training_step_gradients_do_not_depend"),
