@@ -4,6 +4,7 @@ queue, the last weight-gradient / reduce kernel on the side queue, the optimiser
 python3 scripts/r6/tail_analysis.py <kernel_trace.csv>"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
+lo_ms, hi_ms = (float(sys.argv[2]), float(sys.argv[3])) if len(sys.argv) > 3 else (0.0, 1e9)      # keep the steps whose loss-to-loss wall time is in this range
 name = lambda r: r["Kernel_Name"]
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
@@ -14,6 +15,8 @@ print("steps:", len(ce), "queue column:", qkey, "queues:", collections.Counter(r
 mainq = rows[ce[len(ce) // 2]][qkey]
 out = []
 for a, b in zip(ce[3:-1], ce[4:]):
+    if not (lo_ms <= (rows[b]["s"] - rows[a]["s"]) / 1e6 <= hi_ms):
+        continue
     step = rows[a:b]                                  # softmax_ce of step i .. softmax_ce of step i+1: backward i, optimiser i, forward i+1
     adam = [r for r in step if "adamw" in name(r)]
     if not adam:

@@ -151,6 +151,23 @@ def test_gemm_row_strip_kernel_is_bit_identical_to_the_tiled_kernel(ops, mt, sta
             close(out, a.float() @ w.float().t(), rtol=1e-2, atol=1e-2, what=f"strip {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K", [(36928, 1536, 384), (5003, 768, 384), (1300, 1152, 128), (100, 1536, 64)])
+def test_gemm_row_strip_kernel_column_slices_are_bit_identical_to_the_tiled_kernel(ops, M, N, K):
+    """The column-sliced form of csrc/gemm_strip.hip (N = 768 / 1152 / 1536: one strip x one 384-column slice per workgroup, the slices of a strip on
+    one XCD; the FFN-up input gradient with GELU' beside the weight-gradient stream) against gemm_nt_kernel on every epilogue it takes."""
+    a = dev(rnd(M + 3, K + 8, seed=M).to(BF))[:M, :K]
+    w = dev((rnd(N, K, seed=N) * 0.1).to(BF))
+    for name, kw in _gemm_variants(M, N, M + N).items():
+        with _gemm_route("tiled"):
+            ref, ref_aux = _run_variant(ops, a, w, kw)
+        with _gemm_route(("strip", 10, 0)):
+            out, out_aux = _run_variant(ops, a, w, kw)
+        assert torch.equal(ref, out), f"strip slices {M}x{N}x{K} {name}: {int((ref != out).sum())} elements differ"
+        assert ref_aux is None or torch.equal(ref_aux, out_aux), f"strip slices {M}x{N}x{K} {name}: saved pre-activation differs"
+        if name == "plain":
+            close(out, a.float() @ w.float().t(), rtol=1e-2, atol=1e-2, what=f"strip slices {M}x{N}x{K}")
+
+
 @pytest.mark.parametrize("mt", [8, 12, 16])
 @pytest.mark.parametrize("M,K", [(36864, 192), (5003, 768), (100, 64)])
 def test_gemm_row_strip_kernel_n192_is_bit_identical_to_the_tiled_kernel(ops, mt, M, K):
