@@ -235,15 +235,17 @@ class ReportReward:
         self.worker_used = 0                                  # pairs the child processes have served (benchmarks / tests report it)
         if worker and reward.tokenizer is not None:
             from .strings import StringWorker
-            # one child per half (sampled rows | greedy rows): the two halves are decoded and re-tokenised side by side, and the parent pads them
-            # to the common length (what padding="longest" over all rows gives)
+            # k children per half (sampled rows | greedy rows; CXR_STRING_WORKERS = 2 k children in all, default 4): the chunks are decoded and
+            # re-tokenised side by side, and the parent pads them to the common length (what padding="longest" over all rows gives)
+            import os
+            n = max(2, int(os.environ.get("CXR_STRING_WORKERS", "4")) // 2 * 2)
             ws = []
             try:
-                for _ in range(2):
+                for _ in range(n):
                     ws.append(StringWorker(tokenizer, reward.tokenizer, self.special, reward.encode_kw(return_tensors="np")))
             except Exception:                                 # (StringWorker itself degrades on start-up failures; this is for what it cannot foresee)
                 pass
-            if len(ws) == 2 and all(w.alive for w in ws):
+            if len(ws) == n and all(w.alive for w in ws):
                 self.workers = ws
             else:
                 for w in ws:                                  # whichever were created: none is left running
@@ -256,8 +258,11 @@ class ReportReward:
 
     def pair_start(self, sampled_host, greedy_host):
         """Hand both halves' ids (host tensors whose copies have LANDED) to the child processes. -> ticket for pair_finish()."""
-        if len(self.workers) == 2 and all(w.alive for w in self.workers):
-            if self.workers[0].submit(sampled_host.numpy()) and self.workers[1].submit(greedy_host.numpy()):
+        k = len(self.workers) // 2
+        if k and all(w.alive for w in self.workers) and sampled_host.shape[0] >= k:
+            import numpy as np
+            chunks = np.array_split(sampled_host.numpy(), k) + np.array_split(greedy_host.numpy(), k)      # contiguous row ranges, in row order
+            if all(w.submit(c) for w, c in zip(self.workers, chunks)):
                 self.reward.prepare_labels(self.labels)       # this step's labels are tokenised here while the children decode the generated ids
                 return ("worker", sampled_host, greedy_host)
         return ("inline", sampled_host, greedy_host)
@@ -274,7 +279,8 @@ class ReportReward:
         from .strings import pad_and_stack
         pad_id = self.reward.tokenizer.pad_token_id
         ids, mask = pad_and_stack([(g[0], g[1]) for g in got], 0 if pad_id is None else pad_id)
-        self.last_sections = (got[1][2], got[1][3])
+        k = len(got) // 2                                     # the greedy rows' sections, chunk by chunk
+        self.last_sections = ([x for g in got[k:] for x in g[2]], [x for g in got[k:] for x in g[3]])
         self.worker_used += 1
         pe, le = self.reward.embed_with_labels(torch.from_numpy(ids), torch.from_numpy(mask), self.labels + self.labels)
         both = ops.cosine_rows(pe, le)
