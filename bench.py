@@ -457,8 +457,8 @@ def _scst_string_steps(args, model, opt, images, prompt, special, dev, B, reward
             "host_ms": {"ids_to_strings": getattr(rfn, "last_decode_ms", None), "strings_to_ids": getattr(reward, "last_tokenize_ms", None),
                         "note": "in-process path only (the child process does this work when it serves a step)"},
             "what": "scst_step(reward_on_host=True) with reward.ReportReward: async pinned copies of the sequences; all sections decoded by one call into the tokenizers "
-                    "library and both halves re-tokenised by one call (truncated to R = 128) -- in a child process (strings.StringWorker; CXR_STRING_WORKER=0 or any "
-                    "failure of the child: in this process) beside the launches of the re-scoring forward + warper threshold --, token ids uploaded through a pinned staging buffer, "
+                    "library and both halves re-tokenised by one call (truncated to R = 128) -- in four child processes, two per half of the rows (strings.StringWorker; "
+                    "CXR_STRING_WORKERS = 2: one per half; CXR_STRING_WORKER=0 or any failure of a child: in this process) beside the launches of the re-scoring forward + warper threshold --, token ids uploaded through a pinned staging buffer, "
                     "one 48-row CXR-BERT forward (sampled + greedy + this step's label rows); synthetic byte-BPE tokenizer (tests/golden/tokenizer.json) on the random-init model's strings"}
 
 

@@ -366,8 +366,9 @@ def test_scst_generated_prompt_steps_chain_through_the_written_back_report(cuda)
     assert not torch.equal(w0, m.param("decoder.base_model.model.bert.encoder.layer.0.output.dense.weight").detach())
 
 
-def test_scst_step_with_the_string_worker_equals_the_in_process_path(cuda):
-    """reward.ReportReward(worker=True): the CPU part of the reward (ids -> strings -> reward-tokenizer ids) runs in a child process between
+@pytest.mark.parametrize("children", [2, 4])
+def test_scst_step_with_the_string_worker_equals_the_in_process_path(cuda, children, monkeypatch):
+    """(children = CXR_STRING_WORKERS: one | two child processes per half of the rows.) reward.ReportReward(worker=True): the CPU part of the reward (ids -> strings -> reward-tokenizer ids) runs in a child process between
     pair_start() and pair_finish() while scst_step queues its re-scoring pass. Same seeds, lr = 0: the step with the worker reports the rewards,
     the advantage-weighted loss and the greedy sections of the in-process step bit for bit, the child did serve it, and a worker that dies between
     two steps leaves a step that still works (in-process fallback)."""
@@ -399,9 +400,10 @@ def test_scst_step_with_the_string_worker_equals_the_in_process_path(cuda):
 
     plain = ReportReward(m, tok, reward, labels, gu.BOS, gu.SEP, gu.EOS)
     ref = run(plain)
+    monkeypatch.setenv("CXR_STRING_WORKERS", str(children))
     wrk = ReportReward(m, tok, reward, labels, gu.BOS, gu.SEP, gu.EOS, worker=True)
     try:
-        assert wrk.worker is not None and wrk.worker.alive
+        assert wrk.worker is not None and wrk.worker.alive and len(wrk.workers) == children
         got = run(wrk)
         assert wrk.worker_used == 1
         assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]) and got[4] == ref[4]
