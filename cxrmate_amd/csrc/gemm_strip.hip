@@ -174,7 +174,11 @@ __device__ __forceinline__ void gemm_strip_body(const GemmArgs& g, const int str
             const float4 lo = *reinterpret_cast<const float4*>(stg + row * ESTR + cc * 8);
             const float4 hi = *reinterpret_cast<const float4*>(stg + row * ESTR + cc * 8 + 4);
             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            if (rd_aux) {
+            if (g.act == 1) {                                    // GELU, the pre-activation saved for the backward pass (as gemm_nt_kernel)
+                if (g.aux && m < g.M && sl0 < 16 * CPW) *reinterpret_cast<uint4*>(g.aux + (long)m * g.ldaux + n) = pack8(v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+            } else if (rd_aux) {
                 float a8[8];
                 unpack8(rop[it], a8);
 #pragma unroll
@@ -274,14 +278,14 @@ extern "C" int cxr_gemm_strip_config(int enabled, int mt, int min_rows, int stag
     return CXR_OK;
 }
 
-// true when the row-strip kernel took the problem: N == 384, K % 64 == 0, bf16 output, 16-byte aligned rows, no GELU / dropout in the epilogue
+// true when the row-strip kernel took the problem: N == 384 | 192, K % 64 == 0, bf16 output, 16-byte aligned rows, no dropout in the epilogue
 bool gemm_strip_launch(const GemmArgs& g, hipStream_t stream) {
     strip_init();
     const int enabled = strip_enabled, force_mt = strip_force_mt, min_rows = strip_min_rows, stages = strip_stages;
     if (!enabled) return false;
     if (g.N == 192) {
         // N = 192 (CvT stage 2): strips of 256 rows x all 192 columns (8 x 3 MFMA tiles per wave), two stages of 64-deep steps
-        if ((g.K % 64) || g.M < strip_min_rows192 || g.out_f32 || g.act == 1 || g.drop_thr16 || !g.lds_epilogue || (g.act == 2 && g.residual)) return false;
+        if ((g.K % 64) || g.M < strip_min_rows192 || g.out_f32 || g.drop_thr16 || !g.lds_epilogue || (g.act == 2 && g.residual)) return false;
         if ((g.lda % 8) || (g.ldw % 8) || (g.ldc % 8) || (((size_t)g.A | (size_t)g.W | (size_t)g.C) & 15)) return false;
         if (force_mt && force_mt != 16 && force_mt != 12 && force_mt != 8) return false;
         const int mt192 = force_mt ? force_mt : 12;
@@ -291,7 +295,7 @@ bool gemm_strip_launch(const GemmArgs& g, hipStream_t stream) {
         else                  CXR_LAUNCH((gemm_strip384_kernel<8, 2, 64, 3>), dim3(grid192), dim3(512), 0, stream, g, strip_dbg);
         return true;
     }
-    if (g.N != 384 || (g.K % 64) || g.M < min_rows || g.out_f32 || g.act == 1 || g.drop_thr16 || !g.lds_epilogue || (g.act == 2 && g.residual)) return false;
+    if (g.N != 384 || (g.K % 64) || g.M < min_rows || g.out_f32 || g.drop_thr16 || !g.lds_epilogue || (g.act == 2 && g.residual)) return false;
     if ((g.lda % 8) || (g.ldw % 8) || (g.ldc % 8) || (((size_t)g.A | (size_t)g.W | (size_t)g.C) & 15)) return false;
     // strip height: the largest that still gives every CU a strip (one round), at least 32 rows
     if (force_mt && force_mt != 2 && force_mt != 4 && force_mt != 6 && force_mt != 10) return false;      // (8 / 12 / 16 belong to the N = 192 form)
@@ -326,7 +330,7 @@ bool gemm_strip_wide_launch(const GemmArgs& g, hipStream_t stream) {
     if (wide < 0) wide = strip_env("CXR_STRIP_WIDE", 1);
     if (!strip_enabled || !wide || (strip_force_mt && strip_force_mt != 10)) return false;
     // (K <= 1536: the N x K weights stay in an XCD's L2 while the strips stream past; the 9216-deep cross-K/V product runs at 890 TFLOP/s on the tiles)
-    if (g.N <= 384 || (g.N % 384) || g.N > 1536 || (g.K % 64) || g.K > 1536 || g.M < strip_min_rows || g.out_f32 || g.act == 1 || g.drop_thr16 || !g.lds_epilogue ||
+    if (g.N <= 384 || (g.N % 384) || g.N > 1536 || (g.K % 64) || g.K > 1536 || g.M < strip_min_rows || g.out_f32 || g.drop_thr16 || !g.lds_epilogue ||
         (g.act == 2 && g.residual)) return false;
     if ((g.lda % 8) || (g.ldw % 8) || (g.ldc % 8) || (((size_t)g.A | (size_t)g.W | (size_t)g.C) & 15)) return false;
     if ((g.residual && (g.ldr % 8)) || (g.aux && (g.ldaux % 8))) return false;
@@ -336,7 +340,7 @@ bool gemm_strip_wide_launch(const GemmArgs& g, hipStream_t stream) {
 }
 
 static bool strip_takes(const GemmArgs& g) {
-    return g.N == 384 && (g.K % 64) == 0 && !g.out_f32 && g.act != 1 && !g.drop_thr16 && g.lds_epilogue && !(g.act == 2 && g.residual) && !(g.lda % 8) && !(g.ldw % 8) &&
+    return g.N == 384 && (g.K % 64) == 0 && !g.out_f32 && !g.drop_thr16 && g.lds_epilogue && !(g.act == 2 && g.residual) && !(g.lda % 8) && !(g.ldw % 8) &&
            !(g.ldc % 8) && !(((size_t)g.A | (size_t)g.W | (size_t)g.C) & 15);
 }
 

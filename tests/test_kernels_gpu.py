@@ -135,8 +135,8 @@ def test_gemm_w_stationary_kernel_is_bit_identical_to_the_tiled_kernel(ops, M, N
 @pytest.mark.parametrize("M,K", [(36928, 384), (9280, 384), (5003, 1536), (100, 64)])
 def test_gemm_row_strip_kernel_is_bit_identical_to_the_tiled_kernel(ops, mt, stages, M, K):
     """csrc/gemm_strip.hip (M x 384 x K: a strip of 16 mt rows x all 384 columns per workgroup, every strip height and stage count; ragged row tails,
-    row strides != K, every epilogue it takes) against gemm_nt_kernel: same MFMA orientation and K order -> the same bits; the epilogues it does not take
-    (GELU, dropout, fp32 output) must fall through to the tiled kernel unchanged."""
+    row strides != K, every epilogue it takes -- GELU with the saved pre-activation and GELU' included) against gemm_nt_kernel: same MFMA orientation and K order ->
+    the same bits; the epilogues it does not take (dropout, fp32 output) must fall through to the tiled kernel unchanged."""
     N = 384
     a = dev(rnd(M + 3, K + 8, seed=M).to(BF))[:M, :K]
     w = dev((rnd(N, K, seed=N) * 0.1).to(BF))
