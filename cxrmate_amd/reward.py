@@ -10,8 +10,10 @@ Label embeddings are cached per label tuple: the reference embeds the same label
 """
 from __future__ import annotations
 
+import os
 import time
 
+import numpy as np
 import torch
 
 from . import ops, weights
@@ -30,7 +32,6 @@ def load_cxr_bert_checkpoint(path):
         cls_projection_head.dense_to_hidden.{weight,bias}, cls_projection_head.LayerNorm.{weight,bias}, cls_projection_head.dense_to_output.{weight,bias}
     (the MLM head `cls.predictions.*` is ignored: its output is discarded by the reference, quirk Q10). The projection-head layout is the
     stand-in assumption of SURVEY.md 8c: a checkpoint whose head has other key names fails load_state_dict loudly."""
-    import os
     import transformers
     tok = transformers.AutoTokenizer.from_pretrained(path, trust_remote_code=False)
     st = os.path.join(path, "model.safetensors")
@@ -53,7 +54,6 @@ class CXRBERTReward:
         max_length: truncation length of the tokenizer call; None = the reference's `max_position_embeddings` (512, cxrbert.py:38). bench.py sets 128
         ("decoded strings re-tokenised to a fixed R = 128 WordPiece ids") so that the string path and the synthetic-id path of the
         SCST benchmark feed the reward BERT the same number of tokens."""
-        import os
         self.device = torch.device(device)
         self.config = config or reward_config()
         ckpt_dir = ckpt_dir or os.environ.get("CXR_BERT_DIR")
@@ -237,7 +237,6 @@ class ReportReward:
             from .strings import StringWorker
             # k children per half (sampled rows | greedy rows; CXR_STRING_WORKERS = 2 k children in all, default 4): the chunks are decoded and
             # re-tokenised side by side, and the parent pads them to the common length (what padding="longest" over all rows gives)
-            import os
             n = max(2, int(os.environ.get("CXR_STRING_WORKERS", "4")) // 2 * 2)
             ws = []
             try:
@@ -260,7 +259,6 @@ class ReportReward:
         """Hand both halves' ids (host tensors whose copies have LANDED) to the child processes. -> ticket for pair_finish()."""
         k = len(self.workers) // 2
         if k and all(w.alive for w in self.workers) and sampled_host.shape[0] >= k:
-            import numpy as np
             chunks = np.array_split(sampled_host.numpy(), k) + np.array_split(greedy_host.numpy(), k)      # contiguous row ranges, in row order
             if all(w.submit(c) for w, c in zip(self.workers, chunks)):
                 self.reward.prepare_labels(self.labels)       # this step's labels are tokenised here while the children decode the generated ids
