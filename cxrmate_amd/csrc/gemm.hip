@@ -497,7 +497,7 @@ extern "C" int cxr_gemm_nt_bf16(const void* A, long lda, const void* W, long ldw
     if (g_gemm_exclusive) {
         if (gemm_ws_launch(g, stream)) { CXR_LAUNCH_CHECK(); return CXR_OK; }   // K = 384, N >= 768: W resident in registers (gemm_ws.hip)
         if (gemm_pk_launch(g, stream)) { CXR_LAUNCH_CHECK(); return CXR_OK; }   // tall / very wide problems: persistent 256-row tiles (gemm_pk.hip)
-    } else if (gemm_strip_wide_launch(g, stream)) { CXR_LAUNCH_CHECK(); return CXR_OK; }   // M x (384 S) x K beside the weight-gradient stream: strips x column slices
+    }
     static int force_bk = -1, stages = -1;     // tuning aids: CXR_GEMM_BK=32|64, CXR_GEMM_STAGES=2|3|4
     if (force_bk < 0) { const char* e = getenv("CXR_GEMM_BK"); force_bk = e ? atoi(e) : 0; }
     if (stages < 0) { const char* e = getenv("CXR_GEMM_STAGES"); stages = e ? atoi(e) : 2; }

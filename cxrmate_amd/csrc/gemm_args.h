@@ -33,9 +33,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 bool gemm_pk_launch(const GemmArgs& g, hipStream_t stream);
 // defined in gemm_ws.hip: true when the W-stationary kernel took the problem (K == 384, N % 384 == 0, bf16 output, no dropout)
 bool gemm_ws_launch(const GemmArgs& g, hipStream_t stream);
-// defined in gemm_strip.hip: true when the row-strip kernel took the problem (N == 384 | 192, K % 64 == 0, bf16 output, no dropout epilogue)
+// defined in gemm_strip.hip: true when the row-strip kernel took the problem (N == 384, K % 64 == 0, bf16 output, no GELU / dropout epilogue)
 bool gemm_strip_launch(const GemmArgs& g, hipStream_t stream);
-// ... the column-sliced form for N = 768 | 1152 | 1536 (used beside the weight-gradient stream, where the persistent kernels are not)
-bool gemm_strip_wide_launch(const GemmArgs& g, hipStream_t stream);
 // ... and the grouped form: true when ONE row-strip launch took all n (<= 3) problems
 bool gemm_strip_group_launch(const GemmArgs* g, int n, hipStream_t stream);

@@ -134,24 +134,6 @@ __device__ __forceinline__ void gemm_strip_body(const GemmArgs& g, const int str
     const bool rd_aux = g.act == 2;
     const bf16_t* opp = rd_aux ? g.aux : g.residual;
     const long ldop = rd_aux ? g.ldaux : g.ldr;
-    constexpr int CPW = WCOLS / 8, EIT = (16 * CPW + 63) / 64;          // 8-column chunks per wave row; read-back passes (16 rows x CPW slots)
-    // the second [M,N] operand (residual / saved pre-activation) and the row factors of tile row mt + 1 are requested while tile row mt goes through LDS:
-    // loaded where they are used, every tile row began with one exposed global round trip (5 per workgroup at MT = 10)
-    uint4 ropb[2][EIT];
-    float rscb[2][EIT];
-    auto request = [&](const int mt, uint4 (&rop)[EIT], float (&rsc)[EIT]) {
-#pragma unroll
-        for (int it = 0; it < EIT; ++it) {
-            const int sl0 = it * 64 + lane, sl = sl0 < 16 * CPW ? sl0 : 16 * CPW - 1;
-            const int row = sl / CPW, cc = sl % CPW;
-            int m = m0 + wm * (BM / 2) + mt * 16 + row; m = m < g.M ? m : g.M - 1;
-            const int n = wn * WCOLS + cc * 8;
-            if (opp) rop[it] = *reinterpret_cast<const uint4*>(opp + (long)m * ldop + n);
-            if (g.row_scale) rsc[it] = g.row_scale[(unsigned)m / (unsigned)g.rs_rows];
-        }
-    };
-    const bool late = (dbg & 8) != 0;                            // A/B: operands requested where they are used (rounds 6a)
-    if (!late) request(0, ropb[0], rscb[0]);
 #pragma unroll
     for (int mt = 0; mt < MW; ++mt) {
 #pragma unroll
@@ -161,10 +143,18 @@ __device__ __forceinline__ void gemm_strip_body(const GemmArgs& g, const int str
             *reinterpret_cast<float4*>(stg + fr * ESTR + nt * 16 + fq * 4) = v;
         }
         // the wave reads back only what it wrote itself: no workgroup barrier, the reads below wait for the writes through lgkmcnt
-        if (late) request(mt, ropb[mt & 1], rscb[mt & 1]);
-        else if (mt + 1 < MW) request(mt + 1, ropb[(mt + 1) & 1], rscb[(mt + 1) & 1]);
-        uint4 (&rop)[EIT] = ropb[mt & 1];
-        float (&rsc)[EIT] = rscb[mt & 1];
+        constexpr int CPW = WCOLS / 8, EIT = (16 * CPW + 63) / 64;      // 8-column chunks per wave row; read-back passes (16 rows x CPW slots)
+        uint4 rop[EIT];
+        float rsc[EIT];
+#pragma unroll
+        for (int it = 0; it < EIT; ++it) {
+            const int sl0 = it * 64 + lane, sl = sl0 < 16 * CPW ? sl0 : 16 * CPW - 1;
+            const int row = sl / CPW, cc = sl % CPW;
+            int m = m0 + wm * (BM / 2) + mt * 16 + row; m = m < g.M ? m : g.M - 1;
+            const int n = wn * WCOLS + cc * 8;
+            if (opp) rop[it] = *reinterpret_cast<const uint4*>(opp + (long)m * ldop + n);
+            if (g.row_scale) rsc[it] = g.row_scale[(unsigned)m / (unsigned)g.rs_rows];
+        }
 #pragma unroll
         for (int it = 0; it < EIT; ++it) {
             const int sl0 = it * 64 + lane, sl = sl0 < 16 * CPW ? sl0 : 16 * CPW - 1;
@@ -174,11 +164,7 @@ __device__ __forceinline__ void gemm_strip_body(const GemmArgs& g, const int str
             const float4 lo = *reinterpret_cast<const float4*>(stg + row * ESTR + cc * 8);
             const float4 hi = *reinterpret_cast<const float4*>(stg + row * ESTR + cc * 8 + 4);
             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            if (g.act == 1) {                                    // GELU, the pre-activation saved for the backward pass (as gemm_nt_kernel)
-                if (g.aux && m < g.M && sl0 < 16 * CPW) *reinterpret_cast<uint4*>(g.aux + (long)m * g.ldaux + n) = pack8(v);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
-            } else if (rd_aux) {
+            if (rd_aux) {
                 float a8[8];
                 unpack8(rop[it], a8);
 #pragma unroll
@@ -208,24 +194,6 @@ __device__ __forceinline__ void gemm_strip_body(const GemmArgs& g, const int str
 template <int MT, int NST, int BK = 32, int NTW = 6>
 __global__ __launch_bounds__(512) void gemm_strip384_kernel(const GemmArgs g, const int dbg) {
     gemm_strip_body<MT, NST, BK, NTW>(g, blockIdx.x, dbg);
-}
-
-// N = 384 S (S = 2 .. 4: the FFN-up input gradient 36928 x 1536 x 384 + GELU' beside the weight-gradient stream, 16 x 147 us per step on the 128-tiles):
-// a workgroup owns one strip x one 384-column slice. Workgroups b, b + 8, b + 16, .. of a block of 8 S consecutive ids share an XCD under round-robin
-// placement (speed only): they take the S slices of ONE strip, so its A rows come from HBM once and from that XCD's L2 for the other slices.
-template <int MT, int NST, int BK>
-__global__ __launch_bounds__(512) void gemm_strip384_wide_kernel(const GemmArgs g0, const int nslices, const int dbg) {
-    const int b = blockIdx.x, per = 8 * nslices;
-    const int strip = (b / per) * 8 + (b % 8), slice = (b % per) / 8;
-    if (strip * 16 * MT >= g0.M) return;                          // (the grid is padded to whole blocks of 8 strips; workgroup-uniform)
-    GemmArgs g = g0;
-    g.N = 384;
-    g.W += (long)slice * 384 * g.ldw;
-    g.C = reinterpret_cast<bf16_t*>(g.C) + slice * 384;
-    if (g.bias) g.bias += slice * 384;
-    if (g.residual) g.residual += slice * 384;
-    if (g.aux) g.aux += slice * 384;
-    gemm_strip_body<MT, NST, BK, 6>(g, strip, dbg);
 }
 
 // Up to three problems with the same N = 384 and K in ONE launch (the query / key / value projections of a CvT stage-3 layer and their input gradients:
@@ -263,7 +231,7 @@ static void strip_init() {
     // 36864 x 192 x 192: 16 / 17 -> 12 us; TF step -0.03 .. -0.2 ms (call 19)
     strip_min_rows192 = strip_env("CXR_STRIP_MIN_M192", 32768);
     strip_stages = strip_env("CXR_STRIP_STAGES", 0);            // 0: automatic; 2 | 3 | 4: that many stages of 32-deep steps
-    strip_dbg = strip_env("CXR_STRIP_DEBUG", 0);                // timing experiments (wrong results): 1 no MFMA, 2 no LDS-DMA refills, 4 no fragment reads; 8 (correct results): epilogue operands requested late
+    strip_dbg = strip_env("CXR_STRIP_DEBUG", 0);                // timing experiments (wrong results): 1 no MFMA, 2 no LDS-DMA refills, 4 no fragment reads
 }
 
 // tuning / A-B aid (like cxr_gemm_pk_config): enabled 0 | 1, mt 0 (automatic) | 2 | 4 | 6 | 10 (N = 384) | 8 | 12 | 16 (N = 192), min_rows (-2: the shipped thresholds), stages 0 (automatic: mt 10 = two stages of 64-deep steps, else four of 32) | 2 | 3 | 4 (stages of 32-deep steps; 3, 4: mt 10 only); negative = keep
@@ -278,14 +246,14 @@ extern "C" int cxr_gemm_strip_config(int enabled, int mt, int min_rows, int stag
     return CXR_OK;
 }
 
-// true when the row-strip kernel took the problem: N == 384 | 192, K % 64 == 0, bf16 output, 16-byte aligned rows, no dropout in the epilogue
+// true when the row-strip kernel took the problem: N == 384, K % 64 == 0, bf16 output, 16-byte aligned rows, no GELU / dropout in the epilogue
 bool gemm_strip_launch(const GemmArgs& g, hipStream_t stream) {
     strip_init();
     const int enabled = strip_enabled, force_mt = strip_force_mt, min_rows = strip_min_rows, stages = strip_stages;
     if (!enabled) return false;
     if (g.N == 192) {
         // N = 192 (CvT stage 2): strips of 256 rows x all 192 columns (8 x 3 MFMA tiles per wave), two stages of 64-deep steps
-        if ((g.K % 64) || g.M < strip_min_rows192 || g.out_f32 || g.drop_thr16 || !g.lds_epilogue || (g.act == 2 && g.residual)) return false;
+        if ((g.K % 64) || g.M < strip_min_rows192 || g.out_f32 || g.act == 1 || g.drop_thr16 || !g.lds_epilogue || (g.act == 2 && g.residual)) return false;
         if ((g.lda % 8) || (g.ldw % 8) || (g.ldc % 8) || (((size_t)g.A | (size_t)g.W | (size_t)g.C) & 15)) return false;
         if (force_mt && force_mt != 16 && force_mt != 12 && force_mt != 8) return false;
         const int mt192 = force_mt ? force_mt : 12;
@@ -295,7 +263,7 @@ bool gemm_strip_launch(const GemmArgs& g, hipStream_t stream) {
         else                  CXR_LAUNCH((gemm_strip384_kernel<8, 2, 64, 3>), dim3(grid192), dim3(512), 0, stream, g, strip_dbg);
         return true;
     }
-    if (g.N != 384 || (g.K % 64) || g.M < min_rows || g.out_f32 || g.drop_thr16 || !g.lds_epilogue || (g.act == 2 && g.residual)) return false;
+    if (g.N != 384 || (g.K % 64) || g.M < min_rows || g.out_f32 || g.act == 1 || g.drop_thr16 || !g.lds_epilogue || (g.act == 2 && g.residual)) return false;
     if ((g.lda % 8) || (g.ldw % 8) || (g.ldc % 8) || (((size_t)g.A | (size_t)g.W | (size_t)g.C) & 15)) return false;
     // strip height: the largest that still gives every CU a strip (one round), at least 32 rows
     if (force_mt && force_mt != 2 && force_mt != 4 && force_mt != 6 && force_mt != 10) return false;      // (8 / 12 / 16 belong to the N = 192 form)
@@ -323,24 +291,8 @@ bool gemm_strip_launch(const GemmArgs& g, hipStream_t stream) {
     return true;
 }
 
-// true when the sliced row-strip launch took the problem: N = 768 | 1152 | 1536, otherwise as gemm_strip_launch (CXR_STRIP_WIDE=0: off, A/B)
-bool gemm_strip_wide_launch(const GemmArgs& g, hipStream_t stream) {
-    strip_init();
-    static int wide = -1;
-    if (wide < 0) wide = strip_env("CXR_STRIP_WIDE", 1);
-    if (!strip_enabled || !wide || (strip_force_mt && strip_force_mt != 10)) return false;
-    // (K <= 1536: the N x K weights stay in an XCD's L2 while the strips stream past; the 9216-deep cross-K/V product runs at 890 TFLOP/s on the tiles)
-    if (g.N <= 384 || (g.N % 384) || g.N > 1536 || (g.K % 64) || g.K > 1536 || g.M < strip_min_rows || g.out_f32 || g.drop_thr16 || !g.lds_epilogue ||
-        (g.act == 2 && g.residual)) return false;
-    if ((g.lda % 8) || (g.ldw % 8) || (g.ldc % 8) || (((size_t)g.A | (size_t)g.W | (size_t)g.C) & 15)) return false;
-    if ((g.residual && (g.ldr % 8)) || (g.aux && (g.ldaux % 8))) return false;
-    const int nslices = g.N / 384, strips = cdiv(g.M, 160);
-    CXR_LAUNCH((gemm_strip384_wide_kernel<10, 2, 64>), dim3(cdiv(strips, 8) * 8 * nslices), dim3(512), 0, stream, g, nslices, strip_dbg);
-    return true;
-}
-
 static bool strip_takes(const GemmArgs& g) {
-    return g.N == 384 && (g.K % 64) == 0 && !g.out_f32 && !g.drop_thr16 && g.lds_epilogue && !(g.act == 2 && g.residual) && !(g.lda % 8) && !(g.ldw % 8) &&
+    return g.N == 384 && (g.K % 64) == 0 && !g.out_f32 && g.act != 1 && !g.drop_thr16 && g.lds_epilogue && !(g.act == 2 && g.residual) && !(g.lda % 8) && !(g.ldw % 8) &&
            !(g.ldc % 8) && !(((size_t)g.A | (size_t)g.W | (size_t)g.C) & 15);
 }
 

@@ -1514,7 +1514,7 @@ _SWITCH_GROUPS = {
     "VALU cross-attention": (dict(CXR_CROSS_MFMA="0", CXR_CROSS_WG_KEYS="288"), "greedy_and_beam_multi or prompted_generate_and_scst_scores"),
     "encoder fallbacks": (dict(CXR_EARLY_PATCH_COL="0", CXR_DWPROJ="0", CXR_DW3_STATS_FROM_Y="0", CXR_IMPLICIT_EMBED="0", CXR_PATCH_EMBED_FUSED="0", CXR_FP8_FUSED="0"),
                           "encoder_matches_reference_fixture or tf_single_logits_loss_grads or tf_train_mode_matches_oracle or fp8_encoder_against"),
-    "library kernels": (dict(CXR_TN2="0", CXR_TN_STAGES="2", CXR_TN5="0", CXR_STRIP_GROUP="0", CXR_STRIP_WIDE="0", CXR_LN_BWD_PF="0", CXR_GEMM_WS="0", CXR_IM2COL_ROWS="0", CXR_CE_BF16ROW="0", CXR_GEMM_LDS_EPILOGUE="0"),
+    "library kernels": (dict(CXR_TN2="0", CXR_TN_STAGES="2", CXR_TN5="0", CXR_STRIP_GROUP="0", CXR_LN_BWD_PF="0", CXR_GEMM_WS="0", CXR_IM2COL_ROWS="0", CXR_CE_BF16ROW="0", CXR_GEMM_LDS_EPILOGUE="0"),
                         "encoder_matches_reference_fixture or tf_single_logits_loss_grads or tf_train_mode_matches_oracle or forward_with_labels"),
     "library kernels 2": (dict(CXR_TN2_MIN="1", CXR_TN_WGS="64", CXR_TN2_WGS="48", CXR_LN_BWD_GRID="128", CXR_GEMM_BK="32", CXR_GEMM_STAGES="3", CXR_DW3_BAND="4", CXR_TAIL_ON_MAIN="0"),
                           "tf_single_logits_loss_grads or tf_train_mode_matches_oracle"),
