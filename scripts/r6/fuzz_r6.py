@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Random-shape checks of the round-6 GEMM kernels: row-strip NT GEMM (N = 384 / 192 and the column-sliced form N = 768 / 1152 / 1536; every epilogue incl. GELU
+"""(The N > 384 cases exercised the column-sliced strip form while it existed; on the shipped library they compare the tiled kernel with itself.)
+Random-shape checks of the round-6 GEMM kernels: row-strip NT GEMM (N = 384 / 192 and the column-sliced form N = 768 / 1152 / 1536; every epilogue incl. GELU
 and GELU') bit-identical to the tiled kernel, and the 384 x 192-block weight-gradient kernel (gemm_tn5_kernel) against fp32 torch + run-to-run identical.
 python3 scripts/r6/fuzz_r6.py   (FUZZ_SEED=n for another sequence)"""
 import os, sys, random, torch

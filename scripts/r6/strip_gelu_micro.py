@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Round 6: FFN-up products with the GELU epilogue + saved pre-activation (forward, train mode) alone on the chip, cache-cold: tiled kernel, what the
+"""(LAB RECORD: the column-sliced / GELU forms of the strip kernels this script timed were removed again -- profiles/r06_gemm_strip.txt, REVERSAL; on the
+shipped library its 'strip slices' route falls through to the tiled kernel.)
+Round 6: FFN-up products with the GELU epilogue + saved pre-activation (forward, train mode) alone on the chip, cache-cold: tiled kernel, what the
 forward uses today (persistent / W-stationary), column-sliced row strips."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

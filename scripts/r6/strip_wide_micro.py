@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Round 6: the FFN-up input-gradient product of CvT stage 3 (36928 x 1536 x 384, multiplied by GELU'(saved pre-activation)) alone on the chip, cache-cold
+"""(LAB RECORD: the column-sliced / GELU forms of the strip kernels this script timed were removed again -- profiles/r06_gemm_strip.txt, REVERSAL; on the
+shipped library its 'strip slices' route falls through to the tiled kernel.)
+Round 6: the FFN-up input-gradient product of CvT stage 3 (36928 x 1536 x 384, multiplied by GELU'(saved pre-activation)) alone on the chip, cache-cold
 (operands rotate through > 1 GB): tiled kernel, W-stationary kernel (forced: it declines second-operand products by default), column-sliced row strips."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
